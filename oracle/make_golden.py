@@ -1,0 +1,263 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by driving the UNMODIFIED reference.  TEST INFRASTRUCTURE ONLY.
+
+Runs only in the build container: it imports ``/root/reference/pyipm.py`` by path
+(never copied into this repo, never shipped to the GPU box) on top of the
+test-only ``aesara`` stand-in in ``oracle/aesara_standin`` and records what the
+reference computes at the Newton-step seam (pyipm.py:1717-1725):
+
+  x, s, lda, mu, delta_in  ->  g = -grad,  H = hess,  Hc = reghess(H), delta_out,
+  dz_raw = sym_solve_cmp(Hc, g),  dz = flipped
+
+All nine inputs are handed over as "precompiled" Functions (the input state of
+pyipm.py:426-440 that needs no autodiff), so the reference's own NumPy KKT
+assembly (:768-814), ``reghess`` (:1373-1406), line search and loop run verbatim.
+
+    python oracle/make_golden.py            # writes tests/golden/*.npz
+"""
+from __future__ import annotations
+
+import io
+import os
+import sys
+import contextlib
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REFERENCE = "/root/reference"
+sys.path.insert(0, os.path.join(HERE, "aesara_standin"))
+sys.path.insert(0, REFERENCE)
+sys.path.insert(0, ROOT)
+
+import aesara  # noqa: E402  (the stand-in)
+import aesara.tensor as T  # noqa: E402
+import pyipm as ref  # noqa: E402  (the unmodified reference)
+
+from pyipm_amd.problems import example_problem, unit_test_x0, make_qp, qp_callables  # noqa: E402
+
+assert ref.__file__.startswith(REFERENCE), ref.__file__
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+class TracedIPM(ref.IPM):
+    """Reference IPM with recording hooks at the Newton-step seam (no logic changed)."""
+
+    def compile(self, *a, **k):
+        ref.IPM.compile(self, *a, **k)
+        self.trace = []
+        self._cur = None
+        if self.lbfgs:
+            return
+        hess0, solve0 = self.hess, self.sym_solve_cmp
+
+        def hess(x, s, lda):
+            H = hess0(x, s, lda)
+            self._cur = {"x": np.array(x), "s": np.array(s), "lda": np.array(lda),
+                         "mu": float(self.mu_dev.get_value()), "mu_host": float(self.mu_host),
+                         "g": -np.array(self.grad(x, s, lda)), "H": np.array(H)}
+            return H
+
+        def solve(Mx, b):
+            out = solve0(Mx, b)
+            if self._cur is not None and "Hc" in self._cur and "dz_raw" not in self._cur:
+                self._cur["dz_raw"] = np.array(out).reshape(-1)
+                self.trace.append(self._cur)
+                self._cur = None
+            return out
+
+        self.hess, self.sym_solve_cmp = hess, solve
+
+    def reghess(self, Hc):
+        rec = self._cur
+        if rec is not None:
+            rec["delta_in"] = float(self.delta)
+        out = ref.IPM.reghess(self, Hc)
+        if rec is not None:
+            rec["Hc"] = np.array(out)
+            rec["delta_out"] = float(self.delta)
+        return out
+
+
+def as_functions(prob, x_dev, lda_dev):
+    """Wrap NumPy callables as stand-in ``Function`` objects ("precompiled" state)."""
+    out = {}
+    for key in ("f", "df", "d2f", "ce", "dce", "ci", "dci"):
+        fn = prob.get(key)
+        out[key] = None if fn is None else aesara.function([x_dev], aesara.wrap(fn, x_dev))
+    for key in ("d2ce", "d2ci"):
+        fn = prob.get(key)
+        out[key] = None if fn is None else aesara.function([x_dev, lda_dev], aesara.wrap(fn, x_dev, lda_dev))
+    return out
+
+
+def build(prob, x0, **kw):
+    x_dev = T.vector("x_dev")
+    lda_dev = T.vector("lda_dev")
+    fns = as_functions(prob, x_dev, lda_dev)
+    return TracedIPM(x0=np.array(x0, dtype=np.float64), x_dev=x_dev, lambda_dev=lda_dev,
+                     f=fns["f"], df=fns["df"], d2f=fns["d2f"], ce=fns["ce"], dce=fns["dce"],
+                     d2ce=fns["d2ce"], ci=fns["ci"], dci=fns["dci"], d2ci=fns["d2ci"], **kw)
+
+
+def flipped(dz_raw, n, mi, me):
+    dz = np.array(dz_raw)
+    if me or mi:
+        dz[n + mi:] = -dz[n + mi:]
+    return dz
+
+
+def pack_trace(p):
+    n, me, mi = p.nvar, p.neq, p.nineq
+    keys = ("x", "s", "lda", "g", "H", "Hc", "dz_raw")
+    d = {"n_iter": np.int64(len(p.trace))}
+    for k in keys:
+        d["it_" + k] = np.stack([t[k] for t in p.trace]) if p.trace else np.zeros((0,))
+    for k in ("mu", "mu_host", "delta_in", "delta_out"):
+        d["it_" + k] = np.array([t[k] for t in p.trace])
+    d["it_dz"] = np.stack([flipped(t["dz_raw"], n, mi, me) for t in p.trace]) if p.trace else np.zeros((0,))
+    return d
+
+
+def run_example(k, x0, **kw):
+    prob = example_problem(k)
+    p = build(prob, x0, **kw)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        x, s, lda, fval, kkt = p.solve()
+    d = pack_trace(p)
+    d.update(problem=np.int64(k), x0=np.array(x0), x=x, s=s, lda=lda, fval=np.float64(fval),
+             signal=np.int64(p.signal), nvar=np.int64(p.nvar), neq=np.int64(p.neq),
+             nineq=np.int64(p.nineq), transcript=np.array(buf.getvalue()))
+    for i, kk in enumerate(kkt):
+        d["kkt%d" % (i + 1)] = np.atleast_1d(np.array(kk, dtype=np.float64))
+    return d, p
+
+
+def single_step(prob, x, mu=0.2, delta=0.0, s=None, lda=None, **kw):
+    """One Newton step of the reference at a prescribed point (init rules of pyipm.py:1597-1625)."""
+    p = build(prob, x, mu=mu, verbosity=-1, **kw)
+    p.nvar = int(np.size(x))
+    p.compile()
+    x = np.array(x, dtype=np.float64)
+    n, me, mi = p.nvar, p.neq, p.nineq
+    if mi:
+        s = p.init_slack(x) if s is None else np.array(s, dtype=np.float64)
+        p.mu_host = mu
+    else:
+        s = np.array([], dtype=np.float64)
+        p.mu_host = p.Ktol
+        p.mu_dev.set_value(np.float64(p.mu_host))
+    if me or mi:
+        if lda is None:
+            lda = p.init_lambda(x)
+            li = lda[me:]
+            li[li < 0.0] = p.Ktol
+            lda[me:] = li
+        else:
+            lda = np.array(lda, dtype=np.float64)
+    else:
+        lda = np.array([], dtype=np.float64)
+    p.delta = np.float64(delta)
+    g = -p.grad(x, s, lda)
+    H = p.hess(x, s, lda)
+    Hc = p.reghess(np.array(H))
+    dz_raw = p.sym_solve_cmp(Hc, g.reshape((g.size, 1))).reshape((g.size,))
+    w = p.eigh(Hc)
+    d = {"nvar": np.int64(n), "neq": np.int64(me), "nineq": np.int64(mi), "x": x, "s": s, "lda": lda,
+         "mu": np.float64(p.mu_dev.get_value()), "mu_host": np.float64(p.mu_host),
+         "delta_in": np.float64(delta), "delta_out": np.float64(p.delta),
+         "g": g, "H": np.array(H), "Hc": np.array(Hc), "dz_raw": dz_raw,
+         "dz": flipped(dz_raw, n, mi, me), "eig_Hc": w,
+         "neg": np.int64(np.sum(w < -p.eps))}
+    return d, p
+
+
+def qp_step(n, me, mi, seed, keep_H):
+    qp = make_qp(n, me, mi, seed)
+    prob = qp_callables(qp)
+    d, p = single_step(prob, qp["x"], mu=qp["mu"], s=qp["s"] if mi else None,
+                       lda=qp["lam"] if (me or mi) else None)
+    out = {k: d[k] for k in ("nvar", "neq", "nineq", "mu", "mu_host", "delta_in", "delta_out",
+                             "g", "dz", "dz_raw", "neg")}
+    out["seed"] = np.int64(seed)
+    out["H_frob"] = np.float64(np.linalg.norm(d["H"]))
+    out["H_trace"] = np.float64(np.trace(d["H"]))
+    out["H_rowsum"] = d["H"].sum(axis=1)
+    if keep_H:
+        out["H"] = d["H"]
+    return out
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    x0s = unit_test_x0()
+
+    # (ii) full-solve traces, seed-42 x0, the unit-test settings (Ftol=1e-8, unit_tests.py:50)
+    for k in range(1, 11):
+        d, p = run_example(k, x0s[k], Ftol=1.0e-8, verbosity=-1)
+        np.savez_compressed(os.path.join(GOLD, "trace_p%02d.npz" % k), **d)
+        print("p%-2d iters=%-3d signal=%2d x=%s" % (k, int(d["n_iter"]), int(d["signal"]), d["x"]))
+
+    # README transcript shape for problem 7 (README.md:101-122): verbosity=1 banners
+    d, p = run_example(7, x0s[7], Ftol=1.0e-8, verbosity=1)
+    np.savez_compressed(os.path.join(GOLD, "transcript_p07.npz"), transcript=d["transcript"],
+                        x=d["x"], n_iter=d["n_iter"], signal=d["signal"])
+
+    # (i) problem 7 at a fixed point
+    d, p = single_step(example_problem(7), [0.5, 0.3, 0.4], mu=0.2)
+    np.savez_compressed(os.path.join(GOLD, "step_p07_fixed.npz"), **d)
+    print("p7 fixed-point dz =", d["dz"])
+
+    # (iii) synthetic QP KKT systems (generator of SURVEY.md section 8d)
+    for (n, me, mi, seed) in [(24, 8, 16, 0), (40, 0, 12, 1), (40, 12, 0, 2), (64, 0, 0, 3),
+                              (96, 32, 48, 4), (160, 40, 100, 5), (256, 64, 96, 6)]:
+        out = qp_step(n, me, mi, seed, keep_H=(n + 2 * mi + me) <= 64)
+        np.savez_compressed(os.path.join(GOLD, "qp_n%d_me%d_mi%d_s%d.npz" % (n, me, mi, seed)), **out)
+        print("qp n=%d me=%d mi=%d N=%d delta_out=%g neg=%d" % (n, me, mi, n + 2 * mi + me,
+                                                               out["delta_out"], out["neg"]))
+
+    # (iv-a) nonconvex case that forces the delta x10 loop (pyipm.py:1399-1403)
+    rng = np.random.default_rng(11)
+    n, me, mi = 12, 3, 5
+    Mx = rng.standard_normal((n, n))
+    Qnc = 0.5 * (Mx + Mx.T) - 3.0 * np.eye(n)           # strongly indefinite Hessian
+    Anc = rng.standard_normal((me, n))
+    Gnc = rng.standard_normal((mi, n))
+    cnc = rng.standard_normal(n)
+    prob = {"nvar": n, "neq": me, "nineq": mi,
+            "f": lambda x: 0.5 * x @ (Qnc @ x) + cnc @ x, "df": lambda x: Qnc @ x + cnc,
+            "d2f": lambda x: Qnc,
+            "ce": lambda x: Anc @ x - 0.1, "dce": lambda x: np.ascontiguousarray(Anc.T),
+            "d2ce": lambda x, lda: np.zeros((n, n)),
+            "ci": lambda x: Gnc @ x + 1.0, "dci": lambda x: np.ascontiguousarray(Gnc.T),
+            "d2ci": lambda x, lda: np.zeros((n, n))}
+    d, p = single_step(prob, np.zeros(n), mu=0.2)
+    d.update(Q=Qnc, A=Anc, G=Gnc, c=cnc)
+    np.savez_compressed(os.path.join(GOLD, "step_nonconvex_delta_loop.npz"), **d)
+    print("nonconvex: delta_out=%g neg=%d (need %d)" % (d["delta_out"], d["neg"], me + mi))
+
+    # (iv-b) rank-deficient Je that triggers the delta_c branch (pyipm.py:1383-1389)
+    n, me, mi = 10, 4, 3
+    Qr = np.eye(n) * 2.0
+    Ar = rng.standard_normal((me, n))
+    Ar[3] = Ar[0]                                        # duplicated equality row -> singular KKT
+    Gr = rng.standard_normal((mi, n))
+    cr = rng.standard_normal(n)
+    prob = {"nvar": n, "neq": me, "nineq": mi,
+            "f": lambda x: 0.5 * x @ (Qr @ x) + cr @ x, "df": lambda x: Qr @ x + cr,
+            "d2f": lambda x: Qr,
+            "ce": lambda x: Ar @ x - 0.1, "dce": lambda x: np.ascontiguousarray(Ar.T),
+            "d2ce": lambda x, lda: np.zeros((n, n)),
+            "ci": lambda x: Gr @ x + 1.0, "dci": lambda x: np.ascontiguousarray(Gr.T),
+            "d2ci": lambda x, lda: np.zeros((n, n))}
+    d, p = single_step(prob, np.zeros(n), mu=0.2)
+    d.update(Q=Qr, A=Ar, G=Gr, c=cr)
+    np.savez_compressed(os.path.join(GOLD, "step_rankdef_delta_c.npz"), **d)
+    print("rank-deficient Je: delta_out=%g neg=%d Hc[le,le][0,0]=%g" %
+          (d["delta_out"], d["neg"], d["Hc"][n + mi, n + mi]))
+
+
+if __name__ == "__main__":
+    main()
