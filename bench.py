@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py — Newton steps/sec at KKT dim 32k (BASELINE.json metric) on N GPUs of one node.
+
+A "step" = one pass of the hot path over one synthetic dense QP with the derivative blocks already
+resident in HBM: residual (K2) + KKT assembly (K1) + block-LDL' factorisation (K3/K4) +
+substitutions (K5) + multiplier sign flip = /root/reference/pyipm.py:1717-1725 without
+regularisation retries.  Workload at N=1: n=16384, me=4096, mi=6144 ->
+KKT dim N = n + 2*mi + me = 32768.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29511 bench.py --gpus 8 --steps 3 --warmup 1
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_update<128>, the fp64-MFMA
+trailing update): algorithmic flops (sum over launches of 2*nb*#lower-triangle entries updated)
+divided by the summed HIP-event durations of those launches, against the 78.6 TFLOP/s fp64 matrix
+peak.  `cpu_baseline` times the oracle (the reference's CPU path restated) on this box's host cores
+on a bounded sample and N^3-extrapolates to the metric's size.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6      # 256 CU x 2.4 GHz x 128 flop/clk/CU
+
+
+def make_qp_device(n, me, mi, seed, device):
+    """Device-side generator with the distribution of pyipm_amd.problems.make_qp;
+    golden parity is checked at the sizes where the CPU oracle is feasible (tests/)."""
+    import torch
+    gen = torch.Generator(device=device).manual_seed(seed)
+    f64 = torch.float64
+    M = torch.randn(n, n, dtype=f64, device=device, generator=gen)
+    Q = M @ M.T / n
+    Q.diagonal().add_(1.0)
+    del M
+    A = torch.randn(me, n, dtype=f64, device=device, generator=gen) / np.sqrt(n)
+    G = torch.randn(mi, n, dtype=f64, device=device, generator=gen) / np.sqrt(n)
+    c = torch.randn(n, dtype=f64, device=device, generator=gen)
+    x = torch.zeros(n, dtype=f64, device=device)
+    s = torch.rand(mi, dtype=f64, device=device, generator=gen) * 1.5 + 0.5
+    lam_i = torch.rand(mi, dtype=f64, device=device, generator=gen) * 1.5 + 0.5
+    lam_e = torch.randn(me, dtype=f64, device=device, generator=gen)
+    h = G @ x - s - 0.1 * torch.randn(mi, dtype=f64, device=device, generator=gen)
+    b = A @ x - 0.1 * torch.randn(me, dtype=f64, device=device, generator=gen)
+    return {"d2L": Q, "Je": A.T.contiguous(), "Ji": G.T.contiguous(), "df": Q @ x + c, "ce": A @ x - b,
+            "ci": G @ x - h, "s": s, "lam": torch.cat([lam_e, lam_i]), "mu": 0.2}
+
+
+def cpu_baseline(sample_n=2048, sample_me=512, sample_mi=768, target_N=32768, reps=3):
+    """The oracle (reference CPU path restated: NumPy assembly + eigvalsh(H,I) + LU solve + flip)
+    timed on the host cores on a bounded sample, N^3-extrapolated to the metric's KKT dimension."""
+    from oracle import newton_oracle as orc
+    from pyipm_amd.problems import make_qp
+    try:
+        from threadpoolctl import threadpool_info
+        info = threadpool_info()
+        threads = max([i.get("num_threads", 1) for i in info] or [1])
+        blas = ";".join(sorted(set("%s %s" % (i.get("internal_api"), i.get("version")) for i in info)))
+    except Exception:
+        threads, blas = os.cpu_count() or 1, "unknown"
+    qp = make_qp(sample_n, sample_me, sample_mi, seed=0)
+    Ns = sample_n + 2 * sample_mi + sample_me
+    args = (qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], qp["mu"],
+            sample_n, sample_me, sample_mi)
+    orc.newton_step(*args, regularise=False)       # warm-up
+    t_full, t_noeig = [], []
+    for _ in range(reps):
+        t0 = time.perf_counter(); orc.newton_step(*args, regularise=True); t_full.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); orc.newton_step(*args, regularise=False); t_noeig.append(time.perf_counter() - t0)
+    tf, tn = float(np.median(t_full)), float(np.median(t_noeig))
+    scale = (target_N / Ns) ** 3
+    return {"value": 1.0 / (tf * scale), "unit": "steps/s", "cores": int(threads), "kind": "port",
+            "sample": ("oracle/newton_oracle.py (NumPy assembly + scipy eigvalsh(H,I) + scipy LU solve + flip, "
+                       "reference path of pyipm.py:1717-1725) at N=%d (n=%d,me=%d,mi=%d): %.3f s/step median of %d "
+                       "(%.3f s without the eigvalsh inertia test); value = N^3 extrapolation x%.0f to N=%d; "
+                       "BLAS: %s, %d threads, %d host cores" % (Ns, sample_n, sample_me, sample_mi, tf, reps, tn,
+                                                                 scale, target_N, blas, threads, os.cpu_count() or 0)),
+            "measured_N": Ns, "measured_s_per_step": tf, "measured_s_per_step_no_eigvalsh": tn,
+            "value_no_eigvalsh": 1.0 / (tn * scale)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=16384)
+    ap.add_argument("--me", type=int, default=4096)
+    ap.add_argument("--mi", type=int, default=6144)
+    ap.add_argument("--nb", type=int, default=256)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--refine", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="also report the backward error of the last step")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pyipm_amd.newton import NewtonCore, mfma_f64_peak
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the Newton-step core has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    n, me, mi = args.n, args.me, args.mi
+    N = n + 2 * mi + me
+    qp = make_qp_device(n, me, mi, args.seed, device)
+    core = NewtonCore(n, me, mi, device=local_rank, nb=args.nb, world=world, rank=rank)
+    core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    core.set_option("profile", 1)
+
+    if world > 1:
+        from pyipm_amd.dist import DistNewton
+        drv = DistNewton(core)
+
+        def one_step():
+            return drv.step(0.0, 0.0, refine=args.refine)
+    else:
+        def one_step():
+            return core.step(0.0, 0.0, refine=args.refine)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    trailing_ms = trailing_flops = panel_ms = solve_ms = assemble_ms = 0.0
+    n_launch = 0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dz, st = one_step()
+        tm = core.timings()         # reads HIP-event durations of this step (stream already drained by the step)
+        trailing_ms += tm["trailing_ms"]; trailing_flops += tm["trailing_flops"]; n_launch += tm["n_trailing"]
+        panel_ms += tm["panel_ms"]; solve_ms += tm["solve_ms"]; assemble_ms += tm["assemble_ms"]
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        K = args.steps
+        ach = (trailing_flops / 1e12) / (trailing_ms * 1e-3) if trailing_ms > 0 else 0.0
+        try:
+            peak_meas = mfma_f64_peak(local_rank, 20000)
+        except Exception:
+            peak_meas = None
+        out = {
+            "metric": "newton_steps_per_sec", "value": K / elapsed, "unit": "steps/s", "n_gpus": world,
+            "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "synthetic convex dense QP Newton step (residual+KKT assembly+block LDL^T+solve+flip), "
+                                   "n=%d me=%d mi=%d -> KKT dim N=%d, seed %d, nb=%d, refine=%d"
+                                   % (n, me, mi, N, args.seed, args.nb, args.refine),
+                       "kkt_dim": N, "n": n, "me": me, "mi": mi, "nb": args.nb,
+                       "parallelism": "1D block-cyclic column panels over %d GPU(s)" % world,
+                       "pivoting": "Bunch-Kaufman restricted to 64x64 diagonal tiles (block pivots)"},
+            "roofline": {"bound": "mfma", "kernel": "k_update<128> (fp64 MFMA trailing rank-nb update)",
+                         "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": n_launch, "avg_launch_ms": trailing_ms / max(n_launch, 1),
+                         "flops_per_launch_avg": trailing_flops / max(n_launch, 1),
+                         "peak_measured_mfma_only": peak_meas,
+                         "frac_of_measured_peak": (ach / peak_meas) if peak_meas else None},
+            "phases_ms_per_step": {"assemble": assemble_ms / K, "panel(tile+scale+in-panel)": panel_ms / K,
+                                   "trailing": trailing_ms / K, "solve": solve_ms / K},
+            "step_flops_algorithmic": N ** 3 / 3.0 + 2.0 * N ** 2,
+            "step_tflops": (N ** 3 / 3.0 + 2.0 * N ** 2) / (elapsed / K) / 1e12,
+            "step_frac_of_peak": (N ** 3 / 3.0 + 2.0 * N ** 2) / (elapsed / K) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),
+            "inertia": {"n_neg": st["n_neg"], "expected": me + mi, "n_zero": st["n_zero"], "n_2x2": st["n_2x2"],
+                        "growth": st["growth"]},
+        }
+        if args.check and world == 1:
+            g = core.residual()
+            raw = core.solve(flip=False, refine=args.refine)
+            out["backward_error"] = float((core.matvec(raw) - g).norm() / g.norm())
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(target_N=N)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+/*
+ * pyipm_newton.h — C-ABI of the MI355X-native Newton-step core.
+ *
+ * The reference (jkaardal/pyipm) has no FFI: the seam this library replaces is the
+ * Python method boundary inside IPM.solve(), /root/reference/pyipm.py:1717-1725:
+ *
+ *     g  = -self.grad(x, s, lda)                                   # :1717
+ *     Hc = self.reghess(self.hess(x, s, lda))                      # :1718
+ *     dz = self.sym_solve_cmp(Hc, g.reshape((g.size,1))).reshape() # :1720-1721
+ *     dz[nvar+nineq:] = -dz[nvar+nineq:]                           # :1723-1725
+ *
+ * Each entry point below names the reference function it replaces.  Plain C types
+ * only; no torch / C++ types cross this boundary; no exceptions cross it.  Every
+ * function returns 0 on success or a negative PYIPM_E_* code;
+ * pyipm_newton_last_error() gives the message.  A handle is not thread-safe.
+ *
+ * Conventions
+ *   n = nvar, me = neq, mi = nineq, N = n + 2*mi + me   (pyipm.py:824-825)
+ *   block order [x | s | lambda_e | lambda_i]            (pyipm.py:824-842)
+ *   all data fp64.  d2L is n x n ROW-major, only its UPPER triangle is read
+ *   (pyipm.py:826-827); Je is n x me row-major (= dce), Ji is n x mi row-major
+ *   (= dci) (pyipm.py:486-487, 500-501).
+ *   Device KKT storage: column-major, lower triangle referenced, leading dimension
+ *   Npad = roundup(N,128); rows/cols N..Npad-1 are an identity pad.  Read as a
+ *   row-major array this is exactly triu(H) of the reference.
+ */
+#ifndef PYIPM_NEWTON_H
+#define PYIPM_NEWTON_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PYIPM_OK              0
+#define PYIPM_E_BADARG       -1   /* invalid argument / call order            */
+#define PYIPM_E_HIP          -2   /* a HIP runtime call failed                 */
+#define PYIPM_E_NOMEM        -3   /* workspace missing or too small            */
+#define PYIPM_E_NONFINITE    -4   /* NaN/Inf met during factorisation          */
+#define PYIPM_E_NODEVICE     -5   /* no usable HIP device                      */
+
+#define PYIPM_MEM_DEVICE      0   /* pointer is device memory (e.g. torch.Tensor.data_ptr()) */
+#define PYIPM_MEM_HOST        1   /* pointer is host memory; the library stages it           */
+
+#define PYIPM_TILE           64   /* block-pivot (diagonal tile) size          */
+#define PYIPM_PAD           128   /* Npad granularity                          */
+
+typedef struct pyipm_newton_ctx pyipm_newton_ctx;   /* opaque handle */
+
+/* What the factorisation reports instead of the reference's eigen-inertia test
+ * (reghess, pyipm.py:1378-1381, 1399): inertia from the signs of the block pivots. */
+typedef struct pyipm_factor_stats {
+    int64_t n_neg;     /* negative pivots  (must equal me+mi for correct inertia, pyipm.py:1381) */
+    int64_t n_zero;    /* rejected pivots, |d| <= pivtol * max|tile|  (singular direction)        */
+    int64_t n_2x2;     /* 2x2 Bunch-Kaufman pivots taken inside tiles                              */
+    int64_t n_pos;     /* positive pivots among the N real rows                                     */
+    double  d_min;     /* min |pivot| over accepted real pivots                                     */
+    double  d_max;     /* max |pivot|                                                               */
+    double  growth;    /* max |entry| of the block factor L (growth monitor)                        */
+    int64_t nonfinite; /* != 0 if a NaN/Inf was met                                                  */
+} pyipm_factor_stats;
+
+/* ---- lifetime ----------------------------------------------------------------------- */
+
+/* Bytes of device workspace the handle needs for (n,me,mi) when the KKT columns are
+ * distributed block-cyclically (panel width nb) over `world` ranks and this is `rank`.
+ * nb must be a multiple of 64 (0 = default 256). */
+size_t pyipm_newton_workspace_bytes(int64_t n, int64_t me, int64_t mi, int nb, int world, int rank);
+
+/* Create a handle on HIP device `device`.  `workspace` is caller-owned device memory
+ * (a torch tensor) of at least pyipm_newton_workspace_bytes(); pass NULL to let the
+ * library hipMalloc it.  `stream` is a hipStream_t (NULL = default stream). */
+int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t mi, int nb,
+                        int device, int world, int rank, void* workspace, size_t workspace_bytes,
+                        void* stream);
+int pyipm_newton_destroy(pyipm_newton_ctx* ctx);
+int pyipm_newton_set_stream(pyipm_newton_ctx* ctx, void* stream);
+const char* pyipm_newton_last_error(pyipm_newton_ctx* ctx);
+/* Geometry: out[0]=N, [1]=Npad, [2]=nb, [3]=npanels, [4]=local columns, [5]=world, [6]=rank. */
+int pyipm_newton_geometry(pyipm_newton_ctx* ctx, int64_t out[8]);
+
+/* ---- staging (host evaluates derivatives; pyipm.py:474-509 stays host-side) ---------- */
+
+/* Constant-per-iteration blocks: Hessian of the Lagrangian and the constraint Jacobians.
+ * Device pointers are retained (caller keeps them alive until re-staged); host pointers are
+ * copied into library-owned staging and not retained.  Je/Ji may be NULL when me/mi == 0. */
+int pyipm_newton_stage_blocks(pyipm_newton_ctx* ctx, const double* d2L, int64_t ld_d2L,
+                              const double* Je, int64_t ld_Je, const double* Ji, int64_t ld_Ji,
+                              int memkind);
+/* Per-step vectors: df(n), ce(me), ci(mi), s(mi), lda(me+mi) and the scalars mu, eps. */
+int pyipm_newton_stage_vectors(pyipm_newton_ctx* ctx, const double* df, const double* ce,
+                               const double* ci, const double* s, const double* lda,
+                               double mu, double eps, int memkind);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+
+/* replaces self.grad (pyipm.py:655-668) negated as at :1717:
+ *   g = -[ df - Je.lda_e - Ji.lda_i ; lda_i - mu/(s+eps) ; ce ; ci - s ]
+ * g is kept on the device as the right-hand side; g_out (N doubles, may be NULL) receives it. */
+int pyipm_newton_residual(pyipm_newton_ctx* ctx, double* g_out, int memkind);
+
+/* replaces self.hess (pyipm.py:816-844) plus the diagonal shifts reghess applies
+ * (pyipm.py:1383-1397): +delta on the x block, -delta_c on the lambda_e block. */
+int pyipm_newton_assemble(pyipm_newton_ctx* ctx, double delta, double delta_c);
+
+/* replaces the factorisation inside scipy.linalg.solve (pyipm.py:18-20, 1720) and the
+ * eigen-inertia test of reghess (pyipm.py:1378-1381): block LDL' with 64x64 Bunch-Kaufman
+ * block pivots; stats carries the inertia.  Inertia mismatch is NOT an error. */
+int pyipm_newton_factor(pyipm_newton_ctx* ctx, pyipm_factor_stats* stats);
+
+/* replaces the substitution inside sym_solve_cmp (pyipm.py:911-914, 1720-1721) and, when
+ * flip != 0, the multiplier sign flip (pyipm.py:1723-1725).  rhs == NULL uses the residual
+ * kept by pyipm_newton_residual.  refine > 0 adds that many steps of fp64 iterative
+ * refinement against the KKT blocks. */
+int pyipm_newton_solve(pyipm_newton_ctx* ctx, const double* rhs, double* dz, int flip,
+                       int refine, int memkind);
+
+/* y = Hc * v with Hc applied from the staged blocks (never from the factor): used by the
+ * refinement step and by the parity tests (backward error). */
+int pyipm_newton_kkt_matvec(pyipm_newton_ctx* ctx, const double* v, double* y, int memkind);
+
+/* Fused convenience: residual + assemble + factor + solve + flip = pyipm.py:1717-1725
+ * without regularisation retries (the host loop re-issues assemble/factor with new shifts). */
+int pyipm_newton_step(pyipm_newton_ctx* ctx, double delta, double delta_c, int refine,
+                      double* dz, pyipm_factor_stats* stats, int memkind);
+
+/* ---- per-panel phases (multi-GPU host orchestration; single-rank factor() loops these) --- */
+
+/* Factor panel p on its owner: left-looking in-panel updates, tile inversions, scaling. */
+int pyipm_newton_factor_panel(pyipm_newton_ctx* ctx, int64_t p);
+/* Owner: pack rows below panel p of W plus its tile inverses into `buf` for broadcast.
+ * Non-owner: unpack a received buffer and rebuild the block column L = W * inv(T).
+ * pyipm_newton_panel_msg_bytes gives the buffer size. */
+size_t pyipm_newton_panel_msg_bytes(pyipm_newton_ctx* ctx, int64_t p);
+int pyipm_newton_panel_pack(pyipm_newton_ctx* ctx, int64_t p, double* buf);
+int pyipm_newton_panel_unpack(pyipm_newton_ctx* ctx, int64_t p, const double* buf);
+/* Rank-nb trailing update of every locally owned column to the right of panel p. */
+int pyipm_newton_trailing_update(pyipm_newton_ctx* ctx, int64_t p);
+/* Finish: fetch statistics accumulated by this rank's tile kernels. */
+int pyipm_newton_factor_begin(pyipm_newton_ctx* ctx);
+int pyipm_newton_factor_end(pyipm_newton_ctx* ctx, pyipm_factor_stats* stats);
+/* Panel-wise substitution phases (vector `v` is Npad doubles on the device). */
+int pyipm_newton_fwd_panel(pyipm_newton_ctx* ctx, int64_t p, double* v);
+int pyipm_newton_diag_panel(pyipm_newton_ctx* ctx, int64_t p, double* v);
+int pyipm_newton_bwd_panel(pyipm_newton_ctx* ctx, int64_t p, double* v);
+
+/* ---- introspection for tests / bench ------------------------------------------------------ */
+
+/* Device pointer + leading dimension of the local KKT storage (column-major lower). */
+int pyipm_newton_kkt_storage(pyipm_newton_ctx* ctx, double** ptr, int64_t* ld, int64_t* ncols);
+/* Time (ms, HIP events on the handle's stream) of the phases of the last factor/solve call:
+ * out[0]=assemble, [1]=panel work, [2]=trailing updates, [3]=solve, [4]=#trailing launches. */
+int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
+int pyipm_newton_set_option(pyipm_newton_ctx* ctx, const char* name, double value);
+
+/* fp64 MFMA peak micro-benchmark: register-resident v_mfma_f64_16x16x4_f64 only.
+ * Returns achieved TFLOP/s in *tflops. */
+int pyipm_mfma_f64_peak(int device, int iters, double* tflops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYIPM_NEWTON_H */

@@ -1,0 +1,166 @@
+"""NumPy model of the HIP factorisation algorithm.  TEST INFRASTRUCTURE ONLY.
+
+A line-for-line *algorithmic* twin (not a code twin) of the device path in
+``pyipm_amd/csrc``: block LDL' with ``tb x tb`` block pivots, each diagonal tile
+inverted in place by symmetric sweeps with Bunch-Kaufman 1x1/2x2 pivot selection
+restricted to the tile.  It lets the CPU tests (a) check that the algorithm
+itself meets the <=1e-10 parity bar against the reference-following oracle
+before any GPU is involved, and (b) stand in for the HIP panel operations in the
+world_size-2 ``gloo`` tests of the multi-GPU host orchestration.  It is never
+imported by the product.
+
+Factorisation:  A = Lb * blockdiag(T_k) * Lb'   with  Lb unit BLOCK lower triangular,
+T_k the k-th Schur-complement diagonal tile,  Lb[i,k] = S[i,k] * inv(T_k)  where
+S is the Schur-complemented column block ("W" on the device).
+Solve:  y_k = b_k - sum_{j<k} Lb[k,j] y_j ;  z_k = inv(T_k) y_k ;
+        x_k = z_k - sum_{i>k} Lb[i,k]' x_i .
+"""
+from __future__ import annotations
+
+import numpy as np
+
+ALPHA = (1.0 + np.sqrt(17.0)) / 8.0       # Bunch-Kaufman threshold
+
+
+def sweep_invert(T, pivtol_rel=1e-14):
+    """Invert a symmetric tile by symmetric sweeps with tile-local Bunch-Kaufman pivoting.
+
+    Returns (Tinv, stats) with stats = dict(neg, zero, n2x2, dmin, dmax).  After
+    sweeping every index the working matrix equals -inv(T); the unswept block is
+    always the current Schur complement, so pivot selection is ordinary BK on it
+    with no physical row/column swaps.
+    """
+    B = np.array(T, dtype=np.float64)
+    B = np.tril(B) + np.tril(B, -1).T
+    tb = B.shape[0]
+    unswept = np.ones(tb, dtype=bool)
+    scale = np.max(np.abs(B)) if tb else 0.0
+    pivtol = pivtol_rel * scale
+    neg = zero = n2 = 0
+    dmin, dmax = np.inf, 0.0
+
+    def sweep1(p):
+        nonlocal neg, zero, dmin, dmax
+        d = B[p, p]
+        ad = abs(d)
+        if ad <= pivtol:
+            zero += 1
+            d = pivtol if d >= 0.0 else -pivtol
+            if d == 0.0:
+                d = np.finfo(np.float64).tiny
+        else:
+            if d < 0:
+                neg += 1
+            dmin, dmax = min(dmin, ad), max(dmax, ad)
+        col = B[:, p].copy()
+        colp = col / d
+        B[:, :] -= np.outer(colp, col)
+        B[:, p] = colp
+        B[p, :] = colp
+        B[p, p] = -1.0 / d
+        unswept[p] = False
+
+    def sweep2(p, q):
+        nonlocal neg, zero, n2, dmin, dmax
+        a, b, c = B[p, p], B[p, q], B[q, q]
+        det = a * c - b * b
+        # BK guarantees det < 0: one positive, one negative eigenvalue
+        n2 += 1
+        tr = a + c
+        disc = np.sqrt((a - c) ** 2 + 4 * b * b)
+        e1, e2 = 0.5 * (tr + disc), 0.5 * (tr - disc)
+        for e in (e1, e2):
+            if abs(e) <= pivtol:
+                zero += 1
+            else:
+                if e < 0:
+                    neg += 1
+                dmin, dmax = min(dmin, abs(e)), max(dmax, abs(e))
+        if det == 0.0:
+            det = -np.finfo(np.float64).tiny
+        ia, ib, ic = c / det, -b / det, a / det           # inverse of [[a,b],[b,c]]
+        cp, cq = B[:, p].copy(), B[:, q].copy()
+        lp = cp * ia + cq * ib
+        lq = cp * ib + cq * ic
+        B[:, :] -= np.outer(lp, cp) + np.outer(lq, cq)
+        B[:, p] = lp
+        B[p, :] = lp
+        B[:, q] = lq
+        B[q, :] = lq
+        B[p, p], B[p, q], B[q, p], B[q, q] = -ia, -ib, -ib, -ic
+        unswept[p] = unswept[q] = False
+
+    while unswept.any():
+        idx = np.flatnonzero(unswept)
+        diag = np.abs(B[idx, idx])
+        p = idx[int(np.argmax(diag))]
+        app = abs(B[p, p])
+        if idx.size == 1:
+            sweep1(p)
+            continue
+        others = idx[idx != p]
+        colmag = np.abs(B[others, p])
+        r = others[int(np.argmax(colmag))]
+        lam = abs(B[r, p])
+        if lam == 0.0 or app >= ALPHA * lam:
+            sweep1(p)
+            continue
+        rest = idx[idx != r]
+        sigma = np.max(np.abs(B[r, rest]))
+        if app * sigma >= ALPHA * lam * lam:
+            sweep1(p)
+        elif abs(B[r, r]) >= ALPHA * sigma:
+            sweep1(r)
+        else:
+            sweep2(p, r)
+    return -B, dict(neg=neg, zero=zero, n2x2=n2, dmin=dmin, dmax=dmax)
+
+
+class BlockLDL(object):
+    """Dense block-LDL' of a symmetric matrix with tile size ``tb`` (device: 64)."""
+
+    def __init__(self, A, tb=64, nreal=None):
+        A = np.array(A, dtype=np.float64)
+        N = A.shape[0]
+        self.N = N
+        self.tb = tb
+        Np = ((N + tb - 1) // tb) * tb
+        self.Np = Np
+        M = np.eye(Np)
+        M[:N, :N] = np.tril(A) + np.tril(A, -1).T
+        self.nt = Np // tb
+        self.Tinv = []
+        self.stats = dict(neg=0, zero=0, n2x2=0, dmin=np.inf, dmax=0.0)
+        tb_ = tb
+        for k in range(self.nt):
+            k0, k1 = k * tb_, (k + 1) * tb_
+            Ti, st = sweep_invert(M[k0:k1, k0:k1])
+            self.Tinv.append(Ti)
+            for key in ("neg", "zero", "n2x2"):
+                self.stats[key] += st[key]
+            self.stats["dmin"] = min(self.stats["dmin"], st["dmin"])
+            self.stats["dmax"] = max(self.stats["dmax"], st["dmax"])
+            if k1 < Np:
+                W = M[k1:, k0:k1].copy()
+                L = W @ Ti
+                M[k1:, k1:] -= L @ W.T
+                M[k1:, k0:k1] = L
+        # padding rows contribute positive unit pivots only
+        self.M = M
+
+    def solve(self, b):
+        tb, nt, Np = self.tb, self.nt, self.Np
+        y = np.zeros(Np)
+        y[:self.N] = b
+        for k in range(nt):
+            k0, k1 = k * tb, (k + 1) * tb
+            if k1 < Np:
+                y[k1:] -= self.M[k1:, k0:k1] @ y[k0:k1]
+        for k in range(nt):
+            k0, k1 = k * tb, (k + 1) * tb
+            y[k0:k1] = self.Tinv[k] @ y[k0:k1]
+        for k in range(nt - 1, -1, -1):
+            k0, k1 = k * tb, (k + 1) * tb
+            if k1 < Np:
+                y[k0:k1] -= self.M[k1:, k0:k1].T @ y[k1:]
+        return y[:self.N]

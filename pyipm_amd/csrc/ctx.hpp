@@ -1,0 +1,100 @@
+// ctx.hpp — handle, geometry and small helpers of the Newton-step core (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/pyipm_newton.h"
+
+namespace pyipm {
+
+constexpr int TB = PYIPM_TILE;      // 64: block-pivot tile
+constexpr int PADG = PYIPM_PAD;     // 128: Npad granularity = row tile of the MFMA update
+constexpr int BM = 128;             // MFMA update tile rows (i)
+constexpr int BKU = 16;             // MFMA update k-stage
+constexpr int ROWCHUNK = 2048;      // rows per block in the backward column dots
+
+// Block-cyclic 1D column distribution by panels of width nb.
+struct Geo {
+    int64_t n, me, mi, N, Npad;
+    int nb, world, rank;
+    int64_t npanels;        // global panels
+    int64_t ncols_local;    // columns stored on this rank
+    __host__ __device__ int64_t panel_c0(int64_t p) const { return p * (int64_t)nb; }
+    __host__ __device__ int64_t panel_w(int64_t p) const {
+        int64_t w = Npad - p * (int64_t)nb;
+        return w < nb ? w : nb;
+    }
+    __host__ __device__ int owner(int64_t p) const { return (int)(p % world); }
+    __host__ __device__ int64_t local_c0(int64_t p) const { return (p / world) * (int64_t)nb; }
+};
+
+inline Geo make_geo(int64_t n, int64_t me, int64_t mi, int nb, int world, int rank) {
+    Geo g;
+    g.n = n; g.me = me; g.mi = mi;
+    g.N = n + 2 * mi + me;
+    g.Npad = ((g.N + PADG - 1) / PADG) * PADG;
+    if (g.Npad == 0) g.Npad = PADG;
+    g.nb = nb > 0 ? nb : 256;
+    g.world = world; g.rank = rank;
+    g.npanels = (g.Npad + g.nb - 1) / g.nb;
+    int64_t c = 0;
+    for (int64_t p = rank; p < g.npanels; p += world) c += g.panel_w(p);
+    g.ncols_local = c;
+    return g;
+}
+
+struct DevStats {          // lives in device memory; tile kernels of one rank run serially
+    long long n_neg, n_zero, n_2x2, n_pos, nonfinite;
+    double d_min, d_max;
+    unsigned long long growth_bits;   // bit pattern of max |L| (monotone for non-negative doubles)
+};
+
+struct Ctx {
+    Geo g;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_ws = false;
+    char* ws = nullptr; size_t ws_bytes = 0;
+    // carved from workspace
+    double *A = nullptr, *Wbuf = nullptr, *Lbuf = nullptr, *Dinv = nullptr;
+    double *rhs = nullptr, *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *partial = nullptr;
+    double *df = nullptr, *ce = nullptr, *ci = nullptr, *s = nullptr, *lda = nullptr;
+    DevStats* dstats = nullptr;
+    // staged blocks (device pointers; either caller-owned or library staging)
+    const double *d2L = nullptr, *Je = nullptr, *Ji = nullptr;
+    int64_t ld_d2L = 0, ld_Je = 0, ld_Ji = 0;
+    double *stg_d2L = nullptr, *stg_Je = nullptr, *stg_Ji = nullptr;   // lazily hipMalloc'd
+    size_t stg_d2L_sz = 0, stg_Je_sz = 0, stg_Ji_sz = 0;
+    double* hostbuf = nullptr; size_t hostbuf_sz = 0;                   // pinned bounce buffer
+    double mu = 0.2, eps = 2.220446049250313e-16;
+    double delta = 0.0, delta_c = 0.0;
+    bool have_blocks = false, have_vectors = false, have_rhs = false, assembled = false, factored = false;
+    // options
+    double pivtol_rel = 1e-14;
+    int profile = 0;
+    // timings of last calls (ms)
+    double t_assemble = 0, t_panel = 0, t_trailing = 0, t_solve = 0, t_factor = 0;
+    double trailing_flops = 0; int64_t n_trailing = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_trailing;   // reused event pool
+    hipEvent_t ev[8] = {};
+    bool ev_assemble_valid = false, ev_solve_valid = false;
+    std::string err;
+};
+
+#define PYIPM_HIP(call)                                                                   \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e__);                \
+            return PYIPM_E_HIP;                                                           \
+        }                                                                                 \
+    } while (0)
+
+#define PYIPM_KCHECK()  PYIPM_HIP(hipGetLastError())
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace pyipm

@@ -1,0 +1,187 @@
+// kernels_assemble.hpp — K1 KKT assembly, K2 residual, KKT mat-vec from blocks (HBM-bound).
+//
+// K1 replaces self.hess (/root/reference/pyipm.py:816-844).  The device matrix is
+// column-major with the LOWER triangle referenced, which read as row-major is exactly
+// triu(H) of the reference: column j (j < n) is [ d2L[j, j:n] | 0 (mi) | Je[j,:] | Ji[j,:] ],
+// i.e. row j of the reference's upper-triangular build, so the copy is fully coalesced.
+#pragma once
+#include "ctx.hpp"
+
+namespace pyipm {
+
+// One thread-block writes a 256(i) x 16(j) patch of the local storage.
+__global__ __launch_bounds__(256) void k_assemble(
+    double* __restrict__ A, int64_t ld, Geo g,
+    const double* __restrict__ d2L, int64_t ldh,
+    const double* __restrict__ Je, int64_t ldje,
+    const double* __restrict__ Ji, int64_t ldji,
+    const double* __restrict__ s, const double* __restrict__ lda,
+    double eps, double delta, double delta_c)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t lc_base = (int64_t)blockIdx.y * 16;
+    const int64_t n = g.n, me = g.me, mi = g.mi, N = g.N;
+    const int64_t o_s = n, o_e = n + mi, o_i = n + mi + me;
+    #pragma unroll 4
+    for (int c = 0; c < 16; ++c) {
+        const int64_t lc = lc_base + c;
+        if (lc >= g.ncols_local) return;
+        // local column -> global column (block-cyclic by panels of nb)
+        const int64_t lp = lc / g.nb;
+        const int64_t j = (lp * g.world + g.rank) * (int64_t)g.nb + (lc - lp * g.nb);
+        if (i < j || i >= g.Npad) continue;           // only the lower triangle is stored
+        double v = 0.0;
+        if (j < n) {
+            if (i < n)            v = d2L[j * ldh + i] + (i == j ? delta : 0.0);
+            else if (i < o_e)     v = 0.0;
+            else if (i < o_i)     v = Je[j * ldje + (i - o_e)];
+            else if (i < N)       v = Ji[j * ldji + (i - o_i)];
+        } else if (j < o_e) {                          // slack columns: Sigma and -I
+            const int64_t b = j - o_s;
+            if (i == j)           v = lda[me + b] / (s[b] + eps);      // pyipm.py:498
+            else if (i == o_i + b) v = -1.0;                            // pyipm.py:838-842
+        } else if (j < o_i) {                          // lambda_e columns: -delta_c I (reghess)
+            if (i == j)           v = -delta_c;
+        } else if (j < N) {                            // lambda_i columns: zero block
+            v = 0.0;
+        } else {                                       // identity pad
+            v = (i == j) ? 1.0 : 0.0;
+        }
+        A[i + lc * ld] = v;
+    }
+}
+
+// ---- wave-level helpers -------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// y[j] (op)= sum_a M[j*ldm + a] * x[a]   for a in [0, ncol); one wave per row j.
+// Two matrices are fused so that K2 needs one pass.  mode: 0 -> out = base[j] - acc (then negated
+// if neg), used by the residual;  1 -> out[j] += acc.
+__global__ __launch_bounds__(256) void k_rowdot2(
+    double* __restrict__ out, const double* __restrict__ base, int64_t nrow,
+    const double* __restrict__ M1, int64_t ld1, const double* __restrict__ x1, int64_t nc1,
+    const double* __restrict__ M2, int64_t ld2, const double* __restrict__ x2, int64_t nc2,
+    int mode, int neg)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= nrow) return;
+    double acc = 0.0;
+    if (nc1 > 0) {
+        const double* r = M1 + j * ld1;
+        for (int64_t a = lane; a < nc1; a += 64) acc += r[a] * x1[a];
+    }
+    if (nc2 > 0) {
+        const double* r = M2 + j * ld2;
+        for (int64_t a = lane; a < nc2; a += 64) acc += r[a] * x2[a];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        if (mode == 0) { double v = base[j] - acc; out[j] = neg ? -v : v; }
+        else           { out[j] += acc; }
+    }
+}
+
+// K2 tail: the s, lambda_e, lambda_i parts of g = -grad (pyipm.py:655-668, negated at :1717),
+// and zero of the pad.
+__global__ __launch_bounds__(256) void k_residual_tail(
+    double* __restrict__ g, Geo geo, const double* __restrict__ ce, const double* __restrict__ ci,
+    const double* __restrict__ s, const double* __restrict__ lda, double mu, double eps)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;   // index into [n, Npad)
+    const int64_t i = geo.n + t;
+    if (i >= geo.Npad) return;
+    const int64_t n = geo.n, me = geo.me, mi = geo.mi;
+    double v = 0.0;
+    if (i < n + mi)            { int64_t b = i - n;           v = -(lda[me + b] - mu / (s[b] + eps)); }
+    else if (i < n + mi + me)  { int64_t a = i - n - mi;      v = -ce[a]; }
+    else if (i < geo.N)        { int64_t b = i - n - mi - me; v = -(ci[b] - s[b]); }
+    g[i] = v;
+}
+
+// Upper-triangle symmetric product, row part:  y[j] = sum_{k>=j} U[j,k] v[k] + delta v[j]
+__global__ __launch_bounds__(256) void k_symv_row(
+    double* __restrict__ y, const double* __restrict__ U, int64_t ldh, int64_t n,
+    const double* __restrict__ v, double delta)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const double* r = U + j * ldh;
+    double acc = 0.0;
+    for (int64_t k = j + lane; k < n; k += 64) acc += r[k] * v[k];
+    acc = wave_sum(acc);
+    if (lane == 0) y[j] = acc + delta * v[j];
+}
+
+// Column-walk partial products, deterministic two-pass:
+//   part[chunk][a] = sum_{j in chunk, j < jmax(a)} M[j*ldm + a] * x[j]
+// strict_upper != 0 restricts to j < a (the mirrored half of triu(d2L)).
+__global__ __launch_bounds__(256) void k_coldot_partial(
+    double* __restrict__ part, const double* __restrict__ M, int64_t ldm, int64_t nrow, int64_t ncol,
+    const double* __restrict__ x, int64_t rows_per_chunk, int strict_upper)
+{
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= ncol) return;
+    const int64_t j0 = (int64_t)blockIdx.y * rows_per_chunk;
+    int64_t j1 = j0 + rows_per_chunk; if (j1 > nrow) j1 = nrow;
+    if (strict_upper && j1 > a) j1 = a;
+    double acc = 0.0;
+    for (int64_t j = j0; j < j1; ++j) acc += M[j * ldm + a] * x[j];
+    part[(int64_t)blockIdx.y * ncol + a] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_coldot_reduce(
+    double* __restrict__ y, const double* __restrict__ part, int64_t ncol, int nchunk, int accumulate)
+{
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= ncol) return;
+    double acc = 0.0;
+    for (int c = 0; c < nchunk; ++c) acc += part[(int64_t)c * ncol + a];
+    y[a] = accumulate ? y[a] + acc : acc;
+}
+
+// Element-wise remainder of y = Hc v:  Sigma v_s - v_i ;  -delta_c v_e ;  -v_s ; pad passthrough.
+// (J' v_x terms are accumulated by the coldot kernels afterwards.)
+__global__ __launch_bounds__(256) void k_matvec_tail(
+    double* __restrict__ y, const double* __restrict__ v, Geo geo,
+    const double* __restrict__ s, const double* __restrict__ lda, double eps, double delta_c)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = geo.n + t;
+    if (i >= geo.Npad) return;
+    const int64_t n = geo.n, me = geo.me, mi = geo.mi;
+    double r;
+    if (i < n + mi)           { int64_t b = i - n; r = lda[me + b] / (s[b] + eps) * v[i] - v[n + mi + me + b]; }
+    else if (i < n + mi + me) { r = -delta_c * v[i]; }
+    else if (i < geo.N)       { int64_t b = i - n - mi - me; r = -v[n + b]; }
+    else                      { r = v[i]; }
+    y[i] = r;
+}
+
+__global__ __launch_bounds__(256) void k_axpby(double* __restrict__ out, const double* __restrict__ a,
+                                               const double* __restrict__ b, double alpha, double beta, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = alpha * a[i] + beta * b[i];
+}
+
+// dz[nvar+nineq:] = -dz[nvar+nineq:]  (pyipm.py:1723-1725) fused with the copy-out.
+__global__ __launch_bounds__(256) void k_copy_flip(double* __restrict__ out, const double* __restrict__ in,
+                                                   int64_t N, int64_t flip_from, int flip)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < N) out[i] = (flip && i >= flip_from) ? -in[i] : in[i];
+}
+
+__global__ __launch_bounds__(256) void k_fill(double* __restrict__ out, double v, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+
+}  // namespace pyipm

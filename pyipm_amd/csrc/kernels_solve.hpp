@@ -1,0 +1,119 @@
+// kernels_solve.hpp — K5 block substitutions with the block-LDL' factor (HBM-bound).
+// Replaces the triangular solves inside scipy.linalg.solve reached from
+// /root/reference/pyipm.py:911-914,1720-1721.
+//
+//   forward : y_k = b_k - sum_{j<k} Lb[k,j] y_j          (unit BLOCK lower triangular: no
+//   diagonal: z_k = inv(T_k) y_k                            in-tile triangular solve at all)
+//   backward: x_k = z_k - sum_{i>k} Lb[i,k]' x_i
+// organised per panel (nb columns): a one-workgroup kernel resolves the nb x nb diagonal
+// block, streaming kernels handle everything below it.
+#pragma once
+#include "ctx.hpp"
+
+namespace pyipm {
+
+// In-panel forward substitution on the nbw x nbw diagonal block.  blockDim = nbw.
+__global__ void k_fwd_diag(const double* __restrict__ A, int64_t ld, int64_t lc0, int64_t c0,
+                           int nbw, double* __restrict__ v)
+{
+    extern __shared__ double y[];
+    const int tid = threadIdx.x;
+    y[tid] = v[c0 + tid];
+    const int nt = nbw / TB;
+    for (int u = 0; u + 1 < nt; ++u) {
+        __syncthreads();
+        if (tid >= (u + 1) * TB) {
+            const double* col = A + (c0 + tid) + (lc0 + (int64_t)u * TB) * ld;
+            double acc = 0.0;
+            #pragma unroll 8
+            for (int k = 0; k < TB; ++k) acc = fma(col[(int64_t)k * ld], y[u * TB + k], acc);
+            y[tid] -= acc;
+        }
+    }
+    __syncthreads();
+    v[c0 + tid] = y[tid];
+}
+
+// Rows below the panel:  v[i] -= sum_{k<nbw} A[i, lc0+k] * v[c0+k].   One thread per row.
+__global__ __launch_bounds__(256) void k_fwd_gemv(const double* __restrict__ A, int64_t ld, int64_t lc0,
+                                                  int64_t c0, int nbw, int64_t row_begin, int64_t Npad,
+                                                  double* __restrict__ v)
+{
+    extern __shared__ double y[];
+    for (int k = threadIdx.x; k < nbw; k += 256) y[k] = v[c0 + k];
+    __syncthreads();
+    const int64_t i = row_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Npad) return;
+    const double* row = A + i + lc0 * ld;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    for (int k = 0; k < nbw; k += 4) {
+        acc0 = fma(row[(int64_t)(k + 0) * ld], y[k + 0], acc0);
+        acc1 = fma(row[(int64_t)(k + 1) * ld], y[k + 1], acc1);
+        acc2 = fma(row[(int64_t)(k + 2) * ld], y[k + 2], acc2);
+        acc3 = fma(row[(int64_t)(k + 3) * ld], y[k + 3], acc3);
+    }
+    v[i] -= (acc0 + acc1) + (acc2 + acc3);
+}
+
+// z_k = inv(T_k) y_k for the tiles of one panel.  grid = tiles, block = 64.
+__global__ __launch_bounds__(64) void k_diag_apply(const double* __restrict__ Dinv, int64_t tile0,
+                                                   int64_t c0, double* __restrict__ v)
+{
+    __shared__ double y[TB];
+    const int lane = threadIdx.x;
+    const int64_t base = c0 + (int64_t)blockIdx.x * TB;
+    y[lane] = v[base + lane];
+    __syncthreads();
+    const double* T = Dinv + (tile0 + blockIdx.x) * (int64_t)(TB * TB);
+    double acc = 0.0;
+    #pragma unroll 8
+    for (int j = 0; j < TB; ++j) acc = fma(T[j * TB + lane], y[j], acc);
+    v[base + lane] = acc;
+}
+
+// Backward, rows below the panel: part[chunk][k] = sum_{i in chunk} A[i, lc0+k] * v[i].
+// grid = (nbw, nchunk), block 256; deterministic (no atomics).
+__global__ __launch_bounds__(256) void k_bwd_dot(const double* __restrict__ A, int64_t ld, int64_t lc0,
+                                                 int nb, int64_t row_begin, int64_t Npad,
+                                                 const double* __restrict__ v, double* __restrict__ part)
+{
+    __shared__ double red[4];
+    const int k = blockIdx.x;
+    const int64_t r0 = row_begin + (int64_t)blockIdx.y * ROWCHUNK;
+    int64_t r1 = r0 + ROWCHUNK; if (r1 > Npad) r1 = Npad;
+    const double* col = A + (lc0 + k) * ld;
+    double acc = 0.0;
+    for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) acc = fma(col[i], v[i], acc);
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.y * nb + k] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// In-panel backward substitution.  blockDim = nbw.
+__global__ void k_bwd_diag(const double* __restrict__ A, int64_t ld, int64_t lc0, int64_t c0,
+                           int nbw, int nb, const double* __restrict__ part, int nchunk,
+                           double* __restrict__ v)
+{
+    extern __shared__ double x[];
+    const int tid = threadIdx.x;
+    double t = 0.0;
+    for (int c = 0; c < nchunk; ++c) t += part[(int64_t)c * nb + tid];
+    x[tid] = v[c0 + tid] - t;
+    const int nt = nbw / TB;
+    for (int u = nt - 1; u >= 1; --u) {
+        __syncthreads();
+        if (tid < u * TB) {
+            const double* col = A + (c0 + (int64_t)u * TB) + (lc0 + tid) * ld;
+            double acc = 0.0;
+            #pragma unroll 8
+            for (int i = 0; i < TB; ++i) acc = fma(col[i], x[u * TB + i], acc);
+            x[tid] -= acc;
+        }
+    }
+    __syncthreads();
+    v[c0 + tid] = x[tid];
+}
+
+}  // namespace pyipm

@@ -1,0 +1,703 @@
+// pyipm_newton.hip — C-ABI of the MI355X Newton-step core (declared in include/pyipm_newton.h).
+// gfx950 only; no CUDA path, no CPU fallback.  Host-side orchestration of the HIP kernels in
+// kernels_*.hpp.  Replaces /root/reference/pyipm.py:1717-1725 (see the header for the mapping).
+#include "ctx.hpp"
+#include "kernels_assemble.hpp"
+#include "kernels_factor.hpp"
+#include "kernels_solve.hpp"
+
+using namespace pyipm;
+
+namespace {
+
+struct Carve { size_t off = 0; size_t take(size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; } };
+
+// Workspace layout; returns total bytes.  When base != nullptr also sets the pointers.
+size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
+    Carve cv;
+    const size_t D = sizeof(double);
+    const size_t oA = cv.take((size_t)g.Npad * (size_t)(g.ncols_local > 0 ? g.ncols_local : 1) * D);
+    const size_t oW = cv.take((size_t)g.Npad * g.nb * D);
+    const size_t oL = cv.take(g.world > 1 ? (size_t)g.Npad * g.nb * D : 256);
+    const size_t oD = cv.take((size_t)(g.Npad / TB) * TB * TB * D);
+    const size_t orhs = cv.take((size_t)g.Npad * D);
+    const size_t ov0 = cv.take((size_t)g.Npad * D);
+    const size_t ov1 = cv.take((size_t)g.Npad * D);
+    const size_t ov2 = cv.take((size_t)g.Npad * D);
+    const size_t nchunk = (size_t)((g.Npad + ROWCHUNK - 1) / ROWCHUNK) + 1;
+    size_t npart = nchunk * (size_t)g.nb;
+    const size_t cd_chunks = 64;                       // column-dot partials for the mat-vec
+    size_t maxcol = (size_t)(g.n > g.me ? g.n : g.me); if ((size_t)g.mi > maxcol) maxcol = g.mi;
+    if (cd_chunks * maxcol > npart) npart = cd_chunks * maxcol;
+    const size_t op = cv.take(npart * D);
+    const size_t odf = cv.take((size_t)(g.n + 1) * D);
+    const size_t oce = cv.take((size_t)(g.me + 1) * D);
+    const size_t oci = cv.take((size_t)(g.mi + 1) * D);
+    const size_t os = cv.take((size_t)(g.mi + 1) * D);
+    const size_t ol = cv.take((size_t)(g.me + g.mi + 1) * D);
+    const size_t ost = cv.take(sizeof(DevStats));
+    if (base) {
+        c->A = (double*)(base + oA); c->Wbuf = (double*)(base + oW); c->Lbuf = (double*)(base + oL);
+        c->Dinv = (double*)(base + oD); c->rhs = (double*)(base + orhs);
+        c->v0 = (double*)(base + ov0); c->v1 = (double*)(base + ov1); c->v2 = (double*)(base + ov2);
+        c->partial = (double*)(base + op);
+        c->df = (double*)(base + odf); c->ce = (double*)(base + oce); c->ci = (double*)(base + oci);
+        c->s = (double*)(base + os); c->lda = (double*)(base + ol);
+        c->dstats = (DevStats*)(base + ost);
+    }
+    return cv.off;
+}
+
+int check_ctx(pyipm_newton_ctx* h) { return h ? 0 : PYIPM_E_BADARG; }
+inline Ctx* C(pyipm_newton_ctx* h) { return reinterpret_cast<Ctx*>(h); }
+
+int ensure_hostbuf(Ctx* ctx, size_t bytes) {
+    if (ctx->hostbuf_sz >= bytes) return 0;
+    if (ctx->hostbuf) PYIPM_HIP(hipHostFree(ctx->hostbuf));
+    ctx->hostbuf = nullptr; ctx->hostbuf_sz = 0;
+    PYIPM_HIP(hipHostMalloc((void**)&ctx->hostbuf, bytes, hipHostMallocDefault));
+    ctx->hostbuf_sz = bytes;
+    return 0;
+}
+
+// copy `count` doubles from caller memory (host or device) into library device memory
+int put_vec(Ctx* ctx, double* dst, const double* src, size_t count, int memkind) {
+    if (count == 0) return 0;
+    if (!src) { ctx->err = "null vector pointer"; return PYIPM_E_BADARG; }
+    PYIPM_HIP(hipMemcpyAsync(dst, src, count * sizeof(double),
+                             memkind == PYIPM_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                             ctx->stream));
+    if (memkind == PYIPM_MEM_HOST) PYIPM_HIP(hipStreamSynchronize(ctx->stream));   // host memory not retained
+    return 0;
+}
+
+int stage_block(Ctx* ctx, const double* src, int64_t rows, int64_t cols, int64_t ld, int memkind,
+                double** stg, size_t* stg_sz, const double** out_ptr, int64_t* out_ld) {
+    if (rows == 0 || cols == 0) { *out_ptr = nullptr; *out_ld = cols; return 0; }
+    if (!src || ld < cols) { ctx->err = "bad block pointer / leading dimension"; return PYIPM_E_BADARG; }
+    if (memkind == PYIPM_MEM_DEVICE) { *out_ptr = src; *out_ld = ld; return 0; }
+    const size_t need = (size_t)rows * (size_t)cols * sizeof(double);
+    if (*stg_sz < need) {
+        if (*stg) PYIPM_HIP(hipFree(*stg));
+        *stg = nullptr; *stg_sz = 0;
+        PYIPM_HIP(hipMalloc((void**)stg, need));
+        *stg_sz = need;
+    }
+    PYIPM_HIP(hipMemcpy2DAsync(*stg, (size_t)cols * sizeof(double), src, (size_t)ld * sizeof(double),
+                               (size_t)cols * sizeof(double), (size_t)rows, hipMemcpyHostToDevice, ctx->stream));
+    PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+    *out_ptr = *stg; *out_ld = cols;
+    return 0;
+}
+
+inline dim3 grid1(int64_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
+
+// ---- per-panel building blocks -----------------------------------------------------------------
+
+int launch_update128(Ctx* ctx, const double* Lop, int64_t ldl, int K, int64_t row_begin, int64_t first_lp) {
+    const Geo& g = ctx->g;
+    const int64_t m = g.Npad - row_begin;
+    if (m <= 0) return 0;
+    const int64_t local_panels = (g.ncols_local + g.nb - 1) / g.nb;
+    const int64_t ncol_tiles = (local_panels - first_lp) * (g.nb / 128);
+    if (ncol_tiles <= 0) return 0;
+    dim3 grid((unsigned)(m / BM), (unsigned)ncol_tiles);
+    hipLaunchKernelGGL(k_update<128>, grid, dim3(256), 0, ctx->stream, ctx->A, g.Npad, Lop, ldl,
+                       ctx->Wbuf, g.Npad, K, row_begin, g.Npad, first_lp, (int64_t)0, g.nb, g.world, g.rank);
+    PYIPM_KCHECK();
+    return 0;
+}
+
+int factor_panel(Ctx* ctx, int64_t p) {
+    const Geo& g = ctx->g;
+    if (p < 0 || p >= g.npanels || g.owner(p) != g.rank) { ctx->err = "factor_panel: not the owner"; return PYIPM_E_BADARG; }
+    const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
+    const int nbw = (int)g.panel_w(p);
+    const int nt = nbw / TB;
+    const int64_t lp = p / g.world;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t j0 = c0 + (int64_t)t * TB, lcol = lc0 + (int64_t)t * TB;
+        if (t > 0) {
+            // left-looking in-panel update of this tile's column block with the t tiles before it
+            const int64_t row_begin = (j0 / BM) * BM;
+            const int64_t m = g.Npad - row_begin;
+            dim3 grid((unsigned)(m / BM), 1);
+            hipLaunchKernelGGL(k_update<64>, grid, dim3(256), 0, ctx->stream, ctx->A, g.Npad,
+                               ctx->A + lc0 * g.Npad, g.Npad, ctx->Wbuf, g.Npad, t * TB, row_begin, g.Npad,
+                               lp, (int64_t)t, g.nb, g.world, g.rank);
+            PYIPM_KCHECK();
+        }
+        hipLaunchKernelGGL(k_tile_invert, dim3(1), dim3(256), 0, ctx->stream, ctx->A, g.Npad, j0, lcol,
+                           ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), ctx->dstats, g.N, ctx->pivtol_rel);
+        PYIPM_KCHECK();
+        const int64_t below = g.Npad - (j0 + TB);
+        if (below > 0) {
+            hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(below / TB)), dim3(64), 0, ctx->stream,
+                               ctx->A, g.Npad, lcol, ctx->A, g.Npad, lcol, ctx->Wbuf, g.Npad, (int64_t)t * TB,
+                               ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), j0 + TB, &ctx->dstats->growth_bits);
+            PYIPM_KCHECK();
+        }
+    }
+    return 0;
+}
+
+int trailing_update(Ctx* ctx, int64_t p) {
+    const Geo& g = ctx->g;
+    const int64_t c1 = g.panel_c0(p) + g.panel_w(p);
+    if (c1 >= g.Npad) return 0;
+    const int nbw = (int)g.panel_w(p);
+    const bool mine = g.owner(p) == g.rank;
+    const double* Lop = mine ? ctx->A + g.local_c0(p) * g.Npad : ctx->Lbuf;
+    // first locally owned panel strictly after p
+    int64_t q = p + 1;
+    while (q < g.npanels && g.owner(q) != g.rank) ++q;
+    if (q >= g.npanels) return 0;
+    const int64_t first_lp = q / g.world;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->profile) {
+        if ((size_t)ctx->n_trailing >= ctx->ev_trailing.size()) {
+            hipEvent_t a, b;
+            PYIPM_HIP(hipEventCreate(&a)); PYIPM_HIP(hipEventCreate(&b));
+            ctx->ev_trailing.push_back({a, b});
+        }
+        e0 = ctx->ev_trailing[ctx->n_trailing].first; e1 = ctx->ev_trailing[ctx->n_trailing].second;
+        PYIPM_HIP(hipEventRecord(e0, ctx->stream));
+    }
+    int rc = launch_update128(ctx, Lop, g.Npad, nbw, c1, first_lp);
+    if (rc) return rc;
+    if (ctx->profile) PYIPM_HIP(hipEventRecord(e1, ctx->stream));
+    // algorithmic flops of this launch: lower-triangular rank-nbw update of the local columns
+    {
+        double fl = 0.0;
+        for (int64_t qq = q; qq < g.npanels; qq += g.world) {
+            const double w = (double)g.panel_w(qq), r0 = (double)(g.Npad - g.panel_c0(qq));
+            fl += 2.0 * nbw * (w * r0 - 0.5 * w * (w - 1.0));
+        }
+        ctx->trailing_flops += fl;
+    }
+    ctx->n_trailing++;
+    return 0;
+}
+
+int factor_begin(Ctx* ctx) {
+    DevStats z; memset(&z, 0, sizeof(z)); z.d_min = 1.0e308; z.d_max = 0.0;
+    PYIPM_HIP(hipMemcpyAsync(ctx->dstats, &z, sizeof(z), hipMemcpyHostToDevice, ctx->stream));
+    PYIPM_HIP(hipStreamSynchronize(ctx->stream));   // &z is a stack temporary
+    ctx->n_trailing = 0; ctx->trailing_flops = 0.0;
+    return 0;
+}
+
+int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
+    DevStats z;
+    PYIPM_HIP(hipMemcpyAsync(&z, ctx->dstats, sizeof(z), hipMemcpyDeviceToHost, ctx->stream));
+    PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->profile) {
+        double ms = 0.0;
+        for (int64_t i = 0; i < ctx->n_trailing; ++i) {
+            float t = 0.f;
+            PYIPM_HIP(hipEventElapsedTime(&t, ctx->ev_trailing[i].first, ctx->ev_trailing[i].second));
+            ms += t;
+        }
+        ctx->t_trailing = ms;
+    }
+    ctx->factored = true;
+    if (stats) {
+        stats->n_neg = z.n_neg; stats->n_zero = z.n_zero; stats->n_2x2 = z.n_2x2; stats->n_pos = z.n_pos;
+        stats->d_min = z.d_min; stats->d_max = z.d_max;
+        long long gb = (long long)z.growth_bits; double gr; memcpy(&gr, &gb, sizeof(gr));
+        stats->growth = gr; stats->nonfinite = z.nonfinite;
+    }
+    if (z.nonfinite) { ctx->err = "NaN/Inf met during factorisation"; return PYIPM_E_NONFINITE; }
+    return 0;
+}
+
+int fwd_panel(Ctx* ctx, int64_t p, double* v) {
+    const Geo& g = ctx->g;
+    const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
+    const int nbw = (int)g.panel_w(p);
+    hipLaunchKernelGGL(k_fwd_diag, dim3(1), dim3(nbw), nbw * sizeof(double), ctx->stream, ctx->A, g.Npad, lc0, c0, nbw, v);
+    PYIPM_KCHECK();
+    const int64_t below = g.Npad - (c0 + nbw);
+    if (below > 0) {
+        hipLaunchKernelGGL(k_fwd_gemv, grid1(below), dim3(256), nbw * sizeof(double), ctx->stream, ctx->A, g.Npad, lc0, c0,
+                           nbw, c0 + nbw, g.Npad, v);
+        PYIPM_KCHECK();
+    }
+    return 0;
+}
+
+int diag_panel(Ctx* ctx, int64_t p, double* v) {
+    const Geo& g = ctx->g;
+    const int64_t c0 = g.panel_c0(p);
+    const int nbw = (int)g.panel_w(p);
+    hipLaunchKernelGGL(k_diag_apply, dim3(nbw / TB), dim3(64), 0, ctx->stream, ctx->Dinv, c0 / TB, c0, v);
+    PYIPM_KCHECK();
+    return 0;
+}
+
+int bwd_panel(Ctx* ctx, int64_t p, double* v) {
+    const Geo& g = ctx->g;
+    const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
+    const int nbw = (int)g.panel_w(p);
+    const int64_t below = g.Npad - (c0 + nbw);
+    int nchunk = 0;
+    if (below > 0) {
+        nchunk = (int)((below + ROWCHUNK - 1) / ROWCHUNK);
+        hipLaunchKernelGGL(k_bwd_dot, dim3(nbw, nchunk), dim3(256), 0, ctx->stream, ctx->A, g.Npad, lc0, g.nb,
+                           c0 + nbw, g.Npad, v, ctx->partial);
+        PYIPM_KCHECK();
+    }
+    hipLaunchKernelGGL(k_bwd_diag, dim3(1), dim3(nbw), nbw * sizeof(double), ctx->stream, ctx->A, g.Npad, lc0, c0, nbw,
+                       g.nb, ctx->partial, nchunk, v);
+    PYIPM_KCHECK();
+    return 0;
+}
+
+// x := Hc^{-1} x  in place on an Npad device vector (single-rank path)
+int solve_inplace(Ctx* ctx, double* v) {
+    const Geo& g = ctx->g;
+    for (int64_t p = 0; p < g.npanels; ++p) { int rc = fwd_panel(ctx, p, v); if (rc) return rc; }
+    for (int64_t p = 0; p < g.npanels; ++p) { int rc = diag_panel(ctx, p, v); if (rc) return rc; }
+    for (int64_t p = g.npanels - 1; p >= 0; --p) { int rc = bwd_panel(ctx, p, v); if (rc) return rc; }
+    return 0;
+}
+
+// y = Hc v from the staged blocks (Npad vectors on the device)
+int kkt_matvec_dev(Ctx* ctx, const double* v, double* y) {
+    const Geo& g = ctx->g;
+    const int64_t n = g.n, me = g.me, mi = g.mi;
+    if (!ctx->have_blocks || !ctx->have_vectors) { ctx->err = "matvec: stage blocks and vectors first"; return PYIPM_E_BADARG; }
+    // x block: row part of triu(d2L) + delta
+    hipLaunchKernelGGL(k_symv_row, grid1(n, 4), dim3(256), 0, ctx->stream, y, ctx->d2L, ctx->ld_d2L, n, v, ctx->delta);
+    PYIPM_KCHECK();
+    // + Je v_e + Ji v_i
+    if (me + mi > 0) {
+        hipLaunchKernelGGL(k_rowdot2, grid1(n, 4), dim3(256), 0, ctx->stream, y, (const double*)nullptr, n,
+                           ctx->Je, ctx->ld_Je, v + n + mi, me, ctx->Ji, ctx->ld_Ji, v + n + mi + me, mi, 1, 0);
+        PYIPM_KCHECK();
+    }
+    // + mirrored strict upper part of d2L (column walk, deterministic two-pass)
+    {
+        const int nchunk = 64;
+        const int64_t rpc = (n + nchunk - 1) / nchunk;
+        hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((n + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
+                           ctx->partial, ctx->d2L, ctx->ld_d2L, n, n, v, rpc, 1);
+        PYIPM_KCHECK();
+        hipLaunchKernelGGL(k_coldot_reduce, grid1(n), dim3(256), 0, ctx->stream, y, ctx->partial, n, nchunk, 1);
+        PYIPM_KCHECK();
+    }
+    // s, lambda_e, lambda_i, pad: element-wise parts
+    hipLaunchKernelGGL(k_matvec_tail, grid1(g.Npad - n), dim3(256), 0, ctx->stream, y, v, g, ctx->s, ctx->lda,
+                       ctx->eps, ctx->delta_c);
+    PYIPM_KCHECK();
+    // + Je' v_x , Ji' v_x
+    const int nchunk = 64;
+    const int64_t rpc = (n + nchunk - 1) / nchunk;
+    if (me > 0) {
+        hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((me + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
+                           ctx->partial, ctx->Je, ctx->ld_Je, n, me, v, rpc, 0);
+        PYIPM_KCHECK();
+        hipLaunchKernelGGL(k_coldot_reduce, grid1(me), dim3(256), 0, ctx->stream, y + n + mi, ctx->partial, me, nchunk, 1);
+        PYIPM_KCHECK();
+    }
+    if (mi > 0) {
+        hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((mi + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
+                           ctx->partial, ctx->Ji, ctx->ld_Ji, n, mi, v, rpc, 0);
+        PYIPM_KCHECK();
+        hipLaunchKernelGGL(k_coldot_reduce, grid1(mi), dim3(256), 0, ctx->stream, y + n + mi + me, ctx->partial, mi, nchunk, 1);
+        PYIPM_KCHECK();
+    }
+    return 0;
+}
+
+int residual_dev(Ctx* ctx) {
+    const Geo& g = ctx->g;
+    if (!ctx->have_blocks || !ctx->have_vectors) { ctx->err = "residual: stage blocks and vectors first"; return PYIPM_E_BADARG; }
+    hipLaunchKernelGGL(k_rowdot2, grid1(g.n, 4), dim3(256), 0, ctx->stream, ctx->rhs, ctx->df, g.n,
+                       ctx->Je, ctx->ld_Je, ctx->lda, g.me, ctx->Ji, ctx->ld_Ji, ctx->lda + g.me, g.mi, 0, 1);
+    PYIPM_KCHECK();
+    if (g.Npad > g.n) {
+        hipLaunchKernelGGL(k_residual_tail, grid1(g.Npad - g.n), dim3(256), 0, ctx->stream, ctx->rhs, g, ctx->ce, ctx->ci,
+                           ctx->s, ctx->lda, ctx->mu, ctx->eps);
+        PYIPM_KCHECK();
+    }
+    ctx->have_rhs = true;
+    return 0;
+}
+
+int assemble_dev(Ctx* ctx, double delta, double delta_c) {
+    const Geo& g = ctx->g;
+    if (!ctx->have_blocks || !ctx->have_vectors) { ctx->err = "assemble: stage blocks and vectors first"; return PYIPM_E_BADARG; }
+    ctx->delta = delta; ctx->delta_c = delta_c;
+    if (g.ncols_local > 0) {
+        dim3 grid((unsigned)((g.Npad + 255) / 256), (unsigned)((g.ncols_local + 15) / 16));
+        hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
+                           ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c);
+        PYIPM_KCHECK();
+    }
+    ctx->assembled = true; ctx->factored = false;
+    return 0;
+}
+
+int factor_all(Ctx* ctx, pyipm_factor_stats* stats) {
+    const Geo& g = ctx->g;
+    if (g.world != 1) { ctx->err = "factor(): single-rank entry point; use the per-panel phases when world > 1"; return PYIPM_E_BADARG; }
+    if (!ctx->assembled) { ctx->err = "factor: assemble first"; return PYIPM_E_BADARG; }
+    int rc = factor_begin(ctx); if (rc) return rc;
+    PYIPM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    for (int64_t p = 0; p < g.npanels; ++p) {
+        rc = factor_panel(ctx, p); if (rc) return rc;
+        rc = trailing_update(ctx, p); if (rc) return rc;
+    }
+    PYIPM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    ctx->assembled = false;                 // storage now holds the factor
+    rc = factor_end(ctx, stats);
+    float ms = 0.f;
+    PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->t_factor = ms;
+    ctx->t_panel = ctx->profile ? (ms - ctx->t_trailing) : 0.0;
+    return rc;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+size_t pyipm_newton_workspace_bytes(int64_t n, int64_t me, int64_t mi, int nb, int world, int rank) {
+    if (n <= 0 || me < 0 || mi < 0 || world < 1 || rank < 0 || rank >= world) return 0;
+    if (nb == 0) nb = 256;
+    if (nb % 128 != 0 || nb > 512) return 0;
+    Geo g = make_geo(n, me, mi, nb, world, rank);
+    return carve_workspace(nullptr, g, nullptr);
+}
+
+int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t mi, int nb, int device,
+                        int world, int rank, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!out) return PYIPM_E_BADARG;
+    *out = nullptr;
+    if (n <= 0 || me < 0 || mi < 0 || world < 1 || rank < 0 || rank >= world) return PYIPM_E_BADARG;
+    if (nb == 0) nb = 256;
+    if (nb % 128 != 0 || nb > 512) return PYIPM_E_BADARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PYIPM_E_NODEVICE;
+    Ctx* ctx = new Ctx();
+    ctx->g = make_geo(n, me, mi, nb, world, rank);
+    ctx->device = device;
+    ctx->stream = (hipStream_t)stream;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return PYIPM_E_NODEVICE; }
+    const size_t need = carve_workspace(nullptr, ctx->g, nullptr);
+    if (workspace) {
+        if (workspace_bytes < need) { delete ctx; return PYIPM_E_NOMEM; }
+        ctx->ws = (char*)workspace; ctx->own_ws = false;
+    } else {
+        if (hipMalloc((void**)&ctx->ws, need) != hipSuccess) { delete ctx; return PYIPM_E_NOMEM; }
+        ctx->own_ws = true;
+    }
+    ctx->ws_bytes = need;
+    carve_workspace(ctx, ctx->g, ctx->ws);
+    for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return PYIPM_E_HIP; }
+    *out = reinterpret_cast<pyipm_newton_ctx*>(ctx);
+    return PYIPM_OK;
+}
+
+int pyipm_newton_destroy(pyipm_newton_ctx* h) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 8; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+    for (auto& pr : ctx->ev_trailing) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    if (ctx->stg_d2L) hipFree(ctx->stg_d2L);
+    if (ctx->stg_Je) hipFree(ctx->stg_Je);
+    if (ctx->stg_Ji) hipFree(ctx->stg_Ji);
+    if (ctx->hostbuf) hipHostFree(ctx->hostbuf);
+    if (ctx->own_ws && ctx->ws) hipFree(ctx->ws);
+    delete ctx;
+    return PYIPM_OK;
+}
+
+int pyipm_newton_set_stream(pyipm_newton_ctx* h, void* stream) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    C(h)->stream = (hipStream_t)stream;
+    return PYIPM_OK;
+}
+
+const char* pyipm_newton_last_error(pyipm_newton_ctx* h) {
+    if (!h) return "null handle";
+    return C(h)->err.c_str();
+}
+
+int pyipm_newton_geometry(pyipm_newton_ctx* h, int64_t out[8]) {
+    if (check_ctx(h) || !out) return PYIPM_E_BADARG;
+    const Geo& g = C(h)->g;
+    out[0] = g.N; out[1] = g.Npad; out[2] = g.nb; out[3] = g.npanels; out[4] = g.ncols_local;
+    out[5] = g.world; out[6] = g.rank; out[7] = (int64_t)C(h)->ws_bytes;
+    return PYIPM_OK;
+}
+
+int pyipm_newton_stage_blocks(pyipm_newton_ctx* h, const double* d2L, int64_t ld_d2L, const double* Je,
+                              int64_t ld_Je, const double* Ji, int64_t ld_Ji, int memkind) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    int rc;
+    rc = stage_block(ctx, d2L, g.n, g.n, ld_d2L, memkind, &ctx->stg_d2L, &ctx->stg_d2L_sz, &ctx->d2L, &ctx->ld_d2L); if (rc) return rc;
+    rc = stage_block(ctx, Je, g.me ? g.n : 0, g.me, ld_Je, memkind, &ctx->stg_Je, &ctx->stg_Je_sz, &ctx->Je, &ctx->ld_Je); if (rc) return rc;
+    rc = stage_block(ctx, Ji, g.mi ? g.n : 0, g.mi, ld_Ji, memkind, &ctx->stg_Ji, &ctx->stg_Ji_sz, &ctx->Ji, &ctx->ld_Ji); if (rc) return rc;
+    ctx->have_blocks = true;
+    return PYIPM_OK;
+}
+
+int pyipm_newton_stage_vectors(pyipm_newton_ctx* h, const double* df, const double* ce, const double* ci,
+                               const double* s, const double* lda, double mu, double eps, int memkind) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    int rc;
+    rc = put_vec(ctx, ctx->df, df, g.n, memkind); if (rc) return rc;
+    rc = put_vec(ctx, ctx->ce, ce, g.me, memkind); if (rc) return rc;
+    rc = put_vec(ctx, ctx->ci, ci, g.mi, memkind); if (rc) return rc;
+    rc = put_vec(ctx, ctx->s, s, g.mi, memkind); if (rc) return rc;
+    rc = put_vec(ctx, ctx->lda, lda, g.me + g.mi, memkind); if (rc) return rc;
+    ctx->mu = mu; ctx->eps = eps;
+    ctx->have_vectors = true;
+    return PYIPM_OK;
+}
+
+static int copy_out(Ctx* ctx, double* dst, const double* src_dev, size_t count, int memkind) {
+    if (!dst || count == 0) return 0;
+    PYIPM_HIP(hipMemcpyAsync(dst, src_dev, count * sizeof(double),
+                             memkind == PYIPM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
+    if (memkind == PYIPM_MEM_HOST) PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int pyipm_newton_residual(pyipm_newton_ctx* h, double* g_out, int memkind) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    int rc = residual_dev(ctx); if (rc) return rc;
+    return copy_out(ctx, g_out, ctx->rhs, ctx->g.N, memkind);
+}
+
+int pyipm_newton_assemble(pyipm_newton_ctx* h, double delta, double delta_c) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    PYIPM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    int rc = assemble_dev(ctx, delta, delta_c); if (rc) return rc;
+    PYIPM_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
+    ctx->ev_assemble_valid = true;
+    return PYIPM_OK;
+}
+
+int pyipm_newton_factor(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    return factor_all(ctx, stats);
+}
+
+int pyipm_newton_solve(pyipm_newton_ctx* h, const double* rhs, double* dz, int flip, int refine, int memkind) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    if (g.world != 1) { ctx->err = "solve(): single-rank entry point"; return PYIPM_E_BADARG; }
+    if (!ctx->factored) { ctx->err = "solve: factor first"; return PYIPM_E_BADARG; }
+    if (!dz) { ctx->err = "solve: null output"; return PYIPM_E_BADARG; }
+    PYIPM_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    // b -> v1 (kept for refinement), x -> v0
+    if (rhs) {
+        hipLaunchKernelGGL(k_fill, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v1, 0.0, g.Npad); PYIPM_KCHECK();
+        int rc = put_vec(ctx, ctx->v1, rhs, g.N, memkind); if (rc) return rc;
+    } else {
+        if (!ctx->have_rhs) { ctx->err = "solve: no right-hand side (call residual or pass rhs)"; return PYIPM_E_BADARG; }
+        PYIPM_HIP(hipMemcpyAsync(ctx->v1, ctx->rhs, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    PYIPM_HIP(hipMemcpyAsync(ctx->v0, ctx->v1, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = solve_inplace(ctx, ctx->v0); if (rc) return rc;
+    for (int it = 0; it < refine; ++it) {
+        // r = b - Hc x ;  x += Hc^{-1} r      (Hc applied from the blocks, not from the factor)
+        rc = kkt_matvec_dev(ctx, ctx->v0, ctx->v2); if (rc) return rc;
+        hipLaunchKernelGGL(k_axpby, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v2, ctx->v1, ctx->v2, 1.0, -1.0, g.Npad);
+        PYIPM_KCHECK();
+        rc = solve_inplace(ctx, ctx->v2); if (rc) return rc;
+        hipLaunchKernelGGL(k_axpby, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v0, ctx->v0, ctx->v2, 1.0, 1.0, g.Npad);
+        PYIPM_KCHECK();
+    }
+    // flip + copy out (device staging through v2 so host copies stay contiguous)
+    hipLaunchKernelGGL(k_copy_flip, grid1(g.N), dim3(256), 0, ctx->stream, ctx->v2, ctx->v0, g.N, g.n + g.mi,
+                       (flip && (g.me + g.mi) > 0) ? 1 : 0);
+    PYIPM_KCHECK();
+    PYIPM_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
+    rc = copy_out(ctx, dz, ctx->v2, g.N, memkind); if (rc) return rc;
+    ctx->ev_solve_valid = true;
+    return PYIPM_OK;
+}
+
+int pyipm_newton_kkt_matvec(pyipm_newton_ctx* h, const double* v, double* y, int memkind) {
+    if (check_ctx(h) || !v || !y) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_fill, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v1, 0.0, g.Npad); PYIPM_KCHECK();
+    int rc = put_vec(ctx, ctx->v1, v, g.N, memkind); if (rc) return rc;
+    rc = kkt_matvec_dev(ctx, ctx->v1, ctx->v2); if (rc) return rc;
+    return copy_out(ctx, y, ctx->v2, g.N, memkind);
+}
+
+int pyipm_newton_step(pyipm_newton_ctx* h, double delta, double delta_c, int refine, double* dz,
+                      pyipm_factor_stats* stats, int memkind) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    int rc = residual_dev(ctx); if (rc) return rc;
+    rc = pyipm_newton_assemble(h, delta, delta_c); if (rc) return rc;
+    rc = factor_all(ctx, stats); if (rc) return rc;
+    return pyipm_newton_solve(h, nullptr, dz, 1, refine, memkind);
+}
+
+// ---- per-panel phases -----------------------------------------------------------------------------
+int pyipm_newton_factor_begin(pyipm_newton_ctx* h) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    if (!ctx->assembled) { ctx->err = "factor_begin: assemble first"; return PYIPM_E_BADARG; }
+    return factor_begin(ctx);
+}
+int pyipm_newton_factor_end(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    ctx->assembled = false;
+    return factor_end(ctx, stats);
+}
+int pyipm_newton_factor_panel(pyipm_newton_ctx* h, int64_t p) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    return factor_panel(ctx, p);
+}
+int pyipm_newton_trailing_update(pyipm_newton_ctx* h, int64_t p) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    if (p < 0 || p >= ctx->g.npanels) return PYIPM_E_BADARG;
+    return trailing_update(ctx, p);
+}
+
+// message = [ W rows below the panel (m x nbw, column-major, ld = m) | nbw/64 tile inverses ]
+size_t pyipm_newton_panel_msg_bytes(pyipm_newton_ctx* h, int64_t p) {
+    if (check_ctx(h)) return 0;
+    const Geo& g = C(h)->g;
+    if (p < 0 || p >= g.npanels) return 0;
+    const int64_t nbw = g.panel_w(p), m = g.Npad - (g.panel_c0(p) + nbw);
+    return (size_t)(m * nbw + (nbw / TB) * TB * TB) * sizeof(double);
+}
+
+int pyipm_newton_panel_pack(pyipm_newton_ctx* h, int64_t p, double* buf) {
+    if (check_ctx(h) || !buf) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    if (p < 0 || p >= g.npanels || g.owner(p) != g.rank) { ctx->err = "panel_pack: not the owner"; return PYIPM_E_BADARG; }
+    const int64_t nbw = g.panel_w(p), c1 = g.panel_c0(p) + nbw, m = g.Npad - c1;
+    if (m > 0)
+        PYIPM_HIP(hipMemcpy2DAsync(buf, (size_t)m * sizeof(double), ctx->Wbuf + c1, (size_t)g.Npad * sizeof(double),
+                                   (size_t)m * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
+    PYIPM_HIP(hipMemcpyAsync(buf + m * nbw, ctx->Dinv + (g.panel_c0(p) / TB) * (int64_t)(TB * TB),
+                             (size_t)(nbw / TB) * TB * TB * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return PYIPM_OK;
+}
+
+int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf) {
+    if (check_ctx(h) || !buf) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    if (p < 0 || p >= g.npanels || g.owner(p) == g.rank) { ctx->err = "panel_unpack: owner does not unpack"; return PYIPM_E_BADARG; }
+    const int64_t nbw = g.panel_w(p), c0 = g.panel_c0(p), c1 = c0 + nbw, m = g.Npad - c1;
+    double* dinv = ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB);
+    PYIPM_HIP(hipMemcpyAsync(dinv, buf + m * nbw, (size_t)(nbw / TB) * TB * TB * sizeof(double),
+                             hipMemcpyDeviceToDevice, ctx->stream));
+    if (m > 0) {
+        PYIPM_HIP(hipMemcpy2DAsync(ctx->Wbuf + c1, (size_t)g.Npad * sizeof(double), buf, (size_t)m * sizeof(double),
+                                   (size_t)m * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
+        // rebuild the block column L = W * inv(T) tile by tile into Lbuf
+        for (int t = 0; t < nbw / TB; ++t) {
+            hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(m / TB)), dim3(64), 0, ctx->stream,
+                               ctx->Lbuf, g.Npad, (int64_t)t * TB, ctx->Wbuf, g.Npad, (int64_t)t * TB,
+                               (double*)nullptr, (int64_t)0, (int64_t)0, dinv + (int64_t)t * TB * TB, c1,
+                               (unsigned long long*)nullptr);
+            PYIPM_KCHECK();
+        }
+    }
+    return PYIPM_OK;
+}
+
+int pyipm_newton_fwd_panel(pyipm_newton_ctx* h, int64_t p, double* v) {
+    if (check_ctx(h) || !v) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    if (p < 0 || p >= ctx->g.npanels || ctx->g.owner(p) != ctx->g.rank) return PYIPM_E_BADARG;
+    return fwd_panel(ctx, p, v);
+}
+int pyipm_newton_diag_panel(pyipm_newton_ctx* h, int64_t p, double* v) {
+    if (check_ctx(h) || !v) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    if (p < 0 || p >= ctx->g.npanels) return PYIPM_E_BADARG;
+    return diag_panel(ctx, p, v);
+}
+int pyipm_newton_bwd_panel(pyipm_newton_ctx* h, int64_t p, double* v) {
+    if (check_ctx(h) || !v) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    if (p < 0 || p >= ctx->g.npanels || ctx->g.owner(p) != ctx->g.rank) return PYIPM_E_BADARG;
+    return bwd_panel(ctx, p, v);
+}
+
+// ---- introspection --------------------------------------------------------------------------------
+int pyipm_newton_kkt_storage(pyipm_newton_ctx* h, double** ptr, int64_t* ld, int64_t* ncols) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    if (ptr) *ptr = ctx->A;
+    if (ld) *ld = ctx->g.Npad;
+    if (ncols) *ncols = ctx->g.ncols_local;
+    return PYIPM_OK;
+}
+
+int pyipm_newton_last_timings(pyipm_newton_ctx* h, double out[8]) {
+    if (check_ctx(h) || !out) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    PYIPM_HIP(hipStreamSynchronize(ctx->stream));          // timers are resolved lazily, never inside a step
+    if (ctx->ev_assemble_valid) { float ms = 0.f; PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->t_assemble = ms; }
+    if (ctx->ev_solve_valid) { float ms = 0.f; PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->t_solve = ms; }
+    out[0] = ctx->t_assemble; out[1] = ctx->t_panel; out[2] = ctx->t_trailing; out[3] = ctx->t_solve;
+    out[4] = (double)ctx->n_trailing; out[5] = ctx->trailing_flops; out[6] = ctx->t_factor; out[7] = 0.0;
+    return PYIPM_OK;
+}
+
+int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value) {
+    if (check_ctx(h) || !name) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
+    if (!strcmp(name, "profile")) { ctx->profile = (int)value; return PYIPM_OK; }
+    ctx->err = std::string("unknown option ") + name;
+    return PYIPM_E_BADARG;
+}
+
+int pyipm_mfma_f64_peak(int device, int iters, double* tflops) {
+    if (!tflops || iters <= 0) return PYIPM_E_BADARG;
+    if (hipSetDevice(device) != hipSuccess) return PYIPM_E_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return PYIPM_E_HIP;
+    double* d = nullptr;
+    if (hipMalloc((void**)&d, 64) != hipSuccess) return PYIPM_E_NOMEM;
+    const int blocks = prop.multiProcessorCount * 2;        // 8 waves per CU = 2 per SIMD
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, 0, d, 16);   // warm-up
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, 0, d, iters);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 4.0 /*waves*/ * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d);
+    return hipGetLastError() == hipSuccess ? PYIPM_OK : PYIPM_E_HIP;
+}
+
+}  // extern "C"

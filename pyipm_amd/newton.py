@@ -1,0 +1,300 @@
+"""ctypes binding of the C-ABI in ``include/pyipm_newton.h`` — the Newton-step core.
+
+PyTorch-ROCm is plumbing here: it owns the device memory (workspace, staged
+blocks, result vectors) and the stream; every kernel is hand-written HIP behind
+the C-ABI.  The seam replaced is ``/root/reference/pyipm.py:1717-1725``.
+
+There is NO CPU fallback: if the shared library is missing or no GPU is visible,
+constructing ``NewtonCore`` raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpyipm_newton.so")
+
+MEM_DEVICE, MEM_HOST = 0, 1
+TILE, PAD = 64, 128
+
+ERRORS = {0: "ok", -1: "bad argument / call order", -2: "HIP runtime error", -3: "workspace too small",
+          -4: "NaN/Inf met during factorisation", -5: "no usable HIP device"}
+
+
+class FactorStats(ctypes.Structure):
+    """Mirror of ``pyipm_factor_stats``: inertia from block pivots instead of the
+    reference's eigen-inertia test (pyipm.py:1378-1381)."""
+    _fields_ = [("n_neg", c_int64), ("n_zero", c_int64), ("n_2x2", c_int64), ("n_pos", c_int64),
+                ("d_min", c_double), ("d_max", c_double), ("growth", c_double), ("nonfinite", c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class NewtonError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: str | None = None):
+    """dlopen the HIP core; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    # torch bundles its own libamdhip64; it must be loaded FIRST so this library binds to the same
+    # HIP runtime (two runtimes in one process cannot share device pointers or streams).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(p):
+        raise NewtonError("HIP library %s not found — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950). There is no CPU fallback." % p)
+    lib = ctypes.CDLL(p)
+    ctxp = c_void_p
+    sig = {
+        "pyipm_newton_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int, c_int, c_int]),
+        "pyipm_newton_create": (c_int, [POINTER(c_void_p), c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int,
+                                        c_void_p, c_size_t, c_void_p]),
+        "pyipm_newton_destroy": (c_int, [ctxp]),
+        "pyipm_newton_set_stream": (c_int, [ctxp, c_void_p]),
+        "pyipm_newton_last_error": (c_char_p, [ctxp]),
+        "pyipm_newton_geometry": (c_int, [ctxp, POINTER(c_int64)]),
+        "pyipm_newton_stage_blocks": (c_int, [ctxp, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int]),
+        "pyipm_newton_stage_vectors": (c_int, [ctxp, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_double, c_double, c_int]),
+        "pyipm_newton_residual": (c_int, [ctxp, c_void_p, c_int]),
+        "pyipm_newton_assemble": (c_int, [ctxp, c_double, c_double]),
+        "pyipm_newton_factor": (c_int, [ctxp, POINTER(FactorStats)]),
+        "pyipm_newton_solve": (c_int, [ctxp, c_void_p, c_void_p, c_int, c_int, c_int]),
+        "pyipm_newton_kkt_matvec": (c_int, [ctxp, c_void_p, c_void_p, c_int]),
+        "pyipm_newton_step": (c_int, [ctxp, c_double, c_double, c_int, c_void_p, POINTER(FactorStats), c_int]),
+        "pyipm_newton_factor_panel": (c_int, [ctxp, c_int64]),
+        "pyipm_newton_panel_msg_bytes": (c_size_t, [ctxp, c_int64]),
+        "pyipm_newton_panel_pack": (c_int, [ctxp, c_int64, c_void_p]),
+        "pyipm_newton_panel_unpack": (c_int, [ctxp, c_int64, c_void_p]),
+        "pyipm_newton_trailing_update": (c_int, [ctxp, c_int64]),
+        "pyipm_newton_factor_begin": (c_int, [ctxp]),
+        "pyipm_newton_factor_end": (c_int, [ctxp, POINTER(FactorStats)]),
+        "pyipm_newton_fwd_panel": (c_int, [ctxp, c_int64, c_void_p]),
+        "pyipm_newton_diag_panel": (c_int, [ctxp, c_int64, c_void_p]),
+        "pyipm_newton_bwd_panel": (c_int, [ctxp, c_int64, c_void_p]),
+        "pyipm_newton_kkt_storage": (c_int, [ctxp, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64)]),
+        "pyipm_newton_last_timings": (c_int, [ctxp, POINTER(c_double)]),
+        "pyipm_newton_set_option": (c_int, [ctxp, c_char_p, c_double]),
+        "pyipm_mfma_f64_peak": (c_int, [c_int, c_int, POINTER(c_double)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    lib._pyipm_symbols = tuple(sig)
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def exported_symbols():
+    """Names every entry point ``include/pyipm_newton.h`` declares (used by the CPU tests)."""
+    return load_library()._pyipm_symbols
+
+
+def mfma_f64_peak(device: int = 0, iters: int = 20000) -> float:
+    """Measured fp64 MFMA peak (TFLOP/s) from a register-resident MFMA-only loop."""
+    out = c_double(0.0)
+    rc = load_library().pyipm_mfma_f64_peak(device, iters, ctypes.byref(out))
+    if rc:
+        raise NewtonError("pyipm_mfma_f64_peak failed: %s" % ERRORS.get(rc, rc))
+    return out.value
+
+
+class NewtonCore(object):
+    """One handle = one KKT system shape (n, me, mi) on one GPU (one rank of ``world``).
+
+    Typical step (the counterpart of pyipm.py:1717-1725)::
+
+        core.stage_blocks(d2L, Je, Ji)             # host-evaluated derivatives, staged once per iteration
+        core.stage_vectors(df, ce, ci, s, lda, mu)
+        g  = core.residual()                       # -grad                          (:1717)
+        core.assemble(delta, delta_c)              # hess + reghess' diagonal shifts (:1718)
+        st = core.factor()                         # block LDL' + inertia            (:1378-1381, :1720)
+        dz = core.solve(flip=True)                 # substitution + sign flip        (:1720-1725)
+    """
+
+    def __init__(self, n, me, mi, device=None, nb=256, world=1, rank=0):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise NewtonError("no HIP device visible: the Newton-step core has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        self.n, self.me, self.mi = int(n), int(me), int(mi)
+        self.N = self.n + 2 * self.mi + self.me
+        self.nb, self.world, self.rank = int(nb), int(world), int(rank)
+        need = self.lib.pyipm_newton_workspace_bytes(self.n, self.me, self.mi, self.nb, self.world, self.rank)
+        if need == 0:
+            raise NewtonError("invalid geometry n=%d me=%d mi=%d nb=%d world=%d rank=%d" % (n, me, mi, nb, world, rank))
+        with torch.cuda.device(self.device):
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            h = c_void_p()
+            rc = self.lib.pyipm_newton_create(ctypes.byref(h), self.n, self.me, self.mi, self.nb, self.device.index,
+                                              self.world, self.rank, c_void_p(self.workspace.data_ptr()), need,
+                                              c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc:
+            raise NewtonError("pyipm_newton_create failed: %s" % ERRORS.get(rc, rc))
+        self.h = h
+        geo = (c_int64 * 8)()
+        self._ck(self.lib.pyipm_newton_geometry(self.h, geo))
+        self.Npad, self.npanels, self.ncols_local = int(geo[1]), int(geo[3]), int(geo[4])
+        self._keep = {}      # staged device tensors kept alive (the library retains their pointers)
+
+    # -- helpers -----------------------------------------------------------------------------
+    def _ck(self, rc):
+        if rc:
+            msg = self.lib.pyipm_newton_last_error(self.h)
+            raise NewtonError("%s: %s" % (ERRORS.get(rc, rc), msg.decode() if msg else ""))
+
+    def _dev(self, a, shape=None):
+        """Return a contiguous fp64 device tensor for ``a`` (numpy / torch / None)."""
+        torch = self.torch
+        if a is None:
+            return None
+        if isinstance(a, torch.Tensor):
+            t = a.to(device=self.device, dtype=torch.float64)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64))).to(self.device)
+        if shape is not None:
+            t = t.reshape(shape)
+        return t.contiguous()
+
+    @staticmethod
+    def _ptr(t):
+        return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+
+    def sync_stream(self):
+        self._ck(self.lib.pyipm_newton_set_stream(
+            self.h, c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def set_option(self, name, value):
+        self._ck(self.lib.pyipm_newton_set_option(self.h, name.encode(), float(value)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pyipm_newton_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- staging -----------------------------------------------------------------------------
+    def stage_blocks(self, d2L, Je=None, Ji=None):
+        """d2L (n,n) row-major (upper triangle read), Je (n,me), Ji (n,mi)."""
+        n, me, mi = self.n, self.me, self.mi
+        d2L = self._dev(d2L, (n, n))
+        Je = self._dev(Je, (n, me)) if me else None
+        Ji = self._dev(Ji, (n, mi)) if mi else None
+        self._keep.update(d2L=d2L, Je=Je, Ji=Ji)
+        self._ck(self.lib.pyipm_newton_stage_blocks(self.h, self._ptr(d2L), n, self._ptr(Je), max(me, 1),
+                                                    self._ptr(Ji), max(mi, 1), MEM_DEVICE))
+
+    def stage_vectors(self, df, ce=None, ci=None, s=None, lda=None, mu=0.2, eps=float(np.finfo(np.float64).eps)):
+        n, me, mi = self.n, self.me, self.mi
+        df = self._dev(df, (n,))
+        ce = self._dev(ce, (me,)) if me else None
+        ci = self._dev(ci, (mi,)) if mi else None
+        s = self._dev(s, (mi,)) if mi else None
+        lda = self._dev(lda, (me + mi,)) if (me + mi) else None
+        self._ck(self.lib.pyipm_newton_stage_vectors(self.h, self._ptr(df), self._ptr(ce), self._ptr(ci),
+                                                     self._ptr(s), self._ptr(lda), float(mu), float(eps), MEM_DEVICE))
+        self.torch.cuda.current_stream(self.device).synchronize()   # library copied them; temporaries may go
+
+    # -- hot path ------------------------------------------------------------------------------
+    def residual(self):
+        g = self.torch.empty(self.N, dtype=self.torch.float64, device=self.device)
+        self._ck(self.lib.pyipm_newton_residual(self.h, self._ptr(g), MEM_DEVICE))
+        return g
+
+    def assemble(self, delta=0.0, delta_c=0.0):
+        self._ck(self.lib.pyipm_newton_assemble(self.h, float(delta), float(delta_c)))
+
+    def factor(self):
+        st = FactorStats()
+        self._ck(self.lib.pyipm_newton_factor(self.h, ctypes.byref(st)))
+        return st.as_dict()
+
+    def solve(self, rhs=None, flip=True, refine=0):
+        dz = self.torch.empty(self.N, dtype=self.torch.float64, device=self.device)
+        r = None if rhs is None else self._dev(rhs, (self.N,))
+        self._ck(self.lib.pyipm_newton_solve(self.h, self._ptr(r), self._ptr(dz), int(bool(flip)), int(refine),
+                                             MEM_DEVICE))
+        return dz
+
+    def matvec(self, v):
+        v = self._dev(v, (self.N,))
+        y = self.torch.empty(self.N, dtype=self.torch.float64, device=self.device)
+        self._ck(self.lib.pyipm_newton_kkt_matvec(self.h, self._ptr(v), self._ptr(y), MEM_DEVICE))
+        return y
+
+    def step(self, delta=0.0, delta_c=0.0, refine=0):
+        """Fused residual + assemble + factor + solve + flip."""
+        dz = self.torch.empty(self.N, dtype=self.torch.float64, device=self.device)
+        st = FactorStats()
+        self._ck(self.lib.pyipm_newton_step(self.h, float(delta), float(delta_c), int(refine), self._ptr(dz),
+                                            ctypes.byref(st), MEM_DEVICE))
+        return dz, st.as_dict()
+
+    # -- per-panel phases (used by pyipm_amd.dist) ----------------------------------------------
+    def factor_begin(self):
+        self._ck(self.lib.pyipm_newton_factor_begin(self.h))
+
+    def factor_end(self):
+        st = FactorStats()
+        self._ck(self.lib.pyipm_newton_factor_end(self.h, ctypes.byref(st)))
+        return st.as_dict()
+
+    def factor_panel(self, p):
+        self._ck(self.lib.pyipm_newton_factor_panel(self.h, int(p)))
+
+    def trailing_update(self, p):
+        self._ck(self.lib.pyipm_newton_trailing_update(self.h, int(p)))
+
+    def panel_msg_numel(self, p):
+        return int(self.lib.pyipm_newton_panel_msg_bytes(self.h, int(p))) // 8
+
+    def panel_pack(self, p, buf):
+        self._ck(self.lib.pyipm_newton_panel_pack(self.h, int(p), self._ptr(buf)))
+
+    def panel_unpack(self, p, buf):
+        self._ck(self.lib.pyipm_newton_panel_unpack(self.h, int(p), self._ptr(buf)))
+
+    def fwd_panel(self, p, v):
+        self._ck(self.lib.pyipm_newton_fwd_panel(self.h, int(p), self._ptr(v)))
+
+    def diag_panel(self, p, v):
+        self._ck(self.lib.pyipm_newton_diag_panel(self.h, int(p), self._ptr(v)))
+
+    def bwd_panel(self, p, v):
+        self._ck(self.lib.pyipm_newton_bwd_panel(self.h, int(p), self._ptr(v)))
+
+    # -- introspection ---------------------------------------------------------------------------
+    def kkt_storage(self):
+        """View of the local KKT storage as a (ncols_local, Npad) row-major tensor.  For world=1,
+        right after ``assemble`` its upper triangle is the reference's ``triu(H)`` (identity-padded)."""
+        n = self.Npad * self.ncols_local
+        return self.workspace[: n * 8].view(self.torch.float64).view(self.ncols_local, self.Npad)
+
+    def timings(self):
+        t = (c_double * 8)()
+        self._ck(self.lib.pyipm_newton_last_timings(self.h, t))
+        return {"assemble_ms": t[0], "panel_ms": t[1], "trailing_ms": t[2], "solve_ms": t[3],
+                "n_trailing": int(t[4]), "trailing_flops": t[5], "factor_ms": t[6]}

@@ -1,0 +1,58 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/pyipm_newton.h declares; the product path fails loudly without a GPU (no CPU fallback);
+nothing under pyipm_amd/ imports the oracle."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "pyipm_newton.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pyipm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pyipm_amd import newton
+    names = _header_functions()
+    assert len(names) >= 25
+    lib = ctypes.CDLL(newton.LIB_PATH)
+    for name in names:
+        assert hasattr(lib, name), "missing export: " + name
+    assert sorted(newton.exported_symbols()) == names, "ctypes binding and header disagree"
+
+
+def test_workspace_query_needs_no_gpu():
+    from pyipm_amd import newton
+    lib = newton.load_library()
+    b1 = lib.pyipm_newton_workspace_bytes(16384, 4096, 6144, 256, 1, 0)
+    assert b1 > 32768 * 32768 * 8
+    b8 = lib.pyipm_newton_workspace_bytes(16384, 4096, 6144, 256, 8, 3)
+    assert b8 < b1 / 4
+    assert lib.pyipm_newton_workspace_bytes(10, 0, 0, 96, 1, 0) == 0      # nb must be a multiple of 128
+    assert lib.pyipm_newton_workspace_bytes(10, 0, 0, 256, 2, 2) == 0     # rank out of range
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from pyipm_amd.newton import NewtonCore, NewtonError
+    with pytest.raises(NewtonError):
+        NewtonCore(3, 1, 3)
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pyipm_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "/root/reference" in txt.replace(
+                        "``/root/reference", "").replace("/root/reference/pyipm.py:", ""):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
