@@ -92,8 +92,7 @@ def sweep_invert(T, pivtol_rel=1e-14):
 
     while unswept.any():
         idx = np.flatnonzero(unswept)
-        diag = np.abs(B[idx, idx])
-        p = idx[int(np.argmax(diag))]
+        p = idx[0]                       # standard BK candidate: first unswept index (as on the device)
         app = abs(B[p, p])
         if idx.size == 1:
             sweep1(p)

@@ -56,6 +56,9 @@ struct Ctx {
     Geo g;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;           // panel lookahead stream (created on first factor)
+    hipEvent_t ev_head = nullptr, ev_panel = nullptr;
+    int lookahead = 1;
     bool own_ws = false;
     char* ws = nullptr; size_t ws_bytes = 0;
     // carved from workspace

@@ -15,27 +15,20 @@ typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
 // ---------------------------------------------------------------------------------------------
-// K3: invert one 64x64 symmetric tile in LDS by symmetric sweeps with Bunch-Kaufman 1x1 / 2x2
-// pivot selection restricted to the tile.  No row/column swaps: after sweeping a set S the
-// unswept block is the Schur complement, so pivot choice is ordinary BK on what is left; after
-// all 64 indices the working matrix is -inv(T).  Pivot search = wavefront shuffles (wave 0);
-// the rank-1/2 update is spread over 4 waves.  Inertia from pivot signs.
+// K3: invert one 64x64 symmetric tile by symmetric sweeps with Bunch-Kaufman 1x1 / 2x2 pivot
+// selection restricted to the tile.  No row/column swaps: after sweeping a set S the unswept
+// block is the Schur complement, so pivot choice is ordinary BK on what is left; after all 64
+// indices the working matrix is -inv(T).  Inertia from pivot signs.
+//
+// Layout: 256 threads; thread (lane i, wave w) keeps columns [16w,16w+16) of row i in REGISTERS.
+// Per sweep the pivot row (= pivot column, by symmetry) is broadcast through a double-buffered
+// 64-double LDS line; every wave then redundantly runs the same wavefront (DPP) reductions, so the
+// decision needs no second exchange: ONE barrier per sweep in the common 1x1 case.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_argmax(double v, int idx, double& vmax, int& imax) {
-    // larger value wins; ties -> lower index (matches numpy.argmax in the CPU model)
-    #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        double ov = __shfl_xor(v, off, 64);
-        int oi = __shfl_xor(idx, off, 64);
-        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-    }
-    vmax = v; imax = idx;
-}
-__device__ __forceinline__ double wave_max(double v) {
-    #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-    return v;
-}
+extern "C" __device__ __attribute__((const)) unsigned long long __ockl_wfred_max_u64(unsigned long long);
+extern "C" __device__ __attribute__((const)) double __ockl_wfred_max_f64(double);
+
+__device__ __forceinline__ double wave_max(double v) { return __ockl_wfred_max_f64(v); }
 
 #define PYIPM_BK_ALPHA 0.6403882032022076   /* (1+sqrt(17))/8 */
 
@@ -43,124 +36,137 @@ __global__ __launch_bounds__(256) void k_tile_invert(
     const double* __restrict__ A, int64_t ld, int64_t grow0, int64_t lcol0,
     double* __restrict__ Tinv, DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel)
 {
-    __shared__ double B[TB][TB + 1];
-    __shared__ double cp[TB], cq[TB], lp[TB], lq[TB];
-    __shared__ double sh_piv[3];           // new values of B[p][p], B[p][q], B[q][q]
-    __shared__ int sh_kind, sh_p, sh_q;
+    __shared__ double stage[TB][TB + 1];
+    __shared__ double rowbuf[2][2][TB];     // [parity][0: row p, 1: row r][column]
     __shared__ double sh_red[4];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cb = wave * 16;
 
-    // load the lower triangle and mirror it (coalesced along i)
-    double amax = 0.0;
-    for (int e = tid; e < TB * TB; e += 256) {
+    for (int e = tid; e < TB * TB; e += 256) {          // coalesced read of the lower triangle
         const int i = e & 63, j = e >> 6;
-        const double v = (i >= j) ? A[(grow0 + i) + (lcol0 + j) * ld]
-                                  : A[(grow0 + j) + (lcol0 + i) * ld];
-        B[i][j] = v;
-        amax = fmax(amax, fabs(v));
+        if (i >= j) stage[i][j] = A[(grow0 + i) + (lcol0 + j) * ld];
+    }
+    __syncthreads();
+    double row[16];
+    double amax = 0.0;
+    #pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int j = cb + c;
+        row[c] = (lane >= j) ? stage[lane][j] : stage[j][lane];
+        amax = fmax(amax, fabs(row[c]));
     }
     amax = wave_max(amax);
     if (lane == 0) sh_red[wave] = amax;
     __syncthreads();
     const double scale = fmax(fmax(sh_red[0], sh_red[1]), fmax(sh_red[2], sh_red[3]));
     const double pivtol = pivtol_rel * scale;
+    const double tiny = 2.2250738585072014e-308;
 
-    unsigned long long mask = ~0ull;       // unswept set, kept identically by every lane of wave 0
+    unsigned long long mask = ~0ull;        // unswept set (identical in every thread)
+    int left = TB, parity = 0;
     long long neg = 0, zero = 0, n2 = 0, pos = 0, bad = 0;
     double dmin = 1.0e308, dmax = 0.0;
 
-    int left = TB;                         // tracked identically by every thread
-    for (int it = 0; it < TB; ++it) {
-        if (left == 0) break;
-        if (wave == 0) {
-            const bool u = (mask >> lane) & 1ull;
-            double app; int p;
-            wave_argmax(u ? fabs(B[lane][lane]) : -1.0, lane, app, p);
-            double lam; int r;
-            wave_argmax((u && lane != p) ? fabs(B[lane][p]) : -1.0, lane, lam, r);
-            int kind = 1, piv = p, q = p;
-            if (lam > 0.0 && app < PYIPM_BK_ALPHA * lam) {
-                const double sigma = wave_max((u && lane != r) ? fabs(B[r][lane]) : -1.0);
-                const double arr = fabs(B[r][r]);
-                if (app * sigma >= PYIPM_BK_ALPHA * lam * lam) { piv = p; }
-                else if (arr >= PYIPM_BK_ALPHA * sigma)        { piv = r; }
-                else                                            { kind = 2; piv = p; q = r; }
-            }
-            if (kind == 1) {
-                double d = B[piv][piv];
-                const double ad = fabs(d);
-                const bool real = (grow0 + piv) < Nreal;
-                if (!(ad <= 1.0e308)) bad = 1;                     // NaN or Inf
-                if (ad <= pivtol) {
-                    if (real) zero++;
-                    double t = pivtol > 0.0 ? pivtol : 2.2250738585072014e-308;
-                    d = (d >= 0.0) ? t : -t;
-                } else if (real) {
-                    if (d < 0.0) neg++; else pos++;
-                    dmin = fmin(dmin, ad); dmax = fmax(dmax, ad);
-                }
-                const double c = B[lane][piv];
-                cp[lane] = c; cq[lane] = 0.0;
-                lp[lane] = c / d; lq[lane] = 0.0;
-                if (lane == 0) {
-                    sh_piv[0] = -1.0 / d; sh_piv[1] = 0.0; sh_piv[2] = 0.0;
-                    sh_kind = 1; sh_p = piv; sh_q = piv;
-                }
-                mask &= ~(1ull << piv);
-            } else {
-                const double a = B[piv][piv], b = B[piv][q], c = B[q][q];
-                double det = a * c - b * b;                        // < 0 by the BK test
-                if (!(fabs(det) <= 1.0e308)) bad = 1;
-                const double tr = a + c, disc = sqrt((a - c) * (a - c) + 4.0 * b * b);
-                const double e1 = 0.5 * (tr + disc), e2 = 0.5 * (tr - disc);
-                n2++;
-                if (fabs(e1) <= pivtol) zero++; else { if (e1 < 0.0) neg++; else pos++;
-                    dmin = fmin(dmin, fabs(e1)); dmax = fmax(dmax, fabs(e1)); }
-                if (fabs(e2) <= pivtol) zero++; else { if (e2 < 0.0) neg++; else pos++;
-                    dmin = fmin(dmin, fabs(e2)); dmax = fmax(dmax, fabs(e2)); }
-                if (det == 0.0) det = -2.2250738585072014e-308;
-                const double ia = c / det, ib = -b / det, ic = a / det;
-                const double vp = B[lane][piv], vq = B[lane][q];
-                cp[lane] = vp; cq[lane] = vq;
-                lp[lane] = vp * ia + vq * ib;
-                lq[lane] = vp * ib + vq * ic;
-                if (lane == 0) {
-                    sh_piv[0] = -ia; sh_piv[1] = -ib; sh_piv[2] = -ic;
-                    sh_kind = 2; sh_p = piv; sh_q = q;
-                }
-                mask &= ~((1ull << piv) | (1ull << q));
-            }
-        }
-        __syncthreads();
-        {
-            const int kind = sh_kind, p = sh_p, q = sh_q;
-            left -= kind;
-            const int i = lane, jb = wave * 16;
-            const double lpi = lp[i], lqi = lq[i];
+    while (left > 0) {
+        const int p = __ffsll(mask) - 1;    // BK candidate: first unswept index
+        if (lane == p) {
             #pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                const int j = jb + jj;
-                double v = B[i][j] - lpi * cp[j] - lqi * cq[j];
-                if (j == p) v = lpi;
-                if (kind == 2 && j == q) v = lqi;
-                if (i == p) v = lp[j];
-                if (kind == 2 && i == q) v = lq[j];
-                if (i == p && j == p) v = sh_piv[0];
-                if (kind == 2) {
-                    if ((i == p && j == q) || (i == q && j == p)) v = sh_piv[1];
-                    if (i == q && j == q) v = sh_piv[2];
-                }
-                B[i][j] = v;
-            }
+            for (int c = 0; c < 16; ++c) rowbuf[parity][0][cb + c] = row[c];
         }
         __syncthreads();
+        const double* rp = rowbuf[parity][0];
+        const double cpi = rp[lane];        // B[lane][p] (= B[p][lane])
+        const double dpp = rp[p];
+        const bool u = (mask >> lane) & 1ull;
+        // argmax_{i unswept, i != p} |B[i][p]| : magnitude bits (low 6 replaced by 63-lane: ties and
+        // near-ties resolve to the lower index; it only steers pivot choice)
+        unsigned long long key = 0ull;
+        if (u && lane != p)
+            key = ((unsigned long long)__double_as_longlong(fabs(cpi)) & ~63ull) | (unsigned long long)(63 - lane);
+        const unsigned long long kmax = __ockl_wfred_max_u64(key);
+        const int r = 63 - (int)(kmax & 63ull);
+        const double lam = (left > 1) ? fabs(rp[r]) : 0.0;
+        const double app = fabs(dpp);
+        int kind = 1, which = 0, piv = p;
+        if (lam > 0.0 && app < PYIPM_BK_ALPHA * lam) {          // uniform branch
+            if (lane == r) {
+                #pragma unroll
+                for (int c = 0; c < 16; ++c) rowbuf[parity][1][cb + c] = row[c];
+            }
+            __syncthreads();
+            const double* rr = rowbuf[parity][1];
+            const double sigma = wave_max((u && lane != r) ? fabs(rr[lane]) : -1.0);
+            const double arr = fabs(rr[r]);
+            if (app * sigma >= PYIPM_BK_ALPHA * lam * lam) { piv = p; }
+            else if (arr >= PYIPM_BK_ALPHA * sigma)        { piv = r; which = 1; }
+            else                                            { kind = 2; }
+        }
+        if (kind == 1) {
+            const double* rv = rowbuf[parity][which];
+            double d = rv[piv];
+            const double ci = rv[lane];
+            const double ad = fabs(d);
+            const bool real = (grow0 + piv) < Nreal;
+            if (!(ad <= 1.0e308)) bad = 1;                       // NaN or Inf
+            if (ad <= pivtol) {
+                if (real) zero++;
+                const double t = pivtol > 0.0 ? pivtol : tiny;
+                d = (d >= 0.0) ? t : -t;
+            } else if (real) {
+                if (d < 0.0) neg++; else pos++;
+                dmin = fmin(dmin, ad); dmax = fmax(dmax, ad);
+            }
+            const double inv_d = 1.0 / d;
+            const double lpi = ci * inv_d;
+            const bool isp = lane == piv;
+            #pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int j = cb + c;
+                const double cpj = rv[j];
+                double v = fma(-lpi, cpj, row[c]);
+                if (j == piv) v = lpi;
+                if (isp) v = (j == piv) ? -inv_d : cpj * inv_d;
+                row[c] = v;
+            }
+            mask &= ~(1ull << piv);
+            left -= 1;
+        } else {
+            const int q = r;
+            const double* rq = rowbuf[parity][1];
+            const double a = rp[p], b = rp[q], cc = rq[q];
+            double det = a * cc - b * b;                           // < 0 by the BK test
+            if (!(fabs(det) <= 1.0e308)) bad = 1;
+            const double tr = a + cc, disc = sqrt((a - cc) * (a - cc) + 4.0 * b * b);
+            const double e1 = 0.5 * (tr + disc), e2 = 0.5 * (tr - disc);
+            n2++;
+            if (fabs(e1) <= pivtol) zero++; else { if (e1 < 0.0) neg++; else pos++;
+                dmin = fmin(dmin, fabs(e1)); dmax = fmax(dmax, fabs(e1)); }
+            if (fabs(e2) <= pivtol) zero++; else { if (e2 < 0.0) neg++; else pos++;
+                dmin = fmin(dmin, fabs(e2)); dmax = fmax(dmax, fabs(e2)); }
+            if (det == 0.0) det = -tiny;
+            const double ia = cc / det, ib = -b / det, ic = a / det;   // inverse of [[a,b],[b,cc]]
+            const double vp = rp[lane], vq = rq[lane];
+            const double lpi = vp * ia + vq * ib, lqi = vp * ib + vq * ic;
+            const bool isp = lane == p, isq = lane == q;
+            #pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int j = cb + c;
+                const double cpj = rp[j], cqj = rq[j];
+                double v = fma(-lqi, cqj, fma(-lpi, cpj, row[c]));
+                if (j == p) v = lpi;
+                if (j == q) v = lqi;
+                if (isp) v = (j == p) ? -ia : ((j == q) ? -ib : cpj * ia + cqj * ib);
+                if (isq) v = (j == p) ? -ib : ((j == q) ? -ic : cpj * ib + cqj * ic);
+                row[c] = v;
+            }
+            mask &= ~((1ull << p) | (1ull << q));
+            left -= 2;
+        }
+        parity ^= 1;
     }
 
-    for (int e = tid; e < TB * TB; e += 256) {
-        const int i = e & 63, j = e >> 6;
-        Tinv[e] = -B[i][j];
-    }
+    #pragma unroll
+    for (int c = 0; c < 16; ++c) Tinv[(cb + c) * TB + lane] = -row[c];
     if (tid == 0) {
         st->n_neg += neg; st->n_zero += zero; st->n_2x2 += n2; st->n_pos += pos;
         st->nonfinite += bad;
@@ -171,18 +177,18 @@ __global__ __launch_bounds__(256) void k_tile_invert(
 
 // ---------------------------------------------------------------------------------------------
 // Panel scaling: for rows below a factored tile, keep the Schur-complemented block as W and
-// overwrite it with the block factor L = W * inv(T).  One wave per 64 rows; inv(T) in LDS.
+// overwrite it with the block factor L = W * inv(T).  256 threads per 64 rows: wave w produces
+// output columns [16w,16w+16); inv(T) in LDS (broadcast reads).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_panel_scale(
+__global__ __launch_bounds__(256) void k_panel_scale(
     double* __restrict__ Aout, int64_t ld_out, int64_t col_out,      // L written at Aout[i + (col_out+c)*ld_out]
     const double* __restrict__ Win, int64_t ld_in, int64_t col_in,   // S read from  Win[i + (col_in+k)*ld_in]
     double* __restrict__ Wcopy, int64_t ld_w, int64_t col_w,         // copy of S (may be NULL = no copy)
     const double* __restrict__ Tinv, int64_t row_begin, unsigned long long* __restrict__ growth_bits)
 {
     __shared__ double T[TB][TB];
-    const int lane = threadIdx.x;
-    #pragma unroll 8
-    for (int k = 0; k < TB; ++k) T[k][lane] = Tinv[k * TB + lane];   // symmetric: T[c][k] == T[k][c]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < TB * TB; e += 256) T[e >> 6][e & 63] = Tinv[e];     // symmetric
     __syncthreads();
     const int64_t i = row_begin + (int64_t)blockIdx.x * TB + lane;
     double w[TB];
@@ -190,13 +196,20 @@ __global__ __launch_bounds__(64) void k_panel_scale(
     for (int k = 0; k < TB; ++k) w[k] = Win[i + (col_in + k) * ld_in];
     if (Wcopy) {
         #pragma unroll
-        for (int k = 0; k < TB; ++k) Wcopy[i + (col_w + k) * ld_w] = w[k];
+        for (int k = 0; k < TB; ++k)
+            if ((k >> 4) == wave) Wcopy[i + (col_w + k) * ld_w] = w[k];          // wave-uniform branch
     }
     double gmax = 0.0;
-    for (int c = 0; c < TB; ++c) {
-        double acc = 0.0;
+    #pragma unroll 4
+    for (int cc = 0; cc < 16; ++cc) {
+        const int c = wave * 16 + cc;
+        double acc0 = 0.0, acc1 = 0.0;
         #pragma unroll
-        for (int k = 0; k < TB; ++k) acc = fma(w[k], T[c][k], acc);
+        for (int k = 0; k < TB; k += 2) {
+            acc0 = fma(w[k], T[c][k], acc0);
+            acc1 = fma(w[k + 1], T[c][k + 1], acc1);
+        }
+        const double acc = acc0 + acc1;
         Aout[i + (col_out + c) * ld_out] = acc;
         gmax = fmax(gmax, fabs(acc));
     }
@@ -307,7 +320,8 @@ __global__ __launch_bounds__(256, 2) void k_update(
                 C[(i0 + wi + ti * 16 + l15) + (jloc + wj + tj * 16 + l4 + 4 * r) * ldc] = acc[tj][ti][r];
 }
 
-// Register-resident MFMA-only loop for the fp64 matrix peak measurement.
+// Register-resident MFMA-only loop for the fp64 matrix peak measurement.  Inline asm keeps the
+// eight accumulators in VGPRs (the builtin form made hipcc shuttle them through AGPRs every trip).
 __global__ __launch_bounds__(256) void k_mfma_peak(double* out, int iters)
 {
     double4_t acc[8];
@@ -316,9 +330,13 @@ __global__ __launch_bounds__(256) void k_mfma_peak(double* out, int iters)
     double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
     for (int it = 0; it < iters; ++it) {
         #pragma unroll
-        for (int t = 0; t < 8; ++t)
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        for (int rep = 0; rep < 4; ++rep) {
+            #pragma unroll
+            for (int t = 0; t < 8; ++t)
+                asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[t]) : "v"(a), "v"(b));
+        }
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     double s = 0.0;
     #pragma unroll
     for (int t = 0; t < 8; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];

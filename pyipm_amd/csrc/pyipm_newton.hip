@@ -17,7 +17,7 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
     Carve cv;
     const size_t D = sizeof(double);
     const size_t oA = cv.take((size_t)g.Npad * (size_t)(g.ncols_local > 0 ? g.ncols_local : 1) * D);
-    const size_t oW = cv.take((size_t)g.Npad * g.nb * D);
+    const size_t oW = cv.take(2 * (size_t)g.Npad * g.nb * D);        // double-buffered for panel lookahead
     const size_t oL = cv.take(g.world > 1 ? (size_t)g.Npad * g.nb * D : 256);
     const size_t oD = cv.take((size_t)(g.Npad / TB) * TB * TB * D);
     const size_t orhs = cv.take((size_t)g.Npad * D);
@@ -91,30 +91,32 @@ int stage_block(Ctx* ctx, const double* src, int64_t rows, int64_t cols, int64_t
 }
 
 inline dim3 grid1(int64_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
+inline double* wbuf(Ctx* ctx, int64_t p) { return ctx->Wbuf + (p & 1) * ctx->g.Npad * (int64_t)ctx->g.nb; }
 
 // ---- per-panel building blocks -----------------------------------------------------------------
 
-int launch_update128(Ctx* ctx, const double* Lop, int64_t ldl, int K, int64_t row_begin, int64_t first_lp) {
+// Rank-K update of `n_lp` locally owned panels starting at local panel `first_lp`.
+int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ldl, const double* Wop, int K,
+                     int64_t row_begin, int64_t first_lp, int64_t n_lp) {
     const Geo& g = ctx->g;
     const int64_t m = g.Npad - row_begin;
-    if (m <= 0) return 0;
-    const int64_t local_panels = (g.ncols_local + g.nb - 1) / g.nb;
-    const int64_t ncol_tiles = (local_panels - first_lp) * (g.nb / 128);
-    if (ncol_tiles <= 0) return 0;
+    if (m <= 0 || n_lp <= 0) return 0;
+    const int64_t ncol_tiles = n_lp * (g.nb / 128);
     dim3 grid((unsigned)(m / BM), (unsigned)ncol_tiles);
-    hipLaunchKernelGGL(k_update<128>, grid, dim3(256), 0, ctx->stream, ctx->A, g.Npad, Lop, ldl,
-                       ctx->Wbuf, g.Npad, K, row_begin, g.Npad, first_lp, (int64_t)0, g.nb, g.world, g.rank);
+    hipLaunchKernelGGL(k_update<128>, grid, dim3(256), 0, stream, ctx->A, g.Npad, Lop, ldl,
+                       Wop, g.Npad, K, row_begin, g.Npad, first_lp, (int64_t)0, g.nb, g.world, g.rank);
     PYIPM_KCHECK();
     return 0;
 }
 
-int factor_panel(Ctx* ctx, int64_t p) {
+int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream) {
     const Geo& g = ctx->g;
     if (p < 0 || p >= g.npanels || g.owner(p) != g.rank) { ctx->err = "factor_panel: not the owner"; return PYIPM_E_BADARG; }
     const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
     const int nbw = (int)g.panel_w(p);
     const int nt = nbw / TB;
     const int64_t lp = p / g.world;
+    double* W = wbuf(ctx, p);
     for (int t = 0; t < nt; ++t) {
         const int64_t j0 = c0 + (int64_t)t * TB, lcol = lc0 + (int64_t)t * TB;
         if (t > 0) {
@@ -122,18 +124,18 @@ int factor_panel(Ctx* ctx, int64_t p) {
             const int64_t row_begin = (j0 / BM) * BM;
             const int64_t m = g.Npad - row_begin;
             dim3 grid((unsigned)(m / BM), 1);
-            hipLaunchKernelGGL(k_update<64>, grid, dim3(256), 0, ctx->stream, ctx->A, g.Npad,
-                               ctx->A + lc0 * g.Npad, g.Npad, ctx->Wbuf, g.Npad, t * TB, row_begin, g.Npad,
+            hipLaunchKernelGGL(k_update<64>, grid, dim3(256), 0, stream, ctx->A, g.Npad,
+                               ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, t * TB, row_begin, g.Npad,
                                lp, (int64_t)t, g.nb, g.world, g.rank);
             PYIPM_KCHECK();
         }
-        hipLaunchKernelGGL(k_tile_invert, dim3(1), dim3(256), 0, ctx->stream, ctx->A, g.Npad, j0, lcol,
+        hipLaunchKernelGGL(k_tile_invert, dim3(1), dim3(256), 0, stream, ctx->A, g.Npad, j0, lcol,
                            ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), ctx->dstats, g.N, ctx->pivtol_rel);
         PYIPM_KCHECK();
         const int64_t below = g.Npad - (j0 + TB);
         if (below > 0) {
-            hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(below / TB)), dim3(64), 0, ctx->stream,
-                               ctx->A, g.Npad, lcol, ctx->A, g.Npad, lcol, ctx->Wbuf, g.Npad, (int64_t)t * TB,
+            hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(below / TB)), dim3(256), 0, stream,
+                               ctx->A, g.Npad, lcol, ctx->A, g.Npad, lcol, W, g.Npad, (int64_t)t * TB,
                                ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), j0 + TB, &ctx->dstats->growth_bits);
             PYIPM_KCHECK();
         }
@@ -141,18 +143,16 @@ int factor_panel(Ctx* ctx, int64_t p) {
     return 0;
 }
 
-int trailing_update(Ctx* ctx, int64_t p) {
+// One k_update<128> launch covering local panels [first_lp, first_lp+n_lp) with panel p, timed.
+int timed_update(Ctx* ctx, int64_t p, int64_t first_lp, int64_t n_lp) {
     const Geo& g = ctx->g;
-    const int64_t c1 = g.panel_c0(p) + g.panel_w(p);
-    if (c1 >= g.Npad) return 0;
+    if (n_lp <= 0) return 0;
     const int nbw = (int)g.panel_w(p);
     const bool mine = g.owner(p) == g.rank;
     const double* Lop = mine ? ctx->A + g.local_c0(p) * g.Npad : ctx->Lbuf;
-    // first locally owned panel strictly after p
-    int64_t q = p + 1;
-    while (q < g.npanels && g.owner(q) != g.rank) ++q;
-    if (q >= g.npanels) return 0;
-    const int64_t first_lp = q / g.world;
+    const int64_t q0 = first_lp * g.world + g.rank;           // first global panel updated
+    const int64_t row_begin = g.panel_c0(q0);
+    if (row_begin >= g.Npad) return 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->profile) {
         if ((size_t)ctx->n_trailing >= ctx->ev_trailing.size()) {
@@ -163,20 +163,31 @@ int trailing_update(Ctx* ctx, int64_t p) {
         e0 = ctx->ev_trailing[ctx->n_trailing].first; e1 = ctx->ev_trailing[ctx->n_trailing].second;
         PYIPM_HIP(hipEventRecord(e0, ctx->stream));
     }
-    int rc = launch_update128(ctx, Lop, g.Npad, nbw, c1, first_lp);
+    int rc = launch_update128(ctx, ctx->stream, Lop, g.Npad, wbuf(ctx, p), nbw, row_begin, first_lp, n_lp);
     if (rc) return rc;
     if (ctx->profile) PYIPM_HIP(hipEventRecord(e1, ctx->stream));
-    // algorithmic flops of this launch: lower-triangular rank-nbw update of the local columns
-    {
-        double fl = 0.0;
-        for (int64_t qq = q; qq < g.npanels; qq += g.world) {
-            const double w = (double)g.panel_w(qq), r0 = (double)(g.Npad - g.panel_c0(qq));
-            fl += 2.0 * nbw * (w * r0 - 0.5 * w * (w - 1.0));
-        }
-        ctx->trailing_flops += fl;
+    // algorithmic flops of this launch: 2*nbw per lower-triangle entry of the updated local columns
+    double fl = 0.0;
+    for (int64_t k = 0; k < n_lp; ++k) {
+        const int64_t qq = (first_lp + k) * g.world + g.rank;
+        if (qq >= g.npanels) break;
+        const double w = (double)g.panel_w(qq), r0 = (double)(g.Npad - g.panel_c0(qq));
+        fl += 2.0 * nbw * (w * r0 - 0.5 * w * (w - 1.0));
     }
+    ctx->trailing_flops += fl;
     ctx->n_trailing++;
     return 0;
+}
+
+// Rank-nb update of every locally owned panel to the right of panel p.
+int trailing_update(Ctx* ctx, int64_t p) {
+    const Geo& g = ctx->g;
+    if (g.panel_c0(p) + g.panel_w(p) >= g.Npad) return 0;
+    int64_t q = p + 1;
+    while (q < g.npanels && g.owner(q) != g.rank) ++q;
+    if (q >= g.npanels) return 0;
+    const int64_t local_panels = (g.ncols_local + g.nb - 1) / g.nb;
+    return timed_update(ctx, p, q / g.world, local_panels - q / g.world);
 }
 
 int factor_begin(Ctx* ctx) {
@@ -339,15 +350,31 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
     return 0;
 }
 
+// Single-rank factorisation with one-panel lookahead: while the bulk of trailing update p runs on
+// the main stream, panel p+1 (already updated by a small head launch) is factored on a second stream.
 int factor_all(Ctx* ctx, pyipm_factor_stats* stats) {
     const Geo& g = ctx->g;
     if (g.world != 1) { ctx->err = "factor(): single-rank entry point; use the per-panel phases when world > 1"; return PYIPM_E_BADARG; }
     if (!ctx->assembled) { ctx->err = "factor: assemble first"; return PYIPM_E_BADARG; }
     int rc = factor_begin(ctx); if (rc) return rc;
+    if (!ctx->side) PYIPM_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     PYIPM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    for (int64_t p = 0; p < g.npanels; ++p) {
-        rc = factor_panel(ctx, p); if (rc) return rc;
-        rc = trailing_update(ctx, p); if (rc) return rc;
+    const int64_t np = g.npanels;
+    rc = factor_panel(ctx, 0, ctx->stream); if (rc) return rc;
+    for (int64_t p = 0; p < np; ++p) {
+        if (p + 1 >= np) break;
+        if (ctx->lookahead) {
+            rc = timed_update(ctx, p, p + 1, 1); if (rc) return rc;                  // head: panel p+1 only
+            PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
+            PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_head, 0));
+            rc = factor_panel(ctx, p + 1, ctx->side); if (rc) return rc;              // overlaps the bulk below
+            PYIPM_HIP(hipEventRecord(ctx->ev_panel, ctx->side));
+            rc = timed_update(ctx, p, p + 2, np - (p + 2)); if (rc) return rc;        // bulk
+            PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
+        } else {
+            rc = timed_update(ctx, p, p + 1, np - (p + 1)); if (rc) return rc;
+            rc = factor_panel(ctx, p + 1, ctx->stream); if (rc) return rc;
+        }
     }
     PYIPM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->assembled = false;                 // storage now holds the factor
@@ -355,7 +382,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats) {
     float ms = 0.f;
     PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->t_factor = ms;
-    ctx->t_panel = ctx->profile ? (ms - ctx->t_trailing) : 0.0;
+    ctx->t_panel = ctx->profile ? (ms - ctx->t_trailing) : 0.0;    // exposed (non-overlapped) panel time
     return rc;
 }
 
@@ -397,6 +424,8 @@ int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t m
     ctx->ws_bytes = need;
     carve_workspace(ctx, ctx->g, ctx->ws);
     for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return PYIPM_E_HIP; }
+    if (hipEventCreateWithFlags(&ctx->ev_head, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_panel, hipEventDisableTiming) != hipSuccess) { delete ctx; return PYIPM_E_HIP; }
     *out = reinterpret_cast<pyipm_newton_ctx*>(ctx);
     return PYIPM_OK;
 }
@@ -408,6 +437,9 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) {
     hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 8; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
     for (auto& pr : ctx->ev_trailing) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    if (ctx->ev_head) hipEventDestroy(ctx->ev_head);
+    if (ctx->ev_panel) hipEventDestroy(ctx->ev_panel);
+    if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
     if (ctx->stg_d2L) hipFree(ctx->stg_d2L);
     if (ctx->stg_Je) hipFree(ctx->stg_Je);
     if (ctx->stg_Ji) hipFree(ctx->stg_Ji);
@@ -573,7 +605,7 @@ int pyipm_newton_factor_end(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
 int pyipm_newton_factor_panel(pyipm_newton_ctx* h, int64_t p) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
-    return factor_panel(ctx, p);
+    return factor_panel(ctx, p, ctx->stream);
 }
 int pyipm_newton_trailing_update(pyipm_newton_ctx* h, int64_t p) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
@@ -598,7 +630,7 @@ int pyipm_newton_panel_pack(pyipm_newton_ctx* h, int64_t p, double* buf) {
     if (p < 0 || p >= g.npanels || g.owner(p) != g.rank) { ctx->err = "panel_pack: not the owner"; return PYIPM_E_BADARG; }
     const int64_t nbw = g.panel_w(p), c1 = g.panel_c0(p) + nbw, m = g.Npad - c1;
     if (m > 0)
-        PYIPM_HIP(hipMemcpy2DAsync(buf, (size_t)m * sizeof(double), ctx->Wbuf + c1, (size_t)g.Npad * sizeof(double),
+        PYIPM_HIP(hipMemcpy2DAsync(buf, (size_t)m * sizeof(double), wbuf(ctx, p) + c1, (size_t)g.Npad * sizeof(double),
                                    (size_t)m * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
     PYIPM_HIP(hipMemcpyAsync(buf + m * nbw, ctx->Dinv + (g.panel_c0(p) / TB) * (int64_t)(TB * TB),
                              (size_t)(nbw / TB) * TB * TB * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
@@ -615,12 +647,12 @@ int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf)
     PYIPM_HIP(hipMemcpyAsync(dinv, buf + m * nbw, (size_t)(nbw / TB) * TB * TB * sizeof(double),
                              hipMemcpyDeviceToDevice, ctx->stream));
     if (m > 0) {
-        PYIPM_HIP(hipMemcpy2DAsync(ctx->Wbuf + c1, (size_t)g.Npad * sizeof(double), buf, (size_t)m * sizeof(double),
+        PYIPM_HIP(hipMemcpy2DAsync(wbuf(ctx, p) + c1, (size_t)g.Npad * sizeof(double), buf, (size_t)m * sizeof(double),
                                    (size_t)m * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
         // rebuild the block column L = W * inv(T) tile by tile into Lbuf
         for (int t = 0; t < nbw / TB; ++t) {
-            hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(m / TB)), dim3(64), 0, ctx->stream,
-                               ctx->Lbuf, g.Npad, (int64_t)t * TB, ctx->Wbuf, g.Npad, (int64_t)t * TB,
+            hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(m / TB)), dim3(256), 0, ctx->stream,
+                               ctx->Lbuf, g.Npad, (int64_t)t * TB, wbuf(ctx, p), g.Npad, (int64_t)t * TB,
                                (double*)nullptr, (int64_t)0, (int64_t)0, dinv + (int64_t)t * TB * TB, c1,
                                (unsigned long long*)nullptr);
             PYIPM_KCHECK();
@@ -675,6 +707,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     Ctx* ctx = C(h);
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
     if (!strcmp(name, "profile")) { ctx->profile = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "lookahead")) { ctx->lookahead = (int)value; return PYIPM_OK; }
     ctx->err = std::string("unknown option ") + name;
     return PYIPM_E_BADARG;
 }
@@ -694,7 +727,7 @@ int pyipm_mfma_f64_peak(int device, int iters, double* tflops) {
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
-    const double flops = (double)blocks * 4.0 /*waves*/ * (double)iters * 8.0 * 2.0 * 16 * 16 * 4;
+    const double flops = (double)blocks * 4.0 /*waves*/ * (double)iters * 32.0 * 2.0 * 16 * 16 * 4;
     *tflops = flops / (ms * 1e-3) / 1e12;
     hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d);
     return hipGetLastError() == hipSuccess ? PYIPM_OK : PYIPM_E_HIP;

@@ -1,0 +1,487 @@
+"""Host-side ``IPM`` — the reference's user surface over the MI355X Newton-step core.
+
+Mirrors ``/root/reference/pyipm.py``: constructor keywords (``:311-314``),
+``solve(x0, s0, lda0, force_recompile) -> (x, s, lda, fval, kkt)`` (``:1567, 1863``),
+``signal`` codes (``:1656, 1665, 1680, 1761, 1781, 1796, 1502, 1548``) and the
+verbosity transcript (``README.md:101-122``).  The outer/inner barrier loop and the
+line search stay host Python (restated here from the algorithm the reference
+documents: ``:1597-1628`` init, ``:1408-1436`` fraction-to-boundary, ``:1438-1565``
+backtracking search, ``:1727-1735`` merit parameter, ``:1804-1814`` barrier update,
+``:958-991`` KKT report); the per-iteration Newton step ``:1717-1725`` is delegated
+to a *Newton backend* — the HIP core (``pyipm_amd.newton``).  There is no CPU
+implementation of that backend in the product: without the HIP library and a GPU
+the constructor of the default backend raises.
+
+Inputs.  Aesara is not required: ``f, df, d2f, ce, dce, d2ce, ci, dci, d2ci`` are
+plain callables over NumPy arrays with the signatures of the reference's
+"precompiled" functions (``:85-146, 512-562``):
+``f(x)``, ``df(x)``, ``d2f(x)``, ``ce(x)``, ``dce(x)->(n,me)``, ``d2ce(x,lda)``,
+``ci(x)``, ``dci(x)->(n,mi)``, ``d2ci(x,lda)``.  All derivatives must be supplied
+(no autodiff); L-BFGS (``lbfgs=``) is out of scope for this hot path and rejected.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class HipNewtonBackend(object):
+    """Newton backend on the HIP core: the counterpart of ``reghess`` + ``sym_solve_cmp``
+    (pyipm.py:1373-1406, 1717-1725).  Inertia comes from the block pivots of the
+    factorisation instead of ``eigvalsh``; the "rcond <= eps" trigger of the reference
+    (:1379-1381) is replaced by "a pivot was rejected or d_min/d_max <= eps"."""
+
+    def __init__(self, n, me, mi, device=None, nb=256, refine=0, max_shift_tries=60):
+        from .newton import NewtonCore
+        self.core = NewtonCore(n, me, mi, device=device, nb=nb)
+        self.n, self.me, self.mi = n, me, mi
+        self.refine = refine
+        self.max_shift_tries = max_shift_tries
+        self.n_factor = 0
+
+    def direction(self, d2L, Je, Ji, df, ce, ci, s, lda, mu, delta, mu_host, eta, beta, reg_coef, delta0, eps):
+        core, need = self.core, self.me + self.mi
+        core.stage_blocks(d2L, Je, Ji)
+        core.stage_vectors(df, ce, ci, s, lda, mu=mu, eps=eps)
+        core.residual()
+        core.assemble(0.0, 0.0)
+        st = core.factor()
+        self.n_factor += 1
+        singular = st["n_zero"] > 0 or (st["d_max"] > 0 and st["d_min"] / st["d_max"] <= eps)
+        if singular or st["n_neg"] != need:
+            delta_c = reg_coef * eta * (mu_host ** beta) if (singular and self.me) else 0.0
+            delta = delta0 if delta == 0.0 else max(delta / 2.0, delta0)
+            tries = 0
+            while True:
+                core.assemble(delta, delta_c)
+                st = core.factor()
+                self.n_factor += 1
+                if st["n_neg"] == need:
+                    break
+                tries += 1
+                if tries > self.max_shift_tries:
+                    raise RuntimeError("inertia not corrected after %d diagonal shifts" % tries)
+                delta *= 10.0
+        dz = core.solve(flip=True, refine=self.refine).cpu().numpy()
+        return dz, float(delta), st
+
+
+class IPM(object):
+    """Line-search primal-dual interior-point solver; see module docstring."""
+
+    def __init__(self, x0=None, x_dev=None, f=None, df=None, d2f=None, ce=None, dce=None, d2ce=None, ci=None,
+                 dci=None, d2ci=None, lda0=None, lambda_dev=None, s0=None, mu=0.2, nu=10.0, rho=0.1, tau=0.995,
+                 eta=1.0E-4, beta=0.4, miter=20, niter=10, Xtol=None, Ktol=1.0E-4, Ftol=None, lbfgs=False,
+                 lbfgs_zeta=None, float_dtype=np.float64, verbosity=1, backend=None, device=None, nb=256, refine=0):
+        self.x0, self.s0, self.lda0 = x0, s0, lda0
+        self.x_dev, self.lambda_dev = x_dev, lambda_dev        # accepted for signature parity; unused
+        self.f, self.df, self.d2f = f, df, d2f
+        self.ce, self.dce, self.d2ce = ce, dce, d2ce
+        self.ci, self.dci, self.d2ci = ci, dci, d2ci
+        self.nvar = self.neq = self.nineq = None
+        self.float_dtype = float_dtype
+        self.eps = float(np.finfo(float_dtype).eps)
+        self.mu, self.nu, self.rho, self.tau, self.eta, self.beta = mu, nu, rho, tau, eta, beta
+        self.miter, self.niter = miter, niter
+        self.Xtol = Xtol if Xtol else self.eps
+        self.Ktol, self.Ftol = Ktol, Ftol
+        self.reg_coef = float(np.sqrt(self.eps))
+        self.delta0 = self.reg_coef
+        self.lbfgs, self.lbfgs_zeta = lbfgs, lbfgs_zeta
+        self.verbosity = verbosity
+        self.backend = backend
+        self._backend_opts = dict(device=device, nb=nb, refine=refine)
+        self.compiled = False
+        self.signal = 0
+
+    # ------------------------------------------------------------------ setup
+    def validate(self):
+        assert self.f is not None
+        assert (self.ce is not None) or (self.dce is None and self.d2ce is None)
+        assert (self.ci is not None) or (self.dci is None and self.d2ci is None)
+        assert self.mu > 0.0 and self.nu > 0.0
+        assert 0.0 < self.eta < 1.0 and 0.0 < self.rho < 1.0 and 0.0 < self.tau < 1.0
+        assert self.beta < 1.0
+        assert isinstance(self.miter, int) and self.miter >= 0
+        assert isinstance(self.niter, int) and self.niter >= 0
+        assert self.Xtol >= self.eps and self.Ktol >= self.eps
+        assert self.Ftol is None or self.Ftol >= 0.0
+        if self.lbfgs:
+            raise NotImplementedError("L-BFGS direction is outside the accelerated hot path (SURVEY.md section 8f)")
+        if self.float_dtype != np.float64:
+            raise NotImplementedError("the Newton-step core computes in fp64 only")
+        for name in ("df", "d2f"):
+            if getattr(self, name) is None:
+                raise ValueError("%s must be supplied as a callable (no autodiff without Aesara)" % name)
+        if self.ce is not None and (self.dce is None or self.d2ce is None):
+            raise ValueError("dce and d2ce must be supplied with ce")
+        if self.ci is not None and (self.dci is None or self.d2ci is None):
+            raise ValueError("dci and d2ci must be supplied with ci")
+
+    def compile(self, nvar=None, neq=None, nineq=None):
+        """Infer constraint counts (pyipm.py:443-467) and bind the Newton backend."""
+        if nvar is not None:
+            self.nvar = nvar
+        x0 = np.asarray(self.x0, dtype=np.float64)
+        self.neq = int(np.size(self.ce(x0))) if (self.ce is not None and neq is None) else int(neq or 0)
+        self.nineq = int(np.size(self.ci(x0))) if (self.ci is not None and nineq is None) else int(nineq or 0)
+        if self.backend is None:
+            self.backend = HipNewtonBackend(self.nvar, self.neq, self.nineq, **self._backend_opts)
+        self.compiled = True
+
+    # ------------------------------------------------------------------ model pieces (host, O(n m))
+    def _con(self, x, s):
+        parts = []
+        if self.neq:
+            parts.append(np.asarray(self.ce(x), dtype=np.float64).reshape(self.neq))
+        if self.nineq:
+            parts.append(np.asarray(self.ci(x), dtype=np.float64).reshape(self.nineq) - s)
+        return np.concatenate(parts) if parts else np.zeros(0)
+
+    def _jac_x(self, x):
+        cols = []
+        if self.neq:
+            cols.append(np.asarray(self.dce(x), dtype=np.float64).reshape(self.nvar, self.neq))
+        if self.nineq:
+            cols.append(np.asarray(self.dci(x), dtype=np.float64).reshape(self.nvar, self.nineq))
+        return np.concatenate(cols, axis=1)
+
+    def _jaco(self, x):
+        """(n+mi) x (me+mi) composite Jacobian [[Je, Ji],[0, -I]] (pyipm.py:582-607)."""
+        top = self._jac_x(x)
+        if not self.nineq:
+            return top
+        bottom = np.concatenate([np.zeros((self.nineq, self.neq)), -np.eye(self.nineq)], axis=1)
+        return np.concatenate([top, bottom], axis=0)
+
+    def grad(self, x, s, lda):
+        """KKT residual on the host (same formula as K2; used by the KKT report and convergence tests)."""
+        n, me, mi = self.nvar, self.neq, self.nineq
+        gx = np.array(self.df(x), dtype=np.float64).reshape(n)
+        out = [None]
+        if me:
+            gx = gx - np.asarray(self.dce(x), dtype=np.float64).reshape(n, me) @ lda[:me]
+        if mi:
+            gx = gx - np.asarray(self.dci(x), dtype=np.float64).reshape(n, mi) @ lda[me:]
+            out.append(lda[me:] - self.mu_host_dev / (s + self.eps))
+        out[0] = gx
+        if me:
+            out.append(np.asarray(self.ce(x), dtype=np.float64).reshape(me))
+        if mi:
+            out.append(np.asarray(self.ci(x), dtype=np.float64).reshape(mi) - s)
+        return np.concatenate(out)
+
+    def KKT(self, x, s, lda):
+        """First-order conditions split in four blocks, slack block scaled by s (pyipm.py:958-991)."""
+        n, me, mi = self.nvar, self.neq, self.nineq
+        k = self.grad(x, s, lda)
+        zero = np.float64(0.0)
+        k1 = k[:n]
+        k2 = k[n:n + mi] * s if mi else zero
+        k3 = k[n + mi:n + mi + me] if me else zero
+        k4 = k[n + mi + me:] if mi else zero
+        return k1, k2, k3, k4
+
+    def phi(self, x, s):
+        v = float(self.f(x))
+        if self.neq:
+            v += self.nu_host * np.sum(np.abs(self.ce(x)))
+        if self.nineq:
+            v += self.nu_host * np.sum(np.abs(np.asarray(self.ci(x)).reshape(self.nineq) - s))
+            v -= self.mu_host_dev * np.sum(np.log(s))
+        return v
+
+    def dphi(self, x, s, dz):
+        n = self.nvar
+        v = float(np.dot(np.asarray(self.df(x)).reshape(n), dz[:n]))
+        if self.neq:
+            v -= self.nu_host * np.sum(np.abs(self.ce(x)))
+        if self.nineq:
+            v -= self.nu_host * np.sum(np.abs(np.asarray(self.ci(x)).reshape(self.nineq) - s))
+            v -= float(np.dot(self.mu_host_dev / (s + self.eps), dz[n:]))
+        return v
+
+    # ------------------------------------------------------------------ line-search pieces
+    def step(self, x, dx):
+        """Fraction-to-the-boundary step by golden-section search on [0,1] (pyipm.py:1408-1436)."""
+        gold = (np.sqrt(5.0) + 1.0) / 2.0
+        floor = (1.0 - self.tau) * x
+
+        def feasible(alpha):
+            return bool(np.all(x + alpha * dx >= floor))
+
+        lo, hi = 0.0, 1.0
+        if feasible(hi):
+            return hi
+        c = hi - (hi - lo) / gold
+        d = lo + (hi - lo) / gold
+        while abs(hi - lo) > gold * self.Xtol:
+            if feasible(d):
+                lo = d
+            else:
+                hi = d
+            if c > lo:
+                if feasible(c):
+                    lo = c
+                else:
+                    hi = c
+            c = hi - (hi - lo) / gold
+            d = lo + (hi - lo) / gold
+        return lo
+
+    def _restoration(self, x0, c_new):
+        """Feasibility-restoration direction of the second-order correction (pyipm.py:1466-1477,
+        1518-1529): a square solve when the Jacobian happens to be square, otherwise (the usual
+        case) the minimum-norm least-squares solution."""
+        A = self._jaco(x0).T
+        if A.shape[0] == A.shape[1]:
+            try:
+                import scipy.linalg
+                return -scipy.linalg.solve(A, c_new.reshape(-1, 1)).reshape(-1)
+            except Exception:
+                pass
+        return -np.linalg.lstsq(A, c_new, rcond=None)[0]
+
+    def search(self, x0, s0, lda0, dz, alpha_smax, alpha_lmax):
+        """Backtracking Armijo search on the merit function with an optional second-order
+        feasibility correction (pyipm.py:1438-1565)."""
+        n, me, mi = self.nvar, self.neq, self.nineq
+        dx = dz[:n]
+        ds = dz[n:n + mi] if mi else np.zeros(0)
+        if me or mi:
+            dl = dz[n + mi:]
+        else:
+            dl, alpha_lmax = 0.0, 0.0
+        phi0 = self.phi(x0, s0)
+        dphi0 = self.dphi(x0, s0, dz[:n + mi])
+        armijo = lambda a: phi0 + a * self.eta * dphi0    # noqa: E731
+        corrected, alpha_corr, dz_p = False, 1.0, None
+
+        def trial(a):
+            return self.phi(x0 + a * dx, s0 + a * ds) if mi else self.phi(x0 + a * dx, s0)
+
+        if trial(alpha_smax) > armijo(alpha_smax):
+            if me or mi:
+                c_old = self._con(x0, s0)
+                c_new = self._con(x0 + alpha_smax * dx, s0 + alpha_smax * ds if mi else s0)
+                if np.sum(np.abs(c_new)) > np.sum(np.abs(c_old)):
+                    dz_p = self._restoration(x0, c_new)
+                    if mi:
+                        xs = x0 + alpha_smax * dx + dz_p[:n]
+                        ss = s0 + alpha_smax * ds + dz_p[n:]
+                        if self.phi(xs, ss) <= armijo(alpha_smax):
+                            alpha_corr = self.step(s0, alpha_smax * ds + dz_p[n:])
+                            if (self.phi(x0 + alpha_corr * (alpha_smax * dx + dz_p[:n]),
+                                         s0 + alpha_corr * (alpha_smax * ds + dz_p[n:])) <= armijo(alpha_smax)):
+                                corrected = True
+                    else:
+                        if self.phi(x0 + alpha_smax * dx + dz_p[:n], s0) <= armijo(alpha_smax):
+                            alpha_corr, corrected = 1.0, True
+                    if corrected and self.verbosity > 2:
+                        print('Second-order feasibility correction accepted')
+            if not corrected:
+                alpha_smax *= self.tau
+                alpha_lmax *= self.tau
+                while trial(alpha_smax) > armijo(alpha_smax):
+                    size = np.linalg.norm(alpha_smax * dx)
+                    if mi:
+                        size = np.sqrt(size ** 2 + np.linalg.norm(alpha_lmax * ds) ** 2)
+                    if size < self.eps:
+                        if self.verbosity > 2:
+                            print('Search direction is unreliable to machine precision.')
+                        self.signal = -2
+                        return x0, s0, lda0
+                    alpha_smax *= self.tau
+                    alpha_lmax *= self.tau
+        if corrected:
+            x = x0 + alpha_corr * (alpha_smax * dx + dz_p[:n])
+            s = s0 + alpha_corr * (alpha_smax * ds + dz_p[n:]) if mi else np.copy(s0)
+        else:
+            x = x0 + alpha_smax * dx
+            s = s0 + alpha_smax * ds if mi else np.copy(s0)
+        lda = lda0 + alpha_lmax * dl if (me or mi) else np.copy(lda0)
+        return x, s, lda
+
+    # ------------------------------------------------------------------ the Newton step (hot path)
+    def newton_direction(self, x, s, lda):
+        """Counterpart of pyipm.py:1717-1725: host evaluates the derivative blocks, the backend
+        assembles / regularises / factors / solves on the device and returns dz (sign-flipped)."""
+        n, me, mi = self.nvar, self.neq, self.nineq
+        d2L = np.array(self.d2f(x), dtype=np.float64).reshape(n, n)
+        Je = Ji = ce = ci = None
+        if me:
+            d2L = d2L - np.asarray(self.d2ce(x, lda), dtype=np.float64).reshape(n, n)
+            Je = np.asarray(self.dce(x), dtype=np.float64).reshape(n, me)
+            ce = np.asarray(self.ce(x), dtype=np.float64).reshape(me)
+        if mi:
+            d2L = d2L - np.asarray(self.d2ci(x, lda), dtype=np.float64).reshape(n, n)
+            Ji = np.asarray(self.dci(x), dtype=np.float64).reshape(n, mi)
+            ci = np.asarray(self.ci(x), dtype=np.float64).reshape(mi)
+        df = np.asarray(self.df(x), dtype=np.float64).reshape(n)
+        dz, self.delta, self.last_stats = self.backend.direction(
+            d2L, Je, Ji, df, ce, ci, s, lda, self.mu_host_dev, self.delta, self.mu_host, self.eta, self.beta,
+            self.reg_coef, self.delta0, self.eps)
+        return dz
+
+    # ------------------------------------------------------------------ driver
+    def _kkt_small(self, kkt, tol):
+        return all(np.linalg.norm(k) <= tol for k in kkt)
+
+    def solve(self, x0=None, s0=None, lda0=None, force_recompile=False):
+        if x0 is not None:
+            self.x0 = x0
+        if s0 is not None:
+            self.s0 = s0
+        if lda0 is not None:
+            self.lda0 = lda0
+        assert self.x0 is not None and np.size(self.x0) > 0
+        self.x0 = np.asarray(self.x0, dtype=np.float64)
+        assert self.x0.ndim == 1
+        self.nvar = self.x0.size
+        self.validate()
+        if not self.compiled or force_recompile:
+            self.compile()
+        n, me, mi = self.nvar, self.neq, self.nineq
+
+        # initial point (pyipm.py:1597-1625)
+        x = self.x0
+        if mi:
+            s = (np.maximum(np.asarray(self.ci(x), dtype=np.float64).reshape(mi), self.Ktol)
+                 if self.s0 is None else np.asarray(self.s0, dtype=np.float64))
+            self.mu_host = self.mu
+            self.mu_host_dev = self.mu            # value of the reference's shared mu_dev
+        else:
+            s = np.zeros(0)
+            self.mu_host = self.Ktol
+            self.mu_host_dev = self.Ktol
+        self.nu_host = self.nu
+        if me or mi:
+            if self.lda0 is None:
+                lda = (np.linalg.pinv(self._jac_x(x)) @ np.asarray(self.df(x), dtype=np.float64).reshape(n, 1)
+                       ).reshape(me + mi)
+                if mi:
+                    li = lda[me:]
+                    li[li < 0.0] = self.Ktol
+            else:
+                lda = np.asarray(self.lda0, dtype=np.float64).copy()
+        else:
+            lda = np.zeros(0)
+        self.delta = 0.0
+        kkt = self.KKT(x, s, lda)
+
+        if self.verbosity > 0:
+            print('Searching for a feasible local minimizer using the exact Hessian.')
+        iter_count = 0
+        f_past = float(self.f(x)) if self.Ftol is not None else None
+        Ftol_converged = False
+        self.signal = 0
+        outer = inner = 0
+
+        for outer in range(self.niter):
+            if self._kkt_small(kkt, self.Ktol):
+                self.signal = 1
+                break
+            if self.verbosity > 0 and mi:
+                print('OUTER ITERATION {}'.format(outer + 1))
+            for inner in range(self.miter):
+                if self._kkt_small(kkt, max(self.Ktol, self.mu_host)):
+                    if not me and not mi:
+                        self.signal = 1
+                    break
+                if self.verbosity > 0:
+                    msg = ['* INNER ITERATION {}'.format(inner + 1) if mi else 'ITERATION {}'.format(iter_count + 1)]
+                    if self.verbosity > 1:
+                        msg.append('f(x) = {}'.format(self.f(x)))
+                    if self.verbosity > 2:
+                        msg.append('|dL/dx| = {}'.format(np.linalg.norm(kkt[0])))
+                        msg.append('|dL/ds| = {}'.format(np.linalg.norm(kkt[1])))
+                        msg.append('|ce| = {}'.format(np.linalg.norm(kkt[2])))
+                        msg.append('|ci-s| = {}'.format(np.linalg.norm(kkt[3])))
+                    print(', '.join(msg))
+
+                dz = self.newton_direction(x, s, lda)            # <-- the accelerated hot path
+
+                if me or mi:                                      # merit parameter (pyipm.py:1727-1735)
+                    bcg = np.asarray(self.df(x), dtype=np.float64).reshape(n)
+                    if mi:
+                        bcg = np.concatenate([bcg, -self.mu_host_dev / (s + self.eps)])
+                    with np.errstate(divide='ignore', invalid='ignore'):
+                        nu_thres = np.dot(bcg, dz[:n + mi]) / (1 - self.rho) / np.sum(np.abs(self._con(x, s)))
+                    if self.nu_host < nu_thres:
+                        self.nu_host = float(nu_thres)
+                if mi:
+                    a_s = self.step(s, dz[n:n + mi])
+                    a_l = self.step(lda[me:], dz[n + mi + me:])
+                    x, s, lda = self.search(x, s, lda, dz, float(a_s), float(a_l))
+                else:
+                    x, s, lda = self.search(x, s, lda, dz, 1.0, 1.0)
+                iter_count += 1
+                kkt = self.KKT(x, s, lda)
+
+                if self.Ftol is not None and not mi and self.signal != -2:
+                    f_new = float(self.f(x))
+                    if abs(f_past - f_new) <= abs(self.Ftol):
+                        self.signal = 2
+                        Ftol_converged = True
+                        break
+                    f_past = f_new
+                if self.signal == -2:
+                    break
+                if inner >= self.miter - 1 and self.verbosity > 0 and mi:
+                    print('MAXIMUM INNER ITERATIONS EXCEEDED')
+
+            if self.Ftol is not None and mi and self.signal != -2:
+                f_new = float(self.f(x))
+                if abs(f_past - f_new) <= abs(self.Ftol):
+                    self.signal = 2
+                    Ftol_converged = True
+                else:
+                    f_past = f_new
+            if Ftol_converged or self.signal == -2:
+                break
+            if outer >= self.niter - 1:
+                self.signal = -1
+                if self.verbosity > 0:
+                    print('MAXIMUM OUTER ITERATIONS EXCEEDED' if mi else 'MAXIMUM ITERATIONS EXCEEDED')
+                break
+            if mi:                                                # barrier update (pyipm.py:1804-1814)
+                comp = float(np.dot(s, lda[me:]))
+                xi = mi * np.min(s * lda[me:]) / (comp + self.eps)
+                mu_new = 0.1 * min(0.05 * (1.0 - xi) / (xi + self.eps), 2.0) ** 3 * comp / mi
+                self.mu_host = max(float(mu_new), 0.0)
+                self.mu_host_dev = self.mu_host
+
+        self.x, self.s, self.lda, self.kkt = x, s, lda, kkt
+        self.fval = self.f(x)
+        self.iter_count = iter_count
+        if self.verbosity >= 0:
+            self._report(kkt, Ftol_converged, outer, inner, iter_count)
+        return self.x, self.s, self.lda, self.fval, self.kkt
+
+    def _report(self, kkt, Ftol_converged, outer, inner, iter_count):
+        mi = self.nineq
+        words = []
+        if self.signal == -2:
+            words.append('Terminated due to bad direction in backtracking line search')
+        elif self._kkt_small(kkt, self.Ktol):
+            words.append('Converged to Ktol tolerance')
+        elif self.Ftol is not None and Ftol_converged:
+            words.append('Converged to Ftol tolerance')
+        else:
+            words.append('Maximum iterations reached')
+            outer, inner = self.niter, 0
+        if mi:
+            if outer > 1:
+                words += ['after {} outer'.format(outer - 1), 'iterations' if outer > 2 else 'iteration', 'and']
+            else:
+                words.append('after')
+            words += ['{} inner'.format(inner), 'iterations' if inner > 1 else 'iteration',
+                      '({} total).'.format(iter_count)]
+        else:
+            words += ['after {}'.format(iter_count), 'iterations.' if iter_count > 1 else 'iteration.']
+        print(' '.join(words))
+        if self.verbosity > 1:
+            msg = ['FINAL: f(x) = {}'.format(self.f(self.x))]
+            if self.verbosity > 2:
+                msg += ['|dL/dx| = {}'.format(np.linalg.norm(kkt[0])), '|dL/ds| = {}'.format(np.linalg.norm(kkt[1])),
+                        '|ce| = {}'.format(np.linalg.norm(kkt[2])), '|ci-s| = {}'.format(np.linalg.norm(kkt[3]))]
+            print(', '.join(msg))

@@ -1,0 +1,80 @@
+"""CPU tests of the host IPM loop (pyipm_amd/ipm.py) with the oracle standing in for the HIP
+Newton backend: the restated loop must retrace the unmodified reference iteration by iteration
+(tests/golden/trace_pXX.npz), reach its ground truths (unit_tests.py:51,405-415) and print the
+README transcript shape (README.md:101-122)."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+from pyipm_amd.ipm import IPM
+from pyipm_amd.problems import example_problem, unit_test_x0
+from backends import OracleBackend
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def make_ipm(k, backend, **kw):
+    p = example_problem(k)
+    return IPM(x0=unit_test_x0()[k], f=p["f"], df=p["df"], d2f=p["d2f"], ce=p["ce"], dce=p["dce"], d2ce=p["d2ce"],
+               ci=p["ci"], dci=p["dci"], d2ci=p["d2ci"], backend=backend, **kw)
+
+
+@pytest.mark.parametrize("k", range(1, 11))
+def test_host_loop_retraces_reference(k):
+    d = np.load(os.path.join(GOLD, "trace_p%02d.npz" % k))
+    prob = example_problem(k)
+    be = OracleBackend(prob["nvar"], prob["neq"], prob["nineq"])
+    ipm = make_ipm(k, be, Ftol=1.0e-8, verbosity=-1)
+    x, s, lda, fval, kkt = ipm.solve()
+    assert ipm.signal == int(d["signal"])
+    assert len(be.calls) == int(d["n_iter"]) == ipm.iter_count
+    for it, c in enumerate(be.calls):
+        np.testing.assert_allclose(c["Hc"], d["it_Hc"][it], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(c["g"], d["it_g"][it], rtol=1e-8, atol=1e-11)
+        np.testing.assert_allclose(c["dz"], d["it_dz"][it], rtol=1e-6, atol=1e-10)
+        assert np.isclose(c["delta"], d["it_delta_out"][it], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(x, d["x"], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(s, d["s"], rtol=1e-7, atol=1e-10)
+    np.testing.assert_allclose(lda, d["lda"], rtol=1e-6, atol=1e-9)
+    assert np.isclose(float(fval), float(d["fval"]), rtol=1e-9, atol=1e-12)
+    assert min(np.linalg.norm(x - gt) for gt in prob["ground_truth"]) <= 1e-3
+    for i in range(4):
+        np.testing.assert_allclose(np.atleast_1d(kkt[i]), d["kkt%d" % (i + 1)], rtol=1e-4, atol=1e-9)
+
+
+def test_problem7_transcript_matches_reference():
+    ref = str(np.load(os.path.join(GOLD, "transcript_p07.npz"))["transcript"])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        make_ipm(7, OracleBackend(3, 1, 3), Ftol=1.0e-8, verbosity=1).solve()
+    assert buf.getvalue() == ref
+
+
+def test_step_fraction_to_boundary():
+    ipm = make_ipm(5, OracleBackend(2, 0, 3), verbosity=-1)
+    x = np.array([1.0, 2.0, 0.5])
+    assert ipm.step(x, np.array([0.1, -0.2, 1.0])) == 1.0
+    dx = np.array([-4.0, -1.0, 0.3])
+    a = ipm.step(x, dx)
+    exact = min(ipm.tau * x[i] / -dx[i] for i in range(3) if dx[i] < 0)
+    assert 0 < a <= exact and exact - a < 1e-12
+
+
+def test_validation_errors():
+    p = example_problem(5)
+    with pytest.raises(ValueError):
+        IPM(x0=np.zeros(2), f=p["f"], df=p["df"], d2f=p["d2f"], ci=p["ci"], verbosity=-1).solve()
+    with pytest.raises(NotImplementedError):
+        IPM(x0=np.zeros(2), f=p["f"], df=p["df"], d2f=p["d2f"], lbfgs=4, verbosity=-1).solve()
+    with pytest.raises(AssertionError):
+        IPM(x0=np.zeros(2), f=p["f"], df=p["df"], d2f=p["d2f"], mu=-1.0, verbosity=-1).solve()
+
+
+def test_max_iterations_signal():
+    be = OracleBackend(2, 0, 0)
+    ipm = make_ipm(2, be, niter=1, miter=2, verbosity=-1)      # Rosenbrock cannot finish in 2 steps
+    ipm.solve()
+    assert ipm.signal == -1 and len(be.calls) == 2
