@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--refine", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also report the backward error of the last step")
+    ap.add_argument("--opt", action="append", default=[], help="core option name=value (e.g. xcd_swizzle=0, lookahead=0)")
     args = ap.parse_args()
 
     import torch
@@ -130,6 +131,9 @@ def main():
     core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
     core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
     core.set_option("profile", 1)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        core.set_option(k, float(v))
 
     if world > 1:
         from pyipm_amd.dist import DistNewton

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -30,6 +31,17 @@ struct Geo {
     __host__ __device__ int owner(int64_t p) const { return (int)(p % world); }
     __host__ __device__ int64_t local_c0(int64_t p) const { return (p / world) * (int64_t)nb; }
 };
+
+// Panels aggregated per bulk trailing update (K = group * nb).  Grouping needs the group's panels on
+// one rank, so it applies to single-rank handles; PYIPM_NEWTON_GROUP overrides (read at create time).
+inline int default_group(int world) {
+    if (world > 1) return 1;
+    const char* e = getenv("PYIPM_NEWTON_GROUP");
+    int g = e ? atoi(e) : 4;
+    if (g < 1) g = 1;
+    if (g > 8) g = 8;
+    return g;
+}
 
 inline Geo make_geo(int64_t n, int64_t me, int64_t mi, int nb, int world, int rank) {
     Geo g;
@@ -59,6 +71,12 @@ struct Ctx {
     hipStream_t side = nullptr;           // panel lookahead stream (created on first factor)
     hipEvent_t ev_head = nullptr, ev_panel = nullptr;
     int lookahead = 1;
+    int group = 1;                        // panels per bulk trailing update
+    int xcd_swizzle = 1;
+    int extra_lds = 0;                    // diagnostics: extra dynamic LDS per update block
+    unsigned long long* dbg_buf = nullptr;   // diagnostics only
+    int stagger_mode = 1;                 // 0 off, 1 by dispatch index, 2 by hardware wave slot
+    double stagger_us_per_k = 0.11;       // delay = this * K microseconds (~ half a tile period)
     bool own_ws = false;
     char* ws = nullptr; size_t ws_bytes = 0;
     // carved from workspace

@@ -11,6 +11,9 @@
 
 namespace pyipm {
 
+#ifndef PYIPM_ABLATE
+#define PYIPM_ABLATE 0   /* diagnostic builds only: 1 no C load, 2 no C store, 4 no in-loop global loads, 8 no LDS fragment reads */
+#endif
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
@@ -184,11 +187,13 @@ __global__ __launch_bounds__(256) void k_panel_scale(
     double* __restrict__ Aout, int64_t ld_out, int64_t col_out,      // L written at Aout[i + (col_out+c)*ld_out]
     const double* __restrict__ Win, int64_t ld_in, int64_t col_in,   // S read from  Win[i + (col_in+k)*ld_in]
     double* __restrict__ Wcopy, int64_t ld_w, int64_t col_w,         // copy of S (may be NULL = no copy)
-    const double* __restrict__ Tinv, int64_t row_begin, unsigned long long* __restrict__ growth_bits)
+    const double* __restrict__ Tinv, int64_t row_begin, unsigned long long* __restrict__ growth_bits,
+    double sign)      // owner: Win = S, Wcopy = -S (the update kernel wants -W), sign = +1;
+                      // non-owner rebuilding L from a received -S: sign = -1
 {
     __shared__ double T[TB][TB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int e = tid; e < TB * TB; e += 256) T[e >> 6][e & 63] = Tinv[e];     // symmetric
+    for (int e = tid; e < TB * TB; e += 256) T[e >> 6][e & 63] = sign * Tinv[e];     // symmetric
     __syncthreads();
     const int64_t i = row_begin + (int64_t)blockIdx.x * TB + lane;
     double w[TB];
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void k_panel_scale(
     if (Wcopy) {
         #pragma unroll
         for (int k = 0; k < TB; ++k)
-            if ((k >> 4) == wave) Wcopy[i + (col_w + k) * ld_w] = w[k];          // wave-uniform branch
+            if ((k >> 4) == wave) Wcopy[i + (col_w + k) * ld_w] = -w[k];         // wave-uniform branch
     }
     double gmax = 0.0;
     #pragma unroll 4
@@ -223,37 +228,114 @@ __global__ __launch_bounds__(256) void k_panel_scale(
 // MFMA orientation: D[m][n] with m <- j (A operand = W), n <- i (B operand = L); the f64 C/D map
 // is col = lane&15 (-> i, contiguous), row = (lane>>4) + 4*reg (-> j).
 // Block tile 128(i) x BN(j), 4 waves, each wave 64 x (BN/2); K staged through LDS 16 at a time
-// with register prefetch.  W is negated while staging so the accumulator starts at C.
+// with register prefetch.  The W operand buffer holds -W (written by k_panel_scale) so the accumulator
+// starts at C and the staged registers go to LDS untouched (no VALU op forces an early vmcnt wait).
 // Column tiles are enumerated over LOCALLY owned panels (block-cyclic), rows are global.
 // ---------------------------------------------------------------------------------------------
+// Shared by host and device: number of 8x8 super-tiles a launch enumerates, and the decode of a
+// linear super-tile index into (super-row, super-col).  Only super-tiles that contain at least one
+// tile on or below the diagonal are enumerated (column by column).
+struct UpdGeo {
+    int64_t row_begin, Npad, first_lp, sub0;
+    int nb, world, rank, nrt, nct;         // nrt/nct: row / column tiles of this launch
+    int stagger_ticks;                     // >0: delay (100 MHz ticks) applied to half of the first-round blocks
+    int stagger_mode;                      // 1: by dispatch index, 2: by hardware wave-slot parity
+    unsigned long long* dbg;               // diagnostics only (NULL in normal operation): per-block timeline
+};
 template <int BN>
+__host__ __device__ inline void upd_col(const UpdGeo& u, int64_t ct, int64_t& jglob, int64_t& jloc) {
+    const int tpp = u.nb / BN;
+    const int64_t c = ct + u.sub0;
+    const int64_t lp = u.first_lp + c / tpp;
+    const int sub = (int)(c % tpp);
+    jglob = (lp * u.world + u.rank) * (int64_t)u.nb + (int64_t)sub * BN;
+    jloc = lp * (int64_t)u.nb + (int64_t)sub * BN;
+}
+constexpr int SUPER = 8;
+template <int BN>
+__host__ __device__ inline int64_t upd_super_min_row(const UpdGeo& u, int sJ) {
+    int64_t jg, jl;
+    upd_col<BN>(u, (int64_t)sJ * SUPER, jg, jl);
+    int64_t rt_min = (jg - u.row_begin) / BM;            // first row tile with i0 + BM > jg
+    if (rt_min < 0) rt_min = 0;
+    return rt_min / SUPER;
+}
+template <int BN>
+inline int64_t upd_super_count(const UpdGeo& u) {
+    const int nsr = (u.nrt + SUPER - 1) / SUPER, nsc = (u.nct + SUPER - 1) / SUPER;
+    int64_t tot = 0;
+    for (int sJ = 0; sJ < nsc; ++sJ) {
+        const int64_t mn = upd_super_min_row<BN>(u, sJ);
+        if (mn < nsr) tot += nsr - mn;
+    }
+    return tot;
+}
+
+template <int BN, bool SWZ>
 __global__ __launch_bounds__(256, 2) void k_update(
     double* __restrict__ C, int64_t ldc,
     const double* __restrict__ Lop, int64_t ldl,
     const double* __restrict__ Wop, int64_t ldw,
-    int K, int64_t row_begin, int64_t Npad,
-    int64_t first_lp, int64_t sub0, int nb, int world, int rank)
+    int K, UpdGeo u)
 {
     constexpr int TJ = BN / 32;            // 16-wide MFMA tiles per wave along j
     constexpr int TI = 4;                  // along i (wave covers 64 rows)
     constexpr int LSTR = BM + 16;          // padded LDS row strides (doubles): rows k and k+1 hit
     constexpr int WSTR = BN + 16;          // disjoint halves of the 64 banks
-    __shared__ double Ls[BKU][LSTR];
-    __shared__ double Ws[BKU][WSTR];
+    __shared__ double Ls[2][BKU][LSTR];     // double-buffered: one barrier per k-stage
+    __shared__ double Ws[2][BKU][WSTR];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // column tile -> (global column, local column)
-    const int tiles_per_panel = nb / BN;
-    const int64_t ct = (int64_t)blockIdx.y + sub0;
-    const int64_t lp = first_lp + ct / tiles_per_panel;
-    const int sub = (int)(ct % tiles_per_panel);
-    const int64_t jglob = (lp * world + rank) * (int64_t)nb + (int64_t)sub * BN;
-    const int64_t jloc = lp * (int64_t)nb + (int64_t)sub * BN;
+    const int64_t Npad = u.Npad;
+    int64_t rt, ct;
+    if (SWZ) {
+        // XCD-aware order: block b runs on XCD b%8 (observed dispatch); each XCD walks its own
+        // sequence of 8x8 super-tiles so the 16 operand tiles of a super-tile are reused from its L2.
+        const int64_t b = blockIdx.x;
+        const int xcd = (int)(b & 7);
+        const int64_t slot = b >> 3;
+        int64_t sidx = (slot / (SUPER * SUPER)) * 8 + xcd;
+        const int within = (int)(slot % (SUPER * SUPER));
+        const int nsr = (u.nrt + SUPER - 1) / SUPER, nsc = (u.nct + SUPER - 1) / SUPER;
+        int sJ = 0; int64_t sI = -1;
+        for (; sJ < nsc; ++sJ) {
+            const int64_t mn = upd_super_min_row<BN>(u, sJ);
+            const int64_t cnt = mn < nsr ? nsr - mn : 0;
+            if (sidx < cnt) { sI = mn + sidx; break; }
+            sidx -= cnt;
+        }
+        if (sI < 0) return;
+        rt = sI * SUPER + (within & (SUPER - 1));
+        ct = (int64_t)sJ * SUPER + (within >> 3);
+        if (rt >= u.nrt || ct >= u.nct) return;
+    } else {
+        rt = blockIdx.x; ct = blockIdx.y;
+    }
+    int64_t jglob, jloc;
+    upd_col<BN>(u, ct, jglob, jloc);
     if (jglob >= Npad) return;
-    const int64_t i0 = row_begin + (int64_t)blockIdx.x * BM;
+    const int64_t i0 = u.row_begin + rt * BM;
     if (i0 + BM <= jglob) return;          // tile strictly above the diagonal
+    // De-phase the co-resident blocks once per launch.  Every tile costs the same, so without this all
+    // resident blocks load / store their C tiles in the same instant (a 2 x 67 MB burst with every MFMA
+    // pipe idle) and then all compute together.  Delaying half of the FIRST-round blocks by half a tile
+    // period interleaves memory phases with compute phases for the rest of the launch.  Speed only.
+    if (u.stagger_ticks > 0) {
+        const unsigned lin = SWZ ? blockIdx.x : blockIdx.x + gridDim.x * blockIdx.y;
+        if (lin < 512u) {
+            bool late;
+            if (u.stagger_mode == 2) late = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) != 0;   // HW_ID.WAVE_ID
+            else                     late = ((lin >> 8) & 1) != 0;
+            if (late) {
+                const unsigned long long t0 = wall_clock64();
+                while (wall_clock64() - t0 < (unsigned long long)u.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+            }
+        }
+    }
     const int wi = (wave & 1) * 64, wj = (wave >> 1) * (BN / 2);
     const int l15 = lane & 15, l4 = lane >> 4;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    if (u.dbg) ts0 = wall_clock64();
 
     double4_t acc[TJ][TI];
     #pragma unroll
@@ -262,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void k_update(
         for (int ti = 0; ti < TI; ++ti)
             #pragma unroll
             for (int r = 0; r < 4; ++r)
-                acc[tj][ti][r] = C[(i0 + wi + ti * 16 + l15) + (jloc + wj + tj * 16 + l4 + 4 * r) * ldc];
+                acc[tj][ti][r] = (PYIPM_ABLATE & 1) ? 0.0 : C[(i0 + wi + ti * 16 + l15) + (jloc + wj + tj * 16 + l4 + 4 * r) * ldc];
 
     // staging registers: L tile 16 x 128 doubles = 1024 double2 -> 4 per thread;
     //                    W tile 16 x BN  doubles -> BN/32 per thread
@@ -283,32 +365,68 @@ __global__ __launch_bounds__(256, 2) void k_update(
             wreg[ps] = *reinterpret_cast<const double2_t*>(wsrc + (int64_t)((k0_) + WKPP * ps) * ldw);  \
     }
 
-    PYIPM_LOAD_REGS(0)
-    for (int k0 = 0; k0 < K; k0 += BKU) {
-        __syncthreads();
-        #pragma unroll
-        for (int ps = 0; ps < 4; ++ps)
-            *reinterpret_cast<double2_t*>(&Ls[lk + 4 * ps][li]) = lreg[ps];
-        #pragma unroll
-        for (int ps = 0; ps < WPASS; ++ps) {
-            *reinterpret_cast<double2_t*>(&Ws[wk + WKPP * ps][wjj]) = -wreg[ps];
-        }
-        __syncthreads();
-        if (k0 + BKU < K) PYIPM_LOAD_REGS(k0 + BKU)
-        #pragma unroll
-        for (int kk = 0; kk < BKU; kk += 4) {
-            double a[TJ], b[TI];
-            #pragma unroll
-            for (int tj = 0; tj < TJ; ++tj) a[tj] = Ws[kk + l4][wj + tj * 16 + l15];
-            #pragma unroll
-            for (int ti = 0; ti < TI; ++ti) b[ti] = Ls[kk + l4][wi + ti * 16 + l15];
-            #pragma unroll
-            for (int tj = 0; tj < TJ; ++tj)
-                #pragma unroll
-                for (int ti = 0; ti < TI; ++ti)
-                    acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[tj], b[ti], acc[tj][ti], 0, 0, 0);
-        }
+#define PYIPM_STORE_LDS(buf_)                                                                         \
+    {                                                                                                 \
+        _Pragma("unroll") for (int ps = 0; ps < 4; ++ps)                                              \
+            *reinterpret_cast<double2_t*>(&Ls[buf_][lk + 4 * ps][li]) = lreg[ps];                     \
+        _Pragma("unroll") for (int ps = 0; ps < WPASS; ++ps)                                          \
+            *reinterpret_cast<double2_t*>(&Ws[buf_][wk + WKPP * ps][wjj]) = wreg[ps];                 \
     }
+#define PYIPM_FRAGS(buf_, kk_, a_, b_)                                                                \
+    {                                                                                                 \
+        if (!(PYIPM_ABLATE & 8) || (kk_) == 0) {                                                      \
+        _Pragma("unroll") for (int tj = 0; tj < TJ; ++tj) a_[tj] = Ws[buf_][(kk_) + l4][wj + tj * 16 + l15]; \
+        _Pragma("unroll") for (int ti = 0; ti < TI; ++ti) b_[ti] = Ls[buf_][(kk_) + l4][wi + ti * 16 + l15]; } \
+    }
+#define PYIPM_MFMAS(a_, b_)                                                                           \
+    {                                                                                                 \
+        _Pragma("unroll") for (int tj = 0; tj < TJ; ++tj)                                             \
+            _Pragma("unroll") for (int ti = 0; ti < TI; ++ti)                                         \
+                acc[tj][ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_[tj], b_[ti], acc[tj][ti], 0, 0, 0); \
+    }
+
+    // One DS / VMEM instruction is pinned behind each 64-cycle MFMA (sched_group_barrier) and the
+    // fragments are prefetched a full sub-step ahead: the two co-resident waves of a SIMD otherwise
+    // run in lockstep and wait on LDS latency together (tools/ubench/mfma_structure.hip: 66 -> 76.8 TF/s).
+#define PYIPM_ILV(n_, mask_)                                                                          \
+    { _Pragma("unroll") for (int q_ = 0; q_ < (n_); ++q_) {                                           \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                           \
+          __builtin_amdgcn_sched_group_barrier(mask_, 1, 0); } }
+
+    // prologue: stage 0 into LDS buffer 0, stage 1 into registers
+    PYIPM_LOAD_REGS(0)
+    PYIPM_STORE_LDS(0)
+    { const int k1 = (BKU < K) ? BKU : 0; PYIPM_LOAD_REGS(k1) }
+    __syncthreads();
+    if (u.dbg) { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[TJ - 1][TI - 1][3])); ts1 = wall_clock64(); }
+    int cur = 0;
+    double a0[TJ], b0[TI], a1[TJ], b1[TI];
+    PYIPM_FRAGS(cur, 0, a0, b0)
+    for (int k0 = 0; k0 < K; k0 += BKU) {
+        // branch-free body: past the end the staging traffic re-reads the last stage (harmless)
+        int k2 = k0 + 2 * BKU; if (k2 > K - BKU) k2 = K - BKU;
+        PYIPM_FRAGS(cur, 4, a1, b1)
+        PYIPM_MFMAS(a0, b0)
+        PYIPM_ILV(2 * TJ + 2 * TI > 16 ? 16 : TJ + TI, 0x100)
+        PYIPM_FRAGS(cur, 8, a0, b0)
+        PYIPM_MFMAS(a1, b1)
+        PYIPM_ILV(TJ + TI, 0x100)
+        PYIPM_FRAGS(cur, 12, a1, b1)
+        PYIPM_STORE_LDS(cur ^ 1)                    // stage k+1: registers -> the other LDS buffer
+        if (!(PYIPM_ABLATE & 4)) PYIPM_LOAD_REGS(k2)   // stage k+2 -> registers (a full stage ahead of its use)
+        PYIPM_MFMAS(a0, b0)
+        PYIPM_ILV(TJ * TI, 0x0A0)
+        __syncthreads();
+        PYIPM_FRAGS(cur ^ 1, 0, a0, b0)
+        PYIPM_MFMAS(a1, b1)
+        PYIPM_ILV(TJ + TI, 0x100)
+        cur ^= 1;
+    }
+#undef PYIPM_ILV
+    if (u.dbg) ts2 = wall_clock64();
+#undef PYIPM_STORE_LDS
+#undef PYIPM_FRAGS
+#undef PYIPM_MFMAS
 #undef PYIPM_LOAD_REGS
 
     #pragma unroll
@@ -317,7 +435,16 @@ __global__ __launch_bounds__(256, 2) void k_update(
         for (int ti = 0; ti < TI; ++ti)
             #pragma unroll
             for (int r = 0; r < 4; ++r)
-                C[(i0 + wi + ti * 16 + l15) + (jloc + wj + tj * 16 + l4 + 4 * r) * ldc] = acc[tj][ti][r];
+                if (!(PYIPM_ABLATE & 2) || acc[tj][ti][r] == 1.2345e300)
+                    C[(i0 + wi + ti * 16 + l15) + (jloc + wj + tj * 16 + l4 + 4 * r) * ldc] = acc[tj][ti][r];
+    if (u.dbg && tid == 0) {
+        const unsigned lin = SWZ ? blockIdx.x : blockIdx.x + gridDim.x * blockIdx.y;
+        unsigned long long* d = u.dbg + 8ull * lin;
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = wall_clock64();
+        d[4] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);          // HW_ID low 16 bits... (size field = 15+1)
+        d[5] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);          // XCC_ID
+        d[6] = rt; d[7] = ct;
+    }
 }
 
 // Register-resident MFMA-only loop for the fp64 matrix peak measurement.  Inline asm keeps the

@@ -17,7 +17,7 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
     Carve cv;
     const size_t D = sizeof(double);
     const size_t oA = cv.take((size_t)g.Npad * (size_t)(g.ncols_local > 0 ? g.ncols_local : 1) * D);
-    const size_t oW = cv.take(2 * (size_t)g.Npad * g.nb * D);        // double-buffered for panel lookahead
+    const size_t oW = cv.take(2 * (size_t)default_group(g.world) * (size_t)g.Npad * g.nb * D);   // -W of a panel group, double-buffered for lookahead
     const size_t oL = cv.take(g.world > 1 ? (size_t)g.Npad * g.nb * D : 256);
     const size_t oD = cv.take((size_t)(g.Npad / TB) * TB * TB * D);
     const size_t orhs = cv.take((size_t)g.Npad * D);
@@ -91,25 +91,47 @@ int stage_block(Ctx* ctx, const double* src, int64_t rows, int64_t cols, int64_t
 }
 
 inline dim3 grid1(int64_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
-inline double* wbuf(Ctx* ctx, int64_t p) { return ctx->Wbuf + (p & 1) * ctx->g.Npad * (int64_t)ctx->g.nb; }
+// -W columns of panel p: the buffer of its group (parity-alternating) + its offset inside the group
+inline double* wbuf(Ctx* ctx, int64_t p) {
+    const int64_t G = ctx->group, grp = p / G;
+    return ctx->Wbuf + ((grp & 1) * G + (p % G)) * ctx->g.Npad * (int64_t)ctx->g.nb;
+}
 
 // ---- per-panel building blocks -----------------------------------------------------------------
 
 // Rank-K update of `n_lp` locally owned panels starting at local panel `first_lp`.
 int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ldl, const double* Wop, int K,
-                     int64_t row_begin, int64_t first_lp, int64_t n_lp) {
+                     int64_t row_begin, int64_t first_lp, int64_t n_lp, bool bulk = true) {
     const Geo& g = ctx->g;
     const int64_t m = g.Npad - row_begin;
     if (m <= 0 || n_lp <= 0) return 0;
-    const int64_t ncol_tiles = n_lp * (g.nb / 128);
-    dim3 grid((unsigned)(m / BM), (unsigned)ncol_tiles);
-    hipLaunchKernelGGL(k_update<128>, grid, dim3(256), 0, stream, ctx->A, g.Npad, Lop, ldl,
-                       Wop, g.Npad, K, row_begin, g.Npad, first_lp, (int64_t)0, g.nb, g.world, g.rank);
+    UpdGeo u;
+    u.row_begin = row_begin; u.Npad = g.Npad; u.first_lp = first_lp; u.sub0 = 0;
+    u.nb = g.nb; u.world = g.world; u.rank = g.rank;
+    u.nrt = (int)(m / BM); u.nct = (int)(n_lp * (g.nb / 128));
+    // stagger only pays when the launch runs for several rounds of 512 resident blocks
+    const double nctd = (double)(u.nct < u.nrt ? u.nct : u.nrt);
+    const double approx_blocks = nctd * (double)u.nrt - 0.5 * nctd * nctd;    // tiles on/below the diagonal
+    u.stagger_mode = ctx->stagger_mode;
+    u.dbg = ctx->dbg_buf;
+    u.stagger_ticks = (ctx->stagger_mode && approx_blocks >= 1536.0) ? (int)(ctx->stagger_us_per_k * K * 100.0) : 0;
+    if (ctx->xcd_swizzle && bulk) {
+        const int64_t nsup = upd_super_count<128>(u);
+        if (nsup <= 0) return 0;
+        const int64_t rounds = (nsup + 7) / 8;                       // super-tiles per XCD
+        dim3 grid((unsigned)(rounds * 8 * SUPER * SUPER));
+        hipLaunchKernelGGL((k_update<128, true>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, g.Npad, K, u);
+    } else {
+        dim3 grid((unsigned)u.nrt, (unsigned)u.nct);
+        hipLaunchKernelGGL((k_update<128, false>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, g.Npad, K, u);
+    }
     PYIPM_KCHECK();
     return 0;
 }
 
-int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream) {
+// Factor panel p on `stream`.  apply_pending: first apply the earlier panels of p's group to p's columns
+// (grouped single-rank driver; their bulk update is deferred to the end of the group).
+int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = false) {
     const Geo& g = ctx->g;
     if (p < 0 || p >= g.npanels || g.owner(p) != g.rank) { ctx->err = "factor_panel: not the owner"; return PYIPM_E_BADARG; }
     const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
@@ -117,16 +139,25 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream) {
     const int nt = nbw / TB;
     const int64_t lp = p / g.world;
     double* W = wbuf(ctx, p);
+    if (apply_pending && (p % ctx->group) != 0) {
+        const int64_t p0 = p - (p % ctx->group);
+        int rc = launch_update128(ctx, stream, ctx->A + g.local_c0(p0) * g.Npad, g.Npad, wbuf(ctx, p0),
+                                  (int)((p - p0) * g.nb), c0, lp, 1, /*bulk=*/false);
+        if (rc) return rc;
+    }
     for (int t = 0; t < nt; ++t) {
         const int64_t j0 = c0 + (int64_t)t * TB, lcol = lc0 + (int64_t)t * TB;
         if (t > 0) {
             // left-looking in-panel update of this tile's column block with the t tiles before it
             const int64_t row_begin = (j0 / BM) * BM;
             const int64_t m = g.Npad - row_begin;
+            UpdGeo u;
+            u.row_begin = row_begin; u.Npad = g.Npad; u.first_lp = lp; u.sub0 = t;
+            u.nb = g.nb; u.world = g.world; u.rank = g.rank; u.nrt = (int)(m / BM); u.nct = 1;
+            u.stagger_ticks = 0; u.stagger_mode = 0; u.dbg = nullptr;
             dim3 grid((unsigned)(m / BM), 1);
-            hipLaunchKernelGGL(k_update<64>, grid, dim3(256), 0, stream, ctx->A, g.Npad,
-                               ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, t * TB, row_begin, g.Npad,
-                               lp, (int64_t)t, g.nb, g.world, g.rank);
+            hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), 0, stream, ctx->A, g.Npad,
+                               ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, t * TB, u);
             PYIPM_KCHECK();
         }
         hipLaunchKernelGGL(k_tile_invert, dim3(1), dim3(256), 0, stream, ctx->A, g.Npad, j0, lcol,
@@ -136,20 +167,22 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream) {
         if (below > 0) {
             hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(below / TB)), dim3(256), 0, stream,
                                ctx->A, g.Npad, lcol, ctx->A, g.Npad, lcol, W, g.Npad, (int64_t)t * TB,
-                               ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), j0 + TB, &ctx->dstats->growth_bits);
+                               ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), j0 + TB, &ctx->dstats->growth_bits, 1.0);
             PYIPM_KCHECK();
         }
     }
     return 0;
 }
 
-// One k_update<128> launch covering local panels [first_lp, first_lp+n_lp) with panel p, timed.
-int timed_update(Ctx* ctx, int64_t p, int64_t first_lp, int64_t n_lp) {
+// One bulk k_update<128> launch: panels [p0, p0+np) (contiguous, same rank) applied with K = their total
+// width to local panels [first_lp, first_lp+n_lp); timed with HIP events on the handle's stream.
+int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_lp) {
     const Geo& g = ctx->g;
     if (n_lp <= 0) return 0;
-    const int nbw = (int)g.panel_w(p);
-    const bool mine = g.owner(p) == g.rank;
-    const double* Lop = mine ? ctx->A + g.local_c0(p) * g.Npad : ctx->Lbuf;
+    int K = 0;
+    for (int64_t q = p0; q < p0 + np; ++q) K += (int)g.panel_w(q);
+    const bool mine = g.owner(p0) == g.rank;
+    const double* Lop = mine ? ctx->A + g.local_c0(p0) * g.Npad : ctx->Lbuf;
     const int64_t q0 = first_lp * g.world + g.rank;           // first global panel updated
     const int64_t row_begin = g.panel_c0(q0);
     if (row_begin >= g.Npad) return 0;
@@ -163,16 +196,16 @@ int timed_update(Ctx* ctx, int64_t p, int64_t first_lp, int64_t n_lp) {
         e0 = ctx->ev_trailing[ctx->n_trailing].first; e1 = ctx->ev_trailing[ctx->n_trailing].second;
         PYIPM_HIP(hipEventRecord(e0, ctx->stream));
     }
-    int rc = launch_update128(ctx, ctx->stream, Lop, g.Npad, wbuf(ctx, p), nbw, row_begin, first_lp, n_lp);
+    int rc = launch_update128(ctx, ctx->stream, Lop, g.Npad, wbuf(ctx, p0), K, row_begin, first_lp, n_lp);
     if (rc) return rc;
     if (ctx->profile) PYIPM_HIP(hipEventRecord(e1, ctx->stream));
-    // algorithmic flops of this launch: 2*nbw per lower-triangle entry of the updated local columns
+    // algorithmic flops of this launch: 2*K per lower-triangle entry of the updated local columns
     double fl = 0.0;
     for (int64_t k = 0; k < n_lp; ++k) {
         const int64_t qq = (first_lp + k) * g.world + g.rank;
         if (qq >= g.npanels) break;
         const double w = (double)g.panel_w(qq), r0 = (double)(g.Npad - g.panel_c0(qq));
-        fl += 2.0 * nbw * (w * r0 - 0.5 * w * (w - 1.0));
+        fl += 2.0 * K * (w * r0 - 0.5 * w * (w - 1.0));
     }
     ctx->trailing_flops += fl;
     ctx->n_trailing++;
@@ -187,7 +220,7 @@ int trailing_update(Ctx* ctx, int64_t p) {
     while (q < g.npanels && g.owner(q) != g.rank) ++q;
     if (q >= g.npanels) return 0;
     const int64_t local_panels = (g.ncols_local + g.nb - 1) / g.nb;
-    return timed_update(ctx, p, q / g.world, local_panels - q / g.world);
+    return timed_update(ctx, p, 1, q / g.world, local_panels - q / g.world);
 }
 
 int factor_begin(Ctx* ctx) {
@@ -350,30 +383,42 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
     return 0;
 }
 
-// Single-rank factorisation with one-panel lookahead: while the bulk of trailing update p runs on
-// the main stream, panel p+1 (already updated by a small head launch) is factored on a second stream.
+// Single-rank factorisation.  Three-level hierarchy: 64-wide block pivots inside nb-wide panels inside
+// groups of `group` panels.  Panels of a group are factored left-looking against the group's earlier
+// panels; the trailing matrix is updated ONCE per group with K = group*nb, which divides the C-tile
+// read-modify-write traffic (the HBM bound of the rank-nb update) by `group`.  One-group lookahead: while
+// the bulk update of group g runs on the main stream, group g+1 (already updated by a head launch) is
+// factored on a second stream.
 int factor_all(Ctx* ctx, pyipm_factor_stats* stats) {
     const Geo& g = ctx->g;
     if (g.world != 1) { ctx->err = "factor(): single-rank entry point; use the per-panel phases when world > 1"; return PYIPM_E_BADARG; }
     if (!ctx->assembled) { ctx->err = "factor: assemble first"; return PYIPM_E_BADARG; }
     int rc = factor_begin(ctx); if (rc) return rc;
-    if (!ctx->side) PYIPM_HIP(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    if (!ctx->side) {
+        // panel kernels are latency-critical and tiny: highest dispatch priority, so they take the first
+        // CU slot a retiring bulk-update block frees instead of queueing behind the whole bulk grid
+        int lo = 0, hi = 0;
+        PYIPM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        PYIPM_HIP(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, hi));
+    }
     PYIPM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    const int64_t np = g.npanels;
-    rc = factor_panel(ctx, 0, ctx->stream); if (rc) return rc;
-    for (int64_t p = 0; p < np; ++p) {
-        if (p + 1 >= np) break;
+    const int64_t np = g.npanels, G = ctx->group;
+    const int64_t ngroups = (np + G - 1) / G;
+    auto gsize = [&](int64_t grp) { int64_t a = grp * G, b = a + G; if (b > np) b = np; return b - a; };
+    for (int64_t q = 0; q < gsize(0); ++q) { rc = factor_panel(ctx, q, ctx->stream, true); if (rc) return rc; }
+    for (int64_t grp = 0; grp + 1 < ngroups; ++grp) {
+        const int64_t p0 = grp * G, n0 = gsize(grp), p1 = p0 + n0, n1 = gsize(grp + 1);
         if (ctx->lookahead) {
-            rc = timed_update(ctx, p, p + 1, 1); if (rc) return rc;                  // head: panel p+1 only
+            rc = timed_update(ctx, p0, n0, p1, n1); if (rc) return rc;                 // head: next group's columns
             PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
             PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_head, 0));
-            rc = factor_panel(ctx, p + 1, ctx->side); if (rc) return rc;              // overlaps the bulk below
+            for (int64_t q = p1; q < p1 + n1; ++q) { rc = factor_panel(ctx, q, ctx->side, true); if (rc) return rc; }
             PYIPM_HIP(hipEventRecord(ctx->ev_panel, ctx->side));
-            rc = timed_update(ctx, p, p + 2, np - (p + 2)); if (rc) return rc;        // bulk
+            rc = timed_update(ctx, p0, n0, p1 + n1, np - (p1 + n1)); if (rc) return rc;   // bulk (overlaps the side stream)
             PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
         } else {
-            rc = timed_update(ctx, p, p + 1, np - (p + 1)); if (rc) return rc;
-            rc = factor_panel(ctx, p + 1, ctx->stream); if (rc) return rc;
+            rc = timed_update(ctx, p0, n0, p1, np - p1); if (rc) return rc;
+            for (int64_t q = p1; q < p1 + n1; ++q) { rc = factor_panel(ctx, q, ctx->stream, true); if (rc) return rc; }
         }
     }
     PYIPM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -410,6 +455,7 @@ int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t m
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PYIPM_E_NODEVICE;
     Ctx* ctx = new Ctx();
     ctx->g = make_geo(n, me, mi, nb, world, rank);
+    ctx->group = default_group(world);
     ctx->device = device;
     ctx->stream = (hipStream_t)stream;
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return PYIPM_E_NODEVICE; }
@@ -605,7 +651,7 @@ int pyipm_newton_factor_end(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
 int pyipm_newton_factor_panel(pyipm_newton_ctx* h, int64_t p) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
-    return factor_panel(ctx, p, ctx->stream);
+    return factor_panel(ctx, p, ctx->stream, false);
 }
 int pyipm_newton_trailing_update(pyipm_newton_ctx* h, int64_t p) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
@@ -654,7 +700,7 @@ int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf)
             hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(m / TB)), dim3(256), 0, ctx->stream,
                                ctx->Lbuf, g.Npad, (int64_t)t * TB, wbuf(ctx, p), g.Npad, (int64_t)t * TB,
                                (double*)nullptr, (int64_t)0, (int64_t)0, dinv + (int64_t)t * TB * TB, c1,
-                               (unsigned long long*)nullptr);
+                               (unsigned long long*)nullptr, -1.0);
             PYIPM_KCHECK();
         }
     }
@@ -708,6 +754,15 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
     if (!strcmp(name, "profile")) { ctx->profile = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "lookahead")) { ctx->lookahead = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "group")) {           // may only shrink below the create-time value (workspace is sized for it)
+        int v = (int)value; if (v < 1 || v > default_group(ctx->g.world)) { ctx->err = "group out of range"; return PYIPM_E_BADARG; }
+        ctx->group = v; return PYIPM_OK; }
+    if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "stagger_mode")) { ctx->stagger_mode = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "extra_lds")) { ctx->extra_lds = (int)value; return PYIPM_OK; }    // diagnostics: force 1 block/CU
+    if (!strcmp(name, "debug_timeline_ptr")) {      // diagnostics: device buffer of 8 x u64 per block (pointer passed as double-encoded integer halves is lossy; use set via low 52 bits)
+        ctx->dbg_buf = (unsigned long long*)(uintptr_t)(unsigned long long)value; return PYIPM_OK; }
+    if (!strcmp(name, "stagger_us_per_k")) { ctx->stagger_us_per_k = value; return PYIPM_OK; }
     ctx->err = std::string("unknown option ") + name;
     return PYIPM_E_BADARG;
 }

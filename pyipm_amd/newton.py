@@ -16,7 +16,7 @@ from ctypes import POINTER, c_char_p, c_double, c_int, c_int64, c_size_t, c_void
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpyipm_newton.so")
+LIB_PATH = os.environ.get("PYIPM_NEWTON_LIB") or os.path.join(_HERE, "libpyipm_newton.so")
 
 MEM_DEVICE, MEM_HOST = 0, 1
 TILE, PAD = 64, 128
