@@ -95,14 +95,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=16384)
-    ap.add_argument("--me", type=int, default=4096)
-    ap.add_argument("--mi", type=int, default=6144)
+    ap.add_argument("--nvar", "--n", dest="n", type=int, default=16384)
+    ap.add_argument("--neq", "--me", dest="me", type=int, default=4096)
+    ap.add_argument("--nineq", "--mi", dest="mi", type=int, default=6144)
     ap.add_argument("--nb", type=int, default=256)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--refine", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also report the backward error of the last step")
+    ap.add_argument("--force-dist", action="store_true", help="use the per-panel distributed driver even for 1 GPU")
     ap.add_argument("--opt", action="append", default=[], help="core option name=value (e.g. xcd_swizzle=0, lookahead=0)")
     args = ap.parse_args()
 
@@ -120,9 +121,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the Newton-step core has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
     n, me, mi = args.n, args.me, args.mi
     N = n + 2 * mi + me
@@ -135,7 +138,7 @@ def main():
         k, v = kv.split("=")
         core.set_option(k, float(v))
 
-    if world > 1:
+    if use_dist:
         from pyipm_amd.dist import DistNewton
         drv = DistNewton(core)
 
@@ -146,7 +149,7 @@ def main():
             return core.step(0.0, 0.0, refine=args.refine)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -163,7 +166,7 @@ def main():
         panel_ms += tm["panel_ms"]; solve_ms += tm["solve_ms"]; assemble_ms += tm["assemble_ms"]
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -207,7 +210,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(target_N=N)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -178,6 +178,12 @@ class NewtonCore(object):
     def _ptr(t):
         return c_void_p(0) if t is None else c_void_p(t.data_ptr())
 
+    on_device = True
+
+    def new_buffer(self, numel):
+        """fp64 device buffer (message / vector container for pyipm_amd.dist)."""
+        return self.torch.empty(int(numel), dtype=self.torch.float64, device=self.device)
+
     def sync_stream(self):
         self._ck(self.lib.pyipm_newton_set_stream(
             self.h, c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)))

@@ -18,3 +18,140 @@ class OracleBackend(object):
                                            delta=delta, mu_host=mu_host, eta=eta, beta=beta, eps=eps, stats=st)
         self.calls.append({"Hc": Hc, "g": g, "dz": dz, "delta": delta})
         return dz, delta, st
+
+
+class ModelCore(object):
+    """NumPy model of ONE RANK of the HIP core's per-panel interface (block-cyclic local columns,
+    pack/unpack messages, panel-wise substitutions).  Lets the world_size-2 gloo tests exercise
+    pyipm_amd.dist.DistNewton on CPU.  Built on oracle/block_ldl_model.sweep_invert."""
+    on_device = False
+    device = "cpu"
+
+    def __init__(self, n, me, mi, H, g, nb=128, world=1, rank=0, tb=64):
+        import torch
+        from oracle.block_ldl_model import sweep_invert
+        self.torch, self.sweep_invert = torch, sweep_invert
+        self.n, self.me, self.mi = n, me, mi
+        self.N = n + 2 * mi + me
+        self.Npad = ((self.N + 127) // 128) * 128
+        self.nb, self.world, self.rank, self.tb = nb, world, rank, tb
+        self.npanels = (self.Npad + nb - 1) // nb
+        self.H, self.g = np.asarray(H, dtype=np.float64), np.asarray(g, dtype=np.float64)
+        self.mine = [p for p in range(self.npanels) if p % world == rank]
+        self.lcol = {}
+        c = 0
+        for p in self.mine:
+            self.lcol[p] = c
+            c += self.pw(p)
+        self.ncols_local = c
+
+    def pw(self, p):
+        return min(self.nb, self.Npad - p * self.nb)
+
+    def new_buffer(self, numel):
+        return self.torch.empty(int(numel), dtype=self.torch.float64)
+
+    def residual(self):
+        return self.torch.from_numpy(self.g.copy())
+
+    def assemble(self, delta=0.0, delta_c=0.0):
+        N, Npad = self.N, self.Npad
+        full = np.eye(Npad)
+        full[:N, :N] = self.H
+        full[:self.n, :self.n] += delta * np.eye(self.n)
+        if self.me:
+            i1 = self.n + self.mi
+            full[i1:i1 + self.me, i1:i1 + self.me] -= delta_c * np.eye(self.me)
+        self.A = np.zeros((Npad, max(self.ncols_local, 1)))
+        for p in self.mine:
+            c0 = p * self.nb
+            blk = np.tril(full)[:, c0:c0 + self.pw(p)]
+            self.A[:, self.lcol[p]:self.lcol[p] + self.pw(p)] = blk
+        self.W = {}
+        self.L = {}
+        self.Tinv = {}
+
+    def factor_begin(self):
+        self.st = dict(n_neg=0, n_zero=0, n_2x2=0, n_pos=0, nonfinite=0, d_min=1e308, d_max=0.0, growth=0.0)
+
+    def factor_end(self):
+        return dict(self.st)
+
+    def factor_panel(self, p):
+        assert p % self.world == self.rank
+        tb, c0, nbw, lc = self.tb, p * self.nb, self.pw(p), self.lcol[p]
+        W = np.zeros((self.Npad, nbw))
+        for t in range(nbw // tb):
+            j0, l0 = c0 + t * tb, lc + t * tb
+            if t > 0:     # left-looking in-panel update with the tiles before this one
+                self.A[j0:, l0:l0 + tb] -= self.A[j0:, lc:l0] @ W[j0:j0 + tb, :t * tb].T
+            T = self.A[j0:j0 + tb, l0:l0 + tb]
+            Ti, s = self.sweep_invert(T)
+            self.Tinv[(p, t)] = Ti
+            real = max(0, min(tb, self.N - j0))
+            self.st["n_neg"] += s["neg"]; self.st["n_zero"] += s["zero"]; self.st["n_2x2"] += s["n2x2"]
+            self.st["n_pos"] += real - s["neg"] - s["zero"] if real else 0
+            self.st["d_min"] = min(self.st["d_min"], s["dmin"]); self.st["d_max"] = max(self.st["d_max"], s["dmax"])
+            below = slice(j0 + tb, self.Npad)
+            W[below, t * tb:(t + 1) * tb] = self.A[below, l0:l0 + tb]
+            Lt = W[below, t * tb:(t + 1) * tb] @ Ti
+            self.A[below, l0:l0 + tb] = Lt
+            if Lt.size:
+                self.st["growth"] = max(self.st["growth"], float(np.abs(Lt).max()))
+        self.W[p] = W
+        self.L[p] = None        # owner reads L from its own storage
+
+    def panel_msg_numel(self, p):
+        nbw = self.pw(p)
+        m = self.Npad - (p * self.nb + nbw)
+        return m * nbw + (nbw // self.tb) * self.tb * self.tb
+
+    def panel_pack(self, p, buf):
+        nbw = self.pw(p); c1 = p * self.nb + nbw; m = self.Npad - c1
+        out = buf.numpy()
+        out[:m * nbw] = self.W[p][c1:, :].T.reshape(-1)             # column-major, ld = m
+        for t in range(nbw // self.tb):
+            out[m * nbw + t * self.tb ** 2: m * nbw + (t + 1) * self.tb ** 2] = self.Tinv[(p, t)].reshape(-1)
+
+    def panel_unpack(self, p, buf):
+        assert p % self.world != self.rank
+        nbw = self.pw(p); c1 = p * self.nb + nbw; m = self.Npad - c1; tb = self.tb
+        arr = buf.numpy()
+        W = np.zeros((self.Npad, nbw))
+        W[c1:, :] = arr[:m * nbw].reshape(nbw, m).T
+        L = np.zeros((self.Npad, nbw))
+        for t in range(nbw // tb):
+            Ti = arr[m * nbw + t * tb * tb: m * nbw + (t + 1) * tb * tb].reshape(tb, tb)
+            L[c1:, t * tb:(t + 1) * tb] = W[c1:, t * tb:(t + 1) * tb] @ Ti
+        self.W[p], self.L[p] = W, L
+
+    def trailing_update(self, p):
+        nbw = self.pw(p); c1 = p * self.nb + nbw
+        own = p % self.world == self.rank
+        L = self.A[:, self.lcol[p]:self.lcol[p] + nbw] if own else self.L[p]
+        W = self.W[p]
+        for q in self.mine:
+            if q <= p:
+                continue
+            q0, qw, lq = q * self.nb, self.pw(q), self.lcol[q]
+            self.A[q0:, lq:lq + qw] -= L[q0:, :] @ W[q0:q0 + qw, :].T
+
+    def fwd_panel(self, p, v):
+        x = v.numpy(); tb = self.tb
+        c0, nbw, lc = p * self.nb, self.pw(p), self.lcol[p]
+        for t in range(nbw // tb):
+            j0 = c0 + t * tb
+            x[j0 + tb:] -= self.A[j0 + tb:, lc + t * tb: lc + (t + 1) * tb] @ x[j0:j0 + tb]
+
+    def diag_panel(self, p, v):
+        x = v.numpy(); tb = self.tb
+        for t in range(self.pw(p) // tb):
+            j0 = p * self.nb + t * tb
+            x[j0:j0 + tb] = self.Tinv[(p, t)] @ x[j0:j0 + tb]
+
+    def bwd_panel(self, p, v):
+        x = v.numpy(); tb = self.tb
+        c0, nbw, lc = p * self.nb, self.pw(p), self.lcol[p]
+        for t in range(nbw // tb - 1, -1, -1):
+            j0 = c0 + t * tb
+            x[j0:j0 + tb] -= self.A[j0 + tb:, lc + t * tb: lc + (t + 1) * tb].T @ x[j0 + tb:]
