@@ -138,6 +138,9 @@ int pyipm_newton_panel_pack(pyipm_newton_ctx* ctx, int64_t p, double* buf);
 int pyipm_newton_panel_unpack(pyipm_newton_ctx* ctx, int64_t p, const double* buf);
 /* Rank-nb trailing update of every locally owned column to the right of panel p. */
 int pyipm_newton_trailing_update(pyipm_newton_ctx* ctx, int64_t p);
+/* Same, restricted to the locally owned panels q with first <= q < first+count (lookahead:
+ * the next owner updates and factors its panel before the bulk of the update). */
+int pyipm_newton_trailing_update_range(pyipm_newton_ctx* ctx, int64_t p, int64_t first, int64_t count);
 /* Finish: fetch statistics accumulated by this rank's tile kernels. */
 int pyipm_newton_factor_begin(pyipm_newton_ctx* ctx);
 int pyipm_newton_factor_end(pyipm_newton_ctx* ctx, pyipm_factor_stats* stats);

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_tile_invert(
     double dmin = 1.0e308, dmax = 0.0;
 
     while (left > 0) {
-        const int p = __ffsll(mask) - 1;    // BK candidate: first unswept index
+        const int p = __ffsll(mask) - 1;    // BK candidate: first unswept index (wave-uniform, scalar)
         if (lane == p) {
             #pragma unroll
             for (int c = 0; c < 16; ++c) rowbuf[parity][0][cb + c] = row[c];
@@ -79,19 +79,23 @@ __global__ __launch_bounds__(256) void k_tile_invert(
         __syncthreads();
         const double* rp = rowbuf[parity][0];
         const double cpi = rp[lane];        // B[lane][p] (= B[p][lane])
-        const double dpp = rp[p];
+        double cpj[16];                     // this wave's 16 entries of row p, fetched before the reductions
+        #pragma unroll
+        for (int c = 0; c < 16; ++c) cpj[c] = rp[cb + c];
+        // scalars by readlane (no LDS round trip); the reciprocal runs in parallel with the reduction
+        const double dpp = __longlong_as_double(
+            ((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(cpi) >> 32), p) << 32) |
+            (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(cpi), p));
         const bool u = (mask >> lane) & 1ull;
-        // argmax_{i unswept, i != p} |B[i][p]| : magnitude bits (low 6 replaced by 63-lane: ties and
-        // near-ties resolve to the lower index; it only steers pivot choice)
-        unsigned long long key = 0ull;
-        if (u && lane != p)
-            key = ((unsigned long long)__double_as_longlong(fabs(cpi)) & ~63ull) | (unsigned long long)(63 - lane);
-        const unsigned long long kmax = __ockl_wfred_max_u64(key);
-        const int r = 63 - (int)(kmax & 63ull);
-        const double lam = (left > 1) ? fabs(rp[r]) : 0.0;
+        // lambda = max_{i unswept, i != p} |B[i][p]|, r = lowest index attaining it
+        const double mag = (u && lane != p) ? fabs(cpi) : -1.0;
+        const double lam0 = wave_max(mag);
+        const double lam = (left > 1 && lam0 > 0.0) ? lam0 : 0.0;
+        const unsigned long long hit = __ballot(mag == lam0);
+        const int r = __builtin_amdgcn_readfirstlane(__ffsll(hit) - 1);
         const double app = fabs(dpp);
         int kind = 1, which = 0, piv = p;
-        if (lam > 0.0 && app < PYIPM_BK_ALPHA * lam) {          // uniform branch
+        if (lam > 0.0 && app < PYIPM_BK_ALPHA * lam) {          // uniform branch (rare for SPD-like tiles)
             if (lane == r) {
                 #pragma unroll
                 for (int c = 0; c < 16; ++c) rowbuf[parity][1][cb + c] = row[c];
@@ -105,9 +109,14 @@ __global__ __launch_bounds__(256) void k_tile_invert(
             else                                            { kind = 2; }
         }
         if (kind == 1) {
-            const double* rv = rowbuf[parity][which];
-            double d = rv[piv];
-            const double ci = rv[lane];
+            double d, ci;
+            if (which == 0) { d = dpp; ci = cpi; }
+            else {
+                const double* rv = rowbuf[parity][1];
+                d = rv[piv]; ci = rv[lane];
+                #pragma unroll
+                for (int c = 0; c < 16; ++c) cpj[c] = rv[cb + c];
+            }
             const double ad = fabs(d);
             const bool real = (grow0 + piv) < Nreal;
             if (!(ad <= 1.0e308)) bad = 1;                       // NaN or Inf
@@ -121,15 +130,20 @@ __global__ __launch_bounds__(256) void k_tile_invert(
             }
             const double inv_d = 1.0 / d;
             const double lpi = ci * inv_d;
-            const bool isp = lane == piv;
+            const int pw = piv >> 4, pc = piv & 15;              // wave / register holding column piv
             #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const int j = cb + c;
-                const double cpj = rv[j];
-                double v = fma(-lpi, cpj, row[c]);
-                if (j == piv) v = lpi;
-                if (isp) v = (j == piv) ? -inv_d : cpj * inv_d;
-                row[c] = v;
+            for (int c = 0; c < 16; ++c) row[c] = fma(-lpi, cpj[c], row[c]);
+            if (wave == pw) {                                    // wave-uniform: column piv <- lp
+                #pragma unroll
+                for (int c = 0; c < 16; ++c) if (c == pc) row[c] = lpi;
+            }
+            if (lane == piv) {                                   // one lane: row piv <- lp', pivot <- -1/d
+                #pragma unroll
+                for (int c = 0; c < 16; ++c) row[c] = cpj[c] * inv_d;
+                if (wave == pw) {
+                    #pragma unroll
+                    for (int c = 0; c < 16; ++c) if (c == pc) row[c] = -inv_d;
+                }
             }
             mask &= ~(1ull << piv);
             left -= 1;
@@ -154,12 +168,12 @@ __global__ __launch_bounds__(256) void k_tile_invert(
             #pragma unroll
             for (int c = 0; c < 16; ++c) {
                 const int j = cb + c;
-                const double cpj = rp[j], cqj = rq[j];
-                double v = fma(-lqi, cqj, fma(-lpi, cpj, row[c]));
+                const double cpv = rp[j], cqv = rq[j];
+                double v = fma(-lqi, cqv, fma(-lpi, cpv, row[c]));
                 if (j == p) v = lpi;
                 if (j == q) v = lqi;
-                if (isp) v = (j == p) ? -ia : ((j == q) ? -ib : cpj * ia + cqj * ib);
-                if (isq) v = (j == p) ? -ib : ((j == q) ? -ic : cpj * ib + cqj * ic);
+                if (isp) v = (j == p) ? -ia : ((j == q) ? -ib : cpv * ia + cqv * ib);
+                if (isq) v = (j == p) ? -ib : ((j == q) ? -ic : cpv * ib + cqv * ic);
                 row[c] = v;
             }
             mask &= ~((1ull << p) | (1ull << q));

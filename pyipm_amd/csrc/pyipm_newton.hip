@@ -660,6 +660,22 @@ int pyipm_newton_trailing_update(pyipm_newton_ctx* h, int64_t p) {
     return trailing_update(ctx, p);
 }
 
+int pyipm_newton_trailing_update_range(pyipm_newton_ctx* h, int64_t p, int64_t first, int64_t count) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    const Geo& g = ctx->g;
+    if (p < 0 || p >= g.npanels || first <= p || count < 0) return PYIPM_E_BADARG;
+    if (g.panel_c0(p) + g.panel_w(p) >= g.Npad) return PYIPM_OK;
+    // locally owned panels inside [first, first+count)
+    int64_t q = first;
+    while (q < g.npanels && g.owner(q) != g.rank) ++q;
+    int64_t last = first + count; if (last > g.npanels) last = g.npanels;
+    if (q >= last) return PYIPM_OK;
+    int64_t n_lp = 0;
+    for (int64_t qq = q; qq < last; qq += g.world) ++n_lp;
+    return timed_update(ctx, p, 1, q / g.world, n_lp);
+}
+
 // message = [ W rows below the panel (m x nbw, column-major, ld = m) | nbw/64 tile inverses ]
 size_t pyipm_newton_panel_msg_bytes(pyipm_newton_ctx* h, int64_t p) {
     if (check_ctx(h)) return 0;

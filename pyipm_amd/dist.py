@@ -45,6 +45,7 @@ class DistNewton(object):
         self.N, self.Npad, self.nb, self.npanels = core.N, core.Npad, core.nb, core.npanels
         self._msg = None
         self.bytes_broadcast = 0
+        self.lookahead = True
 
     # ------------------------------------------------------------------ helpers
     def owner(self, p):
@@ -73,6 +74,9 @@ class DistNewton(object):
 
     # ------------------------------------------------------------------ phases
     def factor(self):
+        return self._factor_lookahead() if (self.lookahead and self.world > 1) else self._factor_lockstep()
+
+    def _factor_lockstep(self):
         core = self.core
         core.factor_begin()
         for p in range(self.npanels):
@@ -91,6 +95,53 @@ class DistNewton(object):
                     core.panel_unpack(p, buf)
             if below > 0:
                 core.trailing_update(p)
+        st = core.factor_end()
+        return self._reduce_stats(st)
+
+    def _factor_lookahead(self):
+        """One-panel lookahead: as soon as panel p has arrived, the owner of p+1 updates ONLY panel p+1,
+        factors it and posts its broadcast asynchronously; every rank then runs the bulk of update p
+        while that message is in flight (RCCL runs on its own stream)."""
+        core, dist = self.core, self.dist
+        core.factor_begin()
+        np_ = self.npanels
+        bufs = [core.new_buffer(core.panel_msg_numel(0)), core.new_buffer(core.panel_msg_numel(0))]
+
+        def post(p):
+            """factor (owner) + start the broadcast of panel p; returns (work handle, buffer view)."""
+            c0, c1 = self.panel_cols(p)
+            own = self.owner(p) == self.rank
+            if own:
+                core.factor_panel(p)
+            if self.Npad - c1 <= 0:
+                return None, None
+            buf = bufs[p & 1][: core.panel_msg_numel(p)]
+            if own:
+                core.panel_pack(p, buf)
+            if self.stage:                                   # host-staged (test) path: blocking, same ordering
+                self._bcast(buf, self.owner(p))
+                return None, buf
+            work = dist.broadcast(buf, src=self.owner(p), group=self.group, async_op=True)
+            self.bytes_broadcast += buf.numel() * 8
+            return work, buf
+
+        work, buf = post(0)
+        for p in range(np_):
+            c0, c1 = self.panel_cols(p)
+            if self.Npad - c1 <= 0:
+                break
+            if work is not None:
+                work.wait()                                   # current stream waits for the message
+            if self.owner(p) != self.rank:
+                core.panel_unpack(p, buf)
+            nxt = p + 1
+            if nxt < np_:
+                if self.owner(nxt) == self.rank:
+                    core.trailing_update_range(p, nxt, 1)      # head: bring panel p+1 up to date first
+                work, buf = post(nxt)                          # its owner factors + broadcasts p+1 ...
+                core.trailing_update_range(p, nxt + 1, np_)    # ... while everyone runs the bulk of update p
+            else:
+                work, buf = None, None
         st = core.factor_end()
         return self._reduce_stats(st)
 

@@ -81,6 +81,7 @@ def load_library(path: str | None = None):
         "pyipm_newton_panel_pack": (c_int, [ctxp, c_int64, c_void_p]),
         "pyipm_newton_panel_unpack": (c_int, [ctxp, c_int64, c_void_p]),
         "pyipm_newton_trailing_update": (c_int, [ctxp, c_int64]),
+        "pyipm_newton_trailing_update_range": (c_int, [ctxp, c_int64, c_int64, c_int64]),
         "pyipm_newton_factor_begin": (c_int, [ctxp]),
         "pyipm_newton_factor_end": (c_int, [ctxp, POINTER(FactorStats)]),
         "pyipm_newton_fwd_panel": (c_int, [ctxp, c_int64, c_void_p]),
@@ -273,6 +274,9 @@ class NewtonCore(object):
 
     def trailing_update(self, p):
         self._ck(self.lib.pyipm_newton_trailing_update(self.h, int(p)))
+
+    def trailing_update_range(self, p, first, count):
+        self._ck(self.lib.pyipm_newton_trailing_update_range(self.h, int(p), int(first), int(count)))
 
     def panel_msg_numel(self, p):
         return int(self.lib.pyipm_newton_panel_msg_bytes(self.h, int(p))) // 8

@@ -126,12 +126,15 @@ class ModelCore(object):
         self.W[p], self.L[p] = W, L
 
     def trailing_update(self, p):
+        self.trailing_update_range(p, p + 1, self.npanels)
+
+    def trailing_update_range(self, p, first, count):
         nbw = self.pw(p); c1 = p * self.nb + nbw
         own = p % self.world == self.rank
         L = self.A[:, self.lcol[p]:self.lcol[p] + nbw] if own else self.L[p]
         W = self.W[p]
         for q in self.mine:
-            if q <= p:
+            if q <= p or q < first or q >= first + count:
                 continue
             q0, qw, lq = q * self.nb, self.pw(q), self.lcol[q]
             self.A[q0:, lq:lq + qw] -= L[q0:, :] @ W[q0:q0 + qw, :].T

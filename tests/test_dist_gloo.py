@@ -23,7 +23,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, shape, nb, out):
+def _worker(rank, world, port, shape, nb, lookahead, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -38,6 +38,7 @@ def _worker(rank, world, port, shape, nb, out):
         g = -orc.kkt_residual(qp["df"], qp["Je"], qp["Ji"], qp["ce"], qp["ci"], qp["s"], qp["lam"], qp["mu"], n, me, mi)
         core = ModelCore(n, me, mi, H, g, nb=nb, world=world, rank=rank)
         drv = DistNewton(core)
+        drv.lookahead = lookahead
         dz, st = drv.step(0.0, 0.0)
         ref = orc.flip_multipliers(orc.sym_solve(H, g.reshape(-1, 1)).reshape(-1), n, mi)
         err = float(np.linalg.norm(dz.numpy() - ref) / np.linalg.norm(ref))
@@ -46,14 +47,15 @@ def _worker(rank, world, port, shape, nb, out):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("lookahead", [False, True])
 @pytest.mark.parametrize("world,shape,nb", [(2, (150, 40, 60, 3), 128), (2, (300, 90, 120, 4), 128),
                                             (3, (260, 50, 100, 5), 128), (2, (200, 0, 150, 6), 256)])
-def test_dist_newton_gloo(world, shape, nb):
+def test_dist_newton_gloo(world, shape, nb, lookahead):
     n, me, mi, _ = shape
     N = n + 2 * mi + me
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), shape, nb, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), shape, nb, lookahead, out), nprocs=world, join=True)
     assert len(out) == world
     cols = 0
     for r in range(world):

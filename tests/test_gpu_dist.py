@@ -22,7 +22,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, shape, nb, out):
+def _worker(rank, world, port, shape, nb, lookahead, out):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -37,6 +37,7 @@ def _worker(rank, world, port, shape, nb, out):
         core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
         core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
         drv = DistNewton(core)
+        drv.lookahead = lookahead
         dz, st = drv.step(0.0, 0.0)
         torch.cuda.synchronize()
         out[rank] = (dz.cpu().numpy(), st, core.ncols_local)
@@ -44,15 +45,16 @@ def _worker(rank, world, port, shape, nb, out):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("lookahead", [False, True])
 @pytest.mark.parametrize("world,shape,nb", [(2, (300, 100, 150, 7), 128), (2, (900, 200, 300, 8), 256),
                                             (3, (700, 150, 260, 9), 128), (2, (1400, 0, 400, 10), 128)])
-def test_two_ranks_one_gpu(world, shape, nb):
+def test_two_ranks_one_gpu(world, shape, nb, lookahead):
     import torch.multiprocessing as mp
     n, me, mi, seed = shape
     N = n + 2 * mi + me
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), shape, nb, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), shape, nb, lookahead, out), nprocs=world, join=True)
     qp = make_qp(n, me, mi, seed)
     ref, _, _, _ = orc.newton_step(qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"],
                                    qp["mu"], n, me, mi, regularise=False)
