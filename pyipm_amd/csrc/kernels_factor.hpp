@@ -35,15 +35,36 @@ __device__ __forceinline__ double wave_max(double v) { return __ockl_wfred_max_f
 
 #define PYIPM_BK_ALPHA 0.6403882032022076   /* (1+sqrt(17))/8 */
 
+// f32 wave max with the DPP operand fused into v_max_f32 (6 instructions; magnitudes only steer the
+// pivot choice, the Bunch-Kaufman inequalities are evaluated on the exact f64 values).
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, false)));  // row_shr:1
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, false)));  // row_shr:2
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, false)));  // row_shr:4
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, false)));  // row_shr:8
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x142, 0xa, 0xf, false)));  // row_bcast:15
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x143, 0xc, 0xf, false)));  // row_bcast:31
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+    const long long b = __double_as_longlong(x);
+    return __longlong_as_double(((long long)__builtin_amdgcn_readlane((int)(b >> 32), l) << 32) |
+                                (unsigned int)__builtin_amdgcn_readlane((int)b, l));
+}
+
 __global__ __launch_bounds__(256) void k_tile_invert(
     const double* __restrict__ A, int64_t ld, int64_t grow0, int64_t lcol0,
-    double* __restrict__ Tinv, DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel)
+    double* __restrict__ Tinv, DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel,
+    unsigned long long* __restrict__ dbg)      // diagnostics only (NULL normally)
 {
     __shared__ double stage[TB][TB + 1];
-    __shared__ double rowbuf[2][2][TB];     // [parity][0: row p, 1: row r][column]
+    __shared__ double colbuf[2][2][TB];     // [parity][0: column p, 1: column r][row]  (column == row by symmetry)
     __shared__ double sh_red[4];
+    unsigned long long dbg_c0 = 0, dbg_w0 = 0;
+    if (dbg) { dbg_c0 = clock64(); dbg_w0 = wall_clock64(); }
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, cb = wave * 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cb = wave * 16;
 
     for (int e = tid; e < TB * TB; e += 256) {          // coalesced read of the lower triangle
         const int i = e & 63, j = e >> 6;
@@ -63,45 +84,46 @@ __global__ __launch_bounds__(256) void k_tile_invert(
     __syncthreads();
     const double scale = fmax(fmax(sh_red[0], sh_red[1]), fmax(sh_red[2], sh_red[3]));
     const double pivtol = pivtol_rel * scale;
+    const double inv_scale = scale > 0.0 ? 1.0 / scale : 0.0;
     const double tiny = 2.2250738585072014e-308;
+    const int nreal = (int)((Nreal - grow0) < 0 ? 0 : ((Nreal - grow0) > TB ? TB : (Nreal - grow0)));   // real rows in this tile
 
     unsigned long long mask = ~0ull;        // unswept set (identical in every thread)
     int left = TB, parity = 0;
-    long long neg = 0, zero = 0, n2 = 0, pos = 0, bad = 0;
+    int neg = 0, zero = 0, n2 = 0, bad = 0;
     double dmin = 1.0e308, dmax = 0.0;
+
+    // publish column `col` of the tile (== row `col`) from the wave that holds it: one full-wave store
+#define PYIPM_PUBLISH(col_, dst_)                                                            \
+    if (((col_) >> 4) == wave) {                     /* wave-uniform */                       \
+        const int pc_ = (col_) & 15;                                                         \
+        double v_ = row[0];                                                                  \
+        _Pragma("unroll") for (int c = 1; c < 16; ++c) v_ = (pc_ == c) ? row[c] : v_;        \
+        (dst_)[lane] = v_;                                                                   \
+    }
 
     while (left > 0) {
         const int p = __ffsll(mask) - 1;    // BK candidate: first unswept index (wave-uniform, scalar)
-        if (lane == p) {
-            #pragma unroll
-            for (int c = 0; c < 16; ++c) rowbuf[parity][0][cb + c] = row[c];
-        }
+        PYIPM_PUBLISH(p, colbuf[parity][0])
         __syncthreads();
-        const double* rp = rowbuf[parity][0];
+        const double* rp = colbuf[parity][0];
         const double cpi = rp[lane];        // B[lane][p] (= B[p][lane])
-        double cpj[16];                     // this wave's 16 entries of row p, fetched before the reductions
+        double cpj[16];                     // this wave's 16 entries of row p
         #pragma unroll
         for (int c = 0; c < 16; ++c) cpj[c] = rp[cb + c];
-        // scalars by readlane (no LDS round trip); the reciprocal runs in parallel with the reduction
-        const double dpp = __longlong_as_double(
-            ((long long)__builtin_amdgcn_readlane((int)(__double_as_longlong(cpi) >> 32), p) << 32) |
-            (unsigned int)__builtin_amdgcn_readlane((int)__double_as_longlong(cpi), p));
+        const double dpp = readlane_f64(cpi, p);
         const bool u = (mask >> lane) & 1ull;
-        // lambda = max_{i unswept, i != p} |B[i][p]|, r = lowest index attaining it
-        const double mag = (u && lane != p) ? fabs(cpi) : -1.0;
-        const double lam0 = wave_max(mag);
-        const double lam = (left > 1 && lam0 > 0.0) ? lam0 : 0.0;
-        const unsigned long long hit = __ballot(mag == lam0);
-        const int r = __builtin_amdgcn_readfirstlane(__ffsll(hit) - 1);
+        // r = argmax_{i unswept, i != p} |B[i][p]| chosen on f32 magnitudes scaled by the tile maximum
+        const float magf = (u && lane != p) ? (float)(fabs(cpi) * inv_scale) : -1.0f;
+        const float mx = wave_max_f32(magf);
+        const int r = __builtin_amdgcn_readfirstlane(__ffsll(__ballot(magf == mx)) - 1);
+        const double lam = (left > 1 && mx > 0.0f) ? fabs(readlane_f64(cpi, r)) : 0.0;
         const double app = fabs(dpp);
         int kind = 1, which = 0, piv = p;
         if (lam > 0.0 && app < PYIPM_BK_ALPHA * lam) {          // uniform branch (rare for SPD-like tiles)
-            if (lane == r) {
-                #pragma unroll
-                for (int c = 0; c < 16; ++c) rowbuf[parity][1][cb + c] = row[c];
-            }
+            PYIPM_PUBLISH(r, colbuf[parity][1])
             __syncthreads();
-            const double* rr = rowbuf[parity][1];
+            const double* rr = colbuf[parity][1];
             const double sigma = wave_max((u && lane != r) ? fabs(rr[lane]) : -1.0);
             const double arr = fabs(rr[r]);
             if (app * sigma >= PYIPM_BK_ALPHA * lam * lam) { piv = p; }
@@ -112,53 +134,50 @@ __global__ __launch_bounds__(256) void k_tile_invert(
             double d, ci;
             if (which == 0) { d = dpp; ci = cpi; }
             else {
-                const double* rv = rowbuf[parity][1];
+                const double* rv = colbuf[parity][1];
                 d = rv[piv]; ci = rv[lane];
                 #pragma unroll
                 for (int c = 0; c < 16; ++c) cpj[c] = rv[cb + c];
             }
             const double ad = fabs(d);
-            const bool real = (grow0 + piv) < Nreal;
-            if (!(ad <= 1.0e308)) bad = 1;                       // NaN or Inf
-            if (ad <= pivtol) {
-                if (real) zero++;
+            if (__builtin_expect(!(ad <= 1.0e308), 0)) bad = 1;          // NaN or Inf
+            if (__builtin_expect(ad <= pivtol, 0)) {
+                if (piv < nreal) zero++;
                 const double t = pivtol > 0.0 ? pivtol : tiny;
                 d = (d >= 0.0) ? t : -t;
-            } else if (real) {
-                if (d < 0.0) neg++; else pos++;
+            } else if (piv < nreal) {
+                neg += (d < 0.0) ? 1 : 0;
                 dmin = fmin(dmin, ad); dmax = fmax(dmax, ad);
             }
             const double inv_d = 1.0 / d;
             const double lpi = ci * inv_d;
             const int pw = piv >> 4, pc = piv & 15;              // wave / register holding column piv
-            #pragma unroll
-            for (int c = 0; c < 16; ++c) row[c] = fma(-lpi, cpj[c], row[c]);
-            if (wave == pw) {                                    // wave-uniform: column piv <- lp
-                #pragma unroll
-                for (int c = 0; c < 16; ++c) if (c == pc) row[c] = lpi;
-            }
-            if (lane == piv) {                                   // one lane: row piv <- lp', pivot <- -1/d
+            if (lane == piv) {                                   // one lane: row piv <- cp/d
                 #pragma unroll
                 for (int c = 0; c < 16; ++c) row[c] = cpj[c] * inv_d;
-                if (wave == pw) {
-                    #pragma unroll
-                    for (int c = 0; c < 16; ++c) if (c == pc) row[c] = -inv_d;
-                }
+            } else {
+                #pragma unroll
+                for (int c = 0; c < 16; ++c) row[c] = fma(-lpi, cpj[c], row[c]);
+            }
+            if (wave == pw) {                                    // wave-uniform: column piv <- lp, pivot <- -1/d
+                const double colv = (lane == piv) ? -inv_d : lpi;
+                #pragma unroll
+                for (int c = 0; c < 16; ++c) row[c] = (pc == c) ? colv : row[c];
             }
             mask &= ~(1ull << piv);
             left -= 1;
         } else {
             const int q = r;
-            const double* rq = rowbuf[parity][1];
+            const double* rq = colbuf[parity][1];
             const double a = rp[p], b = rp[q], cc = rq[q];
             double det = a * cc - b * b;                           // < 0 by the BK test
             if (!(fabs(det) <= 1.0e308)) bad = 1;
             const double tr = a + cc, disc = sqrt((a - cc) * (a - cc) + 4.0 * b * b);
             const double e1 = 0.5 * (tr + disc), e2 = 0.5 * (tr - disc);
             n2++;
-            if (fabs(e1) <= pivtol) zero++; else { if (e1 < 0.0) neg++; else pos++;
+            if (fabs(e1) <= pivtol) zero++; else { neg += (e1 < 0.0) ? 1 : 0;
                 dmin = fmin(dmin, fabs(e1)); dmax = fmax(dmax, fabs(e1)); }
-            if (fabs(e2) <= pivtol) zero++; else { if (e2 < 0.0) neg++; else pos++;
+            if (fabs(e2) <= pivtol) zero++; else { neg += (e2 < 0.0) ? 1 : 0;
                 dmin = fmin(dmin, fabs(e2)); dmax = fmax(dmax, fabs(e2)); }
             if (det == 0.0) det = -tiny;
             const double ia = cc / det, ib = -b / det, ic = a / det;   // inverse of [[a,b],[b,cc]]
@@ -182,10 +201,12 @@ __global__ __launch_bounds__(256) void k_tile_invert(
         parity ^= 1;
     }
 
+#undef PYIPM_PUBLISH
     #pragma unroll
     for (int c = 0; c < 16; ++c) Tinv[(cb + c) * TB + lane] = -row[c];
+    if (dbg && tid == 0) { dbg[0] = clock64() - dbg_c0; dbg[1] = wall_clock64() - dbg_w0; dbg[2] += 1; }
     if (tid == 0) {
-        st->n_neg += neg; st->n_zero += zero; st->n_2x2 += n2; st->n_pos += pos;
+        st->n_neg += neg; st->n_zero += zero; st->n_2x2 += n2; st->n_pos += nreal - neg - zero;
         st->nonfinite += bad;
         if (dmin < st->d_min) st->d_min = dmin;
         if (dmax > st->d_max) st->d_max = dmax;
@@ -200,38 +221,48 @@ __global__ __launch_bounds__(256) void k_tile_invert(
 __global__ __launch_bounds__(256) void k_panel_scale(
     double* __restrict__ Aout, int64_t ld_out, int64_t col_out,      // L written at Aout[i + (col_out+c)*ld_out]
     const double* __restrict__ Win, int64_t ld_in, int64_t col_in,   // S read from  Win[i + (col_in+k)*ld_in]
-    double* __restrict__ Wcopy, int64_t ld_w, int64_t col_w,         // copy of S (may be NULL = no copy)
+    double* __restrict__ Wcopy, int64_t ld_w, int64_t col_w,         // copy of -S (may be NULL = no copy)
     const double* __restrict__ Tinv, int64_t row_begin, unsigned long long* __restrict__ growth_bits,
     double sign)      // owner: Win = S, Wcopy = -S (the update kernel wants -W), sign = +1;
                       // non-owner rebuilding L from a received -S: sign = -1
 {
-    __shared__ double T[TB][TB];
+    // L[i][c] = sign * sum_k S[i][k] T[k][c] on fp64 MFMA.  D[m][n]: m <- c (A operand = T, symmetric),
+    // n <- i (B operand = S, read straight from global: 16 lanes x 8 B contiguous per k).  One wave owns
+    // 16 rows x 64 columns (4 accumulator tiles); a 256-thread block covers 64 rows.  ~60 VGPRs, so
+    // several blocks fit in the slot one retiring bulk-update block frees.
+    __shared__ double T[TB][TB + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
     for (int e = tid; e < TB * TB; e += 256) T[e >> 6][e & 63] = sign * Tinv[e];     // symmetric
-    __syncthreads();
-    const int64_t i = row_begin + (int64_t)blockIdx.x * TB + lane;
-    double w[TB];
+    const int64_t i = row_begin + (int64_t)blockIdx.x * TB + wave * 16 + l15;
+    double b[16];
     #pragma unroll
-    for (int k = 0; k < TB; ++k) w[k] = Win[i + (col_in + k) * ld_in];
+    for (int ks = 0; ks < 16; ++ks) b[ks] = Win[i + (col_in + ks * 4 + l4) * ld_in];
     if (Wcopy) {
         #pragma unroll
-        for (int k = 0; k < TB; ++k)
-            if ((k >> 4) == wave) Wcopy[i + (col_w + k) * ld_w] = -w[k];         // wave-uniform branch
+        for (int ks = 0; ks < 16; ++ks) Wcopy[i + (col_w + ks * 4 + l4) * ld_w] = -b[ks];
+    }
+    __syncthreads();
+    double4_t acc[4];
+    #pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    #pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        #pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double a = T[t * 16 + l15][ks * 4 + l4];          // A[m = c][k] = T[c][k]
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[ks], acc[t], 0, 0, 0);
+        }
     }
     double gmax = 0.0;
-    #pragma unroll 4
-    for (int cc = 0; cc < 16; ++cc) {
-        const int c = wave * 16 + cc;
-        double acc0 = 0.0, acc1 = 0.0;
+    #pragma unroll
+    for (int t = 0; t < 4; ++t)
         #pragma unroll
-        for (int k = 0; k < TB; k += 2) {
-            acc0 = fma(w[k], T[c][k], acc0);
-            acc1 = fma(w[k + 1], T[c][k + 1], acc1);
+        for (int r = 0; r < 4; ++r) {
+            const int c = t * 16 + l4 + 4 * r;                       // C/D map: row = (lane>>4)+4r -> c, col = lane&15 -> i
+            Aout[i + (col_out + c) * ld_out] = acc[t][r];
+            gmax = fmax(gmax, fabs(acc[t][r]));
         }
-        const double acc = acc0 + acc1;
-        Aout[i + (col_out + c) * ld_out] = acc;
-        gmax = fmax(gmax, fabs(acc));
-    }
     gmax = wave_max(gmax);
     if (lane == 0 && growth_bits) atomicMax(growth_bits, (unsigned long long)__double_as_longlong(gmax));
 }

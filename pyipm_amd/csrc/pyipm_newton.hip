@@ -161,7 +161,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
             PYIPM_KCHECK();
         }
         hipLaunchKernelGGL(k_tile_invert, dim3(1), dim3(256), 0, stream, ctx->A, g.Npad, j0, lcol,
-                           ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), ctx->dstats, g.N, ctx->pivtol_rel);
+                           ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), ctx->dstats, g.N, ctx->pivtol_rel, ctx->dbg_buf);
         PYIPM_KCHECK();
         const int64_t below = g.Npad - (j0 + TB);
         if (below > 0) {
