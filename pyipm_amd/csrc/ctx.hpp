@@ -73,6 +73,7 @@ struct Ctx {
     int lookahead = 1;
     int group = 1;                        // panels per bulk trailing update
     int xcd_swizzle = 1;
+    int bulk_bn = 128;                    // column width of the bulk-update tile (64: experimental)
     int extra_lds = 0;                    // diagnostics: extra dynamic LDS per update block
     unsigned long long* dbg_buf = nullptr;   // diagnostics only
     int stagger_mode = 1;                 // 0 off, 1 by dispatch index, 2 by hardware wave slot

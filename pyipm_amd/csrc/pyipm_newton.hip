@@ -115,7 +115,19 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     u.stagger_mode = ctx->stagger_mode;
     u.dbg = ctx->dbg_buf;
     u.stagger_ticks = (ctx->stagger_mode && approx_blocks >= 1536.0) ? (int)(ctx->stagger_us_per_k * K * 100.0) : 0;
-    if (ctx->xcd_swizzle && bulk) {
+    if (bulk && ctx->bulk_bn == 64) {
+        // experimental: 128x64 tiles (134 VGPRs -> 3 blocks per CU) for the bulk update
+        u.nct = (int)(n_lp * (g.nb / 64));
+        if (ctx->xcd_swizzle) {
+            const int64_t nsup = upd_super_count<64>(u);
+            if (nsup <= 0) return 0;
+            dim3 grid((unsigned)(((nsup + 7) / 8) * 8 * SUPER * SUPER));
+            hipLaunchKernelGGL((k_update<64, true>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, g.Npad, K, u);
+        } else {
+            dim3 grid((unsigned)u.nrt, (unsigned)u.nct);
+            hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, g.Npad, K, u);
+        }
+    } else if (ctx->xcd_swizzle && bulk) {
         const int64_t nsup = upd_super_count<128>(u);
         if (nsup <= 0) return 0;
         const int64_t rounds = (nsup + 7) / 8;                       // super-tiles per XCD
@@ -775,6 +787,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
         ctx->group = v; return PYIPM_OK; }
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "stagger_mode")) { ctx->stagger_mode = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "bulk_bn")) { ctx->bulk_bn = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "extra_lds")) { ctx->extra_lds = (int)value; return PYIPM_OK; }    // diagnostics: force 1 block/CU
     if (!strcmp(name, "debug_timeline_ptr")) {      // diagnostics: device buffer of 8 x u64 per block (pointer passed as double-encoded integer halves is lossy; use set via low 52 bits)
         ctx->dbg_buf = (unsigned long long*)(uintptr_t)(unsigned long long)value; return PYIPM_OK; }

@@ -1,0 +1,67 @@
+"""BASELINE.json configs[4]: batched independent QPs (multi-start) — replicas, no exchange."""
+import numpy as np
+import pytest
+
+from oracle import newton_oracle as orc
+from pyipm_amd.problems import make_qp
+
+pytestmark = pytest.mark.gpu
+
+
+def _stack(qps, key):
+    return np.stack([q[key] for q in qps])
+
+
+def test_batched_small_vs_oracle():
+    from pyipm_amd.batched import BatchedNewton
+    n, me, mi, B = 48, 8, 24, 20
+    qps = [make_qp(n, me, mi, seed=100 + b) for b in range(B)]
+    bn = BatchedNewton(n, me, mi, workers=4)
+    dz, stats = bn.step_all(_stack(qps, "d2L"), _stack(qps, "Je"), _stack(qps, "Ji"), _stack(qps, "df"),
+                            _stack(qps, "ce"), _stack(qps, "ci"), _stack(qps, "s"), _stack(qps, "lam"), mu=0.2)
+    dz = dz.cpu().numpy()
+    for b, q in enumerate(qps):
+        ref, _, _, _ = orc.newton_step(q["d2L"], q["Je"], q["Ji"], q["df"], q["ce"], q["ci"], q["s"], q["lam"],
+                                       q["mu"], n, me, mi, regularise=False)
+        assert np.linalg.norm(dz[b] - ref) / np.linalg.norm(ref) <= 1e-10
+        assert stats[b]["n_neg"] == me + mi and stats[b]["n_zero"] == 0
+    bn.close()
+
+
+def test_config5_512_problems():
+    """512 independent n=256 QPs with 256 inequalities each (KKT dim 768); every 32nd one against the oracle,
+    all of them through inertia + linear-system residual computed with torch fp64."""
+    import torch
+    from pyipm_amd.batched import BatchedNewton
+    n, me, mi, B = 256, 0, 256, 512
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    f64, dev = torch.float64, "cuda"
+    M = torch.randn(B, n, n, dtype=f64, device=dev, generator=gen)
+    Q = M @ M.transpose(1, 2) / n + torch.eye(n, dtype=f64, device=dev)
+    G = torch.randn(B, mi, n, dtype=f64, device=dev, generator=gen) / np.sqrt(n)
+    c = torch.randn(B, n, dtype=f64, device=dev, generator=gen)
+    s = torch.rand(B, mi, dtype=f64, device=dev, generator=gen) * 1.5 + 0.5
+    lam = torch.rand(B, mi, dtype=f64, device=dev, generator=gen) * 1.5 + 0.5
+    ci = s + 0.1 * torch.randn(B, mi, dtype=f64, device=dev, generator=gen)        # small ci - s residual
+    Ji = G.transpose(1, 2).contiguous()
+    bn = BatchedNewton(n, me, mi, workers=16)
+    dz, stats = bn.step_all(Q, None, Ji, c, None, ci, s, lam, mu=0.2)
+    assert all(st["n_neg"] == mi and st["n_zero"] == 0 for st in stats)
+    eps = np.finfo(float).eps
+    # verify H dz' = g block-wise in torch (dz has the multiplier block sign-flipped: undo it)
+    dx, ds, dl = dz[:, :n], dz[:, n:n + mi], -dz[:, n + mi:]
+    gx = -(c - torch.einsum("bnm,bm->bn", Ji, lam))
+    gs = -(lam - 0.2 / (s + eps))
+    gl = -(ci - s)
+    r1 = torch.einsum("bij,bj->bi", Q, dx) + torch.einsum("bnm,bm->bn", Ji, dl) - gx
+    r2 = lam / (s + eps) * ds - dl - gs
+    r3 = torch.einsum("bnm,bn->bm", Ji, dx) - ds - gl
+    res = torch.sqrt((r1 ** 2).sum(1) + (r2 ** 2).sum(1) + (r3 ** 2).sum(1))
+    nrm = torch.sqrt((gx ** 2).sum(1) + (gs ** 2).sum(1) + (gl ** 2).sum(1))
+    assert float((res / nrm).max()) <= 1e-12
+    for b in range(0, B, 32):
+        ref, _, _, _ = orc.newton_step(Q[b].cpu().numpy(), None, Ji[b].cpu().numpy(), c[b].cpu().numpy(), None,
+                                       ci[b].cpu().numpy(), s[b].cpu().numpy(), lam[b].cpu().numpy(), 0.2, n, me, mi,
+                                       regularise=False)
+        assert np.linalg.norm(dz[b].cpu().numpy() - ref) / np.linalg.norm(ref) <= 1e-10
+    bn.close()

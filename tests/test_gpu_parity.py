@@ -207,3 +207,56 @@ def test_large_roundtrip_properties():
     # sign flip touches exactly the multiplier block
     xf = core.solve(flip=True)
     assert torch.equal(xf[: n + mi], x[: n + mi]) and torch.equal(xf[n + mi:], -x[n + mi:])
+
+
+def test_baseline_config2_exact_vs_oracle():
+    """BASELINE.json configs[1]: synthetic convex QP, n=2048 vars, 2048 ineq (KKT dim 6144), fp64, one GPU.
+    The oracle's LU at this size takes a couple of seconds; dz must agree to <= 1e-10 relative."""
+    n, me, mi = 2048, 0, 2048
+    qp = make_qp(n, me, mi, seed=0)
+    core = _core(n, me, mi)
+    core.stage_blocks(qp["d2L"], None, qp["Ji"])
+    core.stage_vectors(qp["df"], None, qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    dz, st = core.step(0.0, 0.0)
+    ref, _, Hc, g = orc.newton_step(qp["d2L"], None, qp["Ji"], qp["df"], None, qp["ci"], qp["s"], qp["lam"],
+                                    qp["mu"], n, me, mi, regularise=False)
+    assert core.N == 6144 and st["n_neg"] == mi and st["n_zero"] == 0
+    assert relerr(dz.cpu().numpy(), ref) <= TOL_DZ
+    S = core.kkt_storage            # (factor overwrote it) -> re-assemble and compare bit for bit
+    core.assemble(0.0, 0.0)
+    A = core.kkt_storage().cpu().numpy()
+    assert np.array_equal(np.triu(A[:6144, :6144]), np.triu(Hc))
+
+
+def test_baseline_config3_properties():
+    """BASELINE.json configs[2]: n=16384, 8192 eq + 8192 ineq -> KKT dim N = n + 2*mi + me = 40960
+    (the reference formula, pyipm.py:824-825; BASELINE.json's '~49k' is approximate).  13.4 GB of KKT
+    storage: no CPU oracle at this size, so parity is through size-independent properties."""
+    import torch
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_qp_device
+    n, me, mi = 16384, 8192, 8192
+    dev = torch.device("cuda", 0)
+    qp = make_qp_device(n, me, mi, 3, dev)
+    core = _core(n, me, mi)
+    assert core.N == 40960
+    core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    g = core.residual()
+    # residual against a torch fp64 evaluation of the same formula (pyipm.py:655-668)
+    lam = qp["lam"]
+    gx = -(qp["df"] - qp["Je"] @ lam[:me] - qp["Ji"] @ lam[me:])
+    gs = -(lam[me:] - qp["mu"] / (qp["s"] + np.finfo(float).eps))
+    ref_g = torch.cat([gx, gs, -qp["ce"], -(qp["ci"] - qp["s"])])
+    assert float((g - ref_g).norm() / ref_g.norm()) <= 1e-13
+    core.assemble(0.0, 0.0)
+    st = core.factor()
+    assert st["n_neg"] == me + mi and st["n_zero"] == 0 and st["n_pos"] == core.N - me - mi and st["nonfinite"] == 0
+    x = core.solve(flip=False)
+    assert float((core.matvec(x) - g).norm() / g.norm()) <= 1e-11          # backward error via the blocks
+    x1 = core.solve(flip=False, refine=1)
+    assert float((core.matvec(x1) - g).norm() / g.norm()) <= 1e-12
+    assert float((x1 - x).norm() / x.norm()) <= 1e-9
+    dz = core.solve(flip=True)
+    assert torch.equal(dz[: n + mi], x[: n + mi]) and torch.equal(dz[n + mi:], -x[n + mi:])
