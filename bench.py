@@ -90,6 +90,21 @@ def cpu_baseline(sample_n=2048, sample_me=512, sample_mi=768, target_N=32768, re
             "value_no_eigvalsh": 1.0 / (tn * scale)}
 
 
+def pmc_traffic(N, nb):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md; tools/pmc_update.sh,
+    tools/pmc_summary.py).  Counters cannot be collected inside this process, so the figure is attached
+    only for the configuration it was measured on; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r01_g_pmc_update.json")
+    if N != 32768 or nb != 256 or os.environ.get("PYIPM_NEWTON_GROUP") not in (None, "4") or not os.path.exists(path):
+        return None, None
+    try:
+        d = json.load(open(path))
+        return float(d["hbm_bytes_per_launch_corrected"]), "profiles/r01_g_pmc_update.json (separate --pmc passes of this command)"
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,7 +205,9 @@ def main():
                        "pivoting": "Bunch-Kaufman restricted to 64x64 diagonal tiles (block pivots)"},
             "roofline": {"bound": "mfma", "kernel": "k_update<128> (fp64 MFMA trailing rank-nb update)",
                          "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(N, args.nb)[0],
+                         "traffic_unit": "bytes per launch (HBM side, PMC)", "traffic_source": pmc_traffic(N, args.nb)[1],
+                         "algorithmic_bytes_per_launch": None,
                          "launches": n_launch, "avg_launch_ms": trailing_ms / max(n_launch, 1),
                          "flops_per_launch_avg": trailing_flops / max(n_launch, 1),
                          "peak_measured_mfma_only": peak_meas,
@@ -203,6 +220,11 @@ def main():
             "inertia": {"n_neg": st["n_neg"], "expected": me + mi, "n_zero": st["n_zero"], "n_2x2": st["n_2x2"],
                         "growth": st["growth"]},
         }
+        if world == 1 and n_launch:
+            # C-tile read-modify-write (16 B per lower-triangle entry per launch) + the two operand panels once
+            groups = max(1, int(os.environ.get("PYIPM_NEWTON_GROUP", "4")))
+            Kb = groups * args.nb
+            out["roofline"]["algorithmic_bytes_per_launch"] = (trailing_flops / (2.0 * Kb)) * 16.0 / n_launch + 2.0 * 8.0 * Kb * (N / 2.0)
         if args.check and world == 1:
             g = core.residual()
             raw = core.solve(flip=False, refine=args.refine)
