@@ -69,10 +69,15 @@ struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;           // panel lookahead stream (created on first factor)
-    hipEvent_t ev_head = nullptr, ev_panel = nullptr;
+    hipEvent_t ev_head = nullptr, ev_panel = nullptr, ev_fwd = nullptr;
+    hipStream_t fwd = nullptr;            // fused forward-substitution stream
+    std::vector<hipEvent_t> ev_done;      // panel q factored
+    int fuse_forward = 1;
+    bool forward_fused = false;
     int lookahead = 1;
     int group = 1;                        // panels per bulk trailing update
     int xcd_swizzle = 1;
+    int side_prio = 1;                    // raise wave priority in panel-chain update launches
     int bulk_bn = 128;                    // column width of the bulk-update tile (64: experimental)
     int extra_lds = 0;                    // diagnostics: extra dynamic LDS per update block
     unsigned long long* dbg_buf = nullptr;   // diagnostics only

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256) void k_tile_invert(
     __shared__ double sh_red[4];
     unsigned long long dbg_c0 = 0, dbg_w0 = 0;
     if (dbg) { dbg_c0 = clock64(); dbg_w0 = wall_clock64(); }
+    __builtin_amdgcn_s_setprio(3);         // latency-critical chain: win issue arbitration against co-resident bulk waves
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cb = wave * 16;
@@ -231,6 +232,7 @@ __global__ __launch_bounds__(256) void k_panel_scale(
     // 16 rows x 64 columns (4 accumulator tiles); a 256-thread block covers 64 rows.  ~60 VGPRs, so
     // several blocks fit in the slot one retiring bulk-update block frees.
     __shared__ double T[TB][TB + 2];
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     for (int e = tid; e < TB * TB; e += 256) T[e >> 6][e & 63] = sign * Tinv[e];     // symmetric
@@ -285,6 +287,7 @@ struct UpdGeo {
     int nb, world, rank, nrt, nct;         // nrt/nct: row / column tiles of this launch
     int stagger_ticks;                     // >0: delay (100 MHz ticks) applied to half of the first-round blocks
     int stagger_mode;                      // 1: by dispatch index, 2: by hardware wave-slot parity
+    int prio;                              // != 0: raise wave priority (latency-critical panel-chain launches)
     unsigned long long* dbg;               // diagnostics only (NULL in normal operation): per-block timeline
 };
 template <int BN>
@@ -331,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void k_update(
     __shared__ double Ws[2][BKU][WSTR];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (u.prio) __builtin_amdgcn_s_setprio(3);     // panel-chain launches (side stream)
     const int64_t Npad = u.Npad;
     int64_t rt, ct;
     if (SWZ) {

@@ -114,6 +114,7 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     const double approx_blocks = nctd * (double)u.nrt - 0.5 * nctd * nctd;    // tiles on/below the diagonal
     u.stagger_mode = ctx->stagger_mode;
     u.dbg = ctx->dbg_buf;
+    u.prio = bulk ? 0 : ctx->side_prio;
     u.stagger_ticks = (ctx->stagger_mode && approx_blocks >= 1536.0) ? (int)(ctx->stagger_us_per_k * K * 100.0) : 0;
     if (bulk && ctx->bulk_bn == 64) {
         // experimental: 128x64 tiles (134 VGPRs -> 3 blocks per CU) for the bulk update
@@ -166,7 +167,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
             UpdGeo u;
             u.row_begin = row_begin; u.Npad = g.Npad; u.first_lp = lp; u.sub0 = t;
             u.nb = g.nb; u.world = g.world; u.rank = g.rank; u.nrt = (int)(m / BM); u.nct = 1;
-            u.stagger_ticks = 0; u.stagger_mode = 0; u.dbg = nullptr;
+            u.stagger_ticks = 0; u.stagger_mode = 0; u.dbg = nullptr; u.prio = ctx->side_prio;
             dim3 grid((unsigned)(m / BM), 1);
             hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), 0, stream, ctx->A, g.Npad,
                                ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, t * TB, u);
@@ -267,26 +268,28 @@ int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
     return 0;
 }
 
-int fwd_panel(Ctx* ctx, int64_t p, double* v) {
+int fwd_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr) {
+    if (!stream) stream = ctx->stream;
     const Geo& g = ctx->g;
     const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
     const int nbw = (int)g.panel_w(p);
-    hipLaunchKernelGGL(k_fwd_diag, dim3(1), dim3(nbw), nbw * sizeof(double), ctx->stream, ctx->A, g.Npad, lc0, c0, nbw, v);
+    hipLaunchKernelGGL(k_fwd_diag, dim3(1), dim3(nbw), nbw * sizeof(double), stream, ctx->A, g.Npad, lc0, c0, nbw, v);
     PYIPM_KCHECK();
     const int64_t below = g.Npad - (c0 + nbw);
     if (below > 0) {
-        hipLaunchKernelGGL(k_fwd_gemv, grid1(below), dim3(256), nbw * sizeof(double), ctx->stream, ctx->A, g.Npad, lc0, c0,
+        hipLaunchKernelGGL(k_fwd_gemv, grid1(below), dim3(256), nbw * sizeof(double), stream, ctx->A, g.Npad, lc0, c0,
                            nbw, c0 + nbw, g.Npad, v);
         PYIPM_KCHECK();
     }
     return 0;
 }
 
-int diag_panel(Ctx* ctx, int64_t p, double* v) {
+int diag_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr) {
+    if (!stream) stream = ctx->stream;
     const Geo& g = ctx->g;
     const int64_t c0 = g.panel_c0(p);
     const int nbw = (int)g.panel_w(p);
-    hipLaunchKernelGGL(k_diag_apply, dim3(nbw / TB), dim3(64), 0, ctx->stream, ctx->Dinv, c0 / TB, c0, v);
+    hipLaunchKernelGGL(k_diag_apply, dim3(nbw / TB), dim3(64), 0, stream, ctx->Dinv, c0 / TB, c0, v);
     PYIPM_KCHECK();
     return 0;
 }
@@ -310,10 +313,12 @@ int bwd_panel(Ctx* ctx, int64_t p, double* v) {
 }
 
 // x := Hc^{-1} x  in place on an Npad device vector (single-rank path)
-int solve_inplace(Ctx* ctx, double* v) {
+int solve_inplace(Ctx* ctx, double* v, bool forward_done = false) {
     const Geo& g = ctx->g;
-    for (int64_t p = 0; p < g.npanels; ++p) { int rc = fwd_panel(ctx, p, v); if (rc) return rc; }
-    for (int64_t p = 0; p < g.npanels; ++p) { int rc = diag_panel(ctx, p, v); if (rc) return rc; }
+    if (!forward_done) {
+        for (int64_t p = 0; p < g.npanels; ++p) { int rc = fwd_panel(ctx, p, v); if (rc) return rc; }
+        for (int64_t p = 0; p < g.npanels; ++p) { int rc = diag_panel(ctx, p, v); if (rc) return rc; }
+    }
     for (int64_t p = g.npanels - 1; p >= 0; --p) { int rc = bwd_panel(ctx, p, v); if (rc) return rc; }
     return 0;
 }
@@ -401,7 +406,7 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
 // read-modify-write traffic (the HBM bound of the rank-nb update) by `group`.  One-group lookahead: while
 // the bulk update of group g runs on the main stream, group g+1 (already updated by a head launch) is
 // factored on a second stream.
-int factor_all(Ctx* ctx, pyipm_factor_stats* stats) {
+int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     const Geo& g = ctx->g;
     if (g.world != 1) { ctx->err = "factor(): single-rank entry point; use the per-panel phases when world > 1"; return PYIPM_E_BADARG; }
     if (!ctx->assembled) { ctx->err = "factor: assemble first"; return PYIPM_E_BADARG; }
@@ -417,21 +422,51 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats) {
     const int64_t np = g.npanels, G = ctx->group;
     const int64_t ngroups = (np + G - 1) / G;
     auto gsize = [&](int64_t grp) { int64_t a = grp * G, b = a + G; if (b > np) b = np; return b - a; };
-    for (int64_t q = 0; q < gsize(0); ++q) { rc = factor_panel(ctx, q, ctx->stream, true); if (rc) return rc; }
+    // Fused forward substitution: y_p only needs panel p factored, so the forward pass of the step's
+    // right-hand side (already in v0) trails the factorisation on its own stream.
+    ctx->forward_fused = false;
+    if (fuse_forward) {
+        if (!ctx->fwd) PYIPM_HIP(hipStreamCreateWithFlags(&ctx->fwd, hipStreamNonBlocking));
+        while ((int64_t)ctx->ev_done.size() < np) { hipEvent_t e; PYIPM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_done.push_back(e); }
+        PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));          // v0 = rhs copy was enqueued on the main stream
+        PYIPM_HIP(hipStreamWaitEvent(ctx->fwd, ctx->ev_head, 0));
+    }
+    auto after_panel = [&](int64_t q, hipStream_t used) -> int {
+        if (!fuse_forward) return 0;
+        PYIPM_HIP(hipEventRecord(ctx->ev_done[q], used));
+        PYIPM_HIP(hipStreamWaitEvent(ctx->fwd, ctx->ev_done[q], 0));
+        int r2 = fwd_panel(ctx, q, ctx->v0, ctx->fwd); if (r2) return r2;
+        return diag_panel(ctx, q, ctx->v0, ctx->fwd);
+    };
+    for (int64_t q = 0; q < gsize(0); ++q) {
+        rc = factor_panel(ctx, q, ctx->stream, true); if (rc) return rc;
+        rc = after_panel(q, ctx->stream); if (rc) return rc;
+    }
     for (int64_t grp = 0; grp + 1 < ngroups; ++grp) {
         const int64_t p0 = grp * G, n0 = gsize(grp), p1 = p0 + n0, n1 = gsize(grp + 1);
         if (ctx->lookahead) {
             rc = timed_update(ctx, p0, n0, p1, n1); if (rc) return rc;                 // head: next group's columns
             PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
             PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_head, 0));
-            for (int64_t q = p1; q < p1 + n1; ++q) { rc = factor_panel(ctx, q, ctx->side, true); if (rc) return rc; }
+            for (int64_t q = p1; q < p1 + n1; ++q) {
+                rc = factor_panel(ctx, q, ctx->side, true); if (rc) return rc;
+                rc = after_panel(q, ctx->side); if (rc) return rc;
+            }
             PYIPM_HIP(hipEventRecord(ctx->ev_panel, ctx->side));
             rc = timed_update(ctx, p0, n0, p1 + n1, np - (p1 + n1)); if (rc) return rc;   // bulk (overlaps the side stream)
             PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
         } else {
             rc = timed_update(ctx, p0, n0, p1, np - p1); if (rc) return rc;
-            for (int64_t q = p1; q < p1 + n1; ++q) { rc = factor_panel(ctx, q, ctx->stream, true); if (rc) return rc; }
+            for (int64_t q = p1; q < p1 + n1; ++q) {
+                rc = factor_panel(ctx, q, ctx->stream, true); if (rc) return rc;
+                rc = after_panel(q, ctx->stream); if (rc) return rc;
+            }
         }
+    }
+    if (fuse_forward) {                     // join: the main stream continues after the forward pass
+        PYIPM_HIP(hipEventRecord(ctx->ev_fwd, ctx->fwd));
+        PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fwd, 0));
+        ctx->forward_fused = true;
     }
     PYIPM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->assembled = false;                 // storage now holds the factor
@@ -482,7 +517,8 @@ int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t m
     ctx->ws_bytes = need;
     carve_workspace(ctx, ctx->g, ctx->ws);
     for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return PYIPM_E_HIP; }
-    if (hipEventCreateWithFlags(&ctx->ev_head, hipEventDisableTiming) != hipSuccess ||
+    if (hipEventCreateWithFlags(&ctx->ev_fwd, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_head, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_panel, hipEventDisableTiming) != hipSuccess) { delete ctx; return PYIPM_E_HIP; }
     *out = reinterpret_cast<pyipm_newton_ctx*>(ctx);
     return PYIPM_OK;
@@ -498,6 +534,9 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) {
     if (ctx->ev_head) hipEventDestroy(ctx->ev_head);
     if (ctx->ev_panel) hipEventDestroy(ctx->ev_panel);
     if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
+    if (ctx->fwd) { hipStreamSynchronize(ctx->fwd); hipStreamDestroy(ctx->fwd); }
+    if (ctx->ev_fwd) hipEventDestroy(ctx->ev_fwd);
+    for (auto e : ctx->ev_done) hipEventDestroy(e);
     if (ctx->stg_d2L) hipFree(ctx->stg_d2L);
     if (ctx->stg_Je) hipFree(ctx->stg_Je);
     if (ctx->stg_Ji) hipFree(ctx->stg_Ji);
@@ -589,15 +628,9 @@ int pyipm_newton_factor(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
     return factor_all(ctx, stats);
 }
 
-int pyipm_newton_solve(pyipm_newton_ctx* h, const double* rhs, double* dz, int flip, int refine, int memkind) {
-    if (check_ctx(h)) return PYIPM_E_BADARG;
-    Ctx* ctx = C(h); const Geo& g = ctx->g;
-    PYIPM_HIP(hipSetDevice(ctx->device));
-    if (g.world != 1) { ctx->err = "solve(): single-rank entry point"; return PYIPM_E_BADARG; }
-    if (!ctx->factored) { ctx->err = "solve: factor first"; return PYIPM_E_BADARG; }
-    if (!dz) { ctx->err = "solve: null output"; return PYIPM_E_BADARG; }
-    PYIPM_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-    // b -> v1 (kept for refinement), x -> v0
+// load the right-hand side into v1 (kept for refinement) and v0 (solved in place)
+static int solve_prepare(Ctx* ctx, const double* rhs, int memkind) {
+    const Geo& g = ctx->g;
     if (rhs) {
         hipLaunchKernelGGL(k_fill, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v1, 0.0, g.Npad); PYIPM_KCHECK();
         int rc = put_vec(ctx, ctx->v1, rhs, g.N, memkind); if (rc) return rc;
@@ -606,7 +639,12 @@ int pyipm_newton_solve(pyipm_newton_ctx* h, const double* rhs, double* dz, int f
         PYIPM_HIP(hipMemcpyAsync(ctx->v1, ctx->rhs, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     }
     PYIPM_HIP(hipMemcpyAsync(ctx->v0, ctx->v1, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    int rc = solve_inplace(ctx, ctx->v0); if (rc) return rc;
+    return 0;
+}
+
+static int solve_finish(Ctx* ctx, double* dz, int flip, int refine, int memkind, bool forward_done) {
+    const Geo& g = ctx->g;
+    int rc = solve_inplace(ctx, ctx->v0, forward_done); if (rc) return rc;
     for (int it = 0; it < refine; ++it) {
         // r = b - Hc x ;  x += Hc^{-1} r      (Hc applied from the blocks, not from the factor)
         rc = kkt_matvec_dev(ctx, ctx->v0, ctx->v2); if (rc) return rc;
@@ -626,6 +664,18 @@ int pyipm_newton_solve(pyipm_newton_ctx* h, const double* rhs, double* dz, int f
     return PYIPM_OK;
 }
 
+int pyipm_newton_solve(pyipm_newton_ctx* h, const double* rhs, double* dz, int flip, int refine, int memkind) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    if (g.world != 1) { ctx->err = "solve(): single-rank entry point"; return PYIPM_E_BADARG; }
+    if (!ctx->factored) { ctx->err = "solve: factor first"; return PYIPM_E_BADARG; }
+    if (!dz) { ctx->err = "solve: null output"; return PYIPM_E_BADARG; }
+    PYIPM_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    int rc = solve_prepare(ctx, rhs, memkind); if (rc) return rc;
+    return solve_finish(ctx, dz, flip, refine, memkind, false);
+}
+
 int pyipm_newton_kkt_matvec(pyipm_newton_ctx* h, const double* v, double* y, int memkind) {
     if (check_ctx(h) || !v || !y) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
@@ -641,10 +691,15 @@ int pyipm_newton_step(pyipm_newton_ctx* h, double delta, double delta_c, int ref
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     PYIPM_HIP(hipSetDevice(ctx->device));
+    if (!dz) { ctx->err = "step: null output"; return PYIPM_E_BADARG; }
     int rc = residual_dev(ctx); if (rc) return rc;
     rc = pyipm_newton_assemble(h, delta, delta_c); if (rc) return rc;
-    rc = factor_all(ctx, stats); if (rc) return rc;
-    return pyipm_newton_solve(h, nullptr, dz, 1, refine, memkind);
+    const bool fuse = ctx->fuse_forward != 0;
+    if (fuse) { rc = solve_prepare(ctx, nullptr, memkind); if (rc) return rc; }     // v0 = v1 = g before factoring
+    rc = factor_all(ctx, stats, fuse); if (rc) return rc;
+    PYIPM_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+    if (!fuse) { rc = solve_prepare(ctx, nullptr, memkind); if (rc) return rc; }
+    return solve_finish(ctx, dz, 1, refine, memkind, fuse && ctx->forward_fused);
 }
 
 // ---- per-panel phases -----------------------------------------------------------------------------
@@ -787,6 +842,8 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
         ctx->group = v; return PYIPM_OK; }
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "stagger_mode")) { ctx->stagger_mode = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "fuse_forward")) { ctx->fuse_forward = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "side_prio")) { ctx->side_prio = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "bulk_bn")) { ctx->bulk_bn = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "extra_lds")) { ctx->extra_lds = (int)value; return PYIPM_OK; }    // diagnostics: force 1 block/CU
     if (!strcmp(name, "debug_timeline_ptr")) {      // diagnostics: device buffer of 8 x u64 per block (pointer passed as double-encoded integer halves is lossy; use set via low 52 bits)
