@@ -74,7 +74,9 @@ struct Ctx {
     std::vector<hipEvent_t> ev_done;      // panel q factored
     int fuse_forward = 1;
     bool forward_fused = false;
-    int lookahead = 1;
+    int lookahead = 1;                    // 0 none, 1 one group (default), 2 two groups (dedicated bulk stream; measured no faster)
+    hipStream_t bulk = nullptr;
+    std::vector<hipEvent_t> ev_grp;       // [2g] group g factored, [2g+1] bulk update of group g done
     int group = 1;                        // panels per bulk trailing update
     int xcd_swizzle = 1;
     int side_prio = 1;                    // raise wave priority in panel-chain update launches

@@ -17,7 +17,7 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
     Carve cv;
     const size_t D = sizeof(double);
     const size_t oA = cv.take((size_t)g.Npad * (size_t)(g.ncols_local > 0 ? g.ncols_local : 1) * D);
-    const size_t oW = cv.take(2 * (size_t)default_group(g.world) * (size_t)g.Npad * g.nb * D);   // -W of a panel group, double-buffered for lookahead
+    const size_t oW = cv.take(3 * (size_t)default_group(g.world) * (size_t)g.Npad * g.nb * D);   // -W of a panel group, triple-buffered (2-deep lookahead)
     const size_t oL = cv.take(g.world > 1 ? (size_t)g.Npad * g.nb * D : 256);
     const size_t oD = cv.take((size_t)(g.Npad / TB) * TB * TB * D);
     const size_t orhs = cv.take((size_t)g.Npad * D);
@@ -94,7 +94,7 @@ inline dim3 grid1(int64_t n, int b = 256) { return dim3((unsigned)((n + b - 1) /
 // -W columns of panel p: the buffer of its group (parity-alternating) + its offset inside the group
 inline double* wbuf(Ctx* ctx, int64_t p) {
     const int64_t G = ctx->group, grp = p / G;
-    return ctx->Wbuf + ((grp & 1) * G + (p % G)) * ctx->g.Npad * (int64_t)ctx->g.nb;
+    return ctx->Wbuf + ((grp % 3) * G + (p % G)) * ctx->g.Npad * (int64_t)ctx->g.nb;
 }
 
 // ---- per-panel building blocks -----------------------------------------------------------------
@@ -189,8 +189,9 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
 
 // One bulk k_update<128> launch: panels [p0, p0+np) (contiguous, same rank) applied with K = their total
 // width to local panels [first_lp, first_lp+n_lp); timed with HIP events on the handle's stream.
-int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_lp) {
+int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_lp, hipStream_t stream = nullptr) {
     const Geo& g = ctx->g;
+    if (!stream) stream = ctx->stream;
     if (n_lp <= 0) return 0;
     int K = 0;
     for (int64_t q = p0; q < p0 + np; ++q) K += (int)g.panel_w(q);
@@ -207,11 +208,11 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
             ctx->ev_trailing.push_back({a, b});
         }
         e0 = ctx->ev_trailing[ctx->n_trailing].first; e1 = ctx->ev_trailing[ctx->n_trailing].second;
-        PYIPM_HIP(hipEventRecord(e0, ctx->stream));
+        PYIPM_HIP(hipEventRecord(e0, stream));
     }
-    int rc = launch_update128(ctx, ctx->stream, Lop, g.Npad, wbuf(ctx, p0), K, row_begin, first_lp, n_lp);
+    int rc = launch_update128(ctx, stream, Lop, g.Npad, wbuf(ctx, p0), K, row_begin, first_lp, n_lp);
     if (rc) return rc;
-    if (ctx->profile) PYIPM_HIP(hipEventRecord(e1, ctx->stream));
+    if (ctx->profile) PYIPM_HIP(hipEventRecord(e1, stream));
     // algorithmic flops of this launch: 2*K per lower-triangle entry of the updated local columns
     double fl = 0.0;
     for (int64_t k = 0; k < n_lp; ++k) {
@@ -442,6 +443,44 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         rc = factor_panel(ctx, q, ctx->stream, true); if (rc) return rc;
         rc = after_panel(q, ctx->stream); if (rc) return rc;
     }
+    if (ctx->lookahead >= 2 && ngroups >= 3) {
+        // 2-deep lookahead.  U(g,h) = update of group h's columns with group g.  Per group g:
+        //   main : H(g)  = U(g,g+1)            -> side: F(g+1)   (the latency-bound chain)
+        //   main : B1(g) = U(g,g+2)            (next head's columns; waits for B2(g-1), which also touched them)
+        //   bulk : B2(g) = U(g,g+3..)          (everything else, back-to-back on its own stream)
+        // The chain runs a full group ahead of the bulk stream, which is never idle while it has work.
+        if (!ctx->bulk) PYIPM_HIP(hipStreamCreateWithFlags(&ctx->bulk, hipStreamNonBlocking));
+        while ((int64_t)ctx->ev_grp.size() < 2 * ngroups) { hipEvent_t e; PYIPM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_grp.push_back(e); }
+        auto evF = [&](int64_t grp) { return ctx->ev_grp[2 * grp]; };
+        auto evB2 = [&](int64_t grp) { return ctx->ev_grp[2 * grp + 1]; };
+        std::vector<char> hasB2(ngroups, 0);
+        PYIPM_HIP(hipEventRecord(evF(0), ctx->stream));
+        for (int64_t grp = 0; grp + 1 < ngroups; ++grp) {
+            const int64_t p0 = grp * G, n0 = gsize(grp), p1 = p0 + n0, n1 = gsize(grp + 1);
+            const int64_t p2 = p1 + n1, n2 = (grp + 2 < ngroups) ? gsize(grp + 2) : 0, p3 = p2 + n2;
+            rc = timed_update(ctx, p0, n0, p1, n1); if (rc) return rc;                      // H(g)
+            PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
+            PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_head, 0));
+            for (int64_t q = p1; q < p1 + n1; ++q) {                                        // F(g+1)
+                rc = factor_panel(ctx, q, ctx->side, true); if (rc) return rc;
+                rc = after_panel(q, ctx->side); if (rc) return rc;
+            }
+            PYIPM_HIP(hipEventRecord(evF(grp + 1), ctx->side));
+            if (n2 > 0) {                                                                   // B1(g)
+                if (grp >= 1 && hasB2[grp - 1]) PYIPM_HIP(hipStreamWaitEvent(ctx->stream, evB2(grp - 1), 0));
+                rc = timed_update(ctx, p0, n0, p2, n2); if (rc) return rc;
+            }
+            if (p3 < np) {                                                                  // B2(g)
+                PYIPM_HIP(hipStreamWaitEvent(ctx->bulk, evF(grp), 0));
+                rc = timed_update(ctx, p0, n0, p3, np - p3, ctx->bulk); if (rc) return rc;
+                PYIPM_HIP(hipEventRecord(evB2(grp), ctx->bulk));
+                hasB2[grp] = 1;
+            }
+            PYIPM_HIP(hipStreamWaitEvent(ctx->stream, evF(grp + 1), 0));
+        }
+        for (int64_t grp = 0; grp < ngroups; ++grp)                                         // join the bulk stream
+            if (hasB2[grp]) PYIPM_HIP(hipStreamWaitEvent(ctx->stream, evB2(grp), 0));
+    } else
     for (int64_t grp = 0; grp + 1 < ngroups; ++grp) {
         const int64_t p0 = grp * G, n0 = gsize(grp), p1 = p0 + n0, n1 = gsize(grp + 1);
         if (ctx->lookahead) {
@@ -486,7 +525,7 @@ extern "C" {
 size_t pyipm_newton_workspace_bytes(int64_t n, int64_t me, int64_t mi, int nb, int world, int rank) {
     if (n <= 0 || me < 0 || mi < 0 || world < 1 || rank < 0 || rank >= world) return 0;
     if (nb == 0) nb = 256;
-    if (nb % 128 != 0 || nb > 512) return 0;
+    if (nb % 128 != 0 || nb > 1024) return 0;
     Geo g = make_geo(n, me, mi, nb, world, rank);
     return carve_workspace(nullptr, g, nullptr);
 }
@@ -497,7 +536,7 @@ int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t m
     *out = nullptr;
     if (n <= 0 || me < 0 || mi < 0 || world < 1 || rank < 0 || rank >= world) return PYIPM_E_BADARG;
     if (nb == 0) nb = 256;
-    if (nb % 128 != 0 || nb > 512) return PYIPM_E_BADARG;
+    if (nb % 128 != 0 || nb > 1024) return PYIPM_E_BADARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PYIPM_E_NODEVICE;
     Ctx* ctx = new Ctx();
@@ -535,6 +574,8 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) {
     if (ctx->ev_panel) hipEventDestroy(ctx->ev_panel);
     if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
     if (ctx->fwd) { hipStreamSynchronize(ctx->fwd); hipStreamDestroy(ctx->fwd); }
+    if (ctx->bulk) { hipStreamSynchronize(ctx->bulk); hipStreamDestroy(ctx->bulk); }
+    for (auto e : ctx->ev_grp) hipEventDestroy(e);
     if (ctx->ev_fwd) hipEventDestroy(ctx->ev_fwd);
     for (auto e : ctx->ev_done) hipEventDestroy(e);
     if (ctx->stg_d2L) hipFree(ctx->stg_d2L);
