@@ -69,6 +69,14 @@ def cpu_baseline(sample_n=2048, sample_me=512, sample_mi=768, target_N=32768, re
         blas = ";".join(sorted(set("%s %s" % (i.get("internal_api"), i.get("version")) for i in info)))
     except Exception:
         threads, blas = os.cpu_count() or 1, "unknown"
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
     qp = make_qp(sample_n, sample_me, sample_mi, seed=0)
     Ns = sample_n + 2 * sample_mi + sample_me
     args = (qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], qp["mu"],
@@ -84,8 +92,8 @@ def cpu_baseline(sample_n=2048, sample_me=512, sample_mi=768, target_N=32768, re
             "sample": ("oracle/newton_oracle.py (NumPy assembly + scipy eigvalsh(H,I) + scipy LU solve + flip, "
                        "reference path of pyipm.py:1717-1725) at N=%d (n=%d,me=%d,mi=%d): %.3f s/step median of %d "
                        "(%.3f s without the eigvalsh inertia test); value = N^3 extrapolation x%.0f to N=%d; "
-                       "BLAS: %s, %d threads, %d host cores" % (Ns, sample_n, sample_me, sample_mi, tf, reps, tn,
-                                                                 scale, target_N, blas, threads, os.cpu_count() or 0)),
+                       "host CPU: %s; BLAS: %s, %d threads, %d host cores" % (Ns, sample_n, sample_me, sample_mi, tf, reps, tn,
+                                                                 scale, target_N, cpu_model, blas, threads, os.cpu_count() or 0)),
             "measured_N": Ns, "measured_s_per_step": tf, "measured_s_per_step_no_eigvalsh": tn,
             "value_no_eigvalsh": 1.0 / (tn * scale)}
 

@@ -1,0 +1,93 @@
+"""The C-ABI used the way INTEGRATION.md's reference-side stub uses it: plain ctypes, NumPy HOST
+pointers (PYIPM_MEM_HOST), library-owned workspace (workspace = NULL), no torch tensors at all."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from oracle import newton_oracle as orc
+from pyipm_amd.problems import make_qp
+
+pytestmark = pytest.mark.gpu
+HOST = 1
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def test_host_pointer_step_matches_oracle():
+    from pyipm_amd import newton
+    lib = newton.load_library()
+    n, me, mi = 200, 60, 90
+    N = n + 2 * mi + me
+    qp = make_qp(n, me, mi, seed=31)
+    h = ctypes.c_void_p()
+    assert lib.pyipm_newton_create(ctypes.byref(h), n, me, mi, 256, 0, 1, 0, None, 0, None) == 0
+    d2L = np.ascontiguousarray(qp["d2L"]); Je = np.ascontiguousarray(qp["Je"]); Ji = np.ascontiguousarray(qp["Ji"])
+    # a padded leading dimension on the host side must be honoured
+    Jpad = np.zeros((n, mi + 7)); Jpad[:, :mi] = Ji
+    assert lib.pyipm_newton_stage_blocks(h, _p(d2L), n, _p(Je), me, _p(Jpad), mi + 7, HOST) == 0
+    assert lib.pyipm_newton_stage_vectors(h, _p(qp["df"]), _p(qp["ce"]), _p(qp["ci"]), _p(qp["s"]), _p(qp["lam"]),
+                                          0.2, float(np.finfo(float).eps), HOST) == 0
+    g = np.empty(N)
+    assert lib.pyipm_newton_residual(h, _p(g), HOST) == 0
+    assert lib.pyipm_newton_assemble(h, 0.0, 0.0) == 0
+    st = newton.FactorStats()
+    assert lib.pyipm_newton_factor(h, ctypes.byref(st)) == 0
+    dz = np.empty(N)
+    assert lib.pyipm_newton_solve(h, None, _p(dz), 1, 0, HOST) == 0
+    ref, _, Hc, gref = orc.newton_step(qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"],
+                                       qp["mu"], n, me, mi, regularise=False)
+    np.testing.assert_allclose(g, gref, rtol=0, atol=1e-13 * np.abs(gref).max())
+    assert np.linalg.norm(dz - ref) / np.linalg.norm(ref) <= 1e-10
+    assert st.n_neg == me + mi and st.n_zero == 0
+    # explicit right-hand side from host memory, no flip; and the block mat-vec
+    b = np.random.default_rng(0).standard_normal(N)
+    x = np.empty(N)
+    assert lib.pyipm_newton_solve(h, _p(b), _p(x), 0, 1, HOST) == 0
+    assert np.linalg.norm(Hc @ x - b) <= 1e-12 * np.linalg.norm(b)
+    y = np.empty(N)
+    assert lib.pyipm_newton_kkt_matvec(h, _p(x), _p(y), HOST) == 0
+    np.testing.assert_allclose(y, Hc @ x, rtol=0, atol=1e-12 * np.abs(Hc @ x).max())
+    # fused convenience entry point
+    dz2 = np.empty(N)
+    assert lib.pyipm_newton_step(h, 0.0, 0.0, 0, _p(dz2), ctypes.byref(st), HOST) == 0
+    assert np.linalg.norm(dz2 - ref) / np.linalg.norm(ref) <= 1e-10
+    assert lib.pyipm_newton_destroy(h) == 0
+
+
+def test_error_codes_and_call_order():
+    from pyipm_amd import newton
+    lib = newton.load_library()
+    h = ctypes.c_void_p()
+    assert lib.pyipm_newton_create(ctypes.byref(h), 0, 0, 0, 256, 0, 1, 0, None, 0, None) == -1      # n must be > 0
+    assert lib.pyipm_newton_create(ctypes.byref(h), 8, 0, 0, 96, 0, 1, 0, None, 0, None) == -1       # nb multiple of 128
+    assert lib.pyipm_newton_create(ctypes.byref(h), 8, 0, 0, 256, 99, 1, 0, None, 0, None) == -5     # no such device
+    assert lib.pyipm_newton_create(ctypes.byref(h), 8, 2, 3, 256, 0, 1, 0, None, 0, None) == 0
+    assert lib.pyipm_newton_assemble(h, 0.0, 0.0) == -1                                              # nothing staged yet
+    assert b"stage" in lib.pyipm_newton_last_error(h)
+    st = newton.FactorStats()
+    assert lib.pyipm_newton_factor(h, ctypes.byref(st)) == -1                                        # not assembled
+    x = np.zeros(8 + 6 + 2)
+    assert lib.pyipm_newton_solve(h, None, _p(x), 1, 0, HOST) == -1                                  # not factored
+    assert lib.pyipm_newton_set_option(h, b"no_such_option", 1.0) == -1
+    assert lib.pyipm_newton_destroy(h) == 0
+
+
+def test_nonfinite_is_reported():
+    from pyipm_amd import newton
+    lib = newton.load_library()
+    n = 16
+    h = ctypes.c_void_p()
+    assert lib.pyipm_newton_create(ctypes.byref(h), n, 0, 0, 256, 0, 1, 0, None, 0, None) == 0
+    Q = np.eye(n); Q[3, 5] = np.nan
+    df = np.ones(n)
+    assert lib.pyipm_newton_stage_blocks(h, _p(Q), n, None, 1, None, 1, HOST) == 0
+    assert lib.pyipm_newton_stage_vectors(h, _p(df), None, None, None, None, 0.2, 2.2e-16, HOST) == 0
+    assert lib.pyipm_newton_assemble(h, 0.0, 0.0) == 0
+    st = newton.FactorStats()
+    assert lib.pyipm_newton_factor(h, ctypes.byref(st)) == -4
+    assert st.nonfinite != 0
+    assert lib.pyipm_newton_destroy(h) == 0

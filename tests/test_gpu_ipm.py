@@ -70,3 +70,17 @@ def test_qp_solve_medium():
     assert all(np.linalg.norm(k) <= 1e-6 for k in kkt)
     assert np.all(s > 0) and np.all(lda[40:] > -1e-12)
     assert np.linalg.norm(qp["A"] @ x - qp["b"]) <= 1e-6 and np.min(qp["G"] @ x - qp["h"]) >= -1e-6
+
+
+def test_cli_problem7(capsys):
+    """BASELINE.json configs[0]: the `python pyipm.py 7` plumbing run, here `python -m pyipm_amd 7 <seed>`."""
+    from pyipm_amd.__main__ import main
+    assert main(["7", "3"]) == 0
+    out = capsys.readouterr().out.splitlines()
+    assert out[0] == "Searching for a feasible local minimizer using the exact Hessian."
+    assert out[1] == "OUTER ITERATION 1" and out[2] == "* INNER ITERATION 1"
+    conv = [l for l in out if l.startswith("Converged to Ktol tolerance")]
+    assert conv and conv[0].endswith("total).")
+    sol = [l for l in out if l.startswith("Solver solution")][0]
+    vals = np.array([float(v) for v in sol.split("[")[1].rstrip("]").split(",")])
+    assert np.linalg.norm(vals - 1.0 / 3.0) <= 1e-3
