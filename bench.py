@@ -222,6 +222,13 @@ def main():
                          "frac_of_measured_peak": (ach / peak_meas) if peak_meas else None},
             "phases_ms_per_step": {"assemble": assemble_ms / K, "panel(tile+scale+in-panel)": panel_ms / K,
                                    "trailing": trailing_ms / K, "solve": solve_ms / K},
+            "hbm_bound_kernels": {
+                "assemble_K1": {"algorithmic_bytes": 4.0 * N * N + 8.0 * (n * n / 2.0 + n * me + n * mi),
+                                "GB_per_s": (4.0 * N * N + 8.0 * (n * n / 2.0 + n * me + n * mi)) / max(assemble_ms / K, 1e-9) / 1e6,
+                                "peak_GB_per_s": 8000.0},
+                "solve_K5_exposed": {"note": "forward pass is fused under the factorisation; exposed part = block-diagonal + backward",
+                                     "algorithmic_bytes_total_solve": 8.0 * N * N, "exposed_ms": solve_ms / K},
+            },
             "step_flops_algorithmic": N ** 3 / 3.0 + 2.0 * N ** 2,
             "step_tflops": (N ** 3 / 3.0 + 2.0 * N ** 2) / (elapsed / K) / 1e12,
             "step_frac_of_peak": (N ** 3 / 3.0 + 2.0 * N ** 2) / (elapsed / K) / 1e12 / (FP64_MFMA_PEAK_TFLOPS * world),

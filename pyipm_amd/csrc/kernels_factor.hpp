@@ -288,6 +288,7 @@ struct UpdGeo {
     int stagger_ticks;                     // >0: delay (100 MHz ticks) applied to half of the first-round blocks
     int stagger_mode;                      // 1: by dispatch index, 2: by hardware wave-slot parity
     int prio;                              // != 0: raise wave priority (latency-critical panel-chain launches)
+    int rt_min0, rt_step;                  // first row tile on/below the diagonal for super-column sJ = rt_min0 + sJ*rt_step (tiles)
     unsigned long long* dbg;               // diagnostics only (NULL in normal operation): per-block timeline
 };
 template <int BN>
@@ -300,20 +301,29 @@ __host__ __device__ inline void upd_col(const UpdGeo& u, int64_t ct, int64_t& jg
     jloc = lp * (int64_t)u.nb + (int64_t)sub * BN;
 }
 constexpr int SUPER = 8;
-template <int BN>
-__host__ __device__ inline int64_t upd_super_min_row(const UpdGeo& u, int sJ) {
-    int64_t jg, jl;
-    upd_col<BN>(u, (int64_t)sJ * SUPER, jg, jl);
-    int64_t rt_min = (jg - u.row_begin) / BM;            // first row tile with i0 + BM > jg
+// First super-row that holds a tile on/below the diagonal, for super-column sJ.  Division-free: the
+// host fills (rt_min0, rt_step) -- the first valid row TILE is affine in sJ because a super-column of 8
+// column tiles always spans whole panels (launches use the swizzled order only when nb/BN divides 8).
+__host__ __device__ inline int upd_super_min_row(const UpdGeo& u, int sJ) {
+    int rt_min = u.rt_min0 + sJ * u.rt_step;
     if (rt_min < 0) rt_min = 0;
-    return rt_min / SUPER;
+    return rt_min >> 3;                                  // / SUPER
 }
+template <int BN>
+inline void upd_fill_affine(UpdGeo& u) {
+    int64_t jg0, jl0;
+    upd_col<BN>(u, 0, jg0, jl0);
+    u.rt_min0 = (int)((jg0 - u.row_begin) / BM);         // may be negative (columns left of the row range)
+    u.rt_step = SUPER * BN * u.world / BM;               // tiles per super-column step
+}
+template <int BN>
+inline bool upd_swizzle_ok(const UpdGeo& u) { const int tpp = u.nb / BN; return tpp >= 1 && (SUPER % tpp) == 0; }
 template <int BN>
 inline int64_t upd_super_count(const UpdGeo& u) {
     const int nsr = (u.nrt + SUPER - 1) / SUPER, nsc = (u.nct + SUPER - 1) / SUPER;
     int64_t tot = 0;
     for (int sJ = 0; sJ < nsc; ++sJ) {
-        const int64_t mn = upd_super_min_row<BN>(u, sJ);
+        const int mn = upd_super_min_row(u, sJ);
         if (mn < nsr) tot += nsr - mn;
     }
     return tot;
@@ -340,16 +350,16 @@ __global__ __launch_bounds__(256, 2) void k_update(
     if (SWZ) {
         // XCD-aware order: block b runs on XCD b%8 (observed dispatch); each XCD walks its own
         // sequence of 8x8 super-tiles so the 16 operand tiles of a super-tile are reused from its L2.
-        const int64_t b = blockIdx.x;
-        const int xcd = (int)(b & 7);
-        const int64_t slot = b >> 3;
-        int64_t sidx = (slot / (SUPER * SUPER)) * 8 + xcd;
-        const int within = (int)(slot % (SUPER * SUPER));
-        const int nsr = (u.nrt + SUPER - 1) / SUPER, nsc = (u.nct + SUPER - 1) / SUPER;
-        int sJ = 0; int64_t sI = -1;
+        const unsigned b = blockIdx.x;
+        const int xcd = (int)(b & 7u);
+        const unsigned slot = b >> 3;
+        int sidx = (int)((slot >> 6) * 8u) + xcd;            // / (SUPER*SUPER)
+        const int within = (int)(slot & 63u);
+        const int nsr = (u.nrt + SUPER - 1) >> 3, nsc = (u.nct + SUPER - 1) >> 3;
+        int sJ = 0; int sI = -1;
         for (; sJ < nsc; ++sJ) {
-            const int64_t mn = upd_super_min_row<BN>(u, sJ);
-            const int64_t cnt = mn < nsr ? nsr - mn : 0;
+            const int mn = upd_super_min_row(u, sJ);
+            const int cnt = mn < nsr ? nsr - mn : 0;
             if (sidx < cnt) { sI = mn + sidx; break; }
             sidx -= cnt;
         }
@@ -489,10 +499,12 @@ __global__ __launch_bounds__(256, 2) void k_update(
     if (u.dbg && tid == 0) {
         const unsigned lin = SWZ ? blockIdx.x : blockIdx.x + gridDim.x * blockIdx.y;
         unsigned long long* d = u.dbg + 8ull * lin;
-        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = wall_clock64();
+        const unsigned long long ts3 = wall_clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // diagnostics: when have this wave's stores drained?
+        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; 
         d[4] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);          // HW_ID low 16 bits... (size field = 15+1)
         d[5] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);          // XCC_ID
-        d[6] = rt; d[7] = ct;
+        d[6] = wall_clock64() - ts3; d[7] = ct;
     }
 }
 

@@ -115,11 +115,13 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     u.stagger_mode = ctx->stagger_mode;
     u.dbg = ctx->dbg_buf;
     u.prio = bulk ? 0 : ctx->side_prio;
+    u.rt_min0 = 0; u.rt_step = 0;
     u.stagger_ticks = (ctx->stagger_mode && approx_blocks >= 1536.0) ? (int)(ctx->stagger_us_per_k * K * 100.0) : 0;
     if (bulk && ctx->bulk_bn == 64) {
         // experimental: 128x64 tiles (134 VGPRs -> 3 blocks per CU) for the bulk update
         u.nct = (int)(n_lp * (g.nb / 64));
-        if (ctx->xcd_swizzle) {
+        if (ctx->xcd_swizzle && upd_swizzle_ok<64>(u)) {
+            upd_fill_affine<64>(u);
             const int64_t nsup = upd_super_count<64>(u);
             if (nsup <= 0) return 0;
             dim3 grid((unsigned)(((nsup + 7) / 8) * 8 * SUPER * SUPER));
@@ -128,7 +130,8 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
             dim3 grid((unsigned)u.nrt, (unsigned)u.nct);
             hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, g.Npad, K, u);
         }
-    } else if (ctx->xcd_swizzle && bulk) {
+    } else if (ctx->xcd_swizzle && bulk && upd_swizzle_ok<128>(u)) {
+        upd_fill_affine<128>(u);
         const int64_t nsup = upd_super_count<128>(u);
         if (nsup <= 0) return 0;
         const int64_t rounds = (nsup + 7) / 8;                       // super-tiles per XCD
@@ -167,7 +170,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
             UpdGeo u;
             u.row_begin = row_begin; u.Npad = g.Npad; u.first_lp = lp; u.sub0 = t;
             u.nb = g.nb; u.world = g.world; u.rank = g.rank; u.nrt = (int)(m / BM); u.nct = 1;
-            u.stagger_ticks = 0; u.stagger_mode = 0; u.dbg = nullptr; u.prio = ctx->side_prio;
+            u.stagger_ticks = 0; u.stagger_mode = 0; u.dbg = nullptr; u.prio = ctx->side_prio; u.rt_min0 = 0; u.rt_step = 0;
             dim3 grid((unsigned)(m / BM), 1);
             hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), 0, stream, ctx->A, g.Npad,
                                ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, t * TB, u);

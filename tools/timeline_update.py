@@ -29,6 +29,8 @@ for name, x in (("prologue(C+stage0 load)", pro), ("main loop", loop), ("epilogu
     print("%-26s mean %7.2f  p10 %7.2f  p50 %7.2f  p90 %7.2f us" % (name, x.mean(), *np.percentile(x, [10, 50, 90])))
 hw = d[:, 4]; xcc = d[:, 5]
 wave_id = hw & 0xF; simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
+drain = d[:, 6] * 0.01
+print("store drain (vmcnt(0) after last store issue): mean %.2f p50 %.2f p90 %.2f us" % (drain.mean(), *np.percentile(drain, [50, 90])))
 print("wave_id values:", np.unique(wave_id), " simd:", np.unique(simd), " cu:", np.unique(cu), " sh:", np.unique(sh), " se:", np.unique(se), " xcc:", np.unique(xcc))
 key = xcc * 100000 + se * 10000 + sh * 1000 + cu * 10 + wave_id
 gaps = []
@@ -50,4 +52,4 @@ for k in np.unique(cukey)[:64]:
         inloop += np.any((T[others, 1] <= mid) & (mid <= T[others, 2]))
 print("prologue midpoints during which a CU-mate is in its main loop: %d / %d" % (inloop, tot))
 first = np.argsort(T[:, 0])[:12]
-for i in first: print("blk rt=%d ct=%d start %.2f pro %.2f loop %.2f epi %.2f wave_id %d cu %d se %d xcc %d" % (d[i,6], d[i,7], T[i,0], pro[i], loop[i], epi[i], wave_id[i], cu[i], se[i], xcc[i]))
+for i in first: print("blk x=%d ct=%d start %.2f pro %.2f loop %.2f epi %.2f wave_id %d cu %d se %d xcc %d" % (d[i,6], d[i,7], T[i,0], pro[i], loop[i], epi[i], wave_id[i], cu[i], se[i], xcc[i]))
