@@ -34,8 +34,7 @@ def sweep_invert(T, pivtol_rel=1e-14):
     B = np.tril(B) + np.tril(B, -1).T
     tb = B.shape[0]
     unswept = np.ones(tb, dtype=bool)
-    scale = np.max(np.abs(B)) if tb else 0.0
-    pivtol = pivtol_rel * scale
+    colmax0 = np.max(np.abs(B), axis=0) if tb else np.zeros(0)   # reference scale of each pivot (as on the device)
     neg = zero = n2 = 0
     dmin, dmax = np.inf, 0.0
 
@@ -43,6 +42,7 @@ def sweep_invert(T, pivtol_rel=1e-14):
         nonlocal neg, zero, dmin, dmax
         d = B[p, p]
         ad = abs(d)
+        pivtol = pivtol_rel * colmax0[p]
         if ad <= pivtol:
             zero += 1
             d = pivtol if d >= 0.0 else -pivtol
@@ -69,6 +69,7 @@ def sweep_invert(T, pivtol_rel=1e-14):
         tr = a + c
         disc = np.sqrt((a - c) ** 2 + 4 * b * b)
         e1, e2 = 0.5 * (tr + disc), 0.5 * (tr - disc)
+        pivtol = pivtol_rel * max(colmax0[p], colmax0[q])
         for e in (e1, e2):
             if abs(e) <= pivtol:
                 zero += 1

@@ -80,11 +80,19 @@ __global__ __launch_bounds__(256) void k_tile_invert(
         row[c] = (lane >= j) ? stage[lane][j] : stage[j][lane];
         amax = fmax(amax, fabs(row[c]));
     }
+    // per-row maximum of the loaded tile (== per-column, by symmetry): the reference scale of a pivot.
+    // A pivot counts as rejected only when it has shrunk below pivtol_rel x its OWN column's original
+    // magnitude (cancellation), so a badly scaled but perfectly regular tile (Sigma entries spanning
+    // 1e-8..1e8 late in an interior-point run) is left alone.
+    colbuf[0][0][lane] = 0.0;                          // reuse as scratch for the cross-wave row maximum
+    __syncthreads();
+    stage[wave][lane] = amax;                           // stage[] is free again (rows already in registers)
+    __syncthreads();
+    const double cmax0 = fmax(fmax(stage[0][lane], stage[1][lane]), fmax(stage[2][lane], stage[3][lane]));
     amax = wave_max(amax);
     if (lane == 0) sh_red[wave] = amax;
     __syncthreads();
     const double scale = fmax(fmax(sh_red[0], sh_red[1]), fmax(sh_red[2], sh_red[3]));
-    const double pivtol = pivtol_rel * scale;
     const double inv_scale = scale > 0.0 ? 1.0 / scale : 0.0;
     const double tiny = 2.2250738585072014e-308;
     const int nreal = (int)((Nreal - grow0) < 0 ? 0 : ((Nreal - grow0) > TB ? TB : (Nreal - grow0)));   // real rows in this tile
@@ -141,6 +149,7 @@ __global__ __launch_bounds__(256) void k_tile_invert(
                 for (int c = 0; c < 16; ++c) cpj[c] = rv[cb + c];
             }
             const double ad = fabs(d);
+            const double pivtol = pivtol_rel * readlane_f64(cmax0, piv);
             if (__builtin_expect(!(ad <= 1.0e308), 0)) bad = 1;          // NaN or Inf
             if (__builtin_expect(ad <= pivtol, 0)) {
                 if (piv < nreal) zero++;
@@ -175,6 +184,7 @@ __global__ __launch_bounds__(256) void k_tile_invert(
             if (!(fabs(det) <= 1.0e308)) bad = 1;
             const double tr = a + cc, disc = sqrt((a - cc) * (a - cc) + 4.0 * b * b);
             const double e1 = 0.5 * (tr + disc), e2 = 0.5 * (tr - disc);
+            const double pivtol = pivtol_rel * fmax(readlane_f64(cmax0, p), readlane_f64(cmax0, q));
             n2++;
             if (fabs(e1) <= pivtol) zero++; else { neg += (e1 < 0.0) ? 1 : 0;
                 dmin = fmin(dmin, fabs(e1)); dmax = fmax(dmax, fabs(e1)); }

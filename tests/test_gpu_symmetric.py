@@ -1,0 +1,99 @@
+"""The factorisation on ARBITRARY symmetric matrices.  With me = mi = 0 the KKT matrix is the staged
+matrix itself (pyipm.py:824-827: only its upper triangle is read), so any symmetric indefinite system can
+be pushed through the C-ABI: inertia from the block pivots must equal the eigenvalue inertia (what
+reghess counts, pyipm.py:1381) and the solve must match LAPACK's LU to ~cond*eps."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(M, b, **kw):
+    from pyipm_amd.newton import NewtonCore
+    n = M.shape[0]
+    core = NewtonCore(n, 0, 0, device=0, **kw)
+    core.stage_blocks(np.triu(M))                       # junk-free upper triangle only: the lower half is never read
+    core.stage_vectors(np.zeros(n))
+    core.assemble(0.0, 0.0)
+    st = core.factor()
+    x = core.solve(rhs=b, flip=False).cpu().numpy()
+    return x, st
+
+
+def _inertia(M):
+    w = np.linalg.eigvalsh(M)
+    return int(np.sum(w < 0)), int(np.sum(w > 0))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 7, 31, 63, 64, 65, 100, 127, 128, 129, 200, 333, 640])
+def test_random_indefinite(n):
+    rng = np.random.default_rng(1000 + n)
+    G = rng.standard_normal((n, n))
+    M = 0.5 * (G + G.T) + np.diag(rng.standard_normal(n) * 2.0)        # GOE-like + diagonal: strongly indefinite
+    b = rng.standard_normal(n)
+    x, st = _solve(M, b)
+    neg, pos = _inertia(M)
+    assert st["n_zero"] == 0 and st["n_neg"] == neg and st["n_pos"] == pos
+    ref = np.linalg.solve(M, b)
+    cond = np.linalg.cond(M)
+    assert np.linalg.norm(x - ref) / np.linalg.norm(ref) <= max(1e-10, 50 * cond * np.finfo(float).eps)
+    assert np.linalg.norm(M @ x - b) <= 1e-11 * (np.linalg.norm(M, 2) * np.linalg.norm(x) + np.linalg.norm(b))
+
+
+@pytest.mark.parametrize("n", [2, 10, 40, 64])
+def test_zero_diagonal_needs_2x2_pivots(n):
+    rng = np.random.default_rng(7 + n)
+    G = rng.standard_normal((n, n))
+    M = 0.5 * (G + G.T)
+    np.fill_diagonal(M, 0.0)
+    b = rng.standard_normal(n)
+    x, st = _solve(M, b)
+    neg, pos = _inertia(M)
+    assert st["n_2x2"] >= 1 and st["n_zero"] == 0 and (st["n_neg"], st["n_pos"]) == (neg, pos)
+    assert np.linalg.norm(M @ x - b) <= 1e-11 * (np.linalg.norm(M, 2) * np.linalg.norm(x) + np.linalg.norm(b))
+
+
+def test_saddle_point_block_matrix():
+    """[[A, B'],[B, 0]] with A positive definite: exactly the structure of an equality-constrained KKT system."""
+    rng = np.random.default_rng(5)
+    n, m = 150, 60
+    A = rng.standard_normal((n, n)); A = A @ A.T / n + np.eye(n)
+    B = rng.standard_normal((m, n))
+    M = np.block([[A, B.T], [B, np.zeros((m, m))]])
+    b = rng.standard_normal(n + m)
+    x, st = _solve(M, b)
+    assert (st["n_neg"], st["n_pos"], st["n_zero"]) == (m, n, 0)
+    assert np.linalg.norm(M @ x - b) <= 1e-11 * (np.linalg.norm(M, 2) * np.linalg.norm(x) + np.linalg.norm(b))
+
+
+def test_badly_scaled_diagonal_blocks():
+    """Late-IPM flavour: Sigma entries spanning 1e-8 .. 1e8 (diagonal), coupled by -I to a zero block."""
+    rng = np.random.default_rng(9)
+    k = 96
+    sig = 10.0 ** rng.uniform(-8, 8, k)
+    M = np.block([[np.diag(sig), -np.eye(k)], [-np.eye(k), np.zeros((k, k))]])
+    b = rng.standard_normal(2 * k)
+    x, st = _solve(M, b)
+    assert st["n_zero"] == 0 and st["n_neg"] == k and st["n_pos"] == k
+    ref = np.linalg.solve(M, b)
+    assert np.linalg.norm(x - ref) / np.linalg.norm(ref) <= 1e-8        # cond ~1e16 * tiny coupling; LU gives the same class
+
+
+def test_restricted_pivoting_limitation_is_reported():
+    """Documented limitation: pivots never leave their 64x64 diagonal tile.  A matrix whose
+    leading tile is exactly singular although the matrix is not (here [[0, I],[I, 0]], 128 x 128) cannot be
+    factored by tile-local pivoting; the statistics MUST say so (rejected pivots), so the host can regularise
+    exactly as reghess does on a failed inertia test (pyipm.py:1390-1403)."""
+    k = 64
+    M = np.block([[np.zeros((k, k)), np.eye(k)], [np.eye(k), np.zeros((k, k))]])
+    x, st = _solve(M, np.ones(2 * k))
+    assert st["n_zero"] >= 1
+    # one reghess-style diagonal shift makes the leading tile invertible again; the inertia of the SHIFTED
+    # matrix is then reported correctly
+    from pyipm_amd.newton import NewtonCore
+    core = NewtonCore(2 * k, 0, 0, device=0)
+    core.stage_blocks(np.triu(M)); core.stage_vectors(np.zeros(2 * k))
+    core.assemble(1e-3, 0.0)
+    st2 = core.factor()
+    neg, pos = _inertia(M + 1e-3 * np.eye(2 * k))
+    assert st2["n_zero"] == 0 and (st2["n_neg"], st2["n_pos"]) == (neg, pos)
