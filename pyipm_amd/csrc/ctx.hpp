@@ -74,6 +74,7 @@ struct Ctx {
     std::vector<hipEvent_t> ev_done;      // panel q factored
     int fuse_forward = 1;
     bool forward_fused = false;
+    bool forward_pending = false;         // factor() already forward-substituted the pending residual into v0
     int lookahead = 1;                    // 0 none, 1 one group (default), 2 two groups (dedicated bulk stream; measured no faster)
     hipStream_t bulk = nullptr;
     std::vector<hipEvent_t> ev_grp;       // [2g] group g factored, [2g+1] bulk update of group g done

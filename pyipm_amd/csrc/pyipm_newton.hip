@@ -387,6 +387,7 @@ int residual_dev(Ctx* ctx) {
         PYIPM_KCHECK();
     }
     ctx->have_rhs = true;
+    ctx->forward_pending = false;
     return 0;
 }
 
@@ -400,7 +401,7 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
                            ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c);
         PYIPM_KCHECK();
     }
-    ctx->assembled = true; ctx->factored = false;
+    ctx->assembled = true; ctx->factored = false; ctx->forward_pending = false;
     return 0;
 }
 
@@ -665,11 +666,19 @@ int pyipm_newton_assemble(pyipm_newton_ctx* h, double delta, double delta_c) {
     return PYIPM_OK;
 }
 
+static int solve_prepare(Ctx* ctx, const double* rhs, int memkind);
+
 int pyipm_newton_factor(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     PYIPM_HIP(hipSetDevice(ctx->device));
-    return factor_all(ctx, stats);
+    // a residual is pending (pyipm.py:1717 precedes :1718): let its forward substitution trail the
+    // factorisation; solve(rhs = NULL) then only runs the block-diagonal and backward parts
+    const bool fuse = ctx->fuse_forward && ctx->have_rhs && ctx->g.world == 1 && ctx->assembled;
+    if (fuse) { int rc = solve_prepare(ctx, nullptr, PYIPM_MEM_DEVICE); if (rc) return rc; }
+    int rc = factor_all(ctx, stats, fuse);
+    ctx->forward_pending = (rc == 0 || rc == PYIPM_E_NONFINITE) ? (fuse && ctx->forward_fused) : false;
+    return rc;
 }
 
 // load the right-hand side into v1 (kept for refinement) and v0 (solved in place)
@@ -716,14 +725,17 @@ int pyipm_newton_solve(pyipm_newton_ctx* h, const double* rhs, double* dz, int f
     if (!ctx->factored) { ctx->err = "solve: factor first"; return PYIPM_E_BADARG; }
     if (!dz) { ctx->err = "solve: null output"; return PYIPM_E_BADARG; }
     PYIPM_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
-    int rc = solve_prepare(ctx, rhs, memkind); if (rc) return rc;
-    return solve_finish(ctx, dz, flip, refine, memkind, false);
+    const bool pending = ctx->forward_pending && rhs == nullptr;      // v0 already holds the forward-substituted residual
+    ctx->forward_pending = false;                                     // consumed (or overwritten) either way
+    if (!pending) { int rc = solve_prepare(ctx, rhs, memkind); if (rc) return rc; }
+    return solve_finish(ctx, dz, flip, refine, memkind, pending);
 }
 
 int pyipm_newton_kkt_matvec(pyipm_newton_ctx* h, const double* v, double* y, int memkind) {
     if (check_ctx(h) || !v || !y) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
     PYIPM_HIP(hipSetDevice(ctx->device));
+    ctx->forward_pending = false;                     // v1 (the saved right-hand side) is about to be reused
     hipLaunchKernelGGL(k_fill, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v1, 0.0, g.Npad); PYIPM_KCHECK();
     int rc = put_vec(ctx, ctx->v1, v, g.N, memkind); if (rc) return rc;
     rc = kkt_matvec_dev(ctx, ctx->v1, ctx->v2); if (rc) return rc;
@@ -741,6 +753,7 @@ int pyipm_newton_step(pyipm_newton_ctx* h, double delta, double delta_c, int ref
     const bool fuse = ctx->fuse_forward != 0;
     if (fuse) { rc = solve_prepare(ctx, nullptr, memkind); if (rc) return rc; }     // v0 = v1 = g before factoring
     rc = factor_all(ctx, stats, fuse); if (rc) return rc;
+    ctx->forward_pending = false;
     PYIPM_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     if (!fuse) { rc = solve_prepare(ctx, nullptr, memkind); if (rc) return rc; }
     return solve_finish(ctx, dz, 1, refine, memkind, fuse && ctx->forward_fused);
