@@ -9,7 +9,36 @@
 
 namespace pyipm {
 
-// One thread-block writes a 256(i) x 16(j) patch of the local storage.
+// KKT entry (i, j), i >= j, in the reference's block order (pyipm.py:816-844 + reghess' shifts).
+__device__ __forceinline__ double kkt_entry(
+    int64_t i, int64_t j, const Geo& g,
+    const double* __restrict__ d2L, int64_t ldh, const double* __restrict__ Je, int64_t ldje,
+    const double* __restrict__ Ji, int64_t ldji, const double* __restrict__ s, const double* __restrict__ lda,
+    double eps, double delta, double delta_c)
+{
+    const int64_t n = g.n, me = g.me, mi = g.mi, N = g.N;
+    const int64_t o_s = n, o_e = n + mi, o_i = n + mi + me;
+    if (j < n) {
+        if (i < n)        return d2L[j * ldh + i] + (i == j ? delta : 0.0);
+        if (i < o_e)      return 0.0;
+        if (i < o_i)      return Je[j * ldje + (i - o_e)];
+        if (i < N)        return Ji[j * ldji + (i - o_i)];
+        return 0.0;
+    }
+    if (j < o_e) {                                     // slack columns: Sigma and -I
+        const int64_t b = j - o_s;
+        if (i == j)       return lda[me + b] / (s[b] + eps);           // pyipm.py:498
+        if (i == o_i + b) return -1.0;                                  // pyipm.py:838-842
+        return 0.0;
+    }
+    if (j < o_i) return (i == j) ? -delta_c : 0.0;     // lambda_e columns: -delta_c I (reghess)
+    if (j < N)   return 0.0;                           // lambda_i columns: zero block
+    return (i == j) ? 1.0 : 0.0;                       // identity pad
+}
+
+// One thread-block writes a 512(i) x 16(j) patch of the local storage; each thread owns two consecutive
+// rows so every store is 16 bytes (and the dominant d2L reads too, when the leading dimension allows).
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void k_assemble(
     double* __restrict__ A, int64_t ld, Geo g,
     const double* __restrict__ d2L, int64_t ldh,
@@ -18,10 +47,10 @@ __global__ __launch_bounds__(256) void k_assemble(
     const double* __restrict__ s, const double* __restrict__ lda,
     double eps, double delta, double delta_c)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;          // even row; rows i, i+1
     const int64_t lc_base = (int64_t)blockIdx.y * 16;
-    const int64_t n = g.n, me = g.me, mi = g.mi, N = g.N;
-    const int64_t o_s = n, o_e = n + mi, o_i = n + mi + me;
+    if (i >= g.Npad) return;
+    const bool vec_h = ((ldh & 1) == 0) && ((reinterpret_cast<uintptr_t>(d2L) & 15) == 0);
     #pragma unroll 4
     for (int c = 0; c < 16; ++c) {
         const int64_t lc = lc_base + c;
@@ -29,25 +58,18 @@ __global__ __launch_bounds__(256) void k_assemble(
         // local column -> global column (block-cyclic by panels of nb)
         const int64_t lp = lc / g.nb;
         const int64_t j = (lp * g.world + g.rank) * (int64_t)g.nb + (lc - lp * g.nb);
-        if (i < j || i >= g.Npad) continue;           // only the lower triangle is stored
-        double v = 0.0;
-        if (j < n) {
-            if (i < n)            v = d2L[j * ldh + i] + (i == j ? delta : 0.0);
-            else if (i < o_e)     v = 0.0;
-            else if (i < o_i)     v = Je[j * ldje + (i - o_e)];
-            else if (i < N)       v = Ji[j * ldji + (i - o_i)];
-        } else if (j < o_e) {                          // slack columns: Sigma and -I
-            const int64_t b = j - o_s;
-            if (i == j)           v = lda[me + b] / (s[b] + eps);      // pyipm.py:498
-            else if (i == o_i + b) v = -1.0;                            // pyipm.py:838-842
-        } else if (j < o_i) {                          // lambda_e columns: -delta_c I (reghess)
-            if (i == j)           v = -delta_c;
-        } else if (j < N) {                            // lambda_i columns: zero block
-            v = 0.0;
-        } else {                                       // identity pad
-            v = (i == j) ? 1.0 : 0.0;
+        if (i + 1 < j) continue;                      // both rows above the diagonal: not stored
+        dbl2_t v;
+        if (vec_h && j < g.n && i + 1 < g.n && i >= j) {
+            v = *reinterpret_cast<const dbl2_t*>(&d2L[j * ldh + i]);
+            if (i == j) v.x += delta;
+            if (i + 1 == j) v.y += delta;
+        } else {
+            v.x = (i >= j) ? kkt_entry(i, j, g, d2L, ldh, Je, ldje, Ji, ldji, s, lda, eps, delta, delta_c) : 0.0;
+            v.y = kkt_entry(i + 1, j, g, d2L, ldh, Je, ldje, Ji, ldji, s, lda, eps, delta, delta_c);
         }
-        A[i + lc * ld] = v;
+        if (i >= j) *reinterpret_cast<dbl2_t*>(&A[i + lc * ld]) = v;
+        else        A[(i + 1) + lc * ld] = v.y;       // the pair straddles the diagonal: store the lower one only
     }
 }
 

@@ -396,7 +396,7 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
     if (!ctx->have_blocks || !ctx->have_vectors) { ctx->err = "assemble: stage blocks and vectors first"; return PYIPM_E_BADARG; }
     ctx->delta = delta; ctx->delta_c = delta_c;
     if (g.ncols_local > 0) {
-        dim3 grid((unsigned)((g.Npad + 255) / 256), (unsigned)((g.ncols_local + 15) / 16));
+        dim3 grid((unsigned)((g.Npad + 511) / 512), (unsigned)((g.ncols_local + 15) / 16));
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
                            ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c);
         PYIPM_KCHECK();
