@@ -66,7 +66,7 @@ typedef struct pyipm_factor_stats {
 
 /* Bytes of device workspace the handle needs for (n,me,mi) when the KKT columns are
  * distributed block-cyclically (panel width nb) over `world` ranks and this is `rank`.
- * nb must be a multiple of 64 (0 = default 256). */
+ * nb must be a multiple of 128, at most 1024 (0 = default 256). */
 size_t pyipm_newton_workspace_bytes(int64_t n, int64_t me, int64_t mi, int nb, int world, int rank);
 
 /* Create a handle on HIP device `device`.  `workspace` is caller-owned device memory
@@ -125,6 +125,13 @@ int pyipm_newton_kkt_matvec(pyipm_newton_ctx* ctx, const double* v, double* y, i
  * without regularisation retries (the host loop re-issues assemble/factor with new shifts). */
 int pyipm_newton_step(pyipm_newton_ctx* ctx, double delta, double delta_c, int refine,
                       double* dz, pyipm_factor_stats* stats, int memkind);
+
+/* SURVEY.md section 8(f) rank 1 — replaces the two IPM.step calls of the inner loop (pyipm.py:1408-1436,
+ * 1737-1742): the largest alpha in [0,1] with v + alpha*dv >= (1-tau)*v, for v = s (dv = ds) and
+ * v = lda_i (dv = dlda_i), from the staged s / lda and the direction of the last solve()/step() kept on
+ * the device.  Closed form min(1, min_{dv_i<0} -tau*v_i/dv_i); the reference's golden-section search
+ * converges to the same value from below (to Xtol = eps).  With mi == 0 both are 1. */
+int pyipm_newton_step_lengths(pyipm_newton_ctx* ctx, double tau, double* alpha_s, double* alpha_l);
 
 /* ---- per-panel phases (multi-GPU host orchestration; single-rank factor() loops these) --- */
 

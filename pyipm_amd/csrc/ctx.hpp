@@ -98,10 +98,10 @@ struct Ctx {
     int64_t ld_d2L = 0, ld_Je = 0, ld_Ji = 0;
     double *stg_d2L = nullptr, *stg_Je = nullptr, *stg_Ji = nullptr;   // lazily hipMalloc'd
     size_t stg_d2L_sz = 0, stg_Je_sz = 0, stg_Ji_sz = 0;
-    double* hostbuf = nullptr; size_t hostbuf_sz = 0;                   // pinned bounce buffer
     double mu = 0.2, eps = 2.220446049250313e-16;
     double delta = 0.0, delta_c = 0.0;
     bool have_blocks = false, have_vectors = false, have_rhs = false, assembled = false, factored = false;
+    bool have_direction = false;          // v2 holds the last sign-flipped direction (for step_lengths)
     // options
     double pivtol_rel = 1e-14;
     int profile = 0;

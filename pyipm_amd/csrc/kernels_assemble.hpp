@@ -200,6 +200,32 @@ __global__ __launch_bounds__(256) void k_copy_flip(double* __restrict__ out, con
     if (i < N) out[i] = (flip && i >= flip_from) ? -in[i] : in[i];
 }
 
+// Fraction-to-the-boundary step lengths (pyipm.py:1408-1436 in closed form) for v = s and v = lda_i.
+// One block; out[0] = alpha_s, out[1] = alpha_l.
+__global__ __launch_bounds__(256) void k_step_lengths(
+    double* __restrict__ out, const double* __restrict__ s, const double* __restrict__ lda_i,
+    const double* __restrict__ ds, const double* __restrict__ dl, int64_t mi, double tau)
+{
+    __shared__ double red[2][4];
+    double as = 1.0, al = 1.0;
+    for (int64_t i = threadIdx.x; i < mi; i += 256) {
+        const double a = ds[i], b = dl[i];
+        if (a < 0.0) as = fmin(as, -tau * s[i] / a);
+        if (b < 0.0) al = fmin(al, -tau * lda_i[i] / b);
+    }
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        as = fmin(as, __shfl_xor(as, off, 64));
+        al = fmin(al, __shfl_xor(al, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = as; red[1][threadIdx.x >> 6] = al; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = fmin(fmin(red[0][0], red[0][1]), fmin(red[0][2], red[0][3]));
+        out[1] = fmin(fmin(red[1][0], red[1][1]), fmin(red[1][2], red[1][3]));
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fill(double* __restrict__ out, double v, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

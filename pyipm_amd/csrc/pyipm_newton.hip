@@ -51,15 +51,6 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
 int check_ctx(pyipm_newton_ctx* h) { return h ? 0 : PYIPM_E_BADARG; }
 inline Ctx* C(pyipm_newton_ctx* h) { return reinterpret_cast<Ctx*>(h); }
 
-int ensure_hostbuf(Ctx* ctx, size_t bytes) {
-    if (ctx->hostbuf_sz >= bytes) return 0;
-    if (ctx->hostbuf) PYIPM_HIP(hipHostFree(ctx->hostbuf));
-    ctx->hostbuf = nullptr; ctx->hostbuf_sz = 0;
-    PYIPM_HIP(hipHostMalloc((void**)&ctx->hostbuf, bytes, hipHostMallocDefault));
-    ctx->hostbuf_sz = bytes;
-    return 0;
-}
-
 // copy `count` doubles from caller memory (host or device) into library device memory
 int put_vec(Ctx* ctx, double* dst, const double* src, size_t count, int memkind) {
     if (count == 0) return 0;
@@ -585,7 +576,6 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) {
     if (ctx->stg_d2L) hipFree(ctx->stg_d2L);
     if (ctx->stg_Je) hipFree(ctx->stg_Je);
     if (ctx->stg_Ji) hipFree(ctx->stg_Ji);
-    if (ctx->hostbuf) hipHostFree(ctx->hostbuf);
     if (ctx->own_ws && ctx->ws) hipFree(ctx->ws);
     delete ctx;
     return PYIPM_OK;
@@ -714,6 +704,7 @@ static int solve_finish(Ctx* ctx, double* dz, int flip, int refine, int memkind,
     PYIPM_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
     rc = copy_out(ctx, dz, ctx->v2, g.N, memkind); if (rc) return rc;
     ctx->ev_solve_valid = true;
+    ctx->have_direction = (flip != 0) || (g.me + g.mi == 0);     // v2 = dz with the reference's sign convention
     return PYIPM_OK;
 }
 
@@ -736,6 +727,7 @@ int pyipm_newton_kkt_matvec(pyipm_newton_ctx* h, const double* v, double* y, int
     Ctx* ctx = C(h); const Geo& g = ctx->g;
     PYIPM_HIP(hipSetDevice(ctx->device));
     ctx->forward_pending = false;                     // v1 (the saved right-hand side) is about to be reused
+    ctx->have_direction = false;                      // ... and v2 (the last direction) too
     hipLaunchKernelGGL(k_fill, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v1, 0.0, g.Npad); PYIPM_KCHECK();
     int rc = put_vec(ctx, ctx->v1, v, g.N, memkind); if (rc) return rc;
     rc = kkt_matvec_dev(ctx, ctx->v1, ctx->v2); if (rc) return rc;
@@ -757,6 +749,25 @@ int pyipm_newton_step(pyipm_newton_ctx* h, double delta, double delta_c, int ref
     PYIPM_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     if (!fuse) { rc = solve_prepare(ctx, nullptr, memkind); if (rc) return rc; }
     return solve_finish(ctx, dz, 1, refine, memkind, fuse && ctx->forward_fused);
+}
+
+int pyipm_newton_step_lengths(pyipm_newton_ctx* h, double tau, double* alpha_s, double* alpha_l) {
+    if (check_ctx(h) || !alpha_s || !alpha_l) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    *alpha_s = 1.0; *alpha_l = 1.0;
+    if (g.mi == 0) return PYIPM_OK;
+    if (!ctx->have_vectors || !ctx->have_direction) { ctx->err = "step_lengths: stage vectors and solve first"; return PYIPM_E_BADARG; }
+    // v2 holds the last direction in the reference's order with the multiplier block already sign-flipped
+    const double* dz = ctx->v2;
+    hipLaunchKernelGGL(k_step_lengths, dim3(1), dim3(256), 0, ctx->stream, ctx->partial, ctx->s, ctx->lda + g.me,
+                       dz + g.n, dz + g.n + g.mi + g.me, g.mi, tau);
+    PYIPM_KCHECK();
+    double out[2];
+    PYIPM_HIP(hipMemcpyAsync(out, ctx->partial, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+    *alpha_s = out[0]; *alpha_l = out[1];
+    return PYIPM_OK;
 }
 
 // ---- per-panel phases -----------------------------------------------------------------------------

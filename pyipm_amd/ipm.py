@@ -30,11 +30,12 @@ class HipNewtonBackend(object):
     factorisation instead of ``eigvalsh``; the "rcond <= eps" trigger of the reference
     (:1379-1381) is replaced by "a pivot was rejected or d_min/d_max <= eps"."""
 
-    def __init__(self, n, me, mi, device=None, nb=256, refine=0, max_shift_tries=60):
+    def __init__(self, n, me, mi, device=None, nb=256, refine=0, max_shift_tries=60, device_step=False):
         from .newton import NewtonCore
         self.core = NewtonCore(n, me, mi, device=device, nb=nb)
         self.n, self.me, self.mi = n, me, mi
         self.refine = refine
+        self.device_step = device_step      # SURVEY 8(f) rank 1: closed-form step lengths on the device
         self.max_shift_tries = max_shift_tries
         self.n_factor = 0
 
@@ -64,6 +65,12 @@ class HipNewtonBackend(object):
         dz = core.solve(flip=True, refine=self.refine).cpu().numpy()
         return dz, float(delta), st
 
+    def step_lengths(self, tau):
+        """(alpha_smax, alpha_lmax) for the direction just returned, or None to let the host search."""
+        if not (self.device_step and self.mi):
+            return None
+        return self.core.step_lengths(tau)
+
 
 class IPM(object):
     """Line-search primal-dual interior-point solver; see module docstring."""
@@ -71,7 +78,8 @@ class IPM(object):
     def __init__(self, x0=None, x_dev=None, f=None, df=None, d2f=None, ce=None, dce=None, d2ce=None, ci=None,
                  dci=None, d2ci=None, lda0=None, lambda_dev=None, s0=None, mu=0.2, nu=10.0, rho=0.1, tau=0.995,
                  eta=1.0E-4, beta=0.4, miter=20, niter=10, Xtol=None, Ktol=1.0E-4, Ftol=None, lbfgs=False,
-                 lbfgs_zeta=None, float_dtype=np.float64, verbosity=1, backend=None, device=None, nb=256, refine=0):
+                 lbfgs_zeta=None, float_dtype=np.float64, verbosity=1, backend=None, device=None, nb=256, refine=0,
+                 device_step=False):
         self.x0, self.s0, self.lda0 = x0, s0, lda0
         self.x_dev, self.lambda_dev = x_dev, lambda_dev        # accepted for signature parity; unused
         self.f, self.df, self.d2f = f, df, d2f
@@ -89,7 +97,7 @@ class IPM(object):
         self.lbfgs, self.lbfgs_zeta = lbfgs, lbfgs_zeta
         self.verbosity = verbosity
         self.backend = backend
-        self._backend_opts = dict(device=device, nb=nb, refine=refine)
+        self._backend_opts = dict(device=device, nb=nb, refine=refine, device_step=device_step)
         self.compiled = False
         self.signal = 0
 
@@ -409,8 +417,12 @@ class IPM(object):
                     if self.nu_host < nu_thres:
                         self.nu_host = float(nu_thres)
                 if mi:
-                    a_s = self.step(s, dz[n:n + mi])
-                    a_l = self.step(lda[me:], dz[n + mi + me:])
+                    dev = self.backend.step_lengths(self.tau) if hasattr(self.backend, "step_lengths") else None
+                    if dev is not None:
+                        a_s, a_l = dev
+                    else:
+                        a_s = self.step(s, dz[n:n + mi])
+                        a_l = self.step(lda[me:], dz[n + mi + me:])
                     x, s, lda = self.search(x, s, lda, dz, float(a_s), float(a_l))
                 else:
                     x, s, lda = self.search(x, s, lda, dz, 1.0, 1.0)

@@ -76,6 +76,7 @@ def load_library(path: str | None = None):
         "pyipm_newton_solve": (c_int, [ctxp, c_void_p, c_void_p, c_int, c_int, c_int]),
         "pyipm_newton_kkt_matvec": (c_int, [ctxp, c_void_p, c_void_p, c_int]),
         "pyipm_newton_step": (c_int, [ctxp, c_double, c_double, c_int, c_void_p, POINTER(FactorStats), c_int]),
+        "pyipm_newton_step_lengths": (c_int, [ctxp, c_double, POINTER(c_double), POINTER(c_double)]),
         "pyipm_newton_factor_panel": (c_int, [ctxp, c_int64]),
         "pyipm_newton_panel_msg_bytes": (c_size_t, [ctxp, c_int64]),
         "pyipm_newton_panel_pack": (c_int, [ctxp, c_int64, c_void_p]),
@@ -259,6 +260,12 @@ class NewtonCore(object):
         self._ck(self.lib.pyipm_newton_step(self.h, float(delta), float(delta_c), int(refine), self._ptr(dz),
                                             ctypes.byref(st), MEM_DEVICE))
         return dz, st.as_dict()
+
+    def step_lengths(self, tau):
+        """Fraction-to-the-boundary step lengths (alpha_s, alpha_l) for the direction of the last solve."""
+        a_s, a_l = c_double(1.0), c_double(1.0)
+        self._ck(self.lib.pyipm_newton_step_lengths(self.h, float(tau), ctypes.byref(a_s), ctypes.byref(a_l)))
+        return a_s.value, a_l.value
 
     # -- per-panel phases (used by pyipm_amd.dist) ----------------------------------------------
     def factor_begin(self):

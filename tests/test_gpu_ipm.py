@@ -84,3 +84,44 @@ def test_cli_problem7(capsys):
     sol = [l for l in out if l.startswith("Solver solution")][0]
     vals = np.array([float(v) for v in sol.split("[")[1].rstrip("]").split(",")])
     assert np.linalg.norm(vals - 1.0 / 3.0) <= 1e-3
+
+
+def test_device_step_lengths_match_host_search():
+    """closed-form fraction-to-the-boundary on the device vs the reference's golden-section
+    search restated on the host (pyipm.py:1408-1436): same alpha to 1e-15 on every Newton system of a trace."""
+    from pyipm_amd.newton import NewtonCore
+    from pyipm_amd.ipm import IPM
+    for k in (5, 6, 7, 9, 10):
+        d = np.load(os.path.join(GOLD, "trace_p%02d.npz" % k))
+        prob = example_problem(k)
+        n, me, mi = prob["nvar"], prob["neq"], prob["nineq"]
+        host = IPM(x0=unit_test_x0()[k], f=prob["f"], df=prob["df"], d2f=prob["d2f"], backend=object(), verbosity=-1)
+        core = NewtonCore(n, me, mi, device=0)
+        for it in range(int(d["n_iter"])):
+            x, s, lda = d["it_x"][it], d["it_s"][it], d["it_lda"][it]
+            d2L = np.array(prob["d2f"](x), dtype=np.float64)
+            Je = ce = None
+            if me:
+                d2L = d2L - prob["d2ce"](x, lda); Je, ce = prob["dce"](x), prob["ce"](x)
+            d2L = d2L - prob["d2ci"](x, lda)
+            core.stage_blocks(d2L, Je, prob["dci"](x))
+            core.stage_vectors(prob["df"](x), ce, prob["ci"](x), s, lda, mu=float(d["it_mu"][it]))
+            delta = float(d["it_delta_out"][it]) if not np.array_equal(d["it_Hc"][it], d["it_H"][it]) else 0.0
+            dz, _ = core.step(delta, 0.0)
+            dz = dz.cpu().numpy()
+            a_s, a_l = core.step_lengths(0.995)
+            h_s = host.step(s, dz[n:n + mi])
+            h_l = host.step(lda[me:], dz[n + mi + me:])
+            assert abs(a_s - h_s) <= 1e-15 * max(1.0, h_s) + 4e-16 and abs(a_l - h_l) <= 1e-15 * max(1.0, h_l) + 4e-16
+            ds, dl = dz[n:n + mi], dz[n + mi + me:]
+            exact_s = min([1.0] + [-0.995 * s[i] / ds[i] for i in range(mi) if ds[i] < 0])
+            assert a_s == exact_s
+
+
+@pytest.mark.parametrize("k", [5, 7, 10])
+def test_solve_with_device_step_lengths(k):
+    d = np.load(os.path.join(GOLD, "trace_p%02d.npz" % k))
+    ipm = make_ipm(k, Ftol=1.0e-8, verbosity=-1, device_step=True)
+    x, s, lda, fval, kkt = ipm.solve()
+    assert ipm.signal == int(d["signal"]) and ipm.iter_count == int(d["n_iter"])
+    np.testing.assert_allclose(x, d["x"], rtol=1e-7, atol=1e-9)
