@@ -159,9 +159,12 @@ def main():
     core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
     core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
     core.set_option("profile", 1)
+    condensed = False
     for kv in args.opt:
         k, v = kv.split("=")
         core.set_option(k, float(v))
+        if k == "condensed":
+            condensed = float(v) != 0 and mi > 0
 
     if use_dist:
         from pyipm_amd.dist import DistNewton
@@ -180,7 +183,7 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    trailing_ms = trailing_flops = panel_ms = solve_ms = assemble_ms = 0.0
+    trailing_ms = trailing_flops = panel_ms = solve_ms = assemble_ms = gram_ms = 0.0
     n_launch = 0
     fence()
     t0 = time.perf_counter()
@@ -189,6 +192,7 @@ def main():
         tm = core.timings()         # reads HIP-event durations of this step (stream already drained by the step)
         trailing_ms += tm["trailing_ms"]; trailing_flops += tm["trailing_flops"]; n_launch += tm["n_trailing"]
         panel_ms += tm["panel_ms"]; solve_ms += tm["solve_ms"]; assemble_ms += tm["assemble_ms"]
+        gram_ms += tm["gram_ms"]
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -237,11 +241,26 @@ def main():
             "inertia": {"n_neg": st["n_neg"], "expected": me + mi, "n_zero": st["n_zero"], "n_2x2": st["n_2x2"],
                         "growth": st["growth"]},
         }
-        if world == 1 and n_launch:
+        if world == 1 and n_launch and not condensed:
             # C-tile read-modify-write (16 B per lower-triangle entry per launch) + the two operand panels once
             groups = max(1, int(os.environ.get("PYIPM_NEWTON_GROUP", "4")))
             Kb = groups * args.nb
             out["roofline"]["algorithmic_bytes_per_launch"] = (trailing_flops / (2.0 * Kb)) * 16.0 / n_launch + 2.0 * 8.0 * Kb * (N / 2.0)
+        if condensed:
+            # same Newton direction from the (n+me)-dimensional condensed system; NOT the
+            # headline configuration: the flop count of the step itself changes
+            Nc = n + me
+            fl = Nc ** 3 / 3.0 + float(mi) * n * n + 2.0 * Nc ** 2 + 4.0 * n * mi
+            out["config"]["kkt_form"] = "condensed: [[H + Ji Sigma Ji', Je],[Je', 0]] of dimension %d (s, lambda_i eliminated)" % Nc
+            out["phases_ms_per_step"]["gram(Ji Sigma Ji' MFMA launch, inside assemble)"] = gram_ms / K
+            out["gram_tflops"] = (float(mi) * n * n / 1e12) / max(gram_ms / K * 1e-3, 1e-12)
+            out["step_flops_algorithmic"] = fl
+            out["step_tflops"] = fl / (elapsed / K) / 1e12
+            out["step_frac_of_peak"] = out["step_tflops"] / (FP64_MFMA_PEAK_TFLOPS * world)
+            out["roofline"]["algorithmic_bytes_per_launch"] = None
+            out["hbm_bound_kernels"].pop("assemble_K1", None)
+        else:
+            out["config"]["kkt_form"] = "full 4-block system of the reference (pyipm.py:816-844)"
         if args.check and world == 1:
             g = core.residual()
             raw = core.solve(flip=False, refine=args.refine)

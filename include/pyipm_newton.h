@@ -161,8 +161,16 @@ int pyipm_newton_bwd_panel(pyipm_newton_ctx* ctx, int64_t p, double* v);
 /* Device pointer + leading dimension of the local KKT storage (column-major lower). */
 int pyipm_newton_kkt_storage(pyipm_newton_ctx* ctx, double** ptr, int64_t* ld, int64_t* ncols);
 /* Time (ms, HIP events on the handle's stream) of the phases of the last factor/solve call:
- * out[0]=assemble, [1]=panel work, [2]=trailing updates, [3]=solve, [4]=#trailing launches. */
+ * out[0]=assemble, [1]=panel work, [2]=trailing updates, [3]=solve, [4]=#trailing launches,
+ * [5]=algorithmic flops of those launches, [6]=factor, [7]=Ji Sigma Ji' launch (condensed option). */
 int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
+/* Options (all default to the measured-best setting):
+ *   "condensed" 0|1  single-rank handles with mi > 0: assemble/factor/solve work on the condensed system
+ *                    [[d2L + delta I + Ji Sigma Ji', Je], [Je', -delta_c I]] of dimension n+me (s and lambda_i
+ *                    eliminated analytically).  Same inputs, same outputs (full [dx|ds|dle|dli], inertia of the
+ *                    full matrix); kkt_storage then exposes the condensed matrix.
+ *   "profile" 0|1, "lookahead" 0|1|2, "group" 1..create-time value, "fuse_forward" 0|1, "pivtol_rel",
+ *   "xcd_swizzle", "stagger_mode", "stagger_us_per_k", "side_prio", "bulk_bn", "extra_lds" (diagnostics). */
 int pyipm_newton_set_option(pyipm_newton_ctx* ctx, const char* name, double value);
 
 /* fp64 MFMA peak micro-benchmark: register-resident v_mfma_f64_16x16x4_f64 only.

@@ -86,6 +86,16 @@ struct Ctx {
     unsigned long long* dbg_buf = nullptr;   // diagnostics only
     int stagger_mode = 1;                 // 0 off, 1 by dispatch index, 2 by hardware wave slot
     double stagger_us_per_k = 0.11;       // delay = this * K microseconds (~ half a tile period)
+    // condensed KKT option: factor the (n+me)-dimensional system
+    //   [[H + delta I + Ji Sigma Ji', Je], [Je', -delta_c I]]  instead of the full (n+2mi+me) one
+    int condensed = 0;                    // requested by set_option("condensed", 1); single-rank, mi > 0
+    bool cond_active = false;             // the current assembled / factored matrix is the condensed one
+    Geo gc;                               // geometry of the condensed system (mi = 0)
+    double *JT = nullptr, *WT = nullptr;  // Ji' and Sigma Ji' operands of the rank-mi update (lazily hipMalloc'd)
+    size_t jt_bytes = 0;
+    double *vc = nullptr, *vt = nullptr;  // condensed vector / mi-sized temporary (carved)
+    double* fwd_vec = nullptr;            // vector the fused forward substitution runs on
+    double t_gram = 0;                    // ms of the Ji Sigma Ji' launch (profile)
     bool own_ws = false;
     char* ws = nullptr; size_t ws_bytes = 0;
     // carved from workspace
@@ -126,5 +136,12 @@ struct Ctx {
 #define PYIPM_KCHECK()  PYIPM_HIP(hipGetLastError())
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Run a section of the single-rank machinery on another geometry (the condensed system).
+struct GeoSwap {
+    Ctx* c; Geo saved;
+    GeoSwap(Ctx* c_, const Geo& g) : c(c_), saved(c_->g) { c->g = g; }
+    ~GeoSwap() { c->g = saved; }
+};
 
 }  // namespace pyipm

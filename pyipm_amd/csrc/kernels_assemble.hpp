@@ -226,6 +226,79 @@ __global__ __launch_bounds__(256) void k_step_lengths(
     }
 }
 
+// ---- condensed KKT: eliminate s and lambda_i ---------------------------
+//   (H + delta I + Ji Sigma Ji') dx + Je dle = b_x + Ji (Sigma b_i + b_s) ,  Je' dx - delta_c dle = b_e
+//   ds = Ji' dx - b_i ,  dli = Sigma ds - b_s          (Sigma = lda_i / (s + eps), pyipm.py:498)
+
+// JT[i + k*ldt] = Ji[i][k]  and  WT[i + k*ldt] = Sigma_k Ji[i][k]  (i < n, k < mi; zero elsewhere up to
+// rows ldt / columns mi_pad): the operands of the rank-mi MFMA update  C += JT * WT' = C + Ji Sigma Ji'
+// (k_update accumulates Lop * Wop'; the factorisation feeds it the pre-negated W).
+// 32x32 tiles through LDS: reads coalesced along k, writes coalesced along i.
+__global__ __launch_bounds__(256) void k_transpose_scale(
+    double* __restrict__ JT, double* __restrict__ WT, int64_t ldt, const double* __restrict__ Ji, int64_t ldji,
+    int64_t n, int64_t mi, int64_t mi_pad, const double* __restrict__ s, const double* __restrict__ lda_i, double eps)
+{
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    const int64_t i0 = (int64_t)blockIdx.x * 32, k0 = (int64_t)blockIdx.y * 32;
+    #pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = i0 + ty + 8 * r, k = k0 + tx;
+        tile[ty + 8 * r][tx] = (i < n && k < mi) ? Ji[i * ldji + k] : 0.0;
+    }
+    __syncthreads();
+    #pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t k = k0 + ty + 8 * r, i = i0 + tx;
+        if (k < mi_pad && i < ldt) {
+            const double v = tile[tx][ty + 8 * r];
+            const double sg = (k < mi) ? lda_i[k] / (s[k] + eps) : 0.0;
+            JT[i + k * ldt] = v;
+            WT[i + k * ldt] = sg * v;
+        }
+    }
+}
+
+// t[k] = -(Sigma_k b_i[k] + b_s[k])   (negated so k_rowdot2's "base - acc" form yields b_x + Ji t)
+__global__ __launch_bounds__(256) void k_cond_t(double* __restrict__ t, const double* __restrict__ b, Geo g,
+                                                const double* __restrict__ s, const double* __restrict__ lda_i, double eps)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= g.mi) return;
+    const double sg = lda_i[k] / (s[k] + eps);
+    t[k] = -(sg * b[g.n + g.mi + g.me + k] + b[g.n + k]);
+}
+
+// condensed right-hand side tail: vc[n + a] = b_e[a], zero pad up to npad_c
+__global__ __launch_bounds__(256) void k_cond_gather(double* __restrict__ vc, const double* __restrict__ b, Geo g, int64_t npad_c)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = g.n + t;
+    if (i >= npad_c) return;
+    vc[i] = (t < g.me) ? b[g.n + g.mi + t] : 0.0;
+}
+
+// full solution from the condensed one: v (holding b on entry) <- [dx ; ds ; dle ; dli],  u = Ji' dx
+__global__ __launch_bounds__(256) void k_cond_expand(double* __restrict__ v, const double* __restrict__ vc,
+                                                     const double* __restrict__ u, Geo g,
+                                                     const double* __restrict__ s, const double* __restrict__ lda_i, double eps)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.Npad) return;
+    const int64_t n = g.n, me = g.me, mi = g.mi;
+    if (i < n) { v[i] = vc[i]; return; }
+    if (i < n + mi) {                                   // one thread does the (s, lambda_i) pair of index k
+        const int64_t k = i - n;
+        const double bs = v[n + k], bi = v[n + mi + me + k];
+        const double ds = u[k] - bi;
+        v[n + k] = ds;
+        v[n + mi + me + k] = lda_i[k] / (s[k] + eps) * ds - bs;
+        return;
+    }
+    if (i < n + mi + me) { v[i] = vc[n + (i - n - mi)]; return; }
+    if (i >= g.N) v[i] = 0.0;
+}
+
 __global__ __launch_bounds__(256) void k_fill(double* __restrict__ out, double v, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

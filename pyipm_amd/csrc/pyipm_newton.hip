@@ -36,7 +36,10 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
     const size_t os = cv.take((size_t)(g.mi + 1) * D);
     const size_t ol = cv.take((size_t)(g.me + g.mi + 1) * D);
     const size_t ost = cv.take(sizeof(DevStats));
+    const size_t ovc = cv.take((size_t)g.Npad * D);
+    const size_t ovt = cv.take((size_t)(g.mi + 16) * D);
     if (base) {
+        c->vc = (double*)(base + ovc); c->vt = (double*)(base + ovt);
         c->A = (double*)(base + oA); c->Wbuf = (double*)(base + oW); c->Lbuf = (double*)(base + oL);
         c->Dinv = (double*)(base + oD); c->rhs = (double*)(base + orhs);
         c->v0 = (double*)(base + ov0); c->v1 = (double*)(base + ov1); c->v2 = (double*)(base + ov2);
@@ -91,13 +94,18 @@ inline double* wbuf(Ctx* ctx, int64_t p) {
 // ---- per-panel building blocks -----------------------------------------------------------------
 
 // Rank-K update of `n_lp` locally owned panels starting at local panel `first_lp`.
+// ldw / row_end / col_end default to the KKT storage's (the Gram launch of the condensed option narrows them).
 int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ldl, const double* Wop, int K,
-                     int64_t row_begin, int64_t first_lp, int64_t n_lp, bool bulk = true) {
+                     int64_t row_begin, int64_t first_lp, int64_t n_lp, bool bulk = true,
+                     int64_t ldw = 0, int64_t row_end = 0, int64_t col_end = 0) {
     const Geo& g = ctx->g;
-    const int64_t m = g.Npad - row_begin;
+    if (ldw <= 0) ldw = g.Npad;
+    if (row_end <= 0) row_end = g.Npad;
+    if (col_end <= 0) col_end = g.Npad;
+    const int64_t m = row_end - row_begin;
     if (m <= 0 || n_lp <= 0) return 0;
     UpdGeo u;
-    u.row_begin = row_begin; u.Npad = g.Npad; u.first_lp = first_lp; u.sub0 = 0;
+    u.row_begin = row_begin; u.Npad = col_end; u.first_lp = first_lp; u.sub0 = 0;
     u.nb = g.nb; u.world = g.world; u.rank = g.rank;
     u.nrt = (int)(m / BM); u.nct = (int)(n_lp * (g.nb / 128));
     // stagger only pays when the launch runs for several rounds of 512 resident blocks
@@ -116,10 +124,10 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
             const int64_t nsup = upd_super_count<64>(u);
             if (nsup <= 0) return 0;
             dim3 grid((unsigned)(((nsup + 7) / 8) * 8 * SUPER * SUPER));
-            hipLaunchKernelGGL((k_update<64, true>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, g.Npad, K, u);
+            hipLaunchKernelGGL((k_update<64, true>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
         } else {
             dim3 grid((unsigned)u.nrt, (unsigned)u.nct);
-            hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, g.Npad, K, u);
+            hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
         }
     } else if (ctx->xcd_swizzle && bulk && upd_swizzle_ok<128>(u)) {
         upd_fill_affine<128>(u);
@@ -127,10 +135,10 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
         if (nsup <= 0) return 0;
         const int64_t rounds = (nsup + 7) / 8;                       // super-tiles per XCD
         dim3 grid((unsigned)(rounds * 8 * SUPER * SUPER));
-        hipLaunchKernelGGL((k_update<128, true>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, g.Npad, K, u);
+        hipLaunchKernelGGL((k_update<128, true>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
     } else {
         dim3 grid((unsigned)u.nrt, (unsigned)u.nct);
-        hipLaunchKernelGGL((k_update<128, false>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, g.Npad, K, u);
+        hipLaunchKernelGGL((k_update<128, false>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
     }
     PYIPM_KCHECK();
     return 0;
@@ -307,8 +315,8 @@ int bwd_panel(Ctx* ctx, int64_t p, double* v) {
     return 0;
 }
 
-// x := Hc^{-1} x  in place on an Npad device vector (single-rank path)
-int solve_inplace(Ctx* ctx, double* v, bool forward_done = false) {
+// x := M^{-1} x in place for the factored matrix of the current geometry (single-rank path)
+int solve_plain(Ctx* ctx, double* v, bool forward_done) {
     const Geo& g = ctx->g;
     if (!forward_done) {
         for (int64_t p = 0; p < g.npanels; ++p) { int rc = fwd_panel(ctx, p, v); if (rc) return rc; }
@@ -316,6 +324,50 @@ int solve_inplace(Ctx* ctx, double* v, bool forward_done = false) {
     }
     for (int64_t p = g.npanels - 1; p >= 0; --p) { int rc = bwd_panel(ctx, p, v); if (rc) return rc; }
     return 0;
+}
+
+// ---- condensed option: right-hand side reduction and solution expansion --------------------------
+// vc <- [ b_x + Ji (Sigma b_i + b_s) ; b_e ; 0 ]   from a full-order right-hand side b
+int cond_reduce(Ctx* ctx, const double* b, double* vc) {
+    const Geo& g = ctx->g;
+    hipLaunchKernelGGL(k_cond_t, grid1(g.mi), dim3(256), 0, ctx->stream, ctx->vt, b, g, ctx->s, ctx->lda + g.me, ctx->eps);
+    PYIPM_KCHECK();
+    hipLaunchKernelGGL(k_rowdot2, grid1(g.n, 4), dim3(256), 0, ctx->stream, vc, b, g.n,
+                       (const double*)nullptr, (int64_t)0, (const double*)nullptr, (int64_t)0,
+                       ctx->Ji, ctx->ld_Ji, ctx->vt, g.mi, 0, 0);
+    PYIPM_KCHECK();
+    if (ctx->gc.Npad > g.n) {
+        hipLaunchKernelGGL(k_cond_gather, grid1(ctx->gc.Npad - g.n), dim3(256), 0, ctx->stream, vc, b, g, ctx->gc.Npad);
+        PYIPM_KCHECK();
+    }
+    return 0;
+}
+
+// v (holding the full right-hand side) <- [dx ; ds ; dle ; dli] from the condensed solution vc
+int cond_expand(Ctx* ctx, const double* vc, double* v) {
+    const Geo& g = ctx->g;
+    const int nchunk = 64;
+    const int64_t rpc = (g.n + nchunk - 1) / nchunk;
+    hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((g.mi + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
+                       ctx->partial, ctx->Ji, ctx->ld_Ji, g.n, g.mi, vc, rpc, 0);
+    PYIPM_KCHECK();
+    hipLaunchKernelGGL(k_coldot_reduce, grid1(g.mi), dim3(256), 0, ctx->stream, ctx->vt, ctx->partial, g.mi, nchunk, 0);
+    PYIPM_KCHECK();
+    hipLaunchKernelGGL(k_cond_expand, grid1(g.Npad), dim3(256), 0, ctx->stream, v, vc, ctx->vt, g, ctx->s, ctx->lda + g.me, ctx->eps);
+    PYIPM_KCHECK();
+    return 0;
+}
+
+// x := Hc^{-1} x  in place on a full-order Npad device vector (single-rank path).  With the condensed
+// factor: reduce, solve the (n+me) system, expand.  forward_done: the fused pass already ran (on v, or on
+// ctx->vc for the condensed factor, in which case v still holds the right-hand side).
+int solve_inplace(Ctx* ctx, double* v, bool forward_done = false) {
+    if (!ctx->cond_active) return solve_plain(ctx, v, forward_done);
+    int rc;
+    if (!forward_done) { rc = cond_reduce(ctx, v, ctx->vc); if (rc) return rc; }
+    { GeoSwap sw(ctx, ctx->gc); rc = solve_plain(ctx, ctx->vc, forward_done); }
+    if (rc) return rc;
+    return cond_expand(ctx, ctx->vc, v);
 }
 
 // y = Hc v from the staged blocks (Npad vectors on the device)
@@ -382,10 +434,54 @@ int residual_dev(Ctx* ctx) {
     return 0;
 }
 
+// Condensed assembly: A (ld = gc.Npad) <- tril [[H + delta I, Je],[Je', -delta_c I]] by K1 on the condensed
+// geometry, then  += Ji Sigma Ji'  as ONE rank-mi launch of the MFMA update kernel (C += JT * WT').
+int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
+    const Geo& g = ctx->g; const Geo& gc = ctx->gc;
+    const int64_t mi_pad = (g.mi + BKU - 1) / BKU * BKU, ldt = gc.Npad;
+    const size_t need = 2 * (size_t)ldt * (size_t)mi_pad * sizeof(double);
+    if (ctx->jt_bytes < need) {
+        if (ctx->JT) PYIPM_HIP(hipFree(ctx->JT));
+        ctx->JT = nullptr; ctx->jt_bytes = 0;
+        if (hipMalloc((void**)&ctx->JT, need) != hipSuccess) { ctx->err = "condensed: no memory for the Ji' operands"; return PYIPM_E_NOMEM; }
+        ctx->jt_bytes = need;
+    }
+    ctx->WT = ctx->JT + (size_t)ldt * (size_t)mi_pad;
+    {
+        dim3 grid((unsigned)((gc.Npad + 511) / 512), (unsigned)((gc.ncols_local + 15) / 16));
+        hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, gc.Npad, gc, ctx->d2L, ctx->ld_d2L,
+                           ctx->Je, ctx->ld_Je, (const double*)nullptr, (int64_t)0, ctx->s, ctx->lda, ctx->eps, delta, delta_c);
+        PYIPM_KCHECK();
+    }
+    {
+        dim3 grid((unsigned)((ldt + 31) / 32), (unsigned)((mi_pad + 31) / 32));
+        hipLaunchKernelGGL(k_transpose_scale, grid, dim3(256), 0, ctx->stream, ctx->JT, ctx->WT, ldt, ctx->Ji, ctx->ld_Ji,
+                           g.n, g.mi, mi_pad, ctx->s, ctx->lda + g.me, ctx->eps);
+        PYIPM_KCHECK();
+    }
+    const int64_t nx = (g.n + BM - 1) / BM * BM;                 // rows / columns touched: the x-x block
+    if (ctx->profile) PYIPM_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
+    {
+        GeoSwap sw(ctx, gc);
+        int rc = launch_update128(ctx, ctx->stream, ctx->JT, ldt, ctx->WT, (int)mi_pad, 0, 0, (nx + gc.nb - 1) / gc.nb,
+                                  true, ldt, nx, nx);
+        if (rc) return rc;
+    }
+    if (ctx->profile) PYIPM_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
+    return 0;
+}
+
 int assemble_dev(Ctx* ctx, double delta, double delta_c) {
     const Geo& g = ctx->g;
     if (!ctx->have_blocks || !ctx->have_vectors) { ctx->err = "assemble: stage blocks and vectors first"; return PYIPM_E_BADARG; }
     ctx->delta = delta; ctx->delta_c = delta_c;
+    if (ctx->condensed && g.world == 1 && g.mi > 0) {
+        int rc = assemble_condensed(ctx, delta, delta_c); if (rc) return rc;
+        ctx->cond_active = true;
+        ctx->assembled = true; ctx->factored = false; ctx->forward_pending = false;
+        return 0;
+    }
+    ctx->cond_active = false;
     if (g.ncols_local > 0) {
         dim3 grid((unsigned)((g.Npad + 511) / 512), (unsigned)((g.ncols_local + 15) / 16));
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
@@ -431,8 +527,8 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         if (!fuse_forward) return 0;
         PYIPM_HIP(hipEventRecord(ctx->ev_done[q], used));
         PYIPM_HIP(hipStreamWaitEvent(ctx->fwd, ctx->ev_done[q], 0));
-        int r2 = fwd_panel(ctx, q, ctx->v0, ctx->fwd); if (r2) return r2;
-        return diag_panel(ctx, q, ctx->v0, ctx->fwd);
+        int r2 = fwd_panel(ctx, q, ctx->fwd_vec, ctx->fwd); if (r2) return r2;
+        return diag_panel(ctx, q, ctx->fwd_vec, ctx->fwd);
     };
     for (int64_t q = 0; q < gsize(0); ++q) {
         rc = factor_panel(ctx, q, ctx->stream, true); if (rc) return rc;
@@ -512,6 +608,20 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     return rc;
 }
 
+// factor_all on whichever system assemble() built; inertia reported for the FULL KKT matrix either way:
+// every eliminated (s_k, lambda_i_k) pair [[Sigma_k, -1], [-1, 0]] has determinant -1, i.e. one positive
+// and one negative eigenvalue whatever the sign of Sigma_k.
+int factor_dispatch(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward) {
+    if (!ctx->cond_active) { ctx->fwd_vec = ctx->v0; return factor_all(ctx, stats, fuse_forward); }
+    pyipm_factor_stats local; if (!stats) stats = &local;
+    int rc;
+    ctx->fwd_vec = ctx->vc;
+    { GeoSwap sw(ctx, ctx->gc); rc = factor_all(ctx, stats, fuse_forward); }
+    stats->n_neg += ctx->g.mi; stats->n_pos += ctx->g.mi;
+    if (ctx->profile) { float ms = 0.f; PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7])); ctx->t_gram = ms; }
+    return rc;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -536,6 +646,7 @@ int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t m
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PYIPM_E_NODEVICE;
     Ctx* ctx = new Ctx();
     ctx->g = make_geo(n, me, mi, nb, world, rank);
+    ctx->gc = make_geo(n, me, 0, nb, 1, 0);
     ctx->group = default_group(world);
     ctx->device = device;
     ctx->stream = (hipStream_t)stream;
@@ -576,6 +687,7 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) {
     if (ctx->stg_d2L) hipFree(ctx->stg_d2L);
     if (ctx->stg_Je) hipFree(ctx->stg_Je);
     if (ctx->stg_Ji) hipFree(ctx->stg_Ji);
+    if (ctx->JT) hipFree(ctx->JT);
     if (ctx->own_ws && ctx->ws) hipFree(ctx->ws);
     delete ctx;
     return PYIPM_OK;
@@ -656,7 +768,7 @@ int pyipm_newton_assemble(pyipm_newton_ctx* h, double delta, double delta_c) {
     return PYIPM_OK;
 }
 
-static int solve_prepare(Ctx* ctx, const double* rhs, int memkind);
+static int solve_prepare(Ctx* ctx, const double* rhs, int memkind, bool for_fused_forward = false);
 
 int pyipm_newton_factor(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
@@ -665,14 +777,14 @@ int pyipm_newton_factor(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
     // a residual is pending (pyipm.py:1717 precedes :1718): let its forward substitution trail the
     // factorisation; solve(rhs = NULL) then only runs the block-diagonal and backward parts
     const bool fuse = ctx->fuse_forward && ctx->have_rhs && ctx->g.world == 1 && ctx->assembled;
-    if (fuse) { int rc = solve_prepare(ctx, nullptr, PYIPM_MEM_DEVICE); if (rc) return rc; }
-    int rc = factor_all(ctx, stats, fuse);
+    if (fuse) { int rc = solve_prepare(ctx, nullptr, PYIPM_MEM_DEVICE, true); if (rc) return rc; }
+    int rc = factor_dispatch(ctx, stats, fuse);
     ctx->forward_pending = (rc == 0 || rc == PYIPM_E_NONFINITE) ? (fuse && ctx->forward_fused) : false;
     return rc;
 }
 
 // load the right-hand side into v1 (kept for refinement) and v0 (solved in place)
-static int solve_prepare(Ctx* ctx, const double* rhs, int memkind) {
+static int solve_prepare(Ctx* ctx, const double* rhs, int memkind, bool for_fused_forward) {
     const Geo& g = ctx->g;
     if (rhs) {
         hipLaunchKernelGGL(k_fill, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v1, 0.0, g.Npad); PYIPM_KCHECK();
@@ -682,6 +794,7 @@ static int solve_prepare(Ctx* ctx, const double* rhs, int memkind) {
         PYIPM_HIP(hipMemcpyAsync(ctx->v1, ctx->rhs, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     }
     PYIPM_HIP(hipMemcpyAsync(ctx->v0, ctx->v1, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if (for_fused_forward && ctx->cond_active) return cond_reduce(ctx, ctx->v0, ctx->vc);   // the fused pass runs on vc
     return 0;
 }
 
@@ -743,8 +856,8 @@ int pyipm_newton_step(pyipm_newton_ctx* h, double delta, double delta_c, int ref
     int rc = residual_dev(ctx); if (rc) return rc;
     rc = pyipm_newton_assemble(h, delta, delta_c); if (rc) return rc;
     const bool fuse = ctx->fuse_forward != 0;
-    if (fuse) { rc = solve_prepare(ctx, nullptr, memkind); if (rc) return rc; }     // v0 = v1 = g before factoring
-    rc = factor_all(ctx, stats, fuse); if (rc) return rc;
+    if (fuse) { rc = solve_prepare(ctx, nullptr, memkind, true); if (rc) return rc; }     // v0 = v1 = g before factoring
+    rc = factor_dispatch(ctx, stats, fuse); if (rc) return rc;
     ctx->forward_pending = false;
     PYIPM_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     if (!fuse) { rc = solve_prepare(ctx, nullptr, memkind); if (rc) return rc; }
@@ -775,6 +888,7 @@ int pyipm_newton_factor_begin(pyipm_newton_ctx* h) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
     if (!ctx->assembled) { ctx->err = "factor_begin: assemble first"; return PYIPM_E_BADARG; }
+    if (ctx->cond_active) { ctx->err = "per-panel phases do not apply to the condensed system; use factor()"; return PYIPM_E_BADARG; }
     return factor_begin(ctx);
 }
 int pyipm_newton_factor_end(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
@@ -882,8 +996,8 @@ int pyipm_newton_kkt_storage(pyipm_newton_ctx* h, double** ptr, int64_t* ld, int
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     if (ptr) *ptr = ctx->A;
-    if (ld) *ld = ctx->g.Npad;
-    if (ncols) *ncols = ctx->g.ncols_local;
+    if (ld) *ld = ctx->cond_active ? ctx->gc.Npad : ctx->g.Npad;
+    if (ncols) *ncols = ctx->cond_active ? ctx->gc.ncols_local : ctx->g.ncols_local;
     return PYIPM_OK;
 }
 
@@ -895,7 +1009,8 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* h, double out[8]) {
     if (ctx->ev_assemble_valid) { float ms = 0.f; PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->t_assemble = ms; }
     if (ctx->ev_solve_valid) { float ms = 0.f; PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->t_solve = ms; }
     out[0] = ctx->t_assemble; out[1] = ctx->t_panel; out[2] = ctx->t_trailing; out[3] = ctx->t_solve;
-    out[4] = (double)ctx->n_trailing; out[5] = ctx->trailing_flops; out[6] = ctx->t_factor; out[7] = 0.0;
+    out[4] = (double)ctx->n_trailing; out[5] = ctx->trailing_flops; out[6] = ctx->t_factor;
+    out[7] = ctx->cond_active ? ctx->t_gram : 0.0;
     return PYIPM_OK;
 }
 
@@ -904,6 +1019,9 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     Ctx* ctx = C(h);
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
     if (!strcmp(name, "profile")) { ctx->profile = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "condensed")) {
+        if (value != 0 && ctx->g.world != 1) { ctx->err = "condensed: single-rank handles only"; return PYIPM_E_BADARG; }
+        ctx->condensed = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "lookahead")) { ctx->lookahead = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "group")) {           // may only shrink below the create-time value (workspace is sized for it)
         int v = (int)value; if (v < 1 || v > default_group(ctx->g.world)) { ctx->err = "group out of range"; return PYIPM_E_BADARG; }

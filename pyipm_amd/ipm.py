@@ -30,9 +30,12 @@ class HipNewtonBackend(object):
     factorisation instead of ``eigvalsh``; the "rcond <= eps" trigger of the reference
     (:1379-1381) is replaced by "a pivot was rejected or d_min/d_max <= eps"."""
 
-    def __init__(self, n, me, mi, device=None, nb=256, refine=0, max_shift_tries=60, device_step=False):
+    def __init__(self, n, me, mi, device=None, nb=256, refine=0, max_shift_tries=60, device_step=False,
+                 condensed=False):
         from .newton import NewtonCore
         self.core = NewtonCore(n, me, mi, device=device, nb=nb)
+        if condensed and mi:                # SURVEY 8(f) rank 2: factor the (n+me) condensed system
+            self.core.set_option("condensed", 1)
         self.n, self.me, self.mi = n, me, mi
         self.refine = refine
         self.device_step = device_step      # SURVEY 8(f) rank 1: closed-form step lengths on the device
@@ -79,7 +82,7 @@ class IPM(object):
                  dci=None, d2ci=None, lda0=None, lambda_dev=None, s0=None, mu=0.2, nu=10.0, rho=0.1, tau=0.995,
                  eta=1.0E-4, beta=0.4, miter=20, niter=10, Xtol=None, Ktol=1.0E-4, Ftol=None, lbfgs=False,
                  lbfgs_zeta=None, float_dtype=np.float64, verbosity=1, backend=None, device=None, nb=256, refine=0,
-                 device_step=False):
+                 device_step=False, condensed=False):
         self.x0, self.s0, self.lda0 = x0, s0, lda0
         self.x_dev, self.lambda_dev = x_dev, lambda_dev        # accepted for signature parity; unused
         self.f, self.df, self.d2f = f, df, d2f
@@ -97,7 +100,7 @@ class IPM(object):
         self.lbfgs, self.lbfgs_zeta = lbfgs, lbfgs_zeta
         self.verbosity = verbosity
         self.backend = backend
-        self._backend_opts = dict(device=device, nb=nb, refine=refine, device_step=device_step)
+        self._backend_opts = dict(device=device, nb=nb, refine=refine, device_step=device_step, condensed=condensed)
         self.compiled = False
         self.signal = 0
 

@@ -307,11 +307,13 @@ class NewtonCore(object):
     def kkt_storage(self):
         """View of the local KKT storage as a (ncols_local, Npad) row-major tensor.  For world=1,
         right after ``assemble`` its upper triangle is the reference's ``triu(H)`` (identity-padded)."""
-        n = self.Npad * self.ncols_local
-        return self.workspace[: n * 8].view(self.torch.float64).view(self.ncols_local, self.Npad)
+        ptr, ld, nc = c_void_p(), c_int64(), c_int64()
+        self._ck(self.lib.pyipm_newton_kkt_storage(self.h, ctypes.byref(ptr), ctypes.byref(ld), ctypes.byref(nc)))
+        ld, nc = int(ld.value), int(nc.value)           # the condensed option stores a smaller matrix
+        return self.workspace[: ld * nc * 8].view(self.torch.float64).view(nc, ld)
 
     def timings(self):
         t = (c_double * 8)()
         self._ck(self.lib.pyipm_newton_last_timings(self.h, t))
         return {"assemble_ms": t[0], "panel_ms": t[1], "trailing_ms": t[2], "solve_ms": t[3],
-                "n_trailing": int(t[4]), "trailing_flops": t[5], "factor_ms": t[6]}
+                "n_trailing": int(t[4]), "trailing_flops": t[5], "factor_ms": t[6], "gram_ms": t[7]}
