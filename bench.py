@@ -130,6 +130,12 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="core option name=value (e.g. xcd_swizzle=0, lookahead=0)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON): native libraries print there too (RCCL's version banner on
+    # rank 0), so fd 1 is pointed at stderr for the whole run and the JSON goes to a private copy of it
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from pyipm_amd.newton import NewtonCore, mfma_f64_peak
@@ -267,7 +273,8 @@ def main():
             out["backward_error"] = float((core.matvec(raw) - g).norm() / g.norm())
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(target_N=N)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

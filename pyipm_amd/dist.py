@@ -46,6 +46,10 @@ class DistNewton(object):
         self._msg = None
         self.bytes_broadcast = 0
         self.lookahead = True
+        # the owner of the next panel factors it on a high-priority side stream while its own share of the
+        # bulk update runs on the main stream (HIP cores only; the NumPy model backend has no streams)
+        self.overlap_owner = bool(getattr(core, "on_device", True)) and hasattr(core, "sync_stream")
+        self._side = None
 
     # ------------------------------------------------------------------ helpers
     def owner(self, p):
@@ -125,6 +129,22 @@ class DistNewton(object):
             self.bytes_broadcast += buf.numel() * 8
             return work, buf
 
+        torch = self.torch
+        side = main = None
+        if self.overlap_owner:
+            main = torch.cuda.current_stream(core.device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=core.device, priority=-1)
+            side = self._side
+
+        def post_owner_overlapped(p):
+            """owner of p: factor + pack + start the broadcast on the side stream (ordered after the head
+            update just enqueued on the main stream); the caller then enqueues its bulk update on main."""
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                core.sync_stream()
+                return post(p)
+
         work, buf = post(0)
         for p in range(np_):
             c0, c1 = self.panel_cols(p)
@@ -138,10 +158,18 @@ class DistNewton(object):
             if nxt < np_:
                 if self.owner(nxt) == self.rank:
                     core.trailing_update_range(p, nxt, 1)      # head: bring panel p+1 up to date first
-                work, buf = post(nxt)                          # its owner factors + broadcasts p+1 ...
+                    if side is not None:
+                        work, buf = post_owner_overlapped(nxt)
+                        core.sync_stream()                     # back to the main stream
+                    else:
+                        work, buf = post(nxt)
+                else:
+                    work, buf = post(nxt)                      # joins the broadcast of p+1 ...
                 core.trailing_update_range(p, nxt + 1, np_)    # ... while everyone runs the bulk of update p
             else:
                 work, buf = None, None
+        if side is not None:
+            main.wait_stream(side)                             # the last panel may have been factored there
         st = core.factor_end()
         return self._reduce_stats(st)
 
