@@ -168,7 +168,9 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *   "condensed" 0|1  single-rank handles with mi > 0: assemble/factor/solve work on the condensed system
  *                    [[d2L + delta I + Ji Sigma Ji', Je], [Je', -delta_c I]] of dimension n+me (s and lambda_i
  *                    eliminated analytically).  Same inputs, same outputs (full [dx|ds|dle|dli], inertia of the
- *                    full matrix); kkt_storage then exposes the condensed matrix.
+ *                    full matrix); kkt_storage then exposes the condensed matrix.  Every condensed solve runs at
+ *                    least "condensed_refine" (default 1) refinement steps against the full blocks: the
+ *                    recovery dli = Sigma ds - b_s multiplies the rounding of ds by Sigma.
  *   "profile" 0|1, "lookahead" 0|1|2, "group" 1..create-time value, "fuse_forward" 0|1, "pivtol_rel",
  *   "xcd_swizzle", "stagger_mode", "stagger_us_per_k", "side_prio", "bulk_bn", "extra_lds" (diagnostics). */
 int pyipm_newton_set_option(pyipm_newton_ctx* ctx, const char* name, double value);

@@ -89,6 +89,8 @@ struct Ctx {
     // condensed KKT option: factor the (n+me)-dimensional system
     //   [[H + delta I + Ji Sigma Ji', Je], [Je', -delta_c I]]  instead of the full (n+2mi+me) one
     int condensed = 0;                    // requested by set_option("condensed", 1); single-rank, mi > 0
+    int cond_min_refine = 1;              // refinement steps against the FULL blocks every condensed solve gets at least
+                                          // (dli = Sigma ds - b_s amplifies the rounding of ds by Sigma; one step repairs it)
     bool cond_active = false;             // the current assembled / factored matrix is the condensed one
     Geo gc;                               // geometry of the condensed system (mi = 0)
     double *JT = nullptr, *WT = nullptr;  // Ji' and Sigma Ji' operands of the rank-mi update (lazily hipMalloc'd)

@@ -801,6 +801,7 @@ static int solve_prepare(Ctx* ctx, const double* rhs, int memkind, bool for_fuse
 static int solve_finish(Ctx* ctx, double* dz, int flip, int refine, int memkind, bool forward_done) {
     const Geo& g = ctx->g;
     int rc = solve_inplace(ctx, ctx->v0, forward_done); if (rc) return rc;
+    if (ctx->cond_active && refine < ctx->cond_min_refine) refine = ctx->cond_min_refine;
     for (int it = 0; it < refine; ++it) {
         // r = b - Hc x ;  x += Hc^{-1} r      (Hc applied from the blocks, not from the factor)
         rc = kkt_matvec_dev(ctx, ctx->v0, ctx->v2); if (rc) return rc;
@@ -840,11 +841,12 @@ int pyipm_newton_kkt_matvec(pyipm_newton_ctx* h, const double* v, double* y, int
     Ctx* ctx = C(h); const Geo& g = ctx->g;
     PYIPM_HIP(hipSetDevice(ctx->device));
     ctx->forward_pending = false;                     // v1 (the saved right-hand side) is about to be reused
-    ctx->have_direction = false;                      // ... and v2 (the last direction) too
+    // the product goes through vc (free outside a condensed solve), so v2 -- the direction of the last
+    // solve, which step_lengths() reads -- survives a backward-error check
     hipLaunchKernelGGL(k_fill, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v1, 0.0, g.Npad); PYIPM_KCHECK();
     int rc = put_vec(ctx, ctx->v1, v, g.N, memkind); if (rc) return rc;
-    rc = kkt_matvec_dev(ctx, ctx->v1, ctx->v2); if (rc) return rc;
-    return copy_out(ctx, y, ctx->v2, g.N, memkind);
+    rc = kkt_matvec_dev(ctx, ctx->v1, ctx->vc); if (rc) return rc;
+    return copy_out(ctx, y, ctx->vc, g.N, memkind);
 }
 
 int pyipm_newton_step(pyipm_newton_ctx* h, double delta, double delta_c, int refine, double* dz,
@@ -1022,6 +1024,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "condensed")) {
         if (value != 0 && ctx->g.world != 1) { ctx->err = "condensed: single-rank handles only"; return PYIPM_E_BADARG; }
         ctx->condensed = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "condensed_refine")) { ctx->cond_min_refine = (int)value < 0 ? 0 : (int)value; return PYIPM_OK; }
     if (!strcmp(name, "lookahead")) { ctx->lookahead = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "group")) {           // may only shrink below the create-time value (workspace is sized for it)
         int v = (int)value; if (v < 1 || v > default_group(ctx->g.world)) { ctx->err = "group out of range"; return PYIPM_E_BADARG; }

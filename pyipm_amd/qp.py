@@ -1,0 +1,341 @@
+"""Device-resident interior-point loop for the QP family.
+
+    min 1/2 x'Qx + c'x    s.t.  Ax = b ,  Gx - h >= 0
+
+Same algorithm as :class:`pyipm_amd.ipm.IPM` (itself a restatement of ``/root/reference/pyipm.py``:
+``:1597-1628`` initial point, ``:1717-1725`` Newton step, ``:1727-1735`` merit parameter,
+``:1408-1436`` fraction to the boundary, ``:1438-1565`` backtracking search, ``:1804-1814``
+barrier update, ``:958-991`` KKT report) with the provider and the iterate living on the GPU:
+
+* Q, Je = A', Ji = G' are staged ONCE (device pointers handed to the Newton core, no copies);
+* df = Qx + c, ce = Ax - b, ci = Gx - h are device GEMVs (the reference evaluates them through
+  compiled Aesara functions on the host, ``pyipm.py:855-954``);
+* x, s, lambda and dz never leave the device; per line-search trial only the merit value (one
+  scalar) crosses PCIe, per iteration the four KKT norms, the step lengths and the merit threshold;
+* the fraction-to-the-boundary rule is the closed form ``pyipm_newton_step_lengths``.
+
+PyTorch supplies the device vectors and the GEMVs of the provider (plumbing); the Newton step
+itself is the HIP library.  No CPU fallback: constructing the solver without a GPU raises.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class QPDeviceIPM(object):
+    def __init__(self, Q, c, A=None, b=None, G=None, h=None, Je=None, Ji=None, x0=None, s0=None, lda0=None,
+                 mu=0.2, nu=10.0, rho=0.1, tau=0.995, eta=1.0E-4, beta=0.4, miter=20, niter=10, Xtol=None,
+                 Ktol=1.0E-4, Ftol=None, verbosity=1, device=None, nb=256, refine=0, condensed=False):
+        import torch
+        from .ipm import HipNewtonBackend
+        if not torch.cuda.is_available():
+            raise RuntimeError("QPDeviceIPM needs a GPU: the Newton-step core has no CPU fallback")
+        self.torch = torch
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        self.device = dev
+
+        def dv(a):
+            if a is None:
+                return None
+            if isinstance(a, torch.Tensor):
+                return a.to(device=dev, dtype=torch.float64)
+            return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64))).to(dev)
+
+        self.Q, self.c = dv(Q).contiguous(), dv(c)
+        n = self.nvar = int(self.c.numel())
+        # Jacobians in the reference's layout: Je = dce (n x me), Ji = dci (n x mi)  (pyipm.py:486-501)
+        self.Je = dv(Je).contiguous() if Je is not None else (dv(A).t().contiguous() if A is not None else None)
+        self.Ji = dv(Ji).contiguous() if Ji is not None else (dv(G).t().contiguous() if G is not None else None)
+        self.b, self.h = dv(b), dv(h)
+        me = self.neq = 0 if self.Je is None else int(self.Je.shape[1])
+        mi = self.nineq = 0 if self.Ji is None else int(self.Ji.shape[1])
+        assert self.Q.shape == (n, n)
+        self.x0 = dv(x0) if x0 is not None else torch.zeros(n, dtype=torch.float64, device=dev)
+        self.s0, self.lda0 = dv(s0), dv(lda0)
+        self.eps = float(np.finfo(np.float64).eps)
+        self.mu, self.nu, self.rho, self.tau, self.eta, self.beta = mu, nu, rho, tau, eta, beta
+        self.miter, self.niter = int(miter), int(niter)
+        self.Xtol = Xtol if Xtol else self.eps
+        self.Ktol, self.Ftol = Ktol, Ftol
+        self.reg_coef = float(np.sqrt(self.eps))
+        self.delta0 = self.reg_coef
+        self.verbosity = verbosity
+        self.backend = HipNewtonBackend(n, me, mi, device=dev.index, nb=nb, refine=refine, device_step=True,
+                                        condensed=condensed)
+        self.signal = 0
+        self.iter_count = 0
+        self.timings = {"newton_s": 0.0, "search_s": 0.0, "n_phi": 0}
+
+    # ------------------------------------------------------------------ provider (device GEMVs)
+    def f(self, x):
+        return float(0.5 * self.torch.dot(x, self.Q @ x) + self.torch.dot(self.c, x))
+
+    def df(self, x):
+        return self.Q @ x + self.c
+
+    def ce(self, x):
+        return x @ self.Je - self.b
+
+    def ci(self, x):
+        return x @ self.Ji - self.h
+
+    def _con(self, x, s):
+        parts = []
+        if self.neq:
+            parts.append(self.ce(x))
+        if self.nineq:
+            parts.append(self.ci(x) - s)
+        return self.torch.cat(parts) if parts else self.torch.zeros(0, dtype=self.torch.float64, device=self.device)
+
+    def grad(self, x, s, lda):
+        """KKT residual blocks (pyipm.py:655-668) as a list [gx, gs, ce, ci - s] of device vectors."""
+        me, mi = self.neq, self.nineq
+        gx = self.df(x)
+        if me:
+            gx = gx - self.Je @ lda[:me]
+        if mi:
+            gx = gx - self.Ji @ lda[me:]
+        return (gx, (lda[me:] - self.mu_host / (s + self.eps)) if mi else None,
+                self.ce(x) if me else None, (self.ci(x) - s) if mi else None)
+
+    def KKT(self, x, s, lda):
+        """Norms of the four first-order blocks, slack block scaled by s (pyipm.py:958-991): ONE host sync."""
+        torch = self.torch
+        g = self.grad(x, s, lda)
+        z = torch.zeros((), dtype=torch.float64, device=self.device)
+        n2 = torch.stack([g[0].norm(), (g[1] * s).norm() if g[1] is not None else z,
+                          g[2].norm() if g[2] is not None else z, g[3].norm() if g[3] is not None else z])
+        return tuple(n2.tolist())
+
+    def phi(self, x, s):
+        """Merit function (pyipm.py:670-721) reduced on the device; one scalar crosses PCIe."""
+        torch = self.torch
+        v = 0.5 * torch.dot(x, self.Q @ x) + torch.dot(self.c, x)
+        if self.neq:
+            v = v + self.nu_host * self.ce(x).abs().sum()
+        if self.nineq:
+            v = v + self.nu_host * (self.ci(x) - s).abs().sum() - self.mu_host * torch.log(s).sum()
+        self.timings["n_phi"] += 1
+        return float(v)
+
+    def dphi(self, x, s, dz):
+        torch, n = self.torch, self.nvar
+        v = torch.dot(self.df(x), dz[:n])
+        if self.neq:
+            v = v - self.nu_host * self.ce(x).abs().sum()
+        if self.nineq:
+            v = v - self.nu_host * (self.ci(x) - s).abs().sum() - torch.dot(self.mu_host / (s + self.eps), dz[n:])
+        return float(v)
+
+    def step(self, x, dx):
+        """Largest alpha in [0,1] with x + alpha dx >= (1 - tau) x: closed form of the golden-section
+        search of pyipm.py:1408-1436."""
+        torch = self.torch
+        neg = dx < 0
+        if not bool(neg.any()):
+            return 1.0
+        return min(1.0, float((-self.tau * x[neg] / dx[neg]).min()))
+
+    def _restoration(self, x0, c_new):
+        """Minimum-norm feasibility-restoration direction (pyipm.py:1466-1477, 1518-1529)."""
+        torch = self.torch
+        n, me, mi = self.nvar, self.neq, self.nineq
+        cols = [m for m in (self.Je, self.Ji) if m is not None]
+        top = torch.cat(cols, dim=1)
+        if mi:
+            bottom = torch.cat([torch.zeros((mi, me), dtype=torch.float64, device=self.device),
+                                -torch.eye(mi, dtype=torch.float64, device=self.device)], dim=1)
+            top = torch.cat([top, bottom], dim=0)
+        At = top.t()                                           # (me+mi) x (n+mi)
+        return -(torch.linalg.pinv(At) @ c_new)
+
+    def search(self, x0, s0, lda0, dz, alpha_smax, alpha_lmax):
+        """Backtracking Armijo search with the optional second-order correction (pyipm.py:1438-1565)."""
+        torch = self.torch
+        n, me, mi = self.nvar, self.neq, self.nineq
+        dx = dz[:n]
+        ds = dz[n:n + mi]
+        dl = dz[n + mi:]
+        if not (me or mi):
+            alpha_lmax = 0.0
+        phi0 = self.phi(x0, s0)
+        dphi0 = self.dphi(x0, s0, dz[:n + mi])
+        armijo = lambda a: phi0 + a * self.eta * dphi0    # noqa: E731
+        corrected, alpha_corr, dz_p = False, 1.0, None
+
+        def trial(a):
+            return self.phi(x0 + a * dx, s0 + a * ds) if mi else self.phi(x0 + a * dx, s0)
+
+        if trial(alpha_smax) > armijo(alpha_smax):
+            if me or mi:
+                c_old = self._con(x0, s0)
+                c_new = self._con(x0 + alpha_smax * dx, s0 + alpha_smax * ds if mi else s0)
+                if float(c_new.abs().sum()) > float(c_old.abs().sum()):
+                    dz_p = self._restoration(x0, c_new)
+                    if mi:
+                        xs = x0 + alpha_smax * dx + dz_p[:n]
+                        ss = s0 + alpha_smax * ds + dz_p[n:]
+                        if self.phi(xs, ss) <= armijo(alpha_smax):
+                            alpha_corr = self.step(s0, alpha_smax * ds + dz_p[n:])
+                            if (self.phi(x0 + alpha_corr * (alpha_smax * dx + dz_p[:n]),
+                                         s0 + alpha_corr * (alpha_smax * ds + dz_p[n:])) <= armijo(alpha_smax)):
+                                corrected = True
+                    else:
+                        if self.phi(x0 + alpha_smax * dx + dz_p[:n], s0) <= armijo(alpha_smax):
+                            alpha_corr, corrected = 1.0, True
+                    if corrected and self.verbosity > 2:
+                        print('Second-order feasibility correction accepted')
+            if not corrected:
+                alpha_smax *= self.tau
+                alpha_lmax *= self.tau
+                ndx = float(dx.norm())
+                nds = float(ds.norm()) if mi else 0.0
+                while trial(alpha_smax) > armijo(alpha_smax):
+                    size = np.sqrt((alpha_smax * ndx) ** 2 + (alpha_lmax * nds) ** 2) if mi else alpha_smax * ndx
+                    if size < self.eps:
+                        if self.verbosity > 2:
+                            print('Search direction is unreliable to machine precision.')
+                        self.signal = -2
+                        return x0, s0, lda0
+                    alpha_smax *= self.tau
+                    alpha_lmax *= self.tau
+        if corrected:
+            x = x0 + alpha_corr * (alpha_smax * dx + dz_p[:n])
+            s = s0 + alpha_corr * (alpha_smax * ds + dz_p[n:]) if mi else s0.clone()
+        else:
+            x = x0 + alpha_smax * dx
+            s = s0 + alpha_smax * ds if mi else s0.clone()
+        lda = lda0 + alpha_lmax * dl if (me or mi) else lda0.clone()
+        return x, s, lda
+
+    # ------------------------------------------------------------------ the Newton step (hot path)
+    def newton_direction(self, x, s, lda):
+        """pyipm.py:1717-1725 on the device: the blocks are resident, the vectors are device GEMVs."""
+        me, mi = self.neq, self.nineq
+        dz, self.delta, self.last_stats = self.backend.direction(
+            self.Q, self.Je, self.Ji, self.df(x), self.ce(x) if me else None, self.ci(x) if mi else None,
+            s if mi else None, lda if (me or mi) else None, self.mu_host, self.delta, self.mu_host, self.eta,
+            self.beta, self.reg_coef, self.delta0, self.eps, as_tensor=True)
+        return dz
+
+    def _small(self, kkt, tol):
+        return all(k <= tol for k in kkt)
+
+    # ------------------------------------------------------------------ driver (pyipm.py:1567-1863)
+    def solve(self):
+        import time
+        torch = self.torch
+        n, me, mi = self.nvar, self.neq, self.nineq
+        x = self.x0.clone()
+        if mi:
+            s = torch.clamp(self.ci(x), min=self.Ktol) if self.s0 is None else self.s0.clone()
+            self.mu_host = self.mu
+        else:
+            s = torch.zeros(0, dtype=torch.float64, device=self.device)
+            self.mu_host = self.Ktol
+        self.nu_host = self.nu
+        if me or mi:
+            if self.lda0 is None:
+                J = torch.cat([m for m in (self.Je, self.Ji) if m is not None], dim=1)
+                lda = torch.linalg.pinv(J) @ self.df(x)
+                del J
+                if mi:
+                    li = lda[me:]
+                    li[li < 0.0] = self.Ktol
+            else:
+                lda = self.lda0.clone()
+        else:
+            lda = torch.zeros(0, dtype=torch.float64, device=self.device)
+        self.delta = 0.0
+        kkt = self.KKT(x, s, lda)
+        if self.verbosity > 0:
+            print('Searching for a feasible local minimizer using the exact Hessian.')
+        iter_count = 0
+        f_past = self.f(x) if self.Ftol is not None else None
+        Ftol_converged = False
+        self.signal = 0
+        outer = inner = 0
+        for outer in range(self.niter):
+            if self._small(kkt, self.Ktol):
+                self.signal = 1
+                break
+            if self.verbosity > 0 and mi:
+                print('OUTER ITERATION {}'.format(outer + 1))
+            for inner in range(self.miter):
+                if self._small(kkt, max(self.Ktol, self.mu_host)):
+                    if not me and not mi:
+                        self.signal = 1
+                    break
+                if self.verbosity > 0:
+                    msg = ['* INNER ITERATION {}'.format(inner + 1) if mi else 'ITERATION {}'.format(iter_count + 1)]
+                    if self.verbosity > 1:
+                        msg.append('f(x) = {}'.format(self.f(x)))
+                    if self.verbosity > 2:
+                        msg += ['|dL/dx| = {}'.format(kkt[0]), '|dL/ds| = {}'.format(kkt[1]),
+                                '|ce| = {}'.format(kkt[2]), '|ci-s| = {}'.format(kkt[3])]
+                    print(', '.join(msg))
+                t0 = time.perf_counter()
+                dz = self.newton_direction(x, s, lda)            # <-- the accelerated hot path
+                if mi:
+                    a_s, a_l = self.backend.step_lengths(self.tau)
+                torch.cuda.synchronize(self.device)
+                t1 = time.perf_counter()
+                if me or mi:                                      # merit parameter (pyipm.py:1727-1735)
+                    bcg = self.df(x)
+                    if mi:
+                        bcg = torch.cat([bcg, -self.mu_host / (s + self.eps)])
+                    den = (1 - self.rho) * float(self._con(x, s).abs().sum())
+                    num = float(torch.dot(bcg, dz[:n + mi]))
+                    with np.errstate(divide='ignore', invalid='ignore'):
+                        nu_thres = np.float64(num) / np.float64(den)
+                    if self.nu_host < nu_thres:
+                        self.nu_host = float(nu_thres)
+                if mi:
+                    x, s, lda = self.search(x, s, lda, dz, float(a_s), float(a_l))
+                else:
+                    x, s, lda = self.search(x, s, lda, dz, 1.0, 1.0)
+                iter_count += 1
+                kkt = self.KKT(x, s, lda)
+                t2 = time.perf_counter()
+                self.timings["newton_s"] += t1 - t0
+                self.timings["search_s"] += t2 - t1
+                if self.Ftol is not None and not mi and self.signal != -2:
+                    f_new = self.f(x)
+                    if abs(f_past - f_new) <= abs(self.Ftol):
+                        self.signal = 2
+                        Ftol_converged = True
+                        break
+                    f_past = f_new
+                if self.signal == -2:
+                    break
+                if inner >= self.miter - 1 and self.verbosity > 0 and mi:
+                    print('MAXIMUM INNER ITERATIONS EXCEEDED')
+            if self.Ftol is not None and mi and self.signal != -2:
+                f_new = self.f(x)
+                if abs(f_past - f_new) <= abs(self.Ftol):
+                    self.signal = 2
+                    Ftol_converged = True
+                else:
+                    f_past = f_new
+            if Ftol_converged or self.signal == -2:
+                break
+            if outer >= self.niter - 1:
+                self.signal = -1
+                if self.verbosity > 0:
+                    print('MAXIMUM OUTER ITERATIONS EXCEEDED' if mi else 'MAXIMUM ITERATIONS EXCEEDED')
+                break
+            if mi:                                                # barrier update (pyipm.py:1804-1814)
+                sl = s * lda[me:]
+                comp, mn = torch.stack([sl.sum(), sl.min()]).tolist()
+                xi = mi * mn / (comp + self.eps)
+                mu_new = 0.1 * min(0.05 * (1.0 - xi) / (xi + self.eps), 2.0) ** 3 * comp / mi
+                self.mu_host = max(float(mu_new), 0.0)
+        self.x, self.s, self.lda, self.kkt = x, s, lda, kkt
+        self.fval = self.f(x)
+        self.iter_count = iter_count
+        if self.verbosity >= 0:
+            words = ('Terminated due to bad direction in backtracking line search' if self.signal == -2 else
+                     'Converged to Ktol tolerance' if self._small(kkt, self.Ktol) else
+                     'Converged to Ftol tolerance' if Ftol_converged else 'Maximum iterations reached')
+            print('{} ({} total iterations).'.format(words, iter_count))
+        return self.x, self.s, self.lda, self.fval, self.kkt

@@ -1,0 +1,87 @@
+"""Device-resident QP interior-point loop (pyipm_amd/qp.py; SURVEY.md section 8f ranks 1+3) against the
+host IPM class driven with the same QP as reference-convention callables, and against closed forms."""
+import numpy as np
+import pytest
+
+from pyipm_amd.problems import make_qp, qp_callables
+
+pytestmark = pytest.mark.gpu
+
+
+def _host_ipm(qp, **kw):
+    from pyipm_amd.ipm import IPM
+    p = qp_callables(qp)
+    return IPM(x0=np.zeros(qp["n"]), f=p["f"], df=p["df"], d2f=p["d2f"], ce=p["ce"], dce=p["dce"], d2ce=p["d2ce"],
+               ci=p["ci"], dci=p["dci"], d2ci=p["d2ci"], verbosity=-1, device_step=True, **kw)
+
+
+def _dev_ipm(qp, **kw):
+    from pyipm_amd.qp import QPDeviceIPM
+    return QPDeviceIPM(qp["Q"], qp["c"], A=qp["A"] if qp["me"] else None, b=qp["b"] if qp["me"] else None,
+                       G=qp["G"] if qp["mi"] else None, h=qp["h"] if qp["mi"] else None, verbosity=-1, **kw)
+
+
+@pytest.mark.parametrize("shape", [(40, 10, 20, 1), (64, 0, 48, 2), (96, 32, 0, 3), (200, 60, 120, 4), (300, 0, 0, 5)])
+@pytest.mark.parametrize("condensed", [False, True])
+def test_device_loop_tracks_host_loop(shape, condensed):
+    n, me, mi, seed = shape
+    qp = make_qp(n, me, mi, seed)
+    kw = dict(Ktol=1e-8, niter=30, miter=30)
+    host = _host_ipm(qp, condensed=condensed, **kw)
+    xh, sh, lh, fh, _ = host.solve()
+    dev = _dev_ipm(qp, condensed=condensed, **kw)
+    xd, sd, ld, fd, kkt = dev.solve()
+    assert dev.signal == host.signal == 1
+    # same algorithm, same Newton core; the provider GEMVs round differently (NumPy vs device), which can
+    # move a stopping test sitting right at its threshold by one iteration
+    assert abs(dev.iter_count - host.iter_count) <= 1
+    np.testing.assert_allclose(xd.cpu().numpy(), xh, rtol=1e-7, atol=1e-9)
+    if mi:
+        np.testing.assert_allclose(sd.cpu().numpy(), sh, rtol=1e-6, atol=1e-9)
+    if me or mi:
+        np.testing.assert_allclose(ld.cpu().numpy(), lh, rtol=1e-5, atol=1e-8)
+    assert abs(fd - float(fh)) <= 1e-9 * max(1.0, abs(float(fh)))
+    assert max(kkt) <= 1e-8
+    # first-order optimality straight from the problem data
+    x, lam = xd.cpu().numpy(), ld.cpu().numpy()
+    r = qp["Q"] @ x + qp["c"]
+    if me:
+        r = r - qp["A"].T @ lam[:me]
+        assert np.linalg.norm(qp["A"] @ x - qp["b"]) <= 1e-7
+    if mi:
+        r = r - qp["G"].T @ lam[me:]
+        slack = qp["G"] @ x - qp["h"]
+        assert slack.min() >= -1e-7 and lam[me:].min() >= 0.0
+        assert np.abs(slack * lam[me:]).max() <= 1e-6
+    assert np.linalg.norm(r) <= 1e-7
+
+
+def test_equality_qp_matches_closed_form():
+    """mi = 0: the minimiser solves [[Q, A'],[A, 0]] [x; -lam] = [-c; b] exactly."""
+    n, me = 256, 64
+    qp = make_qp(n, me, 0, seed=11)
+    dev = _dev_ipm(qp, Ktol=1e-10, niter=30, miter=30)
+    x, s, lam, f, kkt = dev.solve()
+    K = np.block([[qp["Q"], qp["A"].T], [qp["A"], np.zeros((me, me))]])
+    sol = np.linalg.solve(K, np.concatenate([-qp["c"], qp["b"]]))
+    np.testing.assert_allclose(x.cpu().numpy(), sol[:n], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(lam.cpu().numpy(), -sol[n:], rtol=1e-7, atol=1e-9)
+    assert dev.signal == 1
+
+
+def test_medium_qp_all_on_device():
+    """N = 4864: blocks staged once as device tensors, dozens of Newton steps, only scalars cross PCIe."""
+    import torch
+    n, me, mi = 2048, 512, 1152
+    qp = make_qp(n, me, mi, seed=3)
+    d = {k: torch.from_numpy(np.ascontiguousarray(qp[k])).cuda() for k in ("Q", "c", "A", "b", "G", "h")}
+    from pyipm_amd.qp import QPDeviceIPM
+    dev = QPDeviceIPM(d["Q"], d["c"], A=d["A"], b=d["b"], G=d["G"], h=d["h"], verbosity=-1, Ktol=1e-6, niter=30,
+                      condensed=True)
+    x, s, lam, f, kkt = dev.solve()
+    assert dev.signal == 1 and max(kkt) <= 1e-6
+    assert x.is_cuda and s.is_cuda and lam.is_cuda
+    full = QPDeviceIPM(d["Q"], d["c"], A=d["A"], b=d["b"], G=d["G"], h=d["h"], verbosity=-1, Ktol=1e-6, niter=30)
+    x2, _, _, f2, _ = full.solve()
+    assert full.iter_count == dev.iter_count
+    assert float((x - x2).norm() / x2.norm()) <= 1e-7 and abs(f - f2) <= 1e-8 * abs(f2)
