@@ -16,6 +16,7 @@ namespace pyipm {
 #endif
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
+typedef double row16_t __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------
 // K3: invert one 64x64 symmetric tile by symmetric sweeps with Bunch-Kaufman 1x1 / 2x2 pivot
@@ -72,8 +73,8 @@ __global__ __launch_bounds__(256) void k_tile_invert(
         if (i >= j) stage[i][j] = A[(grow0 + i) + (lcol0 + j) * ld];
     }
     __syncthreads();
-    double row[16];
-    double amax = 0.0;
+    row16_t row;                           // native 16-wide vector: a wave-uniform dynamic index becomes ONE
+    double amax = 0.0;                     // relative-addressed move (s_set_gpr_idx), not a 16-deep select chain
     #pragma unroll
     for (int c = 0; c < 16; ++c) {
         const int j = cb + c;
@@ -105,79 +106,72 @@ __global__ __launch_bounds__(256) void k_tile_invert(
     // publish column `col` of the tile (== row `col`) from the wave that holds it: one full-wave store
 #define PYIPM_PUBLISH(col_, dst_)                                                            \
     if (((col_) >> 4) == wave) {                     /* wave-uniform */                       \
-        const int pc_ = (col_) & 15;                                                         \
-        double v_ = row[0];                                                                  \
-        _Pragma("unroll") for (int c = 1; c < 16; ++c) v_ = (pc_ == c) ? row[c] : v_;        \
-        (dst_)[lane] = v_;                                                                   \
+        (dst_)[lane] = row[__builtin_amdgcn_readfirstlane((col_) & 15)];                     \
     }
 
+    // Loop invariant: the BK candidate column p (first unswept index) has been published into
+    // colbuf[parity][0] by the previous iteration (or the prologue), so an iteration starts at the barrier.
+    int p = 0, sel = 0;
+    bool forced = false;                    // pivot already decided (the off-diagonal candidate r): its column
+                                            // sits in colbuf[parity][1], already synchronised
+    PYIPM_PUBLISH(p, colbuf[0][0])
     while (left > 0) {
-        const int p = __ffsll(mask) - 1;    // BK candidate: first unswept index (wave-uniform, scalar)
-        PYIPM_PUBLISH(p, colbuf[parity][0])
-        __syncthreads();
-        const double* rp = colbuf[parity][0];
+        if (!forced) __syncthreads();
+        const double* rp = colbuf[parity][sel];
         const double cpi = rp[lane];        // B[lane][p] (= B[p][lane])
         double cpj[16];                     // this wave's 16 entries of row p
         #pragma unroll
         for (int c = 0; c < 16; ++c) cpj[c] = rp[cb + c];
         const double dpp = readlane_f64(cpi, p);
-        const bool u = (mask >> lane) & 1ull;
-        // r = argmax_{i unswept, i != p} |B[i][p]| chosen on f32 magnitudes scaled by the tile maximum
-        const float magf = (u && lane != p) ? (float)(fabs(cpi) * inv_scale) : -1.0f;
-        const float mx = wave_max_f32(magf);
-        const int r = __builtin_amdgcn_readfirstlane(__ffsll(__ballot(magf == mx)) - 1);
-        const double lam = (left > 1 && mx > 0.0f) ? fabs(readlane_f64(cpi, r)) : 0.0;
-        const double app = fabs(dpp);
-        int kind = 1, which = 0, piv = p;
-        if (lam > 0.0 && app < PYIPM_BK_ALPHA * lam) {          // uniform branch (rare for SPD-like tiles)
-            PYIPM_PUBLISH(r, colbuf[parity][1])
-            __syncthreads();
-            const double* rr = colbuf[parity][1];
-            const double sigma = wave_max((u && lane != r) ? fabs(rr[lane]) : -1.0);
-            const double arr = fabs(rr[r]);
-            if (app * sigma >= PYIPM_BK_ALPHA * lam * lam) { piv = p; }
-            else if (arr >= PYIPM_BK_ALPHA * sigma)        { piv = r; which = 1; }
-            else                                            { kind = 2; }
+        int kind = 1, q = -1;
+        if (!forced) {
+            const bool u = (mask >> lane) & 1ull;
+            const double app = fabs(dpp);
+            // Bunch-Kaufman acceptance |B[p][p]| >= alpha * max_i |B[i][p]| as ONE wave-wide compare: the
+            // maximum itself (a 6-stage DPP reduction + argmax) is only needed when the test fails.
+            if (left > 1 && __ballot(u && lane != p && fabs(cpi) * PYIPM_BK_ALPHA > app) != 0ull) {
+                // r = argmax_{i unswept, i != p} |B[i][p]| chosen on f32 magnitudes scaled by the tile maximum
+                const float magf = (u && lane != p) ? (float)(fabs(cpi) * inv_scale) : -1.0f;
+                const float mx = wave_max_f32(magf);
+                const int r = __builtin_amdgcn_readfirstlane(__ffsll(__ballot(magf == mx)) - 1);
+                const double lam = fabs(readlane_f64(cpi, r));
+                PYIPM_PUBLISH(r, colbuf[parity][1])
+                __syncthreads();
+                const double* rr = colbuf[parity][1];
+                const double sigma = wave_max((u && lane != r) ? fabs(rr[lane]) : -1.0);
+                const double arr = fabs(rr[r]);
+                if (app * sigma >= PYIPM_BK_ALPHA * lam * lam) { /* 1x1 pivot p */ }
+                else if (arr >= PYIPM_BK_ALPHA * sigma)        { forced = true; p = r; sel = 1; continue; }   // 1x1 pivot r
+                else                                            { kind = 2; q = r; }
+            }
         }
         if (kind == 1) {
-            double d, ci;
-            if (which == 0) { d = dpp; ci = cpi; }
-            else {
-                const double* rv = colbuf[parity][1];
-                d = rv[piv]; ci = rv[lane];
-                #pragma unroll
-                for (int c = 0; c < 16; ++c) cpj[c] = rv[cb + c];
-            }
+            double d = dpp;
             const double ad = fabs(d);
-            const double pivtol = pivtol_rel * readlane_f64(cmax0, piv);
+            const double pivtol = pivtol_rel * readlane_f64(cmax0, p);
             if (__builtin_expect(!(ad <= 1.0e308), 0)) bad = 1;          // NaN or Inf
             if (__builtin_expect(ad <= pivtol, 0)) {
-                if (piv < nreal) zero++;
+                if (p < nreal) zero++;
                 const double t = pivtol > 0.0 ? pivtol : tiny;
                 d = (d >= 0.0) ? t : -t;
-            } else if (piv < nreal) {
+            } else if (p < nreal) {
                 neg += (d < 0.0) ? 1 : 0;
                 dmin = fmin(dmin, ad); dmax = fmax(dmax, ad);
             }
             const double inv_d = 1.0 / d;
-            const double lpi = ci * inv_d;
-            const int pw = piv >> 4, pc = piv & 15;              // wave / register holding column piv
-            if (lane == piv) {                                   // one lane: row piv <- cp/d
+            const double lpi = cpi * inv_d;
+            if (lane == p) {                                     // one lane: row p <- cp/d
                 #pragma unroll
                 for (int c = 0; c < 16; ++c) row[c] = cpj[c] * inv_d;
             } else {
                 #pragma unroll
                 for (int c = 0; c < 16; ++c) row[c] = fma(-lpi, cpj[c], row[c]);
             }
-            if (wave == pw) {                                    // wave-uniform: column piv <- lp, pivot <- -1/d
-                const double colv = (lane == piv) ? -inv_d : lpi;
-                #pragma unroll
-                for (int c = 0; c < 16; ++c) row[c] = (pc == c) ? colv : row[c];
-            }
-            mask &= ~(1ull << piv);
+            if (wave == (p >> 4))                                // wave-uniform: column p <- lp, pivot <- -1/d
+                row[__builtin_amdgcn_readfirstlane(p & 15)] = (lane == p) ? -inv_d : lpi;
+            mask &= ~(1ull << p);
             left -= 1;
         } else {
-            const int q = r;
             const double* rq = colbuf[parity][1];
             const double a = rp[p], b = rp[q], cc = rq[q];
             double det = a * cc - b * b;                           // < 0 by the BK test
@@ -208,6 +202,11 @@ __global__ __launch_bounds__(256) void k_tile_invert(
             }
             mask &= ~((1ull << p) | (1ull << q));
             left -= 2;
+        }
+        forced = false; sel = 0;
+        if (left > 0) {
+            p = __ffsll(mask) - 1;          // next BK candidate: first unswept index (wave-uniform, scalar)
+            PYIPM_PUBLISH(p, colbuf[parity ^ 1][0])
         }
         parity ^= 1;
     }
