@@ -171,6 +171,9 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *                    full matrix); kkt_storage then exposes the condensed matrix.  Every condensed solve runs at
  *                    least "condensed_refine" (default 1) refinement steps against the full blocks: the
  *                    recovery dli = Sigma ds - b_s multiplies the rounding of ds by Sigma.
+ *   "block_refine" 0..3 (default 2), "refine_cond" (default 1e3): refinement steps of the block solves
+ *                    L T = S / T z = y for diagonal tiles whose pivot spread exceeds refine_cond (the tile
+ *                    inverses are explicit).
  *   "profile" 0|1, "lookahead" 0|1|2, "group" 1..create-time value, "fuse_forward" 0|1, "pivtol_rel",
  *   "xcd_swizzle", "stagger_mode", "stagger_us_per_k", "side_prio", "bulk_bn", "extra_lds" (diagnostics). */
 int pyipm_newton_set_option(pyipm_newton_ctx* ctx, const char* name, double value);

@@ -11,7 +11,9 @@ imported by the product.
 
 Factorisation:  A = Lb * blockdiag(T_k) * Lb'   with  Lb unit BLOCK lower triangular,
 T_k the k-th Schur-complement diagonal tile,  Lb[i,k] = S[i,k] * inv(T_k)  where
-S is the Schur-complemented column block ("W" on the device).
+S is the Schur-complemented column block ("W" on the device).  The explicit inverse only
+solves Lb T = S to cond(T)*eps, so the block solves get ``refine`` steps of
+R = S - Lb T ; Lb += R inv(T)  (backward-stable rows; same in the substitutions).
 Solve:  y_k = b_k - sum_{j<k} Lb[k,j] y_j ;  z_k = inv(T_k) y_k ;
         x_k = z_k - sum_{i>k} Lb[i,k]' x_i .
 """
@@ -119,7 +121,7 @@ def sweep_invert(T, pivtol_rel=1e-14):
 class BlockLDL(object):
     """Dense block-LDL' of a symmetric matrix with tile size ``tb`` (device: 64)."""
 
-    def __init__(self, A, tb=64, nreal=None):
+    def __init__(self, A, tb=64, nreal=None, refine=1):
         A = np.array(A, dtype=np.float64)
         N = A.shape[0]
         self.N = N
@@ -130,12 +132,16 @@ class BlockLDL(object):
         M[:N, :N] = np.tril(A) + np.tril(A, -1).T
         self.nt = Np // tb
         self.Tinv = []
+        self.T = []
+        self.refine = refine            # refinement steps of the block solves L T = S and T z = y (device: block_refine)
         self.stats = dict(neg=0, zero=0, n2x2=0, dmin=np.inf, dmax=0.0)
         tb_ = tb
         for k in range(self.nt):
             k0, k1 = k * tb_, (k + 1) * tb_
-            Ti, st = sweep_invert(M[k0:k1, k0:k1])
+            T = np.tril(M[k0:k1, k0:k1]) + np.tril(M[k0:k1, k0:k1], -1).T
+            Ti, st = sweep_invert(T)
             self.Tinv.append(Ti)
+            self.T.append(T)
             for key in ("neg", "zero", "n2x2"):
                 self.stats[key] += st[key]
             self.stats["dmin"] = min(self.stats["dmin"], st["dmin"])
@@ -143,6 +149,8 @@ class BlockLDL(object):
             if k1 < Np:
                 W = M[k1:, k0:k1].copy()
                 L = W @ Ti
+                for _ in range(refine):
+                    L = L + (W - L @ T) @ Ti
                 M[k1:, k1:] -= L @ W.T
                 M[k1:, k0:k1] = L
         # padding rows contribute positive unit pivots only
@@ -158,7 +166,11 @@ class BlockLDL(object):
                 y[k1:] -= self.M[k1:, k0:k1] @ y[k0:k1]
         for k in range(nt):
             k0, k1 = k * tb, (k + 1) * tb
-            y[k0:k1] = self.Tinv[k] @ y[k0:k1]
+            yk = y[k0:k1].copy()
+            z = self.Tinv[k] @ yk
+            for _ in range(self.refine):
+                z = z + self.Tinv[k] @ (yk - self.T[k] @ z)
+            y[k0:k1] = z
         for k in range(nt - 1, -1, -1):
             k0, k1 = k * tb, (k + 1) * tb
             if k1 < Np:

@@ -102,6 +102,8 @@ struct Ctx {
     char* ws = nullptr; size_t ws_bytes = 0;
     // carved from workspace
     double *A = nullptr, *Wbuf = nullptr, *Lbuf = nullptr, *Dinv = nullptr;
+    double *Tsv = nullptr;                // the diagonal tiles T_k themselves (refinement of the block solves)
+    double *Tflag = nullptr;              // per tile: 1.0 = refine block solves with it (pivot spread beyond refine_cond)
     double *rhs = nullptr, *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *partial = nullptr;
     double *df = nullptr, *ce = nullptr, *ci = nullptr, *s = nullptr, *lda = nullptr;
     DevStats* dstats = nullptr;
@@ -116,6 +118,8 @@ struct Ctx {
     bool have_direction = false;          // v2 holds the last sign-flipped direction (for step_lengths)
     // options
     double pivtol_rel = 1e-14;
+    int block_refine = 2;                 // refinement steps of L T = S in the panel scaling and of T z = y in the solves
+    double refine_cond = 1.0e3;           // ... applied to tiles whose pivot spread dmax/dmin exceeds this
     int profile = 0;
     // timings of last calls (ms)
     double t_assemble = 0, t_panel = 0, t_trailing = 0, t_solve = 0, t_factor = 0;

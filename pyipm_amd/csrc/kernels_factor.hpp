@@ -55,7 +55,9 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {
 
 __global__ __launch_bounds__(256) void k_tile_invert(
     const double* __restrict__ A, int64_t ld, int64_t grow0, int64_t lcol0,
-    double* __restrict__ Tinv, DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel,
+    double* __restrict__ Tinv, double* __restrict__ Tsave,     // inv(T); the tile T itself (full, symmetric)
+    double* __restrict__ Tflag, double refine_cond,            // *Tflag = 1 when the block solves with this tile need refining
+    DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel,
     unsigned long long* __restrict__ dbg)      // diagnostics only (NULL normally)
 {
     __shared__ double stage[TB][TB + 1];
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(256) void k_tile_invert(
         const int j = cb + c;
         row[c] = (lane >= j) ? stage[lane][j] : stage[j][lane];
         amax = fmax(amax, fabs(row[c]));
+        Tsave[j * TB + lane] = row[c];                 // kept for the refinement of the block solves
     }
     // per-row maximum of the loaded tile (== per-column, by symmetry): the reference scale of a pivot.
     // A pivot counts as rejected only when it has shrunk below pivtol_rel x its OWN column's original
@@ -216,6 +219,10 @@ __global__ __launch_bounds__(256) void k_tile_invert(
     for (int c = 0; c < 16; ++c) Tinv[(cb + c) * TB + lane] = -row[c];
     if (dbg && tid == 0) { dbg[0] = clock64() - dbg_c0; dbg[1] = wall_clock64() - dbg_w0; dbg[2] += 1; }
     if (tid == 0) {
+        // pivot spread of THIS tile ~ cond(T): the explicit inverse is accurate to cond*eps, so only tiles
+        // beyond refine_cond (or with 2x2 pivots) pay for refined block solves.  A tile with a rejected pivot
+        // is singular to working precision: its "inverse" belongs to a perturbed tile, nothing to refine against.
+        *Tflag = (zero == 0 && (n2 > 0 || !(dmax <= refine_cond * dmin))) ? 1.0 : 0.0;
         st->n_neg += neg; st->n_zero += zero; st->n_2x2 += n2; st->n_pos += nreal - neg - zero;
         st->nonfinite += bad;
         if (dmin < st->d_min) st->d_min = dmin;
@@ -232,19 +239,27 @@ __global__ __launch_bounds__(256) void k_panel_scale(
     double* __restrict__ Aout, int64_t ld_out, int64_t col_out,      // L written at Aout[i + (col_out+c)*ld_out]
     const double* __restrict__ Win, int64_t ld_in, int64_t col_in,   // S read from  Win[i + (col_in+k)*ld_in]
     double* __restrict__ Wcopy, int64_t ld_w, int64_t col_w,         // copy of -S (may be NULL = no copy)
-    const double* __restrict__ Tinv, int64_t row_begin, unsigned long long* __restrict__ growth_bits,
+    const double* __restrict__ Tinv, const double* __restrict__ Tsave, const double* __restrict__ Tflag, int nref,
+    int64_t row_begin, unsigned long long* __restrict__ growth_bits,
     double sign)      // owner: Win = S, Wcopy = -S (the update kernel wants -W), sign = +1;
                       // non-owner rebuilding L from a received -S: sign = -1
 {
-    // L[i][c] = sign * sum_k S[i][k] T[k][c] on fp64 MFMA.  D[m][n]: m <- c (A operand = T, symmetric),
-    // n <- i (B operand = S, read straight from global: 16 lanes x 8 B contiguous per k).  One wave owns
-    // 16 rows x 64 columns (4 accumulator tiles); a 256-thread block covers 64 rows.  ~60 VGPRs, so
-    // several blocks fit in the slot one retiring bulk-update block frees.
-    __shared__ double T[TB][TB + 2];
-    __builtin_amdgcn_s_setprio(3);
+    // L[i][c] = sign * sum_k S[i][k] X[k][c], X = inv(T), on fp64 MFMA.  D[m][n]: m <- c (A operand = X,
+    // symmetric), n <- i (B operand = S, read straight from global: 16 lanes x 8 B contiguous per k).  One
+    // wave owns 16 rows x 64 columns (4 accumulator tiles); a 256-thread block covers 64 rows.
+    //
+    // X is an explicit inverse, so L0 = S X solves L T = S only to cond(T)*eps.  nref steps of
+    //     R = S - L T ;  L += R X
+    // make each row of L a backward-stable solution (residual ~ eps |L||T|), which is what keeps the Schur
+    // complement -- and the inertia read off it -- right for ill-conditioned dense tiles.  The f64 C/D map
+    // (row = (lane>>4)+4r of tile t, col = lane&15) puts L[i][16t+4r+(lane>>4)] in accumulator [t][r], which
+    // is exactly the B-operand layout of k-step 4t+r: the refinement GEMMs need no data movement.
+    __shared__ double X[TB][TB + 2];        // holds sign*inv(T), then -sign*T, then sign*inv(T) again (one array: LDS decides
+    __builtin_amdgcn_s_setprio(3);          // how many of these short blocks fit into the slot a retiring update block frees)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    for (int e = tid; e < TB * TB; e += 256) T[e >> 6][e & 63] = sign * Tinv[e];     // symmetric
+    if (nref > 0 && *Tflag == 0.0) nref = 0;            // well-conditioned tile: the plain product is accurate (block-uniform)
+    for (int e = tid; e < TB * TB; e += 256) X[e >> 6][e & 63] = sign * Tinv[e];     // symmetric
     const int64_t i = row_begin + (int64_t)blockIdx.x * TB + wave * 16 + l15;
     double b[16];
     #pragma unroll
@@ -261,8 +276,41 @@ __global__ __launch_bounds__(256) void k_panel_scale(
     for (int ks = 0; ks < 16; ++ks) {
         #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const double a = T[t * 16 + l15][ks * 4 + l4];          // A[m = c][k] = T[c][k]
+            const double a = X[t * 16 + l15][ks * 4 + l4];          // A[m = c][k] = X[c][k]
             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[ks], acc[t], 0, 0, 0);
+        }
+    }
+    for (int it = 0; it < nref; ++it) {
+        __syncthreads();
+        for (int e = tid; e < TB * TB; e += 256) X[e >> 6][e & 63] = -sign * Tsave[e];
+        __syncthreads();
+        // R = S - L T  [D layout]: C operand = S = sign * the loaded b values, in accumulator order
+        double4_t res[4];
+        #pragma unroll
+        for (int t = 0; t < 4; ++t)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) res[t][r] = sign * b[4 * t + r];
+        #pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const double lop = acc[ks >> 2][ks & 3];                 // B[k][n = i] = L[i][k]
+            #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double a = X[t * 16 + l15][ks * 4 + l4];       // -sign*T[c][k], B = sign*L  ->  -T L
+                res[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sign * lop, res[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < TB * TB; e += 256) X[e >> 6][e & 63] = sign * Tinv[e];
+        __syncthreads();
+        // L += R inv(T)   (A = sign*inv(T), B = sign*R)
+        #pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const double rop = sign * res[ks >> 2][ks & 3];
+            #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double a = X[t * 16 + l15][ks * 4 + l4];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rop, acc[t], 0, 0, 0);
+            }
         }
     }
     double gmax = 0.0;

@@ -55,20 +55,40 @@ __global__ __launch_bounds__(256) void k_fwd_gemv(const double* __restrict__ A, 
     v[i] -= (acc0 + acc1) + (acc2 + acc3);
 }
 
-// z_k = inv(T_k) y_k for the tiles of one panel.  grid = tiles, block = 64.
-__global__ __launch_bounds__(64) void k_diag_apply(const double* __restrict__ Dinv, int64_t tile0,
+// z_k = inv(T_k) y_k for the tiles of one panel, refined nref times against T_k itself
+// (r = y - T z ; z += inv(T) r): the explicit inverse alone leaves a residual of cond(T_k)*eps.
+// grid = tiles, block = 64.
+__global__ __launch_bounds__(64) void k_diag_apply(const double* __restrict__ Dinv, const double* __restrict__ Tsave,
+                                                   const double* __restrict__ Tflag, int nref, int64_t tile0,
                                                    int64_t c0, double* __restrict__ v)
 {
     __shared__ double y[TB];
+    __shared__ double w[TB];
     const int lane = threadIdx.x;
     const int64_t base = c0 + (int64_t)blockIdx.x * TB;
-    y[lane] = v[base + lane];
+    const double y0 = v[base + lane];
+    y[lane] = y0;
     __syncthreads();
-    const double* T = Dinv + (tile0 + blockIdx.x) * (int64_t)(TB * TB);
-    double acc = 0.0;
+    const double* X = Dinv + (tile0 + blockIdx.x) * (int64_t)(TB * TB);
+    const double* T = Tsave + (tile0 + blockIdx.x) * (int64_t)(TB * TB);
+    double z = 0.0;
     #pragma unroll 8
-    for (int j = 0; j < TB; ++j) acc = fma(T[j * TB + lane], y[j], acc);
-    v[base + lane] = acc;
+    for (int j = 0; j < TB; ++j) z = fma(X[j * TB + lane], y[j], z);
+    if (Tflag[tile0 + blockIdx.x] == 0.0) nref = 0;      // well-conditioned tile
+    for (int it = 0; it < nref; ++it) {
+        w[lane] = z;
+        __syncthreads();
+        double r = y0;
+        #pragma unroll 8
+        for (int j = 0; j < TB; ++j) r = fma(-T[j * TB + lane], w[j], r);
+        __syncthreads();
+        w[lane] = r;
+        __syncthreads();
+        #pragma unroll 8
+        for (int j = 0; j < TB; ++j) z = fma(X[j * TB + lane], w[j], z);
+        __syncthreads();
+    }
+    v[base + lane] = z;
 }
 
 // Backward, rows below the panel: part[chunk][k] = sum_{i in chunk} A[i, lc0+k] * v[i].

@@ -20,6 +20,8 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
     const size_t oW = cv.take(3 * (size_t)default_group(g.world) * (size_t)g.Npad * g.nb * D);   // -W of a panel group, triple-buffered (2-deep lookahead)
     const size_t oL = cv.take(g.world > 1 ? (size_t)g.Npad * g.nb * D : 256);
     const size_t oD = cv.take((size_t)(g.Npad / TB) * TB * TB * D);
+    const size_t oT = cv.take((size_t)(g.Npad / TB) * TB * TB * D);
+    const size_t oTf = cv.take((size_t)(g.Npad / TB + 1) * D);
     const size_t orhs = cv.take((size_t)g.Npad * D);
     const size_t ov0 = cv.take((size_t)g.Npad * D);
     const size_t ov1 = cv.take((size_t)g.Npad * D);
@@ -41,7 +43,7 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
     if (base) {
         c->vc = (double*)(base + ovc); c->vt = (double*)(base + ovt);
         c->A = (double*)(base + oA); c->Wbuf = (double*)(base + oW); c->Lbuf = (double*)(base + oL);
-        c->Dinv = (double*)(base + oD); c->rhs = (double*)(base + orhs);
+        c->Dinv = (double*)(base + oD); c->Tsv = (double*)(base + oT); c->Tflag = (double*)(base + oTf); c->rhs = (double*)(base + orhs);
         c->v0 = (double*)(base + ov0); c->v1 = (double*)(base + ov1); c->v2 = (double*)(base + ov2);
         c->partial = (double*)(base + op);
         c->df = (double*)(base + odf); c->ce = (double*)(base + oce); c->ci = (double*)(base + oci);
@@ -176,13 +178,15 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
             PYIPM_KCHECK();
         }
         hipLaunchKernelGGL(k_tile_invert, dim3(1), dim3(256), 0, stream, ctx->A, g.Npad, j0, lcol,
-                           ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), ctx->dstats, g.N, ctx->pivtol_rel, ctx->dbg_buf);
+                           ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), ctx->Tsv + (j0 / TB) * (int64_t)(TB * TB),
+                           ctx->Tflag + j0 / TB, ctx->refine_cond, ctx->dstats, g.N, ctx->pivtol_rel, ctx->dbg_buf);
         PYIPM_KCHECK();
         const int64_t below = g.Npad - (j0 + TB);
         if (below > 0) {
             hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(below / TB)), dim3(256), 0, stream,
                                ctx->A, g.Npad, lcol, ctx->A, g.Npad, lcol, W, g.Npad, (int64_t)t * TB,
-                               ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), j0 + TB, &ctx->dstats->growth_bits, 1.0);
+                               ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), ctx->Tsv + (j0 / TB) * (int64_t)(TB * TB),
+                               ctx->Tflag + j0 / TB, ctx->block_refine, j0 + TB, &ctx->dstats->growth_bits, 1.0);
             PYIPM_KCHECK();
         }
     }
@@ -292,7 +296,7 @@ int diag_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr) {
     const Geo& g = ctx->g;
     const int64_t c0 = g.panel_c0(p);
     const int nbw = (int)g.panel_w(p);
-    hipLaunchKernelGGL(k_diag_apply, dim3(nbw / TB), dim3(64), 0, stream, ctx->Dinv, c0 / TB, c0, v);
+    hipLaunchKernelGGL(k_diag_apply, dim3(nbw / TB), dim3(64), 0, stream, ctx->Dinv, ctx->Tsv, ctx->Tflag, ctx->block_refine, c0 / TB, c0, v);
     PYIPM_KCHECK();
     return 0;
 }
@@ -927,13 +931,13 @@ int pyipm_newton_trailing_update_range(pyipm_newton_ctx* h, int64_t p, int64_t f
     return timed_update(ctx, p, 1, q / g.world, n_lp);
 }
 
-// message = [ W rows below the panel (m x nbw, column-major, ld = m) | nbw/64 tile inverses ]
+// message = [ W rows below the panel (m x nbw, column-major, ld = m) | nbw/64 tile inverses | nbw/64 tiles | nbw/64 flags ]
 size_t pyipm_newton_panel_msg_bytes(pyipm_newton_ctx* h, int64_t p) {
     if (check_ctx(h)) return 0;
     const Geo& g = C(h)->g;
     if (p < 0 || p >= g.npanels) return 0;
     const int64_t nbw = g.panel_w(p), m = g.Npad - (g.panel_c0(p) + nbw);
-    return (size_t)(m * nbw + (nbw / TB) * TB * TB) * sizeof(double);
+    return (size_t)(m * nbw + 2 * (nbw / TB) * TB * TB + nbw / TB) * sizeof(double);
 }
 
 int pyipm_newton_panel_pack(pyipm_newton_ctx* h, int64_t p, double* buf) {
@@ -945,8 +949,13 @@ int pyipm_newton_panel_pack(pyipm_newton_ctx* h, int64_t p, double* buf) {
     if (m > 0)
         PYIPM_HIP(hipMemcpy2DAsync(buf, (size_t)m * sizeof(double), wbuf(ctx, p) + c1, (size_t)g.Npad * sizeof(double),
                                    (size_t)m * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
-    PYIPM_HIP(hipMemcpyAsync(buf + m * nbw, ctx->Dinv + (g.panel_c0(p) / TB) * (int64_t)(TB * TB),
-                             (size_t)(nbw / TB) * TB * TB * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    const size_t tbytes = (size_t)(nbw / TB) * TB * TB * sizeof(double);
+    PYIPM_HIP(hipMemcpyAsync(buf + m * nbw, ctx->Dinv + (g.panel_c0(p) / TB) * (int64_t)(TB * TB), tbytes,
+                             hipMemcpyDeviceToDevice, ctx->stream));
+    PYIPM_HIP(hipMemcpyAsync(buf + m * nbw + (nbw / TB) * TB * TB, ctx->Tsv + (g.panel_c0(p) / TB) * (int64_t)(TB * TB),
+                             tbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    PYIPM_HIP(hipMemcpyAsync(buf + m * nbw + 2 * (nbw / TB) * TB * TB, ctx->Tflag + g.panel_c0(p) / TB,
+                             (size_t)(nbw / TB) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return PYIPM_OK;
 }
 
@@ -957,8 +966,12 @@ int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf)
     if (p < 0 || p >= g.npanels || g.owner(p) == g.rank) { ctx->err = "panel_unpack: owner does not unpack"; return PYIPM_E_BADARG; }
     const int64_t nbw = g.panel_w(p), c0 = g.panel_c0(p), c1 = c0 + nbw, m = g.Npad - c1;
     double* dinv = ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB);
-    PYIPM_HIP(hipMemcpyAsync(dinv, buf + m * nbw, (size_t)(nbw / TB) * TB * TB * sizeof(double),
-                             hipMemcpyDeviceToDevice, ctx->stream));
+    double* tsv = ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB);
+    const size_t tbytes = (size_t)(nbw / TB) * TB * TB * sizeof(double);
+    PYIPM_HIP(hipMemcpyAsync(dinv, buf + m * nbw, tbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    PYIPM_HIP(hipMemcpyAsync(tsv, buf + m * nbw + (nbw / TB) * TB * TB, tbytes, hipMemcpyDeviceToDevice, ctx->stream));
+    PYIPM_HIP(hipMemcpyAsync(ctx->Tflag + c0 / TB, buf + m * nbw + 2 * (nbw / TB) * TB * TB,
+                             (size_t)(nbw / TB) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     if (m > 0) {
         PYIPM_HIP(hipMemcpy2DAsync(wbuf(ctx, p) + c1, (size_t)g.Npad * sizeof(double), buf, (size_t)m * sizeof(double),
                                    (size_t)m * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
@@ -966,7 +979,8 @@ int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf)
         for (int t = 0; t < nbw / TB; ++t) {
             hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(m / TB)), dim3(256), 0, ctx->stream,
                                ctx->Lbuf, g.Npad, (int64_t)t * TB, wbuf(ctx, p), g.Npad, (int64_t)t * TB,
-                               (double*)nullptr, (int64_t)0, (int64_t)0, dinv + (int64_t)t * TB * TB, c1,
+                               (double*)nullptr, (int64_t)0, (int64_t)0, dinv + (int64_t)t * TB * TB,
+                               tsv + (int64_t)t * TB * TB, ctx->Tflag + c0 / TB + t, ctx->block_refine, c1,
                                (unsigned long long*)nullptr, -1.0);
             PYIPM_KCHECK();
         }
@@ -1021,6 +1035,8 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     Ctx* ctx = C(h);
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
     if (!strcmp(name, "profile")) { ctx->profile = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "refine_cond")) { ctx->refine_cond = value; return PYIPM_OK; }
+    if (!strcmp(name, "block_refine")) { int v = (int)value; ctx->block_refine = v < 0 ? 0 : (v > 3 ? 3 : v); return PYIPM_OK; }
     if (!strcmp(name, "condensed")) {
         if (value != 0 && ctx->g.world != 1) { ctx->err = "condensed: single-rank handles only"; return PYIPM_E_BADARG; }
         ctx->condensed = (int)value; return PYIPM_OK; }

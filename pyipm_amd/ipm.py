@@ -37,6 +37,8 @@ class HipNewtonBackend(object):
         self.condensed_on = bool(condensed and mi)
         self.condensed_tol = 1e-9           # backward-error bar a condensed direction must meet
         self.n_condensed_fallback = 0
+        self.condensed_fallback_reason = None
+        self.n_calls = 0
         if self.condensed_on:               # factor the (n+me) condensed system
             self.core.set_option("condensed", 1)
         self.n, self.me, self.mi = n, me, mi
@@ -49,6 +51,7 @@ class HipNewtonBackend(object):
                   as_tensor=False):
         """as_tensor: inputs may be device tensors (staged without copies) and dz stays on the device."""
         core, need = self.core, self.me + self.mi
+        self.n_calls += 1
         core.stage_blocks(d2L, Je, Ji)
         core.stage_vectors(df, ce, ci, s, lda, mu=mu, eps=eps)
         g = core.residual()
@@ -61,17 +64,24 @@ class HipNewtonBackend(object):
             st = core.factor()
             self.n_factor += 1
             ok = st["n_zero"] == 0 and st["n_neg"] == need
+            why = "inertia %d/%d, %d rejected pivots" % (st["n_neg"], need, st["n_zero"])
             if ok:
-                dz = core.solve(flip=True, refine=self.refine)
-                raw = dz.clone()
-                raw[self.n + self.mi:] *= -1.0
-                ok = float((core.matvec(raw) - g).norm() / g.norm()) <= self.condensed_tol
+                for refine in (self.refine, max(self.refine, 1) + 3):      # second try: more refinement steps
+                    dz = core.solve(flip=True, refine=refine)
+                    raw = dz.clone()
+                    raw[self.n + self.mi:] *= -1.0
+                    berr = float((core.matvec(raw) - g).norm() / g.norm())
+                    ok = berr <= self.condensed_tol
+                    why = "backward error %.1e after %d refinement steps" % (berr, max(refine, 1))
+                    if ok:
+                        break
             if ok:
                 if not as_tensor:
                     dz = dz.cpu().numpy()
                 return dz, 0.0 if delta == 0.0 else float(delta), st
             self.condensed_on = False
             self.n_condensed_fallback += 1
+            self.condensed_fallback_reason = "call %d: %s" % (self.n_calls, why)
             core.set_option("condensed", 0)
         core.assemble(0.0, 0.0)
         st = core.factor()

@@ -70,6 +70,7 @@ class ModelCore(object):
         self.W = {}
         self.L = {}
         self.Tinv = {}
+        self.Tsave = {}
 
     def factor_begin(self):
         self.st = dict(n_neg=0, n_zero=0, n_2x2=0, n_pos=0, nonfinite=0, d_min=1e308, d_max=0.0, growth=0.0)
@@ -88,13 +89,17 @@ class ModelCore(object):
             T = self.A[j0:j0 + tb, l0:l0 + tb]
             Ti, s = self.sweep_invert(T)
             self.Tinv[(p, t)] = Ti
+            Tf = np.tril(T) + np.tril(T, -1).T
+            self.Tsave[(p, t)] = Tf
             real = max(0, min(tb, self.N - j0))
             self.st["n_neg"] += s["neg"]; self.st["n_zero"] += s["zero"]; self.st["n_2x2"] += s["n2x2"]
             self.st["n_pos"] += real - s["neg"] - s["zero"] if real else 0
             self.st["d_min"] = min(self.st["d_min"], s["dmin"]); self.st["d_max"] = max(self.st["d_max"], s["dmax"])
             below = slice(j0 + tb, self.Npad)
             W[below, t * tb:(t + 1) * tb] = self.A[below, l0:l0 + tb]
-            Lt = W[below, t * tb:(t + 1) * tb] @ Ti
+            St = W[below, t * tb:(t + 1) * tb]
+            Lt = St @ Ti
+            Lt = Lt + (St - Lt @ Tf) @ Ti           # one refinement step of L T = S (as on the device)
             self.A[below, l0:l0 + tb] = Lt
             if Lt.size:
                 self.st["growth"] = max(self.st["growth"], float(np.abs(Lt).max()))
@@ -104,14 +109,16 @@ class ModelCore(object):
     def panel_msg_numel(self, p):
         nbw = self.pw(p)
         m = self.Npad - (p * self.nb + nbw)
-        return m * nbw + (nbw // self.tb) * self.tb * self.tb
+        return m * nbw + 2 * (nbw // self.tb) * self.tb * self.tb + nbw // self.tb
 
     def panel_pack(self, p, buf):
         nbw = self.pw(p); c1 = p * self.nb + nbw; m = self.Npad - c1
         out = buf.numpy()
         out[:m * nbw] = self.W[p][c1:, :].T.reshape(-1)             # column-major, ld = m
-        for t in range(nbw // self.tb):
-            out[m * nbw + t * self.tb ** 2: m * nbw + (t + 1) * self.tb ** 2] = self.Tinv[(p, t)].reshape(-1)
+        nt, t2 = nbw // self.tb, self.tb ** 2
+        for t in range(nt):
+            out[m * nbw + t * t2: m * nbw + (t + 1) * t2] = self.Tinv[(p, t)].reshape(-1)
+            out[m * nbw + (nt + t) * t2: m * nbw + (nt + t + 1) * t2] = self.Tsave[(p, t)].reshape(-1)
 
     def panel_unpack(self, p, buf):
         assert p % self.world != self.rank
@@ -120,9 +127,14 @@ class ModelCore(object):
         W = np.zeros((self.Npad, nbw))
         W[c1:, :] = arr[:m * nbw].reshape(nbw, m).T
         L = np.zeros((self.Npad, nbw))
-        for t in range(nbw // tb):
-            Ti = arr[m * nbw + t * tb * tb: m * nbw + (t + 1) * tb * tb].reshape(tb, tb)
-            L[c1:, t * tb:(t + 1) * tb] = W[c1:, t * tb:(t + 1) * tb] @ Ti
+        nt = nbw // tb
+        for t in range(nt):
+            Ti = arr[m * nbw + t * tb * tb: m * nbw + (t + 1) * tb * tb].reshape(tb, tb).copy()
+            Tf = arr[m * nbw + (nt + t) * tb * tb: m * nbw + (nt + t + 1) * tb * tb].reshape(tb, tb).copy()
+            self.Tinv[(p, t)], self.Tsave[(p, t)] = Ti, Tf
+            St = W[c1:, t * tb:(t + 1) * tb]
+            Lt = St @ Ti
+            L[c1:, t * tb:(t + 1) * tb] = Lt + (St - Lt @ Tf) @ Ti
         self.W[p], self.L[p] = W, L
 
     def trailing_update(self, p):
@@ -150,7 +162,9 @@ class ModelCore(object):
         x = v.numpy(); tb = self.tb
         for t in range(self.pw(p) // tb):
             j0 = p * self.nb + t * tb
-            x[j0:j0 + tb] = self.Tinv[(p, t)] @ x[j0:j0 + tb]
+            y = x[j0:j0 + tb].copy()
+            z = self.Tinv[(p, t)] @ y
+            x[j0:j0 + tb] = z + self.Tinv[(p, t)] @ (y - self.Tsave[(p, t)] @ z)
 
     def bwd_panel(self, p, v):
         x = v.numpy(); tb = self.tb

@@ -215,3 +215,31 @@ def test_condensed_large_properties():
     dzf, _ = full.step(0.0, 0.0)
     dzc, _ = core.step(0.0, 0.0)
     assert float((dzc - dzf).norm() / dzf.norm()) <= TOL_DZ
+
+
+@pytest.mark.parametrize("smax", [1e6, 1e9, 1e11])
+def test_ill_conditioned_tiles_keep_inertia(smax):
+    """Dense ill-conditioned diagonal tiles (H + Ji Sigma Ji' with Sigma up to smax): the block pivots are
+    explicit inverses, so without the refinement of the block solves (block_refine) the Schur complement
+    loses ~eps*cond and the inertia goes wrong near Sigma ~ 1e9-1e10; with it the factor reports the inertia of
+    the full matrix and a refined solve reaches a small backward error."""
+    n, me, mi = 200, 60, 120
+    qp = make_qp(n, me, mi, 4)
+    rng = np.random.default_rng(0)
+    sig = np.exp(rng.uniform(np.log(1e-12), np.log(smax), mi))
+    sig[:5] = smax
+    s = rng.uniform(0.5, 2.0, mi)
+    lam = np.concatenate([qp["lam"][:me], sig * s])          # Sigma = lam_i / s
+    core = _core(n, me, mi)
+    core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    core.stage_vectors(qp["df"], qp["ce"], qp["ci"], s, lam, mu=qp["mu"])
+    g = core.residual()
+    core.assemble(0.0, 0.0)
+    st = core.factor()
+    assert st["n_neg"] == me + mi and st["n_zero"] == 0, st
+    raw = core.solve(flip=False, refine=2)
+    assert float((core.matvec(raw) - g).norm() / g.norm()) <= 1e-9
+    if smax >= 1e11:
+        core.set_option("block_refine", 0)
+        core.assemble(0.0, 0.0)
+        assert core.factor()["n_neg"] != me + mi              # the unrefined block algorithm does lose it

@@ -37,7 +37,8 @@ def main():
                n, me, mi, n + 2 * mi + me, args.seed, args.ktol),
            "condensed": bool(args.condensed), "signal": ipm.signal, "iterations": ipm.iter_count,
            "factorisations": ipm.backend.n_factor,
-           "condensed_fallbacks": ipm.backend.n_condensed_fallback, "condensed_still_on": ipm.backend.condensed_on, "solve_seconds": dt, "newton_seconds": ipm.timings["newton_s"],
+           "condensed_fallbacks": ipm.backend.n_condensed_fallback, "condensed_still_on": ipm.backend.condensed_on,
+           "condensed_fallback_reason": ipm.backend.condensed_fallback_reason, "solve_seconds": dt, "newton_seconds": ipm.timings["newton_s"],
            "search_seconds": ipm.timings["search_s"], "merit_evaluations": ipm.timings["n_phi"],
            "kkt_norms": list(kkt), "fval": f}
     print(json.dumps(out))
