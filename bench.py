@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="also report the backward error of the last step")
     ap.add_argument("--force-dist", action="store_true", help="use the per-panel distributed driver even for 1 GPU")
+    ap.add_argument("--force-lookahead", action="store_true", help="with --force-dist on one GPU: run the overlapped multi-GPU schedule")
     ap.add_argument("--opt", action="append", default=[], help="core option name=value (e.g. xcd_swizzle=0, lookahead=0)")
     args = ap.parse_args()
 
@@ -175,6 +176,7 @@ def main():
     if use_dist:
         from pyipm_amd.dist import DistNewton
         drv = DistNewton(core)
+        drv.force_lookahead = args.force_lookahead
 
         def one_step():
             return drv.step(0.0, 0.0, refine=args.refine)

@@ -46,6 +46,7 @@ class DistNewton(object):
         self._msg = None
         self.bytes_broadcast = 0
         self.lookahead = True
+        self.force_lookahead = False
         # the owner of the next panel factors it on a high-priority side stream while its own share of the
         # bulk update runs on the main stream (HIP cores only; the NumPy model backend has no streams)
         self.overlap_owner = bool(getattr(core, "on_device", True)) and hasattr(core, "sync_stream")
@@ -78,7 +79,11 @@ class DistNewton(object):
 
     # ------------------------------------------------------------------ phases
     def factor(self):
-        return self._factor_lookahead() if (self.lookahead and self.world > 1) else self._factor_lockstep()
+        # world == 1 normally takes the lock-step loop; force_lookahead lets a single rank run the overlapped
+        # schedule (side stream + asynchronous broadcasts) so it can be exercised on a one-GPU box
+        if self.lookahead and (self.world > 1 or self.force_lookahead):
+            return self._factor_lookahead()
+        return self._factor_lockstep()
 
     def _factor_lockstep(self):
         core = self.core
@@ -124,6 +129,8 @@ class DistNewton(object):
                 core.panel_pack(p, buf)
             if self.stage:                                   # host-staged (test) path: blocking, same ordering
                 self._bcast(buf, self.owner(p))
+                return None, buf
+            if self.world == 1 and not dist.is_initialized():
                 return None, buf
             work = dist.broadcast(buf, src=self.owner(p), group=self.group, async_op=True)
             self.bytes_broadcast += buf.numel() * 8
