@@ -168,9 +168,10 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *   "condensed" 0|1  single-rank handles with mi > 0: assemble/factor/solve work on the condensed system
  *                    [[d2L + delta I + Ji Sigma Ji', Je], [Je', -delta_c I]] of dimension n+me (s and lambda_i
  *                    eliminated analytically).  Same inputs, same outputs (full [dx|ds|dle|dli], inertia of the
- *                    full matrix); kkt_storage then exposes the condensed matrix.  Every condensed solve runs at
- *                    least "condensed_refine" (default 1) refinement steps against the full blocks: the
- *                    recovery dli = Sigma ds - b_s multiplies the rounding of ds by Sigma.
+ *                    full matrix); kkt_storage then exposes the condensed matrix.
+ *   "condensed_sigma_max" (default 1e4): inequalities whose Sigma_k = lda_i/(s+eps) exceeds it are not folded
+ *                    into the x-x block but kept as rows with -1/Sigma_k on the diagonal (dimension n+me+|A|);
+ *                    "condensed_refine" (default 0): refinement steps every condensed solve gets at least.
  *   "block_refine" 0..3 (default 2), "refine_cond" (default 1e3): refinement steps of the block solves
  *                    L T = S / T z = y for diagonal tiles whose pivot spread exceeds refine_cond (the tile
  *                    inverses are explicit).

@@ -89,10 +89,14 @@ struct Ctx {
     // condensed KKT option: factor the (n+me)-dimensional system
     //   [[H + delta I + Ji Sigma Ji', Je], [Je', -delta_c I]]  instead of the full (n+2mi+me) one
     int condensed = 0;                    // requested by set_option("condensed", 1); single-rank, mi > 0
-    int cond_min_refine = 1;              // refinement steps against the FULL blocks every condensed solve gets at least
-                                          // (dli = Sigma ds - b_s amplifies the rounding of ds by Sigma; one step repairs it)
+    int cond_min_refine = 0;              // refinement steps against the FULL blocks every condensed solve gets at least
+                                          // (dli = Sigma ds - b_s amplifies the rounding of ds by Sigma <= cond_sigma_max)
     bool cond_active = false;             // the current assembled / factored matrix is the condensed one
-    Geo gc;                               // geometry of the condensed system (mi = 0)
+    Geo gc;                               // geometry of the condensed system: (n, me + cond_na, 0), set by assemble
+    double cond_sigma_max = 1.0e4;        // inequalities with Sigma above this stay explicit rows (-1/Sigma diagonal)
+    int64_t cond_na = 0;                  // |A| of the current condensed system
+    int *cond_pos = nullptr, *cond_idx = nullptr, *cond_cnt = nullptr;   // device: position in A / members / count
+    double* Jx = nullptr; size_t jx_bytes = 0;     // [Je | Ji[:, A]] (lazily hipMalloc'd)
     double *JT = nullptr, *WT = nullptr;  // Ji' and Sigma Ji' operands of the rank-mi update (lazily hipMalloc'd)
     size_t jt_bytes = 0;
     double *vc = nullptr, *vt = nullptr;  // condensed vector / mi-sized temporary (carved)

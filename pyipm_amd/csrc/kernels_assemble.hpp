@@ -227,16 +227,74 @@ __global__ __launch_bounds__(256) void k_step_lengths(
 }
 
 // ---- condensed KKT: eliminate s and lambda_i ---------------------------
-//   (H + delta I + Ji Sigma Ji') dx + Je dle = b_x + Ji (Sigma b_i + b_s) ,  Je' dx - delta_c dle = b_e
-//   ds = Ji' dx - b_i ,  dli = Sigma ds - b_s          (Sigma = lda_i / (s + eps), pyipm.py:498)
+// Inequalities are split by Sigma_k = lda_i[k] / (s[k] + eps) (pyipm.py:498):
+//   I (Sigma_k <= theta): pair (s_k, lambda_i_k) eliminated ->  Ji_I Sigma_I Ji_I' added to the x-x block;
+//   A (Sigma_k >  theta): only s_k eliminated; lambda_i_k stays as a row  Ji_k' dx - dli_k / Sigma_k = b_i + b_s / Sigma_k
+// (the active constraints late in a run: folding a Sigma ~ 1e10 into the x-x block would make a dense
+// matrix of that condition number and multiply the rounding of ds by Sigma; as a row it tends to an
+// equality constraint).  System, dimension n + me + |A|, order [x | lambda_e | lambda_A]:
+//   [[H + delta I + Ji_I Sigma_I Ji_I', Je, Ji_A], [Je', -delta_c I, 0], [Ji_A', 0, -Sigma_A^-1]]
+//   rhs [ b_x + Ji_I (Sigma_I b_i + b_s)_I ; b_e ; (b_i + b_s / Sigma)_A ]
+//   recovery  I: ds = Ji' dx - b_i , dli = Sigma ds - b_s ;   A: dli from the solve, ds = (dli + b_s) / Sigma
 
-// JT[i + k*ldt] = Ji[i][k]  and  WT[i + k*ldt] = Sigma_k Ji[i][k]  (i < n, k < mi; zero elsewhere up to
-// rows ldt / columns mi_pad): the operands of the rank-mi MFMA update  C += JT * WT' = C + Ji Sigma Ji'
+// pos[k] = index of k inside A (or -1), idx[j] = k of the j-th member, *count = |A|.  One block.
+__global__ __launch_bounds__(1024) void k_active_scan(int* __restrict__ pos, int* __restrict__ idx, int* __restrict__ count,
+                                                       const double* __restrict__ s, const double* __restrict__ lda_i,
+                                                       double eps, double theta, int64_t mi)
+{
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (mi + 1023) / 1024, k0 = t * per;
+    int64_t k1 = k0 + per; if (k1 > mi) k1 = mi;
+    int c = 0;
+    for (int64_t k = k0; k < k1; ++k) c += (lda_i[k] / (s[k] + eps) > theta) ? 1 : 0;
+    part[t] = c;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // inclusive Hillis-Steele scan
+        const int v = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int at = part[t] - c;
+    for (int64_t k = k0; k < k1; ++k) {
+        if (lda_i[k] / (s[k] + eps) > theta) { pos[k] = at; idx[at] = (int)k; ++at; }
+        else pos[k] = -1;
+    }
+    if (t == 1023) *count = part[1023];
+}
+
+// Jx = [ Je | Ji[:, A] ]  (n x (me + na), row-major): the "equality-like" Jacobian of the condensed system
+__global__ __launch_bounds__(256) void k_cond_gather_J(double* __restrict__ Jx, int64_t ldx,
+                                                       const double* __restrict__ Je, int64_t ldje, int64_t me,
+                                                       const double* __restrict__ Ji, int64_t ldji,
+                                                       const int* __restrict__ idx, int64_t na)
+{
+    const int64_t i = blockIdx.x;                         // row (grid.x: no 65535 limit)
+    const int64_t a = (int64_t)blockIdx.y * 256 + threadIdx.x;
+    if (a >= me + na) return;
+    Jx[i * ldx + a] = (a < me) ? Je[i * ldje + a] : Ji[i * ldji + idx[a - me]];
+}
+
+// diagonal of the lambda_A rows: -1 / Sigma_k
+__global__ __launch_bounds__(256) void k_cond_fix_diag(double* __restrict__ A, int64_t ld, int64_t r0,
+                                                       const int* __restrict__ idx, int64_t na,
+                                                       const double* __restrict__ s, const double* __restrict__ lda_i, double eps)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= na) return;
+    const int k = idx[j];
+    A[(r0 + j) * (ld + 1)] = -(s[k] + eps) / lda_i[k];
+}
+
+// JT[i + k*ldt] = Ji[i][k]  and  WT[i + k*ldt] = Sigma_k Ji[i][k]  (i < n, k in I; zero elsewhere up to
+// rows ldt / columns mi_pad): the operands of the rank-mi MFMA update  C += JT * WT' = C + Ji_I Sigma_I Ji_I'
 // (k_update accumulates Lop * Wop'; the factorisation feeds it the pre-negated W).
 // 32x32 tiles through LDS: reads coalesced along k, writes coalesced along i.
 __global__ __launch_bounds__(256) void k_transpose_scale(
     double* __restrict__ JT, double* __restrict__ WT, int64_t ldt, const double* __restrict__ Ji, int64_t ldji,
-    int64_t n, int64_t mi, int64_t mi_pad, const double* __restrict__ s, const double* __restrict__ lda_i, double eps)
+    int64_t n, int64_t mi, int64_t mi_pad, const double* __restrict__ s, const double* __restrict__ lda_i, double eps,
+    const int* __restrict__ pos)
 {
     __shared__ double tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
@@ -252,36 +310,46 @@ __global__ __launch_bounds__(256) void k_transpose_scale(
         const int64_t k = k0 + ty + 8 * r, i = i0 + tx;
         if (k < mi_pad && i < ldt) {
             const double v = tile[tx][ty + 8 * r];
-            const double sg = (k < mi) ? lda_i[k] / (s[k] + eps) : 0.0;
+            const double sg = (k < mi && pos[k] < 0) ? lda_i[k] / (s[k] + eps) : 0.0;
             JT[i + k * ldt] = v;
             WT[i + k * ldt] = sg * v;
         }
     }
 }
 
-// t[k] = -(Sigma_k b_i[k] + b_s[k])   (negated so k_rowdot2's "base - acc" form yields b_x + Ji t)
+// t[k] = -(Sigma_k b_i[k] + b_s[k]) for k in I, 0 for k in A   (negated: k_rowdot2's "base - acc" form yields b_x + Ji t)
 __global__ __launch_bounds__(256) void k_cond_t(double* __restrict__ t, const double* __restrict__ b, Geo g,
-                                                const double* __restrict__ s, const double* __restrict__ lda_i, double eps)
+                                                const double* __restrict__ s, const double* __restrict__ lda_i, double eps,
+                                                const int* __restrict__ pos)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= g.mi) return;
     const double sg = lda_i[k] / (s[k] + eps);
-    t[k] = -(sg * b[g.n + g.mi + g.me + k] + b[g.n + k]);
+    t[k] = (pos[k] < 0) ? -(sg * b[g.n + g.mi + g.me + k] + b[g.n + k]) : 0.0;
 }
 
-// condensed right-hand side tail: vc[n + a] = b_e[a], zero pad up to npad_c
-__global__ __launch_bounds__(256) void k_cond_gather(double* __restrict__ vc, const double* __restrict__ b, Geo g, int64_t npad_c)
+// condensed right-hand side tail: vc[n + a] = b_e[a] ; vc[n + me + j] = b_i[k] + b_s[k] / Sigma_k, k = idx[j] ; zero pad
+__global__ __launch_bounds__(256) void k_cond_gather(double* __restrict__ vc, const double* __restrict__ b, Geo g, int64_t npad_c,
+                                                     const int* __restrict__ idx, int64_t na,
+                                                     const double* __restrict__ s, const double* __restrict__ lda_i, double eps)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = g.n + t;
     if (i >= npad_c) return;
-    vc[i] = (t < g.me) ? b[g.n + g.mi + t] : 0.0;
+    double v = 0.0;
+    if (t < g.me) v = b[g.n + g.mi + t];
+    else if (t < g.me + na) {
+        const int k = idx[t - g.me];
+        v = b[g.n + g.mi + g.me + k] + b[g.n + k] * (s[k] + eps) / lda_i[k];
+    }
+    vc[i] = v;
 }
 
 // full solution from the condensed one: v (holding b on entry) <- [dx ; ds ; dle ; dli],  u = Ji' dx
 __global__ __launch_bounds__(256) void k_cond_expand(double* __restrict__ v, const double* __restrict__ vc,
                                                      const double* __restrict__ u, Geo g,
-                                                     const double* __restrict__ s, const double* __restrict__ lda_i, double eps)
+                                                     const double* __restrict__ s, const double* __restrict__ lda_i, double eps,
+                                                     const int* __restrict__ pos)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= g.Npad) return;
@@ -290,9 +358,12 @@ __global__ __launch_bounds__(256) void k_cond_expand(double* __restrict__ v, con
     if (i < n + mi) {                                   // one thread does the (s, lambda_i) pair of index k
         const int64_t k = i - n;
         const double bs = v[n + k], bi = v[n + mi + me + k];
-        const double ds = u[k] - bi;
+        const double sg = lda_i[k] / (s[k] + eps);
+        double ds, dl;
+        if (pos[k] < 0) { ds = u[k] - bi; dl = sg * ds - bs; }
+        else            { dl = vc[n + me + pos[k]]; ds = (dl + bs) / sg; }
         v[n + k] = ds;
-        v[n + mi + me + k] = lda_i[k] / (s[k] + eps) * ds - bs;
+        v[n + mi + me + k] = dl;
         return;
     }
     if (i < n + mi + me) { v[i] = vc[n + (i - n - mi)]; return; }

@@ -334,14 +334,16 @@ int solve_plain(Ctx* ctx, double* v, bool forward_done) {
 // vc <- [ b_x + Ji (Sigma b_i + b_s) ; b_e ; 0 ]   from a full-order right-hand side b
 int cond_reduce(Ctx* ctx, const double* b, double* vc) {
     const Geo& g = ctx->g;
-    hipLaunchKernelGGL(k_cond_t, grid1(g.mi), dim3(256), 0, ctx->stream, ctx->vt, b, g, ctx->s, ctx->lda + g.me, ctx->eps);
+    hipLaunchKernelGGL(k_cond_t, grid1(g.mi), dim3(256), 0, ctx->stream, ctx->vt, b, g, ctx->s, ctx->lda + g.me, ctx->eps,
+                       ctx->cond_pos);
     PYIPM_KCHECK();
     hipLaunchKernelGGL(k_rowdot2, grid1(g.n, 4), dim3(256), 0, ctx->stream, vc, b, g.n,
                        (const double*)nullptr, (int64_t)0, (const double*)nullptr, (int64_t)0,
                        ctx->Ji, ctx->ld_Ji, ctx->vt, g.mi, 0, 0);
     PYIPM_KCHECK();
     if (ctx->gc.Npad > g.n) {
-        hipLaunchKernelGGL(k_cond_gather, grid1(ctx->gc.Npad - g.n), dim3(256), 0, ctx->stream, vc, b, g, ctx->gc.Npad);
+        hipLaunchKernelGGL(k_cond_gather, grid1(ctx->gc.Npad - g.n), dim3(256), 0, ctx->stream, vc, b, g, ctx->gc.Npad,
+                           ctx->cond_idx, ctx->cond_na, ctx->s, ctx->lda + g.me, ctx->eps);
         PYIPM_KCHECK();
     }
     return 0;
@@ -357,7 +359,8 @@ int cond_expand(Ctx* ctx, const double* vc, double* v) {
     PYIPM_KCHECK();
     hipLaunchKernelGGL(k_coldot_reduce, grid1(g.mi), dim3(256), 0, ctx->stream, ctx->vt, ctx->partial, g.mi, nchunk, 0);
     PYIPM_KCHECK();
-    hipLaunchKernelGGL(k_cond_expand, grid1(g.Npad), dim3(256), 0, ctx->stream, v, vc, ctx->vt, g, ctx->s, ctx->lda + g.me, ctx->eps);
+    hipLaunchKernelGGL(k_cond_expand, grid1(g.Npad), dim3(256), 0, ctx->stream, v, vc, ctx->vt, g, ctx->s, ctx->lda + g.me, ctx->eps,
+                       ctx->cond_pos);
     PYIPM_KCHECK();
     return 0;
 }
@@ -438,11 +441,14 @@ int residual_dev(Ctx* ctx) {
     return 0;
 }
 
-// Condensed assembly: A (ld = gc.Npad) <- tril [[H + delta I, Je],[Je', -delta_c I]] by K1 on the condensed
-// geometry, then  += Ji Sigma Ji'  as ONE rank-mi launch of the MFMA update kernel (C += JT * WT').
+// Condensed assembly.  Split the inequalities by Sigma (k_active_scan), then
+//   A (ld = gc.Npad) <- tril [[H + delta I, Jx], [Jx', D]]   by K1 on the condensed geometry, Jx = [Je | Ji_A],
+//                        D = diag(-delta_c I, -1/Sigma_A);
+//   += Ji_I Sigma_I Ji_I'   as ONE rank-mi launch of the MFMA update kernel (C += JT * WT').
 int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
-    const Geo& g = ctx->g; const Geo& gc = ctx->gc;
-    const int64_t mi_pad = (g.mi + BKU - 1) / BKU * BKU, ldt = gc.Npad;
+    const Geo& g = ctx->g;
+    const int64_t nx = (g.n + BM - 1) / BM * BM;                 // rows / columns of the x-x block the Gram launch touches
+    const int64_t mi_pad = (g.mi + BKU - 1) / BKU * BKU, ldt = nx;
     const size_t need = 2 * (size_t)ldt * (size_t)mi_pad * sizeof(double);
     if (ctx->jt_bytes < need) {
         if (ctx->JT) PYIPM_HIP(hipFree(ctx->JT));
@@ -450,20 +456,55 @@ int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
         if (hipMalloc((void**)&ctx->JT, need) != hipSuccess) { ctx->err = "condensed: no memory for the Ji' operands"; return PYIPM_E_NOMEM; }
         ctx->jt_bytes = need;
     }
+    if (!ctx->cond_pos) {
+        if (hipMalloc((void**)&ctx->cond_pos, (size_t)(2 * g.mi + 4) * sizeof(int)) != hipSuccess) { ctx->err = "condensed: no memory"; return PYIPM_E_NOMEM; }
+        ctx->cond_idx = ctx->cond_pos + g.mi;
+        ctx->cond_cnt = ctx->cond_idx + g.mi;
+    }
+    // active rows: Sigma_k > cond_sigma_max  (one scalar comes back to size the system)
+    hipLaunchKernelGGL(k_active_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->cond_pos, ctx->cond_idx, ctx->cond_cnt,
+                       ctx->s, ctx->lda + g.me, ctx->eps, ctx->cond_sigma_max, g.mi);
+    PYIPM_KCHECK();
+    int na = 0;
+    PYIPM_HIP(hipMemcpyAsync(&na, ctx->cond_cnt, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->cond_na = na;
+    ctx->gc = make_geo(g.n, g.me + na, 0, g.nb, 1, 0);
+    const Geo& gc = ctx->gc;
+    const int64_t mx = g.me + na;
     ctx->WT = ctx->JT + (size_t)ldt * (size_t)mi_pad;
+    const double* Jx = ctx->Je; int64_t ldx = ctx->ld_Je;
+    if (na > 0) {
+        const size_t jneed = (size_t)g.n * (size_t)(g.me + g.mi) * sizeof(double);
+        if (ctx->jx_bytes < jneed) {
+            if (ctx->Jx) PYIPM_HIP(hipFree(ctx->Jx));
+            ctx->Jx = nullptr; ctx->jx_bytes = 0;
+            if (hipMalloc((void**)&ctx->Jx, jneed) != hipSuccess) { ctx->err = "condensed: no memory for [Je | Ji_A]"; return PYIPM_E_NOMEM; }
+            ctx->jx_bytes = jneed;
+        }
+        dim3 grid((unsigned)g.n, (unsigned)((mx + 255) / 256));
+        hipLaunchKernelGGL(k_cond_gather_J, grid, dim3(256), 0, ctx->stream, ctx->Jx, mx, ctx->Je, ctx->ld_Je, g.me,
+                           ctx->Ji, ctx->ld_Ji, ctx->cond_idx, (int64_t)na);
+        PYIPM_KCHECK();
+        Jx = ctx->Jx; ldx = mx;
+    }
     {
         dim3 grid((unsigned)((gc.Npad + 511) / 512), (unsigned)((gc.ncols_local + 15) / 16));
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, gc.Npad, gc, ctx->d2L, ctx->ld_d2L,
-                           ctx->Je, ctx->ld_Je, (const double*)nullptr, (int64_t)0, ctx->s, ctx->lda, ctx->eps, delta, delta_c);
+                           Jx, ldx, (const double*)nullptr, (int64_t)0, ctx->s, ctx->lda, ctx->eps, delta, delta_c);
         PYIPM_KCHECK();
+        if (na > 0) {
+            hipLaunchKernelGGL(k_cond_fix_diag, grid1(na), dim3(256), 0, ctx->stream, ctx->A, gc.Npad, g.n + g.me,
+                               ctx->cond_idx, (int64_t)na, ctx->s, ctx->lda + g.me, ctx->eps);
+            PYIPM_KCHECK();
+        }
     }
     {
         dim3 grid((unsigned)((ldt + 31) / 32), (unsigned)((mi_pad + 31) / 32));
         hipLaunchKernelGGL(k_transpose_scale, grid, dim3(256), 0, ctx->stream, ctx->JT, ctx->WT, ldt, ctx->Ji, ctx->ld_Ji,
-                           g.n, g.mi, mi_pad, ctx->s, ctx->lda + g.me, ctx->eps);
+                           g.n, g.mi, mi_pad, ctx->s, ctx->lda + g.me, ctx->eps, ctx->cond_pos);
         PYIPM_KCHECK();
     }
-    const int64_t nx = (g.n + BM - 1) / BM * BM;                 // rows / columns touched: the x-x block
     if (ctx->profile) PYIPM_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
     {
         GeoSwap sw(ctx, gc);
@@ -621,7 +662,9 @@ int factor_dispatch(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward) {
     int rc;
     ctx->fwd_vec = ctx->vc;
     { GeoSwap sw(ctx, ctx->gc); rc = factor_all(ctx, stats, fuse_forward); }
-    stats->n_neg += ctx->g.mi; stats->n_pos += ctx->g.mi;
+    // eliminated pairs (I) carry one negative and one positive eigenvalue each; an active row kept in the
+    // system already counts its negative one there, the positive one is its eliminated Sigma_k pivot
+    stats->n_neg += ctx->g.mi - ctx->cond_na; stats->n_pos += ctx->g.mi;
     if (ctx->profile) { float ms = 0.f; PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[6], ctx->ev[7])); ctx->t_gram = ms; }
     return rc;
 }
@@ -650,7 +693,7 @@ int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t m
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PYIPM_E_NODEVICE;
     Ctx* ctx = new Ctx();
     ctx->g = make_geo(n, me, mi, nb, world, rank);
-    ctx->gc = make_geo(n, me, 0, nb, 1, 0);
+    ctx->gc = make_geo(n, me, 0, nb, 1, 0);          // re-derived by every condensed assemble
     ctx->group = default_group(world);
     ctx->device = device;
     ctx->stream = (hipStream_t)stream;
@@ -692,6 +735,8 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) {
     if (ctx->stg_Je) hipFree(ctx->stg_Je);
     if (ctx->stg_Ji) hipFree(ctx->stg_Ji);
     if (ctx->JT) hipFree(ctx->JT);
+    if (ctx->Jx) hipFree(ctx->Jx);
+    if (ctx->cond_pos) hipFree(ctx->cond_pos);
     if (ctx->own_ws && ctx->ws) hipFree(ctx->ws);
     delete ctx;
     return PYIPM_OK;
@@ -1040,6 +1085,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "condensed")) {
         if (value != 0 && ctx->g.world != 1) { ctx->err = "condensed: single-rank handles only"; return PYIPM_E_BADARG; }
         ctx->condensed = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "condensed_sigma_max")) { ctx->cond_sigma_max = value; return PYIPM_OK; }
     if (!strcmp(name, "condensed_refine")) { ctx->cond_min_refine = (int)value < 0 ? 0 : (int)value; return PYIPM_OK; }
     if (!strcmp(name, "lookahead")) { ctx->lookahead = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "group")) {           // may only shrink below the create-time value (workspace is sized for it)

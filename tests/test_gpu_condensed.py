@@ -231,6 +231,7 @@ def test_ill_conditioned_tiles_keep_inertia(smax):
     s = rng.uniform(0.5, 2.0, mi)
     lam = np.concatenate([qp["lam"][:me], sig * s])          # Sigma = lam_i / s
     core = _core(n, me, mi)
+    core.set_option("condensed_sigma_max", 1e300)            # fold EVERY inequality into the x-x block
     core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
     core.stage_vectors(qp["df"], qp["ce"], qp["ci"], s, lam, mu=qp["mu"])
     g = core.residual()
@@ -243,3 +244,51 @@ def test_ill_conditioned_tiles_keep_inertia(smax):
         core.set_option("block_refine", 0)
         core.assemble(0.0, 0.0)
         assert core.factor()["n_neg"] != me + mi              # the unrefined block algorithm does lose it
+
+
+@pytest.mark.parametrize("theta", [0.0, 0.9, 1.3, 1e4])
+def test_adaptive_split_matches_oracle(theta):
+    """condensed_sigma_max splits the inequalities: Sigma <= theta eliminated into the x-x block, the others kept
+    as rows with -1/Sigma on the diagonal.  Any split solves the same system: theta = 0 keeps every
+    inequality row (dimension n+me+mi), a huge theta is the fully condensed form; in between a mix."""
+    n, me, mi, seed = 700, 200, 300, 8
+    qp = make_qp(n, me, mi, seed)
+    ref, _, Hc, g = orc.newton_step(qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"],
+                                    qp["mu"], n, me, mi, regularise=False)
+    sig = qp["lam"][me:] / qp["s"]
+    na = int((sig > theta).sum())
+    core = _core(n, me, mi)
+    core.set_option("condensed_sigma_max", theta)
+    _stage(core, qp)
+    core.residual()
+    core.assemble(0.0, 0.0)
+    S = core.kkt_storage()
+    assert S.shape[0] == ((n + me + na + 127) // 128) * 128          # the system really has n + me + |A| rows
+    st = core.factor()
+    assert st["n_neg"] == me + mi and st["n_zero"] == 0 and st["n_pos"] == core.N - me - mi
+    dz = core.solve(flip=True).cpu().numpy()
+    assert relerr(dz, ref) <= TOL_DZ
+    dz2, st2 = core.step(0.0, 0.0)
+    assert relerr(dz2.cpu().numpy(), ref) <= TOL_DZ and st2["n_neg"] == me + mi
+    if 0 < na < mi:
+        assert 0.9 <= theta <= 1.3
+
+
+def test_adaptive_split_survives_huge_sigma():
+    """Sigma spanning 1e-12 .. 1e14: the large ones stay rows, so the factor keeps the right inertia and the
+    direction reaches a small backward error without the refinement the fully condensed form needs."""
+    n, me, mi = 200, 60, 120
+    qp = make_qp(n, me, mi, 4)
+    rng = np.random.default_rng(0)
+    sig = np.exp(rng.uniform(np.log(1e-12), np.log(1e14), mi))
+    s = rng.uniform(0.5, 2.0, mi)
+    lam = np.concatenate([qp["lam"][:me], sig * s])
+    core = _core(n, me, mi)
+    core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    core.stage_vectors(qp["df"], qp["ce"], qp["ci"], s, lam, mu=qp["mu"])
+    g = core.residual()
+    core.assemble(0.0, 0.0)
+    st = core.factor()
+    assert st["n_neg"] == me + mi and st["n_zero"] == 0
+    raw = core.solve(flip=False, refine=1)
+    assert float((core.matvec(raw) - g).norm() / g.norm()) <= 1e-10
