@@ -75,16 +75,12 @@ struct Ctx {
     int fuse_forward = 1;
     bool forward_fused = false;
     bool forward_pending = false;         // factor() already forward-substituted the pending residual into v0
-    int lookahead = 1;                    // 0 none, 1 one group (default), 2 two groups (dedicated bulk stream; measured no faster)
-    hipStream_t bulk = nullptr;
-    std::vector<hipEvent_t> ev_grp;       // [2g] group g factored, [2g+1] bulk update of group g done
+    int lookahead = 1;                    // 0 none, 1 one group (two groups on a dedicated stream measured no faster: removed)
     int group = 1;                        // panels per bulk trailing update
     int xcd_swizzle = 1;
     int side_prio = 1;                    // raise wave priority in panel-chain update launches
-    int bulk_bn = 128;                    // column width of the bulk-update tile (64: experimental)
-    int extra_lds = 0;                    // diagnostics: extra dynamic LDS per update block
     unsigned long long* dbg_buf = nullptr;   // diagnostics only
-    int stagger_mode = 1;                 // 0 off, 1 by dispatch index, 2 by hardware wave slot
+    int stagger_mode = 1;                 // 0 off, 1 delay half of the first-round blocks by half a tile period
     double stagger_us_per_k = 0.11;       // delay = this * K microseconds (~ half a tile period)
     // condensed KKT option: factor the (n+me)-dimensional system
     //   [[H + delta I + Ji Sigma Ji', Je], [Je', -delta_c I]]  instead of the full (n+2mi+me) one

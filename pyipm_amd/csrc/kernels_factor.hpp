@@ -11,9 +11,6 @@
 
 namespace pyipm {
 
-#ifndef PYIPM_ABLATE
-#define PYIPM_ABLATE 0   /* diagnostic builds only: 1 no C load, 2 no C store, 4 no in-loop global loads, 8 no LDS fragment reads */
-#endif
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double2_t __attribute__((ext_vector_type(2)));
 typedef double row16_t __attribute__((ext_vector_type(16)));
@@ -343,7 +340,6 @@ struct UpdGeo {
     int64_t row_begin, Npad, first_lp, sub0;
     int nb, world, rank, nrt, nct;         // nrt/nct: row / column tiles of this launch
     int stagger_ticks;                     // >0: delay (100 MHz ticks) applied to half of the first-round blocks
-    int stagger_mode;                      // 1: by dispatch index, 2: by hardware wave-slot parity
     int prio;                              // != 0: raise wave priority (latency-critical panel-chain launches)
     int rt_min0, rt_step;                  // first row tile on/below the diagonal for super-column sJ = rt_min0 + sJ*rt_step (tiles)
     unsigned long long* dbg;               // diagnostics only (NULL in normal operation): per-block timeline
@@ -439,10 +435,7 @@ __global__ __launch_bounds__(256, 2) void k_update(
     if (u.stagger_ticks > 0) {
         const unsigned lin = SWZ ? blockIdx.x : blockIdx.x + gridDim.x * blockIdx.y;
         if (lin < 512u) {
-            bool late;
-            if (u.stagger_mode == 2) late = (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) != 0;   // HW_ID.WAVE_ID
-            else                     late = ((lin >> 8) & 1) != 0;
-            if (late) {
+            if (((lin >> 8) & 1) != 0) {
                 const unsigned long long t0 = wall_clock64();
                 while (wall_clock64() - t0 < (unsigned long long)u.stagger_ticks) __builtin_amdgcn_s_sleep(32);
             }
@@ -460,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void k_update(
         for (int ti = 0; ti < TI; ++ti)
             #pragma unroll
             for (int r = 0; r < 4; ++r)
-                acc[tj][ti][r] = (PYIPM_ABLATE & 1) ? 0.0 : C[(i0 + wi + ti * 16 + l15) + (jloc + wj + tj * 16 + l4 + 4 * r) * ldc];
+                acc[tj][ti][r] = C[(i0 + wi + ti * 16 + l15) + (jloc + wj + tj * 16 + l4 + 4 * r) * ldc];
 
     // staging registers: L tile 16 x 128 doubles = 1024 double2 -> 4 per thread;
     //                    W tile 16 x BN  doubles -> BN/32 per thread
@@ -490,9 +483,8 @@ __global__ __launch_bounds__(256, 2) void k_update(
     }
 #define PYIPM_FRAGS(buf_, kk_, a_, b_)                                                                \
     {                                                                                                 \
-        if (!(PYIPM_ABLATE & 8) || (kk_) == 0) {                                                      \
         _Pragma("unroll") for (int tj = 0; tj < TJ; ++tj) a_[tj] = Ws[buf_][(kk_) + l4][wj + tj * 16 + l15]; \
-        _Pragma("unroll") for (int ti = 0; ti < TI; ++ti) b_[ti] = Ls[buf_][(kk_) + l4][wi + ti * 16 + l15]; } \
+        _Pragma("unroll") for (int ti = 0; ti < TI; ++ti) b_[ti] = Ls[buf_][(kk_) + l4][wi + ti * 16 + l15]; \
     }
 #define PYIPM_MFMAS(a_, b_)                                                                           \
     {                                                                                                 \
@@ -529,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void k_update(
         PYIPM_ILV(TJ + TI, 0x100)
         PYIPM_FRAGS(cur, 12, a1, b1)
         PYIPM_STORE_LDS(cur ^ 1)                    // stage k+1: registers -> the other LDS buffer
-        if (!(PYIPM_ABLATE & 4)) PYIPM_LOAD_REGS(k2)   // stage k+2 -> registers (a full stage ahead of its use)
+        PYIPM_LOAD_REGS(k2)   // stage k+2 -> registers (a full stage ahead of its use)
         PYIPM_MFMAS(a0, b0)
         PYIPM_ILV(TJ * TI, 0x0A0)
         __syncthreads();
@@ -551,8 +543,7 @@ __global__ __launch_bounds__(256, 2) void k_update(
         for (int ti = 0; ti < TI; ++ti)
             #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (!(PYIPM_ABLATE & 2) || acc[tj][ti][r] == 1.2345e300)
-                    C[(i0 + wi + ti * 16 + l15) + (jloc + wj + tj * 16 + l4 + 4 * r) * ldc] = acc[tj][ti][r];
+                C[(i0 + wi + ti * 16 + l15) + (jloc + wj + tj * 16 + l4 + 4 * r) * ldc] = acc[tj][ti][r];
     if (u.dbg && tid == 0) {
         const unsigned lin = SWZ ? blockIdx.x : blockIdx.x + gridDim.x * blockIdx.y;
         unsigned long long* d = u.dbg + 8ull * lin;

@@ -17,7 +17,7 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
     Carve cv;
     const size_t D = sizeof(double);
     const size_t oA = cv.take((size_t)g.Npad * (size_t)(g.ncols_local > 0 ? g.ncols_local : 1) * D);
-    const size_t oW = cv.take(3 * (size_t)default_group(g.world) * (size_t)g.Npad * g.nb * D);   // -W of a panel group, triple-buffered (2-deep lookahead)
+    const size_t oW = cv.take(3 * (size_t)default_group(g.world) * (size_t)g.Npad * g.nb * D);   // -W of a panel group, three rotating buffers (group g+1 is written while g is read)
     const size_t oL = cv.take(g.world > 1 ? (size_t)g.Npad * g.nb * D : 256);
     const size_t oD = cv.take((size_t)(g.Npad / TB) * TB * TB * D);
     const size_t oT = cv.take((size_t)(g.Npad / TB) * TB * TB * D);
@@ -113,34 +113,20 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     // stagger only pays when the launch runs for several rounds of 512 resident blocks
     const double nctd = (double)(u.nct < u.nrt ? u.nct : u.nrt);
     const double approx_blocks = nctd * (double)u.nrt - 0.5 * nctd * nctd;    // tiles on/below the diagonal
-    u.stagger_mode = ctx->stagger_mode;
     u.dbg = ctx->dbg_buf;
     u.prio = bulk ? 0 : ctx->side_prio;
     u.rt_min0 = 0; u.rt_step = 0;
     u.stagger_ticks = (ctx->stagger_mode && approx_blocks >= 1536.0) ? (int)(ctx->stagger_us_per_k * K * 100.0) : 0;
-    if (bulk && ctx->bulk_bn == 64) {
-        // experimental: 128x64 tiles (134 VGPRs -> 3 blocks per CU) for the bulk update
-        u.nct = (int)(n_lp * (g.nb / 64));
-        if (ctx->xcd_swizzle && upd_swizzle_ok<64>(u)) {
-            upd_fill_affine<64>(u);
-            const int64_t nsup = upd_super_count<64>(u);
-            if (nsup <= 0) return 0;
-            dim3 grid((unsigned)(((nsup + 7) / 8) * 8 * SUPER * SUPER));
-            hipLaunchKernelGGL((k_update<64, true>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
-        } else {
-            dim3 grid((unsigned)u.nrt, (unsigned)u.nct);
-            hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
-        }
-    } else if (ctx->xcd_swizzle && bulk && upd_swizzle_ok<128>(u)) {
+    if (ctx->xcd_swizzle && bulk && upd_swizzle_ok<128>(u)) {
         upd_fill_affine<128>(u);
         const int64_t nsup = upd_super_count<128>(u);
         if (nsup <= 0) return 0;
         const int64_t rounds = (nsup + 7) / 8;                       // super-tiles per XCD
         dim3 grid((unsigned)(rounds * 8 * SUPER * SUPER));
-        hipLaunchKernelGGL((k_update<128, true>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
+        hipLaunchKernelGGL((k_update<128, true>), grid, dim3(256), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
     } else {
         dim3 grid((unsigned)u.nrt, (unsigned)u.nct);
-        hipLaunchKernelGGL((k_update<128, false>), grid, dim3(256), ctx->extra_lds, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
+        hipLaunchKernelGGL((k_update<128, false>), grid, dim3(256), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
     }
     PYIPM_KCHECK();
     return 0;
@@ -171,7 +157,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
             UpdGeo u;
             u.row_begin = row_begin; u.Npad = g.Npad; u.first_lp = lp; u.sub0 = t;
             u.nb = g.nb; u.world = g.world; u.rank = g.rank; u.nrt = (int)(m / BM); u.nct = 1;
-            u.stagger_ticks = 0; u.stagger_mode = 0; u.dbg = nullptr; u.prio = ctx->side_prio; u.rt_min0 = 0; u.rt_step = 0;
+            u.stagger_ticks = 0; u.dbg = nullptr; u.prio = ctx->side_prio; u.rt_min0 = 0; u.rt_step = 0;
             dim3 grid((unsigned)(m / BM), 1);
             hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), 0, stream, ctx->A, g.Npad,
                                ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, t * TB, u);
@@ -579,44 +565,6 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         rc = factor_panel(ctx, q, ctx->stream, true); if (rc) return rc;
         rc = after_panel(q, ctx->stream); if (rc) return rc;
     }
-    if (ctx->lookahead >= 2 && ngroups >= 3) {
-        // 2-deep lookahead.  U(g,h) = update of group h's columns with group g.  Per group g:
-        //   main : H(g)  = U(g,g+1)            -> side: F(g+1)   (the latency-bound chain)
-        //   main : B1(g) = U(g,g+2)            (next head's columns; waits for B2(g-1), which also touched them)
-        //   bulk : B2(g) = U(g,g+3..)          (everything else, back-to-back on its own stream)
-        // The chain runs a full group ahead of the bulk stream, which is never idle while it has work.
-        if (!ctx->bulk) PYIPM_HIP(hipStreamCreateWithFlags(&ctx->bulk, hipStreamNonBlocking));
-        while ((int64_t)ctx->ev_grp.size() < 2 * ngroups) { hipEvent_t e; PYIPM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_grp.push_back(e); }
-        auto evF = [&](int64_t grp) { return ctx->ev_grp[2 * grp]; };
-        auto evB2 = [&](int64_t grp) { return ctx->ev_grp[2 * grp + 1]; };
-        std::vector<char> hasB2(ngroups, 0);
-        PYIPM_HIP(hipEventRecord(evF(0), ctx->stream));
-        for (int64_t grp = 0; grp + 1 < ngroups; ++grp) {
-            const int64_t p0 = grp * G, n0 = gsize(grp), p1 = p0 + n0, n1 = gsize(grp + 1);
-            const int64_t p2 = p1 + n1, n2 = (grp + 2 < ngroups) ? gsize(grp + 2) : 0, p3 = p2 + n2;
-            rc = timed_update(ctx, p0, n0, p1, n1); if (rc) return rc;                      // H(g)
-            PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
-            PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_head, 0));
-            for (int64_t q = p1; q < p1 + n1; ++q) {                                        // F(g+1)
-                rc = factor_panel(ctx, q, ctx->side, true); if (rc) return rc;
-                rc = after_panel(q, ctx->side); if (rc) return rc;
-            }
-            PYIPM_HIP(hipEventRecord(evF(grp + 1), ctx->side));
-            if (n2 > 0) {                                                                   // B1(g)
-                if (grp >= 1 && hasB2[grp - 1]) PYIPM_HIP(hipStreamWaitEvent(ctx->stream, evB2(grp - 1), 0));
-                rc = timed_update(ctx, p0, n0, p2, n2); if (rc) return rc;
-            }
-            if (p3 < np) {                                                                  // B2(g)
-                PYIPM_HIP(hipStreamWaitEvent(ctx->bulk, evF(grp), 0));
-                rc = timed_update(ctx, p0, n0, p3, np - p3, ctx->bulk); if (rc) return rc;
-                PYIPM_HIP(hipEventRecord(evB2(grp), ctx->bulk));
-                hasB2[grp] = 1;
-            }
-            PYIPM_HIP(hipStreamWaitEvent(ctx->stream, evF(grp + 1), 0));
-        }
-        for (int64_t grp = 0; grp < ngroups; ++grp)                                         // join the bulk stream
-            if (hasB2[grp]) PYIPM_HIP(hipStreamWaitEvent(ctx->stream, evB2(grp), 0));
-    } else
     for (int64_t grp = 0; grp + 1 < ngroups; ++grp) {
         const int64_t p0 = grp * G, n0 = gsize(grp), p1 = p0 + n0, n1 = gsize(grp + 1);
         if (ctx->lookahead) {
@@ -727,8 +675,6 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) {
     if (ctx->ev_panel) hipEventDestroy(ctx->ev_panel);
     if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
     if (ctx->fwd) { hipStreamSynchronize(ctx->fwd); hipStreamDestroy(ctx->fwd); }
-    if (ctx->bulk) { hipStreamSynchronize(ctx->bulk); hipStreamDestroy(ctx->bulk); }
-    for (auto e : ctx->ev_grp) hipEventDestroy(e);
     if (ctx->ev_fwd) hipEventDestroy(ctx->ev_fwd);
     for (auto e : ctx->ev_done) hipEventDestroy(e);
     if (ctx->stg_d2L) hipFree(ctx->stg_d2L);
@@ -1087,7 +1033,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
         ctx->condensed = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "condensed_sigma_max")) { ctx->cond_sigma_max = value; return PYIPM_OK; }
     if (!strcmp(name, "condensed_refine")) { ctx->cond_min_refine = (int)value < 0 ? 0 : (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "lookahead")) { ctx->lookahead = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "lookahead")) { ctx->lookahead = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "group")) {           // may only shrink below the create-time value (workspace is sized for it)
         int v = (int)value; if (v < 1 || v > default_group(ctx->g.world)) { ctx->err = "group out of range"; return PYIPM_E_BADARG; }
         ctx->group = v; return PYIPM_OK; }
@@ -1095,8 +1041,6 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "stagger_mode")) { ctx->stagger_mode = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "fuse_forward")) { ctx->fuse_forward = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "side_prio")) { ctx->side_prio = (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "bulk_bn")) { ctx->bulk_bn = (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "extra_lds")) { ctx->extra_lds = (int)value; return PYIPM_OK; }    // diagnostics: force 1 block/CU
     if (!strcmp(name, "debug_timeline_ptr")) {      // diagnostics: device buffer of 8 x u64 per block (pointer passed as double-encoded integer halves is lossy; use set via low 52 bits)
         ctx->dbg_buf = (unsigned long long*)(uintptr_t)(unsigned long long)value; return PYIPM_OK; }
     if (!strcmp(name, "stagger_us_per_k")) { ctx->stagger_us_per_k = value; return PYIPM_OK; }
