@@ -156,6 +156,21 @@ int pyipm_newton_fwd_panel(pyipm_newton_ctx* ctx, int64_t p, double* v);
 int pyipm_newton_diag_panel(pyipm_newton_ctx* ctx, int64_t p, double* v);
 int pyipm_newton_bwd_panel(pyipm_newton_ctx* ctx, int64_t p, double* v);
 
+/* ---- batched small systems (BASELINE.json configs[4]: 512 independent n=256 QPs) ------------------------
+ * Independent problems of one shape, Npad = roundup(n+2mi+me,128) <= 1024.  One workgroup per problem: a
+ * single launch factors the whole batch.  Blocks are caller-owned DEVICE arrays with a batch stride (in
+ * doubles); pyipm_newton_stage_vectors on such a handle takes [batch][len] contiguous arrays.  Replaces a
+ * loop of pyipm.py:1717-1725 over independent problems (multi-start); nothing in the reference batches. */
+size_t pyipm_newton_workspace_bytes_batched(int64_t n, int64_t me, int64_t mi, int batch);
+int pyipm_newton_create_batched(pyipm_newton_ctx** ctx, int64_t n, int64_t me, int64_t mi, int batch, int device,
+                                void* workspace, size_t workspace_bytes, void* stream);
+int pyipm_newton_stage_blocks_batched(pyipm_newton_ctx* ctx, const double* d2L, int64_t ld_d2L, int64_t stride_d2L,
+                                      const double* Je, int64_t ld_Je, int64_t stride_Je,
+                                      const double* Ji, int64_t ld_Ji, int64_t stride_Ji);
+/* residual + assemble + factor + solve + flip for every problem; dz is [batch][N], stats (may be NULL) [batch]. */
+int pyipm_newton_step_batched(pyipm_newton_ctx* ctx, double delta, double delta_c, double* dz,
+                              pyipm_factor_stats* stats, int memkind);
+
 /* ---- introspection for tests / bench ------------------------------------------------------ */
 
 /* Device pointer + leading dimension of the local KKT storage (column-major lower). */

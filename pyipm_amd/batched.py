@@ -1,79 +1,105 @@
 """Batched independent Newton steps (BASELINE.json configs[4]: 512 independent n=256 QPs, multi-start).
 
-Independent problems shard with no exchange at all ("replicas only"): a pool of
-``workers`` handles, each on its own HIP stream and driven by its own host thread (ctypes releases the
-GIL inside the C-ABI calls), works through the batch.  Across GPUs the batch is simply split by rank.
-Every problem goes through the same HIP path as the single-system case (no CPU fallback)."""
+Independent problems shard with no exchange at all ("replicas only"), and a system
+this small (Npad <= 1024) fits one workgroup: the library's batched handle
+(``pyipm_newton_create_batched`` / ``stage_blocks_batched`` / ``step_batched``, ``csrc/kernels_batched.hpp``)
+runs the whole batch with four launches -- residuals, assembly, ONE factorisation launch with a workgroup per
+problem (2 resident per CU: 512 problems in flight on an MI355X), substitutions.  Across GPUs the batch is
+simply split by rank.  Same algorithm and tile-inversion code as the single-system path; no CPU fallback."""
 from __future__ import annotations
 
-import threading
-from concurrent.futures import ThreadPoolExecutor
+import ctypes
+from ctypes import c_void_p
 
 import numpy as np
 
+from .newton import ERRORS, MEM_DEVICE, FactorStats, NewtonError, load_library
+
 
 class BatchedNewton(object):
-    def __init__(self, n, me, mi, device=None, workers=8, nb=128, refine=0):
+    def __init__(self, n, me, mi, batch=None, device=None, workers=None, nb=None, refine=0):
+        """``workers`` / ``nb`` are accepted for compatibility with the first (thread-pool) version and ignored."""
         import torch
+        if refine:
+            raise NotImplementedError("iterative refinement is not part of the batched path")
         self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise NewtonError("no HIP device visible: the Newton-step core has no CPU fallback")
         self.n, self.me, self.mi = int(n), int(me), int(mi)
         self.N = self.n + 2 * self.mi + self.me
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
-        self.workers, self.nb, self.refine = int(workers), int(nb), int(refine)
-        self._local = threading.local()
-        self._pool = ThreadPoolExecutor(max_workers=self.workers)
-        self._cores = []
+        self.h, self.batch, self.workspace = None, 0, None
+        self._keep = None
+        if batch:
+            self._create(int(batch))
 
-    def _core(self):
-        loc = self._local
-        if not hasattr(loc, "core"):
-            from .newton import NewtonCore
-            torch = self.torch
-            torch.cuda.set_device(self.device)
-            loc.stream = torch.cuda.Stream(device=self.device)
-            with torch.cuda.stream(loc.stream):
-                loc.core = NewtonCore(self.n, self.me, self.mi, device=self.device.index, nb=self.nb)
-            self._cores.append(loc.core)
-        return loc.core, loc.stream
-
-    def _one(self, b, blocks, vecs, mu, delta, delta_c, out):
+    def _create(self, batch):
         torch = self.torch
-        core, stream = self._core()
-        d2L, Je, Ji = blocks
-        df, ce, ci, s, lda = vecs
-        with torch.cuda.stream(stream):
-            core.stage_blocks(d2L[b], None if Je is None else Je[b], None if Ji is None else Ji[b])
-            core.stage_vectors(df[b], None if ce is None else ce[b], None if ci is None else ci[b],
-                               None if s is None else s[b], None if lda is None else lda[b], mu=mu)
-            dz, st = core.step(delta, delta_c, refine=self.refine)
-            out[b].copy_(dz)
-            stream.synchronize()
-        return st
+        self.close()
+        need = self.lib.pyipm_newton_workspace_bytes_batched(self.n, self.me, self.mi, batch)
+        if need == 0:
+            raise NewtonError("batched handles need n + 2 mi + me <= 1024 (got %d)" % self.N)
+        with torch.cuda.device(self.device):
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            h = c_void_p()
+            rc = self.lib.pyipm_newton_create_batched(ctypes.byref(h), self.n, self.me, self.mi, batch, self.device.index,
+                                                      c_void_p(self.workspace.data_ptr()), need,
+                                                      c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+        if rc:
+            raise NewtonError("pyipm_newton_create_batched failed: %s" % ERRORS.get(rc, rc))
+        self.h, self.batch = h, batch
+
+    def _ck(self, rc):
+        if rc:
+            msg = self.lib.pyipm_newton_last_error(self.h)
+            raise NewtonError("%s: %s" % (ERRORS.get(rc, rc), msg.decode() if msg else ""))
 
     def step_all(self, d2L, Je=None, Ji=None, df=None, ce=None, ci=None, s=None, lda=None, mu=0.2,
-                 delta=0.0, delta_c=0.0):
+                 delta=0.0, delta_c=0.0, eps=float(np.finfo(np.float64).eps)):
         """All arguments carry a leading batch dimension (torch device tensors or NumPy arrays):
         d2L (B,n,n), Je (B,n,me), Ji (B,n,mi), df (B,n), ce (B,me), ci (B,mi), s (B,mi), lda (B,me+mi).
         Returns (dz (B,N) device tensor, list of per-problem factor statistics)."""
         torch = self.torch
+        n, me, mi = self.n, self.me, self.mi
 
-        def dev(a):
+        def dev(a, shape):
             if a is None:
                 return None
             if isinstance(a, torch.Tensor):
-                return a.to(device=self.device, dtype=torch.float64)
-            return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64))).to(self.device)
+                t = a.to(device=self.device, dtype=torch.float64)
+            else:
+                t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64))).to(self.device)
+            return t.reshape(shape).contiguous()
 
-        blocks = (dev(d2L), dev(Je), dev(Ji))
-        vecs = (dev(df), dev(ce), dev(ci), dev(s), dev(lda))
-        B = blocks[0].shape[0]
+        B = int(d2L.shape[0])
+        if self.h is None or B != self.batch:
+            self._create(B)
+        blocks = (dev(d2L, (B, n, n)), dev(Je, (B, n, me)) if me else None, dev(Ji, (B, n, mi)) if mi else None)
+        vecs = (dev(df, (B, n)), dev(ce, (B, me)) if me else None, dev(ci, (B, mi)) if mi else None,
+                dev(s, (B, mi)) if mi else None, dev(lda, (B, me + mi)) if (me + mi) else None)
+        self._keep = (blocks, vecs)            # the library retains the block pointers
+
+        def ptr(t):
+            return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+
+        self._ck(self.lib.pyipm_newton_set_stream(self.h, c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        self._ck(self.lib.pyipm_newton_stage_blocks_batched(self.h, ptr(blocks[0]), n, n * n, ptr(blocks[1]), me, n * me,
+                                                            ptr(blocks[2]), mi, n * mi))
+        self._ck(self.lib.pyipm_newton_stage_vectors(self.h, ptr(vecs[0]), ptr(vecs[1]), ptr(vecs[2]), ptr(vecs[3]),
+                                                     ptr(vecs[4]), float(mu), float(eps), MEM_DEVICE))
         out = torch.empty((B, self.N), dtype=torch.float64, device=self.device)
-        torch.cuda.synchronize(self.device)
-        futs = [self._pool.submit(self._one, b, blocks, vecs, mu, delta, delta_c, out) for b in range(B)]
-        stats = [f.result() for f in futs]
-        return out, stats
+        st = (FactorStats * B)()
+        self._ck(self.lib.pyipm_newton_step_batched(self.h, float(delta), float(delta_c), ptr(out), st, MEM_DEVICE))
+        return out, [x.as_dict() for x in st]
 
     def close(self):
-        self._pool.shutdown(wait=True)
-        for c in self._cores:
-            c.close()
+        if getattr(self, "h", None):
+            self.lib.pyipm_newton_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

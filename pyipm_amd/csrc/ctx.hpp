@@ -66,6 +66,9 @@ struct DevStats {          // lives in device memory; tile kernels of one rank r
 
 struct Ctx {
     Geo g;
+    int batch = 1;                        // problems of a batched small-system handle (kernels_batched.hpp)
+    bool batched = false;                 // batched handle: single-system entry points refuse it
+    int64_t b_sH = 0, b_sJe = 0, b_sJi = 0;   // batch strides (doubles) of the caller's blocks
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;           // panel lookahead stream (created on first factor)

@@ -1,0 +1,294 @@
+// kernels_batched.hpp — many small independent Newton steps at once (BASELINE.json configs[4]: 512 QPs
+// with n = 256, N = 768).  Independent systems shard with no exchange, and a system this small fits one
+// workgroup: ONE launch factors the whole batch (grid = problems, 2 resident per CU, 512 in flight on an
+// MI355X), one assembles, one forms the residuals, one substitutes.  Same algorithm as the big path
+// (block LDL' with 64x64 Bunch-Kaufman block pivots, left-looking over the tile columns, refined block
+// solves), same tile-inversion code (tile_invert_dev), MFMA for the tile products.
+//
+// Storage per problem: A (Npad x Npad, column-major, lower triangle = KKT / factor as in the big path);
+// the strictly upper BLOCKS hold -S(t,u)' (the W operand of the updates), so no separate W buffer exists.
+#pragma once
+#include "ctx.hpp"
+#include "kernels_assemble.hpp"
+#include "kernels_factor.hpp"
+
+namespace pyipm {
+
+struct BatchPtrs {
+    double* A; int64_t sA;                 // [B][Npad*Npad]
+    double *Tinv, *Tsave; int64_t sT;      // [B][nt*64*64]
+    double* Tflag; int64_t sF;             // [B][nt]
+    DevStats* st;                          // [B]
+    double *rhs, *sol; int64_t sV;         // [B][Npad]
+    const double *d2L, *Je, *Ji; int64_t sH, sJe, sJi, ldh, ldje, ldji;      // caller blocks, batch strides in doubles
+    const double *df, *ce, *ci, *s, *lda;  // staged vectors [B][n], [B][me], [B][mi], [B][mi], [B][me+mi]
+};
+
+// K1 for the batch: grid (Npad/512, Npad/16, B)
+__global__ __launch_bounds__(256) void k_b_assemble(BatchPtrs bp, Geo g, double eps, double delta, double delta_c)
+{
+    const int64_t b = blockIdx.z;
+    double* A = bp.A + b * bp.sA;
+    const double* d2L = bp.d2L + b * bp.sH;
+    const double* Je = bp.Je ? bp.Je + b * bp.sJe : nullptr;
+    const double* Ji = bp.Ji ? bp.Ji + b * bp.sJi : nullptr;
+    const double* s = bp.s + b * g.mi;
+    const double* lda = bp.lda + b * (g.me + g.mi);
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i >= g.Npad) return;
+    #pragma unroll 4
+    for (int c = 0; c < 16; ++c) {
+        const int64_t j = (int64_t)blockIdx.y * 16 + c;
+        if (j >= g.Npad) return;
+        if (i + 1 < j) continue;
+        const double v1 = kkt_entry(i + 1, j, g, d2L, bp.ldh, Je, bp.ldje, Ji, bp.ldji, s, lda, eps, delta, delta_c);
+        if (i >= j) {
+            dbl2_t v;
+            v.x = kkt_entry(i, j, g, d2L, bp.ldh, Je, bp.ldje, Ji, bp.ldji, s, lda, eps, delta, delta_c);
+            v.y = v1;
+            *reinterpret_cast<dbl2_t*>(&A[i + j * g.Npad]) = v;
+        } else {
+            A[(i + 1) + j * g.Npad] = v1;
+        }
+    }
+}
+
+// K2 for the batch: g = -grad (pyipm.py:655-668, 1717).  grid B, 256 threads (one wave per row of the x part).
+__global__ __launch_bounds__(256) void k_b_residual(BatchPtrs bp, Geo g, double mu, double eps)
+{
+    const int64_t b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = g.n, me = g.me, mi = g.mi;
+    double* out = bp.rhs + b * bp.sV;
+    const double* lda = bp.lda + b * (me + mi);
+    const double* s = bp.s + b * mi;
+    for (int64_t j = wave; j < n; j += 4) {
+        double acc = 0.0;
+        if (me) { const double* r = bp.Je + b * bp.sJe + j * bp.ldje; for (int64_t a = lane; a < me; a += 64) acc += r[a] * lda[a]; }
+        if (mi) { const double* r = bp.Ji + b * bp.sJi + j * bp.ldji; for (int64_t a = lane; a < mi; a += 64) acc += r[a] * lda[me + a]; }
+        acc = wave_sum(acc);
+        if (lane == 0) out[j] = -(bp.df[b * n + j] - acc);
+    }
+    for (int64_t i = n + threadIdx.x; i < g.Npad; i += 256) {
+        double v = 0.0;
+        if (i < n + mi)            { const int64_t k = i - n;           v = -(lda[me + k] - mu / (s[k] + eps)); }
+        else if (i < n + mi + me)  { const int64_t a = i - n - mi;      v = -bp.ce[b * me + a]; }
+        else if (i < g.N)          { const int64_t k = i - n - mi - me; v = -(bp.ci[b * mi + k] - s[k]); }
+        out[i] = v;
+    }
+}
+
+// Factor one problem per workgroup.  grid B, 256 threads.
+__global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double refine_cond, int nref, double pivtol_rel)
+{
+    __shared__ TileScratch sm;
+    __shared__ double X[TB][TB + 2];
+    const int64_t bi = blockIdx.x, ld = g.Npad;
+    double* A = bp.A + bi * bp.sA;
+    double* Tinv = bp.Tinv + bi * bp.sT;
+    double* Tsave = bp.Tsave + bi * bp.sT;
+    double* Tflag = bp.Tflag + bi * bp.sF;
+    DevStats* st = bp.st + bi;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int nt = (int)(g.Npad / TB);
+    if (tid == 0) {
+        st->n_neg = st->n_zero = st->n_2x2 = st->n_pos = st->nonfinite = 0;
+        st->d_min = 1.0e308; st->d_max = 0.0; st->growth_bits = 0ull;
+    }
+    double gmax = 0.0;
+    for (int t = 0; t < nt; ++t) {
+        const int64_t j0 = (int64_t)t * TB;
+        // (1) left-looking: block column t, row tiles r >= t, gets the contributions of tile columns u < t.
+        // Four row tiles per pass (a wave owns 16 rows of each): the staged W operand is reused 4x -- the batch
+        // as a whole is HBM-bound here (512 problems x 4.7 MB do not fit any cache).
+        if (t > 0) {
+            for (int r0 = t; r0 < nt; r0 += 4) {
+                const int nq = (nt - r0) < 4 ? (nt - r0) : 4;
+                const int64_t ib = (int64_t)r0 * TB + wave * 16 + l15;          // row of tile r0; tile r0+q: + 64 q
+                double4_t acc[4][4];
+                #pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < nq) {
+                        #pragma unroll
+                        for (int cb = 0; cb < 4; ++cb)
+                            #pragma unroll
+                            for (int m = 0; m < 4; ++m) acc[q][cb][m] = A[(ib + q * TB) + (j0 + cb * 16 + l4 + 4 * m) * ld];
+                    }
+                for (int u = 0; u < t; ++u) {
+                    double b[16];
+                    #pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) b[ks] = A[ib + ((int64_t)u * TB + ks * 4 + l4) * ld];   // L(r0,u)
+                    __syncthreads();
+                    for (int e = tid; e < TB * TB; e += 256) {          // -S(t,u)[c][k] sits at A[64u + k][j0 + c]
+                        const int k = e & 63, c = e >> 6;
+                        X[c][k] = A[((int64_t)u * TB + k) + (j0 + c) * ld];
+                    }
+                    __syncthreads();
+                    #pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (q < nq) {
+                            double bn[16];
+                            if (q + 1 < nq) {
+                                #pragma unroll
+                                for (int ks = 0; ks < 16; ++ks)
+                                    bn[ks] = A[(ib + (q + 1) * TB) + ((int64_t)u * TB + ks * 4 + l4) * ld];
+                            }
+                            #pragma unroll
+                            for (int ks = 0; ks < 16; ++ks)
+                                #pragma unroll
+                                for (int cb = 0; cb < 4; ++cb)
+                                    acc[q][cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[cb * 16 + l15][ks * 4 + l4], b[ks], acc[q][cb], 0, 0, 0);
+                            if (q + 1 < nq) {
+                                #pragma unroll
+                                for (int ks = 0; ks < 16; ++ks) b[ks] = bn[ks];
+                            }
+                        }
+                }
+                #pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < nq) {
+                        #pragma unroll
+                        for (int cb = 0; cb < 4; ++cb)
+                            #pragma unroll
+                            for (int m = 0; m < 4; ++m) A[(ib + q * TB) + (j0 + cb * 16 + l4 + 4 * m) * ld] = acc[q][cb][m];
+                    }
+            }
+        }
+        __syncthreads();
+        // (2) the block pivot
+        tile_invert_dev(sm, A, ld, j0, j0, Tinv + (int64_t)t * TB * TB, Tsave + (int64_t)t * TB * TB, Tflag + t,
+                        refine_cond, st, g.N, pivtol_rel, nullptr);
+        __syncthreads();
+        // (3) rows below: keep -S' in the upper blocks, overwrite S with L = S X (refined when the tile is flagged)
+        if (t + 1 < nt) {
+            const double* Xi = Tinv + (int64_t)t * TB * TB;
+            const double* Tt = Tsave + (int64_t)t * TB * TB;
+            const int nr = (nref > 0 && Tflag[t] != 0.0) ? nref : 0;
+            for (int e = tid; e < TB * TB; e += 256) X[e >> 6][e & 63] = Xi[e];
+            __syncthreads();
+            for (int r = t + 1; r < nt; ++r) {
+                const int64_t i = (int64_t)r * TB + wave * 16 + l15;
+                double b[16];
+                #pragma unroll
+                for (int ks = 0; ks < 16; ++ks) {
+                    b[ks] = A[i + (j0 + ks * 4 + l4) * ld];
+                    A[(j0 + ks * 4 + l4) + i * ld] = -b[ks];                   // -S(r,t)' into the upper block (t,r)
+                }
+                double4_t lac[4];
+                #pragma unroll
+                for (int cb = 0; cb < 4; ++cb) lac[cb] = (double4_t){0.0, 0.0, 0.0, 0.0};
+                #pragma unroll
+                for (int ks = 0; ks < 16; ++ks)
+                    #pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        lac[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[cb * 16 + l15][ks * 4 + l4], b[ks], lac[cb], 0, 0, 0);
+                for (int it = 0; it < nr; ++it) {                               // rare: ill-conditioned tile
+                    __syncthreads();
+                    for (int e = tid; e < TB * TB; e += 256) X[e >> 6][e & 63] = -Tt[e];
+                    __syncthreads();
+                    double4_t res[4];
+                    #pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        #pragma unroll
+                        for (int q = 0; q < 4; ++q) res[cb][q] = b[4 * cb + q];
+                    #pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) {
+                        const double lop = lac[ks >> 2][ks & 3];
+                        #pragma unroll
+                        for (int cb = 0; cb < 4; ++cb)
+                            res[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[cb * 16 + l15][ks * 4 + l4], lop, res[cb], 0, 0, 0);
+                    }
+                    __syncthreads();
+                    for (int e = tid; e < TB * TB; e += 256) X[e >> 6][e & 63] = Xi[e];
+                    __syncthreads();
+                    #pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) {
+                        const double rop = res[ks >> 2][ks & 3];
+                        #pragma unroll
+                        for (int cb = 0; cb < 4; ++cb)
+                            lac[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[cb * 16 + l15][ks * 4 + l4], rop, lac[cb], 0, 0, 0);
+                    }
+                }
+                #pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    #pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        A[i + (j0 + cb * 16 + l4 + 4 * q) * ld] = lac[cb][q];
+                        gmax = fmax(gmax, fabs(lac[cb][q]));
+                    }
+            }
+        }
+        __syncthreads();
+    }
+    gmax = wave_max(gmax);
+    if (lane == 0) atomicMax(&st->growth_bits, (unsigned long long)__double_as_longlong(gmax));
+}
+
+// Substitutions + sign flip for one problem per workgroup.  grid B, block Npad (<= 1024), LDS 2*Npad doubles.
+__global__ void k_b_solve(BatchPtrs bp, Geo g, int nref, int flip, double* __restrict__ dz)
+{
+    extern __shared__ double lds[];
+    double* y = lds;
+    double* w = lds + g.Npad;
+    const int64_t bi = blockIdx.x, ld = g.Npad;
+    const double* A = bp.A + bi * bp.sA;
+    const int tid = threadIdx.x, lane = tid & 63, t = tid >> 6;
+    const int nt = (int)(g.Npad / TB);
+    const double y0 = bp.rhs[bi * bp.sV + tid];
+    y[tid] = y0;
+    for (int u = 0; u + 1 < nt; ++u) {                       // forward (unit block lower triangular)
+        __syncthreads();
+        if (tid >= (u + 1) * TB) {
+            const double* col = A + tid + ((int64_t)u * TB) * ld;
+            double acc = 0.0;
+            #pragma unroll 8
+            for (int k = 0; k < TB; ++k) acc = fma(col[(int64_t)k * ld], y[u * TB + k], acc);
+            y[tid] -= acc;
+        }
+    }
+    __syncthreads();
+    // block diagonal: z = inv(T) y, refined against T for flagged tiles (uniform trip count for the barriers)
+    const double* Xi = bp.Tinv + bi * bp.sT + (int64_t)t * TB * TB;
+    const double* Tt = bp.Tsave + bi * bp.sT + (int64_t)t * TB * TB;
+    const bool flagged = bp.Tflag[bi * bp.sF + t] != 0.0;
+    const double yt = y[tid];
+    double z = 0.0;
+    #pragma unroll 8
+    for (int j = 0; j < TB; ++j) z = fma(Xi[j * TB + lane], y[t * TB + j], z);
+    for (int it = 0; it < nref; ++it) {
+        w[tid] = z;
+        __syncthreads();
+        double r = yt;
+        if (flagged) {
+            #pragma unroll 8
+            for (int j = 0; j < TB; ++j) r = fma(-Tt[j * TB + lane], w[t * TB + j], r);
+        }
+        __syncthreads();
+        w[tid] = r;
+        __syncthreads();
+        if (flagged) {
+            #pragma unroll 8
+            for (int j = 0; j < TB; ++j) z = fma(Xi[j * TB + lane], w[t * TB + j], z);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    y[tid] = z;
+    for (int u = nt - 1; u >= 1; --u) {                      // backward
+        __syncthreads();
+        if (tid < u * TB) {
+            const double* col = A + ((int64_t)u * TB) + (int64_t)tid * ld;
+            double acc = 0.0;
+            #pragma unroll 8
+            for (int i = 0; i < TB; ++i) acc = fma(col[i], y[u * TB + i], acc);
+            y[tid] -= acc;
+        }
+    }
+    __syncthreads();
+    const double x = y[tid];
+    bp.sol[bi * bp.sV + tid] = x;
+    if (tid < g.N) dz[bi * g.N + tid] = (flip && tid >= g.n + g.mi) ? -x : x;
+}
+
+}  // namespace pyipm

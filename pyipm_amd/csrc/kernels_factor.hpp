@@ -50,19 +50,28 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {
                                 (unsigned int)__builtin_amdgcn_readlane((int)b, l));
 }
 
-__global__ __launch_bounds__(256) void k_tile_invert(
+// Shared-memory scratch of one tile inversion (a 256-thread workgroup).
+struct TileScratch {
+    double stage[TB][TB + 1];
+    double colbuf[2][2][TB];     // [parity][0: column p, 1: column r][row]  (column == row by symmetry)
+    double sh_red[4];
+};
+
+// The sweep inversion itself; called by k_tile_invert (one tile of the big factorisation) and by the
+// batched small-system kernel (every tile of one problem, one workgroup per problem).
+__device__ __forceinline__ void tile_invert_dev(
+    TileScratch& sm,
     const double* __restrict__ A, int64_t ld, int64_t grow0, int64_t lcol0,
     double* __restrict__ Tinv, double* __restrict__ Tsave,     // inv(T); the tile T itself (full, symmetric)
     double* __restrict__ Tflag, double refine_cond,            // *Tflag = 1 when the block solves with this tile need refining
     DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel,
     unsigned long long* __restrict__ dbg)      // diagnostics only (NULL normally)
 {
-    __shared__ double stage[TB][TB + 1];
-    __shared__ double colbuf[2][2][TB];     // [parity][0: column p, 1: column r][row]  (column == row by symmetry)
-    __shared__ double sh_red[4];
+    double (&stage)[TB][TB + 1] = sm.stage;
+    double (&colbuf)[2][2][TB] = sm.colbuf;
+    double (&sh_red)[4] = sm.sh_red;
     unsigned long long dbg_c0 = 0, dbg_w0 = 0;
     if (dbg) { dbg_c0 = clock64(); dbg_w0 = wall_clock64(); }
-    __builtin_amdgcn_s_setprio(3);         // latency-critical chain: win issue arbitration against co-resident bulk waves
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cb = wave * 16;
@@ -225,6 +234,16 @@ __global__ __launch_bounds__(256) void k_tile_invert(
         if (dmin < st->d_min) st->d_min = dmin;
         if (dmax > st->d_max) st->d_max = dmax;
     }
+}
+
+__global__ __launch_bounds__(256) void k_tile_invert(
+    const double* __restrict__ A, int64_t ld, int64_t grow0, int64_t lcol0,
+    double* __restrict__ Tinv, double* __restrict__ Tsave, double* __restrict__ Tflag, double refine_cond,
+    DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel, unsigned long long* __restrict__ dbg)
+{
+    __shared__ TileScratch sm;
+    __builtin_amdgcn_s_setprio(3);         // latency-critical chain: win issue arbitration against co-resident bulk waves
+    tile_invert_dev(sm, A, ld, grow0, lcol0, Tinv, Tsave, Tflag, refine_cond, st, Nreal, pivtol_rel, dbg);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -5,6 +5,7 @@
 #include "kernels_assemble.hpp"
 #include "kernels_factor.hpp"
 #include "kernels_solve.hpp"
+#include "kernels_batched.hpp"
 
 using namespace pyipm;
 
@@ -53,7 +54,52 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
     return cv.off;
 }
 
+// Batched small-system handles: per problem A (Npad^2), tile inverses / tiles / flags, rhs and solution, the
+// staged vectors; no W buffer (the upper blocks of A hold it) and no panel machinery.
+size_t carve_batched(Ctx* c, const Geo& g, int64_t B, char* base) {
+    Carve cv;
+    const size_t D = sizeof(double), nt = (size_t)(g.Npad / TB);
+    const size_t oA = cv.take((size_t)B * g.Npad * g.Npad * D);
+    const size_t oD = cv.take((size_t)B * nt * TB * TB * D);
+    const size_t oT = cv.take((size_t)B * nt * TB * TB * D);
+    const size_t oTf = cv.take((size_t)B * nt * D);
+    const size_t orhs = cv.take((size_t)B * g.Npad * D);
+    const size_t ov0 = cv.take((size_t)B * g.Npad * D);
+    const size_t ov2 = cv.take((size_t)B * g.N * D);
+    const size_t odf = cv.take((size_t)B * (g.n + 1) * D);
+    const size_t oce = cv.take((size_t)B * (g.me + 1) * D);
+    const size_t oci = cv.take((size_t)B * (g.mi + 1) * D);
+    const size_t os = cv.take((size_t)B * (g.mi + 1) * D);
+    const size_t ol = cv.take((size_t)B * (g.me + g.mi + 1) * D);
+    const size_t ost = cv.take((size_t)B * sizeof(DevStats));
+    if (base) {
+        c->A = (double*)(base + oA); c->Dinv = (double*)(base + oD); c->Tsv = (double*)(base + oT);
+        c->Tflag = (double*)(base + oTf); c->rhs = (double*)(base + orhs); c->v0 = (double*)(base + ov0);
+        c->v2 = (double*)(base + ov2);
+        c->df = (double*)(base + odf); c->ce = (double*)(base + oce); c->ci = (double*)(base + oci);
+        c->s = (double*)(base + os); c->lda = (double*)(base + ol); c->dstats = (DevStats*)(base + ost);
+    }
+    return cv.off;
+}
+
+BatchPtrs batch_ptrs(Ctx* ctx) {
+    const Geo& g = ctx->g;
+    BatchPtrs bp;
+    const int64_t nt = g.Npad / TB;
+    bp.A = ctx->A; bp.sA = g.Npad * g.Npad;
+    bp.Tinv = ctx->Dinv; bp.Tsave = ctx->Tsv; bp.sT = nt * TB * TB;
+    bp.Tflag = ctx->Tflag; bp.sF = nt;
+    bp.st = ctx->dstats;
+    bp.rhs = ctx->rhs; bp.sol = ctx->v0; bp.sV = g.Npad;
+    bp.d2L = ctx->d2L; bp.Je = ctx->Je; bp.Ji = ctx->Ji;
+    bp.sH = ctx->b_sH; bp.sJe = ctx->b_sJe; bp.sJi = ctx->b_sJi;
+    bp.ldh = ctx->ld_d2L; bp.ldje = ctx->ld_Je; bp.ldji = ctx->ld_Ji;
+    bp.df = ctx->df; bp.ce = ctx->ce; bp.ci = ctx->ci; bp.s = ctx->s; bp.lda = ctx->lda;
+    return bp;
+}
+
 int check_ctx(pyipm_newton_ctx* h) { return h ? 0 : PYIPM_E_BADARG; }
+int single_only(Ctx* ctx) { ctx->err = "batched handle: only stage_*_batched / stage_vectors / step_batched apply"; return PYIPM_E_BADARG; }
 inline Ctx* C(pyipm_newton_ctx* h) { return reinterpret_cast<Ctx*>(h); }
 
 // copy `count` doubles from caller memory (host or device) into library device memory
@@ -664,6 +710,108 @@ int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t m
     return PYIPM_OK;
 }
 
+size_t pyipm_newton_workspace_bytes_batched(int64_t n, int64_t me, int64_t mi, int batch) {
+    if (n <= 0 || me < 0 || mi < 0 || batch < 1) return 0;
+    Geo g = make_geo(n, me, mi, 128, 1, 0);
+    if (g.Npad > 1024) return 0;
+    return carve_batched(nullptr, g, batch, nullptr);
+}
+
+int pyipm_newton_create_batched(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t mi, int batch, int device,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    if (!out) return PYIPM_E_BADARG;
+    *out = nullptr;
+    if (n <= 0 || me < 0 || mi < 0 || batch < 1) return PYIPM_E_BADARG;
+    Geo g = make_geo(n, me, mi, 128, 1, 0);
+    if (g.Npad > 1024) return PYIPM_E_BADARG;          // one workgroup per problem: Npad threads in the substitutions
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return PYIPM_E_NODEVICE;
+    Ctx* ctx = new Ctx();
+    ctx->g = g; ctx->gc = g;
+    ctx->batch = batch;
+    ctx->group = 1;
+    ctx->device = device;
+    ctx->stream = (hipStream_t)stream;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return PYIPM_E_NODEVICE; }
+    const size_t need = carve_batched(nullptr, g, batch, nullptr);
+    if (workspace) {
+        if (workspace_bytes < need) { delete ctx; return PYIPM_E_NOMEM; }
+        ctx->ws = (char*)workspace; ctx->own_ws = false;
+    } else {
+        if (hipMalloc((void**)&ctx->ws, need) != hipSuccess) { delete ctx; return PYIPM_E_NOMEM; }
+        ctx->own_ws = true;
+    }
+    ctx->ws_bytes = need;
+    carve_batched(ctx, g, batch, ctx->ws);
+    ctx->batched = true;
+    for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return PYIPM_E_HIP; }
+    *out = reinterpret_cast<pyipm_newton_ctx*>(ctx);
+    return PYIPM_OK;
+}
+
+int pyipm_newton_stage_blocks_batched(pyipm_newton_ctx* h, const double* d2L, int64_t ld_d2L, int64_t stride_d2L,
+                                      const double* Je, int64_t ld_Je, int64_t stride_Je,
+                                      const double* Ji, int64_t ld_Ji, int64_t stride_Ji) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    if (!ctx->batched) { ctx->err = "stage_blocks_batched: not a batched handle"; return PYIPM_E_BADARG; }
+    if (!d2L || ld_d2L < g.n || (g.me && (!Je || ld_Je < g.me)) || (g.mi && (!Ji || ld_Ji < g.mi))) {
+        ctx->err = "stage_blocks_batched: bad block pointer / leading dimension (device pointers only)"; return PYIPM_E_BADARG; }
+    ctx->d2L = d2L; ctx->ld_d2L = ld_d2L; ctx->b_sH = stride_d2L;
+    ctx->Je = g.me ? Je : nullptr; ctx->ld_Je = ld_Je; ctx->b_sJe = stride_Je;
+    ctx->Ji = g.mi ? Ji : nullptr; ctx->ld_Ji = ld_Ji; ctx->b_sJi = stride_Ji;
+    ctx->have_blocks = true;
+    return PYIPM_OK;
+}
+
+int pyipm_newton_step_batched(pyipm_newton_ctx* h, double delta, double delta_c, double* dz,
+                              pyipm_factor_stats* stats, int memkind) {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    if (!ctx->batched) { ctx->err = "step_batched: not a batched handle"; return PYIPM_E_BADARG; }
+    if (!ctx->have_blocks || !ctx->have_vectors) { ctx->err = "step_batched: stage blocks and vectors first"; return PYIPM_E_BADARG; }
+    if (!dz) { ctx->err = "step_batched: null output"; return PYIPM_E_BADARG; }
+    const int B = ctx->batch;
+    BatchPtrs bp = batch_ptrs(ctx);
+    PYIPM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(k_b_residual, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->mu, ctx->eps);
+    PYIPM_KCHECK();
+    {
+        dim3 grid((unsigned)((g.Npad + 511) / 512), (unsigned)((g.Npad + 15) / 16), (unsigned)B);
+        hipLaunchKernelGGL(k_b_assemble, grid, dim3(256), 0, ctx->stream, bp, g, ctx->eps, delta, delta_c);
+        PYIPM_KCHECK();
+    }
+    hipLaunchKernelGGL(k_b_factor, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->refine_cond, ctx->block_refine, ctx->pivtol_rel);
+    PYIPM_KCHECK();
+    double* out_dev = (memkind == PYIPM_MEM_DEVICE) ? dz : ctx->v2;
+    hipLaunchKernelGGL(k_b_solve, dim3(B), dim3((unsigned)g.Npad), 2 * g.Npad * sizeof(double), ctx->stream, bp, g,
+                       ctx->block_refine, (g.me + g.mi) > 0 ? 1 : 0, out_dev);
+    PYIPM_KCHECK();
+    PYIPM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (memkind == PYIPM_MEM_HOST)
+        PYIPM_HIP(hipMemcpyAsync(dz, ctx->v2, (size_t)B * g.N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    int rc = PYIPM_OK;
+    if (stats) {
+        std::vector<DevStats> z((size_t)B);
+        PYIPM_HIP(hipMemcpyAsync(z.data(), ctx->dstats, (size_t)B * sizeof(DevStats), hipMemcpyDeviceToHost, ctx->stream));
+        PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+        for (int b = 0; b < B; ++b) {
+            stats[b].n_neg = z[b].n_neg; stats[b].n_zero = z[b].n_zero; stats[b].n_2x2 = z[b].n_2x2; stats[b].n_pos = z[b].n_pos;
+            stats[b].d_min = z[b].d_min; stats[b].d_max = z[b].d_max;
+            long long gb = (long long)z[b].growth_bits; double gr; memcpy(&gr, &gb, sizeof(gr));
+            stats[b].growth = gr; stats[b].nonfinite = z[b].nonfinite;
+            if (z[b].nonfinite) { ctx->err = "NaN/Inf met during factorisation"; rc = PYIPM_E_NONFINITE; }
+        }
+        float ms = 0.f;
+        PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        ctx->t_factor = ms;
+    } else if (memkind == PYIPM_MEM_HOST) {
+        PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return rc;
+}
+
 int pyipm_newton_destroy(pyipm_newton_ctx* h) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
@@ -711,6 +859,7 @@ int pyipm_newton_stage_blocks(pyipm_newton_ctx* h, const double* d2L, int64_t ld
                               int64_t ld_Je, const double* Ji, int64_t ld_Ji, int memkind) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
+    if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     int rc;
     rc = stage_block(ctx, d2L, g.n, g.n, ld_d2L, memkind, &ctx->stg_d2L, &ctx->stg_d2L_sz, &ctx->d2L, &ctx->ld_d2L); if (rc) return rc;
@@ -726,11 +875,12 @@ int pyipm_newton_stage_vectors(pyipm_newton_ctx* h, const double* df, const doub
     Ctx* ctx = C(h); const Geo& g = ctx->g;
     PYIPM_HIP(hipSetDevice(ctx->device));
     int rc;
-    rc = put_vec(ctx, ctx->df, df, g.n, memkind); if (rc) return rc;
-    rc = put_vec(ctx, ctx->ce, ce, g.me, memkind); if (rc) return rc;
-    rc = put_vec(ctx, ctx->ci, ci, g.mi, memkind); if (rc) return rc;
-    rc = put_vec(ctx, ctx->s, s, g.mi, memkind); if (rc) return rc;
-    rc = put_vec(ctx, ctx->lda, lda, g.me + g.mi, memkind); if (rc) return rc;
+    const size_t B = (size_t)ctx->batch;          // batched handles: every vector is [batch][len], contiguous
+    rc = put_vec(ctx, ctx->df, df, B * g.n, memkind); if (rc) return rc;
+    rc = put_vec(ctx, ctx->ce, ce, B * g.me, memkind); if (rc) return rc;
+    rc = put_vec(ctx, ctx->ci, ci, B * g.mi, memkind); if (rc) return rc;
+    rc = put_vec(ctx, ctx->s, s, B * g.mi, memkind); if (rc) return rc;
+    rc = put_vec(ctx, ctx->lda, lda, B * (g.me + g.mi), memkind); if (rc) return rc;
     ctx->mu = mu; ctx->eps = eps;
     ctx->have_vectors = true;
     return PYIPM_OK;
@@ -747,6 +897,7 @@ static int copy_out(Ctx* ctx, double* dst, const double* src_dev, size_t count, 
 int pyipm_newton_residual(pyipm_newton_ctx* h, double* g_out, int memkind) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
+    if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     int rc = residual_dev(ctx); if (rc) return rc;
     return copy_out(ctx, g_out, ctx->rhs, ctx->g.N, memkind);
@@ -755,6 +906,7 @@ int pyipm_newton_residual(pyipm_newton_ctx* h, double* g_out, int memkind) {
 int pyipm_newton_assemble(pyipm_newton_ctx* h, double delta, double delta_c) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
+    if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     PYIPM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
     int rc = assemble_dev(ctx, delta, delta_c); if (rc) return rc;
@@ -768,6 +920,7 @@ static int solve_prepare(Ctx* ctx, const double* rhs, int memkind, bool for_fuse
 int pyipm_newton_factor(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
+    if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     // a residual is pending (pyipm.py:1717 precedes :1718): let its forward substitution trail the
     // factorisation; solve(rhs = NULL) then only runs the block-diagonal and backward parts
@@ -820,6 +973,7 @@ static int solve_finish(Ctx* ctx, double* dz, int flip, int refine, int memkind,
 int pyipm_newton_solve(pyipm_newton_ctx* h, const double* rhs, double* dz, int flip, int refine, int memkind) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
+    if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     if (g.world != 1) { ctx->err = "solve(): single-rank entry point"; return PYIPM_E_BADARG; }
     if (!ctx->factored) { ctx->err = "solve: factor first"; return PYIPM_E_BADARG; }
@@ -834,6 +988,7 @@ int pyipm_newton_solve(pyipm_newton_ctx* h, const double* rhs, double* dz, int f
 int pyipm_newton_kkt_matvec(pyipm_newton_ctx* h, const double* v, double* y, int memkind) {
     if (check_ctx(h) || !v || !y) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
+    if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     ctx->forward_pending = false;                     // v1 (the saved right-hand side) is about to be reused
     // the product goes through vc (free outside a condensed solve), so v2 -- the direction of the last
@@ -848,6 +1003,7 @@ int pyipm_newton_step(pyipm_newton_ctx* h, double delta, double delta_c, int ref
                       pyipm_factor_stats* stats, int memkind) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
+    if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     if (!dz) { ctx->err = "step: null output"; return PYIPM_E_BADARG; }
     int rc = residual_dev(ctx); if (rc) return rc;
@@ -864,6 +1020,7 @@ int pyipm_newton_step(pyipm_newton_ctx* h, double delta, double delta_c, int ref
 int pyipm_newton_step_lengths(pyipm_newton_ctx* h, double tau, double* alpha_s, double* alpha_l) {
     if (check_ctx(h) || !alpha_s || !alpha_l) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
+    if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     *alpha_s = 1.0; *alpha_l = 1.0;
     if (g.mi == 0) return PYIPM_OK;
@@ -884,6 +1041,7 @@ int pyipm_newton_step_lengths(pyipm_newton_ctx* h, double tau, double* alpha_s, 
 int pyipm_newton_factor_begin(pyipm_newton_ctx* h) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    if (ctx->batched) return single_only(ctx);
     if (!ctx->assembled) { ctx->err = "factor_begin: assemble first"; return PYIPM_E_BADARG; }
     if (ctx->cond_active) { ctx->err = "per-panel phases do not apply to the condensed system; use factor()"; return PYIPM_E_BADARG; }
     return factor_begin(ctx);
@@ -891,17 +1049,20 @@ int pyipm_newton_factor_begin(pyipm_newton_ctx* h) {
 int pyipm_newton_factor_end(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    if (ctx->batched) return single_only(ctx);
     ctx->assembled = false;
     return factor_end(ctx, stats);
 }
 int pyipm_newton_factor_panel(pyipm_newton_ctx* h, int64_t p) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    if (ctx->batched) return single_only(ctx);
     return factor_panel(ctx, p, ctx->stream, false);
 }
 int pyipm_newton_trailing_update(pyipm_newton_ctx* h, int64_t p) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    if (ctx->batched) return single_only(ctx);
     if (p < 0 || p >= ctx->g.npanels) return PYIPM_E_BADARG;
     return trailing_update(ctx, p);
 }
@@ -909,6 +1070,7 @@ int pyipm_newton_trailing_update(pyipm_newton_ctx* h, int64_t p) {
 int pyipm_newton_trailing_update_range(pyipm_newton_ctx* h, int64_t p, int64_t first, int64_t count) {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    if (ctx->batched) return single_only(ctx);
     const Geo& g = ctx->g;
     if (p < 0 || p >= g.npanels || first <= p || count < 0) return PYIPM_E_BADARG;
     if (g.panel_c0(p) + g.panel_w(p) >= g.Npad) return PYIPM_OK;
@@ -934,6 +1096,7 @@ size_t pyipm_newton_panel_msg_bytes(pyipm_newton_ctx* h, int64_t p) {
 int pyipm_newton_panel_pack(pyipm_newton_ctx* h, int64_t p, double* buf) {
     if (check_ctx(h) || !buf) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
+    if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     if (p < 0 || p >= g.npanels || g.owner(p) != g.rank) { ctx->err = "panel_pack: not the owner"; return PYIPM_E_BADARG; }
     const int64_t nbw = g.panel_w(p), c1 = g.panel_c0(p) + nbw, m = g.Npad - c1;
@@ -953,6 +1116,7 @@ int pyipm_newton_panel_pack(pyipm_newton_ctx* h, int64_t p, double* buf) {
 int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf) {
     if (check_ctx(h) || !buf) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
+    if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     if (p < 0 || p >= g.npanels || g.owner(p) == g.rank) { ctx->err = "panel_unpack: owner does not unpack"; return PYIPM_E_BADARG; }
     const int64_t nbw = g.panel_w(p), c0 = g.panel_c0(p), c1 = c0 + nbw, m = g.Npad - c1;
@@ -982,18 +1146,21 @@ int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf)
 int pyipm_newton_fwd_panel(pyipm_newton_ctx* h, int64_t p, double* v) {
     if (check_ctx(h) || !v) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    if (ctx->batched) return single_only(ctx);
     if (p < 0 || p >= ctx->g.npanels || ctx->g.owner(p) != ctx->g.rank) return PYIPM_E_BADARG;
     return fwd_panel(ctx, p, v);
 }
 int pyipm_newton_diag_panel(pyipm_newton_ctx* h, int64_t p, double* v) {
     if (check_ctx(h) || !v) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    if (ctx->batched) return single_only(ctx);
     if (p < 0 || p >= ctx->g.npanels) return PYIPM_E_BADARG;
     return diag_panel(ctx, p, v);
 }
 int pyipm_newton_bwd_panel(pyipm_newton_ctx* h, int64_t p, double* v) {
     if (check_ctx(h) || !v) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
+    if (ctx->batched) return single_only(ctx);
     if (p < 0 || p >= ctx->g.npanels || ctx->g.owner(p) != ctx->g.rank) return PYIPM_E_BADARG;
     return bwd_panel(ctx, p, v);
 }

@@ -91,6 +91,12 @@ def load_library(path: str | None = None):
         "pyipm_newton_kkt_storage": (c_int, [ctxp, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64)]),
         "pyipm_newton_last_timings": (c_int, [ctxp, POINTER(c_double)]),
         "pyipm_newton_set_option": (c_int, [ctxp, c_char_p, c_double]),
+        "pyipm_newton_workspace_bytes_batched": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
+        "pyipm_newton_create_batched": (c_int, [POINTER(c_void_p), c_int64, c_int64, c_int64, c_int, c_int,
+                                                c_void_p, c_size_t, c_void_p]),
+        "pyipm_newton_stage_blocks_batched": (c_int, [ctxp, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
+                                                      c_void_p, c_int64, c_int64]),
+        "pyipm_newton_step_batched": (c_int, [ctxp, c_double, c_double, c_void_p, POINTER(FactorStats), c_int]),
         "pyipm_mfma_f64_peak": (c_int, [c_int, c_int, POINTER(c_double)]),
     }
     for name, (res, args) in sig.items():

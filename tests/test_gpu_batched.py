@@ -65,3 +65,37 @@ def test_config5_512_problems():
                                        regularise=False)
         assert np.linalg.norm(dz[b].cpu().numpy() - ref) / np.linalg.norm(ref) <= 1e-10
     bn.close()
+
+
+def test_batched_indefinite_inertia_and_guards():
+    """Non-convex members of a batch (indefinite d2L -> 2x2 / off-diagonal pivots, flagged tiles) report the
+    eigen-inertia of THEIR matrix; a batch of one works; single-system entry points refuse a batched handle."""
+    import torch
+    from pyipm_amd.batched import BatchedNewton
+    from pyipm_amd.newton import NewtonError, FactorStats
+    import ctypes
+    n, me, mi, B = 70, 10, 30, 9
+    rng = np.random.default_rng(3)
+    qps = [make_qp(n, me, mi, seed=300 + b) for b in range(B)]
+    for b in range(0, B, 2):                                     # every other problem gets an indefinite Hessian
+        M = rng.standard_normal((n, n))
+        qps[b]["d2L"] = (M + M.T) / 2
+    bn = BatchedNewton(n, me, mi)
+    dz, stats = bn.step_all(_stack(qps, "d2L"), _stack(qps, "Je"), _stack(qps, "Ji"), _stack(qps, "df"),
+                            _stack(qps, "ce"), _stack(qps, "ci"), _stack(qps, "s"), _stack(qps, "lam"), mu=0.2)
+    dz = dz.cpu().numpy()
+    for b, q in enumerate(qps):
+        H = orc.kkt_matrix(q["d2L"], q["Je"], q["Ji"], q["s"], q["lam"], n, me, mi)
+        w = np.linalg.eigvalsh(H)
+        assert stats[b]["n_neg"] == int((w < 0).sum()) and stats[b]["n_zero"] == 0
+        ref, _, _, g = orc.newton_step(q["d2L"], q["Je"], q["Ji"], q["df"], q["ce"], q["ci"], q["s"], q["lam"],
+                                       q["mu"], n, me, mi, regularise=False)
+        assert np.linalg.norm(dz[b] - ref) / np.linalg.norm(ref) <= 1e-9
+    assert any(st["n_2x2"] > 0 for st in stats[0::2])
+    one, st1 = bn.step_all(*[_stack(qps[:1], k) for k in ("d2L", "Je", "Ji", "df", "ce", "ci", "s", "lam")], mu=0.2)
+    assert np.array_equal(one.cpu().numpy()[0], dz[0]) and st1[0]["n_neg"] == stats[0]["n_neg"]
+    rc = bn.lib.pyipm_newton_assemble(bn.h, 0.0, 0.0)           # single-system call on a batched handle
+    assert rc == -1 and b"batched handle" in bn.lib.pyipm_newton_last_error(bn.h)
+    with pytest.raises(NewtonError):
+        BatchedNewton(600, 0, 300, batch=2)                      # N = 1200 > 1024: not a small system
+    bn.close()
