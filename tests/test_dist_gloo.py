@@ -49,7 +49,8 @@ def _worker(rank, world, port, shape, nb, lookahead, out):
 
 @pytest.mark.parametrize("lookahead", [False, True])
 @pytest.mark.parametrize("world,shape,nb", [(2, (150, 40, 60, 3), 128), (2, (300, 90, 120, 4), 128),
-                                            (3, (260, 50, 100, 5), 128), (2, (200, 0, 150, 6), 256)])
+                                            (3, (260, 50, 100, 5), 128), (2, (200, 0, 150, 6), 256),
+                                            (4, (420, 100, 180, 7), 128), (8, (640, 128, 200, 8), 128)])
 def test_dist_newton_gloo(world, shape, nb, lookahead):
     n, me, mi, _ = shape
     N = n + 2 * mi + me
