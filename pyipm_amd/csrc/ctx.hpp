@@ -80,6 +80,8 @@ struct Ctx {
     bool forward_pending = false;         // factor() already forward-substituted the pending residual into v0
     int lookahead = 1;                    // 0 none, 1 one group (two groups on a dedicated stream measured no faster: removed)
     int group = 1;                        // panels per bulk trailing update
+    int bulk_waves = 8;                   // waves per block of the BULK update tiles (8: 128 VGPRs each, 4 waves per SIMD;
+                                          // 4: 241 VGPRs, 2 per SIMD: 1.5 % slower); the short side-stream launches keep 4
     int xcd_swizzle = 1;
     int side_prio = 1;                    // raise wave priority in panel-chain update launches
     unsigned long long* dbg_buf = nullptr;   // diagnostics only

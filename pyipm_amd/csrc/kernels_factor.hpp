@@ -401,14 +401,15 @@ inline int64_t upd_super_count(const UpdGeo& u) {
     return tot;
 }
 
-template <int BN, bool SWZ>
-__global__ __launch_bounds__(256, 2) void k_update(
+template <int BN, bool SWZ, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW / 2) void k_update(
     double* __restrict__ C, int64_t ldc,
     const double* __restrict__ Lop, int64_t ldl,
     const double* __restrict__ Wop, int64_t ldw,
     int K, UpdGeo u)
 {
-    constexpr int TJ = BN / 32;            // 16-wide MFMA tiles per wave along j
+    constexpr int NT = NW * 64;            // threads; waves are laid out 2 (along i) x NW/2 (along j)
+    constexpr int TJ = BN / (NW / 2) / 16; // 16-wide MFMA tiles per wave along j
     constexpr int TI = 4;                  // along i (wave covers 64 rows)
     constexpr int LSTR = BM + 16;          // padded LDS row strides (doubles): rows k and k+1 hit
     constexpr int WSTR = BN + 16;          // disjoint halves of the 64 banks
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void k_update(
             }
         }
     }
-    const int wi = (wave & 1) * 64, wj = (wave >> 1) * (BN / 2);
+    const int wi = (wave & 1) * 64, wj = (wave >> 1) * (BN / (NW / 2));
     const int l15 = lane & 15, l4 = lane >> 4;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
     if (u.dbg) ts0 = wall_clock64();
@@ -474,29 +475,31 @@ __global__ __launch_bounds__(256, 2) void k_update(
             for (int r = 0; r < 4; ++r)
                 acc[tj][ti][r] = C[(i0 + wi + ti * 16 + l15) + (jloc + wj + tj * 16 + l4 + 4 * r) * ldc];
 
-    // staging registers: L tile 16 x 128 doubles = 1024 double2 -> 4 per thread;
-    //                    W tile 16 x BN  doubles -> BN/32 per thread
-    constexpr int WPASS = BN / 32;
-    double2_t lreg[4], wreg[WPASS];
-    const int lk = tid >> 6, li = (tid & 63) * 2;                     // L: 4 k-rows per pass
+    // staging registers: L tile 16 x 128 doubles = 1024 double2 -> 1024/NT per thread;
+    //                    W tile 16 x BN  doubles -> 8 BN / NT per thread
+    constexpr int LKPP = NT / 64;                                     // L: k-rows per pass (64 threads x double2 per row)
+    constexpr int LPASS = BKU / LKPP;
     constexpr int WTPR = BN / 2;                                      // threads per k-row of W
-    const int wk = tid / WTPR, wjj = (tid % WTPR) * 2;                // W: 256/WTPR k-rows per pass
-    constexpr int WKPP = 256 / WTPR;
+    constexpr int WKPP = NT / WTPR;                                   // W: k-rows per pass
+    constexpr int WPASS = BKU / WKPP;
+    double2_t lreg[LPASS], wreg[WPASS];
+    const int lk = tid >> 6, li = (tid & 63) * 2;
+    const int wk = tid / WTPR, wjj = (tid % WTPR) * 2;
 
     const double* lsrc = Lop + (i0 + li) + (int64_t)lk * ldl;
     const double* wsrc = Wop + (jglob + wjj) + (int64_t)wk * ldw;
 #define PYIPM_LOAD_REGS(k0_)                                                                          \
     {                                                                                                 \
-        _Pragma("unroll") for (int ps = 0; ps < 4; ++ps)                                              \
-            lreg[ps] = *reinterpret_cast<const double2_t*>(lsrc + (int64_t)((k0_) + 4 * ps) * ldl);     \
+        _Pragma("unroll") for (int ps = 0; ps < LPASS; ++ps)                                          \
+            lreg[ps] = *reinterpret_cast<const double2_t*>(lsrc + (int64_t)((k0_) + LKPP * ps) * ldl);  \
         _Pragma("unroll") for (int ps = 0; ps < WPASS; ++ps)                                          \
             wreg[ps] = *reinterpret_cast<const double2_t*>(wsrc + (int64_t)((k0_) + WKPP * ps) * ldw);  \
     }
 
 #define PYIPM_STORE_LDS(buf_)                                                                         \
     {                                                                                                 \
-        _Pragma("unroll") for (int ps = 0; ps < 4; ++ps)                                              \
-            *reinterpret_cast<double2_t*>(&Ls[buf_][lk + 4 * ps][li]) = lreg[ps];                     \
+        _Pragma("unroll") for (int ps = 0; ps < LPASS; ++ps)                                          \
+            *reinterpret_cast<double2_t*>(&Ls[buf_][lk + LKPP * ps][li]) = lreg[ps];                  \
         _Pragma("unroll") for (int ps = 0; ps < WPASS; ++ps)                                          \
             *reinterpret_cast<double2_t*>(&Ws[buf_][wk + WKPP * ps][wjj]) = wreg[ps];                 \
     }
@@ -542,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void k_update(
         PYIPM_STORE_LDS(cur ^ 1)                    // stage k+1: registers -> the other LDS buffer
         PYIPM_LOAD_REGS(k2)   // stage k+2 -> registers (a full stage ahead of its use)
         PYIPM_MFMAS(a0, b0)
-        PYIPM_ILV(TJ * TI, 0x0A0)
+        PYIPM_ILV(LPASS + WPASS + LPASS + WPASS < TJ * TI ? LPASS + WPASS + LPASS + WPASS : TJ * TI, 0x0A0)
         __syncthreads();
         PYIPM_FRAGS(cur ^ 1, 0, a0, b0)
         PYIPM_MFMAS(a1, b1)

@@ -169,7 +169,10 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
         if (nsup <= 0) return 0;
         const int64_t rounds = (nsup + 7) / 8;                       // super-tiles per XCD
         dim3 grid((unsigned)(rounds * 8 * SUPER * SUPER));
-        hipLaunchKernelGGL((k_update<128, true>), grid, dim3(256), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
+        if (ctx->bulk_waves == 8)
+            hipLaunchKernelGGL((k_update<128, true, 8>), grid, dim3(512), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
+        else
+            hipLaunchKernelGGL((k_update<128, true>), grid, dim3(256), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
     } else {
         dim3 grid((unsigned)u.nrt, (unsigned)u.nct);
         hipLaunchKernelGGL((k_update<128, false>), grid, dim3(256), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
@@ -1204,6 +1207,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "group")) {           // may only shrink below the create-time value (workspace is sized for it)
         int v = (int)value; if (v < 1 || v > default_group(ctx->g.world)) { ctx->err = "group out of range"; return PYIPM_E_BADARG; }
         ctx->group = v; return PYIPM_OK; }
+    if (!strcmp(name, "bulk_waves")) { ctx->bulk_waves = (int)value == 8 ? 8 : 4; return PYIPM_OK; }
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "stagger_mode")) { ctx->stagger_mode = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "fuse_forward")) { ctx->fuse_forward = (int)value; return PYIPM_OK; }
