@@ -85,8 +85,6 @@ struct Ctx {
     int xcd_swizzle = 1;
     int side_prio = 1;                    // raise wave priority in panel-chain update launches
     unsigned long long* dbg_buf = nullptr;   // diagnostics only
-    int stagger_mode = 1;                 // 0 off, 1 delay half of the first-round blocks by half a tile period
-    double stagger_us_per_k = 0.11;       // delay = this * K microseconds (~ half a tile period)
     // condensed KKT option: factor the (n+me)-dimensional system
     //   [[H + delta I + Ji Sigma Ji', Je], [Je', -delta_c I]]  instead of the full (n+2mi+me) one
     int condensed = 0;                    // requested by set_option("condensed", 1); single-rank, mi > 0

@@ -358,7 +358,6 @@ __global__ __launch_bounds__(256) void k_panel_scale(
 struct UpdGeo {
     int64_t row_begin, Npad, first_lp, sub0;
     int nb, world, rank, nrt, nct;         // nrt/nct: row / column tiles of this launch
-    int stagger_ticks;                     // >0: delay (100 MHz ticks) applied to half of the first-round blocks
     int prio;                              // != 0: raise wave priority (latency-critical panel-chain launches)
     int rt_min0, rt_step;                  // first row tile on/below the diagonal for super-column sJ = rt_min0 + sJ*rt_step (tiles)
     unsigned long long* dbg;               // diagnostics only (NULL in normal operation): per-block timeline
@@ -448,19 +447,6 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_update(
     if (jglob >= Npad) return;
     const int64_t i0 = u.row_begin + rt * BM;
     if (i0 + BM <= jglob) return;          // tile strictly above the diagonal
-    // De-phase the co-resident blocks once per launch.  Every tile costs the same, so without this all
-    // resident blocks load / store their C tiles in the same instant (a 2 x 67 MB burst with every MFMA
-    // pipe idle) and then all compute together.  Delaying half of the FIRST-round blocks by half a tile
-    // period interleaves memory phases with compute phases for the rest of the launch.  Speed only.
-    if (u.stagger_ticks > 0) {
-        const unsigned lin = SWZ ? blockIdx.x : blockIdx.x + gridDim.x * blockIdx.y;
-        if (lin < 512u) {
-            if (((lin >> 8) & 1) != 0) {
-                const unsigned long long t0 = wall_clock64();
-                while (wall_clock64() - t0 < (unsigned long long)u.stagger_ticks) __builtin_amdgcn_s_sleep(32);
-            }
-        }
-    }
     const int wi = (wave & 1) * 64, wj = (wave >> 1) * (BN / (NW / 2));
     const int l15 = lane & 15, l4 = lane >> 4;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;

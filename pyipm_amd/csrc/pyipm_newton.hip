@@ -156,13 +156,9 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     u.row_begin = row_begin; u.Npad = col_end; u.first_lp = first_lp; u.sub0 = 0;
     u.nb = g.nb; u.world = g.world; u.rank = g.rank;
     u.nrt = (int)(m / BM); u.nct = (int)(n_lp * (g.nb / 128));
-    // stagger only pays when the launch runs for several rounds of 512 resident blocks
-    const double nctd = (double)(u.nct < u.nrt ? u.nct : u.nrt);
-    const double approx_blocks = nctd * (double)u.nrt - 0.5 * nctd * nctd;    // tiles on/below the diagonal
     u.dbg = ctx->dbg_buf;
     u.prio = bulk ? 0 : ctx->side_prio;
     u.rt_min0 = 0; u.rt_step = 0;
-    u.stagger_ticks = (ctx->stagger_mode && approx_blocks >= 1536.0) ? (int)(ctx->stagger_us_per_k * K * 100.0) : 0;
     if (ctx->xcd_swizzle && bulk && upd_swizzle_ok<128>(u)) {
         upd_fill_affine<128>(u);
         const int64_t nsup = upd_super_count<128>(u);
@@ -206,7 +202,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
             UpdGeo u;
             u.row_begin = row_begin; u.Npad = g.Npad; u.first_lp = lp; u.sub0 = t;
             u.nb = g.nb; u.world = g.world; u.rank = g.rank; u.nrt = (int)(m / BM); u.nct = 1;
-            u.stagger_ticks = 0; u.dbg = nullptr; u.prio = ctx->side_prio; u.rt_min0 = 0; u.rt_step = 0;
+            u.dbg = nullptr; u.prio = ctx->side_prio; u.rt_min0 = 0; u.rt_step = 0;
             dim3 grid((unsigned)(m / BM), 1);
             hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), 0, stream, ctx->A, g.Npad,
                                ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, t * TB, u);
@@ -1209,12 +1205,10 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
         ctx->group = v; return PYIPM_OK; }
     if (!strcmp(name, "bulk_waves")) { ctx->bulk_waves = (int)value == 8 ? 8 : 4; return PYIPM_OK; }
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "stagger_mode")) { ctx->stagger_mode = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "fuse_forward")) { ctx->fuse_forward = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "side_prio")) { ctx->side_prio = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "debug_timeline_ptr")) {      // diagnostics: device buffer of 8 x u64 per block (pointer passed as double-encoded integer halves is lossy; use set via low 52 bits)
         ctx->dbg_buf = (unsigned long long*)(uintptr_t)(unsigned long long)value; return PYIPM_OK; }
-    if (!strcmp(name, "stagger_us_per_k")) { ctx->stagger_us_per_k = value; return PYIPM_OK; }
     ctx->err = std::string("unknown option ") + name;
     return PYIPM_E_BADARG;
 }
