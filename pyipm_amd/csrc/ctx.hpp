@@ -80,6 +80,10 @@ struct Ctx {
     bool forward_pending = false;         // factor() already forward-substituted the pending residual into v0
     int lookahead = 1;                    // 0 none, 1 one group (two groups on a dedicated stream measured no faster: removed)
     int group = 1;                        // panels per bulk trailing update
+    int tail_group = 2;                   // group size once at most tail_cols columns remain: there the panel chain outlasts
+    int64_t tail_cols = 20480;            // the bulk update, and shorter groups move in-group update work off the chain
+    std::vector<int> grp_of, grp_off;     // per panel: group id and offset inside the group (built by factor_all)
+    std::vector<int64_t> grp_first;       // per group: first panel (+ one past the last group)
     int bulk_waves = 8;                   // waves per block of the BULK update tiles (8: 128 VGPRs each, 4 waves per SIMD;
                                           // 4: 241 VGPRs, 2 per SIMD: 1.5 % slower); the short side-stream launches keep 4
     int xcd_swizzle = 1;

@@ -135,8 +135,11 @@ int stage_block(Ctx* ctx, const double* src, int64_t rows, int64_t cols, int64_t
 inline dim3 grid1(int64_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
 // -W columns of panel p: the buffer of its group (parity-alternating) + its offset inside the group
 inline double* wbuf(Ctx* ctx, int64_t p) {
-    const int64_t G = ctx->group, grp = p / G;
-    return ctx->Wbuf + ((grp % 3) * G + (p % G)) * ctx->g.Npad * (int64_t)ctx->g.nb;
+    // group id / offset: uniform groups unless factor_all built a variable schedule (short groups in the tail)
+    const int64_t G = ctx->group;
+    const int64_t grp = (size_t)p < ctx->grp_of.size() ? ctx->grp_of[p] : p / G;
+    const int64_t off = (size_t)p < ctx->grp_off.size() ? ctx->grp_off[p] : p % G;
+    return ctx->Wbuf + ((grp % 3) * G + off) * ctx->g.Npad * (int64_t)ctx->g.nb;
 }
 
 // ---- per-panel building blocks -----------------------------------------------------------------
@@ -187,8 +190,9 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
     const int nt = nbw / TB;
     const int64_t lp = p / g.world;
     double* W = wbuf(ctx, p);
-    if (apply_pending && (p % ctx->group) != 0) {
-        const int64_t p0 = p - (p % ctx->group);
+    const int64_t poff = (size_t)p < ctx->grp_off.size() ? ctx->grp_off[p] : p % ctx->group;
+    if (apply_pending && poff != 0) {
+        const int64_t p0 = p - poff;
         int rc = launch_update128(ctx, stream, ctx->A + g.local_c0(p0) * g.Npad, g.Npad, wbuf(ctx, p0),
                                   (int)((p - p0) * g.nb), c0, lp, 1, /*bulk=*/false);
         if (rc) return rc;
@@ -587,9 +591,26 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         PYIPM_HIP(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, hi));
     }
     PYIPM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    const int64_t np = g.npanels, G = ctx->group;
-    const int64_t ngroups = (np + G - 1) / G;
-    auto gsize = [&](int64_t grp) { int64_t a = grp * G, b = a + G; if (b > np) b = np; return b - a; };
+    // Group schedule: `group` panels per bulk update while the bulk update outlasts the panel chain; once at most
+    // tail_cols columns remain the chain is the critical path and shorter groups (less in-group update work on
+    // the chain, more in the cheap bulk launches) end the factorisation sooner.
+    const int64_t np = g.npanels;
+    ctx->grp_of.assign((size_t)np, 0); ctx->grp_off.assign((size_t)np, 0); ctx->grp_first.clear();
+    {
+        int64_t p = 0; int gid = 0;
+        while (p < np) {
+            const int64_t remaining = g.Npad - g.panel_c0(p);
+            int64_t G = (ctx->tail_group > 0 && remaining <= ctx->tail_cols) ? ctx->tail_group : ctx->group;
+            if (G > ctx->group) G = ctx->group;
+            if (p + G > np) G = np - p;
+            ctx->grp_first.push_back(p);
+            for (int64_t q = 0; q < G; ++q) { ctx->grp_of[(size_t)(p + q)] = gid; ctx->grp_off[(size_t)(p + q)] = (int)q; }
+            p += G; ++gid;
+        }
+        ctx->grp_first.push_back(np);
+    }
+    const int64_t ngroups = (int64_t)ctx->grp_first.size() - 1;
+    auto gsize = [&](int64_t grp) { return ctx->grp_first[(size_t)grp + 1] - ctx->grp_first[(size_t)grp]; };
     // Fused forward substitution: y_p only needs panel p factored, so the forward pass of the step's
     // right-hand side (already in v0) trails the factorisation on its own stream.
     ctx->forward_fused = false;
@@ -611,7 +632,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         rc = after_panel(q, ctx->stream); if (rc) return rc;
     }
     for (int64_t grp = 0; grp + 1 < ngroups; ++grp) {
-        const int64_t p0 = grp * G, n0 = gsize(grp), p1 = p0 + n0, n1 = gsize(grp + 1);
+        const int64_t p0 = ctx->grp_first[(size_t)grp], n0 = gsize(grp), p1 = p0 + n0, n1 = gsize(grp + 1);
         if (ctx->lookahead) {
             rc = timed_update(ctx, p0, n0, p1, n1); if (rc) return rc;                 // head: next group's columns
             PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
@@ -1043,6 +1064,7 @@ int pyipm_newton_factor_begin(pyipm_newton_ctx* h) {
     if (ctx->batched) return single_only(ctx);
     if (!ctx->assembled) { ctx->err = "factor_begin: assemble first"; return PYIPM_E_BADARG; }
     if (ctx->cond_active) { ctx->err = "per-panel phases do not apply to the condensed system; use factor()"; return PYIPM_E_BADARG; }
+    ctx->grp_of.clear(); ctx->grp_off.clear();      // per-panel phases use the uniform group map
     return factor_begin(ctx);
 }
 int pyipm_newton_factor_end(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
@@ -1204,6 +1226,8 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
         int v = (int)value; if (v < 1 || v > default_group(ctx->g.world)) { ctx->err = "group out of range"; return PYIPM_E_BADARG; }
         ctx->group = v; return PYIPM_OK; }
     if (!strcmp(name, "bulk_waves")) { ctx->bulk_waves = (int)value == 8 ? 8 : 4; return PYIPM_OK; }
+    if (!strcmp(name, "tail_group")) { ctx->tail_group = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "tail_cols")) { ctx->tail_cols = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "fuse_forward")) { ctx->fuse_forward = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "side_prio")) { ctx->side_prio = (int)value; return PYIPM_OK; }
