@@ -79,6 +79,7 @@ struct Ctx {
     bool forward_fused = false;
     bool forward_pending = false;         // factor() already forward-substituted the pending residual into v0
     int lookahead = 1;                    // 0 none, 1 one group (two groups on a dedicated stream measured no faster: removed)
+    int skip_zeros = 1;                   // trailing updates skip tiles that the KKT block structure makes exact zeros
     int group = 1;                        // panels per bulk trailing update
     int tail_group = 2;                   // group size once at most tail_cols columns remain: there the panel chain outlasts
     int64_t tail_cols = 20480;            // the bulk update, and shorter groups move in-group update work off the chain

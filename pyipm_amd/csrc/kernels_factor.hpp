@@ -359,6 +359,8 @@ struct UpdGeo {
     int64_t row_begin, Npad, first_lp, sub0;
     int nb, world, rank, nrt, nct;         // nrt/nct: row / column tiles of this launch
     int prio;                              // != 0: raise wave priority (latency-critical panel-chain launches)
+    int64_t a0, a1, b0, b1;                // rows / columns that can be non-zero in BOTH operands: [a0,a1) u [b0,b1); a tile
+                                           // outside them would add an exact zero (KKT block structure) and is skipped
     int rt_min0, rt_step;                  // first row tile on/below the diagonal for super-column sJ = rt_min0 + sJ*rt_step (tiles)
     unsigned long long* dbg;               // diagnostics only (NULL in normal operation): per-block timeline
 };
@@ -447,6 +449,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_update(
     if (jglob >= Npad) return;
     const int64_t i0 = u.row_begin + rt * BM;
     if (i0 + BM <= jglob) return;          // tile strictly above the diagonal
+    {   // structural zeros: the L rows of this tile or the W rows of its columns are identically zero
+        const bool ri = (i0 + BM > u.a0 && i0 < u.a1) || (i0 + BM > u.b0 && i0 < u.b1);
+        const bool ci = (jglob + BN > u.a0 && jglob < u.a1) || (jglob + BN > u.b0 && jglob < u.b1);
+        if (!(ri && ci)) return;
+    }
     const int wi = (wave & 1) * 64, wj = (wave >> 1) * (BN / (NW / 2));
     const int l15 = lane & 15, l4 = lane >> 4;
     unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;

@@ -144,11 +144,41 @@ inline double* wbuf(Ctx* ctx, int64_t p) {
 
 // ---- per-panel building blocks -----------------------------------------------------------------
 
+// Rows (= columns, by symmetry) on which a rank-K update with source columns [cA, cB) can be non-zero.
+// KKT order [x | s | lambda_e | lambda_i] (pyipm.py:824-842): the (s,x) block is zero and nothing fills it, so
+// while the source columns lie in the x block the s rows of L (and the s rows of W) are exact zeros; while they
+// lie in the s block (diagonal Sigma, -I towards lambda_i) only the matching lambda_i rows are touched.
+void active_ranges(const Ctx* ctx, int64_t cA, int64_t cB, int64_t* a0, int64_t* a1, int64_t* b0, int64_t* b1) {
+    const Geo& g = ctx->g;
+    *a0 = 0; *a1 = g.Npad; *b0 = 0; *b1 = 0;
+    if (!ctx->skip_zeros || g.mi == 0) return;
+    const int64_t s0 = g.n, s1 = g.n + g.mi, i0 = g.n + g.mi + g.me;
+    if (cB <= s0)                { *a0 = 0; *a1 = s0; *b0 = s1; *b1 = g.Npad; }              // x-block sources
+    else if (cA >= s0 && cB <= s1) { *a0 = i0 + (cA - s0); *a1 = i0 + (cB - s0); *b0 = 0; *b1 = 0; }   // s-block sources
+}
+
+// lower-triangle entries (i >= j) with i in rows, j in [j0, j1), both restricted to the active ranges
+double active_area(int64_t row_begin, int64_t Npad, int64_t j0, int64_t j1, int64_t a0, int64_t a1, int64_t b0, int64_t b1) {
+    double area = 0.0;
+    const int64_t rng[2][2] = {{a0, a1}, {b0, b1}};
+    for (int cj = 0; cj < 2; ++cj) {
+        const int64_t ja = j0 > rng[cj][0] ? j0 : rng[cj][0], jb = j1 < rng[cj][1] ? j1 : rng[cj][1];
+        if (jb <= ja) continue;
+        for (int ri = 0; ri < 2; ++ri) {
+            int64_t ia = rng[ri][0] > row_begin ? rng[ri][0] : row_begin, ib = rng[ri][1] < Npad ? rng[ri][1] : Npad;
+            if (ib <= ia) continue;
+            // sum over j in [ja,jb) of #{ i in [ia,ib) : i >= j }
+            for (int64_t j = ja; j < jb; ++j) { const int64_t lo = ia > j ? ia : j; if (ib > lo) area += (double)(ib - lo); }
+        }
+    }
+    return area;
+}
+
 // Rank-K update of `n_lp` locally owned panels starting at local panel `first_lp`.
 // ldw / row_end / col_end default to the KKT storage's (the Gram launch of the condensed option narrows them).
 int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ldl, const double* Wop, int K,
                      int64_t row_begin, int64_t first_lp, int64_t n_lp, bool bulk = true,
-                     int64_t ldw = 0, int64_t row_end = 0, int64_t col_end = 0) {
+                     int64_t ldw = 0, int64_t row_end = 0, int64_t col_end = 0, int64_t src_c0 = -1) {
     const Geo& g = ctx->g;
     if (ldw <= 0) ldw = g.Npad;
     if (row_end <= 0) row_end = g.Npad;
@@ -162,6 +192,8 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     u.dbg = ctx->dbg_buf;
     u.prio = bulk ? 0 : ctx->side_prio;
     u.rt_min0 = 0; u.rt_step = 0;
+    if (src_c0 >= 0) active_ranges(ctx, src_c0, src_c0 + K, &u.a0, &u.a1, &u.b0, &u.b1);
+    else { u.a0 = 0; u.a1 = g.Npad; u.b0 = 0; u.b1 = 0; }
     if (ctx->xcd_swizzle && bulk && upd_swizzle_ok<128>(u)) {
         upd_fill_affine<128>(u);
         const int64_t nsup = upd_super_count<128>(u);
@@ -194,7 +226,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
     if (apply_pending && poff != 0) {
         const int64_t p0 = p - poff;
         int rc = launch_update128(ctx, stream, ctx->A + g.local_c0(p0) * g.Npad, g.Npad, wbuf(ctx, p0),
-                                  (int)((p - p0) * g.nb), c0, lp, 1, /*bulk=*/false);
+                                  (int)((p - p0) * g.nb), c0, lp, 1, /*bulk=*/false, 0, 0, 0, g.panel_c0(p0));
         if (rc) return rc;
     }
     for (int t = 0; t < nt; ++t) {
@@ -207,6 +239,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
             u.row_begin = row_begin; u.Npad = g.Npad; u.first_lp = lp; u.sub0 = t;
             u.nb = g.nb; u.world = g.world; u.rank = g.rank; u.nrt = (int)(m / BM); u.nct = 1;
             u.dbg = nullptr; u.prio = ctx->side_prio; u.rt_min0 = 0; u.rt_step = 0;
+            u.a0 = 0; u.a1 = g.Npad; u.b0 = 0; u.b1 = 0;
             dim3 grid((unsigned)(m / BM), 1);
             hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), 0, stream, ctx->A, g.Npad,
                                ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, t * TB, u);
@@ -251,16 +284,19 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
         e0 = ctx->ev_trailing[ctx->n_trailing].first; e1 = ctx->ev_trailing[ctx->n_trailing].second;
         PYIPM_HIP(hipEventRecord(e0, stream));
     }
-    int rc = launch_update128(ctx, stream, Lop, g.Npad, wbuf(ctx, p0), K, row_begin, first_lp, n_lp);
+    int rc = launch_update128(ctx, stream, Lop, g.Npad, wbuf(ctx, p0), K, row_begin, first_lp, n_lp, true, 0, 0, 0,
+                              g.panel_c0(p0));
     if (rc) return rc;
     if (ctx->profile) PYIPM_HIP(hipEventRecord(e1, stream));
     // algorithmic flops of this launch: 2*K per lower-triangle entry of the updated local columns
+    // (entries the KKT block structure leaves at zero are not counted: the launch skips their tiles)
     double fl = 0.0;
+    int64_t a0, a1, b0, b1;
+    active_ranges(ctx, g.panel_c0(p0), g.panel_c0(p0) + K, &a0, &a1, &b0, &b1);
     for (int64_t k = 0; k < n_lp; ++k) {
         const int64_t qq = (first_lp + k) * g.world + g.rank;
         if (qq >= g.npanels) break;
-        const double w = (double)g.panel_w(qq), r0 = (double)(g.Npad - g.panel_c0(qq));
-        fl += 2.0 * K * (w * r0 - 0.5 * w * (w - 1.0));
+        fl += 2.0 * K * active_area(g.panel_c0(qq), g.Npad, g.panel_c0(qq), g.panel_c0(qq) + g.panel_w(qq), a0, a1, b0, b1);
     }
     ctx->trailing_flops += fl;
     ctx->n_trailing++;
@@ -1226,6 +1262,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
         int v = (int)value; if (v < 1 || v > default_group(ctx->g.world)) { ctx->err = "group out of range"; return PYIPM_E_BADARG; }
         ctx->group = v; return PYIPM_OK; }
     if (!strcmp(name, "bulk_waves")) { ctx->bulk_waves = (int)value == 8 ? 8 : 4; return PYIPM_OK; }
+    if (!strcmp(name, "skip_zeros")) { ctx->skip_zeros = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tail_group")) { ctx->tail_group = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "tail_cols")) { ctx->tail_cols = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = (int)value; return PYIPM_OK; }
