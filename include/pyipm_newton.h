@@ -191,7 +191,7 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *                    L T = S / T z = y for diagonal tiles whose pivot spread exceeds refine_cond (the tile
  *                    inverses are explicit).
  *   "profile" 0|1, "lookahead" 0|1, "group" 1..create-time value, "tail_group" / "tail_cols" (group size once
- *   at most tail_cols columns remain; defaults 2 / 20480), "fuse_forward" 0|1, "pivtol_rel",
+ *   at most tail_cols columns remain; defaults 2 / 24576), "fuse_forward" 0|1, "pivtol_rel",
  *   "xcd_swizzle", "side_prio", "bulk_waves" 4|8 (measurement switches). */
 int pyipm_newton_set_option(pyipm_newton_ctx* ctx, const char* name, double value);
 

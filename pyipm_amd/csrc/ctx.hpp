@@ -79,10 +79,12 @@ struct Ctx {
     bool forward_fused = false;
     bool forward_pending = false;         // factor() already forward-substituted the pending residual into v0
     int lookahead = 1;                    // 0 none, 1 one group (two groups on a dedicated stream measured no faster: removed)
+    int s_fast = 1;                       // panels inside the slack block: closed-form elimination (k_s_panel)
+    std::vector<char> grp_fast;           // per group: every panel of it takes that path (built by factor_all)
     int skip_zeros = 1;                   // trailing updates skip tiles that the KKT block structure makes exact zeros
     int group = 1;                        // panels per bulk trailing update
     int tail_group = 2;                   // group size once at most tail_cols columns remain: there the panel chain outlasts
-    int64_t tail_cols = 20480;            // the bulk update, and shorter groups move in-group update work off the chain
+    int64_t tail_cols = 24576;            // the bulk update, and shorter groups move in-group update work off the chain
     std::vector<int> grp_of, grp_off;     // per panel: group id and offset inside the group (built by factor_all)
     std::vector<int64_t> grp_first;       // per group: first panel (+ one past the last group)
     int bulk_waves = 8;                   // waves per block of the BULK update tiles (8: 128 VGPRs each, 4 waves per SIMD;

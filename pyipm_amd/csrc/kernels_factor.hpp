@@ -343,6 +343,93 @@ __global__ __launch_bounds__(256) void k_panel_scale(
 }
 
 // ---------------------------------------------------------------------------------------------
+// Panels that lie inside the slack block.  There the KKT matrix is known in closed form when elimination
+// reaches it: the (s,s) block is still diag(Sigma) (the (s,x) block is zero, so the x columns never touched
+// it), the only other non-zeros of an s column are the -1 towards its own lambda_i row, and an s column
+// updates nothing but that lambda_i's diagonal entry.  One small kernel does for such a panel what the tile
+// inversions, scalings and updates would do on 99.9 % zeros -- with the same operations in the same order
+// (1/d by division, the refinement recurrences of flagged tiles as fused multiply-adds), so the factor, the
+// statistics and the directions are bit for bit those of the dense path.
+// One block, 256 threads: wave w takes tiles w, w+4, ...; lane k owns column 64 t + k of the panel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_s_panel(
+    double* __restrict__ A, int64_t ld, int64_t c0, int nt,
+    double* __restrict__ Tinv, double* __restrict__ Tsave, double* __restrict__ Tflag,     // of the panel's first tile
+    double refine_cond, int nref, DevStats* __restrict__ st, int64_t s0, int64_t i0, double pivtol_rel)
+{
+    __shared__ long long sh_cnt[4][3];      // neg, zero, bad per wave
+    __shared__ double sh_mm[4][3];          // dmin, dmax, gmax per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    long long neg = 0, zero = 0, bad = 0;
+    double dmin = 1.0e308, dmax = 0.0, gmax = 0.0;
+    const double tiny = 2.2250738585072014e-308;
+    for (int t = wave; t < nt; t += 4) {
+        const int64_t col = c0 + (int64_t)t * TB + lane;            // global column (= local: single rank)
+        const int64_t irow = i0 + (col - s0);                        // its lambda_i row
+        double d = A[col + col * ld];
+        const double ad = fabs(d);
+        const bool isbad = !(ad <= 1.0e308);
+        const bool iszero = ad <= pivtol_rel * ad;                   // the tile-local column maximum is |d| itself
+        if (iszero) d = (d >= 0.0) ? tiny : -tiny;
+        const double x = 1.0 / d;
+        // tile statistics (as k_tile_invert keeps them)
+        const unsigned long long mz = __ballot(iszero), mb = __ballot(isbad), mn = __ballot(!iszero && d < 0.0);
+        const double tmin = -wave_max(iszero ? -1.0e308 : -ad), tmax = wave_max(iszero ? 0.0 : ad);
+        const int nz = __popcll(mz);
+        const bool flagged = nz == 0 && !(tmax <= refine_cond * tmin);
+        zero += nz; bad += __popcll(mb); neg += __popcll(mn);
+        dmin = fmin(dmin, tmin); dmax = fmax(dmax, tmax);
+        // inv(T) and T as dense 64x64 tiles (the substitutions and a receiver's rebuild read them densely)
+        double* Xi = Tinv + (int64_t)t * TB * TB;
+        double* Tt = Tsave + (int64_t)t * TB * TB;
+        #pragma unroll 8
+        for (int r = 0; r < TB; ++r) {
+            Xi[lane * TB + r] = (r == lane) ? x : 0.0;
+            Tt[lane * TB + r] = (r == lane) ? A[col + col * ld] : 0.0;
+        }
+        if (lane == 0) Tflag[t] = flagged ? 1.0 : 0.0;
+        // L(lambda_i row, this column) = S X with S = -1, refined like k_panel_scale refines a flagged tile
+        const double sv = A[irow + col * ld];                       // -1 (pyipm.py:838-842)
+        double l = fma(x, sv, 0.0);
+        if (flagged)
+            for (int it = 0; it < nref; ++it) {
+                const double r = fma(-A[col + col * ld], l, sv);
+                l = fma(x, r, l);
+            }
+        A[irow + col * ld] = l;                                     // (its Schur update: k_s_schur, on the update stream)
+        gmax = fmax(gmax, fabs(l));
+    }
+    gmax = wave_max(gmax);
+    if (lane == 0) {
+        sh_cnt[wave][0] = neg; sh_cnt[wave][1] = zero; sh_cnt[wave][2] = bad;
+        sh_mm[wave][0] = dmin; sh_mm[wave][1] = dmax; sh_mm[wave][2] = gmax;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long n = 0, z = 0, b = 0; double mn = 1.0e308, mx = 0.0, gm = 0.0;
+        for (int w = 0; w < 4; ++w) { n += sh_cnt[w][0]; z += sh_cnt[w][1]; b += sh_cnt[w][2];
+                                      mn = fmin(mn, sh_mm[w][0]); mx = fmax(mx, sh_mm[w][1]); gm = fmax(gm, sh_mm[w][2]); }
+        st->n_neg += n; st->n_zero += z; st->n_pos += (long long)nt * TB - n - z; st->nonfinite += b;
+        if (mn < st->d_min) st->d_min = mn;
+        if (mx > st->d_max) st->d_max = mx;
+        atomicMax(&st->growth_bits, (unsigned long long)__double_as_longlong(gm));
+    }
+}
+
+// The trailing update of slack-block source columns [c0, c0+ncols): column c touches exactly one entry, the
+// diagonal of its lambda_i row, C += L * (-S) with -S = 1.  Restricted to target columns [tc0, tc1) so that
+// it can stand in for the head / bulk launches of the group (same place in the order of operations).
+__global__ __launch_bounds__(256) void k_s_schur(double* __restrict__ A, int64_t ld, int64_t c0, int64_t ncols,
+                                                 int64_t s0, int64_t i0, int64_t tc0, int64_t tc1)
+{
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= ncols) return;
+    const int64_t col = c0 + k, irow = i0 + (col - s0);
+    if (irow < tc0 || irow >= tc1) return;
+    A[irow + irow * ld] = fma(A[irow + col * ld], 1.0, A[irow + irow * ld]);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4: C[i,j] -= sum_k L[i,k] * W[j,k]  on the lower block-triangle, fp64 MFMA
 // (v_mfma_f64_16x16x4_f64).  Column-major everywhere, so i is the contiguous index of C, L and W.
 // MFMA orientation: D[m][n] with m <- j (A operand = W), n <- i (B operand = L); the f64 C/D map

@@ -221,6 +221,15 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
     const int nbw = (int)g.panel_w(p);
     const int nt = nbw / TB;
     const int64_t lp = p / g.world;
+    if ((size_t)p < ctx->grp_of.size() && !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)ctx->grp_of[p]]) {
+        // the whole group lies inside the slack block: closed form, no W, no updates (see k_s_panel)
+        hipLaunchKernelGGL(k_s_panel, dim3(1), dim3(256), 0, stream, ctx->A, g.Npad, c0, nt,
+                           ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB), ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB),
+                           ctx->Tflag + c0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats,
+                           g.n, g.n + g.mi + g.me, ctx->pivtol_rel);
+        PYIPM_KCHECK();
+        return 0;
+    }
     double* W = wbuf(ctx, p);
     const int64_t poff = (size_t)p < ctx->grp_off.size() ? ctx->grp_off[p] : p % ctx->group;
     if (apply_pending && poff != 0) {
@@ -269,6 +278,16 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
     if (n_lp <= 0) return 0;
     int K = 0;
     for (int64_t q = p0; q < p0 + np; ++q) K += (int)g.panel_w(q);
+    if ((size_t)p0 < ctx->grp_of.size() && !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)ctx->grp_of[p0]]) {
+        // slack-block sources: each column updates one diagonal entry (k_s_schur), here for the target columns
+        // of this launch -- on the update stream, where the dense launch would have run
+        const int64_t tq0 = first_lp, tq1 = first_lp + n_lp;                       // single rank: local = global panels
+        const int64_t tc0 = g.panel_c0(tq0), tc1 = tq1 >= g.npanels ? g.Npad : g.panel_c0(tq1);
+        hipLaunchKernelGGL(k_s_schur, grid1(K), dim3(256), 0, stream, ctx->A, g.Npad, g.panel_c0(p0), (int64_t)K,
+                           g.n, g.n + g.mi + g.me, tc0, tc1);
+        PYIPM_KCHECK();
+        return 0;
+    }
     const bool mine = g.owner(p0) == g.rank;
     const double* Lop = mine ? ctx->A + g.local_c0(p0) * g.Npad : ctx->Lbuf;
     const int64_t q0 = first_lp * g.world + g.rank;           // first global panel updated
@@ -644,6 +663,13 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             p += G; ++gid;
         }
         ctx->grp_first.push_back(np);
+        ctx->grp_fast.assign(ctx->grp_first.size() - 1, 0);
+        if (ctx->s_fast && ctx->skip_zeros && g.mi > 0 && g.world == 1)
+            for (size_t gi = 0; gi + 1 < ctx->grp_first.size(); ++gi) {
+                const int64_t pa = ctx->grp_first[gi], pb = ctx->grp_first[gi + 1];
+                const int64_t ca = g.panel_c0(pa), cb = g.panel_c0(pb - 1) + g.panel_w(pb - 1);
+                ctx->grp_fast[gi] = (ca >= g.n && cb <= g.n + g.mi) ? 1 : 0;
+            }
     }
     const int64_t ngroups = (int64_t)ctx->grp_first.size() - 1;
     auto gsize = [&](int64_t grp) { return ctx->grp_first[(size_t)grp + 1] - ctx->grp_first[(size_t)grp]; };
@@ -1100,7 +1126,7 @@ int pyipm_newton_factor_begin(pyipm_newton_ctx* h) {
     if (ctx->batched) return single_only(ctx);
     if (!ctx->assembled) { ctx->err = "factor_begin: assemble first"; return PYIPM_E_BADARG; }
     if (ctx->cond_active) { ctx->err = "per-panel phases do not apply to the condensed system; use factor()"; return PYIPM_E_BADARG; }
-    ctx->grp_of.clear(); ctx->grp_off.clear();      // per-panel phases use the uniform group map
+    ctx->grp_of.clear(); ctx->grp_off.clear(); ctx->grp_fast.clear();      // per-panel phases: uniform group map, dense panels
     return factor_begin(ctx);
 }
 int pyipm_newton_factor_end(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
@@ -1262,6 +1288,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
         int v = (int)value; if (v < 1 || v > default_group(ctx->g.world)) { ctx->err = "group out of range"; return PYIPM_E_BADARG; }
         ctx->group = v; return PYIPM_OK; }
     if (!strcmp(name, "bulk_waves")) { ctx->bulk_waves = (int)value == 8 ? 8 : 4; return PYIPM_OK; }
+    if (!strcmp(name, "s_fast")) { ctx->s_fast = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "skip_zeros")) { ctx->skip_zeros = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tail_group")) { ctx->tail_group = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "tail_cols")) { ctx->tail_cols = (int64_t)value; return PYIPM_OK; }
