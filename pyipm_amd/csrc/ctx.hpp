@@ -81,6 +81,7 @@ struct Ctx {
     int lookahead = 1;                    // 0 none, 1 one group (two groups on a dedicated stream measured no faster: removed)
     int s_fast = 1;                       // panels inside the slack block: closed-form elimination (k_s_panel)
     std::vector<char> grp_fast;           // per group: every panel of it takes that path (built by factor_all)
+    std::vector<char> grp_x;              // per group: lies inside the x block (its chain kernels may skip the slack rows)
     int skip_zeros = 1;                   // trailing updates skip tiles that the KKT block structure makes exact zeros
     int group = 1;                        // panels per bulk trailing update
     int tail_group = 2;                   // group size once at most tail_cols columns remain: there the panel chain outlasts

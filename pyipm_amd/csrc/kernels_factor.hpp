@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256) void k_panel_scale(
     const double* __restrict__ Win, int64_t ld_in, int64_t col_in,   // S read from  Win[i + (col_in+k)*ld_in]
     double* __restrict__ Wcopy, int64_t ld_w, int64_t col_w,         // copy of -S (may be NULL = no copy)
     const double* __restrict__ Tinv, const double* __restrict__ Tsave, const double* __restrict__ Tflag, int nref,
-    int64_t row_begin, unsigned long long* __restrict__ growth_bits,
+    int64_t row_begin, int64_t hole0, int64_t hole1,   // 64-row blocks inside [hole0, hole1) hold exact zeros: skipped
+    unsigned long long* __restrict__ growth_bits,
     double sign)      // owner: Win = S, Wcopy = -S (the update kernel wants -W), sign = +1;
                       // non-owner rebuilding L from a received -S: sign = -1
 {
@@ -271,7 +272,11 @@ __global__ __launch_bounds__(256) void k_panel_scale(
     // (row = (lane>>4)+4r of tile t, col = lane&15) puts L[i][16t+4r+(lane>>4)] in accumulator [t][r], which
     // is exactly the B-operand layout of k-step 4t+r: the refinement GEMMs need no data movement.
     __shared__ double X[TB][TB + 2];        // holds sign*inv(T), then -sign*T, then sign*inv(T) again (one array: LDS decides
-    __builtin_amdgcn_s_setprio(3);          // how many of these short blocks fit into the slot a retiring update block frees)
+    {                                       // how many of these short blocks fit into the slot a retiring update block frees)
+        const int64_t r0 = row_begin + (int64_t)blockIdx.x * TB;
+        if (r0 >= hole0 && r0 + TB <= hole1) return;          // S rows identically zero here (KKT structure): L = 0 already
+    }
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     if (nref > 0 && *Tflag == 0.0) nref = 0;            // well-conditioned tile: the plain product is accurate (block-uniform)

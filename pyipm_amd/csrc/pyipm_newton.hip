@@ -238,6 +238,17 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
                                   (int)((p - p0) * g.nb), c0, lp, 1, /*bulk=*/false, 0, 0, 0, g.panel_c0(p0));
         if (rc) return rc;
     }
+    // Panels inside the x block: the slack rows of the panel are exact zeros (active_ranges), whole 128-row tiles of
+    // them are skipped by the in-panel updates and the scalings too (single rank only: a receiver rebuilds L from W).
+    int64_t ha0 = 0, ha1 = g.Npad, hb0 = 0, hb1 = 0, hole0 = 0, hole1 = 0;
+    // Only when the whole GROUP lies in the x block: a group's bulk update reads every W row the structure of its
+    // source columns allows, so a mixed group needs all of them written.
+    const bool grp_in_x = (size_t)p < ctx->grp_of.size() && !ctx->grp_x.empty() && ctx->grp_x[(size_t)ctx->grp_of[p]];
+    if (ctx->skip_zeros && g.world == 1 && g.mi > 0 && grp_in_x) {
+        active_ranges(ctx, c0, c0 + nbw, &ha0, &ha1, &hb0, &hb1);
+        hole0 = (g.n + BM - 1) / BM * BM; hole1 = (g.n + g.mi) / BM * BM;
+        if (hole1 < hole0) hole1 = hole0;
+    }
     for (int t = 0; t < nt; ++t) {
         const int64_t j0 = c0 + (int64_t)t * TB, lcol = lc0 + (int64_t)t * TB;
         if (t > 0) {
@@ -248,7 +259,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
             u.row_begin = row_begin; u.Npad = g.Npad; u.first_lp = lp; u.sub0 = t;
             u.nb = g.nb; u.world = g.world; u.rank = g.rank; u.nrt = (int)(m / BM); u.nct = 1;
             u.dbg = nullptr; u.prio = ctx->side_prio; u.rt_min0 = 0; u.rt_step = 0;
-            u.a0 = 0; u.a1 = g.Npad; u.b0 = 0; u.b1 = 0;
+            u.a0 = ha0; u.a1 = ha1; u.b0 = hb0; u.b1 = hb1;
             dim3 grid((unsigned)(m / BM), 1);
             hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), 0, stream, ctx->A, g.Npad,
                                ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, t * TB, u);
@@ -263,7 +274,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
             hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(below / TB)), dim3(256), 0, stream,
                                ctx->A, g.Npad, lcol, ctx->A, g.Npad, lcol, W, g.Npad, (int64_t)t * TB,
                                ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), ctx->Tsv + (j0 / TB) * (int64_t)(TB * TB),
-                               ctx->Tflag + j0 / TB, ctx->block_refine, j0 + TB, &ctx->dstats->growth_bits, 1.0);
+                               ctx->Tflag + j0 / TB, ctx->block_refine, j0 + TB, hole0, hole1, &ctx->dstats->growth_bits, 1.0);
             PYIPM_KCHECK();
         }
     }
@@ -664,6 +675,11 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         }
         ctx->grp_first.push_back(np);
         ctx->grp_fast.assign(ctx->grp_first.size() - 1, 0);
+        ctx->grp_x.assign(ctx->grp_first.size() - 1, 0);
+        for (size_t gi = 0; gi + 1 < ctx->grp_first.size(); ++gi) {
+            const int64_t pb = ctx->grp_first[gi + 1];
+            ctx->grp_x[gi] = (g.panel_c0(pb - 1) + g.panel_w(pb - 1) <= g.n) ? 1 : 0;
+        }
         if (ctx->s_fast && ctx->skip_zeros && g.mi > 0 && g.world == 1)
             for (size_t gi = 0; gi + 1 < ctx->grp_first.size(); ++gi) {
                 const int64_t pa = ctx->grp_first[gi], pb = ctx->grp_first[gi + 1];
@@ -1126,7 +1142,7 @@ int pyipm_newton_factor_begin(pyipm_newton_ctx* h) {
     if (ctx->batched) return single_only(ctx);
     if (!ctx->assembled) { ctx->err = "factor_begin: assemble first"; return PYIPM_E_BADARG; }
     if (ctx->cond_active) { ctx->err = "per-panel phases do not apply to the condensed system; use factor()"; return PYIPM_E_BADARG; }
-    ctx->grp_of.clear(); ctx->grp_off.clear(); ctx->grp_fast.clear();      // per-panel phases: uniform group map, dense panels
+    ctx->grp_of.clear(); ctx->grp_off.clear(); ctx->grp_fast.clear(); ctx->grp_x.clear();      // per-panel phases: uniform group map, dense panels
     return factor_begin(ctx);
 }
 int pyipm_newton_factor_end(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
@@ -1218,7 +1234,7 @@ int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf)
             hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(m / TB)), dim3(256), 0, ctx->stream,
                                ctx->Lbuf, g.Npad, (int64_t)t * TB, wbuf(ctx, p), g.Npad, (int64_t)t * TB,
                                (double*)nullptr, (int64_t)0, (int64_t)0, dinv + (int64_t)t * TB * TB,
-                               tsv + (int64_t)t * TB * TB, ctx->Tflag + c0 / TB + t, ctx->block_refine, c1,
+                               tsv + (int64_t)t * TB * TB, ctx->Tflag + c0 / TB + t, ctx->block_refine, c1, (int64_t)0, (int64_t)0,
                                (unsigned long long*)nullptr, -1.0);
             PYIPM_KCHECK();
         }
