@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <map>
 #include <vector>
 #include "../../include/pyipm_newton.h"
 
@@ -82,6 +83,8 @@ struct Ctx {
     int s_fast = 1;                       // panels inside the slack block: closed-form elimination (k_s_panel)
     std::vector<char> grp_fast;           // per group: every panel of it takes that path (built by factor_all)
     std::vector<char> grp_x;              // per group: lies inside the x block (its chain kernels may skip the slack rows)
+    struct TileList { unsigned* dev = nullptr; unsigned count = 0; };
+    std::map<std::vector<int64_t>, TileList> tile_lists;   // compact tile orders of the bulk launches (geometry repeats every step)
     int skip_zeros = 1;                   // trailing updates skip tiles that the KKT block structure makes exact zeros
     int group = 1;                        // panels per bulk trailing update
     int tail_group = 2;                   // group size once at most tail_cols columns remain: there the panel chain outlasts

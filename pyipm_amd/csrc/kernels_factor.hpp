@@ -455,6 +455,8 @@ struct UpdGeo {
                                            // outside them would add an exact zero (KKT block structure) and is skipped
     int rt_min0, rt_step;                  // first row tile on/below the diagonal for super-column sJ = rt_min0 + sJ*rt_step (tiles)
     unsigned long long* dbg;               // diagnostics only (NULL in normal operation): per-block timeline
+    const unsigned* tiles;                 // swizzled launches: block b works on tile (tiles[b] & 0xffff, tiles[b] >> 16), built on
+                                           // the host in the XCD-aware order below with every empty tile left out; NULL = decode here
 };
 template <int BN>
 __host__ __device__ inline void upd_col(const UpdGeo& u, int64_t ct, int64_t& jglob, int64_t& jloc) {
@@ -513,7 +515,11 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_update(
     if (u.prio) __builtin_amdgcn_s_setprio(3);     // panel-chain launches (side stream)
     const int64_t Npad = u.Npad;
     int64_t rt, ct;
-    if (SWZ) {
+    if (SWZ && u.tiles) {
+        const unsigned code = u.tiles[blockIdx.x];
+        if (code == 0xffffffffu) return;               // padding of a shorter XCD sequence
+        rt = code & 0xffffu; ct = code >> 16;
+    } else if (SWZ) {
         // XCD-aware order: block b runs on XCD b%8 (observed dispatch); each XCD walks its own
         // sequence of 8x8 super-tiles so the 16 operand tiles of a super-tile are reused from its L2.
         const unsigned b = blockIdx.x;

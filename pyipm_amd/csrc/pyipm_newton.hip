@@ -174,6 +174,61 @@ double active_area(int64_t row_begin, int64_t Npad, int64_t j0, int64_t j1, int6
     return area;
 }
 
+// Compact, XCD-aware tile order of one swizzled launch.  The device decode (k_update, SWZ) is replayed here for
+// every block; tiles that are out of range, above the diagonal or structurally zero are dropped, the eight
+// per-XCD sequences (block b runs on XCD b % 8) are levelled by moving the tails of long ones to short ones,
+// and the result is interleaved back into launch order.  Cached per geometry: it repeats every step.
+int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, unsigned* count) {
+    std::vector<int64_t> key = {u.row_begin, u.Npad, u.first_lp, u.nrt, u.nct, u.a0, u.a1, u.b0, u.b1, u.nb, u.rt_min0, u.rt_step};
+    auto it = ctx->tile_lists.find(key);
+    if (it != ctx->tile_lists.end()) { *dev = it->second.dev; *count = it->second.count; return 0; }
+    const int64_t rounds = (nsup + 7) / 8, nblocks = rounds * 8 * SUPER * SUPER;
+    const int nsr = (u.nrt + SUPER - 1) >> 3, nsc = (u.nct + SUPER - 1) >> 3;
+    std::vector<unsigned> seq[8];
+    for (int64_t b = 0; b < nblocks; ++b) {
+        const int xcd = (int)(b & 7);
+        const int64_t slot = b >> 3;
+        int sidx = (int)((slot >> 6) * 8) + xcd;
+        const int within = (int)(slot & 63);
+        int sJ = 0, sI = -1;
+        for (; sJ < nsc; ++sJ) {
+            const int mn = upd_super_min_row(u, sJ);
+            const int cnt = mn < nsr ? nsr - mn : 0;
+            if (sidx < cnt) { sI = mn + sidx; break; }
+            sidx -= cnt;
+        }
+        if (sI < 0) continue;
+        const int64_t rt = (int64_t)sI * SUPER + (within & (SUPER - 1)), ct = (int64_t)sJ * SUPER + (within >> 3);
+        if (rt >= u.nrt || ct >= u.nct) continue;
+        int64_t jglob, jloc;
+        upd_col<128>(u, ct, jglob, jloc);
+        if (jglob >= u.Npad) continue;
+        const int64_t i0 = u.row_begin + rt * BM;
+        if (i0 + BM <= jglob) continue;
+        const bool ri = (i0 + BM > u.a0 && i0 < u.a1) || (i0 + BM > u.b0 && i0 < u.b1);
+        const bool ci = (jglob + 128 > u.a0 && jglob < u.a1) || (jglob + 128 > u.b0 && jglob < u.b1);
+        if (!(ri && ci)) continue;
+        seq[xcd].push_back((unsigned)rt | ((unsigned)ct << 16));
+    }
+    size_t total = 0;
+    for (auto& v : seq) total += v.size();
+    const size_t target = (total + 7) / 8;
+    std::vector<unsigned> spare;
+    for (auto& v : seq) while (v.size() > target) { spare.push_back(v.back()); v.pop_back(); }
+    for (auto& v : seq) while (v.size() < target && !spare.empty()) { v.push_back(spare.back()); spare.pop_back(); }
+    std::vector<unsigned> list(8 * target, 0xffffffffu);
+    for (int x = 0; x < 8; ++x) for (size_t j = 0; j < seq[x].size(); ++j) list[8 * j + x] = seq[x][j];
+    Ctx::TileList tl;
+    tl.count = (unsigned)list.size();
+    if (tl.count) {
+        PYIPM_HIP(hipMalloc((void**)&tl.dev, list.size() * sizeof(unsigned)));
+        PYIPM_HIP(hipMemcpy(tl.dev, list.data(), list.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    }
+    ctx->tile_lists[key] = tl;
+    *dev = tl.dev; *count = tl.count;
+    return 0;
+}
+
 // Rank-K update of `n_lp` locally owned panels starting at local panel `first_lp`.
 // ldw / row_end / col_end default to the KKT storage's (the Gram launch of the condensed option narrows them).
 int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ldl, const double* Wop, int K,
@@ -191,15 +246,17 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     u.nrt = (int)(m / BM); u.nct = (int)(n_lp * (g.nb / 128));
     u.dbg = ctx->dbg_buf;
     u.prio = bulk ? 0 : ctx->side_prio;
-    u.rt_min0 = 0; u.rt_step = 0;
+    u.rt_min0 = 0; u.rt_step = 0; u.tiles = nullptr;
     if (src_c0 >= 0) active_ranges(ctx, src_c0, src_c0 + K, &u.a0, &u.a1, &u.b0, &u.b1);
     else { u.a0 = 0; u.a1 = g.Npad; u.b0 = 0; u.b1 = 0; }
     if (ctx->xcd_swizzle && bulk && upd_swizzle_ok<128>(u)) {
         upd_fill_affine<128>(u);
         const int64_t nsup = upd_super_count<128>(u);
         if (nsup <= 0) return 0;
-        const int64_t rounds = (nsup + 7) / 8;                       // super-tiles per XCD
-        dim3 grid((unsigned)(rounds * 8 * SUPER * SUPER));
+        unsigned ntiles = 0;
+        int rc = tile_list(ctx, u, nsup, &u.tiles, &ntiles); if (rc) return rc;
+        if (ntiles == 0) return 0;
+        dim3 grid(ntiles);
         if (ctx->bulk_waves == 8)
             hipLaunchKernelGGL((k_update<128, true, 8>), grid, dim3(512), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
         else
@@ -259,7 +316,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
             u.row_begin = row_begin; u.Npad = g.Npad; u.first_lp = lp; u.sub0 = t;
             u.nb = g.nb; u.world = g.world; u.rank = g.rank; u.nrt = (int)(m / BM); u.nct = 1;
             u.dbg = nullptr; u.prio = ctx->side_prio; u.rt_min0 = 0; u.rt_step = 0;
-            u.a0 = ha0; u.a1 = ha1; u.b0 = hb0; u.b1 = hb1;
+            u.a0 = ha0; u.a1 = ha1; u.b0 = hb0; u.b1 = hb1; u.tiles = nullptr;
             dim3 grid((unsigned)(m / BM), 1);
             hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), 0, stream, ctx->A, g.Npad,
                                ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, t * TB, u);
@@ -926,6 +983,7 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) {
     if (ctx->stg_d2L) hipFree(ctx->stg_d2L);
     if (ctx->stg_Je) hipFree(ctx->stg_Je);
     if (ctx->stg_Ji) hipFree(ctx->stg_Ji);
+    for (auto& kv : ctx->tile_lists) if (kv.second.dev) hipFree(kv.second.dev);
     if (ctx->JT) hipFree(ctx->JT);
     if (ctx->Jx) hipFree(ctx->Jx);
     if (ctx->cond_pos) hipFree(ctx->cond_pos);
