@@ -103,12 +103,12 @@ def pmc_traffic(N, nb):
     FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md; tools/pmc_update.sh,
     tools/pmc_summary.py).  Counters cannot be collected inside this process, so the figure is attached
     only for the configuration it was measured on; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r01_l_pmc_update.json")
+    path = os.path.join(ROOT, "profiles", "r01_m_pmc_update.json")
     if N != 32768 or nb != 256 or os.environ.get("PYIPM_NEWTON_GROUP") not in (None, "4") or not os.path.exists(path):
         return None, None
     try:
         d = json.load(open(path))
-        return float(d["hbm_bytes_per_launch_corrected"]), "profiles/r01_l_pmc_update.json (separate --pmc passes of this command)"
+        return float(d["hbm_bytes_per_launch_corrected"]), "profiles/r01_m_pmc_update.json (separate --pmc passes of this command)"
     except Exception:
         return None, None
 
@@ -191,7 +191,7 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    trailing_ms = trailing_flops = panel_ms = solve_ms = assemble_ms = gram_ms = 0.0
+    trailing_ms = trailing_flops = panel_ms = solve_ms = assemble_ms = gram_ms = trailing_area = 0.0
     n_launch = 0
     fence()
     t0 = time.perf_counter()
@@ -201,6 +201,7 @@ def main():
         trailing_ms += tm["trailing_ms"]; trailing_flops += tm["trailing_flops"]; n_launch += tm["n_trailing"]
         panel_ms += tm["panel_ms"]; solve_ms += tm["solve_ms"]; assemble_ms += tm["assemble_ms"]
         gram_ms += tm["gram_ms"]
+        trailing_area += tm["trailing_area"]
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -257,10 +258,8 @@ def main():
                         "growth": st["growth"]},
         }
         if world == 1 and n_launch and not condensed:
-            # C-tile read-modify-write (16 B per lower-triangle entry per launch) + the two operand panels once
-            groups = max(1, int(os.environ.get("PYIPM_NEWTON_GROUP", "4")))
-            Kb = groups * args.nb
-            out["roofline"]["algorithmic_bytes_per_launch"] = (trailing_flops / (2.0 * Kb)) * 16.0 / n_launch + 2.0 * 8.0 * Kb * (N / 2.0)
+            # C-tile read-modify-write: 16 B per matrix entry a launch updates (operand panels, read once, add < 10 %)
+            out["roofline"]["algorithmic_bytes_per_launch"] = 16.0 * trailing_area / n_launch
         if condensed:
             # same Newton direction from the (n+me)-dimensional condensed system; NOT the
             # headline configuration: the flop count of the step itself changes

@@ -177,7 +177,8 @@ int pyipm_newton_step_batched(pyipm_newton_ctx* ctx, double delta, double delta_
 int pyipm_newton_kkt_storage(pyipm_newton_ctx* ctx, double** ptr, int64_t* ld, int64_t* ncols);
 /* Time (ms, HIP events on the handle's stream) of the phases of the last factor/solve call:
  * out[0]=assemble, [1]=panel work, [2]=trailing updates, [3]=solve, [4]=#trailing launches,
- * [5]=algorithmic flops of those launches, [6]=factor, [7]=Ji Sigma Ji' launch (condensed option). */
+ * [5]=algorithmic flops of those launches, [6]=factor, [7]=Ji Sigma Ji' launch (condensed option) or, for the
+ * full system, the number of matrix entries those launches update (their C-tile traffic is 16 B each). */
 int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
 /* Options (all default to the measured-best setting):
  *   "condensed" 0|1  single-rank handles with mi > 0: assemble/factor/solve work on the condensed system

@@ -137,7 +137,7 @@ struct Ctx {
     int profile = 0;
     // timings of last calls (ms)
     double t_assemble = 0, t_panel = 0, t_trailing = 0, t_solve = 0, t_factor = 0;
-    double trailing_flops = 0; int64_t n_trailing = 0;
+    double trailing_flops = 0, trailing_area = 0; int64_t n_trailing = 0;   // area: matrix entries updated, summed over launches
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_trailing;   // reused event pool
     hipEvent_t ev[8] = {};
     bool ev_assemble_valid = false, ev_solve_valid = false;

@@ -386,6 +386,7 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
         fl += 2.0 * K * active_area(g.panel_c0(qq), g.Npad, g.panel_c0(qq), g.panel_c0(qq) + g.panel_w(qq), a0, a1, b0, b1);
     }
     ctx->trailing_flops += fl;
+    ctx->trailing_area += fl / (2.0 * K);
     ctx->n_trailing++;
     return 0;
 }
@@ -405,7 +406,7 @@ int factor_begin(Ctx* ctx) {
     DevStats z; memset(&z, 0, sizeof(z)); z.d_min = 1.0e308; z.d_max = 0.0;
     PYIPM_HIP(hipMemcpyAsync(ctx->dstats, &z, sizeof(z), hipMemcpyHostToDevice, ctx->stream));
     PYIPM_HIP(hipStreamSynchronize(ctx->stream));   // &z is a stack temporary
-    ctx->n_trailing = 0; ctx->trailing_flops = 0.0;
+    ctx->n_trailing = 0; ctx->trailing_flops = 0.0; ctx->trailing_area = 0.0;
     return 0;
 }
 
@@ -1341,7 +1342,7 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* h, double out[8]) {
     if (ctx->ev_solve_valid) { float ms = 0.f; PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->t_solve = ms; }
     out[0] = ctx->t_assemble; out[1] = ctx->t_panel; out[2] = ctx->t_trailing; out[3] = ctx->t_solve;
     out[4] = (double)ctx->n_trailing; out[5] = ctx->trailing_flops; out[6] = ctx->t_factor;
-    out[7] = ctx->cond_active ? ctx->t_gram : 0.0;
+    out[7] = ctx->cond_active ? ctx->t_gram : ctx->trailing_area;   // full system: entries updated by the trailing launches
     return PYIPM_OK;
 }
 

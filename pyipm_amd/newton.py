@@ -322,4 +322,4 @@ class NewtonCore(object):
         t = (c_double * 8)()
         self._ck(self.lib.pyipm_newton_last_timings(self.h, t))
         return {"assemble_ms": t[0], "panel_ms": t[1], "trailing_ms": t[2], "solve_ms": t[3],
-                "n_trailing": int(t[4]), "trailing_flops": t[5], "factor_ms": t[6], "gram_ms": t[7]}
+                "n_trailing": int(t[4]), "trailing_flops": t[5], "factor_ms": t[6], "gram_ms": t[7], "trailing_area": t[7]}
