@@ -182,6 +182,11 @@ int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, uns
     std::vector<int64_t> key = {u.row_begin, u.Npad, u.first_lp, u.nrt, u.nct, u.a0, u.a1, u.b0, u.b1, u.nb, u.rt_min0, u.rt_step};
     auto it = ctx->tile_lists.find(key);
     if (it != ctx->tile_lists.end()) { *dev = it->second.dev; *count = it->second.count; return 0; }
+    if (ctx->tile_lists.size() >= 1024) {              // geometries that keep changing (condensed option: |A| varies): start over
+        PYIPM_HIP(hipDeviceSynchronize());
+        for (auto& kv : ctx->tile_lists) if (kv.second.dev) hipFree(kv.second.dev);
+        ctx->tile_lists.clear();
+    }
     const int64_t rounds = (nsup + 7) / 8, nblocks = rounds * 8 * SUPER * SUPER;
     const int nsr = (u.nrt + SUPER - 1) >> 3, nsc = (u.nct + SUPER - 1) >> 3;
     std::vector<unsigned> seq[8];
