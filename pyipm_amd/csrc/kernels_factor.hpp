@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_panel_scale(
 // One block, 256 threads: wave w takes tiles w, w+4, ...; lane k owns column 64 t + k of the panel.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_s_panel(
-    double* __restrict__ A, int64_t ld, int64_t c0, int nt,
+    double* __restrict__ A, int64_t ld, int64_t c0, int64_t lc0, int nt,       // global / local first column of the panel
     double* __restrict__ Tinv, double* __restrict__ Tsave, double* __restrict__ Tflag,     // of the panel's first tile
     double refine_cond, int nref, DevStats* __restrict__ st, int64_t s0, int64_t i0, double pivtol_rel)
 {
@@ -369,9 +369,10 @@ __global__ __launch_bounds__(256) void k_s_panel(
     double dmin = 1.0e308, dmax = 0.0, gmax = 0.0;
     const double tiny = 2.2250738585072014e-308;
     for (int t = wave; t < nt; t += 4) {
-        const int64_t col = c0 + (int64_t)t * TB + lane;            // global column (= local: single rank)
+        const int64_t col = c0 + (int64_t)t * TB + lane;            // global column = row of its diagonal entry
+        const int64_t lcol = lc0 + (int64_t)t * TB + lane;          // where this rank stores it
         const int64_t irow = i0 + (col - s0);                        // its lambda_i row
-        double d = A[col + col * ld];
+        double d = A[col + lcol * ld];
         const double ad = fabs(d);
         const bool isbad = !(ad <= 1.0e308);
         const bool iszero = ad <= pivtol_rel * ad;                   // the tile-local column maximum is |d| itself
@@ -390,18 +391,18 @@ __global__ __launch_bounds__(256) void k_s_panel(
         #pragma unroll 8
         for (int r = 0; r < TB; ++r) {
             Xi[lane * TB + r] = (r == lane) ? x : 0.0;
-            Tt[lane * TB + r] = (r == lane) ? A[col + col * ld] : 0.0;
+            Tt[lane * TB + r] = (r == lane) ? A[col + lcol * ld] : 0.0;
         }
         if (lane == 0) Tflag[t] = flagged ? 1.0 : 0.0;
         // L(lambda_i row, this column) = S X with S = -1, refined like k_panel_scale refines a flagged tile
-        const double sv = A[irow + col * ld];                       // -1 (pyipm.py:838-842)
+        const double sv = A[irow + lcol * ld];                      // -1 (pyipm.py:838-842)
         double l = fma(x, sv, 0.0);
         if (flagged)
             for (int it = 0; it < nref; ++it) {
-                const double r = fma(-A[col + col * ld], l, sv);
+                const double r = fma(-A[col + lcol * ld], l, sv);
                 l = fma(x, r, l);
             }
-        A[irow + col * ld] = l;                                     // (its Schur update: k_s_schur, on the update stream)
+        A[irow + lcol * ld] = l;                                    // (its Schur update: k_s_schur, on the update stream)
         gmax = fmax(gmax, fabs(l));
     }
     gmax = wave_max(gmax);
@@ -432,6 +433,36 @@ __global__ __launch_bounds__(256) void k_s_schur(double* __restrict__ A, int64_t
     const int64_t col = c0 + k, irow = i0 + (col - s0);
     if (irow < tc0 || irow >= tc1) return;
     A[irow + irow * ld] = fma(A[irow + col * ld], 1.0, A[irow + irow * ld]);
+}
+
+// Same update when the source columns live on another rank (or no group schedule exists): the one non-zero of
+// L is recomputed from the staged s / lambda_i exactly as k_s_panel computes it (d is the assembled
+// lambda_i/(s+eps), pyipm.py:498), so no message is needed for a slack-block panel at all.  One wave per
+// source tile; a rank touches the diagonal entries of the lambda_i columns it owns inside global panels
+// [tp0, tp1).
+__global__ __launch_bounds__(64) void k_s_schur_sigma(
+    double* __restrict__ A, int64_t ld, int64_t c0, int64_t s0, int64_t i0,
+    const double* __restrict__ s, const double* __restrict__ lda_i, double eps,
+    double refine_cond, int nref, double pivtol_rel, int nb, int world, int rank, int64_t tp0, int64_t tp1)
+{
+    const int lane = threadIdx.x;
+    const int64_t col = c0 + (int64_t)blockIdx.x * TB + lane, b = col - s0;
+    const double d0 = lda_i[b] / (s[b] + eps);
+    double d = d0;
+    const double ad = fabs(d), tiny = 2.2250738585072014e-308;
+    const bool iszero = ad <= pivtol_rel * ad;
+    if (iszero) d = (d >= 0.0) ? tiny : -tiny;
+    const double x = 1.0 / d;
+    const double tmin = -wave_max(iszero ? -1.0e308 : -ad), tmax = wave_max(iszero ? 0.0 : ad);
+    const bool flagged = __popcll(__ballot(iszero)) == 0 && !(tmax <= refine_cond * tmin);
+    const double sv = -1.0;
+    double l = fma(x, sv, 0.0);
+    if (flagged)
+        for (int it = 0; it < nref; ++it) { const double r = fma(-d0, l, sv); l = fma(x, r, l); }
+    const int64_t irow = i0 + b, q = irow / nb;
+    if (q < tp0 || q >= tp1 || (int)(q % world) != rank) return;
+    const int64_t lcol = (q / world) * (int64_t)nb + (irow - q * nb);
+    A[irow + lcol * ld] = fma(l, 1.0, A[irow + lcol * ld]);
 }
 
 // ---------------------------------------------------------------------------------------------

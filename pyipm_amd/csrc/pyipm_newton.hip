@@ -274,6 +274,15 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     return 0;
 }
 
+// Per-panel mode (no group schedule: the multi-rank driver): a panel inside the slack block needs no tile chain,
+// no message and no update launch (k_s_panel / k_s_schur_sigma).
+bool panel_in_s(const Ctx* ctx, int64_t p) {
+    const Geo& g = ctx->g;
+    if (!ctx->s_fast || !ctx->skip_zeros || g.mi == 0 || !ctx->grp_of.empty() || ctx->cond_active) return false;
+    const int64_t c0 = g.panel_c0(p);
+    return c0 >= g.n && c0 + g.panel_w(p) <= g.n + g.mi;
+}
+
 // Factor panel p on `stream`.  apply_pending: first apply the earlier panels of p's group to p's columns
 // (grouped single-rank driver; their bulk update is deferred to the end of the group).
 int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = false) {
@@ -283,9 +292,9 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
     const int nbw = (int)g.panel_w(p);
     const int nt = nbw / TB;
     const int64_t lp = p / g.world;
-    if ((size_t)p < ctx->grp_of.size() && !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)ctx->grp_of[p]]) {
-        // the whole group lies inside the slack block: closed form, no W, no updates (see k_s_panel)
-        hipLaunchKernelGGL(k_s_panel, dim3(1), dim3(256), 0, stream, ctx->A, g.Npad, c0, nt,
+    if (((size_t)p < ctx->grp_of.size() && !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)ctx->grp_of[p]]) || panel_in_s(ctx, p)) {
+        // the whole group (or, per-panel mode, the panel) lies inside the slack block: closed form, no W, no updates
+        hipLaunchKernelGGL(k_s_panel, dim3(1), dim3(256), 0, stream, ctx->A, g.Npad, c0, lc0, nt,
                            ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB), ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB),
                            ctx->Tflag + c0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats,
                            g.n, g.n + g.mi + g.me, ctx->pivtol_rel);
@@ -358,6 +367,15 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
         const int64_t tc0 = g.panel_c0(tq0), tc1 = tq1 >= g.npanels ? g.Npad : g.panel_c0(tq1);
         hipLaunchKernelGGL(k_s_schur, grid1(K), dim3(256), 0, stream, ctx->A, g.Npad, g.panel_c0(p0), (int64_t)K,
                            g.n, g.n + g.mi + g.me, tc0, tc1);
+        PYIPM_KCHECK();
+        return 0;
+    }
+    if (np == 1 && panel_in_s(ctx, p0)) {
+        // per-panel mode, slack-block source panel: every rank updates the diagonal entries it owns, from s / lambda
+        const int64_t tp0 = first_lp * g.world + g.rank, tp1 = (first_lp + n_lp - 1) * g.world + g.rank + 1;
+        hipLaunchKernelGGL(k_s_schur_sigma, dim3((unsigned)(K / TB)), dim3(64), 0, stream, ctx->A, g.Npad, g.panel_c0(p0),
+                           g.n, g.n + g.mi + g.me, ctx->s, ctx->lda + g.me, ctx->eps, ctx->refine_cond, ctx->block_refine,
+                           ctx->pivtol_rel, g.nb, g.world, g.rank, tp0, tp1);
         PYIPM_KCHECK();
         return 0;
     }
@@ -1252,6 +1270,7 @@ size_t pyipm_newton_panel_msg_bytes(pyipm_newton_ctx* h, int64_t p) {
     if (check_ctx(h)) return 0;
     const Geo& g = C(h)->g;
     if (p < 0 || p >= g.npanels) return 0;
+    if (panel_in_s(C(h), p)) return 0;                    // slack-block panel: every rank derives what it needs locally
     const int64_t nbw = g.panel_w(p), m = g.Npad - (g.panel_c0(p) + nbw);
     return (size_t)(m * nbw + 2 * (nbw / TB) * TB * TB + nbw / TB) * sizeof(double);
 }

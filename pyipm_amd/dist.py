@@ -95,7 +95,7 @@ class DistNewton(object):
             below = self.Npad - c1
             if own:
                 core.factor_panel(p)
-            if self.world > 1 and below > 0:
+            if self.world > 1 and below > 0 and numel > 0:       # numel == 0: nothing to send (slack-block panel)
                 buf = self._msgbuf(numel)
                 if own:
                     core.panel_pack(p, buf)
@@ -122,7 +122,7 @@ class DistNewton(object):
             own = self.owner(p) == self.rank
             if own:
                 core.factor_panel(p)
-            if self.Npad - c1 <= 0:
+            if self.Npad - c1 <= 0 or core.panel_msg_numel(p) == 0:   # last panel / slack-block panel: no message
                 return None, None
             buf = bufs[p & 1][: core.panel_msg_numel(p)]
             if own:
@@ -159,7 +159,7 @@ class DistNewton(object):
                 break
             if work is not None:
                 work.wait()                                   # current stream waits for the message
-            if self.owner(p) != self.rank:
+            if self.owner(p) != self.rank and buf is not None:
                 core.panel_unpack(p, buf)
             nxt = p + 1
             if nxt < np_:

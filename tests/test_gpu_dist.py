@@ -40,7 +40,7 @@ def _worker(rank, world, port, shape, nb, lookahead, out):
         drv.lookahead = lookahead
         dz, st = drv.step(0.0, 0.0)
         torch.cuda.synchronize()
-        out[rank] = (dz.cpu().numpy(), st, core.ncols_local)
+        out[rank] = (dz.cpu().numpy(), st, core.ncols_local, drv.bytes_broadcast)
     finally:
         dist.destroy_process_group()
 
@@ -60,12 +60,25 @@ def test_two_ranks_one_gpu(world, shape, nb, lookahead):
                                    qp["mu"], n, me, mi, regularise=False)
     cols = 0
     for r in range(world):
-        dz, st, ncl = out[r]
+        dz, st, ncl, _ = out[r]
         assert np.linalg.norm(dz - ref) / np.linalg.norm(ref) <= 1e-10
         assert st["n_neg"] == me + mi and st["n_zero"] == 0 and st["n_pos"] == N - me - mi
         cols += ncl
     assert cols == ((N + 127) // 128) * 128
     assert np.array_equal(out[0][0], out[1][0])          # every rank ends with the same direction, bit for bit
+    # wire traffic of the factorisation: one message per panel that has rows below it, EXCEPT panels inside the slack
+    # block (every rank derives their contribution from s / lambda locally); the substitutions add 8 bytes per entry
+    Npad = ((N + 127) // 128) * 128
+    fact = 0
+    for p in range(Npad // nb + (1 if Npad % nb else 0)):
+        c0 = p * nb
+        w = min(nb, Npad - c0)
+        m = Npad - (c0 + w)
+        in_s = c0 >= n and c0 + w <= n + mi
+        if m > 0 and not in_s:
+            fact += 8 * (m * w + 2 * (w // 64) * 4096 + w // 64)
+    solve = 8 * sum((Npad - p * nb) + min(nb, Npad - p * nb) for p in range((Npad + nb - 1) // nb))
+    assert out[0][3] == fact + solve
 
 
 def test_dist_driver_world1_matches_fused_step():
