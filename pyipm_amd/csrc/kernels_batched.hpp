@@ -78,6 +78,17 @@ __global__ __launch_bounds__(256) void k_b_residual(BatchPtrs bp, Geo g, double 
     }
 }
 
+// Can rows [lo, hi) hold a non-zero of the L / W operand whose source columns are [slo, shi)?  The block pattern
+// of pyipm.py:824-842 (same argument as active_ranges in pyipm_newton.hip): x-block sources never reach the
+// slack rows, slack-block sources only their own lambda_i rows.  Conservative at tile granularity.
+__device__ __forceinline__ bool rows_active(const Geo& g, int64_t slo, int64_t shi, int64_t lo, int64_t hi) {
+    if (g.mi == 0) return true;
+    const int64_t s0 = g.n, s1 = g.n + g.mi, i0 = g.n + g.mi + g.me;
+    if (shi <= s0) return !(lo >= s0 && hi <= s1);
+    if (slo >= s0 && shi <= s1) return hi > i0 + (slo - s0) && lo < i0 + (shi - s0);
+    return true;
+}
+
 // Factor one problem per workgroup.  grid B, 256 threads.
 __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double refine_cond, int nref, double pivtol_rel)
 {
@@ -116,6 +127,12 @@ __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double re
                             for (int m = 0; m < 4; ++m) acc[q][cb][m] = A[(ib + q * TB) + (j0 + cb * 16 + l4 + 4 * m) * ld];
                     }
                 for (int u = 0; u < t; ++u) {
+                    // structural zeros (block-uniform): W(t,u) = 0, or every L(r,u) of this pass = 0
+                    if (!rows_active(g, (int64_t)u * TB, (int64_t)(u + 1) * TB, j0, j0 + TB)) continue;
+                    bool any = false;
+                    for (int q = 0; q < nq; ++q)
+                        any = any || rows_active(g, (int64_t)u * TB, (int64_t)(u + 1) * TB, (int64_t)(r0 + q) * TB, (int64_t)(r0 + q + 1) * TB);
+                    if (!any) continue;
                     double b[16];
                     #pragma unroll
                     for (int ks = 0; ks < 16; ++ks) b[ks] = A[ib + ((int64_t)u * TB + ks * 4 + l4) * ld];   // L(r0,u)
@@ -168,6 +185,7 @@ __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double re
             for (int e = tid; e < TB * TB; e += 256) X[e >> 6][e & 63] = Xi[e];
             __syncthreads();
             for (int r = t + 1; r < nt; ++r) {
+                if (!rows_active(g, j0, j0 + TB, (int64_t)r * TB, (int64_t)(r + 1) * TB)) continue;   // S(r,t) = 0 = L(r,t)
                 const int64_t i = (int64_t)r * TB + wave * 16 + l15;
                 double b[16];
                 #pragma unroll
