@@ -18,7 +18,7 @@ from .newton import ERRORS, MEM_DEVICE, FactorStats, NewtonError, load_library
 
 class BatchedNewton(object):
     def __init__(self, n, me, mi, batch=None, device=None, workers=None, nb=None, refine=0):
-        """``workers`` / ``nb`` are accepted for compatibility with the first (thread-pool) version and ignored."""
+        """``workers`` / ``nb`` are accepted and ignored (an earlier version drove one handle per host thread)."""
         import torch
         if refine:
             raise NotImplementedError("iterative refinement is not part of the batched path")
