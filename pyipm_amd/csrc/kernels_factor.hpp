@@ -55,6 +55,8 @@ struct TileScratch {
     double stage[TB][TB + 1];
     double colbuf[2][2][TB];     // [parity][0: column p, 1: column r][row]  (column == row by symmetry)
     double sh_red[4];
+    double pcol[16][TB];         // block steps: the 16 pre-sweep pivot columns one wave publishes for the others
+    int pcnt;                    // ... how many are out so far (polled), -1-n once it stopped after n (general path next)
 };
 
 // The sweep inversion itself; called by k_tile_invert (one tile of the big factorisation) and by the
@@ -118,12 +120,92 @@ __device__ __forceinline__ void tile_invert_dev(
         (dst_)[lane] = row[__builtin_amdgcn_readfirstlane((col_) & 15)];                     \
     }
 
+    // One symmetric sweep on the 1x1 pivot pv_ whose (pre-sweep) column is cpi_ (this lane's entry), cpj_ (the
+    // entries at this wave's 16 rows) and dpp_ (the diagonal).  Textually shared by both phases below.
+#define PYIPM_SWEEP1(pv_, cpi_, cpj_, dpp_)                                                              \
+    {                                                                                                    \
+        double d = (dpp_);                                                                               \
+        const double ad = fabs(d);                                                                       \
+        const double pivtol = pivtol_rel * readlane_f64(cmax0, (pv_));                                   \
+        if (__builtin_expect(!(ad <= 1.0e308), 0)) bad = 1;          /* NaN or Inf */                    \
+        if (__builtin_expect(ad <= pivtol, 0)) {                                                         \
+            if ((pv_) < nreal) zero++;                                                                   \
+            const double t = pivtol > 0.0 ? pivtol : tiny;                                               \
+            d = (d >= 0.0) ? t : -t;                                                                     \
+        } else if ((pv_) < nreal) {                                                                      \
+            neg += (d < 0.0) ? 1 : 0;                                                                    \
+            dmin = fmin(dmin, ad); dmax = fmax(dmax, ad);                                                \
+        }                                                                                                \
+        const double inv_d = 1.0 / d;                                                                    \
+        const double lpi = (cpi_) * inv_d;                                                               \
+        if (lane == (pv_)) {                                     /* one lane: row p <- cp/d */            \
+            _Pragma("unroll") for (int c = 0; c < 16; ++c) row[c] = (cpj_)[c] * inv_d;                   \
+        } else {                                                                                         \
+            _Pragma("unroll") for (int c = 0; c < 16; ++c) row[c] = fma(-lpi, (cpj_)[c], row[c]);        \
+        }                                                                                                \
+        if (wave == ((pv_) >> 4))                                /* wave-uniform: column p <- lp, pivot <- -1/d */ \
+            row[__builtin_amdgcn_readfirstlane((pv_) & 15)] = (lane == (pv_)) ? -inv_d : lpi;            \
+        mask &= ~(1ull << (pv_));                                                                        \
+        left -= 1;                                                                                       \
+    }
+
+    // ---- block steps --------------------------------------------------------------------------------------
+    // As long as Bunch-Kaufman accepts the diagonal pivots in their natural order (every definite tile; most
+    // others), a sweep only needs the pivot's own column.  The wave that holds columns [16k, 16k+16) therefore
+    // runs those 16 sweeps on ITS columns with no barrier, publishing each pre-sweep column as it goes; the other
+    // waves poll the count and replay each sweep on their columns right behind it.  Same operations on every
+    // entry in the same order as the general loop below (bitwise the same inverse) with one barrier per 16
+    // pivots instead of one per pivot.  The first pivot that fails the acceptance test ends this phase; the
+    // general loop takes over from exactly that state.
+    // (the count goes through explicit LDS instructions: a volatile access through the scratch reference would be
+    //  compiled to a flat store + vmcnt wait per pivot)
+    const unsigned pcnt_lds = (unsigned)(size_t)&sm.pcnt;
+    auto pcnt_store = [&](int v) { asm volatile("ds_write_b32 %0, %1" :: "v"(pcnt_lds), "v"(v) : "memory"); };
+    auto pcnt_load = [&]() { int v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pcnt_lds) : "memory");
+                             return __builtin_amdgcn_readfirstlane(v); };
+    for (int k = 0; k < 4 && left > 0; ++k) {
+        if (tid == 0) sm.pcnt = 0;
+        __syncthreads();
+        int n = 16;
+        if (wave == k) {
+            for (int j = 0; j < 16; ++j) {
+                const int pv = 16 * k + j;
+                const double cpi = row[j];                            // (j is wave-uniform: relative-addressed read)
+                const double dpp = readlane_f64(cpi, pv);
+                if (left > 1 && __ballot(lane > pv && fabs(cpi) * PYIPM_BK_ALPHA > fabs(dpp)) != 0ull) { n = j; break; }
+                sm.pcol[j][lane] = cpi;
+                if (lane == 0) pcnt_store(j + 1);                     // LDS keeps a wave's stores in order
+                double cpj[16];                                       // own rows of the column: read back (8 wide reads
+                #pragma unroll                                        // beat 32 readlanes)
+                for (int c = 0; c < 16; ++c) cpj[c] = sm.pcol[j][cb + c];
+                PYIPM_SWEEP1(pv, cpi, cpj, dpp)
+            }
+            if (n < 16 && lane == 0) pcnt_store(-1 - n);
+        } else {
+            for (int j = 0; j < 16; ++j) {
+                int c;
+                while ((c = pcnt_load()) >= 0 && c <= j) __builtin_amdgcn_s_sleep(1);
+                if (c < 0 && -1 - c <= j) { n = -1 - c; break; }
+                const int pv = 16 * k + j;
+                const double* rp = sm.pcol[j];
+                const double cpi = rp[lane];
+                double cpj[16];
+                #pragma unroll
+                for (int cc = 0; cc < 16; ++cc) cpj[cc] = rp[cb + cc];
+                const double dpp = readlane_f64(cpi, pv);
+                PYIPM_SWEEP1(pv, cpi, cpj, dpp)
+            }
+        }
+        __syncthreads();                                              // everyone is done with pcol
+        if (n < 16) break;                                            // (uniform: every wave saw the same stop count)
+    }
+
     // Loop invariant: the BK candidate column p (first unswept index) has been published into
     // colbuf[parity][0] by the previous iteration (or the prologue), so an iteration starts at the barrier.
-    int p = 0, sel = 0;
+    int p = left > 0 ? __ffsll(mask) - 1 : 0, sel = 0;
     bool forced = false;                    // pivot already decided (the off-diagonal candidate r): its column
                                             // sits in colbuf[parity][1], already synchronised
-    PYIPM_PUBLISH(p, colbuf[0][0])
+    if (left > 0) { PYIPM_PUBLISH(p, colbuf[0][0]) }
     while (left > 0) {
         if (!forced) __syncthreads();
         const double* rp = colbuf[parity][sel];
@@ -155,31 +237,7 @@ __device__ __forceinline__ void tile_invert_dev(
             }
         }
         if (kind == 1) {
-            double d = dpp;
-            const double ad = fabs(d);
-            const double pivtol = pivtol_rel * readlane_f64(cmax0, p);
-            if (__builtin_expect(!(ad <= 1.0e308), 0)) bad = 1;          // NaN or Inf
-            if (__builtin_expect(ad <= pivtol, 0)) {
-                if (p < nreal) zero++;
-                const double t = pivtol > 0.0 ? pivtol : tiny;
-                d = (d >= 0.0) ? t : -t;
-            } else if (p < nreal) {
-                neg += (d < 0.0) ? 1 : 0;
-                dmin = fmin(dmin, ad); dmax = fmax(dmax, ad);
-            }
-            const double inv_d = 1.0 / d;
-            const double lpi = cpi * inv_d;
-            if (lane == p) {                                     // one lane: row p <- cp/d
-                #pragma unroll
-                for (int c = 0; c < 16; ++c) row[c] = cpj[c] * inv_d;
-            } else {
-                #pragma unroll
-                for (int c = 0; c < 16; ++c) row[c] = fma(-lpi, cpj[c], row[c]);
-            }
-            if (wave == (p >> 4))                                // wave-uniform: column p <- lp, pivot <- -1/d
-                row[__builtin_amdgcn_readfirstlane(p & 15)] = (lane == p) ? -inv_d : lpi;
-            mask &= ~(1ull << p);
-            left -= 1;
+            PYIPM_SWEEP1(p, cpi, cpj, dpp)
         } else {
             const double* rq = colbuf[parity][1];
             const double a = rp[p], b = rp[q], cc = rq[q];
@@ -221,6 +279,7 @@ __device__ __forceinline__ void tile_invert_dev(
     }
 
 #undef PYIPM_PUBLISH
+#undef PYIPM_SWEEP1
     #pragma unroll
     for (int c = 0; c < 16; ++c) Tinv[(cb + c) * TB + lane] = -row[c];
     if (dbg && tid == 0) { dbg[0] = clock64() - dbg_c0; dbg[1] = wall_clock64() - dbg_w0; dbg[2] += 1; }
