@@ -53,7 +53,7 @@ typedef struct pyipm_newton_ctx pyipm_newton_ctx;   /* opaque handle */
  * (reghess, pyipm.py:1378-1381, 1399): inertia from the signs of the block pivots. */
 typedef struct pyipm_factor_stats {
     int64_t n_neg;     /* negative pivots  (must equal me+mi for correct inertia, pyipm.py:1381) */
-    int64_t n_zero;    /* rejected pivots, |d| <= pivtol * max|tile|  (singular direction)        */
+    int64_t n_zero;    /* rejected pivots, |d| <= pivtol_rel * max|its tile column| (singular direction)  */
     int64_t n_2x2;     /* 2x2 Bunch-Kaufman pivots taken inside tiles                              */
     int64_t n_pos;     /* positive pivots among the N real rows                                     */
     double  d_min;     /* min |pivot| over accepted real pivots                                     */
