@@ -283,6 +283,18 @@ bool panel_in_s(const Ctx* ctx, int64_t p) {
     return c0 >= g.n && c0 + g.panel_w(p) <= g.n + g.mi;
 }
 
+// Per-panel mode: rows [h0, h1) of a panel that lies inside the x block are whole 128-row tiles of slack rows --
+// exact zeros that no update launch with these source columns ever reads (active_ranges).  The owner's chain
+// kernels skip them and the panel message leaves them out.  Empty range when nothing can be skipped.
+void panel_hole(const Ctx* ctx, int64_t p, int64_t* h0, int64_t* h1) {
+    const Geo& g = ctx->g;
+    *h0 = 0; *h1 = 0;
+    if (!ctx->skip_zeros || g.mi == 0 || !ctx->grp_of.empty() || ctx->cond_active) return;
+    if (g.panel_c0(p) + g.panel_w(p) > g.n) return;
+    const int64_t a = (g.n + BM - 1) / BM * BM, b = (g.n + g.mi) / BM * BM;
+    if (b > a) { *h0 = a; *h1 = b; }
+}
+
 // Factor panel p on `stream`.  apply_pending: first apply the earlier panels of p's group to p's columns
 // (grouped single-rank driver; their bulk update is deferred to the end of the group).
 int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = false) {
@@ -319,6 +331,9 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
         active_ranges(ctx, c0, c0 + nbw, &ha0, &ha1, &hb0, &hb1);
         hole0 = (g.n + BM - 1) / BM * BM; hole1 = (g.n + g.mi) / BM * BM;
         if (hole1 < hole0) hole1 = hole0;
+    } else {
+        panel_hole(ctx, p, &hole0, &hole1);             // per-panel mode (any number of ranks)
+        if (hole1 > hole0) active_ranges(ctx, c0, c0 + nbw, &ha0, &ha1, &hb0, &hb1);
     }
     for (int t = 0; t < nt; ++t) {
         const int64_t j0 = c0 + (int64_t)t * TB, lcol = lc0 + (int64_t)t * TB;
@@ -1271,7 +1286,9 @@ size_t pyipm_newton_panel_msg_bytes(pyipm_newton_ctx* h, int64_t p) {
     const Geo& g = C(h)->g;
     if (p < 0 || p >= g.npanels) return 0;
     if (panel_in_s(C(h), p)) return 0;                    // slack-block panel: every rank derives what it needs locally
-    const int64_t nbw = g.panel_w(p), m = g.Npad - (g.panel_c0(p) + nbw);
+    int64_t h0, h1;
+    panel_hole(C(h), p, &h0, &h1);
+    const int64_t nbw = g.panel_w(p), m = g.Npad - (g.panel_c0(p) + nbw) - (h1 - h0);    // slack rows of an x panel stay home
     return (size_t)(m * nbw + 2 * (nbw / TB) * TB * TB + nbw / TB) * sizeof(double);
 }
 
@@ -1281,10 +1298,17 @@ int pyipm_newton_panel_pack(pyipm_newton_ctx* h, int64_t p, double* buf) {
     if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     if (p < 0 || p >= g.npanels || g.owner(p) != g.rank) { ctx->err = "panel_pack: not the owner"; return PYIPM_E_BADARG; }
-    const int64_t nbw = g.panel_w(p), c1 = g.panel_c0(p) + nbw, m = g.Npad - c1;
-    if (m > 0)
+    int64_t h0, h1;
+    panel_hole(ctx, p, &h0, &h1);
+    const int64_t nbw = g.panel_w(p), c1 = g.panel_c0(p) + nbw, m = g.Npad - c1 - (h1 - h0);
+    // rows [c1, Npad) without [h0, h1): one or two strided copies into a message of leading dimension m
+    const int64_t seg0 = (h1 > h0) ? h0 - c1 : g.Npad - c1, seg1 = (h1 > h0) ? g.Npad - h1 : 0;
+    if (seg0 > 0)
         PYIPM_HIP(hipMemcpy2DAsync(buf, (size_t)m * sizeof(double), wbuf(ctx, p) + c1, (size_t)g.Npad * sizeof(double),
-                                   (size_t)m * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
+                                   (size_t)seg0 * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
+    if (seg1 > 0)
+        PYIPM_HIP(hipMemcpy2DAsync(buf + seg0, (size_t)m * sizeof(double), wbuf(ctx, p) + h1, (size_t)g.Npad * sizeof(double),
+                                   (size_t)seg1 * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
     const size_t tbytes = (size_t)(nbw / TB) * TB * TB * sizeof(double);
     PYIPM_HIP(hipMemcpyAsync(buf + m * nbw, ctx->Dinv + (g.panel_c0(p) / TB) * (int64_t)(TB * TB), tbytes,
                              hipMemcpyDeviceToDevice, ctx->stream));
@@ -1301,7 +1325,10 @@ int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf)
     if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     if (p < 0 || p >= g.npanels || g.owner(p) == g.rank) { ctx->err = "panel_unpack: owner does not unpack"; return PYIPM_E_BADARG; }
-    const int64_t nbw = g.panel_w(p), c0 = g.panel_c0(p), c1 = c0 + nbw, m = g.Npad - c1;
+    int64_t h0, h1;
+    panel_hole(ctx, p, &h0, &h1);
+    const int64_t nbw = g.panel_w(p), c0 = g.panel_c0(p), c1 = c0 + nbw, m = g.Npad - c1 - (h1 - h0);
+    const int64_t seg0 = (h1 > h0) ? h0 - c1 : g.Npad - c1, seg1 = (h1 > h0) ? g.Npad - h1 : 0;
     double* dinv = ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB);
     double* tsv = ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB);
     const size_t tbytes = (size_t)(nbw / TB) * TB * TB * sizeof(double);
@@ -1310,14 +1337,18 @@ int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf)
     PYIPM_HIP(hipMemcpyAsync(ctx->Tflag + c0 / TB, buf + m * nbw + 2 * (nbw / TB) * TB * TB,
                              (size_t)(nbw / TB) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     if (m > 0) {
-        PYIPM_HIP(hipMemcpy2DAsync(wbuf(ctx, p) + c1, (size_t)g.Npad * sizeof(double), buf, (size_t)m * sizeof(double),
-                                   (size_t)m * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
-        // rebuild the block column L = W * inv(T) tile by tile into Lbuf
+        if (seg0 > 0)
+            PYIPM_HIP(hipMemcpy2DAsync(wbuf(ctx, p) + c1, (size_t)g.Npad * sizeof(double), buf, (size_t)m * sizeof(double),
+                                       (size_t)seg0 * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
+        if (seg1 > 0)
+            PYIPM_HIP(hipMemcpy2DAsync(wbuf(ctx, p) + h1, (size_t)g.Npad * sizeof(double), buf + seg0, (size_t)m * sizeof(double),
+                                       (size_t)seg1 * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
+        // rebuild the block column L = W * inv(T) tile by tile into Lbuf (rows of the hole: never read, skipped)
         for (int t = 0; t < nbw / TB; ++t) {
-            hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(m / TB)), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)((g.Npad - c1) / TB)), dim3(256), 0, ctx->stream,
                                ctx->Lbuf, g.Npad, (int64_t)t * TB, wbuf(ctx, p), g.Npad, (int64_t)t * TB,
                                (double*)nullptr, (int64_t)0, (int64_t)0, dinv + (int64_t)t * TB * TB,
-                               tsv + (int64_t)t * TB * TB, ctx->Tflag + c0 / TB + t, ctx->block_refine, c1, (int64_t)0, (int64_t)0,
+                               tsv + (int64_t)t * TB * TB, ctx->Tflag + c0 / TB + t, ctx->block_refine, c1, h0, h1,
                                (unsigned long long*)nullptr, -1.0);
             PYIPM_KCHECK();
         }

@@ -75,6 +75,8 @@ def test_two_ranks_one_gpu(world, shape, nb, lookahead):
         w = min(nb, Npad - c0)
         m = Npad - (c0 + w)
         in_s = c0 >= n and c0 + w <= n + mi
+        if c0 + w <= n and mi:                               # panel inside the x block: whole 128-row tiles of slack rows stay home
+            m -= max(0, (n + mi) // 128 * 128 - (n + 127) // 128 * 128)
         if m > 0 and not in_s:
             fact += 8 * (m * w + 2 * (w // 64) * 4096 + w // 64)
     solve = 8 * sum((Npad - p * nb) + min(nb, Npad - p * nb) for p in range((Npad + nb - 1) // nb))
