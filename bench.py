@@ -275,6 +275,23 @@ def main():
             out["hbm_bound_kernels"].pop("assemble_K1", None)
         else:
             out["config"]["kkt_form"] = "full 4-block system of the reference (pyipm.py:816-844)"
+        if world == 1 and not use_dist and not condensed and not any(kv.startswith("skip_zeros") for kv in args.opt):
+            # transparency: the same step with the structural-zero skipping switched off (all-dense factorisation,
+            # bitwise the same direction); not part of `value`
+            core.set_option("skip_zeros", 0)
+            core.step(0.0, 0.0)
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            for _ in range(2):
+                dzd, _std = core.step(0.0, 0.0)
+            torch.cuda.synchronize()
+            td = (time.perf_counter() - td) / 2
+            core.set_option("skip_zeros", 1)
+            dz1, _ = core.step(0.0, 0.0)
+            out["all_dense_factorisation"] = {"value": 1.0 / td, "unit": "steps/s", "ms_per_step": 1e3 * td,
+                                              "same_direction_bitwise": bool(torch.equal(dzd, dz1)),
+                                              "note": "skip_zeros=0: every tile of the dense N^3/3 is computed; "
+                                                      "`value` skips tiles the KKT block pattern makes exact zeros"}
         if args.check and world == 1:
             g = core.residual()
             raw = core.solve(flip=False, refine=args.refine)
