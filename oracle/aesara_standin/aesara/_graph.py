@@ -58,7 +58,26 @@ class Expr(object):
     def __neg__(self): return Expr(lambda a: -a, (self,))
 
     def __getitem__(self, idx):
-        return Expr(lambda a: a[idx], (self,))
+        # slice bounds may be lazy (``WT_g[:m_lbfgs]``, pyipm.py:1169)
+        parts = idx if isinstance(idx, tuple) else (idx,)
+        lazy = []
+        for q in parts:
+            if isinstance(q, slice):
+                lazy += [v for v in (q.start, q.stop, q.step) if isinstance(v, Expr)]
+            elif isinstance(q, Expr):
+                lazy.append(q)
+
+        def f(a, *vals):
+            if not vals:
+                return a[idx]
+            it = iter(vals)
+            pick = lambda v: int(next(it)) if isinstance(v, Expr) else v      # noqa: E731
+            out = tuple(slice(pick(q.start), pick(q.stop), pick(q.step)) if isinstance(q, slice) else pick(q)
+                        for q in parts)
+            return a[out if isinstance(idx, tuple) else out[0]]
+        sub = Expr(f, (self,) + tuple(lazy))
+        sub._index = idx
+        return sub
 
     @property
     def shape(self):
@@ -68,8 +87,19 @@ class Expr(object):
     def T(self):
         return Expr(lambda a: a.T, (self,))
 
+    @property
+    def size(self):
+        return Expr(lambda a: int(np.size(a)), (self,))
+
     def reshape(self, shp):
-        return Expr(lambda a: np.reshape(a, shp), (self,))
+        # shape entries may themselves be lazy (e.g. ``Adiag.reshape((Adiag.size,))``, pyipm.py:1103)
+        dims = tuple(shp) if isinstance(shp, (tuple, list)) else (shp,)
+        lazy = [d for d in dims if isinstance(d, Expr)]
+
+        def f(a, *vals):
+            it = iter(vals)
+            return np.reshape(a, tuple(int(next(it)) if isinstance(d, Expr) else d for d in dims))
+        return Expr(f, (self,) + tuple(lazy))
 
     def ravel(self):
         return Expr(lambda a: np.ravel(a), (self,))

@@ -8,6 +8,10 @@ def vector(name=None, **kw):
     return Variable(name, 1)
 
 
+def scalar(name=None, **kw):
+    return Variable(name, 0)
+
+
 def matrix(name=None, **kw):
     return Variable(name, 2)
 
@@ -21,8 +25,22 @@ def log(x): return _e(np.log, x)
 def abs_(x): return _e(np.abs, x)
 def dot(a, b): return _e(np.dot, a, b)
 def eye(n, *a): return _e(lambda k: np.eye(int(k)), n)
-def zeros(shape, **kw): return _e(lambda: np.zeros(shape))
-def ones(shape, **kw): return _e(lambda: np.ones(shape))
+def _shaped(ctor, shape):
+    # shape entries may be lazy (``T.zeros((self.nineq, 2 * m_lbfgs))``, pyipm.py:1082)
+    dims = tuple(shape) if isinstance(shape, (tuple, list)) else (shape,)
+    lazy = [d for d in dims if isinstance(d, Expr)]
+
+    def f(*vals):
+        it = iter(vals)
+        return ctor(tuple(int(next(it)) if isinstance(d, Expr) else d for d in dims))
+    return Expr(f, tuple(lazy))
+
+
+def zeros(shape, **kw): return _shaped(np.zeros, shape)
+def ones(shape, **kw): return _shaped(np.ones, shape)
+def min(x, axis=None): return _e(lambda a: np.min(a, axis=axis), x)          # noqa: A001
+def gt(a, b): return _e(lambda u, v: u > v, a, b)
+def le(a, b): return _e(lambda u, v: u <= v, a, b)
 def triu(x, k=0): return _e(lambda a: np.triu(a, k), x)
 def diagonal(x): return _e(np.diagonal, x)
 def max(x, axis=None): return _e(lambda a: np.max(a, axis=axis), x)          # noqa: A001
@@ -36,7 +54,7 @@ class _Sub(object):
 def _split(sub):
     # ``sub`` was produced by Expr.__getitem__: recover (parent, idx) from its closure
     parent = sub._args[0]
-    idx = sub._fn.__closure__[0].cell_contents
+    idx = sub._index
     return parent, idx
 
 

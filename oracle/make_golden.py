@@ -13,7 +13,8 @@ All nine inputs are handed over as "precompiled" Functions (the input state of
 pyipm.py:426-440 that needs no autodiff), so the reference's own NumPy KKT
 assembly (:768-814), ``reghess`` (:1373-1406), line search and loop run verbatim.
 
-    python oracle/make_golden.py            # writes tests/golden/*.npz
+    python oracle/make_golden.py            # writes tests/golden/*.npz (exact-Hessian seam)
+    python oracle/make_golden.py --lbfgs    # writes tests/golden/lbfgs_*.npz (L-BFGS seam, pyipm.py:1713)
 """
 from __future__ import annotations
 
@@ -49,7 +50,7 @@ class TracedIPM(ref.IPM):
         self.trace = []
         self._cur = None
         if self.lbfgs:
-            return
+            return                      # the L-BFGS seam is recorded by lbfgs_dir below
         hess0, solve0 = self.hess, self.sym_solve_cmp
 
         def hess(x, s, lda):
@@ -68,6 +69,15 @@ class TracedIPM(ref.IPM):
             return out
 
         self.hess, self.sym_solve_cmp = hess, solve
+
+    def lbfgs_dir(self, x, s, lda, g, zeta, S, Y, SS, L, D):
+        """Record the L-BFGS seam (pyipm.py:1713): inputs of lbfgs_dir and the RAW direction it returns."""
+        dz = ref.IPM.lbfgs_dir(self, x, s, lda, g, zeta, S, Y, SS, L, D)
+        self.trace.append({"x": np.array(x), "s": np.array(s), "lda": np.array(lda), "g": np.array(g),
+                           "zeta": float(zeta), "S": np.array(S), "Y": np.array(Y), "SS": np.array(SS),
+                           "L": np.array(L), "D": np.array(D), "mu": float(self.mu_dev.get_value()),
+                           "mu_host": float(self.mu_host), "dz_raw": np.array(dz)})
+        return dz
 
     def reghess(self, Hc):
         rec = self._cur
@@ -118,6 +128,95 @@ def pack_trace(p):
         d["it_" + k] = np.array([t[k] for t in p.trace])
     d["it_dz"] = np.stack([flipped(t["dz_raw"], n, mi, me) for t in p.trace]) if p.trace else np.zeros((0,))
     return d
+
+
+def pack_lbfgs_trace(p, memory):
+    """Variable-size storage zero-padded to memory+1 pairs (the reference lets it grow that far, :1300)."""
+    n, cap = p.nvar, memory + 1
+    d = {"n_iter": np.int64(len(p.trace)), "it_m": np.array([t["S"].shape[1] for t in p.trace], dtype=np.int64)}
+    for k in ("x", "s", "lda", "g", "dz_raw"):
+        d["it_" + k] = np.stack([t[k] for t in p.trace])
+    for k in ("zeta", "mu", "mu_host"):
+        d["it_" + k] = np.array([t[k] for t in p.trace])
+    for k in ("S", "Y"):
+        d["it_" + k] = np.stack([np.pad(t[k], ((0, 0), (0, cap - t[k].shape[1]))) for t in p.trace])
+    for k in ("SS", "L", "D"):
+        d["it_" + k] = np.stack([np.pad(t[k], ((0, cap - t[k].shape[0]), (0, cap - t[k].shape[1]))) for t in p.trace])
+    return d
+
+
+def run_example_lbfgs(k, x0, memory, **kw):
+    prob = dict(example_problem(k))
+    for key in ("d2f", "d2ce", "d2ci"):
+        prob[key] = None                                  # L-BFGS takes no second derivatives (:478-562)
+    p = build(prob, x0, lbfgs=memory, **kw)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf), np.errstate(all="ignore"):
+        x, s, lda, fval, kkt = p.solve()
+    d = pack_lbfgs_trace(p, memory)
+    d.update(problem=np.int64(k), x0=np.array(x0), x=x, s=s, lda=lda, fval=np.float64(fval),
+             signal=np.int64(p.signal), nvar=np.int64(p.nvar), neq=np.int64(p.neq), nineq=np.int64(p.nineq),
+             memory=np.int64(memory), transcript=np.array(buf.getvalue()))
+    return d, p
+
+
+def lbfgs_direction_fixture(n, me, mi, m, seed, rank_deficient=False):
+    """One call of the reference's lbfgs_dir on QP-shaped data with a storage built by the reference's own
+    lbfgs_update from random displacement pairs of positive curvature."""
+    rng = np.random.default_rng(seed)
+    qp = make_qp(n, me, mi, seed)
+    if rank_deficient and me >= 2:
+        qp["Je"][:, me - 1] = qp["Je"][:, 0]              # duplicated equality gradient -> rcond = 0 (:1108-1113)
+    Je, Ji = qp["Je"], qp["Ji"]
+    prob = {"nvar": n, "neq": me, "nineq": mi, "f": lambda x: 0.0, "df": lambda x: np.zeros(n), "d2f": None,
+            "ce": (lambda x: np.zeros(me)) if me else None, "dce": (lambda x: Je) if me else None, "d2ce": None,
+            "ci": (lambda x: np.ones(mi)) if mi else None, "dci": (lambda x: Ji) if mi else None, "d2ci": None}
+    p = build(prob, np.zeros(n), lbfgs=max(m, 1), verbosity=-1)
+    p.nvar = n
+    p.compile()
+    p.mu_host = 0.2
+    p.mu_dev.set_value(np.float64(0.2))
+    zeta, S, Y, SS, L, D, fail = p.lbfgs_init()
+    Mq = rng.standard_normal((n, n)) / np.sqrt(n)
+    Qh = Mq @ Mq.T + 0.5 * np.eye(n)                     # curvature model: dg = Qh dx  => dx'dg > 0
+    pad = n + 2 * mi + me - n
+    x_old = rng.standard_normal(n)
+    for _ in range(m):
+        x_new = x_old + rng.standard_normal(n) / np.sqrt(n)
+        g_old = np.concatenate([-(Qh @ x_old), np.zeros(pad)])
+        g_new = np.concatenate([-(Qh @ x_new), np.zeros(pad)])
+        zeta, S, Y, SS, L, D, fail = p.lbfgs_update(x_old, x_new, g_old, g_new, zeta, S, Y, SS, L, D, fail)
+        x_old = x_new
+    g = rng.standard_normal(n + 2 * mi + me)
+    s = qp["s"] if mi else np.array([])
+    lda = qp["lam"] if (me or mi) else np.array([])
+    dz = p.lbfgs_dir(np.zeros(n), s, lda, g, zeta, S, Y, SS, L, D)
+    out = {"n": np.int64(n), "me": np.int64(me), "mi": np.int64(mi), "m": np.int64(S.shape[1]), "seed": np.int64(seed),
+           "g": g, "s": s, "lda": lda, "zeta": np.float64(zeta), "S": S, "Y": Y, "SS": SS, "L": L, "D": D,
+           "mu": np.float64(0.2), "eta": np.float64(p.eta), "beta": np.float64(p.beta),
+           "reg_coef": np.float64(p.reg_coef), "dz_raw": np.array(dz),
+           "rank_deficient": np.int64(bool(rank_deficient and me >= 2))}
+    if me:
+        out["Je"] = Je
+    if mi:
+        out["Ji"] = Ji
+    return out
+
+
+def main_lbfgs():
+    """tests/golden/lbfgs_*.npz."""
+    os.makedirs(GOLD, exist_ok=True)
+    x0s = unit_test_x0()
+    for k in range(1, 11):                                # unit-test setting: lbfgs=4, Ftol=1e-8 (unit_tests.py:49-50)
+        d, p = run_example_lbfgs(k, x0s[k], 4, Ftol=1.0e-8, verbosity=-1)
+        np.savez_compressed(os.path.join(GOLD, "lbfgs_trace_p%02d.npz" % k), **d)
+        print("lbfgs p%-2d iters=%-3d signal=%2d x=%s" % (k, int(d["n_iter"]), int(d["signal"]), d["x"]))
+    for (n, me, mi, m, seed, rd) in [(40, 0, 0, 3, 0, False), (64, 0, 0, 6, 1, False), (48, 12, 0, 4, 2, False),
+                                     (48, 0, 20, 4, 3, False), (96, 24, 40, 5, 4, False), (200, 30, 90, 8, 5, False),
+                                     (96, 24, 40, 0, 6, False), (60, 10, 16, 4, 7, True)]:
+        out = lbfgs_direction_fixture(n, me, mi, m, seed, rd)
+        np.savez_compressed(os.path.join(GOLD, "lbfgs_dir_n%d_me%d_mi%d_m%d_s%d.npz" % (n, me, mi, m, seed)), **out)
+        print("lbfgs dir n=%d me=%d mi=%d m=%d |dz|=%.6g" % (n, me, mi, int(out["m"]), np.linalg.norm(out["dz_raw"])))
 
 
 def run_example(k, x0, **kw):
@@ -260,4 +359,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--lbfgs" in sys.argv[1:]:
+        main_lbfgs()
+    else:
+        main()

@@ -17,7 +17,13 @@ plain callables over NumPy arrays with the signatures of the reference's
 "precompiled" functions (``:85-146, 512-562``):
 ``f(x)``, ``df(x)``, ``d2f(x)``, ``ce(x)``, ``dce(x)->(n,me)``, ``d2ce(x,lda)``,
 ``ci(x)``, ``dci(x)->(n,mi)``, ``d2ci(x,lda)``.  All derivatives must be supplied
-(no autodiff); L-BFGS (``lbfgs=``) is out of scope for this hot path and rejected.
+(no autodiff).
+
+``lbfgs=m`` (pyipm.py:195-203) switches the direction to the limited-memory quasi-Newton form
+(``:1007-1371``): no second derivatives are needed, the host keeps the displacement storage
+(``lbfgs_init`` / ``lbfgs_update``, O(n m)) and the direction itself — a Gram matrix over the n
+variables, an (me+mi)-order symmetric factorisation and the Woodbury correction — runs on the device
+behind ``pyipm_lbfgs_direction`` (``HipLbfgsBackend``).
 """
 from __future__ import annotations
 
@@ -113,6 +119,25 @@ class HipNewtonBackend(object):
         return self.core.step_lengths(tau)
 
 
+class HipLbfgsBackend(object):
+    """L-BFGS direction on the HIP library: the counterpart of ``lbfgs_dir_func`` (pyipm.py:872-875,
+    1184-1246).  The "rcond <= eps" trigger on the equality block (:1108-1113, an ``eigh`` in the
+    reference) is taken from the block pivots of the factorisation, as in ``HipNewtonBackend``."""
+
+    def __init__(self, n, me, mi, memory, device=None, nb=256):
+        from .lbfgs import LbfgsCore
+        self.core = LbfgsCore(n, me, mi, int(memory) + 1, device=device, nb=nb)   # storage grows to memory+1 (:1300)
+        self.n, self.me, self.mi = n, me, mi
+        self.n_calls = 0
+
+    def lbfgs_direction(self, Je, Ji, s, lda, g, zeta, S, Y, SS, L, D, reg, eps):
+        self.n_calls += 1
+        if self.me or self.mi:
+            self.core.stage_jacobian(Je, Ji)
+        dz, self.last_stats = self.core.direction(g, s, lda, zeta, S, Y, SS, L, D, reg=reg, eps=eps, flip=False)
+        return dz.cpu().numpy()
+
+
 class IPM(object):
     """Line-search primal-dual interior-point solver; see module docstring."""
 
@@ -135,7 +160,9 @@ class IPM(object):
         self.Ktol, self.Ftol = Ktol, Ftol
         self.reg_coef = float(np.sqrt(self.eps))
         self.delta0 = self.reg_coef
-        self.lbfgs, self.lbfgs_zeta = lbfgs, lbfgs_zeta
+        self.lbfgs = lbfgs
+        self.lbfgs_zeta = 1.0 if (lbfgs and lbfgs_zeta is None) else lbfgs_zeta         # pyipm.py:355-359
+        self.lbfgs_fail_max = lbfgs                                                     # :360
         self.verbosity = verbosity
         self.backend = backend
         self._backend_opts = dict(device=device, nb=nb, refine=refine, device_step=device_step, condensed=condensed)
@@ -154,16 +181,21 @@ class IPM(object):
         assert isinstance(self.niter, int) and self.niter >= 0
         assert self.Xtol >= self.eps and self.Ktol >= self.eps
         assert self.Ftol is None or self.Ftol >= 0.0
+        assert self.lbfgs is False or self.lbfgs >= 0                                  # pyipm.py:405-408
         if self.lbfgs:
-            raise NotImplementedError("L-BFGS direction is outside the accelerated hot path (SURVEY.md section 8f)")
+            assert isinstance(self.lbfgs, int) and not isinstance(self.lbfgs, bool)
+            if self.lbfgs > 31:
+                raise NotImplementedError("the device direction keeps the 2m x 2m system in one 64 x 64 tile: lbfgs <= 31")
+        assert self.lbfgs_zeta is None or self.lbfgs_zeta > 0.0
         if self.float_dtype != np.float64:
             raise NotImplementedError("the Newton-step core computes in fp64 only")
-        for name in ("df", "d2f"):
+        second = () if self.lbfgs else ("d2f",)
+        for name in ("df",) + second:
             if getattr(self, name) is None:
                 raise ValueError("%s must be supplied as a callable (no autodiff without Aesara)" % name)
-        if self.ce is not None and (self.dce is None or self.d2ce is None):
+        if self.ce is not None and (self.dce is None or (self.d2ce is None and not self.lbfgs)):
             raise ValueError("dce and d2ce must be supplied with ce")
-        if self.ci is not None and (self.dci is None or self.d2ci is None):
+        if self.ci is not None and (self.dci is None or (self.d2ci is None and not self.lbfgs)):
             raise ValueError("dci and d2ci must be supplied with ci")
 
     def compile(self, nvar=None, neq=None, nineq=None):
@@ -174,7 +206,11 @@ class IPM(object):
         self.neq = int(np.size(self.ce(x0))) if (self.ce is not None and neq is None) else int(neq or 0)
         self.nineq = int(np.size(self.ci(x0))) if (self.ci is not None and nineq is None) else int(nineq or 0)
         if self.backend is None:
-            self.backend = HipNewtonBackend(self.nvar, self.neq, self.nineq, **self._backend_opts)
+            if self.lbfgs:
+                self.backend = HipLbfgsBackend(self.nvar, self.neq, self.nineq, self.lbfgs,
+                                               device=self._backend_opts["device"], nb=self._backend_opts["nb"])
+            else:
+                self.backend = HipNewtonBackend(self.nvar, self.neq, self.nineq, **self._backend_opts)
         self.compiled = True
 
     # ------------------------------------------------------------------ model pieces (host, O(n m))
@@ -371,6 +407,64 @@ class IPM(object):
             self.reg_coef, self.delta0, self.eps)
         return dz
 
+    # ------------------------------------------------------------------ L-BFGS storage (host, O(n m))
+    def lbfgs_init(self):
+        """Empty displacement storage (pyipm.py:993-1005)."""
+        n, z = self.nvar, np.zeros
+        return float(self.lbfgs_zeta), z((n, 0)), z((n, 0)), z((0, 0)), z((0, 0)), z((0, 0)), 0
+
+    def lbfgs_update(self, x_old, x_new, g_old, g_new, zeta, S, Y, SS, L, D, lbfgs_fail):
+        """Append the newest (dx, dg) pair and its inner products; pairs of non-positive curvature are
+        skipped and counted, too many skips in a row reset the storage (pyipm.py:1282-1371).  For constrained
+        problems SS = S'S, L = strictly-lower(S'Y), zeta scales the Hessian; for unconstrained ones the same
+        arrays hold Y'Y and the upper-triangular S'Y and zeta scales the inverse Hessian."""
+        n, con = self.nvar, bool(self.neq or self.nineq)
+        dx = x_new - x_old
+        dg = g_old[:n] - g_new[:n]
+        curv = float(np.dot(dg, dx))
+        zeta_new = curv / ((np.dot(dx, dx) if con else np.dot(dg, dg)) + self.eps)
+        root = np.sqrt(self.eps)
+        if curv > root and zeta_new > root:
+            zeta = zeta_new
+            k = S.shape[1]
+            if k > self.lbfgs:                           # the reference lets the storage reach lbfgs+1 pairs (:1300)
+                S, Y = np.roll(S, -1, axis=1), np.roll(Y, -1, axis=1)
+                SS, L, D = (np.roll(Mx, (-1, -1), axis=(0, 1)) for Mx in (SS, L, D))
+                SS[-1, :] = SS[:, -1] = 0.0
+                L[-1, :] = L[:, -1] = 0.0
+                D[-1, :] = D[:, -1] = 0.0
+            else:
+                S, Y = np.pad(S, ((0, 0), (0, 1))), np.pad(Y, ((0, 0), (0, 1)))
+                SS, L, D = (np.pad(Mx, ((0, 1), (0, 1))) for Mx in (SS, L, D))
+            S[:, -1], Y[:, -1] = dx, dg
+            inner = S.T @ dx if con else Y.T @ dg
+            SS[:, -1] = SS[-1, :] = inner
+            if con:
+                L[-1, :] = dx @ Y
+                L[-1, -1] = 0.0
+            else:
+                L[:, -1] = S.T @ dg
+            D[-1, -1] = curv
+            lbfgs_fail = 0
+        else:
+            lbfgs_fail += 1
+        if lbfgs_fail > self.lbfgs_fail_max and S.shape[1] > 0:
+            if self.verbosity > 2:
+                print('Max failures reached, resetting storage arrays.')
+            return self.lbfgs_init()
+        return zeta, S, Y, SS, L, D, lbfgs_fail
+
+    def lbfgs_dir(self, x, s, lda, g, zeta, S, Y, SS, L, D):
+        """Counterpart of pyipm.py:1184-1246: the host evaluates the constraint Jacobians, the backend forms
+        and solves the Woodbury system on the device and returns the RAW direction (the caller flips the
+        multiplier rows, :1723-1725).  The square-Jacobian shortcut (:1188-1198) is not taken: it returns the
+        same direction through inv(B) and, as written, cannot be compiled (duplicate input, :877-880)."""
+        n, me, mi = self.nvar, self.neq, self.nineq
+        Je = np.asarray(self.dce(x), dtype=np.float64).reshape(n, me) if me else None
+        Ji = np.asarray(self.dci(x), dtype=np.float64).reshape(n, mi) if mi else None
+        reg = self.reg_coef * self.eta * (self.mu_host_dev ** self.beta)              # :1113
+        return self.backend.lbfgs_direction(Je, Ji, s, lda, g, zeta, S, Y, SS, L, D, reg, self.eps)
+
     # ------------------------------------------------------------------ driver
     def _kkt_small(self, kkt, tol):
         return all(np.linalg.norm(k) <= tol for k in kkt)
@@ -417,8 +511,14 @@ class IPM(object):
         self.delta = 0.0
         kkt = self.KKT(x, s, lda)
 
+        if self.lbfgs:                                           # pyipm.py:1633-1637
+            zeta, S, Y, SS, L, D, lbfgs_fail = self.lbfgs_init()
+            x_old = np.copy(x)
+            g = -self.grad(x, s, lda)
+
         if self.verbosity > 0:
-            print('Searching for a feasible local minimizer using the exact Hessian.')
+            print('Searching for a feasible local minimizer using L-BFGS to approximate the Hessian.' if self.lbfgs
+                  else 'Searching for a feasible local minimizer using the exact Hessian.')
         iter_count = 0
         f_past = float(self.f(x)) if self.Ftol is not None else None
         Ftol_converged = False
@@ -447,7 +547,19 @@ class IPM(object):
                         msg.append('|ci-s| = {}'.format(np.linalg.norm(kkt[3])))
                     print(', '.join(msg))
 
-                dz = self.newton_direction(x, s, lda)            # <-- the accelerated hot path
+                if self.lbfgs:                                    # pyipm.py:1702-1713
+                    if inner > 0 or outer > 0:
+                        g_old = -self.grad(x_old, s, lda)
+                        g_new = -self.grad(x, s, lda)
+                        zeta, S, Y, SS, L, D, lbfgs_fail = self.lbfgs_update(x_old, x, g_old, g_new, zeta, S, Y, SS,
+                                                                             L, D, lbfgs_fail)
+                        x_old = np.copy(x)
+                        g = np.copy(g_new)
+                    dz = self.lbfgs_dir(x, s, lda, g, zeta, S, Y, SS, L, D)
+                    if me or mi:
+                        dz[n + mi:] = -dz[n + mi:]                # :1723-1725
+                else:
+                    dz = self.newton_direction(x, s, lda)        # <-- the accelerated hot path
 
                 if me or mi:                                      # merit parameter (pyipm.py:1727-1735)
                     bcg = np.asarray(self.df(x), dtype=np.float64).reshape(n)

@@ -20,6 +20,21 @@ class OracleBackend(object):
         return dz, delta, st
 
 
+class OracleLbfgsBackend(object):
+    """L-BFGS backend interface of pyipm_amd.ipm on the CPU oracle (oracle/lbfgs_oracle.py)."""
+
+    def __init__(self, n, me, mi):
+        self.n, self.me, self.mi = n, me, mi
+        self.calls = []
+
+    def lbfgs_direction(self, Je, Ji, s, lda, g, zeta, S, Y, SS, L, D, reg, eps):
+        from oracle import lbfgs_oracle as lo
+        dz = lo.direction(g, zeta, S, Y, SS, L, D, Je=Je, Ji=Ji, s=s, lda=lda, eps=eps, reg=reg)
+        self.calls.append({"g": np.array(g), "zeta": float(zeta), "S": np.array(S), "Y": np.array(Y),
+                           "SS": np.array(SS), "L": np.array(L), "D": np.array(D), "dz_raw": np.array(dz)})
+        return dz
+
+
 class ModelCore(object):
     """NumPy model of ONE RANK of the HIP core's per-panel interface (block-cyclic local columns,
     pack/unpack messages, panel-wise substitutions).  Lets the world_size-2 gloo tests exercise

@@ -11,7 +11,7 @@ import pytest
 
 from pyipm_amd.ipm import IPM
 from pyipm_amd.problems import example_problem, unit_test_x0
-from backends import OracleBackend
+from backends import OracleBackend, OracleLbfgsBackend
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -45,6 +45,64 @@ def test_host_loop_retraces_reference(k):
         np.testing.assert_allclose(np.atleast_1d(kkt[i]), d["kkt%d" % (i + 1)], rtol=1e-4, atol=1e-9)
 
 
+def make_lbfgs_ipm(k, backend, memory=4, **kw):
+    p = example_problem(k)
+    return IPM(x0=unit_test_x0()[k], f=p["f"], df=p["df"], ce=p["ce"], dce=p["dce"], ci=p["ci"], dci=p["dci"],
+               lbfgs=memory, backend=backend, **kw)
+
+
+@pytest.mark.parametrize("k", range(1, 11))
+def test_host_lbfgs_loop_retraces_reference(k):
+    """lbfgs=4 (unit_tests.py:49): storage updates (lbfgs_update), direction inputs and the RAW direction of every
+    iteration, and the final point, against the unmodified reference (tests/golden/lbfgs_trace_pXX.npz)."""
+    d = np.load(os.path.join(GOLD, "lbfgs_trace_p%02d.npz" % k))
+    prob = example_problem(k)
+    be = OracleLbfgsBackend(prob["nvar"], prob["neq"], prob["nineq"])
+    ipm = make_lbfgs_ipm(k, be, Ftol=1.0e-8, verbosity=-1)
+    with np.errstate(all="ignore"):
+        x, s, lda, fval, kkt = ipm.solve()
+    assert ipm.signal == int(d["signal"])
+    assert len(be.calls) == int(d["n_iter"]) == ipm.iter_count
+    for it, c in enumerate(be.calls):
+        m = int(d["it_m"][it])
+        assert c["S"].shape[1] == m
+        np.testing.assert_allclose(c["zeta"], d["it_zeta"][it], rtol=1e-7)
+        np.testing.assert_allclose(c["g"], d["it_g"][it], rtol=1e-6, atol=1e-9)
+        for key in ("S", "Y"):
+            np.testing.assert_allclose(c[key], d["it_" + key][it][:, :m], rtol=1e-6, atol=1e-9)
+        for key in ("SS", "L", "D"):
+            np.testing.assert_allclose(c[key], d["it_" + key][it][:m, :m], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(c["dz_raw"], d["it_dz_raw"][it], rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(x, d["x"], rtol=1e-7, atol=1e-9)
+    assert min(np.linalg.norm(x - gt) for gt in prob["ground_truth"]) <= 1e-3
+
+
+def test_lbfgs_storage_is_bounded_and_shifts():
+    """The storage reaches memory+1 pairs and then drops the oldest (pyipm.py:1300-1307); a pair of non-positive
+    curvature is skipped, and more than ``lbfgs`` skips in a row reset the storage (:1359-1368)."""
+    ipm = make_lbfgs_ipm(2, OracleLbfgsBackend(2, 0, 0), memory=2, verbosity=-1)
+    ipm.nvar, ipm.neq, ipm.nineq = 2, 0, 0
+    st = ipm.lbfgs_init()
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(2)
+    pairs = []
+    for i in range(5):
+        xn = x + rng.standard_normal(2)
+        dg = 2.0 * (xn - x)
+        st = ipm.lbfgs_update(x, xn, dg, np.zeros(2), *st)        # g_old - g_new = dg  => curvature 2|dx|^2 > 0
+        pairs.append((xn - x, dg))
+        x = xn
+        assert st[1].shape[1] == min(i + 1, 3)
+    zeta, S, Y, SS, L, D, fail = st
+    np.testing.assert_allclose(S, np.stack([q[0] for q in pairs[-3:]], axis=1))
+    np.testing.assert_allclose(SS, Y.T @ Y)                        # unconstrained: "SS" is Y'Y
+    np.testing.assert_allclose(L, np.triu(S.T @ Y))                # and "L" the upper-triangular S'Y
+    np.testing.assert_allclose(np.diag(D), np.sum(S * Y, axis=0))
+    for i in range(3):                                             # non-positive curvature: skipped, counted, then reset
+        st = ipm.lbfgs_update(x, x + 1.0, np.zeros(2), np.ones(2), *st)
+    assert st[1].shape[1] == 0 and st[0] == 1.0 and st[-1] == 0
+
+
 def test_problem7_transcript_matches_reference():
     ref = str(np.load(os.path.join(GOLD, "transcript_p07.npz"))["transcript"])
     buf = io.StringIO()
@@ -68,7 +126,7 @@ def test_validation_errors():
     with pytest.raises(ValueError):
         IPM(x0=np.zeros(2), f=p["f"], df=p["df"], d2f=p["d2f"], ci=p["ci"], verbosity=-1).solve()
     with pytest.raises(NotImplementedError):
-        IPM(x0=np.zeros(2), f=p["f"], df=p["df"], d2f=p["d2f"], lbfgs=4, verbosity=-1).solve()
+        IPM(x0=np.zeros(2), f=p["f"], df=p["df"], lbfgs=32, verbosity=-1).solve()
     with pytest.raises(AssertionError):
         IPM(x0=np.zeros(2), f=p["f"], df=p["df"], d2f=p["d2f"], mu=-1.0, verbosity=-1).solve()
 

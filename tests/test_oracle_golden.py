@@ -120,3 +120,43 @@ def test_rank_deficient_delta_c():
     assert st["delta_c_used"] and delta == float(d["delta_out"])
     assert np.array_equal(Hc, d["Hc"])
     assert Hc[n + mi, n + mi] < 0.0
+
+
+# ---------------------------------------------------------------------- L-BFGS direction
+import glob  # noqa: E402
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "lbfgs_dir_*.npz"))), ids=os.path.basename)
+def test_lbfgs_oracle_reproduces_reference_direction(path):
+    """oracle/lbfgs_oracle.py against single calls of the UNMODIFIED reference's lbfgs_dir (pyipm.py:1184-1246)
+    on QP-shaped data: unconstrained, equality-only, inequality-only, both, empty storage, rank-deficient Je."""
+    from oracle import lbfgs_oracle as lo
+    d = np.load(path)
+    me, mi = int(d["me"]), int(d["mi"])
+    reg = float(d["reg_coef"]) * float(d["eta"]) * float(d["mu"]) ** float(d["beta"])
+    dz = lo.direction(d["g"], float(d["zeta"]), d["S"], d["Y"], d["SS"], d["L"], d["D"],
+                      Je=d["Je"] if me else None, Ji=d["Ji"] if mi else None, s=d["s"], lda=d["lda"], reg=reg)
+    tol = 1e-6 if int(d["rank_deficient"]) else 1e-11
+    assert np.linalg.norm(dz - d["dz_raw"]) <= tol * np.linalg.norm(d["dz_raw"])
+
+
+@pytest.mark.parametrize("k", range(1, 11))
+def test_lbfgs_oracle_reproduces_reference_trace_directions(k):
+    """Every direction of the reference's lbfgs=4 runs on its ten example problems, from the recorded inputs."""
+    from oracle import lbfgs_oracle as lo
+    from pyipm_amd.problems import example_problem
+    d = np.load(os.path.join(GOLD, "lbfgs_trace_p%02d.npz" % k))
+    prob = example_problem(k)
+    n, me, mi = int(d["nvar"]), int(d["neq"]), int(d["nineq"])
+    eps = np.finfo(float).eps
+    for it in range(int(d["n_iter"])):
+        m = int(d["it_m"][it])
+        x = d["it_x"][it]
+        Je = np.asarray(prob["dce"](x), dtype=float).reshape(n, me) if me else None
+        Ji = np.asarray(prob["dci"](x), dtype=float).reshape(n, mi) if mi else None
+        reg = np.sqrt(eps) * 1.0e-4 * float(d["it_mu"][it]) ** 0.4
+        dz = lo.direction(d["it_g"][it], float(d["it_zeta"][it]), d["it_S"][it][:, :m], d["it_Y"][it][:, :m],
+                          d["it_SS"][it][:m, :m], d["it_L"][it][:m, :m], d["it_D"][it][:m, :m], Je=Je, Ji=Ji,
+                          s=d["it_s"][it], lda=d["it_lda"][it], reg=reg)
+        ref = d["it_dz_raw"][it]
+        assert np.linalg.norm(dz - ref) <= 1e-9 * max(np.linalg.norm(ref), 1e-300)
