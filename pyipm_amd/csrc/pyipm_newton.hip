@@ -1453,3 +1453,7 @@ int pyipm_mfma_f64_peak(int device, int iters, double* tflops) {
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// L-BFGS search direction (include/pyipm_lbfgs.h): same shared object, built on the machinery above.
+#include "lbfgs_impl.hpp"

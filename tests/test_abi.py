@@ -10,8 +10,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    txt = open(os.path.join(ROOT, "include", "pyipm_newton.h")).read()
+def _header_functions(name="pyipm_newton.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(pyipm_[a-z0-9_]+)\s*\(", txt)))
 
@@ -24,6 +24,21 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), "missing export: " + name
     assert sorted(newton.exported_symbols()) == names, "ctypes binding and header disagree"
+
+
+def test_library_exports_every_lbfgs_symbol():
+    """include/pyipm_lbfgs.h: same shared object, its own ctypes table."""
+    from pyipm_amd import newton, lbfgs
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["pyipm_lbfgs.h", "pyipm_newton.h"]
+    names = _header_functions("pyipm_lbfgs.h")
+    assert len(names) == 9
+    lib = ctypes.CDLL(newton.LIB_PATH)
+    for name in names:
+        assert hasattr(lib, name), "missing export: " + name
+    assert sorted(lbfgs.exported_symbols()) == names, "ctypes binding and header disagree"
+    b = lbfgs.load().pyipm_lbfgs_workspace_bytes(262144, 1024, 3072, 9, 256)
+    assert b > 262144 * 4096 * 8                               # the padded Jacobian operand dominates
+    assert lbfgs.load().pyipm_lbfgs_workspace_bytes(100, 0, 0, 33, 256) == 0       # max_pairs <= 32
 
 
 def test_workspace_query_needs_no_gpu():
@@ -42,8 +57,11 @@ def test_no_cpu_fallback():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     from pyipm_amd.newton import NewtonCore, NewtonError
+    from pyipm_amd.lbfgs import LbfgsCore
     with pytest.raises(NewtonError):
         NewtonCore(3, 1, 3)
+    with pytest.raises(NewtonError):
+        LbfgsCore(3, 1, 3, 5)
 
 
 def test_product_never_imports_oracle():

@@ -1,0 +1,173 @@
+"""L-BFGS search direction through the C-ABI (include/pyipm_lbfgs.h) against the unmodified reference's
+recorded directions (tests/golden/lbfgs_*.npz) and, at sizes the reference never ran, against the CPU oracle
+(oracle/lbfgs_oracle.py, itself pinned to those records by tests/test_oracle_golden.py)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+EPS = float(np.finfo(float).eps)
+
+
+def _core(n, me, mi, cap, **kw):
+    from pyipm_amd.lbfgs import LbfgsCore
+    return LbfgsCore(n, me, mi, cap, device=0, **kw)
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLD, "lbfgs_dir_*.npz"))), ids=os.path.basename)
+def test_direction_matches_reference_fixture(path):
+    d = np.load(path)
+    n, me, mi, m = int(d["n"]), int(d["me"]), int(d["mi"]), int(d["m"])
+    reg = float(d["reg_coef"]) * float(d["eta"]) * float(d["mu"]) ** float(d["beta"])
+    core = _core(n, me, mi, max(m, 1))
+    core.stage_jacobian(d["Je"] if me else None, d["Ji"] if mi else None)
+    dz, st = core.direction(d["g"], d["s"], d["lda"], float(d["zeta"]), d["S"], d["Y"], d["SS"], d["L"], d["D"], reg=reg)
+    dz = dz.cpu().numpy()
+    if int(d["rank_deficient"]):
+        # duplicated equality gradient: G_ee is singular, the reference adds reg ~ 8e-13 and gets |dz| ~ 4e11;
+        # the factorisation must notice (rejected / negative pivot) and take the same branch.  The direction is
+        # then the solution of a system of condition ~1e13: compare through the system itself.
+        assert st["regularised"] == 1 and st["n_factor"] == 2
+        assert np.all(np.isfinite(dz))
+        assert _rel(dz, d["dz_raw"]) <= 5e-2
+    else:
+        assert st["regularised"] == 0 and st["n_neg"] == 0 and st["n_zero"] == 0
+        assert _rel(dz, d["dz_raw"]) <= 1e-9
+    flipped, _ = core.direction(d["g"], d["s"], d["lda"], float(d["zeta"]), d["S"], d["Y"], d["SS"], d["L"], d["D"],
+                                reg=reg, flip=True)
+    flipped = flipped.cpu().numpy()
+    np.testing.assert_array_equal(flipped[:n + mi], dz[:n + mi])
+    np.testing.assert_array_equal(flipped[n + mi:], -dz[n + mi:])            # pyipm.py:1723-1725
+    core.close()
+
+
+@pytest.mark.parametrize("k", range(1, 11))
+def test_direction_matches_reference_traces(k):
+    """Every direction of the reference's lbfgs=4 runs on its example problems, from the recorded inputs."""
+    from pyipm_amd.problems import example_problem
+    d = np.load(os.path.join(GOLD, "lbfgs_trace_p%02d.npz" % k))
+    prob = example_problem(k)
+    n, me, mi = int(d["nvar"]), int(d["neq"]), int(d["nineq"])
+    core = _core(n, me, mi, int(d["memory"]) + 1)
+    for it in range(int(d["n_iter"])):
+        m = int(d["it_m"][it])
+        x = d["it_x"][it]
+        Je = np.asarray(prob["dce"](x), dtype=float).reshape(n, me) if me else None
+        Ji = np.asarray(prob["dci"](x), dtype=float).reshape(n, mi) if mi else None
+        core.stage_jacobian(Je, Ji)
+        reg = np.sqrt(EPS) * 1.0e-4 * float(d["it_mu"][it]) ** 0.4
+        dz, st = core.direction(d["it_g"][it], d["it_s"][it], d["it_lda"][it], float(d["it_zeta"][it]),
+                                d["it_S"][it][:, :m], d["it_Y"][it][:, :m], d["it_SS"][it][:m, :m],
+                                d["it_L"][it][:m, :m], d["it_D"][it][:m, :m], reg=reg)
+        ref = d["it_dz_raw"][it]
+        assert st["m"] == m
+        assert _rel(dz.cpu().numpy(), ref) <= 1e-7, (k, it, st)
+    core.close()
+
+
+@pytest.mark.parametrize("k", range(1, 11))
+def test_ipm_lbfgs_solves_example_problems_on_the_device(k):
+    """IPM(lbfgs=4) with the HIP backend: the reference's own acceptance test (unit_tests.py:49-51, 405-415:
+    |x - x_gt| <= 1e-3) and its termination signal."""
+    from pyipm_amd.ipm import IPM
+    from pyipm_amd.problems import example_problem, unit_test_x0
+    d = np.load(os.path.join(GOLD, "lbfgs_trace_p%02d.npz" % k))
+    p = example_problem(k)
+    ipm = IPM(x0=unit_test_x0()[k], f=p["f"], df=p["df"], ce=p["ce"], dce=p["dce"], ci=p["ci"], dci=p["dci"],
+              lbfgs=4, Ftol=1.0e-8, verbosity=-1, device=0)
+    with np.errstate(all="ignore"):
+        x, s, lda, fval, kkt = ipm.solve()
+    assert min(np.linalg.norm(x - gt) for gt in p["ground_truth"]) <= 1e-3
+    assert ipm.signal == int(d["signal"])
+    assert ipm.backend.n_calls == ipm.iter_count
+    np.testing.assert_allclose(x, d["x"], rtol=1e-5, atol=1e-6)
+
+
+def _storage(n, m, rng, constrained, memory):
+    """Displacement storage built with the oracle's restatement of lbfgs_update (pyipm.py:1282-1371)."""
+    from oracle import lbfgs_oracle as lo
+    zeta, S, Y, SS, L, D, fail = lo.lbfgs_init(n)
+    Mq = rng.standard_normal((n, 32)) / np.sqrt(32.0)
+    x_old = rng.standard_normal(n)
+    for _ in range(m):
+        x_new = x_old + rng.standard_normal(n) / np.sqrt(n)
+        hv = lambda v: Mq @ (Mq.T @ v) + 0.5 * v           # noqa: E731   SPD curvature model, applied matrix-free
+        zeta, S, Y, SS, L, D, fail = lo.lbfgs_update(x_old, x_new, -hv(x_old), -hv(x_new), zeta, S, Y, SS, L, D, fail,
+                                                     n, constrained, memory, EPS)
+        x_old = x_new
+    return zeta, S, Y, SS, L, D
+
+
+@pytest.mark.parametrize("n,me,mi,m", [(1500, 0, 0, 7), (1000, 130, 0, 5), (1200, 0, 333, 6), (2000, 100, 300, 8),
+                                       (777, 65, 191, 31), (3000, 256, 512, 2), (5, 1, 2, 3), (300, 64, 64, 0)])
+def test_direction_matches_oracle_at_larger_sizes(n, me, mi, m):
+    from oracle import lbfgs_oracle as lo
+    from pyipm_amd.problems import make_qp
+    rng = np.random.default_rng(n + 7 * me + 13 * mi + m)
+    qp = make_qp(n, me, mi, 3)
+    zeta, S, Y, SS, L, D = _storage(n, m, rng, bool(me or mi), max(m, 1))
+    assert S.shape[1] == m
+    g = rng.standard_normal(n + 2 * mi + me)
+    s = qp["s"] if mi else np.zeros(0)
+    lda = qp["lam"] if (me or mi) else np.zeros(0)
+    ref = lo.direction(g, zeta, S, Y, SS, L, D, Je=qp["Je"] if me else None, Ji=qp["Ji"] if mi else None, s=s, lda=lda,
+                       reg=1e-12)
+    core = _core(n, me, mi, max(m, 1), nb=128 if n < 1000 else 256)
+    core.stage_jacobian(qp["Je"] if me else None, qp["Ji"] if mi else None)
+    dz, st = core.direction(g, s, lda, zeta, S, Y, SS, L, D, reg=1e-12)
+    assert st["regularised"] == 0 and st["n_neg"] == 0 and st["n_zero"] == 0
+    assert _rel(dz.cpu().numpy(), ref) <= 1e-9
+    tm = core.last_timings()
+    assert tm["total_ms"] > 0.0
+    core.close()
+
+
+def test_sigma_spread_and_device_inputs():
+    """Sigma over 16 orders of magnitude (late interior-point iterations) and device-tensor inputs."""
+    import torch
+    from oracle import lbfgs_oracle as lo
+    from pyipm_amd.problems import make_qp
+    n, me, mi, m = 600, 40, 200, 4
+    rng = np.random.default_rng(99)
+    qp = make_qp(n, me, mi, 8)
+    zeta, S, Y, SS, L, D = _storage(n, m, rng, True, m)
+    sig = np.exp(rng.uniform(np.log(1e-8), np.log(1e8), mi))
+    s = rng.uniform(0.5, 2.0, mi)
+    lda = np.concatenate([qp["lam"][:me], sig * s])
+    g = rng.standard_normal(n + 2 * mi + me)
+    ref = lo.direction(g, zeta, S, Y, SS, L, D, Je=qp["Je"], Ji=qp["Ji"], s=s, lda=lda, reg=1e-12)
+    core = _core(n, me, mi, m)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()       # noqa: E731
+    core.stage_jacobian(dev(qp["Je"]), dev(qp["Ji"]))
+    dz, st = core.direction(dev(g), dev(s), dev(lda), zeta, dev(S), dev(Y), SS, L, D, reg=1e-12)
+    assert st["regularised"] == 0
+    # the s rows are scaled by 1/Sigma (up to 1e8): compare block-wise relative to each block's own size
+    out = dz.cpu().numpy()
+    for lo_, hi in ((0, n), (n, n + mi), (n + mi, n + mi + me), (n + mi + me, n + 2 * mi + me)):
+        assert _rel(out[lo_:hi], ref[lo_:hi]) <= 1e-7
+    core.close()
+
+
+def test_argument_errors_are_reported_not_thrown():
+    from pyipm_amd.lbfgs import LbfgsCore
+    from pyipm_amd.newton import NewtonError
+    with pytest.raises(NewtonError):
+        LbfgsCore(10, 0, 0, 33, device=0)                      # max_pairs <= 32
+    core = _core(10, 2, 0, 2)
+    z = np.zeros
+    with pytest.raises(NewtonError, match="stage the Jacobians"):
+        core.direction(z(12), z(0), z(2), 1.0, z((10, 0)), z((10, 0)), z((0, 0)), z((0, 0)), z((0, 0)))
+    core.stage_jacobian(np.eye(10)[:, :2], None)
+    with pytest.raises(NewtonError, match="max_pairs"):
+        core.direction(z(12), z(0), z(2), 1.0, z((10, 3)), z((10, 3)), z((3, 3)), z((3, 3)), z((3, 3)))
+    with pytest.raises(NewtonError, match="zeta"):
+        core.direction(z(12), z(0), z(2), 0.0, z((10, 0)), z((10, 0)), z((0, 0)), z((0, 0)), z((0, 0)))
+    core.close()
