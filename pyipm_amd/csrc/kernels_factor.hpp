@@ -547,6 +547,8 @@ struct UpdGeo {
     unsigned long long* dbg;               // diagnostics only (NULL in normal operation): per-block timeline
     const unsigned* tiles;                 // swizzled launches: block b works on tile (tiles[b] & 0xffff, tiles[b] >> 16), built on
                                            // the host in the XCD-aware order below with every empty tile left out; NULL = decode here
+    int64_t ks_cstride;                    // split-K launches (grid.y = splits, tile-list order only): split y accumulates its K
+                                           // columns of the operands into C + y*ks_cstride; 0 = one split (every KKT launch)
 };
 template <int BN>
 __host__ __device__ inline void upd_col(const UpdGeo& u, int64_t ct, int64_t& jglob, int64_t& jloc) {
@@ -606,9 +608,17 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_update(
     const int64_t Npad = u.Npad;
     int64_t rt, ct;
     if (SWZ && u.tiles) {
-        const unsigned code = u.tiles[blockIdx.x];
+        // split-K launches rotate the XCD sequences by the split index: a list shorter than 8 real entries
+        // per round (few output tiles) would otherwise put every split's blocks on the same XCDs
+        const unsigned b = u.ks_cstride ? ((blockIdx.x & ~7u) | ((blockIdx.x + blockIdx.y) & 7u)) : blockIdx.x;
+        const unsigned code = u.tiles[b];
         if (code == 0xffffffffu) return;               // padding of a shorter XCD sequence
         rt = code & 0xffffu; ct = code >> 16;
+        if (u.ks_cstride) {                            // Gram launches over a long K (kernels_lbfgs.hpp)
+            C += (int64_t)blockIdx.y * u.ks_cstride;
+            Lop += (int64_t)blockIdx.y * K * ldl;
+            Wop += (int64_t)blockIdx.y * K * ldw;
+        }
     } else if (SWZ) {
         // XCD-aware order: block b runs on XCD b%8 (observed dispatch); each XCD walks its own
         // sequence of 8x8 super-tiles so the 16 operand tiles of a super-tile are reused from its L2.

@@ -14,7 +14,7 @@
 
 namespace pyipm {
 
-constexpr int LB_CC = 8;          // skinny columns per pass over J
+constexpr int LB_CC = 17;         // skinny columns per pass over J (2m+1 = 17 for m = 8: one pass)
 constexpr int LB_GCH = 32;        // rows per LDS chunk in the skinny-skinny reduction
 constexpr int LB_GBLK = 256;      // blocks (= partial sums) of that reduction
 
@@ -57,20 +57,19 @@ __global__ __launch_bounds__(256) void k_tall_tn(double* __restrict__ part, int6
     #pragma unroll
     for (int u = 0; u < LB_CC; ++u) acc[u] = 0.0;
     const int nc = rr - c0 < LB_CC ? rr - c0 : LB_CC;
-    if (nc == LB_CC) {
-        for (int64_t k = k0; k < k1; ++k) {
-            const double a = JT[j + k * ldj];
-            const double* vr = V + k * rr + c0;
-            #pragma unroll
-            for (int u = 0; u < LB_CC; ++u) acc[u] = fma(a, vr[u], acc[u]);
-        }
-    } else {
-        for (int64_t k = k0; k < k1; ++k) {
-            const double a = JT[j + k * ldj];
-            const double* vr = V + k * rr + c0;
-            #pragma unroll
-            for (int u = 0; u < LB_CC; ++u) if (u < nc) acc[u] = fma(a, vr[u], acc[u]);
-        }
+    int64_t k = k0;
+    for (; k + 4 <= k1; k += 4) {             // four independent loads in flight per thread
+        const double a0 = JT[j + k * ldj], a1 = JT[j + (k + 1) * ldj], a2 = JT[j + (k + 2) * ldj], a3 = JT[j + (k + 3) * ldj];
+        const double* vr = V + k * rr + c0;
+        #pragma unroll
+        for (int u = 0; u < LB_CC; ++u)
+            if (u < nc) acc[u] = fma(a3, vr[3 * rr + u], fma(a2, vr[2 * rr + u], fma(a1, vr[rr + u], fma(a0, vr[u], acc[u]))));
+    }
+    for (; k < k1; ++k) {
+        const double a = JT[j + k * ldj];
+        const double* vr = V + k * rr + c0;
+        #pragma unroll
+        for (int u = 0; u < LB_CC; ++u) if (u < nc) acc[u] = fma(a, vr[u], acc[u]);
     }
     #pragma unroll
     for (int u = 0; u < LB_CC; ++u)
@@ -112,32 +111,47 @@ __global__ __launch_bounds__(256) void k_lb_rhs(double* __restrict__ P, int64_t 
     P[(int64_t)c * ldp + j] = v;
 }
 
-// T[k*rr + c] = sum_j JT[j + k*ldj] * R[j + c*ldr]       (J R; one wave per row k, lanes over j)
-// grid (blocks over k, ceil(rr/LB_CC)), block 256
+// T[k*rr + c] = sum_j JT[j + k*ldj] * R[j + c*ldr]       (J R)
+// One block = 64 rows k; J is walked in 64 x 64 tiles staged through LDS (the global read is coalesced along j, the
+// compute wants one row per thread), the matching 64 x nc slab of R beside it.  Thread (kr, cg): row kr, columns
+// cg, cg+4, ...  grid (ceil(n/64), ceil(rr/LB_CC)), block 256.
+constexpr int LB_NNU = (LB_CC + 3) / 4;
 __global__ __launch_bounds__(256) void k_tall_nn(double* __restrict__ T, int rr, const double* __restrict__ JT,
                                                  int64_t ldj, const double* __restrict__ R, int64_t ldr, int64_t p,
                                                  int64_t n)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ double tile[64][65];
+    __shared__ double Rs[64][LB_CC + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kr = lane, cg = wave;
     const int c0 = blockIdx.y * LB_CC;
     const int nc = rr - c0 < LB_CC ? rr - c0 : LB_CC;
-    for (int64_t k = (int64_t)blockIdx.x * 4 + wave; k < n; k += (int64_t)gridDim.x * 4) {
-        double acc[LB_CC];
-        #pragma unroll
-        for (int u = 0; u < LB_CC; ++u) acc[u] = 0.0;
-        const double* col = JT + k * ldj;
-        for (int64_t j = lane; j < p; j += 64) {
-            const double a = col[j];
-            #pragma unroll
-            for (int u = 0; u < LB_CC; ++u) if (u < nc) acc[u] = fma(a, R[j + (int64_t)(c0 + u) * ldr], acc[u]);
+    const int64_t k0 = (int64_t)blockIdx.x * 64;
+    double acc[LB_NNU];
+    #pragma unroll
+    for (int u = 0; u < LB_NNU; ++u) acc[u] = 0.0;
+    for (int64_t j0 = 0; j0 < p; j0 += 64) {
+        #pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int64_t k = k0 + wave * 16 + i, j = j0 + lane;
+            tile[wave * 16 + i][lane] = (k < n && j < p) ? JT[j + k * ldj] : 0.0;
         }
-        #pragma unroll
-        for (int u = 0; u < LB_CC; ++u) {
-            double t = acc[u];
-            #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
-            if (lane == 0 && u < nc) T[k * rr + c0 + u] = t;
+        for (int t = tid; t < 64 * nc; t += 256) {
+            const int jj = t & 63, c = t >> 6;
+            Rs[jj][c] = (j0 + jj < p) ? R[(j0 + jj) + (int64_t)(c0 + c) * ldr] : 0.0;
         }
+        __syncthreads();
+        #pragma unroll 8
+        for (int jj = 0; jj < 64; ++jj) {
+            const double a = tile[kr][jj];
+            #pragma unroll
+            for (int u = 0; u < LB_NNU; ++u) if (cg + 4 * u < nc) acc[u] = fma(a, Rs[jj][cg + 4 * u], acc[u]);
+        }
+        __syncthreads();
+    }
+    if (k0 + kr < n) {
+        #pragma unroll
+        for (int u = 0; u < LB_NNU; ++u) if (cg + 4 * u < nc) T[(k0 + kr) * rr + c0 + cg + 4 * u] = acc[u];
     }
 }
 
@@ -290,6 +304,16 @@ __global__ __launch_bounds__(256) void k_lb_comb_ls(double* __restrict__ dz, con
     for (int c = 0; c < r; ++c) u = fma(R[j + (int64_t)(1 + c) * ldr], v[c], u);
     dz[n + mi + j] = sgn * u;
     if (j >= me) dz[n + (j - me)] = (g[n + (j - me)] + u) / sig[j - me];
+}
+
+// A = sum of the split-K partial Gram matrices (ns buffers of `count` doubles, stride `count`; fixed order)
+__global__ __launch_bounds__(256) void k_lb_ksum(double* __restrict__ A, const double* __restrict__ Cs, int64_t count, int ns)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double t = 0.0;
+    for (int sp = 0; sp < ns; ++sp) t += Cs[(int64_t)sp * count + i];
+    A[i] = t;
 }
 
 // Diagonal of zeta*G on top of the Gram launch; identity on the padding.

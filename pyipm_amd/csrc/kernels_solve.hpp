@@ -7,6 +7,9 @@
 //   backward: x_k = z_k - sum_{i>k} Lb[i,k]' x_i
 // organised per panel (nb columns): a one-workgroup kernel resolves the nb x nb diagonal
 // block, streaming kernels handle everything below it.
+//
+// Several right-hand sides: every kernel takes a vector stride and reads its right-hand side index from the
+// last grid dimension (v + index*vstride); single-vector callers launch that dimension as 1 with stride 0.
 #pragma once
 #include "ctx.hpp"
 
@@ -14,10 +17,11 @@ namespace pyipm {
 
 // In-panel forward substitution on the nbw x nbw diagonal block.  blockDim = nbw.
 __global__ void k_fwd_diag(const double* __restrict__ A, int64_t ld, int64_t lc0, int64_t c0,
-                           int nbw, double* __restrict__ v)
+                           int nbw, double* __restrict__ v, int64_t vstride)
 {
     extern __shared__ double y[];
     const int tid = threadIdx.x;
+    v += (int64_t)blockIdx.y * vstride;
     y[tid] = v[c0 + tid];
     const int nt = nbw / TB;
     for (int u = 0; u + 1 < nt; ++u) {
@@ -37,9 +41,10 @@ __global__ void k_fwd_diag(const double* __restrict__ A, int64_t ld, int64_t lc0
 // Rows below the panel:  v[i] -= sum_{k<nbw} A[i, lc0+k] * v[c0+k].   One thread per row.
 __global__ __launch_bounds__(256) void k_fwd_gemv(const double* __restrict__ A, int64_t ld, int64_t lc0,
                                                   int64_t c0, int nbw, int64_t row_begin, int64_t Npad,
-                                                  double* __restrict__ v)
+                                                  double* __restrict__ v, int64_t vstride)
 {
     extern __shared__ double y[];
+    v += (int64_t)blockIdx.y * vstride;
     for (int k = threadIdx.x; k < nbw; k += 256) y[k] = v[c0 + k];
     __syncthreads();
     const int64_t i = row_begin + (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -60,11 +65,12 @@ __global__ __launch_bounds__(256) void k_fwd_gemv(const double* __restrict__ A, 
 // grid = tiles, block = 64.
 __global__ __launch_bounds__(64) void k_diag_apply(const double* __restrict__ Dinv, const double* __restrict__ Tsave,
                                                    const double* __restrict__ Tflag, int nref, int64_t tile0,
-                                                   int64_t c0, double* __restrict__ v)
+                                                   int64_t c0, double* __restrict__ v, int64_t vstride)
 {
     __shared__ double y[TB];
     __shared__ double w[TB];
     const int lane = threadIdx.x;
+    v += (int64_t)blockIdx.y * vstride;
     const int64_t base = c0 + (int64_t)blockIdx.x * TB;
     const double y0 = v[base + lane];
     y[lane] = y0;
@@ -95,9 +101,12 @@ __global__ __launch_bounds__(64) void k_diag_apply(const double* __restrict__ Di
 // grid = (nbw, nchunk), block 256; deterministic (no atomics).
 __global__ __launch_bounds__(256) void k_bwd_dot(const double* __restrict__ A, int64_t ld, int64_t lc0,
                                                  int nb, int64_t row_begin, int64_t Npad,
-                                                 const double* __restrict__ v, double* __restrict__ part)
+                                                 const double* __restrict__ v, double* __restrict__ part,
+                                                 int64_t vstride, int64_t pstride)
 {
     __shared__ double red[4];
+    v += (int64_t)blockIdx.z * vstride;
+    part += (int64_t)blockIdx.z * pstride;
     const int k = blockIdx.x;
     const int64_t r0 = row_begin + (int64_t)blockIdx.y * ROWCHUNK;
     int64_t r1 = r0 + ROWCHUNK; if (r1 > Npad) r1 = Npad;
@@ -114,10 +123,12 @@ __global__ __launch_bounds__(256) void k_bwd_dot(const double* __restrict__ A, i
 // In-panel backward substitution.  blockDim = nbw.
 __global__ void k_bwd_diag(const double* __restrict__ A, int64_t ld, int64_t lc0, int64_t c0,
                            int nbw, int nb, const double* __restrict__ part, int nchunk,
-                           double* __restrict__ v)
+                           double* __restrict__ v, int64_t vstride, int64_t pstride)
 {
     extern __shared__ double x[];
     const int tid = threadIdx.x;
+    v += (int64_t)blockIdx.y * vstride;
+    part += (int64_t)blockIdx.y * pstride;
     double t = 0.0;
     for (int c = 0; c < nchunk; ++c) t += part[(int64_t)c * nb + tid];
     x[tid] = v[c0 + tid] - t;

@@ -15,11 +15,14 @@ struct LbCtx {
     int64_t p_pad = 0, n_pad = 0;
     char* ws = nullptr; size_t ws_bytes = 0;
     double *JT = nullptr;               // p_pad x n_pad, column-major (see kernels_lbfgs.hpp)
+    int ksplit = 1;                     // split-K factor of the Gram launch (fixed by the shape)
+    double *Cs = nullptr;               // ksplit partial Gram matrices, p_pad^2 each (ksplit > 1)
     double *g = nullptr, *s = nullptr, *lda = nullptr, *sig = nullptr, *dz = nullptr;
     double *S = nullptr, *Y = nullptr;  // staging of host S, Y (n x cap, row-major)
     double *V = nullptr, *T = nullptr;  // n x rrmax row-major
     double *P = nullptr;                // p_pad x rrmax column-major
     double *part = nullptr;             // J'V partial sums: nsplit x rrmax x p_pad
+    double *spart = nullptr; int64_t spstride = 0;   // backward-substitution partial sums, one slab per right-hand side
     double *gpart = nullptr, *Hs = nullptr, *M2 = nullptr, *v11 = nullptr, *info = nullptr;
     int nsplit = 1;
     bool have_J = false;
@@ -42,10 +45,33 @@ struct LbCtx {
 
 inline LbCtx* LB(pyipm_lbfgs_ctx* h) { return reinterpret_cast<LbCtx*>(h); }
 
-int lb_nsplit(int64_t n) {
-    int64_t s = (n + 2047) / 2048;
+// Split-K factor of the Gram launch.  J'J has only T = nt(nt+1)/2 output tiles (nt = p_pad/128) against 512 block
+// slots (2 per CU), while K = n is long: splitting K fills the machine and shortens the ragged last round.
+// Model (seconds): rounds of 512 blocks at the in-situ tile rate + clearing and summing the partial matrices at
+// HBM speed; every split at least 1024 deep, scratch <= 1 GiB.
+int lb_ksplit(int64_t p_pad, int64_t n_pad) {
+    const int64_t nt = p_pad / 128, T = nt * (nt + 1) / 2;
+    const double cnt = (double)p_pad * (double)p_pad;
+    int best = 1; double bc = 1e300;
+    for (int ks = 1; ks <= 512; ks *= 2) {
+        if (ks > 1 && (n_pad / ks < 1024 || ks * cnt * 8.0 > 1073741824.0)) break;
+        const double t_tile = 2.0 * 128.0 * 128.0 * (double)(n_pad / ks) / (62.0e12 / 512.0);
+        const double c = (double)((T * ks + 511) / 512) * t_tile + (ks > 1 ? (2.0 * ks + 1.0) * cnt * 8.0 / 3.0e12 + 5.0e-6 : 0.0);
+        if (c < bc) { bc = c; best = ks; }
+    }
+    return best;
+}
+constexpr int64_t LB_KPAD = 8192;       // n_pad granularity: BKU * the largest split factor
+
+// Splits of the reduction over n in the J'V pass (one thread per constraint column, so a narrow J needs many):
+// aim at >= 512k threads, keep >= 256 rows per split and the partial sums under 256 MB.
+int lb_nsplit(int64_t n, int64_t p_pad, int rrmax) {
+    if (p_pad <= 0) return 1;
+    int64_t s = (524288 + p_pad - 1) / p_pad;
+    const int64_t by_rows = (n + 255) / 256, by_mem = 268435456 / ((int64_t)rrmax * p_pad * 8);
+    if (s > by_rows) s = by_rows;
+    if (s > by_mem) s = by_mem;
     if (s < 1) s = 1;
-    if (s > 32) s = 32;
     return (int)s;
 }
 
@@ -55,8 +81,10 @@ size_t lb_carve(LbCtx* c, int64_t n, int64_t me, int64_t mi, int cap, int64_t p_
     const size_t D = sizeof(double);
     const int64_t p = me + mi, N = n + 2 * mi + me;
     const int rr = 2 * cap + 1;
-    const int nsplit = lb_nsplit(n);
+    const int nsplit = lb_nsplit(n, p_pad, rr);
+    const int ks = p > 0 ? lb_ksplit(p_pad, n_pad) : 1;
     const size_t oJT = cv.take(p > 0 ? (size_t)p_pad * (size_t)n_pad * D : 256);
+    const size_t oCs = cv.take(ks > 1 ? (size_t)ks * (size_t)p_pad * (size_t)p_pad * D : 256);
     const size_t og = cv.take((size_t)(N + 1) * D);
     const size_t os = cv.take((size_t)(mi + 1) * D);
     const size_t ol = cv.take((size_t)(p + 1) * D);
@@ -68,16 +96,19 @@ size_t lb_carve(LbCtx* c, int64_t n, int64_t me, int64_t mi, int cap, int64_t p_
     const size_t oT = cv.take((size_t)n * rr * D);
     const size_t oP = cv.take(p > 0 ? (size_t)p_pad * rr * D : 256);
     const size_t opart = cv.take(p > 0 ? (size_t)nsplit * rr * (size_t)p_pad * D : 256);
+    const int64_t spstride = ((p_pad + ROWCHUNK - 1) / ROWCHUNK + 2) * 1024;          // nchunk * nb, nb <= 1024
+    const size_t osp = cv.take(p > 0 ? (size_t)rr * (size_t)spstride * D : 256);
     const size_t ogp = cv.take((size_t)LB_GBLK * (size_t)(2 * cap) * rr * D);
     const size_t oHs = cv.take((size_t)(2 * cap) * rr * D);
     const size_t oM2 = cv.take((size_t)(2 * cap) * (2 * cap) * D);
     const size_t ov = cv.take((size_t)(2 * cap + 8) * D);
     const size_t oi = cv.take(64);
     if (base) {
-        c->JT = (double*)(base + oJT); c->g = (double*)(base + og); c->s = (double*)(base + os);
+        c->JT = (double*)(base + oJT); c->Cs = (double*)(base + oCs); c->ksplit = ks; c->g = (double*)(base + og); c->s = (double*)(base + os);
         c->lda = (double*)(base + ol); c->sig = (double*)(base + osg); c->dz = (double*)(base + odz);
         c->S = (double*)(base + oS); c->Y = (double*)(base + oY); c->V = (double*)(base + oV);
         c->T = (double*)(base + oT); c->P = (double*)(base + oP); c->part = (double*)(base + opart);
+        c->spart = (double*)(base + osp); c->spstride = spstride;
         c->gpart = (double*)(base + ogp); c->Hs = (double*)(base + oHs); c->M2 = (double*)(base + oM2);
         c->v11 = (double*)(base + ov); c->info = (double*)(base + oi);
     }
@@ -107,11 +138,28 @@ int lb_factor_G(LbCtx* lb, double zeta, double reg_e, pyipm_factor_stats* st, bo
     Ctx* gc = lb->gcx;
     const Geo& g = gc->g;
     gc->stream = lb->stream;
-    LB_HIP(hipMemsetAsync(gc->A, 0, (size_t)g.Npad * (size_t)g.Npad * sizeof(double), lb->stream));
-    if (timed) LB_HIP(hipEventRecord(lb->ev[1], lb->stream));
-    int rc = launch_update128(gc, lb->stream, lb->JT, lb->p_pad, lb->JT, (int)lb->n_pad, 0, 0,
+    const int ks = gc->xcd_swizzle ? lb->ksplit : 1;
+    const int64_t cnt = g.Npad * g.Npad;
+    int rc;
+    if (ks > 1) {
+        // split y of ONE launch accumulates columns [y K/ks, (y+1) K/ks) of JT into its own matrix Cs[y]; A = sum
+        LB_HIP(hipMemsetAsync(lb->Cs, 0, (size_t)ks * (size_t)cnt * sizeof(double), lb->stream));
+        if (timed) LB_HIP(hipEventRecord(lb->ev[1], lb->stream));
+        double* keep = gc->A;
+        gc->A = lb->Cs;
+        rc = launch_update128(gc, lb->stream, lb->JT, lb->p_pad, lb->JT, (int)(lb->n_pad / ks), 0, 0,
+                              (g.Npad + g.nb - 1) / g.nb, true, lb->p_pad, g.Npad, g.Npad, -1, ks, cnt);
+        gc->A = keep;
+        if (rc) { lb->err = gc->err; return rc; }
+        hipLaunchKernelGGL(k_lb_ksum, grid1(cnt), dim3(256), 0, lb->stream, gc->A, lb->Cs, cnt, ks);
+        LB_KCHECK();
+    } else {
+        LB_HIP(hipMemsetAsync(gc->A, 0, (size_t)cnt * sizeof(double), lb->stream));
+        if (timed) LB_HIP(hipEventRecord(lb->ev[1], lb->stream));
+        rc = launch_update128(gc, lb->stream, lb->JT, lb->p_pad, lb->JT, (int)lb->n_pad, 0, 0,
                               (g.Npad + g.nb - 1) / g.nb, true, lb->p_pad, g.Npad, g.Npad);
-    if (rc) { lb->err = gc->err; return rc; }
+        if (rc) { lb->err = gc->err; return rc; }
+    }
     if (timed) LB_HIP(hipEventRecord(lb->ev[2], lb->stream));
     hipLaunchKernelGGL(k_lb_gram_diag, grid1(g.Npad), dim3(256), 0, lb->stream, gc->A, g.Npad, lb->p, lb->me, lb->sig,
                        zeta, reg_e);
@@ -132,7 +180,7 @@ size_t pyipm_lbfgs_workspace_bytes(int64_t n, int64_t me, int64_t mi, int max_pa
     if (nb == 0) nb = 256;
     if (nb % 128 != 0 || nb > 1024) return 0;
     const int64_t p = me + mi;
-    const int64_t p_pad = p > 0 ? (p + PADG - 1) / PADG * PADG : 0, n_pad = (n + BKU - 1) / BKU * BKU;
+    const int64_t p_pad = p > 0 ? (p + PADG - 1) / PADG * PADG : 0, n_pad = (n + LB_KPAD - 1) / LB_KPAD * LB_KPAD;
     size_t total = lb_carve(nullptr, n, me, mi, max_pairs, p_pad, n_pad, nullptr);
     if (p > 0) total += pyipm_newton_workspace_bytes(p, 0, 0, nb, 1, 0);
     return total;
@@ -152,8 +200,7 @@ int pyipm_lbfgs_create(pyipm_lbfgs_ctx** out, int64_t n, int64_t me, int64_t mi,
     lb->n = n; lb->me = me; lb->mi = mi; lb->p = me + mi; lb->N = n + 2 * mi + me;
     lb->cap = max_pairs; lb->rrmax = 2 * max_pairs + 1; lb->device = device; lb->nb = nb;
     lb->stream = (hipStream_t)stream;
-    lb->nsplit = lb_nsplit(n);
-    lb->n_pad = (n + BKU - 1) / BKU * BKU;
+    lb->n_pad = (n + LB_KPAD - 1) / LB_KPAD * LB_KPAD;
     if (lb->p > 0) {
         pyipm_newton_ctx* gh = nullptr;
         int rc = pyipm_newton_create(&gh, lb->p, 0, 0, nb, device, 1, 0, nullptr, 0, stream);
@@ -161,6 +208,7 @@ int pyipm_lbfgs_create(pyipm_lbfgs_ctx** out, int64_t n, int64_t me, int64_t mi,
         lb->gcx = C(gh);
         lb->p_pad = lb->gcx->g.Npad;
     }
+    lb->nsplit = lb_nsplit(n, lb->p_pad, lb->rrmax);
     lb->ws_bytes = lb_carve(nullptr, n, me, mi, max_pairs, lb->p_pad, lb->n_pad, nullptr);
     if (hipMalloc((void**)&lb->ws, lb->ws_bytes) != hipSuccess) {
         if (lb->gcx) pyipm_newton_destroy(reinterpret_cast<pyipm_newton_ctx*>(lb->gcx));
@@ -326,15 +374,12 @@ int pyipm_lbfgs_direction(pyipm_lbfgs_ctx* h, const double* g, const double* s, 
         }
         LB_HIP(hipEventRecord(lb->ev[4], st));
         // ---- 2m+1 substitutions with the factor of zeta*G: column 0 -> y, column c -> X00_c
-        for (int c = 0; c < rr; ++c) {
-            rc = solve_plain(gc, lb->P + (int64_t)c * ldp, false);
-            if (rc) { lb->err = gc->err; return rc; }
-        }
+        rc = solve_plain(gc, lb->P, false, rr, ldp, lb->spart, lb->spstride);
+        if (rc) { lb->err = gc->err; return rc; }
         LB_HIP(hipEventRecord(lb->ev[5], st));
         // ---- pass 2 over J:  T = J [y | X00] ;  E = [Zg_x | X01_x]
         {
-            int64_t nblk = (n + 3) / 4; if (nblk > 8192) nblk = 8192;
-            dim3 grid((unsigned)nblk, (unsigned)((rr + LB_CC - 1) / LB_CC));
+            dim3 grid((unsigned)((n + 63) / 64), (unsigned)((rr + LB_CC - 1) / LB_CC));
             hipLaunchKernelGGL(k_tall_nn, grid, dim3(256), 0, st, lb->T, rr, lb->JT, ldp, lb->P, ldp, p, n);
             LB_KCHECK();
             hipLaunchKernelGGL(k_lb_E, grid1(n * rr), dim3(256), 0, st, lb->T, lb->V, rr, n, zeta, 1);

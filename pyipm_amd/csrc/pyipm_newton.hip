@@ -238,7 +238,8 @@ int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, uns
 // ldw / row_end / col_end default to the KKT storage's (the Gram launch of the condensed option narrows them).
 int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ldl, const double* Wop, int K,
                      int64_t row_begin, int64_t first_lp, int64_t n_lp, bool bulk = true,
-                     int64_t ldw = 0, int64_t row_end = 0, int64_t col_end = 0, int64_t src_c0 = -1) {
+                     int64_t ldw = 0, int64_t row_end = 0, int64_t col_end = 0, int64_t src_c0 = -1,
+                     int ksplit = 1, int64_t ks_cstride = 0) {
     const Geo& g = ctx->g;
     if (ldw <= 0) ldw = g.Npad;
     if (row_end <= 0) row_end = g.Npad;
@@ -251,7 +252,7 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     u.nrt = (int)(m / BM); u.nct = (int)(n_lp * (g.nb / 128));
     u.dbg = ctx->dbg_buf;
     u.prio = bulk ? 0 : ctx->side_prio;
-    u.rt_min0 = 0; u.rt_step = 0; u.tiles = nullptr;
+    u.rt_min0 = 0; u.rt_step = 0; u.tiles = nullptr; u.ks_cstride = 0;
     if (src_c0 >= 0) active_ranges(ctx, src_c0, src_c0 + K, &u.a0, &u.a1, &u.b0, &u.b1);
     else { u.a0 = 0; u.a1 = g.Npad; u.b0 = 0; u.b1 = 0; }
     if (ctx->xcd_swizzle && bulk && upd_swizzle_ok<128>(u)) {
@@ -261,12 +262,14 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
         unsigned ntiles = 0;
         int rc = tile_list(ctx, u, nsup, &u.tiles, &ntiles); if (rc) return rc;
         if (ntiles == 0) return 0;
-        dim3 grid(ntiles);
+        dim3 grid(ntiles, (unsigned)ksplit);             // K is the length of ONE split
+        if (ksplit > 1) u.ks_cstride = ks_cstride;
         if (ctx->bulk_waves == 8)
             hipLaunchKernelGGL((k_update<128, true, 8>), grid, dim3(512), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
         else
             hipLaunchKernelGGL((k_update<128, true>), grid, dim3(256), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
     } else {
+        if (ksplit > 1) { ctx->err = "split-K launches need the tile-list order (xcd_swizzle)"; return PYIPM_E_BADARG; }
         dim3 grid((unsigned)u.nrt, (unsigned)u.nct);
         hipLaunchKernelGGL((k_update<128, false>), grid, dim3(256), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
     }
@@ -345,7 +348,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
             u.row_begin = row_begin; u.Npad = g.Npad; u.first_lp = lp; u.sub0 = t;
             u.nb = g.nb; u.world = g.world; u.rank = g.rank; u.nrt = (int)(m / BM); u.nct = 1;
             u.dbg = nullptr; u.prio = ctx->side_prio; u.rt_min0 = 0; u.rt_step = 0;
-            u.a0 = ha0; u.a1 = ha1; u.b0 = hb0; u.b1 = hb1; u.tiles = nullptr;
+            u.a0 = ha0; u.a1 = ha1; u.b0 = hb0; u.b1 = hb1; u.tiles = nullptr; u.ks_cstride = 0;
             dim3 grid((unsigned)(m / BM), 1);
             hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), 0, stream, ctx->A, g.Npad,
                                ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, t * TB, u);
@@ -472,58 +475,64 @@ int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
     return 0;
 }
 
-int fwd_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr) {
+// nrhs right-hand sides at stride vstride (doubles) share every launch (last grid dimension); the single-vector
+// callers use the defaults.
+int fwd_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr, int nrhs = 1, int64_t vstride = 0) {
     if (!stream) stream = ctx->stream;
     const Geo& g = ctx->g;
     const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
     const int nbw = (int)g.panel_w(p);
-    hipLaunchKernelGGL(k_fwd_diag, dim3(1), dim3(nbw), nbw * sizeof(double), stream, ctx->A, g.Npad, lc0, c0, nbw, v);
+    hipLaunchKernelGGL(k_fwd_diag, dim3(1, nrhs), dim3(nbw), nbw * sizeof(double), stream, ctx->A, g.Npad, lc0, c0, nbw, v, vstride);
     PYIPM_KCHECK();
     const int64_t below = g.Npad - (c0 + nbw);
     if (below > 0) {
-        hipLaunchKernelGGL(k_fwd_gemv, grid1(below), dim3(256), nbw * sizeof(double), stream, ctx->A, g.Npad, lc0, c0,
-                           nbw, c0 + nbw, g.Npad, v);
+        hipLaunchKernelGGL(k_fwd_gemv, dim3(grid1(below).x, nrhs), dim3(256), nbw * sizeof(double), stream, ctx->A, g.Npad, lc0, c0,
+                           nbw, c0 + nbw, g.Npad, v, vstride);
         PYIPM_KCHECK();
     }
     return 0;
 }
 
-int diag_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr) {
+int diag_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr, int nrhs = 1, int64_t vstride = 0) {
     if (!stream) stream = ctx->stream;
     const Geo& g = ctx->g;
     const int64_t c0 = g.panel_c0(p);
     const int nbw = (int)g.panel_w(p);
-    hipLaunchKernelGGL(k_diag_apply, dim3(nbw / TB), dim3(64), 0, stream, ctx->Dinv, ctx->Tsv, ctx->Tflag, ctx->block_refine, c0 / TB, c0, v);
+    hipLaunchKernelGGL(k_diag_apply, dim3(nbw / TB, nrhs), dim3(64), 0, stream, ctx->Dinv, ctx->Tsv, ctx->Tflag, ctx->block_refine,
+                       c0 / TB, c0, v, vstride);
     PYIPM_KCHECK();
     return 0;
 }
 
-int bwd_panel(Ctx* ctx, int64_t p, double* v) {
+// part / pstride: partial-sum buffer for several right-hand sides (>= nchunk*nb doubles each); default = the handle's own
+int bwd_panel(Ctx* ctx, int64_t p, double* v, int nrhs = 1, int64_t vstride = 0, double* part = nullptr, int64_t pstride = 0) {
     const Geo& g = ctx->g;
+    if (!part) part = ctx->partial;
     const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
     const int nbw = (int)g.panel_w(p);
     const int64_t below = g.Npad - (c0 + nbw);
     int nchunk = 0;
     if (below > 0) {
         nchunk = (int)((below + ROWCHUNK - 1) / ROWCHUNK);
-        hipLaunchKernelGGL(k_bwd_dot, dim3(nbw, nchunk), dim3(256), 0, ctx->stream, ctx->A, g.Npad, lc0, g.nb,
-                           c0 + nbw, g.Npad, v, ctx->partial);
+        hipLaunchKernelGGL(k_bwd_dot, dim3(nbw, nchunk, nrhs), dim3(256), 0, ctx->stream, ctx->A, g.Npad, lc0, g.nb,
+                           c0 + nbw, g.Npad, v, part, vstride, pstride);
         PYIPM_KCHECK();
     }
-    hipLaunchKernelGGL(k_bwd_diag, dim3(1), dim3(nbw), nbw * sizeof(double), ctx->stream, ctx->A, g.Npad, lc0, c0, nbw,
-                       g.nb, ctx->partial, nchunk, v);
+    hipLaunchKernelGGL(k_bwd_diag, dim3(1, nrhs), dim3(nbw), nbw * sizeof(double), ctx->stream, ctx->A, g.Npad, lc0, c0, nbw,
+                       g.nb, part, nchunk, v, vstride, pstride);
     PYIPM_KCHECK();
     return 0;
 }
 
 // x := M^{-1} x in place for the factored matrix of the current geometry (single-rank path)
-int solve_plain(Ctx* ctx, double* v, bool forward_done) {
+int solve_plain(Ctx* ctx, double* v, bool forward_done, int nrhs = 1, int64_t vstride = 0, double* part = nullptr,
+                int64_t pstride = 0) {
     const Geo& g = ctx->g;
     if (!forward_done) {
-        for (int64_t p = 0; p < g.npanels; ++p) { int rc = fwd_panel(ctx, p, v); if (rc) return rc; }
-        for (int64_t p = 0; p < g.npanels; ++p) { int rc = diag_panel(ctx, p, v); if (rc) return rc; }
+        for (int64_t p = 0; p < g.npanels; ++p) { int rc = fwd_panel(ctx, p, v, nullptr, nrhs, vstride); if (rc) return rc; }
+        for (int64_t p = 0; p < g.npanels; ++p) { int rc = diag_panel(ctx, p, v, nullptr, nrhs, vstride); if (rc) return rc; }
     }
-    for (int64_t p = g.npanels - 1; p >= 0; --p) { int rc = bwd_panel(ctx, p, v); if (rc) return rc; }
+    for (int64_t p = g.npanels - 1; p >= 0; --p) { int rc = bwd_panel(ctx, p, v, nrhs, vstride, part, pstride); if (rc) return rc; }
     return 0;
 }
 
