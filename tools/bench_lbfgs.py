@@ -122,7 +122,7 @@ def main():
         lo.direction(g2, z2, S2, Y2, SS2, L2, D2, Je=Jc[:, :me] if me else None, Ji=Jc[:, me:] if mi else None, s=s,
                      lda=lda, reg=1e-12)
         out["cpu_oracle"] = {"n": nc, "seconds": time.perf_counter() - t0, "cores": os.cpu_count(), "kind": "port",
-                             "note": "same p and m; the reference's arithmetic scales linearly in n at fixed p"}
+                             "note": "same p and m, smaller n: the reference's literal arithmetic multiplies by a DENSE (n+mi)x(n+mi) diag(1/A) (pyipm.py:1103), quadratic in n; it cannot be run at the device size"}
     print(json.dumps(out))
 
 
