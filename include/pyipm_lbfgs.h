@@ -63,7 +63,9 @@ size_t pyipm_lbfgs_workspace_bytes(int64_t n, int64_t me, int64_t mi, int max_pa
 
 /* Constraint Jacobians as the reference's dce / dci return them (:223-225, 486-487): Je n x me, Ji n x mi,
  * row-major with leading dimensions ld_*.  Copied into the library's padded operand buffer (strided copy,
- * no transposition); stage again whenever they change, once for linear constraints.  No-op when me = mi = 0. */
+ * no transposition); stage again whenever they change, once for linear constraints: J'J is computed on the
+ * first direction after a staging and reused until the next one (it depends on neither zeta nor Sigma).
+ * No-op when me = mi = 0. */
 int pyipm_lbfgs_stage_jacobian(pyipm_lbfgs_ctx* h, const double* Je, int64_t ld_Je, const double* Ji,
                                int64_t ld_Ji, int memkind);
 
@@ -79,7 +81,8 @@ int pyipm_lbfgs_direction(pyipm_lbfgs_ctx* h, const double* g, const double* s, 
 
 /* ms of the last direction call (HIP events on the handle's stream):
  * out[0] total, [1] Gram launch, [2] factorisation(s) of G, [3] the 2m+1 substitutions,
- * [4] the two passes over J, [5] small system + combination, [6] flop count of the Gram launch, [7] 0. */
+ * [4] the two passes over J, [5] small system + combination, [6] flop count of a Gram launch,
+ * [7] Gram launches since create ([1] is ~0 for a direction that reused J'J). */
 int pyipm_lbfgs_last_timings(pyipm_lbfgs_ctx* h, double out[8]);
 
 /* Pass an option of pyipm_newton_set_option through to the internal factorisation handle. */

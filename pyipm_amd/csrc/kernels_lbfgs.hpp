@@ -113,9 +113,11 @@ __global__ __launch_bounds__(256) void k_lb_rhs(double* __restrict__ P, int64_t 
 
 // T[k*rr + c] = sum_j JT[j + k*ldj] * R[j + c*ldr]       (J R)
 // One block = 64 rows k; J is walked in 64 x 64 tiles staged through LDS (the global read is coalesced along j, the
-// compute wants one row per thread), the matching 64 x nc slab of R beside it.  Thread (kr, cg): row kr, columns
-// cg, cg+4, ...  grid (ceil(n/64), ceil(rr/LB_CC)), block 256.
+// compute wants one row per thread), the matching 64 x nc slab of R beside it; the next tile is already in flight
+// (registers) while the current one is consumed.  Thread (kr, cg): row kr, columns cg, cg+4, ...
+// grid (ceil(n/64), ceil(rr/LB_CC)), block 256.
 constexpr int LB_NNU = (LB_CC + 3) / 4;
+constexpr int LB_NNR = 64;
 __global__ __launch_bounds__(256) void k_tall_nn(double* __restrict__ T, int rr, const double* __restrict__ JT,
                                                  int64_t ldj, const double* __restrict__ R, int64_t ldr, int64_t p,
                                                  int64_t n)
@@ -130,17 +132,27 @@ __global__ __launch_bounds__(256) void k_tall_nn(double* __restrict__ T, int rr,
     double acc[LB_NNU];
     #pragma unroll
     for (int u = 0; u < LB_NNU; ++u) acc[u] = 0.0;
+    double pre[16];
+    #pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t k = k0 + wave * 16 + i;
+        pre[i] = (k < n && lane < p) ? JT[lane + k * ldj] : 0.0;
+    }
     for (int64_t j0 = 0; j0 < p; j0 += 64) {
-        #pragma unroll 4
-        for (int i = 0; i < 16; ++i) {
-            const int64_t k = k0 + wave * 16 + i, j = j0 + lane;
-            tile[wave * 16 + i][lane] = (k < n && j < p) ? JT[j + k * ldj] : 0.0;
-        }
+        #pragma unroll
+        for (int i = 0; i < 16; ++i) tile[wave * 16 + i][lane] = pre[i];
         for (int t = tid; t < 64 * nc; t += 256) {
             const int jj = t & 63, c = t >> 6;
             Rs[jj][c] = (j0 + jj < p) ? R[(j0 + jj) + (int64_t)(c0 + c) * ldr] : 0.0;
         }
         __syncthreads();
+        if (j0 + 64 < p) {
+            #pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t k = k0 + wave * 16 + i, j = j0 + 64 + lane;
+                pre[i] = (k < n && j < p) ? JT[j + k * ldj] : 0.0;
+            }
+        }
         #pragma unroll 8
         for (int jj = 0; jj < 64; ++jj) {
             const double a = tile[kr][jj];

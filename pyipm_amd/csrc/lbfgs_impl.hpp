@@ -17,6 +17,8 @@ struct LbCtx {
     double *JT = nullptr;               // p_pad x n_pad, column-major (see kernels_lbfgs.hpp)
     int ksplit = 1;                     // split-K factor of the Gram launch (fixed by the shape)
     double *Cs = nullptr;               // ksplit partial Gram matrices, p_pad^2 each (ksplit > 1)
+    double *Gc = nullptr;               // J'J of the staged Jacobians (p_pad^2): reused until they are staged again
+    bool gram_valid = false;
     double *g = nullptr, *s = nullptr, *lda = nullptr, *sig = nullptr, *dz = nullptr;
     double *S = nullptr, *Y = nullptr;  // staging of host S, Y (n x cap, row-major)
     double *V = nullptr, *T = nullptr;  // n x rrmax row-major
@@ -26,6 +28,7 @@ struct LbCtx {
     double *gpart = nullptr, *Hs = nullptr, *M2 = nullptr, *v11 = nullptr, *info = nullptr;
     int nsplit = 1;
     bool have_J = false;
+    long long n_gram = 0;               // Gram launches so far
     hipEvent_t ev[8] = {};
     bool ev_valid = false;
     double gram_flops = 0;
@@ -85,6 +88,7 @@ size_t lb_carve(LbCtx* c, int64_t n, int64_t me, int64_t mi, int cap, int64_t p_
     const int ks = p > 0 ? lb_ksplit(p_pad, n_pad) : 1;
     const size_t oJT = cv.take(p > 0 ? (size_t)p_pad * (size_t)n_pad * D : 256);
     const size_t oCs = cv.take(ks > 1 ? (size_t)ks * (size_t)p_pad * (size_t)p_pad * D : 256);
+    const size_t oGc = cv.take(p > 0 ? (size_t)p_pad * (size_t)p_pad * D : 256);
     const size_t og = cv.take((size_t)(N + 1) * D);
     const size_t os = cv.take((size_t)(mi + 1) * D);
     const size_t ol = cv.take((size_t)(p + 1) * D);
@@ -104,7 +108,7 @@ size_t lb_carve(LbCtx* c, int64_t n, int64_t me, int64_t mi, int cap, int64_t p_
     const size_t ov = cv.take((size_t)(2 * cap + 8) * D);
     const size_t oi = cv.take(64);
     if (base) {
-        c->JT = (double*)(base + oJT); c->Cs = (double*)(base + oCs); c->ksplit = ks; c->g = (double*)(base + og); c->s = (double*)(base + os);
+        c->JT = (double*)(base + oJT); c->Cs = (double*)(base + oCs); c->Gc = (double*)(base + oGc); c->ksplit = ks; c->g = (double*)(base + og); c->s = (double*)(base + os);
         c->lda = (double*)(base + ol); c->sig = (double*)(base + osg); c->dz = (double*)(base + odz);
         c->S = (double*)(base + oS); c->Y = (double*)(base + oY); c->V = (double*)(base + oV);
         c->T = (double*)(base + oT); c->P = (double*)(base + oP); c->part = (double*)(base + opart);
@@ -141,25 +145,33 @@ int lb_factor_G(LbCtx* lb, double zeta, double reg_e, pyipm_factor_stats* st, bo
     const int ks = gc->xcd_swizzle ? lb->ksplit : 1;
     const int64_t cnt = g.Npad * g.Npad;
     int rc;
-    if (ks > 1) {
-        // split y of ONE launch accumulates columns [y K/ks, (y+1) K/ks) of JT into its own matrix Cs[y]; A = sum
-        LB_HIP(hipMemsetAsync(lb->Cs, 0, (size_t)ks * (size_t)cnt * sizeof(double), lb->stream));
-        if (timed) LB_HIP(hipEventRecord(lb->ev[1], lb->stream));
+    if (timed) LB_HIP(hipEventRecord(lb->ev[1], lb->stream));
+    if (!lb->gram_valid) {
+        // J'J of the staged Jacobians -> Gc.  It depends on neither zeta nor Sigma (the factor is of zeta*G), so it is
+        // computed once per stage_jacobian: every direction for linear constraints, and the regularised retry, reuse it.
         double* keep = gc->A;
-        gc->A = lb->Cs;
-        rc = launch_update128(gc, lb->stream, lb->JT, lb->p_pad, lb->JT, (int)(lb->n_pad / ks), 0, 0,
-                              (g.Npad + g.nb - 1) / g.nb, true, lb->p_pad, g.Npad, g.Npad, -1, ks, cnt);
-        gc->A = keep;
-        if (rc) { lb->err = gc->err; return rc; }
-        hipLaunchKernelGGL(k_lb_ksum, grid1(cnt), dim3(256), 0, lb->stream, gc->A, lb->Cs, cnt, ks);
-        LB_KCHECK();
-    } else {
-        LB_HIP(hipMemsetAsync(gc->A, 0, (size_t)cnt * sizeof(double), lb->stream));
-        if (timed) LB_HIP(hipEventRecord(lb->ev[1], lb->stream));
-        rc = launch_update128(gc, lb->stream, lb->JT, lb->p_pad, lb->JT, (int)lb->n_pad, 0, 0,
-                              (g.Npad + g.nb - 1) / g.nb, true, lb->p_pad, g.Npad, g.Npad);
-        if (rc) { lb->err = gc->err; return rc; }
+        if (ks > 1) {
+            // split y of ONE launch accumulates columns [y K/ks, (y+1) K/ks) of JT into its own matrix Cs[y]; Gc = sum
+            LB_HIP(hipMemsetAsync(lb->Cs, 0, (size_t)ks * (size_t)cnt * sizeof(double), lb->stream));
+            gc->A = lb->Cs;
+            rc = launch_update128(gc, lb->stream, lb->JT, lb->p_pad, lb->JT, (int)(lb->n_pad / ks), 0, 0,
+                                  (g.Npad + g.nb - 1) / g.nb, true, lb->p_pad, g.Npad, g.Npad, -1, ks, cnt);
+            gc->A = keep;
+            if (rc) { lb->err = gc->err; return rc; }
+            hipLaunchKernelGGL(k_lb_ksum, grid1(cnt), dim3(256), 0, lb->stream, lb->Gc, lb->Cs, cnt, ks);
+            LB_KCHECK();
+        } else {
+            LB_HIP(hipMemsetAsync(lb->Gc, 0, (size_t)cnt * sizeof(double), lb->stream));
+            gc->A = lb->Gc;
+            rc = launch_update128(gc, lb->stream, lb->JT, lb->p_pad, lb->JT, (int)lb->n_pad, 0, 0,
+                                  (g.Npad + g.nb - 1) / g.nb, true, lb->p_pad, g.Npad, g.Npad);
+            gc->A = keep;
+            if (rc) { lb->err = gc->err; return rc; }
+        }
+        lb->gram_valid = true;
+        lb->n_gram++;
     }
+    LB_HIP(hipMemcpyAsync(gc->A, lb->Gc, (size_t)cnt * sizeof(double), hipMemcpyDeviceToDevice, lb->stream));
     if (timed) LB_HIP(hipEventRecord(lb->ev[2], lb->stream));
     hipLaunchKernelGGL(k_lb_gram_diag, grid1(g.Npad), dim3(256), 0, lb->stream, gc->A, g.Npad, lb->p, lb->me, lb->sig,
                        zeta, reg_e);
@@ -266,6 +278,7 @@ int pyipm_lbfgs_stage_jacobian(pyipm_lbfgs_ctx* h, const double* Je, int64_t ld_
     rc = lb_put2d(lb, lb->JT + lb->me, lb->p_pad, Ji, ld_Ji, lb->n, lb->mi, memkind); if (rc) return rc;
     if (memkind == PYIPM_MEM_HOST) LB_HIP(hipStreamSynchronize(lb->stream));     // host memory is not retained
     lb->have_J = true;
+    lb->gram_valid = false;
     return PYIPM_OK;
 }
 
@@ -379,7 +392,7 @@ int pyipm_lbfgs_direction(pyipm_lbfgs_ctx* h, const double* g, const double* s, 
         LB_HIP(hipEventRecord(lb->ev[5], st));
         // ---- pass 2 over J:  T = J [y | X00] ;  E = [Zg_x | X01_x]
         {
-            dim3 grid((unsigned)((n + 63) / 64), (unsigned)((rr + LB_CC - 1) / LB_CC));
+            dim3 grid((unsigned)((n + LB_NNR - 1) / LB_NNR), (unsigned)((rr + LB_CC - 1) / LB_CC));
             hipLaunchKernelGGL(k_tall_nn, grid, dim3(256), 0, st, lb->T, rr, lb->JT, ldp, lb->P, ldp, p, n);
             LB_KCHECK();
             hipLaunchKernelGGL(k_lb_E, grid1(n * rr), dim3(256), 0, st, lb->T, lb->V, rr, n, zeta, 1);
@@ -434,6 +447,7 @@ int pyipm_lbfgs_last_timings(pyipm_lbfgs_ctx* h, double out[8]) {
         out[4] = a + b;
         LB_HIP(hipEventElapsedTime(&ms, lb->ev[6], lb->ev[7])); out[5] = ms;
         out[6] = lb->gram_flops;
+        out[7] = (double)lb->n_gram;
     }
     return PYIPM_OK;
 }

@@ -124,16 +124,18 @@ class HipLbfgsBackend(object):
     1184-1246).  The "rcond <= eps" trigger on the equality block (:1108-1113, an ``eigh`` in the
     reference) is taken from the block pivots of the factorisation, as in ``HipNewtonBackend``."""
 
-    def __init__(self, n, me, mi, memory, device=None, nb=256):
+    def __init__(self, n, me, mi, memory, device=None, nb=256, linear_constraints=False):
         from .lbfgs import LbfgsCore
         self.core = LbfgsCore(n, me, mi, int(memory) + 1, device=device, nb=nb)   # storage grows to memory+1 (:1300)
         self.n, self.me, self.mi = n, me, mi
-        self.n_calls = 0
+        self.linear_constraints = bool(linear_constraints)   # dce/dci do not depend on x: stage once, J'J is reused
+        self.n_calls = self.n_staged = 0
 
     def lbfgs_direction(self, Je, Ji, s, lda, g, zeta, S, Y, SS, L, D, reg, eps):
         self.n_calls += 1
-        if self.me or self.mi:
+        if (self.me or self.mi) and not (self.linear_constraints and self.n_staged):
             self.core.stage_jacobian(Je, Ji)
+            self.n_staged += 1
         dz, self.last_stats = self.core.direction(g, s, lda, zeta, S, Y, SS, L, D, reg=reg, eps=eps, flip=False)
         return dz.cpu().numpy()
 
@@ -145,7 +147,7 @@ class IPM(object):
                  dci=None, d2ci=None, lda0=None, lambda_dev=None, s0=None, mu=0.2, nu=10.0, rho=0.1, tau=0.995,
                  eta=1.0E-4, beta=0.4, miter=20, niter=10, Xtol=None, Ktol=1.0E-4, Ftol=None, lbfgs=False,
                  lbfgs_zeta=None, float_dtype=np.float64, verbosity=1, backend=None, device=None, nb=256, refine=0,
-                 device_step=False, condensed=False):
+                 device_step=False, condensed=False, linear_constraints=False):
         self.x0, self.s0, self.lda0 = x0, s0, lda0
         self.x_dev, self.lambda_dev = x_dev, lambda_dev        # accepted for signature parity; unused
         self.f, self.df, self.d2f = f, df, d2f
@@ -166,6 +168,7 @@ class IPM(object):
         self.verbosity = verbosity
         self.backend = backend
         self._backend_opts = dict(device=device, nb=nb, refine=refine, device_step=device_step, condensed=condensed)
+        self.linear_constraints = linear_constraints       # L-BFGS mode: Jacobians staged once, J'J reused
         self.compiled = False
         self.signal = 0
 
@@ -208,7 +211,8 @@ class IPM(object):
         if self.backend is None:
             if self.lbfgs:
                 self.backend = HipLbfgsBackend(self.nvar, self.neq, self.nineq, self.lbfgs,
-                                               device=self._backend_opts["device"], nb=self._backend_opts["nb"])
+                                               device=self._backend_opts["device"], nb=self._backend_opts["nb"],
+                                               linear_constraints=self.linear_constraints)
             else:
                 self.backend = HipNewtonBackend(self.nvar, self.neq, self.nineq, **self._backend_opts)
         self.compiled = True

@@ -153,7 +153,8 @@ class LbfgsCore(object):
     def last_timings(self):
         out = (c_double * 8)()
         self._ck(self.lib.pyipm_lbfgs_last_timings(self.h, out))
-        keys = ("total_ms", "gram_ms", "factor_ms", "solves_ms", "jacobian_passes_ms", "small_ms", "gram_flops")
+        keys = ("total_ms", "gram_ms", "factor_ms", "solves_ms", "jacobian_passes_ms", "small_ms", "gram_flops",
+                "gram_launches")
         return {k: out[i] for i, k in enumerate(keys)}
 
 

@@ -171,3 +171,49 @@ def test_argument_errors_are_reported_not_thrown():
     with pytest.raises(NewtonError, match="zeta"):
         core.direction(z(12), z(0), z(2), 0.0, z((10, 0)), z((10, 0)), z((0, 0)), z((0, 0)), z((0, 0)))
     core.close()
+
+
+def test_gram_matrix_is_reused_until_the_jacobians_are_staged_again():
+    """J'J depends on neither zeta nor Sigma: directions with different zeta / s / lda between two stagings must
+    reuse it (one Gram launch) and still match the oracle; a new staging must invalidate it."""
+    from oracle import lbfgs_oracle as lo
+    from pyipm_amd.problems import make_qp
+    n, me, mi, m = 900, 50, 150, 4
+    rng = np.random.default_rng(5)
+    qp = make_qp(n, me, mi, 4)
+    zeta, S, Y, SS, L, D = _storage(n, m, rng, True, m)
+    core = _core(n, me, mi, m)
+    core.stage_jacobian(qp["Je"], qp["Ji"])
+    for trial in range(3):
+        g = rng.standard_normal(n + 2 * mi + me)
+        s = rng.uniform(0.5, 2.0, mi)
+        lda = np.concatenate([rng.standard_normal(me), rng.uniform(0.1, 3.0, mi)])
+        z = zeta * (1.0 + trial)
+        ref = lo.direction(g, z, S, Y, SS, L, D, Je=qp["Je"], Ji=qp["Ji"], s=s, lda=lda, reg=1e-12)
+        dz, st = core.direction(g, s, lda, z, S, Y, SS, L, D, reg=1e-12)
+        assert _rel(dz.cpu().numpy(), ref) <= 1e-9
+        assert core.last_timings()["gram_launches"] == 1
+    Je2 = qp["Je"] * 1.5
+    core.stage_jacobian(Je2, qp["Ji"])
+    ref = lo.direction(g, zeta, S, Y, SS, L, D, Je=Je2, Ji=qp["Ji"], s=s, lda=lda, reg=1e-12)
+    dz, st = core.direction(g, s, lda, zeta, S, Y, SS, L, D, reg=1e-12)
+    assert _rel(dz.cpu().numpy(), ref) <= 1e-9
+    assert core.last_timings()["gram_launches"] == 2
+    core.close()
+
+
+def test_ipm_lbfgs_linear_constraints_stage_once():
+    """Problem 7 has linear constraints (README.md:60-75): with linear_constraints=True the Jacobians are staged
+    once and the run is the same."""
+    from pyipm_amd.ipm import IPM
+    from pyipm_amd.problems import example_problem, unit_test_x0
+    p = example_problem(7)
+    runs = []
+    for lin in (False, True):
+        ipm = IPM(x0=unit_test_x0()[7], f=p["f"], df=p["df"], ce=p["ce"], dce=p["dce"], ci=p["ci"], dci=p["dci"],
+                  lbfgs=4, Ftol=1.0e-8, verbosity=-1, device=0, linear_constraints=lin)
+        x, s, lda, fval, kkt = ipm.solve()
+        runs.append((x, ipm.iter_count, ipm.backend.n_staged, ipm.signal))
+    assert runs[1][2] == 1 and runs[0][2] == runs[0][1]
+    assert runs[0][1] == runs[1][1] and runs[0][3] == runs[1][3]
+    np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=1e-12, atol=1e-14)
