@@ -12,10 +12,18 @@ barrier update, ``:958-991`` KKT report) with the provider and the iterate livin
   compiled Aesara functions on the host, ``pyipm.py:855-954``);
 * x, s, lambda and dz never leave the device; per line-search trial only the merit value (one
   scalar) crosses PCIe, per iteration the four KKT norms, the step lengths and the merit threshold;
-* the fraction-to-the-boundary rule is the closed form ``pyipm_newton_step_lengths``.
+* the fraction-to-the-boundary rule is the closed form ``pyipm_newton_step_lengths``;
+* the backtracking search shrinks alpha by tau = 0.995 per trial (``pyipm.py:1534-1548``) — hundreds of merit
+  evaluations for one rejected step.  Along the ray the QP's merit function is a closed form in alpha (f quadratic,
+  constraints affine), so a trial costs O(me + mi) after three GEMVs per iteration instead of a pass over Q, A, G.
 
 PyTorch supplies the device vectors and the GEMVs of the provider (plumbing); the Newton step
 itself is the HIP library.  No CPU fallback: constructing the solver without a GPU raises.
+
+``lbfgs=m`` runs the reference's limited-memory mode (``pyipm.py:1633-1637, 1702-1713``) with the storage
+(S, Y) resident too: the direction is ``pyipm_lbfgs_direction`` on device tensors, the constraints are linear so
+the Jacobians are staged once and J'J is reused by every direction, and Q may then be given in the factored
+form ``("diag+lowrank", d, F)`` = diag(d) + F F' (a dense n x n Q is exactly what L-BFGS is for avoiding).
 """
 from __future__ import annotations
 
@@ -25,7 +33,8 @@ import numpy as np
 class QPDeviceIPM(object):
     def __init__(self, Q, c, A=None, b=None, G=None, h=None, Je=None, Ji=None, x0=None, s0=None, lda0=None,
                  mu=0.2, nu=10.0, rho=0.1, tau=0.995, eta=1.0E-4, beta=0.4, miter=20, niter=10, Xtol=None,
-                 Ktol=1.0E-4, Ftol=None, verbosity=1, device=None, nb=256, refine=0, condensed=False):
+                 Ktol=1.0E-4, Ftol=None, verbosity=1, device=None, nb=256, refine=0, condensed=False,
+                 lbfgs=False, lbfgs_zeta=None):
         import torch
         from .ipm import HipNewtonBackend
         if not torch.cuda.is_available():
@@ -41,15 +50,23 @@ class QPDeviceIPM(object):
                 return a.to(device=dev, dtype=torch.float64)
             return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64))).to(dev)
 
-        self.Q, self.c = dv(Q).contiguous(), dv(c)
+        self.c = dv(c)
         n = self.nvar = int(self.c.numel())
+        if isinstance(Q, (tuple, list)) and len(Q) == 3 and Q[0] == "diag+lowrank":
+            if not lbfgs:
+                raise ValueError("a factored Q needs lbfgs=m: the exact-Hessian step stages a dense n x n block")
+            self.Q, self.Qd, self.QF = None, dv(Q[1]), dv(Q[2]).contiguous()
+        else:
+            self.Q, self.Qd, self.QF = dv(Q).contiguous(), None, None
+            assert self.Q.shape == (n, n)
         # Jacobians in the reference's layout: Je = dce (n x me), Ji = dci (n x mi)  (pyipm.py:486-501)
         self.Je = dv(Je).contiguous() if Je is not None else (dv(A).t().contiguous() if A is not None else None)
         self.Ji = dv(Ji).contiguous() if Ji is not None else (dv(G).t().contiguous() if G is not None else None)
+        self.JeT = self.Je.t().contiguous() if self.Je is not None else None
+        self.JiT = self.Ji.t().contiguous() if self.Ji is not None else None
         self.b, self.h = dv(b), dv(h)
         me = self.neq = 0 if self.Je is None else int(self.Je.shape[1])
         mi = self.nineq = 0 if self.Ji is None else int(self.Ji.shape[1])
-        assert self.Q.shape == (n, n)
         self.x0 = dv(x0) if x0 is not None else torch.zeros(n, dtype=torch.float64, device=dev)
         self.s0, self.lda0 = dv(s0), dv(lda0)
         self.eps = float(np.finfo(np.float64).eps)
@@ -60,24 +77,41 @@ class QPDeviceIPM(object):
         self.reg_coef = float(np.sqrt(self.eps))
         self.delta0 = self.reg_coef
         self.verbosity = verbosity
-        self.backend = HipNewtonBackend(n, me, mi, device=dev.index, nb=nb, refine=refine, device_step=True,
-                                        condensed=condensed)
+        self.lbfgs = int(lbfgs) if lbfgs else 0
+        self.lbfgs_zeta = 1.0 if (lbfgs and lbfgs_zeta is None) else lbfgs_zeta
+        if self.lbfgs:
+            from .lbfgs import LbfgsCore
+            if not 1 <= self.lbfgs <= 31:
+                raise ValueError("1 <= lbfgs <= 31")
+            self.backend = None
+            self.lb = LbfgsCore(n, me, mi, self.lbfgs + 1, device=dev.index, nb=nb)     # storage reaches lbfgs+1 pairs
+            self.lb.stage_jacobian(self.Je, self.Ji)                                    # linear constraints: once
+        else:
+            self.backend = HipNewtonBackend(n, me, mi, device=dev.index, nb=nb, refine=refine, device_step=True,
+                                            condensed=condensed)
         self.signal = 0
         self.iter_count = 0
         self.timings = {"newton_s": 0.0, "search_s": 0.0, "n_phi": 0}
 
     # ------------------------------------------------------------------ provider (device GEMVs)
+    def Qx(self, x):
+        if self.Q is not None:
+            return self.Q @ x
+        return self.Qd * x + self.QF @ (self.QF.t() @ x)
+
     def f(self, x):
-        return float(0.5 * self.torch.dot(x, self.Q @ x) + self.torch.dot(self.c, x))
+        return float(0.5 * self.torch.dot(x, self.Qx(x)) + self.torch.dot(self.c, x))
 
     def df(self, x):
-        return self.Q @ x + self.c
+        return self.Qx(x) + self.c
 
+    # x @ J through the stored transposes: a row-vector times a row-major matrix is rocBLAS' slow GEMV flavour
+    # (28 ms for 8.6 GB), the transposed copy runs at HBM speed (1.7 ms)
     def ce(self, x):
-        return x @ self.Je - self.b
+        return self.JeT @ x - self.b
 
     def ci(self, x):
-        return x @ self.Ji - self.h
+        return self.JiT @ x - self.h
 
     def _con(self, x, s):
         parts = []
@@ -110,13 +144,39 @@ class QPDeviceIPM(object):
     def phi(self, x, s):
         """Merit function (pyipm.py:670-721) reduced on the device; one scalar crosses PCIe."""
         torch = self.torch
-        v = 0.5 * torch.dot(x, self.Q @ x) + torch.dot(self.c, x)
+        v = 0.5 * torch.dot(x, self.Qx(x)) + torch.dot(self.c, x)
         if self.neq:
             v = v + self.nu_host * self.ce(x).abs().sum()
         if self.nineq:
             v = v + self.nu_host * (self.ci(x) - s).abs().sum() - self.mu_host * torch.log(s).sum()
         self.timings["n_phi"] += 1
         return float(v)
+
+    def _ray(self, x0, s0, dx, ds):
+        """alpha -> phi(x0 + alpha dx, s0 + alpha ds) - phi(x0, s0) in closed form (see the module docstring).
+        The DIFFERENCE is formed term by term (|c + a dc| - |c| element-wise, log1p(a ds/s)), so its error is relative
+        to the change of the merit function, not to its size: the Armijo test stays meaningful for the tiny steps of
+        the last iterations, where evaluating phi twice and subtracting has cancelled everything."""
+        torch = self.torch
+        q0 = self.Qx(x0)
+        g1 = torch.dot(q0 + self.c, dx)
+        g2 = torch.dot(dx, self.Qx(dx))
+        ce0 = self.ce(x0) if self.neq else None
+        dce = (self.JeT @ dx) if self.neq else None
+        if self.nineq:
+            r0 = self.ci(x0) - s0
+            dr = (self.JiT @ dx) - ds
+            rs = ds / s0
+
+        def delta(a):
+            v = a * g1 + (0.5 * a * a) * g2
+            if self.neq:
+                v = v + self.nu_host * ((ce0 + a * dce).abs() - ce0.abs()).sum()
+            if self.nineq:
+                v = v + self.nu_host * ((r0 + a * dr).abs() - r0.abs()).sum() - self.mu_host * torch.log1p(a * rs).sum()
+            self.timings["n_phi"] += 1
+            return float(v)
+        return delta
 
     def dphi(self, x, s, dz):
         torch, n = self.torch, self.nvar
@@ -147,6 +207,8 @@ class QPDeviceIPM(object):
                                 -torch.eye(mi, dtype=torch.float64, device=self.device)], dim=1)
             top = torch.cat([top, bottom], dim=0)
         At = top.t()                                           # (me+mi) x (n+mi)
+        if At.numel() > (1 << 26):                             # large: minimum-norm solution through At At' (full row rank)
+            return -(top @ torch.linalg.solve(At @ top, c_new))
         return -(torch.linalg.pinv(At) @ c_new)
 
     def search(self, x0, s0, lda0, dz, alpha_smax, alpha_lmax):
@@ -158,15 +220,16 @@ class QPDeviceIPM(object):
         dl = dz[n + mi:]
         if not (me or mi):
             alpha_lmax = 0.0
+        delta = self._ray(x0, s0, dx, ds)                  # phi(x0 + a dx, s0 + a ds) - phi(x0, s0)
         phi0 = self.phi(x0, s0)
         dphi0 = self.dphi(x0, s0, dz[:n + mi])
-        armijo = lambda a: phi0 + a * self.eta * dphi0    # noqa: E731
+        armijo = lambda a: phi0 + a * self.eta * dphi0     # noqa: E731
+        # rounded to the merit function's own precision, as the reference's two evaluations are: a change below
+        # ulp(phi0) compares equal and is accepted, which is how its last tiny steps pass (pyipm.py:1454-1459)
+        trial = lambda a: (phi0 + delta(a)) - armijo(a)    # noqa: E731   > 0: rejected
         corrected, alpha_corr, dz_p = False, 1.0, None
 
-        def trial(a):
-            return self.phi(x0 + a * dx, s0 + a * ds) if mi else self.phi(x0 + a * dx, s0)
-
-        if trial(alpha_smax) > armijo(alpha_smax):
+        if trial(alpha_smax) > 0.0:
             if me or mi:
                 c_old = self._con(x0, s0)
                 c_new = self._con(x0 + alpha_smax * dx, s0 + alpha_smax * ds if mi else s0)
@@ -190,7 +253,7 @@ class QPDeviceIPM(object):
                 alpha_lmax *= self.tau
                 ndx = float(dx.norm())
                 nds = float(ds.norm()) if mi else 0.0
-                while trial(alpha_smax) > armijo(alpha_smax):
+                while trial(alpha_smax) > 0.0:
                     size = np.sqrt((alpha_smax * ndx) ** 2 + (alpha_lmax * nds) ** 2) if mi else alpha_smax * ndx
                     if size < self.eps:
                         if self.verbosity > 2:
@@ -217,6 +280,51 @@ class QPDeviceIPM(object):
             s if mi else None, lda if (me or mi) else None, self.mu_host, self.delta, self.mu_host, self.eta,
             self.beta, self.reg_coef, self.delta0, self.eps, as_tensor=True)
         return dz
+
+    # ------------------------------------------------------------------ L-BFGS mode (storage on the device)
+    def _gvec(self, x, s, lda):
+        """-grad as ONE device vector (pyipm.py:1637, 1705-1706)."""
+        return -self.torch.cat([b for b in self.grad(x, s, lda) if b is not None])
+
+    def _lbfgs_init(self):
+        t, n, dev = self.torch, self.nvar, self.device
+        e = lambda r, c: t.zeros((r, c), dtype=t.float64, device=dev)       # noqa: E731
+        z = np.zeros((0, 0))
+        return float(self.lbfgs_zeta), e(n, 0), e(n, 0), z, z.copy(), z.copy(), 0
+
+    def _lbfgs_update(self, x_old, x_new, g_old, g_new, zeta, S, Y, SS, L, D, fail):
+        """pyipm.py:1282-1371 with S, Y on the device; only the O(m) inner products cross PCIe."""
+        t, n = self.torch, self.nvar
+        con = bool(self.neq or self.nineq)
+        dx = x_new - x_old
+        dg = g_old[:n] - g_new[:n]
+        k = S.shape[1]
+        drop = k > self.lbfgs
+        Sn = t.cat([S[:, 1:] if drop else S, dx[:, None]], dim=1)
+        Yn = t.cat([Y[:, 1:] if drop else Y, dg[:, None]], dim=1)
+        prods = t.cat([Sn.t() @ dx if con else Yn.t() @ dg, dx @ Yn if con else Sn.t() @ dg,
+                       t.stack([t.dot(dg, dx), t.dot(dx, dx) if con else t.dot(dg, dg)])]).tolist()     # ONE sync
+        kk = Sn.shape[1]
+        inner, cross, curv, den = np.array(prods[:kk]), np.array(prods[kk:2 * kk]), prods[-2], prods[-1]
+        zeta_new = curv / (den + self.eps)
+        root = np.sqrt(self.eps)
+        if curv > root and zeta_new > root:
+            if drop:
+                SS, L, D = SS[1:, 1:], L[1:, 1:], D[1:, 1:]
+            SS, L, D = (np.pad(Mx, ((0, 1), (0, 1))) for Mx in (SS, L, D))
+            SS[:, -1] = SS[-1, :] = inner
+            if con:
+                L[-1, :] = cross
+                L[-1, -1] = 0.0
+            else:
+                L[:, -1] = cross
+            D[-1, -1] = curv
+            zeta, S, Y, fail = zeta_new, Sn.contiguous(), Yn.contiguous(), 0
+        else:
+            fail += 1
+        if fail > self.lbfgs and S.shape[1] > 0:
+            return self._lbfgs_init()
+        return zeta, S, Y, SS, L, D, fail
 
     def _small(self, kkt, tol):
         return all(k <= tol for k in kkt)
@@ -248,8 +356,12 @@ class QPDeviceIPM(object):
             lda = torch.zeros(0, dtype=torch.float64, device=self.device)
         self.delta = 0.0
         kkt = self.KKT(x, s, lda)
+        if self.lbfgs:
+            zeta, S, Y, SS, L, D, lb_fail = self._lbfgs_init()
+            x_old, g = x.clone(), self._gvec(x, s, lda)
         if self.verbosity > 0:
-            print('Searching for a feasible local minimizer using the exact Hessian.')
+            print('Searching for a feasible local minimizer using L-BFGS to approximate the Hessian.' if self.lbfgs
+                  else 'Searching for a feasible local minimizer using the exact Hessian.')
         iter_count = 0
         f_past = self.f(x) if self.Ftol is not None else None
         Ftol_converged = False
@@ -275,9 +387,21 @@ class QPDeviceIPM(object):
                                 '|ce| = {}'.format(kkt[2]), '|ci-s| = {}'.format(kkt[3])]
                     print(', '.join(msg))
                 t0 = time.perf_counter()
-                dz = self.newton_direction(x, s, lda)            # <-- the accelerated hot path
-                if mi:
-                    a_s, a_l = self.backend.step_lengths(self.tau)
+                if self.lbfgs:                                    # pyipm.py:1702-1713, 1723-1725
+                    if inner > 0 or outer > 0:
+                        g_old, g_new = self._gvec(x_old, s, lda), self._gvec(x, s, lda)
+                        zeta, S, Y, SS, L, D, lb_fail = self._lbfgs_update(x_old, x, g_old, g_new, zeta, S, Y, SS, L, D,
+                                                                           lb_fail)
+                        x_old, g = x.clone(), g_new
+                    reg = self.reg_coef * self.eta * (self.mu_host ** self.beta)
+                    dz, self.last_stats = self.lb.direction(g, s if mi else None, lda if (me or mi) else None, zeta,
+                                                            S, Y, SS, L, D, reg=reg, eps=self.eps, flip=True)
+                    if mi:
+                        a_s, a_l = self.step(s, dz[n:n + mi]), self.step(lda[me:], dz[n + mi + me:])
+                else:
+                    dz = self.newton_direction(x, s, lda)        # <-- the accelerated hot path
+                    if mi:
+                        a_s, a_l = self.backend.step_lengths(self.tau)
                 torch.cuda.synchronize(self.device)
                 t1 = time.perf_counter()
                 if me or mi:                                      # merit parameter (pyipm.py:1727-1735)

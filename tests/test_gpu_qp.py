@@ -87,3 +87,63 @@ def test_medium_qp_all_on_device():
     # see the tiny Sigma entries), so late iterates differ in the 1e-8 shift and the counts by an iteration or two
     assert abs(full.iter_count - dev.iter_count) <= 3
     assert float((x - x2).norm() / x2.norm()) <= 1e-7 and abs(f - f2) <= 1e-8 * abs(f2)
+
+
+# ---------------------------------------------------------------------- L-BFGS mode (pyipm.py:1633-1637, 1702-1713)
+@pytest.mark.parametrize("shape", [(60, 8, 20, 1), (120, 0, 40, 2), (90, 30, 0, 3), (150, 0, 0, 4)])
+def test_device_lbfgs_loop_tracks_host_lbfgs_loop(shape):
+    """QPDeviceIPM(lbfgs=m) (storage and iterate on the device, Jacobians staged once) against IPM(lbfgs=m) driven
+    with the same QP as callables: same algorithm, same direction kernels."""
+    from pyipm_amd.ipm import IPM
+    n, me, mi, seed = shape
+    qp = make_qp(n, me, mi, seed)
+    p = qp_callables(qp)
+    kw = dict(niter=20, miter=30)                              # Ktol = 1e-4, the reference's default
+    host = IPM(x0=np.zeros(n), f=p["f"], df=p["df"], ce=p["ce"], dce=p["dce"], ci=p["ci"], dci=p["dci"], lbfgs=6,
+               verbosity=-1, device=0, **kw)
+    with np.errstate(all="ignore"):
+        xh, sh, lh, fh, _ = host.solve()
+    dev = _dev_ipm(qp, lbfgs=6, **kw)
+    xd, sd, ld, fd, kkt = dev.solve()
+    exact = _dev_ipm(qp, Ktol=1e-9, niter=30, miter=30)        # exact-Hessian run: the minimiser itself
+    xe = exact.solve()[0].cpu().numpy()
+    assert dev.signal == host.signal == 1
+    # quasi-Newton paths are sensitive to rounding (NumPy vs device GEMVs in the provider): the two runs agree in
+    # where they end and roughly in how long they take, not iteration by iteration
+    assert abs(dev.iter_count - host.iter_count) <= 0.25 * host.iter_count + 3
+    scale = 1.0 + np.linalg.norm(xe)
+    assert np.linalg.norm(xd.cpu().numpy() - xe) <= 2e-3 * scale and np.linalg.norm(xh - xe) <= 2e-3 * scale
+    assert max(kkt) <= 1e-4
+    x = xd.cpu().numpy()
+    lam = ld.cpu().numpy()
+    r = qp["Q"] @ x + qp["c"]
+    if me:
+        r = r - qp["A"].T @ lam[:me]
+    if mi:
+        r = r - qp["G"].T @ lam[me:]
+        assert (qp["G"] @ x - qp["h"]).min() >= -1e-4
+    assert np.linalg.norm(r) <= 1e-3
+
+
+def test_device_lbfgs_factored_hessian_equals_dense():
+    """Q = diag(d) + F F' handed over in factored form: same run as with the dense matrix."""
+    rng = np.random.default_rng(12)
+    n, me, mi, k = 200, 20, 60, 5
+    qp = make_qp(n, me, mi, 9)
+    d = rng.uniform(0.5, 2.0, n)
+    F = rng.standard_normal((n, k)) / np.sqrt(k)
+    qp["Q"] = np.diag(d) + F @ F.T
+    # a dozen iterations: long enough to fill and rotate the storage, short enough that the two provider roundings
+    # (dense GEMV vs diag + low-rank) have not yet been amplified by the quasi-Newton recursion
+    kw = dict(niter=2, miter=6, lbfgs=5)
+    dense = _dev_ipm(qp, **kw)
+    x1, s1, l1, f1, _ = dense.solve()
+    from pyipm_amd.qp import QPDeviceIPM
+    fac = QPDeviceIPM(("diag+lowrank", d, F), qp["c"], A=qp["A"], b=qp["b"], G=qp["G"], h=qp["h"], verbosity=-1, **kw)
+    x2, s2, l2, f2, kkt = fac.solve()
+    assert dense.iter_count == fac.iter_count == 12 and dense.signal == fac.signal
+    assert float((x2 - x1).norm()) <= 1e-7 * (1.0 + float(x1.norm()))
+    assert float((s2 - s1).norm()) <= 1e-7 * (1.0 + float(s1.norm()))
+    assert float((l2 - l1).norm()) <= 1e-6 * (1.0 + float(l1.norm()))
+    with pytest.raises(ValueError):
+        QPDeviceIPM(("diag+lowrank", d, F), qp["c"], verbosity=-1)          # exact Hessian needs the dense block
