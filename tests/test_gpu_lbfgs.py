@@ -217,3 +217,45 @@ def test_ipm_lbfgs_linear_constraints_stage_once():
     assert runs[1][2] == 1 and runs[0][2] == runs[0][1]
     assert runs[0][1] == runs[1][1] and runs[0][3] == runs[1][3]
     np.testing.assert_allclose(runs[0][0], runs[1][0], rtol=1e-12, atol=1e-14)
+
+
+def test_large_direction_satisfies_the_quasi_newton_system():
+    """Size-independent property at a size the oracle cannot reach (its dense diag(1/A) alone would be 140 GB):
+    the direction solves H dz = g for H = Z - U inv(M) U' (pyipm.py:1036-1052), applied matrix-free with torch as the
+    checker.  n = 131072, p = 1024 (J = 1 GB), m = 8; also through the split-K Gram launch and the cached J'J."""
+    import torch
+    n, me, mi, m = 131072, 256, 768, 8
+    p, N = me + mi, n + 2 * mi + me
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    J = torch.randn((n, p), generator=gen, dtype=torch.float64, device=dev) / np.sqrt(n)
+    rng = np.random.default_rng(4)
+    S = rng.standard_normal((n, m)) / np.sqrt(n)
+    Mq = rng.standard_normal((n, 8)) / 3.0
+    Y = Mq @ (Mq.T @ S) + 0.5 * S
+    SY = S.T @ Y
+    SS, L, D = S.T @ S, np.tril(SY, -1), np.diag(np.diag(SY))
+    zeta = float(SY[-1, -1] / SS[-1, -1])
+    td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)       # noqa: E731
+    Sd, Yd = td(S), td(Y)
+    core = _core(n, me, mi, m)
+    core.stage_jacobian(J[:, :me], J[:, me:])
+    for trial in range(2):                                  # second pass: other Sigma / zeta on the cached J'J
+        s = td(rng.uniform(0.5, 2.0, mi))
+        lda = td(np.concatenate([rng.standard_normal(me), rng.uniform(0.5, 2.0, mi)]))
+        g = td(rng.standard_normal(N))
+        z = zeta * (1.0 + trial)
+        dz, st = core.direction(g, s, lda, z, Sd, Yd, SS, L, D, reg=1e-12)
+        assert st["regularised"] == 0 and st["n_neg"] == 0 and st["n_zero"] == 0
+        x, ds, dl = dz[:n], dz[n:n + mi], dz[n + mi:]
+        W = torch.cat([z * Sd, Yd], dim=1)
+        Minv = td(np.block([[z * SS, L], [L.T, -D]]))
+        res = torch.empty_like(dz)
+        res[:n] = z * x - W @ torch.linalg.solve(Minv, W.T @ x) + J @ dl
+        res[n:n + mi] = lda[me:] / (s + EPS) * ds - dl[me:]
+        low = J.t() @ x
+        low[me:] -= ds
+        res[n + mi:] = low
+        assert float((res - g).norm() / g.norm()) <= 1e-10
+    assert core.last_timings()["gram_launches"] == 1
+    core.close()
