@@ -15,6 +15,9 @@
  *     Zg  = [inv(A)(g1 - B y) ; y] ,      X01 = inv(A)([W;0] + B X00)
  *     v11 = inv(W'X01 - [[zeta SS, L], [L', -D]]) (W'Zg_x)                 2m x 2m, one workgroup
  *     dz  = Zg - [X01 ; -X00] v11                                          RAW: multiplier rows not yet negated
+ *   evaluated so that J is read twice only: P = J'[g_x | W] (one pass, 2m+1 columns); W'X01_x = (W'W + P_w'X00)/zeta
+ *   and W'Zg_x = (W'g_x - P_w'y)/zeta need no J; with u = y + X00 v11:  dz_x = (g_x - W v11 - J u)/zeta (one pass,
+ *   one vector), dz_s = (g_s + u_i)/Sigma, dz_lambda = u.
  *   The factorisation of G is the block LDL' of pyipm_newton.h (an internal handle of order p); the
  *   reference's "rcond(G_ee) <= eps" test (an eigh, :1108-1109) is replaced by "the factorisation rejected
  *   a pivot or met a negative one" (G is positive semidefinite by construction), and additionally

@@ -1,8 +1,9 @@
 // kernels_lbfgs.hpp — L-BFGS search direction (include/pyipm_lbfgs.h; /root/reference/pyipm.py:1007-1182).
 //
 // The Gram matrix J'J and the factorisation of G reuse k_update and the block LDL' unchanged; what is here
-// is the HBM-bound remainder: two passes over J (J'V and J R with skinny V, R of <= 2m+1 columns), the
-// skinny-skinny reductions over n, the 2m x 2m dense solve and the element-wise glue.
+// is the HBM-bound remainder: two passes over J (J'V with skinny V of 2m+1 columns, then J u with ONE vector:
+// everything the 2m x 2m system needs from J X00 is P'X00 with P = J'W already at hand, see lbfgs_impl.hpp), the
+// skinny-skinny reductions, the 2m x 2m dense solve and the element-wise glue.
 //
 // Layouts.  JT: p_pad x n_pad column-major, JT[j + k*ldj] = J[k][j]  (= the caller's row-major J with padded
 // rows: no transposition on staging, and exactly the operand layout k_update wants for C += JT * JT').
@@ -88,10 +89,10 @@ __global__ __launch_bounds__(256) void k_tall_tn_reduce(double* __restrict__ P, 
     P[(int64_t)c * ldp + j] = t;
 }
 
-// Right-hand sides of the block solves, in place on P (column-major, ld = ldp):
+// Right-hand sides of the block solves, R from P (both column-major, ld = ldp; P = J'V is kept):
 //   column 0 :  J'g_x + [0 ; -zeta g_s / Sigma] - zeta g2     (= zeta (B' inv(A) g1 - g2); the factor is of zeta G)
 //   column c :  -J'W_c                                          (= -zeta (J'W_c / zeta))
-__global__ __launch_bounds__(256) void k_lb_rhs(double* __restrict__ P, int64_t ldp, int rr, int64_t p, int64_t me,
+__global__ __launch_bounds__(256) void k_lb_rhs(double* __restrict__ R, const double* __restrict__ P, int64_t ldp, int rr, int64_t p, int64_t me,
                                                 const double* __restrict__ g, int64_t n, int64_t mi,
                                                 const double* __restrict__ sig, double zeta)
 {
@@ -108,87 +109,52 @@ __global__ __launch_bounds__(256) void k_lb_rhs(double* __restrict__ P, int64_t 
             v = -v;
         }
     }
-    P[(int64_t)c * ldp + j] = v;
+    R[(int64_t)c * ldp + j] = v;
 }
 
-// T[k*rr + c] = sum_j JT[j + k*ldj] * R[j + c*ldr]       (J R)
-// One block = 64 rows k; J is walked in 64 x 64 tiles staged through LDS (the global read is coalesced along j, the
-// compute wants one row per thread), the matching 64 x nc slab of R beside it; the next tile is already in flight
-// (registers) while the current one is consumed.  Thread (kr, cg): row kr, columns cg, cg+4, ...
-// grid (ceil(n/64), ceil(rr/LB_CC)), block 256.
-constexpr int LB_NNU = (LB_CC + 3) / 4;
-constexpr int LB_NNR = 64;
-__global__ __launch_bounds__(256) void k_tall_nn(double* __restrict__ T, int rr, const double* __restrict__ JT,
-                                                 int64_t ldj, const double* __restrict__ R, int64_t ldr, int64_t p,
-                                                 int64_t n)
+// out[k] = sum_j JT[j + k*ldj] * u[j]        (J u: one streaming pass, a wave per row, four rows in flight)
+__global__ __launch_bounds__(256) void k_jvec(double* __restrict__ out, const double* __restrict__ JT, int64_t ldj,
+                                              const double* __restrict__ u, int64_t p, int64_t n)
 {
-    __shared__ double tile[64][65];
-    __shared__ double Rs[64][LB_CC + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kr = lane, cg = wave;
-    const int c0 = blockIdx.y * LB_CC;
-    const int nc = rr - c0 < LB_CC ? rr - c0 : LB_CC;
-    const int64_t k0 = (int64_t)blockIdx.x * 64;
-    double acc[LB_NNU];
-    #pragma unroll
-    for (int u = 0; u < LB_NNU; ++u) acc[u] = 0.0;
-    double pre[16];
-    #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int64_t k = k0 + wave * 16 + i;
-        pre[i] = (k < n && lane < p) ? JT[lane + k * ldj] : 0.0;
-    }
-    for (int64_t j0 = 0; j0 < p; j0 += 64) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t k0 = ((int64_t)blockIdx.x * 4 + wave) * 4; k0 < n; k0 += (int64_t)gridDim.x * 16) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        const double* c0 = JT + k0 * ldj;
+        const bool h1 = k0 + 1 < n, h2 = k0 + 2 < n, h3 = k0 + 3 < n;
+        for (int64_t j = lane; j < p; j += 64) {
+            const double uj = u[j];
+            a0 = fma(c0[j], uj, a0);
+            if (h1) a1 = fma(c0[j + ldj], uj, a1);
+            if (h2) a2 = fma(c0[j + 2 * ldj], uj, a2);
+            if (h3) a3 = fma(c0[j + 3 * ldj], uj, a3);
+        }
         #pragma unroll
-        for (int i = 0; i < 16; ++i) tile[wave * 16 + i][lane] = pre[i];
-        for (int t = tid; t < 64 * nc; t += 256) {
-            const int jj = t & 63, c = t >> 6;
-            Rs[jj][c] = (j0 + jj < p) ? R[(j0 + jj) + (int64_t)(c0 + c) * ldr] : 0.0;
+        for (int off = 32; off > 0; off >>= 1) {
+            a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64);
+            a2 += __shfl_xor(a2, off, 64); a3 += __shfl_xor(a3, off, 64);
         }
-        __syncthreads();
-        if (j0 + 64 < p) {
-            #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int64_t k = k0 + wave * 16 + i, j = j0 + 64 + lane;
-                pre[i] = (k < n && j < p) ? JT[j + k * ldj] : 0.0;
-            }
+        if (lane == 0) {
+            out[k0] = a0;
+            if (h1) out[k0 + 1] = a1;
+            if (h2) out[k0 + 2] = a2;
+            if (h3) out[k0 + 3] = a3;
         }
-        #pragma unroll 8
-        for (int jj = 0; jj < 64; ++jj) {
-            const double a = tile[kr][jj];
-            #pragma unroll
-            for (int u = 0; u < LB_NNU; ++u) if (cg + 4 * u < nc) acc[u] = fma(a, Rs[jj][cg + 4 * u], acc[u]);
-        }
-        __syncthreads();
-    }
-    if (k0 + kr < n) {
-        #pragma unroll
-        for (int u = 0; u < LB_NNU; ++u) if (cg + 4 * u < nc) T[(k0 + kr) * rr + c0 + cg + 4 * u] = acc[u];
     }
 }
 
-// E = inv(A_x) applied:  E[k][0] = (V[k][0] - T[k][0]) / zeta   (Zg_x)
-//                        E[k][c] = (V[k][c] + T[k][c]) / zeta   (X01_x), in place on T
-__global__ __launch_bounds__(256) void k_lb_E(double* __restrict__ T, const double* __restrict__ V, int rr, int64_t n,
-                                              double zeta, int have_T)
-{
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n * rr) return;
-    const int c = (int)(idx % rr);
-    const double t = have_T ? T[idx] : 0.0;
-    T[idx] = (c == 0 ? V[idx] - t : V[idx] + t) / zeta;
-}
-
-// part[b][a*ne + e] = sum_{k in block b's chunks} V[k*rr + 1 + a] * E[k*ldE + e]     a < r, e < ne
-// (W'E over the n variables; deterministic: fixed block count, second pass sums the partials)
-__global__ __launch_bounds__(256) void k_small_gram(double* __restrict__ part, const double* __restrict__ V, int rr,
-                                                    const double* __restrict__ E, int ldE, int ne, int r, int64_t n)
+// part[b][a*ne + e] = sum_{k in block b's chunks} V(k, a) * E(k, e)     a < r, e < ne, k < n
+// with V(k, a) = V[k*vrs + (voff + a)*vcs], E(k, e) = E[k*ers + e*ecs]: skinny-skinny products over a long index for
+// row-major operands over n (W'V) and column-major ones over p (P'R).  Deterministic: fixed block count, a second
+// pass sums the partials.
+__global__ __launch_bounds__(256) void k_small_gram(double* __restrict__ part, const double* __restrict__ V, int64_t vrs,
+                                                    int64_t vcs, int voff, const double* __restrict__ E, int64_t ers,
+                                                    int64_t ecs, int ne, int r, int64_t n)
 {
     extern __shared__ double sm[];
     double* sV = sm;                       // LB_GCH x r
     double* sE = sm + LB_GCH * r;          // LB_GCH x ne
     const int nout = r * ne;
-    constexpr int MAXO = 16;               // r*ne <= 64*65 = 4160 <= 256*17: see the host check
+    constexpr int MAXO = 16;               // r*ne <= 64*65 = 4160 <= 256*17
     double acc[MAXO + 1];
     #pragma unroll
     for (int u = 0; u <= MAXO; ++u) acc[u] = 0.0;
@@ -199,11 +165,11 @@ __global__ __launch_bounds__(256) void k_small_gram(double* __restrict__ part, c
         __syncthreads();
         for (int t = threadIdx.x; t < LB_GCH * r; t += 256) {
             const int kk = t / r, a = t - kk * r;
-            sV[t] = kk < rows ? V[(k0 + kk) * rr + 1 + a] : 0.0;
+            sV[t] = kk < rows ? V[(k0 + kk) * vrs + (int64_t)(voff + a) * vcs] : 0.0;
         }
         for (int t = threadIdx.x; t < LB_GCH * ne; t += 256) {
             const int kk = t / ne, e = t - kk * ne;
-            sE[t] = kk < rows ? E[(k0 + kk) * ldE + e] : 0.0;
+            sE[t] = kk < rows ? E[(k0 + kk) * ers + (int64_t)e * ecs] : 0.0;
         }
         __syncthreads();
         #pragma unroll
@@ -291,21 +257,43 @@ __global__ __launch_bounds__(64) void k_small_solve(double* __restrict__ x, doub
     if (i == 0) info[0] = pmin;
 }
 
-// out[k] = a0 * E[k*rr] - sum_{c<r} E[k*rr + 1 + c] * v[c]          (x rows of Zg - X10 v11, or zeta g - W c)
+// Hs = (W'V + sgn * P_w'R) / zeta, sgn = -1 on column 0, +1 elsewhere:
+//   column 0     = W'Zg_x  = (W'g_x - (J'W)'y) / zeta
+//   columns 1..  = W'X01_x = (W'W + (J'W)'X00) / zeta            (X00 = -inv(zeta G) J'W carries the minus)
+__global__ __launch_bounds__(256) void k_lb_hs(double* __restrict__ Hs, const double* __restrict__ Ha,
+                                               const double* __restrict__ Hb, int r, int rr, double zeta)
+{
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= r * rr) return;
+    const int e = o % rr;
+    Hs[o] = (e == 0 ? Ha[o] - Hb[o] : Ha[o] + Hb[o]) / zeta;
+}
+
+// out[k] = a0 * E[k*rr] - sum_{c<r} E[k*rr + 1 + c] * v[c]                    (unconstrained: zeta g - W c)
+// with Ju: out[k] = (E[k*rr] - sum_c E[k*rr + 1 + c] v[c] - Ju[k]) * a0      (x rows of Zg - X10 v11, a0 = 1/zeta:
+//                                                                              (g_x - W v11 - J u) / zeta)
 __global__ __launch_bounds__(256) void k_lb_comb_x(double* __restrict__ out, const double* __restrict__ E, int rr,
-                                                   int64_t n, const double* __restrict__ v, int r, double a0)
+                                                   int64_t n, const double* __restrict__ v, int r, double a0,
+                                                   const double* __restrict__ Ju)
 {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
     const double* row = E + k * rr;
-    double t = a0 * row[0];
-    for (int c = 0; c < r; ++c) t = fma(-row[1 + c], v[c], t);
-    out[k] = t;
+    if (Ju) {
+        double t = row[0] - Ju[k];
+        for (int c = 0; c < r; ++c) t = fma(-row[1 + c], v[c], t);
+        out[k] = t * a0;
+    } else {
+        double t = a0 * row[0];
+        for (int c = 0; c < r; ++c) t = fma(-row[1 + c], v[c], t);
+        out[k] = t;
+    }
 }
 
-// u[j] = R[j] + sum_c R[j + (1+c)*ldr] v[c]  (= y - (-X00) v11);  dz_lambda[j] = sgn*u[j];
+// u[j] = R[j] + sum_c R[j + (1+c)*ldr] v[c]  (= y - (-X00) v11), kept for the J u pass;  dz_lambda[j] = sgn*u[j];
 // dz_s[i] = (g_s[i] + u[me+i]) / Sigma_i      (rows of Zg - X10 v11 below x; uses X01_s = -X00_i / Sigma)
-__global__ __launch_bounds__(256) void k_lb_comb_ls(double* __restrict__ dz, const double* __restrict__ R, int64_t ldr,
+__global__ __launch_bounds__(256) void k_lb_comb_ls(double* __restrict__ dz, double* __restrict__ uout,
+                                                    const double* __restrict__ R, int64_t ldr,
                                                     int64_t p, int64_t me, int64_t n, int64_t mi,
                                                     const double* __restrict__ g, const double* __restrict__ sig,
                                                     const double* __restrict__ v, int r, double sgn)
@@ -314,6 +302,7 @@ __global__ __launch_bounds__(256) void k_lb_comb_ls(double* __restrict__ dz, con
     if (j >= p) return;
     double u = R[j];
     for (int c = 0; c < r; ++c) u = fma(R[j + (int64_t)(1 + c) * ldr], v[c], u);
+    uout[j] = u;
     dz[n + mi + j] = sgn * u;
     if (j >= me) dz[n + (j - me)] = (g[n + (j - me)] + u) / sig[j - me];
 }

@@ -21,15 +21,16 @@ struct LbCtx {
     bool gram_valid = false;
     double *g = nullptr, *s = nullptr, *lda = nullptr, *sig = nullptr, *dz = nullptr;
     double *S = nullptr, *Y = nullptr;  // staging of host S, Y (n x cap, row-major)
-    double *V = nullptr, *T = nullptr;  // n x rrmax row-major
-    double *P = nullptr;                // p_pad x rrmax column-major
+    double *V = nullptr;                // n x rrmax row-major: [g_x | S-part | Y-part]
+    double *Ju = nullptr, *u = nullptr; // J u (n) and u = y + X00 v11 (p_pad)
+    double *P = nullptr, *R = nullptr;  // p_pad x rrmax column-major: J'V (kept) and the solved right-hand sides
     double *part = nullptr;             // J'V partial sums: nsplit x rrmax x p_pad
     double *spart = nullptr; int64_t spstride = 0;   // backward-substitution partial sums, one slab per right-hand side
-    double *gpart = nullptr, *Hs = nullptr, *M2 = nullptr, *v11 = nullptr, *info = nullptr;
+    double *gpart = nullptr, *Hs = nullptr, *Ha = nullptr, *Hb = nullptr, *M2 = nullptr, *v11 = nullptr, *info = nullptr;
     int nsplit = 1;
     bool have_J = false;
     long long n_gram = 0;               // Gram launches so far
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[9] = {};
     bool ev_valid = false;
     double gram_flops = 0;
     bool did[8] = {};
@@ -97,13 +98,17 @@ size_t lb_carve(LbCtx* c, int64_t n, int64_t me, int64_t mi, int cap, int64_t p_
     const size_t oS = cv.take((size_t)n * cap * D);
     const size_t oY = cv.take((size_t)n * cap * D);
     const size_t oV = cv.take((size_t)n * rr * D);
-    const size_t oT = cv.take((size_t)n * rr * D);
+    const size_t oJu = cv.take((size_t)(n + 1) * D);
+    const size_t ou = cv.take((size_t)(p_pad + 1) * D);
     const size_t oP = cv.take(p > 0 ? (size_t)p_pad * rr * D : 256);
+    const size_t oR = cv.take(p > 0 ? (size_t)p_pad * rr * D : 256);
     const size_t opart = cv.take(p > 0 ? (size_t)nsplit * rr * (size_t)p_pad * D : 256);
     const int64_t spstride = ((p_pad + ROWCHUNK - 1) / ROWCHUNK + 2) * 1024;          // nchunk * nb, nb <= 1024
     const size_t osp = cv.take(p > 0 ? (size_t)rr * (size_t)spstride * D : 256);
     const size_t ogp = cv.take((size_t)LB_GBLK * (size_t)(2 * cap) * rr * D);
     const size_t oHs = cv.take((size_t)(2 * cap) * rr * D);
+    const size_t oHa = cv.take((size_t)(2 * cap) * rr * D);
+    const size_t oHb = cv.take((size_t)(2 * cap) * rr * D);
     const size_t oM2 = cv.take((size_t)(2 * cap) * (2 * cap) * D);
     const size_t ov = cv.take((size_t)(2 * cap + 8) * D);
     const size_t oi = cv.take(64);
@@ -111,9 +116,10 @@ size_t lb_carve(LbCtx* c, int64_t n, int64_t me, int64_t mi, int cap, int64_t p_
         c->JT = (double*)(base + oJT); c->Cs = (double*)(base + oCs); c->Gc = (double*)(base + oGc); c->ksplit = ks; c->g = (double*)(base + og); c->s = (double*)(base + os);
         c->lda = (double*)(base + ol); c->sig = (double*)(base + osg); c->dz = (double*)(base + odz);
         c->S = (double*)(base + oS); c->Y = (double*)(base + oY); c->V = (double*)(base + oV);
-        c->T = (double*)(base + oT); c->P = (double*)(base + oP); c->part = (double*)(base + opart);
+        c->Ju = (double*)(base + oJu); c->u = (double*)(base + ou); c->P = (double*)(base + oP); c->R = (double*)(base + oR);
+        c->part = (double*)(base + opart);
         c->spart = (double*)(base + osp); c->spstride = spstride;
-        c->gpart = (double*)(base + ogp); c->Hs = (double*)(base + oHs); c->M2 = (double*)(base + oM2);
+        c->gpart = (double*)(base + ogp); c->Hs = (double*)(base + oHs); c->Ha = (double*)(base + oHa); c->Hb = (double*)(base + oHb); c->M2 = (double*)(base + oM2);
         c->v11 = (double*)(base + ov); c->info = (double*)(base + oi);
     }
     return cv.off;
@@ -229,7 +235,7 @@ int pyipm_lbfgs_create(pyipm_lbfgs_ctx** out, int64_t n, int64_t me, int64_t mi,
     lb_carve(lb, n, me, mi, max_pairs, lb->p_pad, lb->n_pad, lb->ws);
     bool ok = true;
     if (lb->p > 0) ok = hipMemsetAsync(lb->JT, 0, (size_t)lb->p_pad * (size_t)lb->n_pad * sizeof(double), lb->stream) == hipSuccess;
-    for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreate(&lb->ev[i]) == hipSuccess;
+    for (int i = 0; i < 9 && ok; ++i) ok = hipEventCreate(&lb->ev[i]) == hipSuccess;
     if (!ok) { pyipm_lbfgs_destroy(reinterpret_cast<pyipm_lbfgs_ctx*>(lb)); return PYIPM_E_HIP; }
     *out = reinterpret_cast<pyipm_lbfgs_ctx*>(lb);
     return PYIPM_OK;
@@ -240,7 +246,7 @@ int pyipm_lbfgs_destroy(pyipm_lbfgs_ctx* h) {
     LbCtx* lb = LB(h);
     hipSetDevice(lb->device);
     hipStreamSynchronize(lb->stream);
-    for (int i = 0; i < 8; ++i) if (lb->ev[i]) hipEventDestroy(lb->ev[i]);
+    for (int i = 0; i < 9; ++i) if (lb->ev[i]) hipEventDestroy(lb->ev[i]);
     if (lb->gcx) pyipm_newton_destroy(reinterpret_cast<pyipm_newton_ctx*>(lb->gcx));
     if (lb->ws) hipFree(lb->ws);
     delete lb;
@@ -340,7 +346,7 @@ int pyipm_lbfgs_direction(pyipm_lbfgs_ctx* h, const double* g, const double* s, 
         // ---------------- unconstrained: dz = zeta g - [S, zeta Y] c
         if (m > 0) {
             hipLaunchKernelGGL(k_small_gram, dim3(LB_GBLK), dim3(256), (size_t)LB_GCH * (r + 1) * sizeof(double), st,
-                               lb->gpart, lb->V, rr, lb->V, rr, 1, r, n);
+                               lb->gpart, lb->V, (int64_t)rr, (int64_t)1, 1, lb->V, (int64_t)rr, (int64_t)1, 1, r, n);
             LB_KCHECK();
             hipLaunchKernelGGL(k_small_gram_reduce, grid1(r), dim3(256), 0, st, lb->Hs, lb->gpart, r, LB_GBLK);
             LB_KCHECK();
@@ -348,7 +354,7 @@ int pyipm_lbfgs_direction(pyipm_lbfgs_ctx* h, const double* g, const double* s, 
                                lb->M2, 1.0, lb->Hs, 1, r);
             LB_KCHECK();
         }
-        hipLaunchKernelGGL(k_lb_comb_x, grid1(n), dim3(256), 0, st, lb->dz, lb->V, rr, n, lb->v11, r, zeta);
+        hipLaunchKernelGGL(k_lb_comb_x, grid1(n), dim3(256), 0, st, lb->dz, lb->V, rr, n, lb->v11, r, zeta, (const double*)nullptr);
         LB_KCHECK();
     } else {
         const int64_t ldp = lb->p_pad;
@@ -381,40 +387,48 @@ int pyipm_lbfgs_direction(pyipm_lbfgs_ctx* h, const double* g, const double* s, 
             hipLaunchKernelGGL(k_tall_tn_reduce, dim3((unsigned)((ldp + 255) / 256), (unsigned)rr), dim3(256), 0, st,
                                lb->P, lb->part, ldp, rr, lb->nsplit);
             LB_KCHECK();
-            hipLaunchKernelGGL(k_lb_rhs, dim3((unsigned)((ldp + 255) / 256), (unsigned)rr), dim3(256), 0, st, lb->P, ldp, rr,
+            hipLaunchKernelGGL(k_lb_rhs, dim3((unsigned)((ldp + 255) / 256), (unsigned)rr), dim3(256), 0, st, lb->R, lb->P, ldp, rr,
                                p, me, lb->g, n, mi, lb->sig, zeta);
             LB_KCHECK();
         }
         LB_HIP(hipEventRecord(lb->ev[4], st));
         // ---- 2m+1 substitutions with the factor of zeta*G: column 0 -> y, column c -> X00_c
-        rc = solve_plain(gc, lb->P, false, rr, ldp, lb->spart, lb->spstride);
+        rc = solve_plain(gc, lb->R, false, rr, ldp, lb->spart, lb->spstride);
         if (rc) { lb->err = gc->err; return rc; }
         LB_HIP(hipEventRecord(lb->ev[5], st));
-        // ---- pass 2 over J:  T = J [y | X00] ;  E = [Zg_x | X01_x]
-        {
-            dim3 grid((unsigned)((n + LB_NNR - 1) / LB_NNR), (unsigned)((rr + LB_CC - 1) / LB_CC));
-            hipLaunchKernelGGL(k_tall_nn, grid, dim3(256), 0, st, lb->T, rr, lb->JT, ldp, lb->P, ldp, p, n);
-            LB_KCHECK();
-            hipLaunchKernelGGL(k_lb_E, grid1(n * rr), dim3(256), 0, st, lb->T, lb->V, rr, n, zeta, 1);
-            LB_KCHECK();
-        }
-        LB_HIP(hipEventRecord(lb->ev[6], st));
-        // ---- small system: (W'X01 - Minv) v11 = W'Zg_x
+        // ---- small system (W'X01 - Minv) v11 = W'Zg_x without touching J again:
+        //        W'X01_x = (W'W + P_w'X00) / zeta ,  W'Zg_x = (W'g_x - P_w'y) / zeta ,  P_w = J'W (columns 1.. of P)
         if (m > 0) {
             hipLaunchKernelGGL(k_small_gram, dim3(LB_GBLK), dim3(256), (size_t)LB_GCH * (r + rr) * sizeof(double), st,
-                               lb->gpart, lb->V, rr, lb->T, rr, rr, r, n);
+                               lb->gpart, lb->V, (int64_t)rr, (int64_t)1, 1, lb->V, (int64_t)rr, (int64_t)1, rr, r, n);
             LB_KCHECK();
-            hipLaunchKernelGGL(k_small_gram_reduce, grid1(r * rr), dim3(256), 0, st, lb->Hs, lb->gpart, r * rr, LB_GBLK);
+            hipLaunchKernelGGL(k_small_gram_reduce, grid1(r * rr), dim3(256), 0, st, lb->Ha, lb->gpart, r * rr, LB_GBLK);
+            LB_KCHECK();
+            hipLaunchKernelGGL(k_small_gram, dim3(LB_GBLK), dim3(256), (size_t)LB_GCH * (r + rr) * sizeof(double), st,
+                               lb->gpart, lb->P, (int64_t)1, ldp, 1, lb->R, (int64_t)1, ldp, rr, r, p);
+            LB_KCHECK();
+            hipLaunchKernelGGL(k_small_gram_reduce, grid1(r * rr), dim3(256), 0, st, lb->Hb, lb->gpart, r * rr, LB_GBLK);
+            LB_KCHECK();
+            hipLaunchKernelGGL(k_lb_hs, grid1(r * rr), dim3(256), 0, st, lb->Hs, lb->Ha, lb->Hb, r, rr, zeta);
             LB_KCHECK();
             hipLaunchKernelGGL(k_small_solve, dim3(1), dim3(64), 0, st, lb->v11, lb->info, lb->Hs, rr, 1, lb->M2, -1.0,
                                lb->Hs, rr, r);
             LB_KCHECK();
         }
-        // ---- dz = Zg - X10 v11
-        hipLaunchKernelGGL(k_lb_comb_x, grid1(n), dim3(256), 0, st, lb->dz, lb->T, rr, n, lb->v11, r, 1.0);
-        LB_KCHECK();
-        hipLaunchKernelGGL(k_lb_comb_ls, grid1(p), dim3(256), 0, st, lb->dz, lb->P, ldp, p, me, n, mi, lb->g, lb->sig,
+        LB_HIP(hipEventRecord(lb->ev[8], st));
+        // ---- u = y + X00 v11 ;  dz_lambda = u ;  dz_s = (g_s + u_i) / Sigma
+        hipLaunchKernelGGL(k_lb_comb_ls, grid1(p), dim3(256), 0, st, lb->dz, lb->u, lb->R, ldp, p, me, n, mi, lb->g, lb->sig,
                            lb->v11, r, flip ? -1.0 : 1.0);
+        LB_KCHECK();
+        // ---- pass 2 over J: ONE vector.  dz_x = (g_x - W v11 - J u) / zeta
+        {
+            int64_t nblk = (n + 15) / 16; if (nblk > 16384) nblk = 16384;
+            hipLaunchKernelGGL(k_jvec, dim3((unsigned)nblk), dim3(256), 0, st, lb->Ju, lb->JT, ldp, lb->u, p, n);
+            LB_KCHECK();
+        }
+        LB_HIP(hipEventRecord(lb->ev[6], st));
+        hipLaunchKernelGGL(k_lb_comb_x, grid1(n), dim3(256), 0, st, lb->dz, lb->V, rr, n, lb->v11, r, 1.0 / zeta,
+                           (const double*)lb->Ju);
         LB_KCHECK();
     }
     LB_HIP(hipEventRecord(lb->ev[7], st));
@@ -443,9 +457,11 @@ int pyipm_lbfgs_last_timings(pyipm_lbfgs_ctx* h, double out[8]) {
         LB_HIP(hipEventElapsedTime(&ms, lb->ev[4], lb->ev[5])); out[3] = ms;
         float a = 0.f, b = 0.f;
         LB_HIP(hipEventElapsedTime(&a, lb->ev[3], lb->ev[4]));
-        LB_HIP(hipEventElapsedTime(&b, lb->ev[5], lb->ev[6]));
+        LB_HIP(hipEventElapsedTime(&b, lb->ev[8], lb->ev[6]));
         out[4] = a + b;
-        LB_HIP(hipEventElapsedTime(&ms, lb->ev[6], lb->ev[7])); out[5] = ms;
+        LB_HIP(hipEventElapsedTime(&a, lb->ev[5], lb->ev[8]));
+        LB_HIP(hipEventElapsedTime(&b, lb->ev[6], lb->ev[7]));
+        out[5] = a + b;
         out[6] = lb->gram_flops;
         out[7] = (double)lb->n_gram;
     }

@@ -116,7 +116,7 @@ def main():
            "residual_H_dz_minus_g_rel": check}
     if p:
         out["gram_tflops"] = med["gram_flops"] / (med["gram_ms"] * 1e-3) / 1e12 if med["gram_ms"] > 0 else None
-        out["jacobian_pass_GBps"] = 2 * chunks * n * ((p + 127) // 128 * 128) * 8 / (med["jacobian_passes_ms"] * 1e-3) / 1e9
+        out["jacobian_pass_GBps"] = (chunks + 1) * n * ((p + 127) // 128 * 128) * 8 / (med["jacobian_passes_ms"] * 1e-3) / 1e9
         out["jacobian_bytes"] = n * p * 8
     if a.cpu_n:
         from oracle import lbfgs_oracle as lo
