@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="use the per-panel distributed driver even for 1 GPU")
     ap.add_argument("--force-lookahead", action="store_true", help="with --force-dist on one GPU: run the overlapped multi-GPU schedule")
     ap.add_argument("--opt", action="append", default=[], help="core option name=value (e.g. xcd_swizzle=0, lookahead=0)")
+    ap.add_argument("--no-lbfgs", action="store_true", help="skip the L-BFGS direction block (SURVEY 8f rank 4) of the report")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON): native libraries print there too (RCCL's version banner on
@@ -292,6 +293,8 @@ def main():
                                               "same_direction_bitwise": bool(torch.equal(dzd, dz1)),
                                               "note": "skip_zeros=0: every tile of the dense N^3/3 is computed; "
                                                       "`value` skips tiles the KKT block pattern makes exact zeros"}
+        if world == 1 and not use_dist and not args.no_lbfgs:
+            out["lbfgs_direction"] = lbfgs_block(device)
         if args.check and world == 1:
             g = core.residual()
             raw = core.solve(flip=False, refine=args.refine)
@@ -303,6 +306,55 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def lbfgs_block(device, n=131072, me=512, mi=1536, m=8, reps=3):
+    """One L-BFGS search direction (include/pyipm_lbfgs.h; pyipm.py:1184-1246) on synthetic QP-shaped data, outside the
+    timed region of `value`: ms per direction with a fresh Jacobian and with J'J reused, the Gram launch's rate, and the
+    size-independent check |H dz - g| / |g| for H = Z - U inv(M) U' applied matrix-free.  Details: tools/bench_lbfgs.py."""
+    import torch
+    from pyipm_amd.lbfgs import LbfgsCore
+    p, N = me + mi, n + 2 * mi + me
+    gen = torch.Generator(device=device); gen.manual_seed(1)
+    J = torch.randn((n, p), generator=gen, dtype=torch.float64, device=device) / np.sqrt(n)
+    S = torch.randn((n, m), generator=gen, dtype=torch.float64, device=device) / np.sqrt(n)
+    Mq = torch.randn((n, 8), generator=gen, dtype=torch.float64, device=device) / 3.0
+    Y = Mq @ (Mq.t() @ S) + 0.5 * S
+    SY = (S.t() @ Y).cpu().numpy()
+    SS, L, D = (S.t() @ S).cpu().numpy(), np.tril(SY, -1), np.diag(np.diag(SY))
+    zeta = float(SY[-1, -1] / SS[-1, -1])
+    u = lambda k, lo, hi: lo + (hi - lo) * torch.rand(k, generator=gen, dtype=torch.float64, device=device)   # noqa: E731
+    s, lda = u(mi, 0.5, 2.0), torch.cat([torch.randn(me, generator=gen, dtype=torch.float64, device=device), u(mi, 0.5, 2.0)])
+    g = torch.randn(N, generator=gen, dtype=torch.float64, device=device)
+    core = LbfgsCore(n, me, mi, m, device=device.index)
+
+    def run(restage):
+        ts = []
+        for it in range(reps + 1):
+            if restage:
+                core.stage_jacobian(J[:, :me], J[:, me:])
+            dz, st = core.direction(g, s, lda, zeta, S, Y, SS, L, D, reg=1e-12)
+            if it:
+                ts.append(core.last_timings())
+        return dz, st, {k: float(np.median([t[k] for t in ts])) for k in ts[0]}
+
+    dz, st, fresh = run(True)
+    _, _, reuse = run(False)
+    x, ds, dl = dz[:n], dz[n:n + mi], dz[n + mi:]
+    W = torch.cat([zeta * S, Y], dim=1)
+    Minv = torch.from_numpy(np.block([[zeta * SS, L], [L.T, -D]])).to(device)
+    res = torch.empty_like(dz)
+    res[:n] = zeta * x - W @ torch.linalg.solve(Minv, W.t() @ x) + J @ dl
+    res[n:n + mi] = lda[me:] / (s + np.finfo(float).eps) * ds - dl[me:]
+    low = J.t() @ x
+    low[me:] -= ds
+    res[n + mi:] = low
+    core.close()
+    return {"workload": "n=%d me=%d mi=%d m=%d (J = %.1f GB), synthetic" % (n, me, mi, m, n * p * 8 / 1e9),
+            "ms_per_direction": fresh["total_ms"], "ms_per_direction_reusing_gram": reuse["total_ms"],
+            "gram_ms": fresh["gram_ms"], "gram_tflops": fresh["gram_flops"] / (fresh["gram_ms"] * 1e-3) / 1e12,
+            "factor_ms": fresh["factor_ms"], "jacobian_passes_ms": fresh["jacobian_passes_ms"],
+            "residual_H_dz_minus_g_rel": float((res - g).norm() / g.norm()), "regularised": st["regularised"]}
 
 
 if __name__ == "__main__":
