@@ -159,6 +159,10 @@ class DistNewton(object):
                 break
             if work is not None:
                 work.wait()                                   # current stream waits for the message
+            if side is not None and self.owner(p) == self.rank:
+                # the owner factored panel p on the side stream; a panel without a message (slack block) has no
+                # work handle to order the main stream behind it
+                main.wait_stream(side)
             if self.owner(p) != self.rank and buf is not None:
                 core.panel_unpack(p, buf)
             nxt = p + 1
