@@ -292,3 +292,35 @@ def test_fused_forward_call_orders():
     gg = -orc.kkt_residual(qp["df"], qp["Je"], qp["Ji"], qp["ce"], qp["ci"], qp["s"], qp["lam"], qp["mu"], n, me, mi)
     ref = orc.flip_multipliers(np.linalg.solve(H, gg), n, mi)
     assert relerr(dz_shift.cpu().numpy(), ref) <= TOL_DZ
+
+
+def _ragged_shapes(count, seed):
+    """Seeded ragged shapes: block boundaries on and off the 64 / 128 / nb grid, empty blocks, tiny systems."""
+    rng = np.random.default_rng(seed)
+    edge = [1, 2, 3, 63, 64, 65, 127, 128, 129, 191, 192, 255, 256, 257, 320, 383, 385]
+    out = []
+    for i in range(count):
+        pick = lambda top: int(rng.choice(edge)) if rng.random() < 0.5 else int(rng.integers(1, top))   # noqa: E731
+        n = pick(420)
+        me = 0 if rng.random() < 0.25 else min(pick(200), n)          # at most n independent equalities
+        mi = 0 if rng.random() < 0.25 else pick(260)
+        out.append((n, me, mi, 1000 + i, int(rng.choice([128, 256, 512]))))
+    return out
+
+
+@pytest.mark.parametrize("n,me,mi,seed,nb", _ragged_shapes(40, 2024))
+def test_ragged_shapes_vs_oracle(n, me, mi, seed, nb):
+    """Forty seeded ragged (n, me, mi, nb) combinations against the oracle's LU and the eigen-inertia rule: the skipping
+    of structurally zero tiles, the closed-form slack panels and the group schedule all depend on where the block
+    boundaries fall relative to tiles, panels and groups."""
+    qp = make_qp(n, me, mi, seed)
+    core = _core(n, me, mi, nb=nb)
+    core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    dz, st = core.step(0.0, 0.0)
+    ref, _, Hc, g = orc.newton_step(qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"],
+                                    qp["mu"], n, me, mi, regularise=False)
+    assert st["n_neg"] == me + mi and st["n_zero"] == 0 and st["n_pos"] == n + mi
+    cond = np.linalg.cond(Hc)
+    assert relerr(dz.cpu().numpy(), ref) <= max(TOL_DZ, 20 * cond * np.finfo(float).eps)
+    core.close()
