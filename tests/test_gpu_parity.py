@@ -324,3 +324,27 @@ def test_ragged_shapes_vs_oracle(n, me, mi, seed, nb):
     cond = np.linalg.cond(Hc)
     assert relerr(dz.cpu().numpy(), ref) <= max(TOL_DZ, 20 * cond * np.finfo(float).eps)
     core.close()
+
+
+@pytest.mark.parametrize("n,me,mi,nb,tail_cols", [(1500, 700, 1111, 128, 2048), (2049, 0, 1500, 128, 1024), (3000, 1000, 0, 256, 4096),
+                                                  (1000, 333, 2500, 128, 0), (2600, 513, 1300, 256, 24576), (4100, 1, 2047, 512, 3000)])
+def test_ragged_multi_group_shapes_vs_oracle(n, me, mi, nb, tail_cols):
+    """Mid-size ragged systems (N up to 8200: tens of panels, both group sizes of the schedule in one factorisation via
+    `tail_cols`) against the oracle's LU; bitwise equal with and without the structural-zero skipping."""
+    import torch
+    qp = make_qp(n, me, mi, n % 97)
+    ref, _, Hc, g = orc.newton_step(qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"],
+                                    qp["mu"], n, me, mi, regularise=False)
+    out = []
+    for skip in (1, 0):
+        core = _core(n, me, mi, nb=nb)
+        core.set_option("tail_cols", tail_cols)
+        core.set_option("skip_zeros", skip)
+        core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+        core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+        dz, st = core.step(0.0, 0.0)
+        assert st["n_neg"] == me + mi and st["n_zero"] == 0
+        out.append(dz.clone())
+        core.close()
+    assert torch.equal(out[0], out[1])
+    assert relerr(out[0].cpu().numpy(), ref) <= 1e-9
