@@ -23,6 +23,17 @@
  *   Device KKT storage: column-major, lower triangle referenced, leading dimension
  *   Npad = roundup(N,128); rows/cols N..Npad-1 are an identity pad.  Read as a
  *   row-major array this is exactly triu(H) of the reference.
+ *
+ * Streams and synchronisation
+ *   Work is enqueued on the handle's stream (create / set_stream; NULL = the default stream; the
+ *   caller passes torch's current stream).  The library also runs panel work and the fused forward
+ *   substitution on internal streams, always joined back into the handle's stream before an entry
+ *   point's results are visible on it.  A call whose results go to DEVICE memory (PYIPM_MEM_DEVICE)
+ *   returns after enqueue: it is asynchronous with respect to the host and ordered on the stream.  A
+ *   call that returns data to the HOST — a PYIPM_MEM_HOST output, pyipm_factor_stats, step lengths,
+ *   timings — synchronises the stream before returning, and host INPUT buffers are never read after
+ *   the call returns (the library stages them).  Device input blocks passed to stage_blocks are NOT
+ *   copied: their pointers are retained until the next stage_blocks / destroy.
  */
 #ifndef PYIPM_NEWTON_H
 #define PYIPM_NEWTON_H
