@@ -88,6 +88,19 @@ int pyipm_lbfgs_direction(pyipm_lbfgs_ctx* h, const double* g, const double* s, 
  * [7] Gram launches since create ([1] is ~0 for a direction that reused J'J). */
 int pyipm_lbfgs_last_timings(pyipm_lbfgs_ctx* h, double out[8]);
 
+/* Row-sharded use (one process per GPU; the direction shards by rows of J with three real exchanges).
+ * Every rank creates its handle with n = ITS number of rows, stages its rows of Je / Ji and passes
+ * g = [its rows of g_x | g_s | g_lambda], its rows of S and Y; zeta, SS, L, D, s, lda, reg are replicated.  With a
+ * callback installed the library calls it — sum over ranks, in place, on device memory, enqueued on `stream` — on
+ *   (1) J'J                 p_pad^2 doubles, once per staging of the Jacobians,
+ *   (2) P = J'[g_x | W]     p_pad (2m+1) doubles per direction,
+ *   (3) W'[g_x | W]         2m (2m+1) doubles per direction            (unconstrained problems: W'g, 2m doubles),
+ * everything else is row-local (V, J u, dz_x) or replicated (G and its factor, the 2m x 2m system, dz_s, dz_lambda).
+ * dz returns [its rows of dz_x | dz_s | dz_lambda].  fn returns 0 on success (anything else -> PYIPM_E_COMM).
+ * pyipm_amd/lbfgs.py binds it to torch.distributed.all_reduce (backend "nccl" = RCCL). */
+typedef int (*pyipm_lbfgs_allreduce_fn)(void* user, double* device_buf, int64_t count, void* stream);
+int pyipm_lbfgs_set_allreduce(pyipm_lbfgs_ctx* h, pyipm_lbfgs_allreduce_fn fn, void* user);
+
 /* Pass an option of pyipm_newton_set_option through to the internal factorisation handle. */
 int pyipm_lbfgs_set_option(pyipm_lbfgs_ctx* h, const char* name, double value);
 

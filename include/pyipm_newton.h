@@ -51,6 +51,7 @@ extern "C" {
 #define PYIPM_E_NOMEM        -3   /* workspace missing or too small            */
 #define PYIPM_E_NONFINITE    -4   /* NaN/Inf met during factorisation          */
 #define PYIPM_E_NODEVICE     -5   /* no usable HIP device                      */
+#define PYIPM_E_COMM         -6   /* a caller-supplied exchange callback failed */
 
 #define PYIPM_MEM_DEVICE      0   /* pointer is device memory (e.g. torch.Tensor.data_ptr()) */
 #define PYIPM_MEM_HOST        1   /* pointer is host memory; the library stages it           */

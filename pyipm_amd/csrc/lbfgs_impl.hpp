@@ -28,6 +28,7 @@ struct LbCtx {
     double *spart = nullptr; int64_t spstride = 0;   // backward-substitution partial sums, one slab per right-hand side
     double *gpart = nullptr, *Hs = nullptr, *Ha = nullptr, *Hb = nullptr, *M2 = nullptr, *v11 = nullptr, *info = nullptr;
     int nsplit = 1;
+    pyipm_lbfgs_allreduce_fn allreduce = nullptr; void* allreduce_user = nullptr;   // row-sharded use
     bool have_J = false;
     long long n_gram = 0;               // Gram launches so far
     hipEvent_t ev[9] = {};
@@ -48,6 +49,15 @@ struct LbCtx {
 #define LB_KCHECK() LB_HIP(hipGetLastError())
 
 inline LbCtx* LB(pyipm_lbfgs_ctx* h) { return reinterpret_cast<LbCtx*>(h); }
+
+// sum over the ranks of a row-sharded problem (no-op without a callback)
+int lb_allreduce(LbCtx* lb, double* buf, int64_t count) {
+    if (!lb->allreduce || count <= 0) return 0;
+    if (lb->allreduce(lb->allreduce_user, buf, count, (void*)lb->stream) != 0) {
+        lb->err = "the all-reduce callback failed"; return PYIPM_E_COMM;
+    }
+    return 0;
+}
 
 // Split-K factor of the Gram launch.  J'J has only T = nt(nt+1)/2 output tiles (nt = p_pad/128) against 512 block
 // slots (2 per CU), while K = n is long: splitting K fills the machine and shortens the ragged last round.
@@ -174,6 +184,7 @@ int lb_factor_G(LbCtx* lb, double zeta, double reg_e, pyipm_factor_stats* st, bo
             gc->A = keep;
             if (rc) { lb->err = gc->err; return rc; }
         }
+        rc = lb_allreduce(lb, lb->Gc, cnt); if (rc) return rc;         // row-sharded: J'J = sum of the ranks' J_r'J_r
         lb->gram_valid = true;
         lb->n_gram++;
     }
@@ -265,6 +276,13 @@ int pyipm_lbfgs_set_stream(pyipm_lbfgs_ctx* h, void* stream) {
     return PYIPM_OK;
 }
 
+int pyipm_lbfgs_set_allreduce(pyipm_lbfgs_ctx* h, pyipm_lbfgs_allreduce_fn fn, void* user) {
+    if (!h) return PYIPM_E_BADARG;
+    LB(h)->allreduce = fn; LB(h)->allreduce_user = user;
+    LB(h)->gram_valid = false;
+    return PYIPM_OK;
+}
+
 int pyipm_lbfgs_set_option(pyipm_lbfgs_ctx* h, const char* name, double value) {
     if (!h) return PYIPM_E_BADARG;
     LbCtx* lb = LB(h);
@@ -350,6 +368,7 @@ int pyipm_lbfgs_direction(pyipm_lbfgs_ctx* h, const double* g, const double* s, 
             LB_KCHECK();
             hipLaunchKernelGGL(k_small_gram_reduce, grid1(r), dim3(256), 0, st, lb->Hs, lb->gpart, r, LB_GBLK);
             LB_KCHECK();
+            rc = lb_allreduce(lb, lb->Hs, r); if (rc) return rc;
             hipLaunchKernelGGL(k_small_solve, dim3(1), dim3(64), 0, st, lb->v11, lb->info, (const double*)nullptr, 0, 0,
                                lb->M2, 1.0, lb->Hs, 1, r);
             LB_KCHECK();
@@ -387,6 +406,7 @@ int pyipm_lbfgs_direction(pyipm_lbfgs_ctx* h, const double* g, const double* s, 
             hipLaunchKernelGGL(k_tall_tn_reduce, dim3((unsigned)((ldp + 255) / 256), (unsigned)rr), dim3(256), 0, st,
                                lb->P, lb->part, ldp, rr, lb->nsplit);
             LB_KCHECK();
+            rc = lb_allreduce(lb, lb->P, ldp * rr); if (rc) return rc;
             hipLaunchKernelGGL(k_lb_rhs, dim3((unsigned)((ldp + 255) / 256), (unsigned)rr), dim3(256), 0, st, lb->R, lb->P, ldp, rr,
                                p, me, lb->g, n, mi, lb->sig, zeta);
             LB_KCHECK();
@@ -404,6 +424,7 @@ int pyipm_lbfgs_direction(pyipm_lbfgs_ctx* h, const double* g, const double* s, 
             LB_KCHECK();
             hipLaunchKernelGGL(k_small_gram_reduce, grid1(r * rr), dim3(256), 0, st, lb->Ha, lb->gpart, r * rr, LB_GBLK);
             LB_KCHECK();
+            rc = lb_allreduce(lb, lb->Ha, (int64_t)r * rr); if (rc) return rc;
             hipLaunchKernelGGL(k_small_gram, dim3(LB_GBLK), dim3(256), (size_t)LB_GCH * (r + rr) * sizeof(double), st,
                                lb->gpart, lb->P, (int64_t)1, ldp, 1, lb->R, (int64_t)1, ldp, rr, r, p);
             LB_KCHECK();

@@ -36,7 +36,17 @@ _SIG = {
                                       c_void_p, c_int, c_int, POINTER(LbfgsStats)]),
     "pyipm_lbfgs_last_timings": (c_int, [c_void_p, POINTER(c_double)]),
     "pyipm_lbfgs_set_option": (c_int, [c_void_p, c_char_p, c_double]),
+    "pyipm_lbfgs_set_allreduce": (c_int, [c_void_p, c_void_p, c_void_p]),
 }
+ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_int64, c_void_p)
+
+
+class _RawDeviceArray(object):
+    """fp64 device memory owned by the library, exposed to torch without a copy."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": (int(count),), "typestr": "<f8",
+                                         "version": 2, "strides": None}
 _bound = None
 
 
@@ -67,7 +77,10 @@ class LbfgsCore(object):
         dz, st = core.direction(g, s, lda, zeta, S, Y, SS, L, D, reg=reg)     # RAW direction (flip=False), :1713
     """
 
-    def __init__(self, n, me, mi, max_pairs, device=None, nb=256):
+    def __init__(self, n, me, mi, max_pairs, device=None, nb=256, group=None, shard=False):
+        """shard=True (or a process group): this handle holds ``n`` ROWS of a row-sharded problem; the three sums over
+        the ranks (J'J, J'[g_x|W], W'[g_x|W]) go through ``torch.distributed.all_reduce`` on ``group`` — backend "nccl"
+        (= RCCL) in place on the device buffers, "gloo" staged through the host (tests)."""
         import torch
         self.torch = torch
         self.lib = load()
@@ -86,6 +99,34 @@ class LbfgsCore(object):
         if rc:
             raise NewtonError("pyipm_lbfgs_create failed: %s" % ERRORS.get(rc, rc))
         self.h = h
+        self.group, self.bytes_reduced, self._cb = group, 0, None
+        if shard or group is not None:
+            self._install_allreduce()
+
+    def _install_allreduce(self):
+        import torch.distributed as dist
+        torch = self.torch
+        if not dist.is_initialized():
+            raise NewtonError("row-sharded L-BFGS needs an initialised torch.distributed process group")
+        staged = dist.get_backend(self.group) == "gloo"
+
+        def cb(user, ptr, count, stream):
+            try:
+                t = torch.as_tensor(_RawDeviceArray(ptr, count), device=self.device)
+                if staged:
+                    hbuf = t.cpu()                                   # synchronises the stream
+                    dist.all_reduce(hbuf, op=dist.ReduceOp.SUM, group=self.group)
+                    t.copy_(hbuf)
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)     # ordered on the current stream
+                self.bytes_reduced += 8 * int(count)
+                return 0
+            except Exception as e:                                   # nothing may propagate through the C frames
+                self._cb_error = e
+                return 1
+
+        self._cb = ALLREDUCE_FN(cb)                                  # keep alive as long as the handle
+        self._ck(self.lib.pyipm_lbfgs_set_allreduce(self.h, ctypes.cast(self._cb, c_void_p), None))
 
     def _ck(self, rc):
         if rc:

@@ -22,7 +22,8 @@ MEM_DEVICE, MEM_HOST = 0, 1
 TILE, PAD = 64, 128
 
 ERRORS = {0: "ok", -1: "bad argument / call order", -2: "HIP runtime error", -3: "workspace too small",
-          -4: "NaN/Inf met during factorisation", -5: "no usable HIP device"}
+          -4: "NaN/Inf met during factorisation", -5: "no usable HIP device",
+          -6: "a caller-supplied exchange callback failed"}
 
 
 class FactorStats(ctypes.Structure):

@@ -187,3 +187,50 @@ class ModelCore(object):
         for t in range(nbw // tb - 1, -1, -1):
             j0 = c0 + t * tb
             x[j0:j0 + tb] -= self.A[j0 + tb:, lc + t * tb: lc + (t + 1) * tb].T @ x[j0 + tb:]
+
+
+def lbfgs_direction_row_shard(allreduce, Je, Ji, g_loc, s, lda, zeta, S, Y, SS, L, D, me, mi):
+    """NumPy model of ONE RANK of the row-sharded L-BFGS direction, with the three sums of include/pyipm_lbfgs.h
+    (pyipm_lbfgs_set_allreduce) at the same places and on the same quantities as pyipm_amd/csrc/lbfgs_impl.hpp.
+    Inputs are this rank's rows (Je, Ji, S, Y and the x part of g_loc = [g_x rows | g_s | g_lambda]); returns
+    [dz_x rows | dz_s | dz_lambda], RAW.  `allreduce(array)` sums over the ranks in place."""
+    import scipy.linalg
+    n = S.shape[0]
+    m = S.shape[1]
+    p, r = me + mi, 2 * m
+    gx, gs, gl = g_loc[:n], g_loc[n:n + mi], g_loc[n + mi:]
+    if p == 0:
+        W = np.concatenate([S, zeta * Y], axis=1)
+        t = W.T @ gx
+        allreduce(t)                                                   # (3') W'g
+        if m == 0:
+            return zeta * gx
+        K = np.block([[np.zeros((m, m)), L], [L.T, D + zeta * SS]])
+        return zeta * gx - W @ scipy.linalg.solve(K, t)
+    J = np.concatenate([c for c in (Je, Ji) if c is not None], axis=1)
+    sig = lda[me:] / (s + np.finfo(float).eps) if mi else np.zeros(0)
+    G = J.T @ J
+    allreduce(G)                                                       # (1) J'J
+    G = G + np.diag(np.concatenate([np.zeros(me), zeta / sig]))        # zeta * G of the reference
+    W = np.concatenate([zeta * S, Y], axis=1)
+    V = np.concatenate([gx[:, None], W], axis=1)
+    P = J.T @ V
+    allreduce(P)                                                       # (2) J'[g_x | W]
+    R = np.empty_like(P)
+    R[:, 0] = P[:, 0] - zeta * gl
+    if mi:
+        R[me:, 0] -= zeta * gs / sig
+    R[:, 1:] = -P[:, 1:]
+    R = scipy.linalg.solve(G, R, assume_a="pos")
+    v11 = np.zeros(0)
+    if m:
+        Ha = W.T @ V
+        allreduce(Ha)                                                  # (3) W'[g_x | W]
+        Hb = P[:, 1:].T @ R
+        Hs = np.concatenate([(Ha[:, :1] - Hb[:, :1]), Ha[:, 1:] + Hb[:, 1:]], axis=1) / zeta
+        Minv = np.block([[zeta * SS, L], [L.T, -D]])
+        v11 = scipy.linalg.solve(Hs[:, 1:] - Minv, Hs[:, 0])
+    u = R[:, 0] + (R[:, 1:] @ v11 if m else 0.0)
+    dzx = (gx - (W @ v11 if m else 0.0) - J @ u) / zeta
+    dzs = (gs + u[me:]) / sig if mi else np.zeros(0)
+    return np.concatenate([dzx, dzs, u])

@@ -31,7 +31,7 @@ def test_library_exports_every_lbfgs_symbol():
     from pyipm_amd import newton, lbfgs
     assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["pyipm_lbfgs.h", "pyipm_newton.h"]
     names = _header_functions("pyipm_lbfgs.h")
-    assert len(names) == 9
+    assert len(names) == 10
     lib = ctypes.CDLL(newton.LIB_PATH)
     for name in names:
         assert hasattr(lib, name), "missing export: " + name

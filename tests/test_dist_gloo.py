@@ -66,3 +66,72 @@ def test_dist_newton_gloo(world, shape, nb, lookahead):
         cols += ncl
     assert cols == ((N + 127) // 128) * 128                               # every column owned exactly once
     assert out[0][4] == out[1][4] > 0                                     # same bytes on the wire on every rank
+
+
+# ---------------------------------------------------------------------- row-sharded L-BFGS direction
+def _lbfgs_case(n, me, mi, m, seed):
+    from oracle import lbfgs_oracle as lo
+    rng = np.random.default_rng(seed)
+    qp = make_qp(n, me, mi, seed)
+    eps = float(np.finfo(float).eps)
+    zeta, S, Y, SS, L, D, fail = lo.lbfgs_init(n)
+    x_old = rng.standard_normal(n)
+    Mq = rng.standard_normal((n, 8)) / 3.0
+    for _ in range(m):
+        x_new = x_old + rng.standard_normal(n) / np.sqrt(n)
+        hv = lambda v: Mq @ (Mq.T @ v) + 0.5 * v           # noqa: E731
+        zeta, S, Y, SS, L, D, fail = lo.lbfgs_update(x_old, x_new, -hv(x_old), -hv(x_new), zeta, S, Y, SS, L, D, fail,
+                                                     n, bool(me or mi), max(m, 1), eps)
+        x_old = x_new
+    g = rng.standard_normal(n + 2 * mi + me)
+    return qp, zeta, S, Y, SS, L, D, g
+
+
+def _lbfgs_worker(rank, world, port, shape, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from backends import lbfgs_direction_row_shard
+        n, me, mi, m, seed = shape
+        qp, zeta, S, Y, SS, L, D, g = _lbfgs_case(n, me, mi, m, seed)
+        cut = [(n * r) // world for r in range(world + 1)]
+        a, b = cut[rank], cut[rank + 1]
+        nbytes = [0]
+
+        def allreduce(arr):
+            t = torch.from_numpy(arr)                      # shares memory: in place
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            nbytes[0] += arr.size * 8
+
+        dz = lbfgs_direction_row_shard(allreduce, qp["Je"][a:b] if me else None, qp["Ji"][a:b] if mi else None,
+                                       np.concatenate([g[a:b], g[n:]]), qp["s"] if mi else np.zeros(0),
+                                       qp["lam"] if (me or mi) else np.zeros(0), zeta, S[a:b], Y[a:b], SS, L, D, me, mi)
+        out[rank] = (a, b, dz, nbytes[0])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape", [(2, (300, 30, 70, 5, 1)), (3, (250, 0, 60, 4, 2)), (2, (200, 40, 0, 3, 3)),
+                                         (4, (320, 0, 0, 6, 4)), (2, (150, 20, 30, 0, 5))])
+def test_lbfgs_row_sharding_gloo(world, shape):
+    """The sharding scheme of the L-BFGS direction (rows of J, three all-reduces: include/pyipm_lbfgs.h) on CPU: a
+    NumPy model of one rank (tests/backends.py) with the sums at the places the HIP library calls its callback,
+    against the oracle's unsharded direction.  The HIP ranks themselves are covered by tests/test_gpu_lbfgs.py."""
+    from oracle import lbfgs_oracle as lo
+    n, me, mi, m, seed = shape
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_lbfgs_worker, args=(world, _free_port(), shape, out), nprocs=world, join=True)
+    qp, zeta, S, Y, SS, L, D, g = _lbfgs_case(n, me, mi, m, seed)
+    ref = lo.direction(g, zeta, S, Y, SS, L, D, Je=qp["Je"] if me else None, Ji=qp["Ji"] if mi else None,
+                       s=qp["s"] if mi else np.zeros(0), lda=qp["lam"] if (me or mi) else np.zeros(0), reg=0.0)
+    scale = np.linalg.norm(ref)
+    p, r, rr = me + mi, 2 * m, 2 * m + 1
+    for rk in range(world):
+        a, b, dz, nbytes = out[rk]
+        assert np.linalg.norm(dz[:b - a] - ref[a:b]) <= 1e-10 * scale
+        assert np.linalg.norm(dz[b - a:] - ref[n:]) <= 1e-10 * scale
+        assert nbytes == 8 * ((p * p + p * rr + (r * rr if m else 0)) if p else r)

@@ -259,3 +259,77 @@ def test_large_direction_satisfies_the_quasi_newton_system():
         assert float((res - g).norm() / g.norm()) <= 1e-10
     assert core.last_timings()["gram_launches"] == 1
     core.close()
+
+
+# ---------------------------------------------------------------------- row-sharded direction (several ranks)
+def _shard_problem(n, me, mi, m, seed):
+    from pyipm_amd.problems import make_qp
+    rng = np.random.default_rng(seed)
+    qp = make_qp(n, me, mi, seed)
+    zeta, S, Y, SS, L, D = _storage(n, m, rng, bool(me or mi), max(m, 1))
+    g = rng.standard_normal(n + 2 * mi + me)
+    s = qp["s"] if mi else np.zeros(0)
+    lda = qp["lam"] if (me or mi) else np.zeros(0)
+    return qp, zeta, S, Y, SS, L, D, g, s, lda
+
+
+def _shard_worker(rank, world, port, shape, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyipm_amd.lbfgs import LbfgsCore
+        n, me, mi, m, seed = shape
+        qp, zeta, S, Y, SS, L, D, g, s, lda = _shard_problem(n, me, mi, m, seed)
+        cut = [(n * r) // world for r in range(world + 1)]          # uneven row blocks
+        a, b = cut[rank], cut[rank + 1]
+        core = LbfgsCore(b - a, me, mi, max(m, 1), device=0, shard=True)
+        core.stage_jacobian(qp["Je"][a:b] if me else None, qp["Ji"][a:b] if mi else None)
+        res = []
+        for trial in range(2):                                        # second direction reuses the reduced J'J
+            gl = np.concatenate([g[a:b], g[n:]]) * (1.0 + trial)
+            dz, st = core.direction(gl, s, lda, zeta, S[a:b], Y[a:b], SS, L, D, reg=1e-12)
+            res.append(dz.cpu().numpy())
+        torch.cuda.synchronize()
+        out[rank] = (a, b, res, st, core.bytes_reduced, core.last_timings()["gram_launches"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape", [(2, (1000, 60, 140, 5, 1)), (3, (777, 0, 130, 4, 2)), (2, (640, 90, 0, 3, 3)),
+                                         (3, (900, 0, 0, 6, 4)), (2, (500, 40, 80, 0, 5))])
+def test_row_sharded_direction_on_one_gpu(world, shape):
+    """The direction shards by rows of J with three sums over the ranks (pyipm_lbfgs_set_allreduce).  The box has one
+    GPU, so the ranks share it and the sums ride a gloo group through the host — the kernels, the callback points and
+    the buffers are those an RCCL group would use.  Every rank must return its rows of dz_x and the replicated
+    dz_s / dz_lambda of the unsharded direction."""
+    import torch.multiprocessing as mp
+    from oracle import lbfgs_oracle as lo
+    from test_gpu_dist import _free_port
+    n, me, mi, m, seed = shape
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_shard_worker, args=(world, _free_port(), shape, out), nprocs=world, join=True)
+    qp, zeta, S, Y, SS, L, D, g, s, lda = _shard_problem(n, me, mi, m, seed)
+    p_pad = ((me + mi + 127) // 128) * 128 if (me + mi) else 0
+    r, rr = 2 * m, 2 * m + 1
+    for trial in range(2):
+        ref = lo.direction(g * (1.0 + trial), zeta, S, Y, SS, L, D, Je=qp["Je"] if me else None,
+                           Ji=qp["Ji"] if mi else None, s=s, lda=lda, reg=1e-12)
+        scale = np.linalg.norm(ref)
+        for rk in range(world):
+            a, b, res, st, nbytes, ngram = out[rk]
+            dz = res[trial]
+            assert np.linalg.norm(dz[:b - a] - ref[a:b]) <= 1e-9 * scale
+            assert np.linalg.norm(dz[b - a:] - ref[n:]) <= 1e-9 * scale
+            if rk:
+                assert np.array_equal(dz[b - a:], out[0][2][trial][out[0][1] - out[0][0]:])     # replicated rows: bit for bit
+    for rk in range(world):
+        a, b, res, st, nbytes, ngram = out[rk]
+        if me + mi:
+            assert ngram == 1                                         # J'J reduced once, reused by the second direction
+            assert nbytes == 8 * (p_pad * p_pad + 2 * (p_pad * rr + r * rr))
+        else:
+            assert nbytes == 8 * 2 * r
