@@ -124,3 +124,50 @@ def test_two_handles_on_two_streams_interleaved():
         assert torch.equal(dz, ref)
     for c in cores:
         c.close()
+
+
+def test_lbfgs_host_pointers_match_oracle():
+    """include/pyipm_lbfgs.h the way INTEGRATION.md section 2b uses it: NumPy host pointers for everything
+    (PYIPM_MEM_HOST), padded leading dimensions, the timings entry point and a user callback that must NOT be called
+    when none is installed."""
+    from oracle import lbfgs_oracle as lo
+    from pyipm_amd import lbfgs
+    lib = lbfgs.load()
+    n, me, mi, m = 500, 40, 110, 5
+    N = n + 2 * mi + me
+    qp = make_qp(n, me, mi, seed=77)
+    rng = np.random.default_rng(3)
+    S = rng.standard_normal((n, m)) / np.sqrt(n)
+    Y = 0.7 * S + 0.05 * rng.standard_normal((n, 4)) @ (rng.standard_normal((4, n)) @ S)
+    SY = S.T @ Y
+    SS, L, D = np.ascontiguousarray(S.T @ S), np.ascontiguousarray(np.tril(SY, -1)), np.ascontiguousarray(np.diag(np.diag(SY)))
+    zeta = float(SY[-1, -1] / SS[-1, -1])
+    g = rng.standard_normal(N)
+    h = ctypes.c_void_p()
+    assert lib.pyipm_lbfgs_create(ctypes.byref(h), n, me, mi, m + 2, 0, 0, None) == 0
+    Je = np.ascontiguousarray(qp["Je"])
+    Jipad = np.zeros((n, mi + 5)); Jipad[:, :mi] = qp["Ji"]              # padded leading dimension
+    Spad = np.zeros((n, m + 3)); Spad[:, :m] = S
+    Yc = np.ascontiguousarray(Y)
+    dz = np.empty(N)
+    st = lbfgs.LbfgsStats()
+    # direction before staging: reported, not thrown
+    rc = lib.pyipm_lbfgs_direction(h, _p(g), _p(qp["s"]), _p(qp["lam"]), zeta, m, _p(Spad), m + 3, _p(Yc), m, _p(SS), _p(L),
+                                   _p(D), 1e-12, float(np.finfo(float).eps), _p(dz), 0, HOST, ctypes.byref(st))
+    assert rc == -1 and b"stage the Jacobians" in lib.pyipm_lbfgs_last_error(h)
+    assert lib.pyipm_lbfgs_stage_jacobian(h, _p(Je), me, _p(Jipad), mi + 5, HOST) == 0
+    for flip in (0, 1):
+        rc = lib.pyipm_lbfgs_direction(h, _p(g), _p(qp["s"]), _p(qp["lam"]), zeta, m, _p(Spad), m + 3, _p(Yc), m, _p(SS),
+                                       _p(L), _p(D), 1e-12, float(np.finfo(float).eps), _p(dz), flip, HOST, ctypes.byref(st))
+        assert rc == 0, lib.pyipm_lbfgs_last_error(h)
+        ref = lo.direction(g, zeta, S, Y, SS, L, D, Je=qp["Je"], Ji=qp["Ji"], s=qp["s"], lda=qp["lam"], reg=1e-12)
+        if flip:
+            ref = orc.flip_multipliers(ref, n, mi)
+        assert np.linalg.norm(dz - ref) <= 1e-9 * np.linalg.norm(ref)
+        assert st.m == m and st.regularised == 0 and st.n_neg == 0 and st.n_zero == 0
+    tm = (ctypes.c_double * 8)()
+    assert lib.pyipm_lbfgs_last_timings(h, tm) == 0
+    assert tm[0] > 0.0 and tm[7] == 1.0                                  # one Gram launch for the two directions
+    assert lib.pyipm_lbfgs_set_option(h, b"block_refine", 1.0) == 0
+    assert lib.pyipm_lbfgs_set_option(h, b"no_such_option", 1.0) != 0
+    assert lib.pyipm_lbfgs_destroy(h) == 0
