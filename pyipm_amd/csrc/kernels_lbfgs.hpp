@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64) void k_small_solve(double* __restrict__ x, doub
             const int ow = __shfl_xor(who, off, 64);
             if (ob > best || (ob == best && ow < who)) { best = ob; who = ow; }
         }
-        if (best < pmin) pmin = best;
+        { const double bm = best > 0.0 ? best : 0.0; if (bm < pmin) pmin = bm; }      // NaN after a zero pivot counts as 0
         if (who != k) {                         // swap rows k and who: lane j moves column j
             if (i < r) { const double t = a[k][i]; a[k][i] = a[who][i]; a[who][i] = t; }
             if (i == 0) { const double t = b[k]; b[k] = b[who]; b[who] = t; }

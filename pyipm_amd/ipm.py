@@ -137,6 +137,9 @@ class HipLbfgsBackend(object):
             self.core.stage_jacobian(Je, Ji)
             self.n_staged += 1
         dz, self.last_stats = self.core.direction(g, s, lda, zeta, S, Y, SS, L, D, reg=reg, eps=eps, flip=False)
+        if S.shape[1] and self.last_stats["small_pivot_min"] == 0.0:
+            # the reference's sym_solve raises on an exactly singular system (scipy.linalg.solve, pyipm.py:18-20)
+            raise np.linalg.LinAlgError("L-BFGS: the 2m x 2m system is singular (zero pivot)")
         return dz.cpu().numpy()
 
 

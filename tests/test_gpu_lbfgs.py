@@ -333,3 +333,24 @@ def test_row_sharded_direction_on_one_gpu(world, shape):
             assert nbytes == 8 * (p_pad * p_pad + 2 * (p_pad * rr + r * rr))
         else:
             assert nbytes == 8 * 2 * r
+
+
+def test_singular_small_system_is_reported_and_raised():
+    """Displacements orthogonal to their gradient changes (S'Y = 0) make the 2m x 2m system exactly singular: the
+    C-ABI reports a zero pivot (stats, NaN direction, return code 0 — the host decides), the host backend raises like
+    scipy's solve does in the reference (pyipm.py:18-20)."""
+    from pyipm_amd.ipm import HipLbfgsBackend
+    n, m = 50, 2
+    rng = np.random.default_rng(0)
+    S, Y = np.zeros((n, m)), np.zeros((n, m))
+    S[0, 0] = S[1, 1] = 1.0
+    Y[2, 0] = Y[3, 1] = 1.0
+    SS, L, D = Y.T @ Y, np.triu(S.T @ Y), np.diag(np.diag(S.T @ Y))
+    g = rng.standard_normal(n)
+    core = _core(n, 0, 0, m)
+    dz, st = core.direction(g, np.zeros(0), np.zeros(0), 1.0, S, Y, SS, L, D)
+    assert st["small_pivot_min"] == 0.0 and not np.all(np.isfinite(dz.cpu().numpy()))
+    core.close()
+    be = HipLbfgsBackend(n, 0, 0, m, device=0)
+    with pytest.raises(np.linalg.LinAlgError):
+        be.lbfgs_direction(None, None, np.zeros(0), np.zeros(0), g, 1.0, S, Y, SS, L, D, 0.0, EPS)
