@@ -131,7 +131,12 @@ class LbfgsCore(object):
     def _ck(self, rc):
         if rc:
             msg = self.lib.pyipm_lbfgs_last_error(self.h)
-            raise NewtonError("%s: %s" % (ERRORS.get(rc, rc), msg.decode() if msg else ""))
+            err = NewtonError("%s: %s" % (ERRORS.get(rc, rc), msg.decode() if msg else ""))
+            cause = getattr(self, "_cb_error", None)          # what the all-reduce callback swallowed, if that was it
+            self._cb_error = None
+            if cause is not None:
+                raise err from cause
+            raise err
 
     def _dev(self, a, shape):
         torch = self.torch
