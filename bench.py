@@ -353,7 +353,18 @@ def lbfgs_block(device, n=131072, me=512, mi=1536, m=8, reps=3):
     low[me:] -= ds
     res[n + mi:] = low
     core.close()
-    return {"workload": "n=%d me=%d mi=%d m=%d (J = %.1f GB), synthetic" % (n, me, mi, m, n * p * 8 / 1e9),
+    # CPU leg (part of this file's cpu_baseline duty): the reference's arithmetic as restated by oracle/lbfgs_oracle.py on a
+    # bounded sample — same p and m, fewer rows: its B' diag(1/A) is a DENSE (n+mi)^2 product (pyipm.py:1102-1104),
+    # quadratic in n, so it cannot run at the device size at all
+    from oracle import lbfgs_oracle as lo
+    nc = 8192
+    t0 = time.perf_counter()
+    lo.direction(np.concatenate([g[:nc].cpu().numpy(), g[n:].cpu().numpy()]), zeta, S[:nc].cpu().numpy(), Y[:nc].cpu().numpy(),
+                 SS, L, D, Je=J[:nc, :me].cpu().numpy() * np.sqrt(n / nc), Ji=J[:nc, me:].cpu().numpy() * np.sqrt(n / nc),
+                 s=s.cpu().numpy(), lda=lda.cpu().numpy(), reg=1e-12)
+    cpu = {"seconds_per_direction": time.perf_counter() - t0, "n": nc, "me": me, "mi": mi, "m": m, "kind": "port",
+           "cores": os.cpu_count(), "sample": "oracle/lbfgs_oracle.py, same p and m, n = %d rows of the %d" % (nc, n)}
+    return {"workload": "n=%d me=%d mi=%d m=%d (J = %.1f GB), synthetic" % (n, me, mi, m, n * p * 8 / 1e9), "cpu_baseline": cpu,
             "ms_per_direction": fresh["total_ms"], "ms_per_direction_reusing_gram": reuse["total_ms"],
             "gram_ms": fresh["gram_ms"], "gram_tflops": fresh["gram_flops"] / (fresh["gram_ms"] * 1e-3) / 1e12,
             "factor_ms": fresh["factor_ms"], "jacobian_passes_ms": fresh["jacobian_passes_ms"],

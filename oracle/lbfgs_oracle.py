@@ -1,6 +1,6 @@
 """CPU restatement of the reference's L-BFGS search direction.  TEST INFRASTRUCTURE ONLY.
 
-Not part of the product: only ``tests/`` and the tools' CPU comparison legs may import this module
+Not part of the product: only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s CPU-baseline leg import this module
 (the product's L-BFGS direction is ``pyipm_lbfgs_direction`` in the HIP library and fails loudly
 without it).  Each function names the reference lines it follows; terminal arithmetic is the same
 SciPy routine the reference reaches through Aesara (``scipy.linalg.solve(assume_a='gen')`` for

@@ -6,7 +6,7 @@
 Inputs are synthetic and generated on the device (J ~ N(0,1)/sqrt(n), storage from random displacement pairs
 of positive curvature).  The check is size-independent: the direction must satisfy H dz = g for
 H = Z - U inv(M) U' (the matrix of pyipm.py:1036-1052), applied matrix-free with torch as the checker.
-The CPU leg times oracle/lbfgs_oracle.py (the reference's NumPy/SciPy arithmetic) on a bounded sample.
+The CPU comparison (the reference's arithmetic, oracle/lbfgs_oracle.py) lives in bench.py --extras: tools do not touch oracle/.
 Prints one JSON line.
 """
 import argparse
@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--mi", type=int, default=3072)
     ap.add_argument("--m", type=int, default=8)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--cpu-n", type=int, default=16384, help="n of the CPU oracle sample (0 = skip)")
+    ap.add_argument("--cpu-n", type=int, default=0, help="ignored (kept for old command lines): the CPU leg is bench.py --extras")
     a = ap.parse_args()
     import torch
     from pyipm_amd.lbfgs import LbfgsCore
@@ -118,17 +118,6 @@ def main():
         out["gram_tflops"] = med["gram_flops"] / (med["gram_ms"] * 1e-3) / 1e12 if med["gram_ms"] > 0 else None
         out["jacobian_pass_GBps"] = (chunks + 1) * n * ((p + 127) // 128 * 128) * 8 / (med["jacobian_passes_ms"] * 1e-3) / 1e9
         out["jacobian_bytes"] = n * p * 8
-    if a.cpu_n:
-        from oracle import lbfgs_oracle as lo
-        nc = min(a.cpu_n, n)
-        Jc = J[:nc].cpu().numpy() * np.sqrt(n / nc) if p else None
-        z2, S2, Y2, SS2, L2, D2 = storage(nc, m, 1, bool(p))
-        g2 = np.concatenate([g[:nc], g[n:]])
-        t0 = time.perf_counter()
-        lo.direction(g2, z2, S2, Y2, SS2, L2, D2, Je=Jc[:, :me] if me else None, Ji=Jc[:, me:] if mi else None, s=s,
-                     lda=lda, reg=1e-12)
-        out["cpu_oracle"] = {"n": nc, "seconds": time.perf_counter() - t0, "cores": os.cpu_count(), "kind": "port",
-                             "note": "same p and m, smaller n: the reference's literal arithmetic multiplies by a DENSE (n+mi)x(n+mi) diag(1/A) (pyipm.py:1103), quadratic in n; it cannot be run at the device size"}
     print(json.dumps(out))
 
 
