@@ -354,3 +354,42 @@ def test_singular_small_system_is_reported_and_raised():
     be = HipLbfgsBackend(n, 0, 0, m, device=0)
     with pytest.raises(np.linalg.LinAlgError):
         be.lbfgs_direction(None, None, np.zeros(0), np.zeros(0), g, 1.0, S, Y, SS, L, D, 0.0, EPS)
+
+
+def _ragged_lbfgs_shapes(count, seed):
+    rng = np.random.default_rng(seed)
+    edge = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257]
+    out = []
+    for i in range(count):
+        pick = lambda top: int(rng.choice(edge)) if rng.random() < 0.5 else int(rng.integers(1, top))   # noqa: E731
+        n = pick(700) + 8
+        me = 0 if rng.random() < 0.3 else min(pick(140), n - 1)
+        mi = 0 if rng.random() < 0.3 else pick(300)
+        m = int(rng.integers(0, 9))
+        out.append((n, me, mi, m, 500 + i))
+    return out
+
+
+@pytest.mark.parametrize("n,me,mi,m,seed", _ragged_lbfgs_shapes(24, 77))
+def test_ragged_lbfgs_shapes_vs_oracle(n, me, mi, m, seed):
+    """Seeded ragged (n, me, mi, m): constraint counts on and off the 64 / 128 grid of the internal factorisation, empty
+    blocks, empty storage, n barely above me — against the oracle."""
+    from oracle import lbfgs_oracle as lo
+    from pyipm_amd.problems import make_qp
+    rng = np.random.default_rng(seed)
+    qp = make_qp(n, me, mi, seed % 50)
+    zeta, S, Y, SS, L, D = _storage(n, m, rng, bool(me or mi), max(m, 1))
+    m_eff = S.shape[1]
+    g = rng.standard_normal(n + 2 * mi + me)
+    s = qp["s"] if mi else np.zeros(0)
+    lda = qp["lam"] if (me or mi) else np.zeros(0)
+    ref = lo.direction(g, zeta, S, Y, SS, L, D, Je=qp["Je"] if me else None, Ji=qp["Ji"] if mi else None, s=s, lda=lda,
+                       reg=1e-12)
+    core = _core(n, me, mi, max(m_eff, 1), nb=128)
+    core.stage_jacobian(qp["Je"] if me else None, qp["Ji"] if mi else None)
+    dz, st = core.direction(g, s, lda, zeta, S, Y, SS, L, D, reg=1e-12)
+    assert st["m"] == m_eff and st["regularised"] == 0
+    # the constraint-space system is a Gram matrix: its condition number is the square of J's
+    tol = 1e-9 if (me + mi) * 4 <= n else 1e-6
+    assert _rel(dz.cpu().numpy(), ref) <= tol, st
+    core.close()
