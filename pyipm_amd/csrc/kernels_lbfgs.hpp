@@ -44,7 +44,43 @@ __global__ __launch_bounds__(256) void k_lb_sigma(double* __restrict__ sig, cons
 }
 
 // part[(split*rr + c)*ldp + j] = sum_{k in split} JT[j + k*ldj] * V[k*rr + c]      (J'V, one thread per j)
-// grid (ldp/256, nsplit, ceil(rr/LB_CC))
+// grid (ldp/256, nsplit, ceil(rr/LB_CC)).  The V rows are wave-uniform (scalar loads, one wide load per row when the
+// chunk is full); the next four J values are already in flight while the current four are consumed.
+template <bool FULL>
+__device__ __forceinline__ void tall_tn_body(double* __restrict__ part, int64_t ldp, const double* __restrict__ JT,
+                                             int64_t ldj, const double* __restrict__ V, int rr, int64_t k0, int64_t k1,
+                                             int64_t j, int c0, int nc)
+{
+    double acc[LB_CC];
+    #pragma unroll
+    for (int u = 0; u < LB_CC; ++u) acc[u] = 0.0;
+    int64_t k = k0;
+    if (k + 4 <= k1) {
+        const double* col = JT + j + k * ldj;
+        double a0 = col[0], a1 = col[ldj], a2 = col[2 * ldj], a3 = col[3 * ldj];
+        for (; k + 4 <= k1; k += 4) {
+            const int64_t kn = (k + 8 <= k1) ? k + 4 : k;                // past the end: re-read the current four (harmless)
+            const double* cn = JT + j + kn * ldj;
+            const double b0 = cn[0], b1 = cn[ldj], b2 = cn[2 * ldj], b3 = cn[3 * ldj];
+            const double* vr = V + k * rr + c0;
+            #pragma unroll
+            for (int u = 0; u < LB_CC; ++u)
+                if (FULL || u < nc)
+                    acc[u] = fma(a3, vr[3 * rr + u], fma(a2, vr[2 * rr + u], fma(a1, vr[rr + u], fma(a0, vr[u], acc[u]))));
+            a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+        }
+    }
+    for (; k < k1; ++k) {
+        const double a = JT[j + k * ldj];
+        const double* vr = V + k * rr + c0;
+        #pragma unroll
+        for (int u = 0; u < LB_CC; ++u) if (FULL || u < nc) acc[u] = fma(a, vr[u], acc[u]);
+    }
+    #pragma unroll
+    for (int u = 0; u < LB_CC; ++u)
+        if (FULL || u < nc) part[((int64_t)blockIdx.y * rr + c0 + u) * ldp + j] = acc[u];
+}
+
 __global__ __launch_bounds__(256) void k_tall_tn(double* __restrict__ part, int64_t ldp, const double* __restrict__ JT,
                                                  int64_t ldj, const double* __restrict__ V, int rr, int64_t n,
                                                  int64_t kper)
@@ -54,27 +90,9 @@ __global__ __launch_bounds__(256) void k_tall_tn(double* __restrict__ part, int6
     const int c0 = blockIdx.z * LB_CC;
     const int64_t k0 = (int64_t)blockIdx.y * kper;
     int64_t k1 = k0 + kper; if (k1 > n) k1 = n;
-    double acc[LB_CC];
-    #pragma unroll
-    for (int u = 0; u < LB_CC; ++u) acc[u] = 0.0;
     const int nc = rr - c0 < LB_CC ? rr - c0 : LB_CC;
-    int64_t k = k0;
-    for (; k + 4 <= k1; k += 4) {             // four independent loads in flight per thread
-        const double a0 = JT[j + k * ldj], a1 = JT[j + (k + 1) * ldj], a2 = JT[j + (k + 2) * ldj], a3 = JT[j + (k + 3) * ldj];
-        const double* vr = V + k * rr + c0;
-        #pragma unroll
-        for (int u = 0; u < LB_CC; ++u)
-            if (u < nc) acc[u] = fma(a3, vr[3 * rr + u], fma(a2, vr[2 * rr + u], fma(a1, vr[rr + u], fma(a0, vr[u], acc[u]))));
-    }
-    for (; k < k1; ++k) {
-        const double a = JT[j + k * ldj];
-        const double* vr = V + k * rr + c0;
-        #pragma unroll
-        for (int u = 0; u < LB_CC; ++u) if (u < nc) acc[u] = fma(a, vr[u], acc[u]);
-    }
-    #pragma unroll
-    for (int u = 0; u < LB_CC; ++u)
-        if (u < nc) part[((int64_t)blockIdx.y * rr + c0 + u) * ldp + j] = acc[u];
+    if (nc == LB_CC) tall_tn_body<true>(part, ldp, JT, ldj, V, rr, k0, k1, j, c0, nc);
+    else tall_tn_body<false>(part, ldp, JT, ldj, V, rr, k0, k1, j, c0, nc);
 }
 
 // P[c*ldp + j] = sum_split part[(split*rr + c)*ldp + j]        grid (ldp/256, rr)
