@@ -111,8 +111,20 @@ __global__ __launch_bounds__(256) void k_bwd_dot(const double* __restrict__ A, i
     const int64_t r0 = row_begin + (int64_t)blockIdx.y * ROWCHUNK;
     int64_t r1 = r0 + ROWCHUNK; if (r1 > Npad) r1 = Npad;
     const double* col = A + (lc0 + k) * ld;
+    // all ROWCHUNK/256 loads of a thread in flight at once (a rolled loop waits out the memory latency every trip:
+    // 8 x ~1.2 us was the whole kernel); same products in the same order, so the same bits
+    constexpr int PER = ROWCHUNK / 256;
+    double ca[PER], va[PER];
+    #pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t i = r0 + threadIdx.x + 256 * u;
+        const bool ok = i < r1;
+        ca[u] = ok ? col[i] : 0.0;
+        va[u] = ok ? v[i] : 0.0;
+    }
     double acc = 0.0;
-    for (int64_t i = r0 + threadIdx.x; i < r1; i += 256) acc = fma(col[i], v[i], acc);
+    #pragma unroll
+    for (int u = 0; u < PER; ++u) acc = fma(ca[u], va[u], acc);
     #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -130,7 +142,15 @@ __global__ void k_bwd_diag(const double* __restrict__ A, int64_t ld, int64_t lc0
     v += (int64_t)blockIdx.y * vstride;
     part += (int64_t)blockIdx.y * pstride;
     double t = 0.0;
-    for (int c = 0; c < nchunk; ++c) t += part[(int64_t)c * nb + tid];
+    {   // partial sums of the rows below: independent loads four at a time, added in the original order
+        int c = 0;
+        for (; c + 4 <= nchunk; c += 4) {
+            const double p0 = part[(int64_t)c * nb + tid], p1 = part[(int64_t)(c + 1) * nb + tid];
+            const double p2 = part[(int64_t)(c + 2) * nb + tid], p3 = part[(int64_t)(c + 3) * nb + tid];
+            t += p0; t += p1; t += p2; t += p3;
+        }
+        for (; c < nchunk; ++c) t += part[(int64_t)c * nb + tid];
+    }
     x[tid] = v[c0 + tid] - t;
     const int nt = nbw / TB;
     for (int u = nt - 1; u >= 1; --u) {
