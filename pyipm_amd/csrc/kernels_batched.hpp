@@ -137,9 +137,18 @@ __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double re
                     #pragma unroll
                     for (int ks = 0; ks < 16; ++ks) b[ks] = A[ib + ((int64_t)u * TB + ks * 4 + l4) * ld];   // L(r0,u)
                     __syncthreads();
-                    for (int e = tid; e < TB * TB; e += 256) {          // -S(t,u)[c][k] sits at A[64u + k][j0 + c]
-                        const int k = e & 63, c = e >> 6;
-                        X[c][k] = A[((int64_t)u * TB + k) + (j0 + c) * ld];
+                    {   // -S(t,u)[c][k] sits at A[64u + k][j0 + c]; the 16 loads of a thread go out together
+                        double stg[TB * TB / 256];
+                        #pragma unroll
+                        for (int q = 0; q < TB * TB / 256; ++q) {
+                            const int e = tid + 256 * q, k = e & 63, c = e >> 6;
+                            stg[q] = A[((int64_t)u * TB + k) + (j0 + c) * ld];
+                        }
+                        #pragma unroll
+                        for (int q = 0; q < TB * TB / 256; ++q) {
+                            const int e = tid + 256 * q;
+                            X[e >> 6][e & 63] = stg[q];
+                        }
                     }
                     __syncthreads();
                     #pragma unroll
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double re
             const double* Xi = Tinv + (int64_t)t * TB * TB;
             const double* Tt = Tsave + (int64_t)t * TB * TB;
             const int nr = (nref > 0 && Tflag[t] != 0.0) ? nref : 0;
-            for (int e = tid; e < TB * TB; e += 256) X[e >> 6][e & 63] = Xi[e];
+            PYIPM_STAGE_TILE(X, 1.0, Xi)
             __syncthreads();
             for (int r = t + 1; r < nt; ++r) {
                 if (!rows_active(g, j0, j0 + TB, (int64_t)r * TB, (int64_t)(r + 1) * TB)) continue;   // S(r,t) = 0 = L(r,t)
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double re
                         lac[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[cb * 16 + l15][ks * 4 + l4], b[ks], lac[cb], 0, 0, 0);
                 for (int it = 0; it < nr; ++it) {                               // rare: ill-conditioned tile
                     __syncthreads();
-                    for (int e = tid; e < TB * TB; e += 256) X[e >> 6][e & 63] = -Tt[e];
+                    PYIPM_STAGE_TILE(X, -1.0, Tt)
                     __syncthreads();
                     double4_t res[4];
                     #pragma unroll
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double re
                             res[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[cb * 16 + l15][ks * 4 + l4], lop, res[cb], 0, 0, 0);
                     }
                     __syncthreads();
-                    for (int e = tid; e < TB * TB; e += 256) X[e >> 6][e & 63] = Xi[e];
+                    PYIPM_STAGE_TILE(X, 1.0, Xi)
                     __syncthreads();
                     #pragma unroll
                     for (int ks = 0; ks < 16; ++ks) {

@@ -78,9 +78,19 @@ __device__ __forceinline__ void tile_invert_dev(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cb = wave * 16;
 
-    for (int e = tid; e < TB * TB; e += 256) {          // coalesced read of the lower triangle
-        const int i = e & 63, j = e >> 6;
-        if (i >= j) stage[i][j] = A[(grow0 + i) + (lcol0 + j) * ld];
+    {   // coalesced read of the lower triangle: ALL 16 loads of a thread in flight before the first wait (the rolled loop
+        // waited out one memory latency per trip, on the critical path of the whole factorisation)
+        double tmp[TB * TB / 256];
+        #pragma unroll
+        for (int q = 0; q < TB * TB / 256; ++q) {
+            const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+            tmp[q] = (i >= j) ? A[(grow0 + i) + (lcol0 + j) * ld] : 0.0;
+        }
+        #pragma unroll
+        for (int q = 0; q < TB * TB / 256; ++q) {
+            const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+            if (i >= j) stage[i][j] = tmp[q];
+        }
     }
     __syncthreads();
     row16_t row;                           // native 16-wide vector: a wave-uniform dynamic index becomes ONE
@@ -305,6 +315,18 @@ __global__ __launch_bounds__(256) void k_tile_invert(
     tile_invert_dev(sm, A, ld, grow0, lcol0, Tinv, Tsave, Tflag, refine_cond, st, Nreal, pivtol_rel, dbg);
 }
 
+// 64x64 tile (global, row-major [k][c]) -> LDS array dst_[k][c], scaled: the 16 loads of a thread are issued together
+// (a rolled loop costs one memory latency per trip -- 16 of them were the whole run time of k_panel_scale).
+#define PYIPM_STAGE_TILE(dst_, scale_, src_)                                                          \
+    {                                                                                                 \
+        double stg_[TB * TB / 256];                                                                   \
+        _Pragma("unroll") for (int q_ = 0; q_ < TB * TB / 256; ++q_) stg_[q_] = (src_)[tid + 256 * q_]; \
+        _Pragma("unroll") for (int q_ = 0; q_ < TB * TB / 256; ++q_) {                                \
+            const int e_ = tid + 256 * q_;                                                            \
+            (dst_)[e_ >> 6][e_ & 63] = (scale_) * stg_[q_];                                           \
+        }                                                                                             \
+    }
+
 // ---------------------------------------------------------------------------------------------
 // Panel scaling: for rows below a factored tile, keep the Schur-complemented block as W and
 // overwrite it with the block factor L = W * inv(T).  256 threads per 64 rows: wave w produces
@@ -339,7 +361,7 @@ __global__ __launch_bounds__(256) void k_panel_scale(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     if (nref > 0 && *Tflag == 0.0) nref = 0;            // well-conditioned tile: the plain product is accurate (block-uniform)
-    for (int e = tid; e < TB * TB; e += 256) X[e >> 6][e & 63] = sign * Tinv[e];     // symmetric
+    PYIPM_STAGE_TILE(X, sign, Tinv)        // symmetric
     const int64_t i = row_begin + (int64_t)blockIdx.x * TB + wave * 16 + l15;
     double b[16];
     #pragma unroll
@@ -362,7 +384,7 @@ __global__ __launch_bounds__(256) void k_panel_scale(
     }
     for (int it = 0; it < nref; ++it) {
         __syncthreads();
-        for (int e = tid; e < TB * TB; e += 256) X[e >> 6][e & 63] = -sign * Tsave[e];
+        PYIPM_STAGE_TILE(X, -sign, Tsave)
         __syncthreads();
         // R = S - L T  [D layout]: C operand = S = sign * the loaded b values, in accumulator order
         double4_t res[4];
@@ -380,7 +402,7 @@ __global__ __launch_bounds__(256) void k_panel_scale(
             }
         }
         __syncthreads();
-        for (int e = tid; e < TB * TB; e += 256) X[e >> 6][e & 63] = sign * Tinv[e];
+        PYIPM_STAGE_TILE(X, sign, Tinv)
         __syncthreads();
         // L += R inv(T)   (A = sign*inv(T), B = sign*R)
         #pragma unroll
