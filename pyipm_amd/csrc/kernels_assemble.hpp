@@ -95,10 +95,12 @@ __global__ __launch_bounds__(256) void k_rowdot2(
     double acc = 0.0;
     if (nc1 > 0) {
         const double* r = M1 + j * ld1;
+        #pragma unroll 8
         for (int64_t a = lane; a < nc1; a += 64) acc += r[a] * x1[a];
     }
     if (nc2 > 0) {
         const double* r = M2 + j * ld2;
+        #pragma unroll 8
         for (int64_t a = lane; a < nc2; a += 64) acc += r[a] * x2[a];
     }
     acc = wave_sum(acc);

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void k_fwd_gemv(const double* __restrict__ A, 
     if (i >= Npad) return;
     const double* row = A + i + lc0 * ld;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    #pragma unroll 4                                   // 16 loads in flight per thread instead of 4 (rolled: one latency per trip)
     for (int k = 0; k < nbw; k += 4) {
         acc0 = fma(row[(int64_t)(k + 0) * ld], y[k + 0], acc0);
         acc1 = fma(row[(int64_t)(k + 1) * ld], y[k + 1], acc1);
