@@ -791,6 +791,63 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_update(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// In-panel left-looking update of one 64-column block with the K = 64 t columns before it (K <= nb - 64):
+//   C[i][c] += sum_k L[i][k] * Wn[c][k]        (Wn = -W), rows i >= row_begin
+// The big update kernel is built for long K (LDS-staged 16-deep stages, two in flight); at K <= 192 its fixed
+// latencies are most of its 8-17 us, and a 128-row tile keeps one CU busy for 3.4 us of MFMA per 64 columns of K
+// while, late in the factorisation, most CUs have no tile at all.  Here a block is 32 rows x 64 columns (4x the
+// blocks), operands go straight from global memory into the MFMA operand registers (lanes along the contiguous
+// index of both, as in k_panel_scale), a whole 64-wide slab of K in flight at a time.  Same products accumulated in
+// the same order as k_update<64> (D[m <- c][n <- i], k ascending in MFMA groups of 4): bit-identical results.
+// grid = rows/32, block 256: wave w owns columns [16w, 16w+16) x 32 rows (two accumulator tiles).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_inpanel_update(
+    double* __restrict__ C, int64_t ldc, int64_t ccol,                 // column block: local column ccol, global row range = cglob..+64
+    const double* __restrict__ Lop, int64_t ldl,                       // L[i][k] = Lop[i + k*ldl]
+    const double* __restrict__ Wop, int64_t ldw, int64_t cglob,        // Wn[c][k] = Wop[(cglob + c) + k*ldw]
+    int K, int64_t row_begin, int64_t Npad,
+    int64_t a0, int64_t a1, int64_t b0, int64_t b1, int prio)
+{
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    const int64_t i0 = row_begin + (int64_t)blockIdx.x * 32;
+    if (i0 + 32 <= cglob) return;                                      // wholly above the diagonal block
+    {   // structural zeros (see k_update): rows or columns outside the active ranges add exact zeros
+        const bool ri = (i0 + 32 > a0 && i0 < a1) || (i0 + 32 > b0 && i0 < b1);
+        const bool ci = (cglob + TB > a0 && cglob < a1) || (cglob + TB > b0 && cglob < b1);
+        if (!(ri && ci)) return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double4_t acc[2];
+    #pragma unroll
+    for (int h = 0; h < 2; ++h)
+        #pragma unroll
+        for (int r = 0; r < 4; ++r)
+            acc[h][r] = C[(i0 + 16 * h + l15) + (ccol + wave * 16 + l4 + 4 * r) * ldc];
+    const double* wp = Wop + (cglob + wave * 16 + l15) + (int64_t)l4 * ldw;       // A operand: m = c, k = 4 ks + l4
+    const double* lp = Lop + (i0 + l15) + (int64_t)l4 * ldl;                       // B operand: n = i, k = 4 ks + l4
+    for (int k0 = 0; k0 < K; k0 += TB) {
+        double wa[16], lb0[16], lb1[16];
+        #pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            wa[ks] = wp[(int64_t)(k0 + 4 * ks) * ldw];
+            lb0[ks] = lp[(int64_t)(k0 + 4 * ks) * ldl];
+            lb1[ks] = lp[16 + (int64_t)(k0 + 4 * ks) * ldl];
+        }
+        #pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[ks], lb0[ks], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[ks], lb1[ks], acc[1], 0, 0, 0);
+        }
+    }
+    #pragma unroll
+    for (int h = 0; h < 2; ++h)
+        #pragma unroll
+        for (int r = 0; r < 4; ++r)
+            C[(i0 + 16 * h + l15) + (ccol + wave * 16 + l4 + 4 * r) * ldc] = acc[h][r];
+}
+
 // Register-resident MFMA-only loop for the fp64 matrix peak measurement.  Inline asm keeps the
 // eight accumulators in VGPRs (the builtin form made hipcc shuttle them through AGPRs every trip).
 __global__ __launch_bounds__(256) void k_mfma_peak(double* out, int iters)

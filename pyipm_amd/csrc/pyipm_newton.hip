@@ -340,7 +340,14 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
     }
     for (int t = 0; t < nt; ++t) {
         const int64_t j0 = c0 + (int64_t)t * TB, lcol = lc0 + (int64_t)t * TB;
-        if (t > 0) {
+        if (t > 0 && ctx->inpanel32) {
+            // left-looking in-panel update of this tile's column block with the t tiles before it (32-row blocks)
+            const int64_t row_begin = (j0 / 32) * 32;
+            hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - row_begin) / 32)), dim3(256), 0, stream,
+                               ctx->A, g.Npad, lcol, ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, j0, t * TB, row_begin, g.Npad,
+                               ha0, ha1, hb0, hb1, ctx->side_prio);
+            PYIPM_KCHECK();
+        } else if (t > 0) {
             // left-looking in-panel update of this tile's column block with the t tiles before it
             const int64_t row_begin = (j0 / BM) * BM;
             const int64_t m = g.Npad - row_begin;
@@ -1432,6 +1439,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "tail_group")) { ctx->tail_group = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "tail_cols")) { ctx->tail_cols = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "inpanel32")) { ctx->inpanel32 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "fuse_forward")) { ctx->fuse_forward = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "side_prio")) { ctx->side_prio = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "debug_timeline_ptr")) {      // diagnostics: device buffer of 8 x u64 per block (pointer passed as double-encoded integer halves is lossy; use set via low 52 bits)
