@@ -800,7 +800,7 @@ __global__ __launch_bounds__(NW * 64, NW / 2) void k_update(
 // blocks), operands go straight from global memory into the MFMA operand registers (lanes along the contiguous
 // index of both, as in k_panel_scale), a whole 64-wide slab of K in flight at a time.  Same products accumulated in
 // the same order as k_update<64> (D[m <- c][n <- i], k ascending in MFMA groups of 4): bit-identical results.
-// grid = rows/32, block 256: wave w owns columns [16w, 16w+16) x 32 rows (two accumulator tiles).
+// grid = (rows/32, column blocks), block 256: wave w owns columns [16w, 16w+16) x 32 rows (two accumulator tiles).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_inpanel_update(
     double* __restrict__ C, int64_t ldc, int64_t ccol,                 // column block: local column ccol, global row range = cglob..+64
@@ -810,6 +810,8 @@ __global__ __launch_bounds__(256) void k_inpanel_update(
     int64_t a0, int64_t a1, int64_t b0, int64_t b1, int prio)
 {
     if (prio) __builtin_amdgcn_s_setprio(3);
+    ccol += (int64_t)blockIdx.y * TB;                                  // grid.y column blocks of 64 (the pending update of a
+    cglob += (int64_t)blockIdx.y * TB;                                 // whole panel inside its group uses nb/64 of them)
     const int64_t i0 = row_begin + (int64_t)blockIdx.x * 32;
     if (i0 + 32 <= cglob) return;                                      // wholly above the diagonal block
     {   // structural zeros (see k_update): rows or columns outside the active ranges add exact zeros

@@ -320,9 +320,19 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
     const int64_t poff = (size_t)p < ctx->grp_off.size() ? ctx->grp_off[p] : p % ctx->group;
     if (apply_pending && poff != 0) {
         const int64_t p0 = p - poff;
-        int rc = launch_update128(ctx, stream, ctx->A + g.local_c0(p0) * g.Npad, g.Npad, wbuf(ctx, p0),
-                                  (int)((p - p0) * g.nb), c0, lp, 1, /*bulk=*/false, 0, 0, 0, g.panel_c0(p0));
-        if (rc) return rc;
+        const int K = (int)((p - p0) * g.nb);
+        if (ctx->inpanel32 && g.Npad - c0 <= ctx->pending32_rows) {
+            int64_t pa0, pa1, pb0, pb1;
+            active_ranges(ctx, g.panel_c0(p0), g.panel_c0(p0) + K, &pa0, &pa1, &pb0, &pb1);
+            hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - c0) / 32), (unsigned)(nbw / TB)), dim3(256), 0, stream,
+                               ctx->A, g.Npad, lc0, ctx->A + g.local_c0(p0) * g.Npad, g.Npad, wbuf(ctx, p0), g.Npad, c0, K, c0,
+                               g.Npad, pa0, pa1, pb0, pb1, ctx->side_prio);
+            PYIPM_KCHECK();
+        } else {
+            int rc = launch_update128(ctx, stream, ctx->A + g.local_c0(p0) * g.Npad, g.Npad, wbuf(ctx, p0),
+                                      K, c0, lp, 1, /*bulk=*/false, 0, 0, 0, g.panel_c0(p0));
+            if (rc) return rc;
+        }
     }
     // Panels inside the x block: the slack rows of the panel are exact zeros (active_ranges), whole 128-row tiles of
     // them are skipped by the in-panel updates and the scalings too (single rank only: a receiver rebuilds L from W).
@@ -1440,6 +1450,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "tail_cols")) { ctx->tail_cols = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "inpanel32")) { ctx->inpanel32 = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "fuse_forward")) { ctx->fuse_forward = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "side_prio")) { ctx->side_prio = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "debug_timeline_ptr")) {      // diagnostics: device buffer of 8 x u64 per block (pointer passed as double-encoded integer halves is lossy; use set via low 52 bits)
