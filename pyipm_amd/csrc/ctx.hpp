@@ -94,6 +94,8 @@ struct Ctx {
     int bulk_waves = 8;                   // waves per block of the BULK update tiles (8: 128 VGPRs each, 4 waves per SIMD;
                                           // 4: 241 VGPRs, 2 per SIMD: 1.5 % slower); the short side-stream launches keep 4
     int inpanel32 = 1;                    // in-panel updates on 32-row blocks straight from global memory (k_inpanel_update)
+    int64_t head32_rows = 6144;           // ... and the lookahead HEAD update (next group's columns, on the critical path between two
+                                          // groups' chains: one 128x128 tile at K = 512 takes 132 us however few tiles there are)
     int64_t pending32_rows = 24576;       // ... and a panel's pending in-group update too while at most this many rows remain
                                           // (128x128 tiles keep one CU busy for 27 us per 256 columns of K, on the chain)
     int xcd_swizzle = 1;

@@ -834,7 +834,22 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     for (int64_t grp = 0; grp + 1 < ngroups; ++grp) {
         const int64_t p0 = ctx->grp_first[(size_t)grp], n0 = gsize(grp), p1 = p0 + n0, n1 = gsize(grp + 1);
         if (ctx->lookahead) {
-            rc = timed_update(ctx, p0, n0, p1, n1); if (rc) return rc;                 // head: next group's columns
+            // head: next group's columns (the next chain waits for it)
+            const int64_t hc0 = g.panel_c0(p1);
+            const bool fast_src = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)grp];
+            if (ctx->inpanel32 && !fast_src && g.Npad - hc0 <= ctx->head32_rows) {
+                int K = 0; int64_t cols = 0;
+                for (int64_t q = p0; q < p0 + n0; ++q) K += (int)g.panel_w(q);
+                for (int64_t q = p1; q < p1 + n1; ++q) cols += g.panel_w(q);
+                int64_t pa0, pa1, pb0, pb1;
+                active_ranges(ctx, g.panel_c0(p0), g.panel_c0(p0) + K, &pa0, &pa1, &pb0, &pb1);
+                hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - hc0) / 32), (unsigned)(cols / TB)), dim3(256), 0,
+                                   ctx->stream, ctx->A, g.Npad, g.local_c0(p1), ctx->A + g.local_c0(p0) * g.Npad, g.Npad,
+                                   wbuf(ctx, p0), g.Npad, hc0, K, hc0, g.Npad, pa0, pa1, pb0, pb1, ctx->side_prio);
+                PYIPM_KCHECK();
+            } else {
+                rc = timed_update(ctx, p0, n0, p1, n1); if (rc) return rc;
+            }
             PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
             PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_head, 0));
             for (int64_t q = p1; q < p1 + n1; ++q) {
@@ -1451,6 +1466,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "inpanel32")) { ctx->inpanel32 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
+    if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "fuse_forward")) { ctx->fuse_forward = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "side_prio")) { ctx->side_prio = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "debug_timeline_ptr")) {      // diagnostics: device buffer of 8 x u64 per block (pointer passed as double-encoded integer halves is lossy; use set via low 52 bits)
