@@ -96,6 +96,9 @@ struct Ctx {
     int inpanel32 = 1;                    // in-panel updates on 32-row blocks straight from global memory (k_inpanel_update)
     int64_t head32_rows = 6144;           // ... and the lookahead HEAD update (next group's columns, on the critical path between two
                                           // groups' chains: one 128x128 tile at K = 512 takes 132 us however few tiles there are)
+    bool per_panel_mode = false;          // the per-panel phases (pyipm_newton_factor_begin ...) drive this factorisation
+    int64_t head32_rows_dist = 16384;     // per-panel (multi-GPU) schedule: single-panel launches (the owner's head update of the
+                                          // next panel, always on the critical path there) while at most this many rows remain
     int64_t pending32_rows = 24576;       // ... and a panel's pending in-group update too while at most this many rows remain
                                           // (128x128 tiles keep one CU busy for 27 us per 256 columns of K, on the chain)
     int xcd_swizzle = 1;

@@ -429,9 +429,19 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
         e0 = ctx->ev_trailing[ctx->n_trailing].first; e1 = ctx->ev_trailing[ctx->n_trailing].second;
         PYIPM_HIP(hipEventRecord(e0, stream));
     }
-    int rc = launch_update128(ctx, stream, Lop, g.Npad, wbuf(ctx, p0), K, row_begin, first_lp, n_lp, true, 0, 0, 0,
-                              g.panel_c0(p0));
-    if (rc) return rc;
+    if (ctx->inpanel32 && ctx->per_panel_mode && n_lp == 1 && g.Npad - row_begin <= ctx->head32_rows_dist) {
+        // one panel of columns (the head of the per-panel schedule): 32 x 64 blocks instead of a handful of 128 x 128 tiles
+        int64_t pa0, pa1, pb0, pb1;
+        active_ranges(ctx, g.panel_c0(p0), g.panel_c0(p0) + K, &pa0, &pa1, &pb0, &pb1);
+        hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - row_begin) / 32), (unsigned)(g.panel_w(q0) / TB)), dim3(256), 0,
+                           stream, ctx->A, g.Npad, first_lp * (int64_t)g.nb, Lop, g.Npad, wbuf(ctx, p0), g.Npad, row_begin, K,
+                           row_begin, g.Npad, pa0, pa1, pb0, pb1, ctx->side_prio);
+        PYIPM_KCHECK();
+    } else {
+        int rc = launch_update128(ctx, stream, Lop, g.Npad, wbuf(ctx, p0), K, row_begin, first_lp, n_lp, true, 0, 0, 0,
+                                  g.panel_c0(p0));
+        if (rc) return rc;
+    }
     if (ctx->profile) PYIPM_HIP(hipEventRecord(e1, stream));
     // algorithmic flops of this launch: 2*K per lower-triangle entry of the updated local columns
     // (entries the KKT block structure leaves at zero are not counted: the launch skips their tiles)
@@ -770,6 +780,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     const Geo& g = ctx->g;
     if (g.world != 1) { ctx->err = "factor(): single-rank entry point; use the per-panel phases when world > 1"; return PYIPM_E_BADARG; }
     if (!ctx->assembled) { ctx->err = "factor: assemble first"; return PYIPM_E_BADARG; }
+    ctx->per_panel_mode = false;
     int rc = factor_begin(ctx); if (rc) return rc;
     if (!ctx->side) {
         // panel kernels are latency-critical and tiny: highest dispatch priority, so they take the first
@@ -1281,6 +1292,7 @@ int pyipm_newton_factor_begin(pyipm_newton_ctx* h) {
     if (!ctx->assembled) { ctx->err = "factor_begin: assemble first"; return PYIPM_E_BADARG; }
     if (ctx->cond_active) { ctx->err = "per-panel phases do not apply to the condensed system; use factor()"; return PYIPM_E_BADARG; }
     ctx->grp_of.clear(); ctx->grp_off.clear(); ctx->grp_fast.clear(); ctx->grp_x.clear();      // per-panel phases: uniform group map, dense panels
+    ctx->per_panel_mode = true;
     return factor_begin(ctx);
 }
 int pyipm_newton_factor_end(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
@@ -1467,6 +1479,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "inpanel32")) { ctx->inpanel32 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
+    if (!strcmp(name, "head32_rows_dist")) { ctx->head32_rows_dist = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "fuse_forward")) { ctx->fuse_forward = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "side_prio")) { ctx->side_prio = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "debug_timeline_ptr")) {      // diagnostics: device buffer of 8 x u64 per block (pointer passed as double-encoded integer halves is lossy; use set via low 52 bits)
