@@ -159,7 +159,7 @@ __global__ void k_bwd_diag(const double* __restrict__ A, int64_t ld, int64_t lc0
         if (tid < u * TB) {
             const double* col = A + (c0 + (int64_t)u * TB) + (lc0 + tid) * ld;
             double acc = 0.0;
-            #pragma unroll 8
+            #pragma unroll                                  // all 64 loads in flight: the recursion has nt - 1 latency-bound steps
             for (int i = 0; i < TB; ++i) acc = fma(col[i], x[u * TB + i], acc);
             x[tid] -= acc;
         }
