@@ -76,6 +76,7 @@ struct Ctx {
     hipEvent_t ev_head = nullptr, ev_panel = nullptr, ev_fwd = nullptr;
     hipStream_t fwd = nullptr;            // fused forward-substitution stream
     std::vector<hipEvent_t> ev_done;      // panel q factored
+    std::vector<hipEvent_t> ev_early;     // panel (by offset in its group) factored: early head updates wait for it
     int fuse_forward = 1;
     bool forward_fused = false;
     bool forward_pending = false;         // factor() already forward-substituted the pending residual into v0
@@ -94,6 +95,8 @@ struct Ctx {
     int bulk_waves = 8;                   // waves per block of the BULK update tiles (8: 128 VGPRs each, 4 waves per SIMD;
                                           // 4: 241 VGPRs, 2 per SIMD: 1.5 % slower); the short side-stream launches keep 4
     int inpanel32 = 1;                    // in-panel updates on 32-row blocks straight from global memory (k_inpanel_update)
+    int early_head = 1;                   // tail regime: a group's panels except the last update the next group's columns as soon
+                                          // as each is factored (beside the chain), so only the last panel's K = nb is left between two chains
     int64_t head32_rows = 6144;           // ... and the lookahead HEAD update (next group's columns, on the critical path between two
                                           // groups' chains: one 128x128 tile at K = 512 takes 132 us however few tiles there are)
     bool per_panel_mode = false;          // the per-panel phases (pyipm_newton_factor_begin ...) drive this factorisation

@@ -842,33 +842,64 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         rc = factor_panel(ctx, q, ctx->stream, true); if (rc) return rc;
         rc = after_panel(q, ctx->stream); if (rc) return rc;
     }
+    std::vector<char> early((size_t)np, 0);       // panel's contribution to the NEXT group's columns already applied
     for (int64_t grp = 0; grp + 1 < ngroups; ++grp) {
         const int64_t p0 = ctx->grp_first[(size_t)grp], n0 = gsize(grp), p1 = p0 + n0, n1 = gsize(grp + 1);
         if (ctx->lookahead) {
-            // head: next group's columns (the next chain waits for it)
+            // head: next group's columns (the next chain waits for it).  Sources: the panels of this group whose
+            // contribution an early head has not applied yet (see below).
             const int64_t hc0 = g.panel_c0(p1);
             const bool fast_src = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)grp];
-            if (ctx->inpanel32 && !fast_src && g.Npad - hc0 <= ctx->head32_rows) {
-                int K = 0; int64_t cols = 0;
-                for (int64_t q = p0; q < p0 + n0; ++q) K += (int)g.panel_w(q);
-                for (int64_t q = p1; q < p1 + n1; ++q) cols += g.panel_w(q);
-                int64_t pa0, pa1, pb0, pb1;
-                active_ranges(ctx, g.panel_c0(p0), g.panel_c0(p0) + K, &pa0, &pa1, &pb0, &pb1);
-                hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - hc0) / 32), (unsigned)(cols / TB)), dim3(256), 0,
-                                   ctx->stream, ctx->A, g.Npad, g.local_c0(p1), ctx->A + g.local_c0(p0) * g.Npad, g.Npad,
-                                   wbuf(ctx, p0), g.Npad, hc0, K, hc0, g.Npad, pa0, pa1, pb0, pb1, ctx->side_prio);
-                PYIPM_KCHECK();
-            } else {
-                rc = timed_update(ctx, p0, n0, p1, n1); if (rc) return rc;
+            auto head_from = [&](int64_t q0, int64_t nq, int64_t tp, int64_t tn) -> int {
+                const int64_t tc0 = g.panel_c0(tp);
+                if (ctx->inpanel32 && !fast_src && g.Npad - tc0 <= ctx->head32_rows) {
+                    int K = 0; int64_t cols = 0;
+                    for (int64_t q = q0; q < q0 + nq; ++q) K += (int)g.panel_w(q);
+                    for (int64_t q = tp; q < tp + tn; ++q) cols += g.panel_w(q);
+                    int64_t pa0, pa1, pb0, pb1;
+                    active_ranges(ctx, g.panel_c0(q0), g.panel_c0(q0) + K, &pa0, &pa1, &pb0, &pb1);
+                    // W of a panel inside its group's buffer: wbuf(q0) addresses it (column offset of q0 in the group)
+                    hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - tc0) / 32), (unsigned)(cols / TB)), dim3(256), 0,
+                                       ctx->stream, ctx->A, g.Npad, g.local_c0(tp), ctx->A + g.local_c0(q0) * g.Npad, g.Npad,
+                                       wbuf(ctx, q0), g.Npad, tc0, K, tc0, g.Npad, pa0, pa1, pb0, pb1, ctx->side_prio);
+                    PYIPM_KCHECK();
+                    return 0;
+                }
+                return timed_update(ctx, q0, nq, tp, tn);
+            };
+            {
+                int64_t q = p0;
+                while (q < p0 + n0 && early[(size_t)q]) ++q;                       // applied early (always a prefix of the group)
+                if (q < p0 + n0) { rc = head_from(q, p0 + n0 - q, p1, n1); if (rc) return rc; }
             }
+            (void)hc0;
             PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
             PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_head, 0));
+            // early heads: in the tail regime the panels of the NEXT group except its last one update the group after it
+            // as soon as each is factored, on the main stream behind this group's bulk update
+            const bool nxt_fast = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)(grp + 1)];
+            const bool do_early = ctx->early_head && grp + 2 < ngroups && n1 >= 2 && !nxt_fast && !fast_src &&
+                                  g.Npad - g.panel_c0(p1) <= ctx->tail_cols;
             for (int64_t q = p1; q < p1 + n1; ++q) {
                 rc = factor_panel(ctx, q, ctx->side, true); if (rc) return rc;
                 rc = after_panel(q, ctx->side); if (rc) return rc;
+                if (do_early && q + 1 < p1 + n1) {
+                    while (ctx->ev_early.size() <= (size_t)(q - p1)) {
+                        hipEvent_t e; PYIPM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_early.push_back(e);
+                    }
+                    PYIPM_HIP(hipEventRecord(ctx->ev_early[(size_t)(q - p1)], ctx->side));
+                }
             }
             PYIPM_HIP(hipEventRecord(ctx->ev_panel, ctx->side));
             rc = timed_update(ctx, p0, n0, p1 + n1, np - (p1 + n1)); if (rc) return rc;   // bulk (overlaps the side stream)
+            if (do_early) {
+                const int64_t p2 = p1 + n1, n2 = gsize(grp + 2);
+                for (int64_t q = p1; q + 1 < p1 + n1; ++q) {
+                    PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_early[(size_t)(q - p1)], 0));
+                    rc = head_from(q, 1, p2, n2); if (rc) return rc;
+                    early[(size_t)q] = 1;
+                }
+            }
             PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
         } else {
             rc = timed_update(ctx, p0, n0, p1, np - p1); if (rc) return rc;
@@ -1071,6 +1102,7 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) {
     if (ctx->fwd) { hipStreamSynchronize(ctx->fwd); hipStreamDestroy(ctx->fwd); }
     if (ctx->ev_fwd) hipEventDestroy(ctx->ev_fwd);
     for (auto e : ctx->ev_done) hipEventDestroy(e);
+    for (auto e : ctx->ev_early) hipEventDestroy(e);
     if (ctx->stg_d2L) hipFree(ctx->stg_d2L);
     if (ctx->stg_Je) hipFree(ctx->stg_Je);
     if (ctx->stg_Ji) hipFree(ctx->stg_Ji);
@@ -1479,6 +1511,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "inpanel32")) { ctx->inpanel32 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
+    if (!strcmp(name, "early_head")) { ctx->early_head = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows_dist")) { ctx->head32_rows_dist = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "fuse_forward")) { ctx->fuse_forward = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "side_prio")) { ctx->side_prio = (int)value; return PYIPM_OK; }
