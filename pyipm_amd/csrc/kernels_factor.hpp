@@ -469,10 +469,11 @@ __global__ __launch_bounds__(256) void k_s_panel(
         // inv(T) and T as dense 64x64 tiles (the substitutions and a receiver's rebuild read them densely)
         double* Xi = Tinv + (int64_t)t * TB * TB;
         double* Tt = Tsave + (int64_t)t * TB * TB;
+        const double dorig = A[col + lcol * ld];
         #pragma unroll 8
-        for (int r = 0; r < TB; ++r) {
-            Xi[lane * TB + r] = (r == lane) ? x : 0.0;
-            Tt[lane * TB + r] = (r == lane) ? A[col + lcol * ld] : 0.0;
+        for (int r = 0; r < TB; ++r) {                              // diagonal tiles: row r written by the whole wave (one
+            Xi[r * TB + lane] = (r == lane) ? x : 0.0;              // contiguous 512 B store per row; lane-major indexing
+            Tt[r * TB + lane] = (r == lane) ? dorig : 0.0;          // scattered every store over 64 cache lines)
         }
         if (lane == 0) Tflag[t] = flagged ? 1.0 : 0.0;
         // L(lambda_i row, this column) = S X with S = -1, refined like k_panel_scale refines a flagged tile
