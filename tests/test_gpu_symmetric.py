@@ -131,3 +131,36 @@ def test_structural_zero_skipping_is_bitwise_neutral(shape, nb):
     assert out[0][1] == out[1][1]
     assert out[0][1]["n_neg"] == me + mi and out[0][1]["n_zero"] == 0
     assert out[1][2] <= 1e-9
+
+
+@pytest.mark.parametrize("shape,nb", [((1500, 300, 500, 11), 256), ((2048, 0, 2048, 3), 256), ((3000, 1000, 0, 7), 128),
+                                      ((900, 64, 1800, 5), 256)])
+def test_chain_kernel_choices_are_bitwise_neutral(shape, nb):
+    """The updates that sit on the panel chain have two implementations (k_inpanel_update: 32 x 64 blocks straight from
+    global memory; k_update: LDS-staged 128-wide tiles) chosen by how many rows remain, and the lookahead head can be
+    applied panel by panel (early_head).  All of them accumulate the same products in the same order: every combination
+    must give the same bits."""
+    import torch
+    from pyipm_amd.newton import NewtonCore
+    from pyipm_amd.problems import make_qp
+    n, me, mi, seed = shape
+    qp = make_qp(n, me, mi, seed)
+    out = []
+    for opts in ({}, {"inpanel32": 0}, {"early_head": 0}, {"head32_rows": 0, "pending32_rows": 0},
+                 {"head32_rows": 1 << 20, "pending32_rows": 1 << 20}, {"tail_cols": 1024, "early_head": 1}):
+        core = NewtonCore(n, me, mi, device=0, nb=nb)
+        for k, v in opts.items():
+            core.set_option(k, v)
+        core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+        core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+        dz, st = core.step(0.0, 0.0)
+        out.append((dz.clone(), st, opts))
+        core.close()
+    base = out[0]
+    for dz, st, opts in out[1:]:
+        if "tail_cols" in opts:
+            continue                      # a different group schedule regroups the accumulation: equal only to rounding
+        assert torch.equal(dz, base[0]), opts
+        assert st == base[1], opts
+    ref = out[-1][0]
+    assert float((ref - base[0]).norm() / base[0].norm()) <= 1e-12
