@@ -205,7 +205,12 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *                    inverses are explicit).
  *   "profile" 0|1, "lookahead" 0|1, "group" 1..create-time value, "tail_group" / "tail_cols" (group size once
  *   at most tail_cols columns remain; defaults 2 / 24576), "fuse_forward" 0|1, "pivtol_rel",
- *   "xcd_swizzle", "side_prio", "bulk_waves" 4|8 (measurement switches). */
+ *   "xcd_swizzle", "side_prio", "bulk_waves" 4|8 (measurement switches);
+ *   "inpanel32" 0|1 (updates on the panel chain through the fine-grained kernel), "pending32_rows", "head32_rows",
+ *   "head32_rows_dist" (row counts up to which a panel's pending in-group update / the lookahead head / the per-panel
+ *   head take that kernel; defaults 24576 / 6144 / 16384), "early_head" 0|1 (tail regime: the next group's columns are
+ *   updated panel by panel beside the chain) -- all of these choose between implementations that accumulate the same
+ *   products in the same order: the results are bit-identical (tests/test_gpu_symmetric.py). */
 int pyipm_newton_set_option(pyipm_newton_ctx* ctx, const char* name, double value);
 
 /* fp64 MFMA peak micro-benchmark: register-resident v_mfma_f64_16x16x4_f64 only.
