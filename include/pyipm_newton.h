@@ -10,7 +10,8 @@
  *     dz[nvar+nineq:] = -dz[nvar+nineq:]                           # :1723-1725
  *
  * Each entry point below names the reference function it replaces.  Plain C types
- * only; no torch / C++ types cross this boundary; no exceptions cross it.  Every
+ * only; no torch / C++ types cross this boundary; no exceptions cross it (every entry
+ * point catches: std::bad_alloc -> PYIPM_E_NOMEM, anything else -> PYIPM_E_HIP).  Every
  * function returns 0 on success or a negative PYIPM_E_* code;
  * pyipm_newton_last_error() gives the message.  A handle is not thread-safe.
  *
@@ -48,7 +49,7 @@ extern "C" {
 #define PYIPM_OK              0
 #define PYIPM_E_BADARG       -1   /* invalid argument / call order            */
 #define PYIPM_E_HIP          -2   /* a HIP runtime call failed                 */
-#define PYIPM_E_NOMEM        -3   /* workspace missing or too small            */
+#define PYIPM_E_NOMEM        -3   /* workspace missing or too small, or host memory exhausted */
 #define PYIPM_E_NONFINITE    -4   /* NaN/Inf met during factorisation          */
 #define PYIPM_E_NODEVICE     -5   /* no usable HIP device                      */
 #define PYIPM_E_COMM         -6   /* a caller-supplied exchange callback failed */
@@ -65,9 +66,13 @@ typedef struct pyipm_newton_ctx pyipm_newton_ctx;   /* opaque handle */
  * (reghess, pyipm.py:1378-1381, 1399): inertia from the signs of the block pivots. */
 typedef struct pyipm_factor_stats {
     int64_t n_neg;     /* negative pivots  (must equal me+mi for correct inertia, pyipm.py:1381) */
-    int64_t n_zero;    /* rejected pivots, |d| <= pivtol_rel * max|its tile column| (singular direction)  */
+    int64_t n_zero;    /* STATIC pivots: |d| <= pivtol_rel * max|its tile column|, i.e. a pivot Bunch-Kaufman could not
+                          avoid INSIDE its 64x64 tile had cancelled to nothing.  It was replaced by sqrt(eps)*max|Hc| with
+                          the sign its KKT block calls for (+ for x and s rows, - for multiplier rows) and is ALSO
+                          counted in n_neg / n_pos by that sign.  The factor is then that of a slightly perturbed
+                          matrix: solve with refine < 0 and read pyipm_newton_solve_info (see there)          */
     int64_t n_2x2;     /* 2x2 Bunch-Kaufman pivots taken inside tiles                              */
-    int64_t n_pos;     /* positive pivots among the N real rows                                     */
+    int64_t n_pos;     /* positive pivots among the N real rows (n_neg + n_pos == N)                 */
     double  d_min;     /* min |pivot| over accepted real pivots                                     */
     double  d_max;     /* max |pivot|                                                               */
     double  growth;    /* max |entry| of the block factor L (growth monitor)                        */
@@ -125,9 +130,31 @@ int pyipm_newton_factor(pyipm_newton_ctx* ctx, pyipm_factor_stats* stats);
 /* replaces the substitution inside sym_solve_cmp (pyipm.py:911-914, 1720-1721) and, when
  * flip != 0, the multiplier sign flip (pyipm.py:1723-1725).  rhs == NULL uses the residual
  * kept by pyipm_newton_residual.  refine > 0 adds that many steps of fp64 iterative
- * refinement against the KKT blocks. */
+ * refinement against the KKT blocks.  refine < 0 = ADAPTIVE refinement: |rhs - Hc dz| / |rhs| (Hc from the
+ * blocks) is measured before every step; it stops at "refine_target" (option, default 1e-14), after
+ * "refine_max" steps (default 8) or when a step gains less than 4x.  This is how the solution of the
+ * UNPERTURBED system is recovered from a factor with static pivots (stats.n_zero > 0): the reference's LU
+ * pivots across the whole matrix (pyipm.py:18-20), the tile-local pivot search here cannot, static pivots +
+ * refinement (GESP) give the same dz with the same "no shift" decision of reghess whenever Hc is
+ * non-singular -- and no convergence (solve_info) when it is not, which the host treats like the
+ * reference's rcond test (pyipm.py:1379-1381). */
 int pyipm_newton_solve(pyipm_newton_ctx* ctx, const double* rhs, double* dz, int flip,
                        int refine, int memkind);
+/* Outcome of the last solve()/step(): out[0] = refinement steps taken, out[1] = |rhs - Hc dz|/|rhs| before the
+ * first step, out[2] = after the last, out[3] = 1 when the adaptive loop met its target (out[1..2] = -1 for a
+ * fixed-count solve, which does not measure). */
+int pyipm_newton_solve_info(pyipm_newton_ctx* ctx, double out[4]);
+/* Restates the quantity reghess tests (pyipm.py:1379-1381: rcond = min|w| / max|w| over the eigenvalues w of Hc, "singular"
+ * when rcond <= eps) without the eigendecomposition: it_pow power iterations on Hc applied from the blocks give max|w|,
+ * it_inv inverse iterations through the factor (one substitution sweep each) give min|w| (0 = defaults 6 / 3).
+ * out[0] = min|w| estimate (of the FACTORED matrix: with static pivots that is the perturbed one, whose smallest
+ * eigenvalue sits at the perturbation level out[3] exactly when Hc itself is singular), out[1] = max|w| estimate,
+ * out[2] = their ratio, out[3] = magnitude of a static pivot (sqrt(eps) max|Hc|).  Call between factor() and solve();
+ * a forward substitution fused into factor() is redone by the next solve(). */
+int pyipm_newton_rcond(pyipm_newton_ctx* ctx, int it_inv, int it_pow, double out[4]);
+/* Device address of max |assembled entry| (one double, valid after assemble): the scale of a static pivot.  Ranks of
+ * a distributed factorisation reduce it (MAX) so that every rank perturbs alike. */
+int pyipm_newton_anorm(pyipm_newton_ctx* ctx, double** dev_ptr);
 
 /* y = Hc * v with Hc applied from the staged blocks (never from the factor): used by the
  * refinement step and by the parity tests (backward error). */

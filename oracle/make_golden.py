@@ -358,8 +358,80 @@ def main():
           (d["delta_out"], d["neg"], d["Hc"][n + mi, n + mi]))
 
 
+def pivot_step(name, n, me, mi, Q, seed, c_scale=1.0, blind=None):
+    """One Newton step of the reference on  min 0.5 x'Qx + c'x  s.t.  A x = b,  G x - h >= 0  with a Hessian whose
+    x-x tiles the device cannot pivot on their own (zero / zero-diagonal / zero rows).  Keeps the problem data, not
+    the N x N matrices."""
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((me, n)) / np.sqrt(n)
+    G = rng.standard_normal((mi, n)) / np.sqrt(n)
+    if blind is not None:                      # constraint gradients orthogonal to `blind`: no constraint sees that direction
+        A -= np.outer(A @ blind, blind)
+        G -= np.outer(G @ blind, blind)
+    c = c_scale * rng.standard_normal(n)
+    x = 0.1 * rng.standard_normal(n)
+    s = rng.uniform(0.5, 2.0, mi)
+    lam = np.concatenate([rng.standard_normal(me), rng.uniform(0.5, 2.0, mi)])
+    h = G @ x - s - 0.1 * rng.standard_normal(mi)
+    b = A @ x - 0.1 * rng.standard_normal(me)
+    Z = np.zeros((n, n))
+    prob = {"nvar": n, "neq": me, "nineq": mi,
+            "f": lambda x: 0.5 * x @ (Q @ x) + c @ x, "df": lambda x: Q @ x + c, "d2f": lambda x: Q,
+            "ce": (lambda x: A @ x - b) if me else None, "dce": (lambda x: np.ascontiguousarray(A.T)) if me else None,
+            "d2ce": (lambda x, lda: Z) if me else None,
+            "ci": (lambda x: G @ x - h) if mi else None, "dci": (lambda x: np.ascontiguousarray(G.T)) if mi else None,
+            "d2ci": (lambda x, lda: Z) if mi else None}
+    d, p = single_step(prob, x, mu=0.2, s=s if mi else None, lda=lam if (me or mi) else None)
+    out = {k: d[k] for k in ("nvar", "neq", "nineq", "mu", "mu_host", "delta_in", "delta_out", "g", "dz", "dz_raw", "neg",
+                             "x", "s", "lda")}
+    w = d["eig_Hc"]
+    out.update(name=np.array(name), seed=np.int64(seed), Q=Q, A=A, G=G, c=c, b=b, h=h,
+               rcond=np.float64(np.abs(w).min() / np.abs(w).max()), H_rowsum=d["H"].sum(axis=1),
+               Hc_diag=np.diag(d["Hc"]).copy())
+    return out
+
+
+def main_pivot():
+    """tests/golden/pivot_*.npz: systems whose x-x diagonal tiles are singular or indefinite on their own although the
+    KKT matrix is fine -- the reference's LU pivots across the whole matrix (pyipm.py:18-20) and reghess leaves them
+    unshifted (pyipm.py:1381) -- plus one where rcond fires although the inertia is right (pyipm.py:1379-1381)."""
+    os.makedirs(GOLD, exist_ok=True)
+    rng = np.random.default_rng(5)
+    cases = []
+    n = 128; cases.append(("lp", n, 0, 160, np.zeros((n, n)), 21))                         # d2L == 0, mi >= n
+    n = 192; cases.append(("lp_eq", n, 48, 224, np.zeros((n, n)), 22))                     # LP with equalities
+    n = 160
+    M = 0.001 * rng.standard_normal((n, n)); Qz = M + M.T; np.fill_diagonal(Qz, 0.0)
+    cases.append(("zerodiag", n, 16, 480, Qz, 23))                                         # zero diagonal, indefinite tiles
+    n = 144
+    M = rng.standard_normal((80, 80)); Ql = np.zeros((n, n)); Ql[:80, :80] = M @ M.T / 80 + np.eye(80)
+    cases.append(("linear_vars", n, 12, 200, Ql, 24))                                      # 64 variables enter linearly
+    for name, n, me, mi, Q, seed in cases:
+        out = pivot_step(name, n, me, mi, Q, seed)
+        np.savez_compressed(os.path.join(GOLD, "pivot_%s.npz" % name), **out)
+        print("pivot %-12s N=%d delta_out=%g neg=%d (need %d) rcond=%.3g |dz|=%.6g" %
+              (name, n + 2 * mi + me, out["delta_out"], out["neg"], me + mi, out["rcond"], np.linalg.norm(out["dz"])))
+        assert out["delta_out"] == 0.0 and out["neg"] == me + mi
+    # singular KKT matrix (pyipm.py:1379-1403): a variable with no curvature that no constraint touches -- an exactly
+    # zero row, eigenvalue 0.  What the reference's test sees is the eigensolver's rounding of that zero (here
+    # -3.2e-15: "one negative eigenvalue too many", rcond 6.9e-16 just above eps), so it shifts by delta without the
+    # delta_c branch; either branch gives the same dz to ~delta_c = 8e-13.
+    n, me, mi = 136, 8, 40
+    M = rng.standard_normal((n, n)); Qr = M @ M.T / n + np.eye(n)
+    k = 77
+    Qr[k, :] = 0.0; Qr[:, k] = 0.0
+    u = np.zeros(n); u[k] = 1.0
+    out = pivot_step("rcond", n, me, mi, Qr, 25, blind=u)
+    np.savez_compressed(os.path.join(GOLD, "pivot_singular.npz"), **out)
+    print("pivot singular     delta_out=%g neg(after shift)=%d (need %d) Hc_diag[le]=%g" %
+          (out["delta_out"], out["neg"], me + mi, out["Hc_diag"][n + mi]))
+    assert out["delta_out"] > 0.0
+
+
 if __name__ == "__main__":
-    if "--lbfgs" in sys.argv[1:]:
+    if "--pivot" in sys.argv[1:]:
+        main_pivot()
+    elif "--lbfgs" in sys.argv[1:]:
         main_lbfgs()
     else:
         main()

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <new>
+#include <stdexcept>
 #include <map>
 #include <vector>
 #include "../../include/pyipm_newton.h"
@@ -104,6 +106,10 @@ struct Ctx {
                                           // next panel, always on the critical path there) while at most this many rows remain
     int64_t pending32_rows = 24576;       // ... and a panel's pending in-group update too while at most this many rows remain
                                           // (128x128 tiles keep one CU busy for 27 us per 256 columns of K, on the chain)
+    int reserve_cus = 0;                  // > 0: the bulk updates run on a CU-masked stream that leaves this many CUs free for the
+    int reserve_mode = 0;                 //      panel chain (mode 0: mask bits 0..k-1 cleared; 1: every (256/k)-th bit cleared)
+    hipStream_t bulk = nullptr; int bulk_key = 0;   // the masked stream and the (reserve_cus, mode) it was built for
+    hipEvent_t ev_bulk0 = nullptr, ev_bulk1 = nullptr;
     int xcd_swizzle = 1;
     int side_prio = 1;                    // raise wave priority in panel-chain update launches
     unsigned long long* dbg_buf = nullptr;   // diagnostics only
@@ -132,6 +138,7 @@ struct Ctx {
     double *rhs = nullptr, *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *partial = nullptr;
     double *df = nullptr, *ce = nullptr, *ci = nullptr, *s = nullptr, *lda = nullptr;
     DevStats* dstats = nullptr;
+    unsigned long long* anorm = nullptr;  // device: bits of max |assembled KKT entry| (per problem for a batched handle): scale of a static pivot
     // staged blocks (device pointers; either caller-owned or library staging)
     const double *d2L = nullptr, *Je = nullptr, *Ji = nullptr;
     int64_t ld_d2L = 0, ld_Je = 0, ld_Ji = 0;
@@ -141,6 +148,12 @@ struct Ctx {
     double delta = 0.0, delta_c = 0.0;
     bool have_blocks = false, have_vectors = false, have_rhs = false, assembled = false, factored = false;
     bool have_direction = false;          // v2 holds the last sign-flipped direction (for step_lengths)
+    // last solve (pyipm_newton_solve_info): refinement steps taken, |b - Hc x|/|b| before the first and after the last
+    // one (-1 = not measured: a fixed-count solve), 1 = the adaptive loop met its target
+    int info_steps = 0, info_converged = 0;
+    double info_berr0 = -1.0, info_berr = -1.0;
+    double refine_target = 1.0e-14;       // adaptive refinement stops at this backward error ...
+    int refine_max = 8;                   // ... or after this many steps, or when a step gains less than 4x
     // options
     double pivtol_rel = 1e-14;
     int block_refine = 2;                 // refinement steps of L T = S in the panel scaling and of T z = y in the solves
@@ -152,6 +165,7 @@ struct Ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_trailing;   // reused event pool
     hipEvent_t ev[8] = {};
     bool ev_assemble_valid = false, ev_solve_valid = false;
+    int debug_fault = 0;                  // test hook: 1 / 2 = the next tile-list build throws std::bad_alloc / std::runtime_error
     std::string err;
 };
 
@@ -165,6 +179,22 @@ struct Ctx {
     } while (0)
 
 #define PYIPM_KCHECK()  PYIPM_HIP(hipGetLastError())
+
+// No C++ exception crosses the C-ABI (include/pyipm_newton.h): every extern "C" entry is a function-try-block that
+// ends in one of these.  std::bad_alloc (host containers: tile lists, schedules, event pools) -> PYIPM_E_NOMEM,
+// anything else -> PYIPM_E_HIP; the message goes to last_error when that itself does not throw.
+template <class H>
+inline void set_err_noexcept(H* h, const char* what) noexcept {
+    if (!h) return;
+    try { h->err = what; } catch (...) {}
+}
+#define PYIPM_CATCH_CORE(seterr_, ret_nomem_, ret_other_)                                              \
+    catch (const std::bad_alloc&) { seterr_("out of host memory (std::bad_alloc)"); return ret_nomem_; } \
+    catch (const std::exception& e__) { seterr_(e__.what()); return ret_other_; }                        \
+    catch (...) { seterr_("unknown C++ exception"); return ret_other_; }
+#define PYIPM_SETERR_NONE(msg_) (void)(msg_)
+#define PYIPM_CATCH_NOH   PYIPM_CATCH_CORE(PYIPM_SETERR_NONE, PYIPM_E_NOMEM, PYIPM_E_HIP)
+#define PYIPM_CATCH_SIZE  PYIPM_CATCH_CORE(PYIPM_SETERR_NONE, 0, 0)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -36,6 +36,18 @@ __device__ __forceinline__ double kkt_entry(
     return (i == j) ? 1.0 : 0.0;                       // identity pad
 }
 
+// Largest |entry| a wave has assembled -> *anorm_bits (bit pattern of a non-negative double: monotone as an integer).
+// One read of the running maximum per wave; the atomic only fires while the maximum still grows.
+__device__ __forceinline__ void anorm_publish(unsigned long long* __restrict__ anorm_bits, double amax) {
+    if (!anorm_bits) return;
+    #pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
+    if ((threadIdx.x & 63) == 0 && amax <= 1.0e308) {          // (a NaN / Inf entry is the factorisation's to report)
+        const unsigned long long b = (unsigned long long)__double_as_longlong(amax);
+        if (b > *reinterpret_cast<volatile unsigned long long*>(anorm_bits)) atomicMax(anorm_bits, b);
+    }
+}
+
 // One thread-block writes a 512(i) x 16(j) patch of the local storage; each thread owns two consecutive
 // rows so every store is 16 bytes (and the dominant d2L reads too, when the leading dimension allows).
 typedef double dbl2_t __attribute__((ext_vector_type(2)));
@@ -45,16 +57,17 @@ __global__ __launch_bounds__(256) void k_assemble(
     const double* __restrict__ Je, int64_t ldje,
     const double* __restrict__ Ji, int64_t ldji,
     const double* __restrict__ s, const double* __restrict__ lda,
-    double eps, double delta, double delta_c)
+    double eps, double delta, double delta_c, unsigned long long* __restrict__ anorm_bits)
 {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;          // even row; rows i, i+1
     const int64_t lc_base = (int64_t)blockIdx.y * 16;
-    if (i >= g.Npad) return;
+    if (i >= g.Npad) return;                          // (wave-uniform: Npad is a multiple of 128)
     const bool vec_h = ((ldh & 1) == 0) && ((reinterpret_cast<uintptr_t>(d2L) & 15) == 0);
+    double amax = 0.0;
     #pragma unroll 4
     for (int c = 0; c < 16; ++c) {
         const int64_t lc = lc_base + c;
-        if (lc >= g.ncols_local) return;
+        if (lc >= g.ncols_local) break;
         // local column -> global column (block-cyclic by panels of nb)
         const int64_t lp = lc / g.nb;
         const int64_t j = (lp * g.world + g.rank) * (int64_t)g.nb + (lc - lp * g.nb);
@@ -68,9 +81,11 @@ __global__ __launch_bounds__(256) void k_assemble(
             v.x = (i >= j) ? kkt_entry(i, j, g, d2L, ldh, Je, ldje, Ji, ldji, s, lda, eps, delta, delta_c) : 0.0;
             v.y = kkt_entry(i + 1, j, g, d2L, ldh, Je, ldje, Ji, ldji, s, lda, eps, delta, delta_c);
         }
+        amax = fmax(amax, fmax(fabs(v.x), fabs(v.y)));
         if (i >= j) *reinterpret_cast<dbl2_t*>(&A[i + lc * ld]) = v;
         else        A[(i + 1) + lc * ld] = v.y;       // the pair straddles the diagonal: store the lower one only
     }
+    anorm_publish(anorm_bits, amax);
 }
 
 // ---- wave-level helpers -------------------------------------------------------------------
@@ -370,6 +385,43 @@ __global__ __launch_bounds__(256) void k_cond_expand(double* __restrict__ v, con
     }
     if (i < n + mi + me) { v[i] = vc[n + (i - n - mi)]; return; }
     if (i >= g.N) v[i] = 0.0;
+}
+
+// out[0] = sum a_i^2, out[1] = sum b_i^2 (one block, fixed order: deterministic).  The adaptive refinement of
+// pyipm_newton_solve(refine < 0) reads the two back to form |b - Hc x| / |b|.
+__global__ __launch_bounds__(1024) void k_sumsq2(double* __restrict__ out, const double* __restrict__ a,
+                                                 const double* __restrict__ b, int64_t n)
+{
+    __shared__ double red[2][16];
+    double sa = 0.0, sb = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) { const double x = a[i], y = b[i]; sa = fma(x, x, sa); sb = fma(y, y, sb); }
+    sa = wave_sum(sa); sb = wave_sum(sb);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sa; red[1][threadIdx.x >> 6] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ta = 0.0, tb = 0.0;
+        for (int w = 0; w < 16; ++w) { ta += red[0][w]; tb += red[1][w]; }
+        out[0] = ta; out[1] = tb;
+    }
+}
+
+// Deterministic pseudo-random start vector in [-1, 1) for the eigenvalue estimates (zero in the pad).
+__global__ __launch_bounds__(256) void k_hash_vector(double* __restrict__ out, int64_t N, int64_t Npad, unsigned long long seed)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Npad) return;
+    unsigned long long z = (unsigned long long)i + seed * 0x9E3779B97F4A7C15ull + 0x9E3779B97F4A7C15ull;   // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    out[i] = (i < N) ? (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0 : 0.0;
+}
+
+// out = alpha * in
+__global__ __launch_bounds__(256) void k_scale_copy(double* __restrict__ out, const double* __restrict__ in, double alpha, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = alpha * in[i];
 }
 
 __global__ __launch_bounds__(256) void k_fill(double* __restrict__ out, double v, int64_t n)

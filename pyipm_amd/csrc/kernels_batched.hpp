@@ -22,6 +22,7 @@ struct BatchPtrs {
     double *rhs, *sol; int64_t sV;         // [B][Npad]
     const double *d2L, *Je, *Ji; int64_t sH, sJe, sJi, ldh, ldje, ldji;      // caller blocks, batch strides in doubles
     const double *df, *ce, *ci, *s, *lda;  // staged vectors [B][n], [B][me], [B][mi], [B][mi], [B][me+mi]
+    unsigned long long* anorm;             // [B] bits of max |assembled entry| (scale of a static pivot)
 };
 
 // K1 for the batch: grid (Npad/512, Npad/16, B)
@@ -35,22 +36,26 @@ __global__ __launch_bounds__(256) void k_b_assemble(BatchPtrs bp, Geo g, double 
     const double* s = bp.s + b * g.mi;
     const double* lda = bp.lda + b * (g.me + g.mi);
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
-    if (i >= g.Npad) return;
+    if (i >= g.Npad) return;                           // (wave-uniform: Npad is a multiple of 128)
+    double amax = 0.0;
     #pragma unroll 4
     for (int c = 0; c < 16; ++c) {
         const int64_t j = (int64_t)blockIdx.y * 16 + c;
-        if (j >= g.Npad) return;
+        if (j >= g.Npad) break;
         if (i + 1 < j) continue;
         const double v1 = kkt_entry(i + 1, j, g, d2L, bp.ldh, Je, bp.ldje, Ji, bp.ldji, s, lda, eps, delta, delta_c);
+        amax = fmax(amax, fabs(v1));
         if (i >= j) {
             dbl2_t v;
             v.x = kkt_entry(i, j, g, d2L, bp.ldh, Je, bp.ldje, Ji, bp.ldji, s, lda, eps, delta, delta_c);
             v.y = v1;
+            amax = fmax(amax, fabs(v.x));
             *reinterpret_cast<dbl2_t*>(&A[i + j * g.Npad]) = v;
         } else {
             A[(i + 1) + j * g.Npad] = v1;
         }
     }
+    anorm_publish(bp.anorm + b, amax);
 }
 
 // K2 for the batch: g = -grad (pyipm.py:655-668, 1717).  grid B, 256 threads (one wave per row of the x part).
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double re
         __syncthreads();
         // (2) the block pivot
         tile_invert_dev(sm, A, ld, j0, j0, Tinv + (int64_t)t * TB * TB, Tsave + (int64_t)t * TB * TB, Tflag + t,
-                        refine_cond, st, g.N, pivtol_rel, nullptr);
+                        refine_cond, st, g.N, pivtol_rel, bp.anorm + bi, g.n + g.mi, nullptr);
         __syncthreads();
         // (3) rows below: keep -S' in the upper blocks, overwrite S with L = S X (refined when the tile is flagged)
         if (t + 1 < nt) {

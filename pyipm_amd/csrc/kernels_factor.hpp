@@ -50,6 +50,12 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {
                                 (unsigned int)__builtin_amdgcn_readlane((int)b, l));
 }
 
+// Magnitude of a static pivot: sqrt(eps) x the largest assembled entry (sqrt(eps) when that is unknown).
+__device__ __forceinline__ double static_pivot(const unsigned long long* __restrict__ anorm_bits) {
+    const double an = anorm_bits ? __longlong_as_double((long long)*anorm_bits) : 0.0;
+    return 1.4901161193847656e-08 * ((an > 0.0 && an <= 1.0e300) ? an : 1.0);
+}
+
 // Shared-memory scratch of one tile inversion (a 256-thread workgroup).
 struct TileScratch {
     double stage[TB][TB + 1];
@@ -67,6 +73,8 @@ __device__ __forceinline__ void tile_invert_dev(
     double* __restrict__ Tinv, double* __restrict__ Tsave,     // inv(T); the tile T itself (full, symmetric)
     double* __restrict__ Tflag, double refine_cond,            // *Tflag = 1 when the block solves with this tile need refining
     DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel,
+    const unsigned long long* __restrict__ anorm_bits,   // bits of max |assembled entry| (0 = unknown): scale of a static pivot
+    int64_t neg_from,                          // global index from which pivots are expected negative (n + mi; pyipm.py:1381)
     unsigned long long* __restrict__ dbg)      // diagnostics only (NULL normally)
 {
     double (&stage)[TB][TB + 1] = sm.stage;
@@ -116,7 +124,14 @@ __device__ __forceinline__ void tile_invert_dev(
     __syncthreads();
     const double scale = fmax(fmax(sh_red[0], sh_red[1]), fmax(sh_red[2], sh_red[3]));
     const double inv_scale = scale > 0.0 ? 1.0 / scale : 0.0;
-    const double tiny = 2.2250738585072014e-308;
+    // Static pivot (GESP, as in SuperLU_DIST): a pivot that BK cannot avoid inside the tile and that has cancelled to
+    // nothing is REPLACED by +-sqrt(eps)*max|A| with the sign its KKT block calls for, and reported (n_zero).  The
+    // factor is then that of a matrix perturbed by ~sqrt(eps)|A| in those diagonal entries: finite, the same inertia
+    // as the unperturbed matrix whenever that one is non-singular, and an excellent preconditioner -- the host
+    // recovers the unperturbed solution by refinement against the KKT blocks (HipNewtonBackend.direction), or
+    // regularises as reghess does when that does not converge (pyipm.py:1379-1403).
+    const double pert = static_pivot(anorm_bits);
+    const int neg_lim = (int)((neg_from - grow0) < 0 ? 0 : ((neg_from - grow0) > TB ? TB : (neg_from - grow0)));   // pivots >= this: expected negative
     const int nreal = (int)((Nreal - grow0) < 0 ? 0 : ((Nreal - grow0) > TB ? TB : (Nreal - grow0)));   // real rows in this tile
 
     unsigned long long mask = ~0ull;        // unswept set (identical in every thread)
@@ -139,9 +154,9 @@ __device__ __forceinline__ void tile_invert_dev(
         const double pivtol = pivtol_rel * readlane_f64(cmax0, (pv_));                                   \
         if (__builtin_expect(!(ad <= 1.0e308), 0)) bad = 1;          /* NaN or Inf */                    \
         if (__builtin_expect(ad <= pivtol, 0)) {                                                         \
-            if ((pv_) < nreal) zero++;                                                                   \
-            const double t = pivtol > 0.0 ? pivtol : tiny;                                               \
-            d = (d >= 0.0) ? t : -t;                                                                     \
+            const double t = pivtol > pert ? pivtol : pert;                                              \
+            d = ((pv_) < neg_lim) ? t : -t;                      /* static pivot, expected sign */       \
+            if ((pv_) < nreal) { zero++; neg += (d < 0.0) ? 1 : 0; }                                     \
         } else if ((pv_) < nreal) {                                                                      \
             neg += (d < 0.0) ? 1 : 0;                                                                    \
             dmin = fmin(dmin, ad); dmax = fmax(dmax, ad);                                                \
@@ -257,11 +272,11 @@ __device__ __forceinline__ void tile_invert_dev(
             const double e1 = 0.5 * (tr + disc), e2 = 0.5 * (tr - disc);
             const double pivtol = pivtol_rel * fmax(readlane_f64(cmax0, p), readlane_f64(cmax0, q));
             n2++;
-            if (fabs(e1) <= pivtol) zero++; else { neg += (e1 < 0.0) ? 1 : 0;
-                dmin = fmin(dmin, fabs(e1)); dmax = fmax(dmax, fabs(e1)); }
-            if (fabs(e2) <= pivtol) zero++; else { neg += (e2 < 0.0) ? 1 : 0;
-                dmin = fmin(dmin, fabs(e2)); dmax = fmax(dmax, fabs(e2)); }
-            if (det == 0.0) det = -tiny;
+            // a 2x2 block pivot has det < 0 by the BK test: one positive, one negative eigenvalue (e1 >= 0 >= e2)
+            neg += 1;
+            if (fabs(e1) <= pivtol) zero++; else { dmin = fmin(dmin, fabs(e1)); dmax = fmax(dmax, fabs(e1)); }
+            if (fabs(e2) <= pivtol) zero++; else { dmin = fmin(dmin, fabs(e2)); dmax = fmax(dmax, fabs(e2)); }
+            if (!(fabs(det) > 0.0)) det = -pert * pert;
             const double ia = cc / det, ib = -b / det, ic = a / det;   // inverse of [[a,b],[b,cc]]
             const double vp = rp[lane], vq = rq[lane];
             const double lpi = vp * ia + vq * ib, lqi = vp * ib + vq * ic;
@@ -298,7 +313,7 @@ __device__ __forceinline__ void tile_invert_dev(
         // beyond refine_cond (or with 2x2 pivots) pay for refined block solves.  A tile with a rejected pivot
         // is singular to working precision: its "inverse" belongs to a perturbed tile, nothing to refine against.
         *Tflag = (zero == 0 && (n2 > 0 || !(dmax <= refine_cond * dmin))) ? 1.0 : 0.0;
-        st->n_neg += neg; st->n_zero += zero; st->n_2x2 += n2; st->n_pos += nreal - neg - zero;
+        st->n_neg += neg; st->n_zero += zero; st->n_2x2 += n2; st->n_pos += nreal - neg;    // static pivots count by their sign
         st->nonfinite += bad;
         if (dmin < st->d_min) st->d_min = dmin;
         if (dmax > st->d_max) st->d_max = dmax;
@@ -308,11 +323,12 @@ __device__ __forceinline__ void tile_invert_dev(
 __global__ __launch_bounds__(256) void k_tile_invert(
     const double* __restrict__ A, int64_t ld, int64_t grow0, int64_t lcol0,
     double* __restrict__ Tinv, double* __restrict__ Tsave, double* __restrict__ Tflag, double refine_cond,
-    DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel, unsigned long long* __restrict__ dbg)
+    DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel,
+    const unsigned long long* __restrict__ anorm_bits, int64_t neg_from, unsigned long long* __restrict__ dbg)
 {
     __shared__ TileScratch sm;
     __builtin_amdgcn_s_setprio(3);         // latency-critical chain: win issue arbitration against co-resident bulk waves
-    tile_invert_dev(sm, A, ld, grow0, lcol0, Tinv, Tsave, Tflag, refine_cond, st, Nreal, pivtol_rel, dbg);
+    tile_invert_dev(sm, A, ld, grow0, lcol0, Tinv, Tsave, Tflag, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg);
 }
 
 // 64x64 tile (global, row-major [k][c]) -> LDS array dst_[k][c], scaled: the 16 loads of a thread are issued together
@@ -441,14 +457,16 @@ __global__ __launch_bounds__(256) void k_panel_scale(
 __global__ __launch_bounds__(256) void k_s_panel(
     double* __restrict__ A, int64_t ld, int64_t c0, int64_t lc0, int nt,       // global / local first column of the panel
     double* __restrict__ Tinv, double* __restrict__ Tsave, double* __restrict__ Tflag,     // of the panel's first tile
-    double refine_cond, int nref, DevStats* __restrict__ st, int64_t s0, int64_t i0, double pivtol_rel)
+    double refine_cond, int nref, DevStats* __restrict__ st, int64_t s0, int64_t i0, double pivtol_rel,
+    const unsigned long long* __restrict__ anorm_bits)
 {
     __shared__ long long sh_cnt[4][3];      // neg, zero, bad per wave
     __shared__ double sh_mm[4][3];          // dmin, dmax, gmax per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     long long neg = 0, zero = 0, bad = 0;
     double dmin = 1.0e308, dmax = 0.0, gmax = 0.0;
-    const double tiny = 2.2250738585072014e-308;
+    const double spert = static_pivot(anorm_bits);         // static pivot of a Sigma entry that is exactly zero (lambda_i = 0),
+                                                            // as tile_invert_dev would place it (its tile column is zero)
     for (int t = wave; t < nt; t += 4) {
         const int64_t col = c0 + (int64_t)t * TB + lane;            // global column = row of its diagonal entry
         const int64_t lcol = lc0 + (int64_t)t * TB + lane;          // where this rank stores it
@@ -457,7 +475,7 @@ __global__ __launch_bounds__(256) void k_s_panel(
         const double ad = fabs(d);
         const bool isbad = !(ad <= 1.0e308);
         const bool iszero = ad <= pivtol_rel * ad;                   // the tile-local column maximum is |d| itself
-        if (iszero) d = (d >= 0.0) ? tiny : -tiny;
+        if (iszero) d = spert;
         const double x = 1.0 / d;
         // tile statistics (as k_tile_invert keeps them)
         const unsigned long long mz = __ballot(iszero), mb = __ballot(isbad), mn = __ballot(!iszero && d < 0.0);
@@ -497,7 +515,7 @@ __global__ __launch_bounds__(256) void k_s_panel(
         long long n = 0, z = 0, b = 0; double mn = 1.0e308, mx = 0.0, gm = 0.0;
         for (int w = 0; w < 4; ++w) { n += sh_cnt[w][0]; z += sh_cnt[w][1]; b += sh_cnt[w][2];
                                       mn = fmin(mn, sh_mm[w][0]); mx = fmax(mx, sh_mm[w][1]); gm = fmax(gm, sh_mm[w][2]); }
-        st->n_neg += n; st->n_zero += z; st->n_pos += (long long)nt * TB - n - z; st->nonfinite += b;
+        st->n_neg += n; st->n_zero += z; st->n_pos += (long long)nt * TB - n; st->nonfinite += b;   // static pivots are positive
         if (mn < st->d_min) st->d_min = mn;
         if (mx > st->d_max) st->d_max = mx;
         atomicMax(&st->growth_bits, (unsigned long long)__double_as_longlong(gm));
@@ -525,15 +543,16 @@ __global__ __launch_bounds__(256) void k_s_schur(double* __restrict__ A, int64_t
 __global__ __launch_bounds__(64) void k_s_schur_sigma(
     double* __restrict__ A, int64_t ld, int64_t c0, int64_t s0, int64_t i0,
     const double* __restrict__ s, const double* __restrict__ lda_i, double eps,
-    double refine_cond, int nref, double pivtol_rel, int nb, int world, int rank, int64_t tp0, int64_t tp1)
+    double refine_cond, int nref, double pivtol_rel, int nb, int world, int rank, int64_t tp0, int64_t tp1,
+    const unsigned long long* __restrict__ anorm_bits)     // (ranks agree on it: DistNewton reduces it after assembly)
 {
     const int lane = threadIdx.x;
     const int64_t col = c0 + (int64_t)blockIdx.x * TB + lane, b = col - s0;
     const double d0 = lda_i[b] / (s[b] + eps);
     double d = d0;
-    const double ad = fabs(d), tiny = 2.2250738585072014e-308;
+    const double ad = fabs(d), spert = static_pivot(anorm_bits);
     const bool iszero = ad <= pivtol_rel * ad;
-    if (iszero) d = (d >= 0.0) ? tiny : -tiny;
+    if (iszero) d = spert;
     const double x = 1.0 / d;
     const double tmin = -wave_max(iszero ? -1.0e308 : -ad), tmax = wave_max(iszero ? 0.0 : ad);
     const bool flagged = __popcll(__ballot(iszero)) == 0 && !(tmax <= refine_cond * tmin);

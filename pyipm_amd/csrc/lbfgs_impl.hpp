@@ -202,9 +202,14 @@ int lb_factor_G(LbCtx* lb, double zeta, double reg_e, pyipm_factor_stats* st, bo
 
 }  // namespace
 
+#undef PYIPM_SETERR_NEWTON
+#undef PYIPM_CATCH_H
+#define PYIPM_SETERR_LBFGS(msg_) set_err_noexcept(reinterpret_cast<LbCtx*>(h), (msg_))
+#define PYIPM_CATCH_H(h_)  PYIPM_CATCH_CORE(PYIPM_SETERR_LBFGS, PYIPM_E_NOMEM, PYIPM_E_HIP)
+
 extern "C" {
 
-size_t pyipm_lbfgs_workspace_bytes(int64_t n, int64_t me, int64_t mi, int max_pairs, int nb) {
+size_t pyipm_lbfgs_workspace_bytes(int64_t n, int64_t me, int64_t mi, int max_pairs, int nb) try {
     if (n <= 0 || me < 0 || mi < 0 || max_pairs < 1 || max_pairs > 32) return 0;
     if (nb == 0) nb = 256;
     if (nb % 128 != 0 || nb > 1024) return 0;
@@ -213,10 +218,10 @@ size_t pyipm_lbfgs_workspace_bytes(int64_t n, int64_t me, int64_t mi, int max_pa
     size_t total = lb_carve(nullptr, n, me, mi, max_pairs, p_pad, n_pad, nullptr);
     if (p > 0) total += pyipm_newton_workspace_bytes(p, 0, 0, nb, 1, 0);
     return total;
-}
+} PYIPM_CATCH_SIZE
 
 int pyipm_lbfgs_create(pyipm_lbfgs_ctx** out, int64_t n, int64_t me, int64_t mi, int max_pairs, int nb,
-                       int device, void* stream) {
+                       int device, void* stream) try {
     if (!out) return PYIPM_E_BADARG;
     *out = nullptr;
     if (n <= 0 || me < 0 || mi < 0 || max_pairs < 1 || max_pairs > 32) return PYIPM_E_BADARG;
@@ -250,9 +255,9 @@ int pyipm_lbfgs_create(pyipm_lbfgs_ctx** out, int64_t n, int64_t me, int64_t mi,
     if (!ok) { pyipm_lbfgs_destroy(reinterpret_cast<pyipm_lbfgs_ctx*>(lb)); return PYIPM_E_HIP; }
     *out = reinterpret_cast<pyipm_lbfgs_ctx*>(lb);
     return PYIPM_OK;
-}
+} PYIPM_CATCH_NOH
 
-int pyipm_lbfgs_destroy(pyipm_lbfgs_ctx* h) {
+int pyipm_lbfgs_destroy(pyipm_lbfgs_ctx* h) try {
     if (!h) return PYIPM_E_BADARG;
     LbCtx* lb = LB(h);
     hipSetDevice(lb->device);
@@ -262,38 +267,38 @@ int pyipm_lbfgs_destroy(pyipm_lbfgs_ctx* h) {
     if (lb->ws) hipFree(lb->ws);
     delete lb;
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
 const char* pyipm_lbfgs_last_error(pyipm_lbfgs_ctx* h) {
     if (!h) return "null handle";
     return LB(h)->err.c_str();
 }
 
-int pyipm_lbfgs_set_stream(pyipm_lbfgs_ctx* h, void* stream) {
+int pyipm_lbfgs_set_stream(pyipm_lbfgs_ctx* h, void* stream) try {
     if (!h) return PYIPM_E_BADARG;
     LB(h)->stream = (hipStream_t)stream;
     if (LB(h)->gcx) LB(h)->gcx->stream = (hipStream_t)stream;
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
-int pyipm_lbfgs_set_allreduce(pyipm_lbfgs_ctx* h, pyipm_lbfgs_allreduce_fn fn, void* user) {
+int pyipm_lbfgs_set_allreduce(pyipm_lbfgs_ctx* h, pyipm_lbfgs_allreduce_fn fn, void* user) try {
     if (!h) return PYIPM_E_BADARG;
     LB(h)->allreduce = fn; LB(h)->allreduce_user = user;
     LB(h)->gram_valid = false;
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
-int pyipm_lbfgs_set_option(pyipm_lbfgs_ctx* h, const char* name, double value) {
+int pyipm_lbfgs_set_option(pyipm_lbfgs_ctx* h, const char* name, double value) try {
     if (!h) return PYIPM_E_BADARG;
     LbCtx* lb = LB(h);
     if (!lb->gcx) return PYIPM_OK;
     int rc = pyipm_newton_set_option(reinterpret_cast<pyipm_newton_ctx*>(lb->gcx), name, value);
     if (rc) lb->err = lb->gcx->err;
     return rc;
-}
+} PYIPM_CATCH_H(h)
 
 int pyipm_lbfgs_stage_jacobian(pyipm_lbfgs_ctx* h, const double* Je, int64_t ld_Je, const double* Ji,
-                               int64_t ld_Ji, int memkind) {
+                               int64_t ld_Ji, int memkind) try {
     if (!h) return PYIPM_E_BADARG;
     LbCtx* lb = LB(h);
     if (lb->p == 0) return PYIPM_OK;
@@ -304,12 +309,12 @@ int pyipm_lbfgs_stage_jacobian(pyipm_lbfgs_ctx* h, const double* Je, int64_t ld_
     lb->have_J = true;
     lb->gram_valid = false;
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
 int pyipm_lbfgs_direction(pyipm_lbfgs_ctx* h, const double* g, const double* s, const double* lda, double zeta,
                           int m, const double* S, int64_t ld_S, const double* Y, int64_t ld_Y,
                           const double* SS, const double* L, const double* D, double reg, double eps,
-                          double* dz, int flip, int memkind, pyipm_lbfgs_stats* stats) {
+                          double* dz, int flip, int memkind, pyipm_lbfgs_stats* stats) try {
     if (!h) return PYIPM_E_BADARG;
     LbCtx* lb = LB(h);
     const int64_t n = lb->n, me = lb->me, mi = lb->mi, p = lb->p, N = lb->N;
@@ -463,9 +468,9 @@ int pyipm_lbfgs_direction(pyipm_lbfgs_ctx* h, const double* g, const double* s, 
     lb->did[0] = p > 0;
     if (stats) *stats = out;
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
-int pyipm_lbfgs_last_timings(pyipm_lbfgs_ctx* h, double out[8]) {
+int pyipm_lbfgs_last_timings(pyipm_lbfgs_ctx* h, double out[8]) try {
     if (!h || !out) return PYIPM_E_BADARG;
     LbCtx* lb = LB(h);
     for (int i = 0; i < 8; ++i) out[i] = 0.0;
@@ -487,6 +492,6 @@ int pyipm_lbfgs_last_timings(pyipm_lbfgs_ctx* h, double out[8]) {
         out[7] = (double)lb->n_gram;
     }
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
 }  // extern "C"

@@ -9,6 +9,9 @@
 
 using namespace pyipm;
 
+#define PYIPM_SETERR_NEWTON(msg_) set_err_noexcept(reinterpret_cast<Ctx*>(h), (msg_))
+#define PYIPM_CATCH_H(h_)  PYIPM_CATCH_CORE(PYIPM_SETERR_NEWTON, PYIPM_E_NOMEM, PYIPM_E_HIP)
+
 namespace {
 
 struct Carve { size_t off = 0; size_t take(size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; } };
@@ -41,8 +44,10 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
     const size_t ost = cv.take(sizeof(DevStats));
     const size_t ovc = cv.take((size_t)g.Npad * D);
     const size_t ovt = cv.take((size_t)(g.mi + 16) * D);
+    const size_t oan = cv.take(64);
     if (base) {
         c->vc = (double*)(base + ovc); c->vt = (double*)(base + ovt);
+        c->anorm = (unsigned long long*)(base + oan);
         c->A = (double*)(base + oA); c->Wbuf = (double*)(base + oW); c->Lbuf = (double*)(base + oL);
         c->Dinv = (double*)(base + oD); c->Tsv = (double*)(base + oT); c->Tflag = (double*)(base + oTf); c->rhs = (double*)(base + orhs);
         c->v0 = (double*)(base + ov0); c->v1 = (double*)(base + ov1); c->v2 = (double*)(base + ov2);
@@ -72,7 +77,9 @@ size_t carve_batched(Ctx* c, const Geo& g, int64_t B, char* base) {
     const size_t os = cv.take((size_t)B * (g.mi + 1) * D);
     const size_t ol = cv.take((size_t)B * (g.me + g.mi + 1) * D);
     const size_t ost = cv.take((size_t)B * sizeof(DevStats));
+    const size_t oan = cv.take((size_t)B * sizeof(unsigned long long));
     if (base) {
+        c->anorm = (unsigned long long*)(base + oan);
         c->A = (double*)(base + oA); c->Dinv = (double*)(base + oD); c->Tsv = (double*)(base + oT);
         c->Tflag = (double*)(base + oTf); c->rhs = (double*)(base + orhs); c->v0 = (double*)(base + ov0);
         c->v2 = (double*)(base + ov2);
@@ -95,6 +102,7 @@ BatchPtrs batch_ptrs(Ctx* ctx) {
     bp.sH = ctx->b_sH; bp.sJe = ctx->b_sJe; bp.sJi = ctx->b_sJi;
     bp.ldh = ctx->ld_d2L; bp.ldje = ctx->ld_Je; bp.ldji = ctx->ld_Ji;
     bp.df = ctx->df; bp.ce = ctx->ce; bp.ci = ctx->ci; bp.s = ctx->s; bp.lda = ctx->lda;
+    bp.anorm = ctx->anorm;
     return bp;
 }
 
@@ -179,6 +187,11 @@ double active_area(int64_t row_begin, int64_t Npad, int64_t j0, int64_t j1, int6
 // per-XCD sequences (block b runs on XCD b % 8) are levelled by moving the tails of long ones to short ones,
 // and the result is interleaved back into launch order.  Cached per geometry: it repeats every step.
 int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, unsigned* count) {
+    if (ctx->debug_fault) {                             // test hook (tests/test_gpu_host_abi.py): the containers below can throw
+        const int k = ctx->debug_fault; ctx->debug_fault = 0;
+        if (k == 1) throw std::bad_alloc();
+        throw std::runtime_error("injected fault");
+    }
     std::vector<int64_t> key = {u.row_begin, u.Npad, u.first_lp, u.nrt, u.nct, u.a0, u.a1, u.b0, u.b1, u.nb, u.rt_min0, u.rt_step};
     auto it = ctx->tile_lists.find(key);
     if (it != ctx->tile_lists.end()) { *dev = it->second.dev; *count = it->second.count; return 0; }
@@ -312,7 +325,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
         hipLaunchKernelGGL(k_s_panel, dim3(1), dim3(256), 0, stream, ctx->A, g.Npad, c0, lc0, nt,
                            ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB), ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB),
                            ctx->Tflag + c0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats,
-                           g.n, g.n + g.mi + g.me, ctx->pivtol_rel);
+                           g.n, g.n + g.mi + g.me, ctx->pivtol_rel, ctx->anorm);
         PYIPM_KCHECK();
         return 0;
     }
@@ -373,7 +386,8 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
         }
         hipLaunchKernelGGL(k_tile_invert, dim3(1), dim3(256), 0, stream, ctx->A, g.Npad, j0, lcol,
                            ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), ctx->Tsv + (j0 / TB) * (int64_t)(TB * TB),
-                           ctx->Tflag + j0 / TB, ctx->refine_cond, ctx->dstats, g.N, ctx->pivtol_rel, ctx->dbg_buf);
+                           ctx->Tflag + j0 / TB, ctx->refine_cond, ctx->dstats, g.N, ctx->pivtol_rel, ctx->anorm,
+                           g.n + g.mi, ctx->dbg_buf);
         PYIPM_KCHECK();
         const int64_t below = g.Npad - (j0 + TB);
         if (below > 0) {
@@ -410,7 +424,7 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
         const int64_t tp0 = first_lp * g.world + g.rank, tp1 = (first_lp + n_lp - 1) * g.world + g.rank + 1;
         hipLaunchKernelGGL(k_s_schur_sigma, dim3((unsigned)(K / TB)), dim3(64), 0, stream, ctx->A, g.Npad, g.panel_c0(p0),
                            g.n, g.n + g.mi + g.me, ctx->s, ctx->lda + g.me, ctx->eps, ctx->refine_cond, ctx->block_refine,
-                           ctx->pivtol_rel, g.nb, g.world, g.rank, tp0, tp1);
+                           ctx->pivtol_rel, g.nb, g.world, g.rank, tp0, tp1, ctx->anorm);
         PYIPM_KCHECK();
         return 0;
     }
@@ -723,8 +737,9 @@ int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
     }
     {
         dim3 grid((unsigned)((gc.Npad + 511) / 512), (unsigned)((gc.ncols_local + 15) / 16));
+        PYIPM_HIP(hipMemsetAsync(ctx->anorm, 0, sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, gc.Npad, gc, ctx->d2L, ctx->ld_d2L,
-                           Jx, ldx, (const double*)nullptr, (int64_t)0, ctx->s, ctx->lda, ctx->eps, delta, delta_c);
+                           Jx, ldx, (const double*)nullptr, (int64_t)0, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm);
         PYIPM_KCHECK();
         if (na > 0) {
             hipLaunchKernelGGL(k_cond_fix_diag, grid1(na), dim3(256), 0, ctx->stream, ctx->A, gc.Npad, g.n + g.me,
@@ -760,10 +775,11 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
         return 0;
     }
     ctx->cond_active = false;
+    PYIPM_HIP(hipMemsetAsync(ctx->anorm, 0, sizeof(unsigned long long), ctx->stream));
     if (g.ncols_local > 0) {
         dim3 grid((unsigned)((g.Npad + 511) / 512), (unsigned)((g.ncols_local + 15) / 16));
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
-                           ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c);
+                           ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm);
         PYIPM_KCHECK();
     }
     ctx->assembled = true; ctx->factored = false; ctx->forward_pending = false;
@@ -781,6 +797,34 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     if (g.world != 1) { ctx->err = "factor(): single-rank entry point; use the per-panel phases when world > 1"; return PYIPM_E_BADARG; }
     if (!ctx->assembled) { ctx->err = "factor: assemble first"; return PYIPM_E_BADARG; }
     ctx->per_panel_mode = false;
+    // Optional: run everything this function puts on the handle's stream (the bulk updates, above all) on a CU-masked
+    // stream that leaves `reserve_cus` CUs to the panel chain (side stream, unmasked): the chain's kernels then find
+    // free slots at once instead of waiting for a 250-us bulk block to retire.  Fenced by events at both ends.
+    struct StreamSwap {
+        Ctx* c; hipStream_t user; bool on = false;
+        ~StreamSwap() { if (on) { hipEventRecord(c->ev_bulk1, c->stream); hipStream_t b = c->stream; c->stream = user;
+                                  hipStreamWaitEvent(user, c->ev_bulk1, 0); (void)b; } }
+    } swap{ctx, ctx->stream};
+    if (ctx->reserve_cus > 0) {
+        const int key = ctx->reserve_cus * 4 + ctx->reserve_mode;
+        if (!ctx->bulk || ctx->bulk_key != key) {
+            if (ctx->bulk) { PYIPM_HIP(hipStreamSynchronize(ctx->bulk)); PYIPM_HIP(hipStreamDestroy(ctx->bulk)); ctx->bulk = nullptr; }
+            hipDeviceProp_t prop; PYIPM_HIP(hipGetDeviceProperties(&prop, ctx->device));
+            const int ncu = prop.multiProcessorCount, k = ctx->reserve_cus < ncu / 2 ? ctx->reserve_cus : ncu / 2;
+            std::vector<uint32_t> mask((size_t)((ncu + 31) / 32), 0xffffffffu);
+            for (int q = 0; q < k; ++q) {
+                const int bit = ctx->reserve_mode == 0 ? q : (int)((int64_t)q * ncu / k);
+                mask[(size_t)(bit / 32)] &= ~(1u << (bit % 32));
+            }
+            PYIPM_HIP(hipExtStreamCreateWithCUMask(&ctx->bulk, (uint32_t)mask.size(), mask.data()));
+            ctx->bulk_key = key;
+            if (!ctx->ev_bulk0) { PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_bulk0, hipEventDisableTiming));
+                                  PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_bulk1, hipEventDisableTiming)); }
+        }
+        PYIPM_HIP(hipEventRecord(ctx->ev_bulk0, ctx->stream));
+        PYIPM_HIP(hipStreamWaitEvent(ctx->bulk, ctx->ev_bulk0, 0));
+        ctx->stream = ctx->bulk; swap.on = true;
+    }
     int rc = factor_begin(ctx); if (rc) return rc;
     if (!ctx->side) {
         // panel kernels are latency-critical and tiny: highest dispatch priority, so they take the first
@@ -940,21 +984,27 @@ int factor_dispatch(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward) {
     return rc;
 }
 
+// a failed create releases whatever the handle already owns (events, a library-owned workspace) the way destroy does
+int create_fail(Ctx* ctx, int code) {
+    pyipm_newton_destroy(reinterpret_cast<pyipm_newton_ctx*>(ctx));
+    return code;
+}
+
 }  // namespace
 
 // =================================================================================================
 extern "C" {
 
-size_t pyipm_newton_workspace_bytes(int64_t n, int64_t me, int64_t mi, int nb, int world, int rank) {
+size_t pyipm_newton_workspace_bytes(int64_t n, int64_t me, int64_t mi, int nb, int world, int rank) try {
     if (n <= 0 || me < 0 || mi < 0 || world < 1 || rank < 0 || rank >= world) return 0;
     if (nb == 0) nb = 256;
     if (nb % 128 != 0 || nb > 1024) return 0;
     Geo g = make_geo(n, me, mi, nb, world, rank);
     return carve_workspace(nullptr, g, nullptr);
-}
+} PYIPM_CATCH_SIZE
 
 int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t mi, int nb, int device,
-                        int world, int rank, void* workspace, size_t workspace_bytes, void* stream) {
+                        int world, int rank, void* workspace, size_t workspace_bytes, void* stream) try {
     if (!out) return PYIPM_E_BADARG;
     *out = nullptr;
     if (n <= 0 || me < 0 || mi < 0 || world < 1 || rank < 0 || rank >= world) return PYIPM_E_BADARG;
@@ -968,34 +1018,35 @@ int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t m
     ctx->group = default_group(world);
     ctx->device = device;
     ctx->stream = (hipStream_t)stream;
-    if (hipSetDevice(device) != hipSuccess) { delete ctx; return PYIPM_E_NODEVICE; }
+    if (hipSetDevice(device) != hipSuccess) return create_fail(ctx, PYIPM_E_NODEVICE);
     const size_t need = carve_workspace(nullptr, ctx->g, nullptr);
     if (workspace) {
-        if (workspace_bytes < need) { delete ctx; return PYIPM_E_NOMEM; }
+        if (workspace_bytes < need) return create_fail(ctx, PYIPM_E_NOMEM);
         ctx->ws = (char*)workspace; ctx->own_ws = false;
     } else {
-        if (hipMalloc((void**)&ctx->ws, need) != hipSuccess) { delete ctx; return PYIPM_E_NOMEM; }
+        if (hipMalloc((void**)&ctx->ws, need) != hipSuccess) return create_fail(ctx, PYIPM_E_NOMEM);
         ctx->own_ws = true;
     }
     ctx->ws_bytes = need;
     carve_workspace(ctx, ctx->g, ctx->ws);
-    for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return PYIPM_E_HIP; }
+    if (hipMemset(ctx->anorm, 0, sizeof(unsigned long long)) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
+    for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     if (hipEventCreateWithFlags(&ctx->ev_fwd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_head, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_panel, hipEventDisableTiming) != hipSuccess) { delete ctx; return PYIPM_E_HIP; }
+        hipEventCreateWithFlags(&ctx->ev_panel, hipEventDisableTiming) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     *out = reinterpret_cast<pyipm_newton_ctx*>(ctx);
     return PYIPM_OK;
-}
+} PYIPM_CATCH_NOH
 
-size_t pyipm_newton_workspace_bytes_batched(int64_t n, int64_t me, int64_t mi, int batch) {
+size_t pyipm_newton_workspace_bytes_batched(int64_t n, int64_t me, int64_t mi, int batch) try {
     if (n <= 0 || me < 0 || mi < 0 || batch < 1) return 0;
     Geo g = make_geo(n, me, mi, 128, 1, 0);
     if (g.Npad > 1024) return 0;
     return carve_batched(nullptr, g, batch, nullptr);
-}
+} PYIPM_CATCH_SIZE
 
 int pyipm_newton_create_batched(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t mi, int batch, int device,
-                                void* workspace, size_t workspace_bytes, void* stream) {
+                                void* workspace, size_t workspace_bytes, void* stream) try {
     if (!out) return PYIPM_E_BADARG;
     *out = nullptr;
     if (n <= 0 || me < 0 || mi < 0 || batch < 1) return PYIPM_E_BADARG;
@@ -1009,26 +1060,27 @@ int pyipm_newton_create_batched(pyipm_newton_ctx** out, int64_t n, int64_t me, i
     ctx->group = 1;
     ctx->device = device;
     ctx->stream = (hipStream_t)stream;
-    if (hipSetDevice(device) != hipSuccess) { delete ctx; return PYIPM_E_NODEVICE; }
+    if (hipSetDevice(device) != hipSuccess) return create_fail(ctx, PYIPM_E_NODEVICE);
     const size_t need = carve_batched(nullptr, g, batch, nullptr);
     if (workspace) {
-        if (workspace_bytes < need) { delete ctx; return PYIPM_E_NOMEM; }
+        if (workspace_bytes < need) return create_fail(ctx, PYIPM_E_NOMEM);
         ctx->ws = (char*)workspace; ctx->own_ws = false;
     } else {
-        if (hipMalloc((void**)&ctx->ws, need) != hipSuccess) { delete ctx; return PYIPM_E_NOMEM; }
+        if (hipMalloc((void**)&ctx->ws, need) != hipSuccess) return create_fail(ctx, PYIPM_E_NOMEM);
         ctx->own_ws = true;
     }
     ctx->ws_bytes = need;
     carve_batched(ctx, g, batch, ctx->ws);
     ctx->batched = true;
-    for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return PYIPM_E_HIP; }
+    if (hipMemset(ctx->anorm, 0, (size_t)batch * sizeof(unsigned long long)) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
+    for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     *out = reinterpret_cast<pyipm_newton_ctx*>(ctx);
     return PYIPM_OK;
-}
+} PYIPM_CATCH_NOH
 
 int pyipm_newton_stage_blocks_batched(pyipm_newton_ctx* h, const double* d2L, int64_t ld_d2L, int64_t stride_d2L,
                                       const double* Je, int64_t ld_Je, int64_t stride_Je,
-                                      const double* Ji, int64_t ld_Ji, int64_t stride_Ji) {
+                                      const double* Ji, int64_t ld_Ji, int64_t stride_Ji) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
     if (!ctx->batched) { ctx->err = "stage_blocks_batched: not a batched handle"; return PYIPM_E_BADARG; }
@@ -1039,10 +1091,10 @@ int pyipm_newton_stage_blocks_batched(pyipm_newton_ctx* h, const double* d2L, in
     ctx->Ji = g.mi ? Ji : nullptr; ctx->ld_Ji = ld_Ji; ctx->b_sJi = stride_Ji;
     ctx->have_blocks = true;
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
 int pyipm_newton_step_batched(pyipm_newton_ctx* h, double delta, double delta_c, double* dz,
-                              pyipm_factor_stats* stats, int memkind) {
+                              pyipm_factor_stats* stats, int memkind) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
     PYIPM_HIP(hipSetDevice(ctx->device));
@@ -1055,6 +1107,7 @@ int pyipm_newton_step_batched(pyipm_newton_ctx* h, double delta, double delta_c,
     hipLaunchKernelGGL(k_b_residual, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->mu, ctx->eps);
     PYIPM_KCHECK();
     {
+        PYIPM_HIP(hipMemsetAsync(ctx->anorm, 0, (size_t)B * sizeof(unsigned long long), ctx->stream));
         dim3 grid((unsigned)((g.Npad + 511) / 512), (unsigned)((g.Npad + 15) / 16), (unsigned)B);
         hipLaunchKernelGGL(k_b_assemble, grid, dim3(256), 0, ctx->stream, bp, g, ctx->eps, delta, delta_c);
         PYIPM_KCHECK();
@@ -1087,9 +1140,9 @@ int pyipm_newton_step_batched(pyipm_newton_ctx* h, double delta, double delta_c,
         PYIPM_HIP(hipStreamSynchronize(ctx->stream));
     }
     return rc;
-}
+} PYIPM_CATCH_H(h)
 
-int pyipm_newton_destroy(pyipm_newton_ctx* h) {
+int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     hipSetDevice(ctx->device);
@@ -1099,6 +1152,9 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) {
     if (ctx->ev_head) hipEventDestroy(ctx->ev_head);
     if (ctx->ev_panel) hipEventDestroy(ctx->ev_panel);
     if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
+    if (ctx->bulk) { hipStreamSynchronize(ctx->bulk); hipStreamDestroy(ctx->bulk); }
+    if (ctx->ev_bulk0) hipEventDestroy(ctx->ev_bulk0);
+    if (ctx->ev_bulk1) hipEventDestroy(ctx->ev_bulk1);
     if (ctx->fwd) { hipStreamSynchronize(ctx->fwd); hipStreamDestroy(ctx->fwd); }
     if (ctx->ev_fwd) hipEventDestroy(ctx->ev_fwd);
     for (auto e : ctx->ev_done) hipEventDestroy(e);
@@ -1113,29 +1169,29 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) {
     if (ctx->own_ws && ctx->ws) hipFree(ctx->ws);
     delete ctx;
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
-int pyipm_newton_set_stream(pyipm_newton_ctx* h, void* stream) {
+int pyipm_newton_set_stream(pyipm_newton_ctx* h, void* stream) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     C(h)->stream = (hipStream_t)stream;
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
 const char* pyipm_newton_last_error(pyipm_newton_ctx* h) {
     if (!h) return "null handle";
     return C(h)->err.c_str();
 }
 
-int pyipm_newton_geometry(pyipm_newton_ctx* h, int64_t out[8]) {
+int pyipm_newton_geometry(pyipm_newton_ctx* h, int64_t out[8]) try {
     if (check_ctx(h) || !out) return PYIPM_E_BADARG;
     const Geo& g = C(h)->g;
     out[0] = g.N; out[1] = g.Npad; out[2] = g.nb; out[3] = g.npanels; out[4] = g.ncols_local;
     out[5] = g.world; out[6] = g.rank; out[7] = (int64_t)C(h)->ws_bytes;
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
 int pyipm_newton_stage_blocks(pyipm_newton_ctx* h, const double* d2L, int64_t ld_d2L, const double* Je,
-                              int64_t ld_Je, const double* Ji, int64_t ld_Ji, int memkind) {
+                              int64_t ld_Je, const double* Ji, int64_t ld_Ji, int memkind) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
     if (ctx->batched) return single_only(ctx);
@@ -1146,10 +1202,10 @@ int pyipm_newton_stage_blocks(pyipm_newton_ctx* h, const double* d2L, int64_t ld
     rc = stage_block(ctx, Ji, g.mi ? g.n : 0, g.mi, ld_Ji, memkind, &ctx->stg_Ji, &ctx->stg_Ji_sz, &ctx->Ji, &ctx->ld_Ji); if (rc) return rc;
     ctx->have_blocks = true;
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
 int pyipm_newton_stage_vectors(pyipm_newton_ctx* h, const double* df, const double* ce, const double* ci,
-                               const double* s, const double* lda, double mu, double eps, int memkind) {
+                               const double* s, const double* lda, double mu, double eps, int memkind) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
     PYIPM_HIP(hipSetDevice(ctx->device));
@@ -1163,7 +1219,7 @@ int pyipm_newton_stage_vectors(pyipm_newton_ctx* h, const double* df, const doub
     ctx->mu = mu; ctx->eps = eps;
     ctx->have_vectors = true;
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
 static int copy_out(Ctx* ctx, double* dst, const double* src_dev, size_t count, int memkind) {
     if (!dst || count == 0) return 0;
@@ -1173,16 +1229,16 @@ static int copy_out(Ctx* ctx, double* dst, const double* src_dev, size_t count, 
     return 0;
 }
 
-int pyipm_newton_residual(pyipm_newton_ctx* h, double* g_out, int memkind) {
+int pyipm_newton_residual(pyipm_newton_ctx* h, double* g_out, int memkind) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     int rc = residual_dev(ctx); if (rc) return rc;
     return copy_out(ctx, g_out, ctx->rhs, ctx->g.N, memkind);
-}
+} PYIPM_CATCH_H(h)
 
-int pyipm_newton_assemble(pyipm_newton_ctx* h, double delta, double delta_c) {
+int pyipm_newton_assemble(pyipm_newton_ctx* h, double delta, double delta_c) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     if (ctx->batched) return single_only(ctx);
@@ -1192,11 +1248,11 @@ int pyipm_newton_assemble(pyipm_newton_ctx* h, double delta, double delta_c) {
     PYIPM_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
     ctx->ev_assemble_valid = true;
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
 static int solve_prepare(Ctx* ctx, const double* rhs, int memkind, bool for_fused_forward = false);
 
-int pyipm_newton_factor(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
+int pyipm_newton_factor(pyipm_newton_ctx* h, pyipm_factor_stats* stats) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     if (ctx->batched) return single_only(ctx);
@@ -1208,7 +1264,7 @@ int pyipm_newton_factor(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
     int rc = factor_dispatch(ctx, stats, fuse);
     ctx->forward_pending = (rc == 0 || rc == PYIPM_E_NONFINITE) ? (fuse && ctx->forward_fused) : false;
     return rc;
-}
+} PYIPM_CATCH_H(h)
 
 // load the right-hand side into v1 (kept for refinement) and v0 (solved in place)
 static int solve_prepare(Ctx* ctx, const double* rhs, int memkind, bool for_fused_forward) {
@@ -1228,15 +1284,38 @@ static int solve_prepare(Ctx* ctx, const double* rhs, int memkind, bool for_fuse
 static int solve_finish(Ctx* ctx, double* dz, int flip, int refine, int memkind, bool forward_done) {
     const Geo& g = ctx->g;
     int rc = solve_inplace(ctx, ctx->v0, forward_done); if (rc) return rc;
-    if (ctx->cond_active && refine < ctx->cond_min_refine) refine = ctx->cond_min_refine;
-    for (int it = 0; it < refine; ++it) {
-        // r = b - Hc x ;  x += Hc^{-1} r      (Hc applied from the blocks, not from the factor)
+    if (ctx->cond_active && refine >= 0 && refine < ctx->cond_min_refine) refine = ctx->cond_min_refine;
+    ctx->info_steps = 0; ctx->info_converged = 0; ctx->info_berr0 = -1.0; ctx->info_berr = -1.0;
+    // refine >= 0: that many steps of   r = b - Hc x ;  x += Hc^{-1} r   (Hc applied from the blocks, not from the factor).
+    // refine <  0: adaptive -- measure |r|/|b| before every step and stop at refine_target, after refine_max steps or
+    //              when a step gains less than 4x.  This is what turns the factor of a statically pivoted (perturbed)
+    //              matrix into the solution of the UNperturbed system; the host reads the outcome with solve_info.
+    const bool adaptive = refine < 0;
+    const int maxit = adaptive ? ctx->refine_max : refine;
+    double prev = -1.0;
+    for (int it = 0; it <= maxit; ++it) {
+        if (!adaptive && it == maxit) break;
         rc = kkt_matvec_dev(ctx, ctx->v0, ctx->v2); if (rc) return rc;
         hipLaunchKernelGGL(k_axpby, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v2, ctx->v1, ctx->v2, 1.0, -1.0, g.Npad);
         PYIPM_KCHECK();
+        if (adaptive) {
+            double ss[2];
+            hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, ctx->stream, ctx->partial, ctx->v2, ctx->v1, g.N);
+            PYIPM_KCHECK();
+            PYIPM_HIP(hipMemcpyAsync(ss, ctx->partial, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+            const double berr = ss[1] > 0.0 ? sqrt(ss[0] / ss[1]) : sqrt(ss[0]);
+            if (it == 0) ctx->info_berr0 = berr;
+            ctx->info_berr = berr;
+            if (!(berr <= 1.0e300)) break;                                    // NaN / Inf: nothing to refine
+            if (berr <= ctx->refine_target) { ctx->info_converged = 1; break; }
+            if (it == maxit || (prev >= 0.0 && berr > 0.25 * prev)) break;    // out of budget / stagnating
+            prev = berr;
+        }
         rc = solve_inplace(ctx, ctx->v2); if (rc) return rc;
         hipLaunchKernelGGL(k_axpby, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v0, ctx->v0, ctx->v2, 1.0, 1.0, g.Npad);
         PYIPM_KCHECK();
+        ctx->info_steps = it + 1;
     }
     // flip + copy out (device staging through v2 so host copies stay contiguous)
     hipLaunchKernelGGL(k_copy_flip, grid1(g.N), dim3(256), 0, ctx->stream, ctx->v2, ctx->v0, g.N, g.n + g.mi,
@@ -1249,7 +1328,7 @@ static int solve_finish(Ctx* ctx, double* dz, int flip, int refine, int memkind,
     return PYIPM_OK;
 }
 
-int pyipm_newton_solve(pyipm_newton_ctx* h, const double* rhs, double* dz, int flip, int refine, int memkind) {
+int pyipm_newton_solve(pyipm_newton_ctx* h, const double* rhs, double* dz, int flip, int refine, int memkind) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
     if (ctx->batched) return single_only(ctx);
@@ -1262,9 +1341,9 @@ int pyipm_newton_solve(pyipm_newton_ctx* h, const double* rhs, double* dz, int f
     ctx->forward_pending = false;                                     // consumed (or overwritten) either way
     if (!pending) { int rc = solve_prepare(ctx, rhs, memkind); if (rc) return rc; }
     return solve_finish(ctx, dz, flip, refine, memkind, pending);
-}
+} PYIPM_CATCH_H(h)
 
-int pyipm_newton_kkt_matvec(pyipm_newton_ctx* h, const double* v, double* y, int memkind) {
+int pyipm_newton_kkt_matvec(pyipm_newton_ctx* h, const double* v, double* y, int memkind) try {
     if (check_ctx(h) || !v || !y) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
     if (ctx->batched) return single_only(ctx);
@@ -1276,10 +1355,75 @@ int pyipm_newton_kkt_matvec(pyipm_newton_ctx* h, const double* v, double* y, int
     int rc = put_vec(ctx, ctx->v1, v, g.N, memkind); if (rc) return rc;
     rc = kkt_matvec_dev(ctx, ctx->v1, ctx->vc); if (rc) return rc;
     return copy_out(ctx, y, ctx->vc, g.N, memkind);
-}
+} PYIPM_CATCH_H(h)
+
+int pyipm_newton_solve_info(pyipm_newton_ctx* h, double out[4]) try {
+    if (check_ctx(h) || !out) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    out[0] = (double)ctx->info_steps; out[1] = ctx->info_berr0; out[2] = ctx->info_berr; out[3] = (double)ctx->info_converged;
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+// Restates the quantity reghess tests, rcond = min|w| / max|w| over the eigenvalues of Hc (pyipm.py:1379-1381), without
+// an eigendecomposition: max|w| by power iteration on Hc applied from the blocks, min|w| by inverse iteration with
+// the factor (each step one substitution sweep).  Few iterations suffice for a threshold test at eps: a singular
+// direction dominates inv(Hc) by many orders of magnitude.
+int pyipm_newton_rcond(pyipm_newton_ctx* h, int it_inv, int it_pow, double out[4]) try {
+    if (check_ctx(h) || !out) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    if (g.world != 1) { ctx->err = "rcond(): single-rank entry point"; return PYIPM_E_BADARG; }
+    if (!ctx->factored) { ctx->err = "rcond: factor first"; return PYIPM_E_BADARG; }
+    if (it_inv < 1) it_inv = 3;
+    if (it_pow < 1) it_pow = 6;
+    ctx->forward_pending = false; ctx->have_direction = false;       // v0..v2 / vc are about to be reused
+    double ss[2], lmax = 0.0, linv = 0.0;
+    auto norm_of = [&](const double* v, double* nrm) -> int {
+        hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, ctx->stream, ctx->partial, v, v, g.N);
+        PYIPM_KCHECK();
+        PYIPM_HIP(hipMemcpyAsync(ss, ctx->partial, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+        *nrm = sqrt(ss[0]);
+        return 0;
+    };
+    for (int phase = 0; phase < 2; ++phase) {
+        hipLaunchKernelGGL(k_hash_vector, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v1, g.N, g.Npad, (unsigned long long)(17 + phase));
+        PYIPM_KCHECK();
+        double nrm = 0.0, est = 0.0;
+        int rc = norm_of(ctx->v1, &nrm); if (rc) return rc;
+        const int its = phase == 0 ? it_pow : it_inv;
+        for (int it = 0; it < its; ++it) {
+            if (!(nrm > 0.0) || !(nrm <= 1.0e300)) break;
+            if (phase == 0) {
+                hipLaunchKernelGGL(k_scale_copy, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v0, ctx->v1, 1.0 / nrm, g.Npad); PYIPM_KCHECK();
+                rc = kkt_matvec_dev(ctx, ctx->v0, ctx->v1); if (rc) return rc;          // v1 = Hc (v / |v|)
+            } else {
+                hipLaunchKernelGGL(k_scale_copy, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v0, ctx->v1, 1.0 / nrm, g.Npad); PYIPM_KCHECK();
+                rc = solve_inplace(ctx, ctx->v0); if (rc) return rc;                     // v0 = inv(factored) (v / |v|)
+                PYIPM_HIP(hipMemcpyAsync(ctx->v1, ctx->v0, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            rc = norm_of(ctx->v1, &nrm); if (rc) return rc;
+            est = nrm;
+        }
+        if (phase == 0) lmax = est; else linv = est;
+    }
+    const double lmin = linv > 0.0 ? 1.0 / linv : 0.0;
+    out[0] = lmin; out[1] = lmax; out[2] = (lmax > 0.0) ? lmin / lmax : 0.0;
+    double an = 0.0;
+    PYIPM_HIP(hipMemcpy(&an, ctx->anorm, sizeof(double), hipMemcpyDeviceToHost));
+    out[3] = 1.4901161193847656e-08 * ((an > 0.0 && an <= 1.0e300) ? an : 1.0);      // magnitude of a static pivot
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+int pyipm_newton_anorm(pyipm_newton_ctx* h, double** dev_ptr) try {
+    if (check_ctx(h) || !dev_ptr) return PYIPM_E_BADARG;
+    *dev_ptr = reinterpret_cast<double*>(C(h)->anorm);        // bits of a non-negative double ARE that double
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
 
 int pyipm_newton_step(pyipm_newton_ctx* h, double delta, double delta_c, int refine, double* dz,
-                      pyipm_factor_stats* stats, int memkind) {
+                      pyipm_factor_stats* stats, int memkind) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     if (ctx->batched) return single_only(ctx);
@@ -1294,9 +1438,9 @@ int pyipm_newton_step(pyipm_newton_ctx* h, double delta, double delta_c, int ref
     PYIPM_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     if (!fuse) { rc = solve_prepare(ctx, nullptr, memkind); if (rc) return rc; }
     return solve_finish(ctx, dz, 1, refine, memkind, fuse && ctx->forward_fused);
-}
+} PYIPM_CATCH_H(h)
 
-int pyipm_newton_step_lengths(pyipm_newton_ctx* h, double tau, double* alpha_s, double* alpha_l) {
+int pyipm_newton_step_lengths(pyipm_newton_ctx* h, double tau, double* alpha_s, double* alpha_l) try {
     if (check_ctx(h) || !alpha_s || !alpha_l) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
     if (ctx->batched) return single_only(ctx);
@@ -1314,10 +1458,10 @@ int pyipm_newton_step_lengths(pyipm_newton_ctx* h, double tau, double* alpha_s, 
     PYIPM_HIP(hipStreamSynchronize(ctx->stream));
     *alpha_s = out[0]; *alpha_l = out[1];
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
 // ---- per-panel phases -----------------------------------------------------------------------------
-int pyipm_newton_factor_begin(pyipm_newton_ctx* h) {
+int pyipm_newton_factor_begin(pyipm_newton_ctx* h) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
     if (ctx->batched) return single_only(ctx);
@@ -1326,29 +1470,29 @@ int pyipm_newton_factor_begin(pyipm_newton_ctx* h) {
     ctx->grp_of.clear(); ctx->grp_off.clear(); ctx->grp_fast.clear(); ctx->grp_x.clear();      // per-panel phases: uniform group map, dense panels
     ctx->per_panel_mode = true;
     return factor_begin(ctx);
-}
-int pyipm_newton_factor_end(pyipm_newton_ctx* h, pyipm_factor_stats* stats) {
+} PYIPM_CATCH_H(h)
+int pyipm_newton_factor_end(pyipm_newton_ctx* h, pyipm_factor_stats* stats) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
     if (ctx->batched) return single_only(ctx);
     ctx->assembled = false;
     return factor_end(ctx, stats);
-}
-int pyipm_newton_factor_panel(pyipm_newton_ctx* h, int64_t p) {
+} PYIPM_CATCH_H(h)
+int pyipm_newton_factor_panel(pyipm_newton_ctx* h, int64_t p) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
     if (ctx->batched) return single_only(ctx);
     return factor_panel(ctx, p, ctx->stream, false);
-}
-int pyipm_newton_trailing_update(pyipm_newton_ctx* h, int64_t p) {
+} PYIPM_CATCH_H(h)
+int pyipm_newton_trailing_update(pyipm_newton_ctx* h, int64_t p) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
     if (ctx->batched) return single_only(ctx);
     if (p < 0 || p >= ctx->g.npanels) return PYIPM_E_BADARG;
     return trailing_update(ctx, p);
-}
+} PYIPM_CATCH_H(h)
 
-int pyipm_newton_trailing_update_range(pyipm_newton_ctx* h, int64_t p, int64_t first, int64_t count) {
+int pyipm_newton_trailing_update_range(pyipm_newton_ctx* h, int64_t p, int64_t first, int64_t count) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
     if (ctx->batched) return single_only(ctx);
@@ -1363,10 +1507,10 @@ int pyipm_newton_trailing_update_range(pyipm_newton_ctx* h, int64_t p, int64_t f
     int64_t n_lp = 0;
     for (int64_t qq = q; qq < last; qq += g.world) ++n_lp;
     return timed_update(ctx, p, 1, q / g.world, n_lp);
-}
+} PYIPM_CATCH_H(h)
 
 // message = [ W rows below the panel (m x nbw, column-major, ld = m) | nbw/64 tile inverses | nbw/64 tiles | nbw/64 flags ]
-size_t pyipm_newton_panel_msg_bytes(pyipm_newton_ctx* h, int64_t p) {
+size_t pyipm_newton_panel_msg_bytes(pyipm_newton_ctx* h, int64_t p) try {
     if (check_ctx(h)) return 0;
     const Geo& g = C(h)->g;
     if (p < 0 || p >= g.npanels) return 0;
@@ -1375,9 +1519,9 @@ size_t pyipm_newton_panel_msg_bytes(pyipm_newton_ctx* h, int64_t p) {
     panel_hole(C(h), p, &h0, &h1);
     const int64_t nbw = g.panel_w(p), m = g.Npad - (g.panel_c0(p) + nbw) - (h1 - h0);    // slack rows of an x panel stay home
     return (size_t)(m * nbw + 2 * (nbw / TB) * TB * TB + nbw / TB) * sizeof(double);
-}
+} PYIPM_CATCH_SIZE
 
-int pyipm_newton_panel_pack(pyipm_newton_ctx* h, int64_t p, double* buf) {
+int pyipm_newton_panel_pack(pyipm_newton_ctx* h, int64_t p, double* buf) try {
     if (check_ctx(h) || !buf) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
     if (ctx->batched) return single_only(ctx);
@@ -1402,9 +1546,9 @@ int pyipm_newton_panel_pack(pyipm_newton_ctx* h, int64_t p, double* buf) {
     PYIPM_HIP(hipMemcpyAsync(buf + m * nbw + 2 * (nbw / TB) * TB * TB, ctx->Tflag + g.panel_c0(p) / TB,
                              (size_t)(nbw / TB) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
-int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf) {
+int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf) try {
     if (check_ctx(h) || !buf) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
     if (ctx->batched) return single_only(ctx);
@@ -1439,41 +1583,41 @@ int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf)
         }
     }
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
-int pyipm_newton_fwd_panel(pyipm_newton_ctx* h, int64_t p, double* v) {
+int pyipm_newton_fwd_panel(pyipm_newton_ctx* h, int64_t p, double* v) try {
     if (check_ctx(h) || !v) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
     if (ctx->batched) return single_only(ctx);
     if (p < 0 || p >= ctx->g.npanels || ctx->g.owner(p) != ctx->g.rank) return PYIPM_E_BADARG;
     return fwd_panel(ctx, p, v);
-}
-int pyipm_newton_diag_panel(pyipm_newton_ctx* h, int64_t p, double* v) {
+} PYIPM_CATCH_H(h)
+int pyipm_newton_diag_panel(pyipm_newton_ctx* h, int64_t p, double* v) try {
     if (check_ctx(h) || !v) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
     if (ctx->batched) return single_only(ctx);
     if (p < 0 || p >= ctx->g.npanels) return PYIPM_E_BADARG;
     return diag_panel(ctx, p, v);
-}
-int pyipm_newton_bwd_panel(pyipm_newton_ctx* h, int64_t p, double* v) {
+} PYIPM_CATCH_H(h)
+int pyipm_newton_bwd_panel(pyipm_newton_ctx* h, int64_t p, double* v) try {
     if (check_ctx(h) || !v) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); PYIPM_HIP(hipSetDevice(ctx->device));
     if (ctx->batched) return single_only(ctx);
     if (p < 0 || p >= ctx->g.npanels || ctx->g.owner(p) != ctx->g.rank) return PYIPM_E_BADARG;
     return bwd_panel(ctx, p, v);
-}
+} PYIPM_CATCH_H(h)
 
 // ---- introspection --------------------------------------------------------------------------------
-int pyipm_newton_kkt_storage(pyipm_newton_ctx* h, double** ptr, int64_t* ld, int64_t* ncols) {
+int pyipm_newton_kkt_storage(pyipm_newton_ctx* h, double** ptr, int64_t* ld, int64_t* ncols) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     if (ptr) *ptr = ctx->A;
     if (ld) *ld = ctx->cond_active ? ctx->gc.Npad : ctx->g.Npad;
     if (ncols) *ncols = ctx->cond_active ? ctx->gc.ncols_local : ctx->g.ncols_local;
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
-int pyipm_newton_last_timings(pyipm_newton_ctx* h, double out[8]) {
+int pyipm_newton_last_timings(pyipm_newton_ctx* h, double out[8]) try {
     if (check_ctx(h) || !out) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     PYIPM_HIP(hipSetDevice(ctx->device));
@@ -1484,13 +1628,16 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* h, double out[8]) {
     out[4] = (double)ctx->n_trailing; out[5] = ctx->trailing_flops; out[6] = ctx->t_factor;
     out[7] = ctx->cond_active ? ctx->t_gram : ctx->trailing_area;   // full system: entries updated by the trailing launches
     return PYIPM_OK;
-}
+} PYIPM_CATCH_H(h)
 
-int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value) {
+int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value) try {
     if (check_ctx(h) || !name) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
     if (!strcmp(name, "profile")) { ctx->profile = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "debug_fault")) { ctx->debug_fault = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "refine_target")) { ctx->refine_target = value; return PYIPM_OK; }
+    if (!strcmp(name, "refine_max")) { ctx->refine_max = (int)value < 0 ? 0 : (int)value; return PYIPM_OK; }
     if (!strcmp(name, "refine_cond")) { ctx->refine_cond = value; return PYIPM_OK; }
     if (!strcmp(name, "block_refine")) { int v = (int)value; ctx->block_refine = v < 0 ? 0 : (v > 3 ? 3 : v); return PYIPM_OK; }
     if (!strcmp(name, "condensed")) {
@@ -1508,6 +1655,8 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "tail_group")) { ctx->tail_group = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "tail_cols")) { ctx->tail_cols = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "reserve_cus")) { ctx->reserve_cus = (int)value < 0 ? 0 : (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "reserve_mode")) { ctx->reserve_mode = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "inpanel32")) { ctx->inpanel32 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
@@ -1519,9 +1668,9 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
         ctx->dbg_buf = (unsigned long long*)(uintptr_t)(unsigned long long)value; return PYIPM_OK; }
     ctx->err = std::string("unknown option ") + name;
     return PYIPM_E_BADARG;
-}
+} PYIPM_CATCH_H(h)
 
-int pyipm_mfma_f64_peak(int device, int iters, double* tflops) {
+int pyipm_mfma_f64_peak(int device, int iters, double* tflops) try {
     if (!tflops || iters <= 0) return PYIPM_E_BADARG;
     if (hipSetDevice(device) != hipSuccess) return PYIPM_E_NODEVICE;
     hipDeviceProp_t prop;
@@ -1540,7 +1689,7 @@ int pyipm_mfma_f64_peak(int device, int iters, double* tflops) {
     *tflops = flops / (ms * 1e-3) / 1e12;
     hipEventDestroy(e0); hipEventDestroy(e1); hipFree(d);
     return hipGetLastError() == hipSuccess ? PYIPM_OK : PYIPM_E_HIP;
-}
+} PYIPM_CATCH_NOH
 
 }  // extern "C"
 

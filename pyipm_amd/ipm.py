@@ -32,15 +32,27 @@ import numpy as np
 
 class HipNewtonBackend(object):
     """Newton backend on the HIP core: the counterpart of ``reghess`` + ``sym_solve_cmp``
-    (pyipm.py:1373-1406, 1717-1725).  Inertia comes from the block pivots of the
-    factorisation instead of ``eigvalsh``; the "rcond <= eps" trigger of the reference
-    (:1379-1381) is replaced by "a pivot was rejected or d_min/d_max <= eps"."""
+    (pyipm.py:1373-1406, 1717-1725).
+
+    * Inertia comes from the block pivots of the factorisation instead of ``eigvalsh`` (Sylvester).
+    * The reference solves with LU + partial pivoting over the WHOLE matrix (pyipm.py:18-20); the device pivots
+      inside 64x64 tiles.  A pivot that cannot be avoided inside its tile and has cancelled to nothing (LPs and
+      other problems with zero Hessian rows: the x-x tile is singular although the KKT matrix is not) becomes a
+      *static pivot* (``n_zero``): the factor is that of a matrix perturbed by sqrt(eps)|Hc| in those diagonal
+      entries, and the direction of the UNperturbed system is recovered by refinement against the KKT blocks
+      (``solve(refine=-1)``).  Converged => the reference's own answer with its own "no shift" decision.  Not
+      converged => Hc is singular to working precision, which is what the reference's ``rcond <= eps`` test
+      detects (pyipm.py:1379-1381): the same delta / delta_c branch is taken.
+    * Without static pivots the "rcond <= eps" trigger is "d_min/d_max <= eps" on the block pivots."""
+
+    berr_tol = 1e-11                       # backward error a refined direction must meet to count as converged
 
     def __init__(self, n, me, mi, device=None, nb=256, refine=0, max_shift_tries=60, device_step=False,
                  condensed=False):
         from .newton import NewtonCore
         self.core = NewtonCore(n, me, mi, device=device, nb=nb)
-        self.condensed_on = bool(condensed and mi)
+        self.condensed_requested = bool(condensed and mi)
+        self.condensed_on = self.condensed_requested
         self.condensed_tol = 1e-9           # backward-error bar a condensed direction must meet
         self.n_condensed_fallback = 0
         self.condensed_fallback_reason = None
@@ -52,6 +64,65 @@ class HipNewtonBackend(object):
         self.device_step = device_step      # closed-form step lengths on the device
         self.max_shift_tries = max_shift_tries
         self.n_factor = 0
+        self.n_static = 0                   # directions recovered from a statically pivoted factor
+        self.last_solve_info = None
+
+    def shape(self):
+        return (self.n, self.me, self.mi)
+
+    def new_solve(self):
+        """Called at the start of every IPM.solve(): a condensed-form fallback lasts for one solve, not for the
+        lifetime of the backend."""
+        if self.condensed_requested and not self.condensed_on:
+            self.condensed_on = True
+            self.core.set_option("condensed", 1)
+
+    def _factor(self):
+        """factor(); a NaN/Inf met on the way is reported like a singular matrix (the host regularises and retries,
+        as reghess would) instead of aborting the solve."""
+        from .newton import NewtonError
+        self.n_factor += 1
+        try:
+            return self.core.factor()
+        except NewtonError as e:
+            if e.code != -4 or e.stats is None:
+                raise
+            return e.stats
+
+    suspect_spread = 1e-10                 # pivot spread d_min/d_max below which the condition estimate is consulted
+
+    def _singular(self, st, eps):
+        """The reference's ``rcond <= eps`` test (pyipm.py:1379-1381, rcond = min|w|/max|w| over the eigenvalues).
+        Block pivots of moderate spread cannot hide an eigenvalue ratio at the eps level; otherwise, and whenever
+        static pivots were placed, the ratio is ESTIMATED from the factor and the blocks (``core.rcond``: inverse /
+        power iterations).  With static pivots the factor is that of a perturbed matrix, whose smallest eigenvalue
+        sits at the perturbation level exactly when the unperturbed matrix is singular."""
+        self.last_rcond = None
+        if st["nonfinite"]:
+            return True
+        spread = st["d_min"] / st["d_max"] if st["d_max"] > 0 else 1.0
+        if st["n_zero"] == 0 and spread > self.suspect_spread:
+            return False
+        est = self.last_rcond = self.core.rcond()
+        if st["n_zero"] > 0 and est["w_min"] <= 100.0 * est["static_pivot"]:
+            return True
+        return est["rcond"] <= eps
+
+    @staticmethod
+    def _at_risk(st):
+        """Block pivots whose accuracy the tile-local pivot search does not guarantee: static pivots, 2x2 pivots
+        (indefinite tiles) or large entries of L.  Such a direction is checked against the blocks and refined."""
+        return st["n_zero"] > 0 or st["n_2x2"] > 0 or st["growth"] > 64.0
+
+    def _solve(self, st):
+        """Substitution for the current factor; (dz tensor, converged)."""
+        core = self.core
+        if self._at_risk(st):
+            dz = core.solve(flip=True, refine=-1)
+            info = self.last_solve_info = core.solve_info()
+            return dz, info["backward_error"] >= 0.0 and info["backward_error"] <= self.berr_tol
+        self.last_solve_info = None
+        return core.solve(flip=True, refine=self.refine), True
 
     def direction(self, d2L, Je, Ji, df, ce, ci, s, lda, mu, delta, mu_host, eta, beta, reg_coef, delta0, eps,
                   as_tensor=False):
@@ -65,18 +136,19 @@ class HipNewtonBackend(object):
             # Condensed system first (2x fewer flops at the benchmark shape).  The block pivots are explicit
             # 64x64 inverses, so a dense ill-conditioned tile (Sigma spanning > ~1e8 late in a run) costs
             # accuracy ~ eps*sqrt(cond): accept only a direction whose backward error against the FULL blocks
-            # is small and whose inertia is right; otherwise switch to the full system for good.
+            # is small and whose inertia is right; otherwise use the full system for the rest of this solve.
             core.assemble(0.0, 0.0)
-            st = core.factor()
-            self.n_factor += 1
-            ok = st["n_zero"] == 0 and st["n_neg"] == need
-            why = "inertia %d/%d, %d rejected pivots" % (st["n_neg"], need, st["n_zero"])
+            st = self._factor()
+            ok = st["n_zero"] == 0 and st["n_neg"] == need and not st["nonfinite"]
+            why = "inertia %d/%d, %d static pivots" % (st["n_neg"], need, st["n_zero"])
             if ok:
+                gn = float(g.norm())
                 for refine in (self.refine, max(self.refine, 1) + 3):      # second try: more refinement steps
                     dz = core.solve(flip=True, refine=refine)
                     raw = dz.clone()
                     raw[self.n + self.mi:] *= -1.0
-                    berr = float((core.matvec(raw) - g).norm() / g.norm())
+                    rn = float((core.matvec(raw) - g).norm())
+                    berr = rn / gn if gn > 0.0 else rn                     # zero residual: the zero direction is exact
                     ok = berr <= self.condensed_tol
                     why = "backward error %.1e after %d refinement steps" % (berr, max(refine, 1))
                     if ok:
@@ -90,24 +162,27 @@ class HipNewtonBackend(object):
             self.condensed_fallback_reason = "call %d: %s" % (self.n_calls, why)
             core.set_option("condensed", 0)
         core.assemble(0.0, 0.0)
-        st = core.factor()
-        self.n_factor += 1
-        singular = st["n_zero"] > 0 or (st["d_max"] > 0 and st["d_min"] / st["d_max"] <= eps)
-        if singular or st["n_neg"] != need:
+        st = self._factor()
+        singular = self._singular(st, eps)
+        dz = None
+        if not singular and st["n_neg"] == need:
+            dz, _ = self._solve(st)
+            if st["n_zero"] > 0:
+                self.n_static += 1         # reference: LU over the whole matrix, no shift (pyipm.py:1381 not taken)
+        if dz is None:
             delta_c = reg_coef * eta * (mu_host ** beta) if (singular and self.me) else 0.0
             delta = delta0 if delta == 0.0 else max(delta / 2.0, delta0)
             tries = 0
             while True:
                 core.assemble(delta, delta_c)
-                st = core.factor()
-                self.n_factor += 1
-                if st["n_neg"] == need:
+                st = self._factor()
+                if st["n_neg"] == need and not st["nonfinite"]:
                     break
                 tries += 1
                 if tries > self.max_shift_tries:
                     raise RuntimeError("inertia not corrected after %d diagonal shifts" % tries)
                 delta *= 10.0
-        dz = core.solve(flip=True, refine=self.refine)
+            dz, _ = self._solve(st)
         if not as_tensor:
             dz = dz.cpu().numpy()
         return dz, float(delta), st
@@ -130,6 +205,9 @@ class HipLbfgsBackend(object):
         self.n, self.me, self.mi = n, me, mi
         self.linear_constraints = bool(linear_constraints)   # dce/dci do not depend on x: stage once, J'J is reused
         self.n_calls = self.n_staged = 0
+
+    def shape(self):
+        return (self.n, self.me, self.mi)
 
     def lbfgs_direction(self, Je, Ji, s, lda, g, zeta, S, Y, SS, L, D, reg, eps):
         self.n_calls += 1
@@ -170,6 +248,7 @@ class IPM(object):
         self.lbfgs_fail_max = lbfgs                                                     # :360
         self.verbosity = verbosity
         self.backend = backend
+        self._own_backend = backend is None
         self._backend_opts = dict(device=device, nb=nb, refine=refine, device_step=device_step, condensed=condensed)
         self.linear_constraints = linear_constraints       # L-BFGS mode: Jacobians staged once, J'J reused
         self.compiled = False
@@ -211,7 +290,11 @@ class IPM(object):
         x0 = np.asarray(self.x0, dtype=np.float64)
         self.neq = int(np.size(self.ce(x0))) if (self.ce is not None and neq is None) else int(neq or 0)
         self.nineq = int(np.size(self.ci(x0))) if (self.ci is not None and nineq is None) else int(nineq or 0)
+        if self.backend is not None and self._own_backend and hasattr(self.backend, "shape") and \
+                self.backend.shape() != (self.nvar, self.neq, self.nineq):
+            self.backend = None            # force_recompile with another problem shape: the handle is per shape
         if self.backend is None:
+            self._own_backend = True
             if self.lbfgs:
                 self.backend = HipLbfgsBackend(self.nvar, self.neq, self.nineq, self.lbfgs,
                                                device=self._backend_opts["device"], nb=self._backend_opts["nb"],
@@ -490,6 +573,8 @@ class IPM(object):
         self.validate()
         if not self.compiled or force_recompile:
             self.compile()
+        if hasattr(self.backend, "new_solve"):
+            self.backend.new_solve()
         n, me, mi = self.nvar, self.neq, self.nineq
 
         # initial point (pyipm.py:1597-1625)

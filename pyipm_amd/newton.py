@@ -37,7 +37,10 @@ class FactorStats(ctypes.Structure):
 
 
 class NewtonError(RuntimeError):
-    pass
+    """``code`` is the PYIPM_E_* value; ``stats`` carries the factor statistics when the call produced them
+    (PYIPM_E_NONFINITE from factor()/step(): the host may still regularise and retry, as reghess would)."""
+    code = None
+    stats = None
 
 
 _lib = None
@@ -75,6 +78,9 @@ def load_library(path: str | None = None):
         "pyipm_newton_assemble": (c_int, [ctxp, c_double, c_double]),
         "pyipm_newton_factor": (c_int, [ctxp, POINTER(FactorStats)]),
         "pyipm_newton_solve": (c_int, [ctxp, c_void_p, c_void_p, c_int, c_int, c_int]),
+        "pyipm_newton_solve_info": (c_int, [ctxp, POINTER(c_double)]),
+        "pyipm_newton_anorm": (c_int, [ctxp, POINTER(c_void_p)]),
+        "pyipm_newton_rcond": (c_int, [ctxp, c_int, c_int, POINTER(c_double)]),
         "pyipm_newton_kkt_matvec": (c_int, [ctxp, c_void_p, c_void_p, c_int]),
         "pyipm_newton_step": (c_int, [ctxp, c_double, c_double, c_int, c_void_p, POINTER(FactorStats), c_int]),
         "pyipm_newton_step_lengths": (c_int, [ctxp, c_double, POINTER(c_double), POINTER(c_double)]),
@@ -165,10 +171,12 @@ class NewtonCore(object):
         self._keep = {}      # staged device tensors kept alive (the library retains their pointers)
 
     # -- helpers -----------------------------------------------------------------------------
-    def _ck(self, rc):
+    def _ck(self, rc, stats=None):
         if rc:
             msg = self.lib.pyipm_newton_last_error(self.h)
-            raise NewtonError("%s: %s" % (ERRORS.get(rc, rc), msg.decode() if msg else ""))
+            err = NewtonError("%s: %s" % (ERRORS.get(rc, rc), msg.decode() if msg else ""))
+            err.code, err.stats = rc, stats
+            raise err
 
     def _dev(self, a, shape=None):
         """Return a contiguous fp64 device tensor for ``a`` (numpy / torch / None)."""
@@ -194,8 +202,17 @@ class NewtonCore(object):
         return self.torch.empty(int(numel), dtype=self.torch.float64, device=self.device)
 
     def sync_stream(self):
-        self._ck(self.lib.pyipm_newton_set_stream(
-            self.h, c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)))
+        st = self.torch.cuda.current_stream(self.device).cuda_stream
+        self._ck(self.lib.pyipm_newton_set_stream(self.h, c_void_p(st)))
+        self._bound_stream = st
+
+    def _use_current_stream(self):
+        """The binding allocates outputs / temporaries on torch's CURRENT stream, so the handle must enqueue on that
+        same stream: rebind it at the top of every call that touches torch memory (one pointer store)."""
+        st = self.torch.cuda.current_stream(self.device).cuda_stream
+        if st != getattr(self, "_bound_stream", None):
+            self._ck(self.lib.pyipm_newton_set_stream(self.h, c_void_p(st)))
+            self._bound_stream = st
 
     def set_option(self, name, value):
         self._ck(self.lib.pyipm_newton_set_option(self.h, name.encode(), float(value)))
@@ -214,6 +231,7 @@ class NewtonCore(object):
     # -- staging -----------------------------------------------------------------------------
     def stage_blocks(self, d2L, Je=None, Ji=None):
         """d2L (n,n) row-major (upper triangle read), Je (n,me), Ji (n,mi)."""
+        self._use_current_stream()
         n, me, mi = self.n, self.me, self.mi
         d2L = self._dev(d2L, (n, n))
         Je = self._dev(Je, (n, me)) if me else None
@@ -223,6 +241,7 @@ class NewtonCore(object):
                                                     self._ptr(Ji), max(mi, 1), MEM_DEVICE))
 
     def stage_vectors(self, df, ce=None, ci=None, s=None, lda=None, mu=0.2, eps=float(np.finfo(np.float64).eps)):
+        self._use_current_stream()
         n, me, mi = self.n, self.me, self.mi
         df = self._dev(df, (n,))
         ce = self._dev(ce, (me,)) if me else None
@@ -235,26 +254,53 @@ class NewtonCore(object):
 
     # -- hot path ------------------------------------------------------------------------------
     def residual(self):
+        self._use_current_stream()
         g = self.torch.empty(self.N, dtype=self.torch.float64, device=self.device)
         self._ck(self.lib.pyipm_newton_residual(self.h, self._ptr(g), MEM_DEVICE))
         return g
 
     def assemble(self, delta=0.0, delta_c=0.0):
+        self._use_current_stream()
         self._ck(self.lib.pyipm_newton_assemble(self.h, float(delta), float(delta_c)))
 
     def factor(self):
+        self._use_current_stream()
         st = FactorStats()
-        self._ck(self.lib.pyipm_newton_factor(self.h, ctypes.byref(st)))
+        rc = self.lib.pyipm_newton_factor(self.h, ctypes.byref(st))
+        self._ck(rc, st.as_dict())
         return st.as_dict()
 
     def solve(self, rhs=None, flip=True, refine=0):
+        """refine > 0: that many refinement steps against the KKT blocks; refine < 0: adaptive (``solve_info``)."""
+        self._use_current_stream()
         dz = self.torch.empty(self.N, dtype=self.torch.float64, device=self.device)
         r = None if rhs is None else self._dev(rhs, (self.N,))
         self._ck(self.lib.pyipm_newton_solve(self.h, self._ptr(r), self._ptr(dz), int(bool(flip)), int(refine),
                                              MEM_DEVICE))
         return dz
 
+    def solve_info(self):
+        """Outcome of the last solve: refinement steps, backward error before / after, converged flag."""
+        o = (c_double * 4)()
+        self._ck(self.lib.pyipm_newton_solve_info(self.h, o))
+        return {"steps": int(o[0]), "backward_error0": o[1], "backward_error": o[2], "converged": bool(o[3])}
+
+    def rcond(self, it_inv=0, it_pow=0):
+        """Estimate of reghess' rcond = min|w| / max|w| (pyipm.py:1379-1381) from the factor and the blocks."""
+        self._use_current_stream()
+        o = (c_double * 4)()
+        self._ck(self.lib.pyipm_newton_rcond(self.h, int(it_inv), int(it_pow), o))
+        return {"w_min": o[0], "w_max": o[1], "rcond": o[2], "static_pivot": o[3]}
+
+    def anorm(self):
+        """One-element device tensor view of max |assembled entry| (the scale of a static pivot)."""
+        ptr = c_void_p()
+        self._ck(self.lib.pyipm_newton_anorm(self.h, ctypes.byref(ptr)))
+        off = ptr.value - self.workspace.data_ptr()
+        return self.workspace[off: off + 8].view(self.torch.float64)
+
     def matvec(self, v):
+        self._use_current_stream()
         v = self._dev(v, (self.N,))
         y = self.torch.empty(self.N, dtype=self.torch.float64, device=self.device)
         self._ck(self.lib.pyipm_newton_kkt_matvec(self.h, self._ptr(v), self._ptr(y), MEM_DEVICE))
@@ -262,14 +308,17 @@ class NewtonCore(object):
 
     def step(self, delta=0.0, delta_c=0.0, refine=0):
         """Fused residual + assemble + factor + solve + flip."""
+        self._use_current_stream()
         dz = self.torch.empty(self.N, dtype=self.torch.float64, device=self.device)
         st = FactorStats()
-        self._ck(self.lib.pyipm_newton_step(self.h, float(delta), float(delta_c), int(refine), self._ptr(dz),
-                                            ctypes.byref(st), MEM_DEVICE))
+        rc = self.lib.pyipm_newton_step(self.h, float(delta), float(delta_c), int(refine), self._ptr(dz),
+                                        ctypes.byref(st), MEM_DEVICE)
+        self._ck(rc, st.as_dict())
         return dz, st.as_dict()
 
     def step_lengths(self, tau):
         """Fraction-to-the-boundary step lengths (alpha_s, alpha_l) for the direction of the last solve."""
+        self._use_current_stream()
         a_s, a_l = c_double(1.0), c_double(1.0)
         self._ck(self.lib.pyipm_newton_step_lengths(self.h, float(tau), ctypes.byref(a_s), ctypes.byref(a_l)))
         return a_s.value, a_l.value

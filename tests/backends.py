@@ -108,7 +108,7 @@ class ModelCore(object):
             self.Tsave[(p, t)] = Tf
             real = max(0, min(tb, self.N - j0))
             self.st["n_neg"] += s["neg"]; self.st["n_zero"] += s["zero"]; self.st["n_2x2"] += s["n2x2"]
-            self.st["n_pos"] += real - s["neg"] - s["zero"] if real else 0
+            self.st["n_pos"] += real - s["neg"] if real else 0     # static pivots count by their sign (device semantics)
             self.st["d_min"] = min(self.st["d_min"], s["dmin"]); self.st["d_max"] = max(self.st["d_max"], s["dmax"])
             below = slice(j0 + tb, self.Npad)
             W[below, t * tb:(t + 1) * tb] = self.A[below, l0:l0 + tb]

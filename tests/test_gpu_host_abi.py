@@ -171,3 +171,32 @@ def test_lbfgs_host_pointers_match_oracle():
     assert lib.pyipm_lbfgs_set_option(h, b"block_refine", 1.0) == 0
     assert lib.pyipm_lbfgs_set_option(h, b"no_such_option", 1.0) != 0
     assert lib.pyipm_lbfgs_destroy(h) == 0
+
+
+def test_no_exception_crosses_the_abi():
+    """include/pyipm_newton.h: "no exceptions cross it".  Every extern "C" entry is a function-try-block; a
+    std::bad_alloc from a host container (here injected where the tile lists are built) comes back as PYIPM_E_NOMEM,
+    any other exception as PYIPM_E_HIP, with a message, and the handle stays usable."""
+    from pyipm_amd.newton import NewtonCore, NewtonError
+    from pyipm_amd.problems import make_qp
+    n, me, mi = 700, 100, 300                      # several panels: the bulk launches build tile lists
+    qp = make_qp(n, me, mi, seed=5)
+    core = NewtonCore(n, me, mi, device=0, nb=128)
+    core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    ref, _ = core.step(0.0, 0.0)
+    for fault, code in ((1, -3), (2, -2)):
+        fresh = NewtonCore(n, me, mi, device=0, nb=128)          # tile lists are cached per handle: use a new one
+        fresh.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+        fresh.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+        fresh.set_option("debug_fault", fault)
+        with pytest.raises(NewtonError) as ei:
+            fresh.step(0.0, 0.0)
+        assert ei.value.code == code, (fault, ei.value.code, str(ei.value))
+        assert ("bad_alloc" in str(ei.value)) if fault == 1 else ("injected fault" in str(ei.value))
+        import torch
+        torch.cuda.synchronize()
+        dz, st = fresh.step(0.0, 0.0)                            # the hook is one-shot; the handle still works
+        assert torch.equal(dz, ref) and st["n_neg"] == me + mi
+        fresh.close()
+    core.close()

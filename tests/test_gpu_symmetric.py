@@ -79,17 +79,17 @@ def test_badly_scaled_diagonal_blocks():
     assert np.linalg.norm(x - ref) / np.linalg.norm(ref) <= 1e-8        # cond ~1e16 * tiny coupling; LU gives the same class
 
 
-def test_restricted_pivoting_limitation_is_reported():
-    """Documented limitation: pivots never leave their 64x64 diagonal tile.  A matrix whose
-    leading tile is exactly singular although the matrix is not (here [[0, I],[I, 0]], 128 x 128) cannot be
-    factored by tile-local pivoting; the statistics MUST say so (rejected pivots), so the host can regularise
-    exactly as reghess does on a failed inertia test (pyipm.py:1390-1403)."""
+def test_tile_local_pivoting_falls_back_to_static_pivots():
+    """Pivots never leave their 64x64 diagonal tile.  A matrix whose leading tile is exactly singular although the
+    matrix is not (here [[0, I],[I, 0]], 128 x 128) used to be a documented limitation (rejected pivots -> the host had
+    to shift).  Now the zero pivots become static pivots (reported in n_zero, counted by their sign), the factor stays
+    finite with the inertia of the matrix, and a plain solve is a sqrt(eps)-accurate preconditioner; the refined solve
+    (tests/test_gpu_pivoting.py) recovers the exact answer.  A reghess-style shift still works as before."""
     k = 64
     M = np.block([[np.zeros((k, k)), np.eye(k)], [np.eye(k), np.zeros((k, k))]])
     x, st = _solve(M, np.ones(2 * k))
-    assert st["n_zero"] >= 1
-    # one reghess-style diagonal shift makes the leading tile invertible again; the inertia of the SHIFTED
-    # matrix is then reported correctly
+    assert st["n_zero"] == k and (st["n_neg"], st["n_pos"]) == _inertia(M) and st["nonfinite"] == 0
+    assert np.isfinite(x).all() and np.linalg.norm(M @ x - 1.0) <= 1e-6 * np.sqrt(2 * k)
     from pyipm_amd.newton import NewtonCore
     core = NewtonCore(2 * k, 0, 0, device=0)
     core.stage_blocks(np.triu(M)); core.stage_vectors(np.zeros(2 * k))

@@ -1,0 +1,99 @@
+"""Static pivots + refinement on the CPU model of the device algorithm (oracle/block_ldl_model.py).
+
+The reference solves the KKT system with LU + partial pivoting over the WHOLE matrix (pyipm.py:18-20) and shifts
+only when the eigen-inertia is wrong or rcond <= eps (pyipm.py:1379-1381).  The device pivots inside 64x64 tiles;
+a KKT matrix whose x-x tile is singular although the matrix is not (LPs, variables that enter linearly) used to
+overflow there.  These tests pin the replacement at algorithm level, before any GPU is involved: static pivots
+(sqrt(eps)|A| with the sign of the block), reported, and refinement against the unfactored matrix -- the same dz
+as the reference's solve with the same "no shift" decision."""
+import numpy as np
+import pytest
+
+from oracle import newton_oracle as orc
+from oracle.block_ldl_model import BlockLDL
+
+
+def _kkt(H, Je, Ji, sig):
+    n, me, mi = H.shape[0], Je.shape[1], Ji.shape[1]
+    N = n + 2 * mi + me
+    K = np.zeros((N, N))
+    K[:n, :n] = np.triu(H)
+    K[:n, n + mi:n + mi + me] = Je
+    K[:n, n + mi + me:] = Ji
+    K[n:n + mi, n:n + mi] = np.diag(sig)
+    K[n:n + mi, n + mi + me:] = -np.eye(mi)
+    return np.triu(K) + np.triu(K, 1).T
+
+
+def _case(name, rng):
+    if name == "lp":                      # d2L == 0, n >= 128, mi >= n
+        n, me, mi = 128, 0, 200
+        H = np.zeros((n, n))
+    elif name == "lp_eq":
+        n, me, mi = 192, 40, 300
+        H = np.zeros((n, n))
+    elif name == "linear_variables":      # epigraph-like: the last 70 variables have no curvature at all
+        n, me, mi = 160, 20, 220
+        M = rng.standard_normal((90, 90))
+        H = np.zeros((n, n))
+        H[:90, :90] = M @ M.T / 90 + np.eye(90)
+    elif name == "zero_rows":             # single zero Hessian rows scattered over two tiles
+        n, me, mi = 150, 10, 180
+        M = rng.standard_normal((n, n))
+        H = M @ M.T / n + np.eye(n)
+        for k in (5, 70, 71, 149):
+            H[k, :] = 0.0
+            H[:, k] = 0.0
+    Je = rng.standard_normal((n, me)) / np.sqrt(n)
+    Ji = rng.standard_normal((n, mi)) / np.sqrt(n)
+    sig = rng.uniform(0.5, 2.0, mi) / rng.uniform(0.5, 2.0, mi)
+    return n, me, mi, _kkt(H, Je, Ji, sig)
+
+
+@pytest.mark.parametrize("name", ["lp", "lp_eq", "linear_variables", "zero_rows"])
+def test_singular_x_tiles_are_pivoted_statically_and_refined_to_the_lu_answer(name):
+    rng = np.random.default_rng(11)
+    n, me, mi, K = _case(name, rng)
+    N = K.shape[0]
+    w = np.linalg.eigvalsh(K)
+    # what the reference would decide (pyipm.py:1378-1381): inertia right, rcond fine -> no shift
+    assert int((w < -np.finfo(float).eps).sum()) == me + mi and np.abs(w).min() / np.abs(w).max() > 1e-6
+    f = BlockLDL(K, neg_from=n + mi)
+    assert np.isfinite(f.M).all()                                  # the factor used to overflow here
+    assert f.stats["neg"] == me + mi                               # same inertia as the eigenvalues
+    if name in ("lp", "lp_eq"):
+        assert f.stats["zero"] == n                                # every x pivot is static
+    elif name == "linear_variables":
+        assert f.stats["zero"] >= 64                               # at least the tile that is entirely zero
+    b = rng.standard_normal(N)
+    x, info = f.solve_refined(b)
+    assert info["converged"] and info["steps"] <= 4, info
+    ref = orc.sym_solve(K, b)                                      # scipy LU, what pyipm.py:18-20 reaches
+    assert np.linalg.norm(x - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+def test_singular_matrix_does_not_converge():
+    """Rank-deficient equality Jacobian (two equal columns): the KKT matrix is singular, the reference's rcond test
+    fires (pyipm.py:1379-1381).  Static pivots keep the factor finite; the refinement must NOT report convergence,
+    which is what sends the host into the same delta / delta_c branch."""
+    rng = np.random.default_rng(3)
+    n, me, mi = 140, 12, 0
+    M = rng.standard_normal((n, n))
+    H = M @ M.T / n + np.eye(n)
+    Je = rng.standard_normal((n, me)) / np.sqrt(n)
+    Je[:, 7] = Je[:, 3]
+    K = _kkt(H, Je, np.zeros((n, 0)), np.zeros(0))
+    f = BlockLDL(K, neg_from=n)
+    assert np.isfinite(f.M).all() and f.stats["zero"] >= 1
+    x, info = f.solve_refined(rng.standard_normal(n + me))
+    assert not (info["converged"] and info["backward_error"] <= 1e-11)
+
+
+def test_regular_matrices_are_untouched():
+    """No static pivot on the benchmark family: same statistics and the same solution as before."""
+    from pyipm_amd.problems import make_qp
+    n, me, mi = 96, 32, 48
+    qp = make_qp(n, me, mi, seed=2)
+    H = orc.kkt_matrix(qp["d2L"], qp["Je"], qp["Ji"], qp["s"], qp["lam"], n, me, mi)
+    f = BlockLDL(H, neg_from=n + mi)
+    assert f.stats["zero"] == 0 and f.stats["neg"] == me + mi
