@@ -166,7 +166,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--check", action="store_true", help="(kept for compatibility: the backward error is always reported)")
     ap.add_argument("--force-dist", action="store_true", help="use the per-panel distributed driver even for 1 GPU")
-    ap.add_argument("--force-lookahead", action="store_true", help="with --force-dist on one GPU: run the overlapped multi-GPU schedule")
+    ap.add_argument("--force-lookahead", action="store_true", help="with --force-dist --python-driver on one GPU: run the overlapped schedule")
+    ap.add_argument("--python-driver", action="store_true", help="distributed runs: the Python loop over the per-panel phases instead of the library's driver")
+    ap.add_argument("--selfmsg", action="store_true", help="with --force-dist on one GPU: pack and 'send' every panel anyway (message path cost)")
     ap.add_argument("--opt", action="append", default=[], help="core option name=value (e.g. xcd_swizzle=0, lookahead=0)")
     ap.add_argument("--extras", action="store_true",
                     help="after the timed region also run and report (a) the all-dense factorisation (skip_zeros=0) with a "
@@ -206,7 +208,16 @@ def main():
     N = n + 2 * mi + me
     qp = make_qp_device(n, me, mi, args.seed, device)
     core = NewtonCore(n, me, mi, device=local_rank, nb=args.nb, world=world, rank=rank)
-    core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    if world > 1:
+        # row-sharded staging: a rank assembles only the KKT columns it owns, i.e. it needs only those rows of
+        # d2L / Je / Ji (every rank generated the same matrices from the same seed; the full copies are dropped)
+        rows = torch.from_numpy(core.owned_rows()).to(device)
+        core.stage_blocks_owned(qp["d2L"].index_select(0, rows), qp["Je"].index_select(0, rows) if me else None,
+                                qp["Ji"].index_select(0, rows) if mi else None)
+        qp["d2L"] = qp["Je"] = qp["Ji"] = None
+        torch.cuda.empty_cache()
+    else:
+        core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
     core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
     core.set_option("profile", 1)
     condensed = False
@@ -217,9 +228,12 @@ def main():
             condensed = float(v) != 0 and mi > 0
 
     if use_dist:
+        # the library's own per-panel driver (pyipm_newton_step_dist); exchange = a handle-owned RCCL communicator
         from pyipm_amd.dist import DistNewton
-        drv = DistNewton(core)
+        drv = DistNewton(core, native=not args.python_driver)
         drv.force_lookahead = args.force_lookahead
+        if args.selfmsg and world == 1:
+            core.set_option("dist_selfmsg", 1)
 
         def one_step():
             return drv.step(0.0, 0.0, refine=args.refine)
@@ -236,6 +250,7 @@ def main():
         one_step()
     trailing_ms = trailing_flops = panel_ms = solve_ms = assemble_ms = gram_ms = trailing_area = 0.0
     n_launch = 0
+    dist_ms = {}
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -245,12 +260,27 @@ def main():
         panel_ms += tm["panel_ms"]; solve_ms += tm["solve_ms"]; assemble_ms += tm["assemble_ms"]
         gram_ms += tm["gram_ms"]
         trailing_area += tm["trailing_area"]
+        if use_dist and not args.python_driver:
+            for k, v in core.dist_timings().items():
+                dist_ms[k] = dist_ms.get(k, 0.0) + v
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # correctness of the timed steps' direction, outside the timed region: |Hc dz - g| / |g| with Hc applied from the KKT
+    # blocks (never from the factor); dz is the last timed step's output with the flip undone.  (All ranks take part.)
+    raw = dz.clone()
+    if me + mi:
+        raw[n + mi:] *= -1.0
+    if world > 1:
+        g_res = core.residual_dist()
+        berr = float((core.matvec_dist(raw) - g_res).norm() / g_res.norm())
+    else:
+        g_res = core.residual()
+        berr = float((core.matvec(raw) - g_res).norm() / g_res.norm())
 
     if rank == 0:
         K = args.steps
@@ -303,6 +333,13 @@ def main():
         if world == 1 and n_launch and not condensed:
             # C-tile read-modify-write: 16 B per matrix entry a launch updates (operand panels, read once, add < 10 %)
             out["roofline"]["algorithmic_bytes_per_launch"] = 16.0 * trailing_area / n_launch
+        if dist_ms:
+            # rank 0's view of the distributed schedule, per step: wall time of the factorisation, its own panel
+            # factorisations (chain), packing, broadcasts as seen on the collective stream, rebuilding L from received
+            # panels (unpack), the sweeps; bytes / messages of the panel exchange
+            out["dist_phases_per_step"] = {k: v / K for k, v in dist_ms.items()}
+            out["dist_driver"] = "pyipm_newton_step_dist (per-panel schedule in C); exchange: %s" % (
+                "handle-owned RCCL communicator" if world > 1 else "none (one rank)")
         if condensed:
             # same Newton direction from the (n+me)-dimensional condensed system; NOT the
             # headline configuration: the flop count of the step itself changes
@@ -337,15 +374,8 @@ def main():
                                                       "`value` skips tiles the KKT block pattern makes exact zeros"}
         if args.extras and world == 1 and not use_dist:
             out["lbfgs_direction"] = lbfgs_block(device)
-        if world == 1 and not use_dist:
-            # correctness of the timed steps' direction, outside the timed region: |Hc dz - g| / |g| with Hc applied from
-            # the KKT blocks (never from the factor); dz is the last timed step's output with the flip undone
-            g = core.residual()
-            raw = dz.clone()
-            if me + mi:
-                raw[n + mi:] *= -1.0
-            out["backward_error"] = float((core.matvec(raw) - g).norm() / g.norm())
-            out["backward_error_note"] = "|Hc dz - g|/|g| of the last timed step, Hc from the staged blocks (pyipm_newton_kkt_matvec)"
+        out["backward_error"] = berr
+        out["backward_error_note"] = "|Hc dz - g|/|g| of the last timed step, Hc from the staged blocks (pyipm_newton_kkt_matvec)"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(target_N=N)
         sys.stdout.flush()

@@ -195,6 +195,47 @@ int pyipm_newton_fwd_panel(pyipm_newton_ctx* ctx, int64_t p, double* v);
 int pyipm_newton_diag_panel(pyipm_newton_ctx* ctx, int64_t p, double* v);
 int pyipm_newton_bwd_panel(pyipm_newton_ctx* ctx, int64_t p, double* v);
 
+/* ---- distributed driver: one call per phase, the per-panel schedule runs inside the library -------------------
+ * (SURVEY.md section 8e / 8b "Multi-GPU").  One process per GPU, handle created with (world, rank).  The per-panel
+ * phases above remain for callers that orchestrate themselves; these entry points run the whole one-panel-lookahead
+ * schedule (owner: head update -> factor -> pack -> broadcast on helper streams; everyone: unpack -> bulk update on
+ * the handle's stream) and the sweeps in C, so no interpreter sits between two panels.
+ *
+ * Exchange, variant 1 -- caller-supplied collectives (like pyipm_lbfgs_set_allreduce).  A callback must leave its
+ * result ordered on `stream` (a hipStream_t): enqueue on it, or complete before returning.  bcast: `bytes` bytes at
+ * dev_buf from rank `root` to every rank, in place.  allreduce: `count` doubles in place, op 0 = sum, 1 = max.
+ * Non-zero return = failure (PYIPM_E_COMM). */
+typedef int (*pyipm_bcast_fn)(void* user, void* dev_buf, size_t bytes, int root, void* stream);
+typedef int (*pyipm_allreduce_fn)(void* user, double* dev_buf, size_t count, int op, void* stream);
+int pyipm_newton_set_exchange(pyipm_newton_ctx* ctx, pyipm_bcast_fn bcast, pyipm_allreduce_fn allreduce, void* user);
+/* Exchange, variant 2 -- the handle owns an RCCL communicator over the `world` ranks it was created for.  Rank 0
+ * obtains an id (128 bytes), it reaches the other ranks out of band (torch.distributed, MPI, a file), every rank calls
+ * comm_init.  RCCL is dlopen'ed at that point (pyipm_newton_rccl_library names the library to bind: a process that has
+ * torch loaded should name torch's own librccl; default: one already loaded, then librccl.so.1). */
+int pyipm_newton_rccl_library(const char* path);
+int pyipm_newton_comm_unique_id(void* id128);
+int pyipm_newton_comm_init(pyipm_newton_ctx* ctx, const void* id128);
+/* Row-sharded staging: a rank assembles only the KKT columns it owns, and column j (j < n) of the lower triangle is
+ * row j of triu(d2L) | Je | Ji -- so it needs only those rows.  owned_rows returns their number and (rows != NULL)
+ * their global indices in the order the arrays must hold them (= the rank's local column order).  After
+ * stage_blocks_owned, residual / assemble / kkt_matvec address the blocks by local row. */
+int64_t pyipm_newton_owned_rows(pyipm_newton_ctx* ctx, int64_t* rows);
+int pyipm_newton_stage_blocks_owned(pyipm_newton_ctx* ctx, const double* d2L_rows, int64_t ld_d2L, const double* Je_rows,
+                                    int64_t ld_Je, const double* Ji_rows, int64_t ld_Ji, int memkind);
+/* The phases of pyipm.py:1717-1725 over the ranks (vectors replicated: every rank passes the same s / lda / rhs and
+ * receives the same g / dz; statistics reduced over the ranks).  refine as in pyipm_newton_solve (Hc applied from the
+ * ranks' blocks, one N-long sum per product).  With world == 1 they run the same per-panel schedule on one GPU. */
+int pyipm_newton_residual_dist(pyipm_newton_ctx* ctx, double* g_out, int memkind);
+int pyipm_newton_factor_dist(pyipm_newton_ctx* ctx, pyipm_factor_stats* stats);
+int pyipm_newton_solve_dist(pyipm_newton_ctx* ctx, const double* rhs, double* dz, int flip, int refine, int memkind);
+int pyipm_newton_kkt_matvec_dist(pyipm_newton_ctx* ctx, const double* v, double* y, int memkind);
+int pyipm_newton_step_dist(pyipm_newton_ctx* ctx, double delta, double delta_c, int refine, double* dz,
+                           pyipm_factor_stats* stats, int memkind);
+/* ms of the last factor_dist / solve_dist ("profile" = 1): out[0] factorisation wall, [1] this rank's panel
+ * factorisations, [2] packing, [3] broadcasts as seen on the collective stream, [4] unpacking (rebuild of L),
+ * [5] solve wall, [6] bytes this rank put on / took off the wire, [7] messages. */
+int pyipm_newton_dist_timings(pyipm_newton_ctx* ctx, double out[8]);
+
 /* ---- batched small systems (BASELINE.json configs[4]: 512 independent n=256 QPs) ------------------------
  * Independent problems of one shape, Npad = roundup(n+2mi+me,128) <= 1024.  One workgroup per problem: a
  * single launch factors the whole batch.  Blocks are caller-owned DEVICE arrays with a batch stride (in

@@ -106,10 +106,6 @@ struct Ctx {
                                           // next panel, always on the critical path there) while at most this many rows remain
     int64_t pending32_rows = 24576;       // ... and a panel's pending in-group update too while at most this many rows remain
                                           // (128x128 tiles keep one CU busy for 27 us per 256 columns of K, on the chain)
-    int reserve_cus = 0;                  // > 0: the bulk updates run on a CU-masked stream that leaves this many CUs free for the
-    int reserve_mode = 0;                 //      panel chain (mode 0: mask bits 0..k-1 cleared; 1: every (256/k)-th bit cleared)
-    hipStream_t bulk = nullptr; int bulk_key = 0;   // the masked stream and the (reserve_cus, mode) it was built for
-    hipEvent_t ev_bulk0 = nullptr, ev_bulk1 = nullptr;
     int xcd_swizzle = 1;
     int side_prio = 1;                    // raise wave priority in panel-chain update launches
     unsigned long long* dbg_buf = nullptr;   // diagnostics only
@@ -136,12 +132,17 @@ struct Ctx {
     double *Tsv = nullptr;                // the diagonal tiles T_k themselves (refinement of the block solves)
     double *Tflag = nullptr;              // per tile: 1.0 = refine block solves with it (pivot spread beyond refine_cond)
     double *rhs = nullptr, *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *partial = nullptr;
+    double *Minv = nullptr;               // per local panel: inv(Lb_pp)' (nb x nb) for the backward sweep (k_bwd_apply)
+    bool minv_valid = false;              // Minv matches the current factor
+    int bwd_fused = 1;                    // 0: the in-panel recursion (k_bwd_diag) instead of the inverse block (k_bwd_apply)
     double *df = nullptr, *ce = nullptr, *ci = nullptr, *s = nullptr, *lda = nullptr;
     DevStats* dstats = nullptr;
     unsigned long long* anorm = nullptr;  // device: bits of max |assembled KKT entry| (per problem for a batched handle): scale of a static pivot
     // staged blocks (device pointers; either caller-owned or library staging)
     const double *d2L = nullptr, *Je = nullptr, *Ji = nullptr;
     int64_t ld_d2L = 0, ld_Je = 0, ld_Ji = 0;
+    int sharded = 0;                      // the staged blocks hold only the rows of the x-columns this rank owns (local column order)
+    struct DistState* dist = nullptr;     // distributed driver (dist_impl.hpp): exchange, streams, message buffers
     double *stg_d2L = nullptr, *stg_Je = nullptr, *stg_Ji = nullptr;   // lazily hipMalloc'd
     size_t stg_d2L_sz = 0, stg_Je_sz = 0, stg_Ji_sz = 0;
     double mu = 0.2, eps = 2.220446049250313e-16;

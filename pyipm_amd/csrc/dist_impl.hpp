@@ -1,0 +1,573 @@
+// dist_impl.hpp — the distributed Newton step, driven from C (included at the end of
+// pyipm_newton.hip).  One process per GPU; KKT columns 1-D block-cyclic by panels of nb; ONE exchange per panel
+// (the factored panel goes from its owner to everyone), one nb-long sum per panel in the forward sweep, one nb-long
+// broadcast per panel in the backward sweep.  Round 1 ran this schedule from Python (a dozen ctypes calls and a
+// torch.distributed call per panel on the critical path: +19 % on one rank before any wire time); here one C call
+// runs the whole lookahead schedule on the handle's streams.
+//
+// Exchange: either caller-supplied callbacks (pyipm_newton_set_exchange -- how the CPU-staged gloo tests and any
+// non-RCCL transport plug in) or a handle-owned RCCL communicator (pyipm_newton_comm_init; RCCL is dlopen'ed, the
+// 128-byte id travels out of band).  world == 1 needs neither.
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>          // types and enums only: the entry points are resolved with dlsym
+
+namespace {
+
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi g_rccl;
+std::string g_rccl_path;              // pyipm_newton_rccl_library(): which librccl to bind (torch ships its own)
+
+int rccl_load(std::string* err) {
+    if (g_rccl.lib) return 0;
+    const char* env = getenv("PYIPM_RCCL_LIB");
+    std::vector<std::string> names;
+    if (!g_rccl_path.empty()) names.push_back(g_rccl_path);
+    if (env && *env) names.push_back(env);
+    names.push_back("librccl.so.1"); names.push_back("librccl.so"); names.push_back("/opt/rocm/lib/librccl.so.1");
+    void* lib = nullptr;
+    for (auto& n : names) { lib = dlopen(n.c_str(), RTLD_NOW | RTLD_NOLOAD); if (lib) break; }    // one already in the process first
+    if (!lib) for (auto& n : names) { lib = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+    if (!lib) { if (err) *err = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "?"); return PYIPM_E_COMM; }
+    RcclApi a; a.lib = lib;
+    a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
+    a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    a.Broadcast = (decltype(a.Broadcast))dlsym(lib, "ncclBroadcast");
+    a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
+    a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.Broadcast || !a.AllReduce) {
+        if (err) *err = "RCCL library lacks an entry point"; return PYIPM_E_COMM;
+    }
+    g_rccl = a;
+    return 0;
+}
+
+}  // namespace
+
+namespace pyipm {
+
+struct DistState {
+    pyipm_bcast_fn bcast = nullptr; pyipm_allreduce_fn allreduce = nullptr; void* user = nullptr;
+    ncclComm_t comm = nullptr;
+    hipStream_t side = nullptr, cs = nullptr;          // owner's factor + pack stream (high priority); collectives
+    hipEvent_t ev_fact[2] = {}, ev_msg[2] = {}, ev_free[2] = {}, ev_head = nullptr, ev_join = nullptr;
+    double* msg[2] = {nullptr, nullptr}; size_t msg_bytes = 0;
+    double* seg = nullptr;                             // nb doubles: the panel segment of the forward sum
+    double* vloc = nullptr;                            // Npad: this rank's share of the vector during the sweeps
+    double* small = nullptr;                           // 16 doubles: statistics reduction
+    int selfmsg = 0;                                   // world == 1: pack + broadcast anyway (measures the message path on one GPU)
+    // profile (ms, last factor_dist / solve_dist): chain = owner's panel factorisations, pack, wait-for-message, unpack
+    std::vector<hipEvent_t> pool; size_t used = 0;
+    struct Span { int kind; hipEvent_t a, b; };
+    std::vector<Span> spans;
+    double t_chain = 0, t_pack = 0, t_bcast = 0, t_unpack = 0, t_factor = 0, t_solve = 0;
+    size_t bytes_sent = 0; int64_t n_msgs = 0;
+};
+
+}  // namespace pyipm
+
+namespace {
+
+#define DIST_HIP(call)                                                                    \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e__);                \
+            return PYIPM_E_HIP;                                                           \
+        }                                                                                 \
+    } while (0)
+
+#define DIST_KCHECK() DIST_HIP(hipGetLastError())
+
+int dist_state(Ctx* ctx, DistState** out) {
+    if (!ctx->dist) ctx->dist = new DistState();
+    DistState* D = ctx->dist;
+    const Geo& g = ctx->g;
+    if (!D->side) {
+        int lo = 0, hi = 0;
+        DIST_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        DIST_HIP(hipStreamCreateWithPriority(&D->side, hipStreamNonBlocking, hi));
+        DIST_HIP(hipStreamCreateWithPriority(&D->cs, hipStreamNonBlocking, hi));
+        for (int b = 0; b < 2; ++b) {
+            DIST_HIP(hipEventCreateWithFlags(&D->ev_fact[b], hipEventDisableTiming));
+            DIST_HIP(hipEventCreateWithFlags(&D->ev_msg[b], hipEventDisableTiming));
+            DIST_HIP(hipEventCreateWithFlags(&D->ev_free[b], hipEventDisableTiming));
+        }
+        DIST_HIP(hipEventCreateWithFlags(&D->ev_head, hipEventDisableTiming));
+        DIST_HIP(hipEventCreateWithFlags(&D->ev_join, hipEventDisableTiming));
+        DIST_HIP(hipMalloc((void**)&D->seg, (size_t)g.nb * sizeof(double)));
+        DIST_HIP(hipMalloc((void**)&D->vloc, (size_t)g.Npad * sizeof(double)));
+        DIST_HIP(hipMalloc((void**)&D->small, 16 * sizeof(double)));
+    }
+    *out = D;
+    return 0;
+}
+
+void dist_free(Ctx* ctx) {
+    DistState* D = ctx->dist;
+    if (!D) return;
+    if (D->side) { hipStreamSynchronize(D->side); hipStreamDestroy(D->side); }
+    if (D->cs) { hipStreamSynchronize(D->cs); hipStreamDestroy(D->cs); }
+    for (int b = 0; b < 2; ++b) {
+        if (D->ev_fact[b]) hipEventDestroy(D->ev_fact[b]);
+        if (D->ev_msg[b]) hipEventDestroy(D->ev_msg[b]);
+        if (D->ev_free[b]) hipEventDestroy(D->ev_free[b]);
+        if (D->msg[b]) hipFree(D->msg[b]);
+    }
+    if (D->ev_head) hipEventDestroy(D->ev_head);
+    if (D->ev_join) hipEventDestroy(D->ev_join);
+    for (auto e : D->pool) hipEventDestroy(e);
+    if (D->seg) hipFree(D->seg);
+    if (D->vloc) hipFree(D->vloc);
+    if (D->small) hipFree(D->small);
+    if (D->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(D->comm);
+    delete D;
+    ctx->dist = nullptr;
+}
+
+int dist_set_option(Ctx* ctx, const char* name, double value, bool* handled) {
+    *handled = false;
+    if (!strcmp(name, "dist_selfmsg")) {                // world == 1: pack + "broadcast" every panel anyway (measures the message path)
+        *handled = true;
+        DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
+        D->selfmsg = (int)value != 0;
+        return PYIPM_OK;
+    }
+    return PYIPM_OK;
+}
+
+// ---- exchange -----------------------------------------------------------------------------------------------------
+int ex_bcast(Ctx* ctx, DistState* D, void* buf, size_t bytes, int root, hipStream_t st) {
+    if (bytes == 0) return 0;
+    if (D->comm) {
+        ncclResult_t r = g_rccl.Broadcast(buf, buf, bytes / sizeof(double), ncclDouble, root, D->comm, st);
+        if (r != ncclSuccess) { ctx->err = std::string("ncclBroadcast: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; }
+        return 0;
+    }
+    if (ctx->g.world == 1) return 0;
+    if (!D->bcast) { ctx->err = "no exchange installed: pyipm_newton_set_exchange or pyipm_newton_comm_init first"; return PYIPM_E_COMM; }
+    if (D->bcast(D->user, buf, bytes, root, (void*)st)) { ctx->err = "the broadcast callback failed"; return PYIPM_E_COMM; }
+    return 0;
+}
+
+int ex_allreduce(Ctx* ctx, DistState* D, double* buf, size_t count, int op, hipStream_t st) {
+    if (count == 0) return 0;
+    if (D->comm) {
+        ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclDouble, op ? ncclMax : ncclSum, D->comm, st);
+        if (r != ncclSuccess) { ctx->err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; }
+        return 0;
+    }
+    if (ctx->g.world == 1) return 0;
+    if (!D->allreduce) { ctx->err = "no exchange installed: pyipm_newton_set_exchange or pyipm_newton_comm_init first"; return PYIPM_E_COMM; }
+    if (D->allreduce(D->user, buf, count, op, (void*)st)) { ctx->err = "the all-reduce callback failed"; return PYIPM_E_COMM; }
+    return 0;
+}
+
+// run a piece of the per-panel machinery (which enqueues on ctx->stream) on another stream
+struct StreamScope {
+    Ctx* c; hipStream_t saved;
+    StreamScope(Ctx* c_, hipStream_t s) : c(c_), saved(c_->stream) { c->stream = s; }
+    ~StreamScope() { c->stream = saved; }
+};
+
+// profile spans: kind 0 chain (owner's panel factorisation), 1 pack, 2 broadcast (as seen on the collective stream), 3 unpack
+int span_begin(Ctx* ctx, DistState* D, int kind, hipStream_t st, size_t* idx) {
+    *idx = (size_t)-1;
+    if (!ctx->profile) return 0;
+    while (D->pool.size() < D->used + 2) { hipEvent_t e; DIST_HIP(hipEventCreate(&e)); D->pool.push_back(e); }
+    DistState::Span s{kind, D->pool[D->used], D->pool[D->used + 1]};
+    D->used += 2;
+    DIST_HIP(hipEventRecord(s.a, st));
+    D->spans.push_back(s);
+    *idx = D->spans.size() - 1;
+    return 0;
+}
+int span_end(Ctx* ctx, DistState* D, size_t idx, hipStream_t st) {
+    if (idx == (size_t)-1) return 0;
+    DIST_HIP(hipEventRecord(D->spans[idx].b, st));
+    return 0;
+}
+
+size_t dist_msg_bytes(Ctx* ctx, int64_t p) {
+    const Geo& g = ctx->g;
+    if (panel_in_s(ctx, p)) return 0;
+    int64_t h0, h1;
+    panel_hole(ctx, p, &h0, &h1);
+    const int64_t nbw = g.panel_w(p), m = g.Npad - (g.panel_c0(p) + nbw) - (h1 - h0);
+    if (m <= 0) return 0;
+    return (size_t)(m * nbw + 2 * (nbw / TB) * TB * TB + nbw / TB) * sizeof(double);
+}
+
+int update_range(Ctx* ctx, int64_t p, int64_t first, int64_t count, hipStream_t st) {
+    const Geo& g = ctx->g;
+    if (g.panel_c0(p) + g.panel_w(p) >= g.Npad) return 0;
+    int64_t q = first;
+    while (q < g.npanels && g.owner(q) != g.rank) ++q;
+    int64_t last = first + count; if (last > g.npanels) last = g.npanels;
+    if (q >= last) return 0;
+    int64_t n_lp = 0;
+    for (int64_t qq = q; qq < last; qq += g.world) ++n_lp;
+    return timed_update(ctx, p, 1, q / g.world, n_lp, st);
+}
+
+// The factorisation across the ranks: one-panel lookahead.  As soon as panel p has arrived, the owner of p+1 updates
+// only panel p+1 (head), factors and packs it on the side stream and starts its broadcast on the collective stream;
+// every rank runs its share of the bulk update of p on the main stream meanwhile.
+int factor_dist(Ctx* ctx, pyipm_factor_stats* stats) {
+    const Geo& g = ctx->g;
+    if (!ctx->assembled) { ctx->err = "factor_dist: assemble first"; return PYIPM_E_BADARG; }
+    if (ctx->cond_active) { ctx->err = "factor_dist: the condensed option is single-rank (use factor())"; return PYIPM_E_BADARG; }
+    DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
+    ctx->grp_of.clear(); ctx->grp_off.clear(); ctx->grp_fast.clear(); ctx->grp_x.clear();
+    ctx->per_panel_mode = true;
+    rc = factor_begin(ctx); if (rc) return rc;
+    D->used = 0; D->spans.clear(); D->bytes_sent = 0; D->n_msgs = 0;
+    hipStream_t main = ctx->stream, side = D->side, cs = D->cs;
+    DIST_HIP(hipEventRecord(ctx->ev[0], main));
+    // every rank perturbs alike: the scale of a static pivot is the largest entry over ALL ranks' columns
+    rc = ex_allreduce(ctx, D, reinterpret_cast<double*>(ctx->anorm), 1, 1, main); if (rc) return rc;
+    const int64_t np = g.npanels;
+    const bool wire = g.world > 1 || D->selfmsg;
+    size_t need = 0;
+    if (wire) for (int64_t p = 0; p < np; ++p) { const size_t b = dist_msg_bytes(ctx, p); if (b > need) need = b; }
+    if (need > D->msg_bytes) {
+        for (int b = 0; b < 2; ++b) { if (D->msg[b]) DIST_HIP(hipFree(D->msg[b])); D->msg[b] = nullptr; }
+        for (int b = 0; b < 2; ++b)
+            if (hipMalloc((void**)&D->msg[b], need) != hipSuccess) { ctx->err = "factor_dist: no memory for the panel messages"; return PYIPM_E_NOMEM; }
+        D->msg_bytes = need;
+    }
+    std::vector<char> has_msg((size_t)np, 0), on_side((size_t)np, 0);
+    auto below = [&](int64_t p) { return g.Npad - (g.panel_c0(p) + g.panel_w(p)); };
+
+    // factor (owner) + start the broadcast of panel p; fst = the stream the owner factors on
+    auto post = [&](int64_t p, hipStream_t fst) -> int {
+        const bool own = g.owner(p) == g.rank;
+        const int b = (int)(p & 1);
+        int r;
+        if (own) {
+            size_t sp; r = span_begin(ctx, D, 0, fst, &sp); if (r) return r;
+            r = factor_panel(ctx, p, fst, false); if (r) return r;
+            r = span_end(ctx, D, sp, fst); if (r) return r;
+        }
+        const size_t bytes = (wire && below(p) > 0) ? dist_msg_bytes(ctx, p) : 0;
+        has_msg[(size_t)p] = bytes > 0;
+        if (!bytes) { if (own) DIST_HIP(hipEventRecord(D->ev_fact[b], fst)); return 0; }
+        double* buf = D->msg[b];
+        if (own) {
+            DIST_HIP(hipStreamWaitEvent(fst, D->ev_free[b], 0));         // the previous message in this buffer has left / been unpacked
+            size_t sp; r = span_begin(ctx, D, 1, fst, &sp); if (r) return r;
+            { StreamScope sc(ctx, fst); r = pyipm_newton_panel_pack(reinterpret_cast<pyipm_newton_ctx*>(ctx), p, buf); }
+            if (r) return r;
+            r = span_end(ctx, D, sp, fst); if (r) return r;
+            DIST_HIP(hipEventRecord(D->ev_fact[b], fst));
+            DIST_HIP(hipStreamWaitEvent(cs, D->ev_fact[b], 0));
+        } else {
+            DIST_HIP(hipStreamWaitEvent(cs, D->ev_free[b], 0));
+        }
+        size_t sp; r = span_begin(ctx, D, 2, cs, &sp); if (r) return r;
+        r = ex_bcast(ctx, D, buf, bytes, g.owner(p), cs); if (r) return r;
+        r = span_end(ctx, D, sp, cs); if (r) return r;
+        DIST_HIP(hipEventRecord(D->ev_msg[b], cs));
+        if (own) DIST_HIP(hipEventRecord(D->ev_free[b], cs));           // an owner's buffer is free once the message has left
+        D->bytes_sent += bytes; D->n_msgs++;
+        return 0;
+    };
+
+    rc = post(0, main); if (rc) return rc;
+    for (int64_t p = 0; p < np; ++p) {
+        if (below(p) <= 0) break;
+        const int b = (int)(p & 1);
+        const bool own = g.owner(p) == g.rank;
+        if (own) {
+            if (on_side[(size_t)p]) DIST_HIP(hipStreamWaitEvent(main, D->ev_fact[b], 0));     // factored on the side stream
+        } else if (has_msg[(size_t)p]) {
+            DIST_HIP(hipStreamWaitEvent(main, D->ev_msg[b], 0));
+            size_t sp; rc = span_begin(ctx, D, 3, main, &sp); if (rc) return rc;
+            rc = pyipm_newton_panel_unpack(reinterpret_cast<pyipm_newton_ctx*>(ctx), p, D->msg[b]); if (rc) return rc;
+            rc = span_end(ctx, D, sp, main); if (rc) return rc;
+            DIST_HIP(hipEventRecord(D->ev_free[b], main));
+        }
+        const int64_t nxt = p + 1;
+        if (nxt < np) {
+            if (g.owner(nxt) == g.rank) {
+                rc = update_range(ctx, p, nxt, 1, main); if (rc) return rc;               // head: bring panel p+1 up to date first
+                DIST_HIP(hipEventRecord(D->ev_head, main));
+                DIST_HIP(hipStreamWaitEvent(side, D->ev_head, 0));
+                on_side[(size_t)nxt] = 1;
+                rc = post(nxt, side); if (rc) return rc;
+            } else {
+                rc = post(nxt, nullptr); if (rc) return rc;                               // joins the broadcast of p+1 ...
+            }
+            rc = update_range(ctx, p, nxt + 1, np, main); if (rc) return rc;              // ... while everyone runs the bulk of update p
+        }
+    }
+    // join the helper streams (the last panel may have been factored on the side stream; messages in flight)
+    DIST_HIP(hipEventRecord(D->ev_join, side)); DIST_HIP(hipStreamWaitEvent(main, D->ev_join, 0));
+    DIST_HIP(hipEventRecord(D->ev_head, cs));   DIST_HIP(hipStreamWaitEvent(main, D->ev_head, 0));
+    DIST_HIP(hipEventRecord(ctx->ev[1], main));
+    ctx->assembled = false;
+    pyipm_factor_stats loc;
+    rc = factor_end(ctx, &loc);
+    const int rc_nonfinite = rc;
+    if (rc && rc != PYIPM_E_NONFINITE) return rc;
+    {   float ms = 0.f; DIST_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); D->t_factor = ms; ctx->t_factor = ms; }
+    if (ctx->profile) {
+        D->t_chain = D->t_pack = D->t_bcast = D->t_unpack = 0.0;
+        DIST_HIP(hipStreamSynchronize(cs)); DIST_HIP(hipStreamSynchronize(side));
+        for (auto& s : D->spans) {
+            float ms = 0.f; DIST_HIP(hipEventElapsedTime(&ms, s.a, s.b));
+            (s.kind == 0 ? D->t_chain : s.kind == 1 ? D->t_pack : s.kind == 2 ? D->t_bcast : D->t_unpack) += ms;
+        }
+        ctx->t_panel = D->t_chain;
+    }
+    // statistics over the ranks: counts add, extrema combine
+    if (g.world > 1) {
+        double h[8] = {(double)loc.n_neg, (double)loc.n_zero, (double)loc.n_2x2, (double)loc.n_pos, (double)loc.nonfinite,
+                       loc.d_max, loc.growth, -loc.d_min};
+        DIST_HIP(hipMemcpyAsync(D->small, h, sizeof(h), hipMemcpyHostToDevice, main));
+        rc = ex_allreduce(ctx, D, D->small, 5, 0, main); if (rc) return rc;
+        rc = ex_allreduce(ctx, D, D->small + 5, 3, 1, main); if (rc) return rc;
+        DIST_HIP(hipMemcpyAsync(h, D->small, sizeof(h), hipMemcpyDeviceToHost, main));
+        DIST_HIP(hipStreamSynchronize(main));
+        loc.n_neg = (int64_t)h[0]; loc.n_zero = (int64_t)h[1]; loc.n_2x2 = (int64_t)h[2]; loc.n_pos = (int64_t)h[3];
+        loc.nonfinite = (int64_t)h[4]; loc.d_max = h[5]; loc.growth = h[6]; loc.d_min = -h[7];
+    }
+    if (stats) *stats = loc;
+    if (loc.nonfinite) { ctx->err = "NaN/Inf met during factorisation"; return PYIPM_E_NONFINITE; }
+    return rc_nonfinite == PYIPM_E_NONFINITE ? PYIPM_E_NONFINITE : 0;
+}
+
+// x := Hc^{-1} b across the ranks.  b, x: Npad device vectors, replicated (b on entry, x on return).
+// Forward: rank r keeps vloc_r with sum_r vloc_r = b - (updates applied so far); the owner of panel p needs the SUM of
+// the segment [c0, c1) -- one nb-long all-reduce -- resolves it and pushes its update into its own vloc.  No vector
+// travels.  Backward: the owner needs every x below, so each resolved segment is broadcast (nb doubles).
+int solve_dist_once(Ctx* ctx, DistState* D, const double* b, double* x) {
+    const Geo& g = ctx->g;
+    hipStream_t st = ctx->stream;
+    double* v = D->vloc;
+    hipLaunchKernelGGL(k_mask_owned, grid1(g.Npad), dim3(256), 0, st, v, b, g);
+    DIST_KCHECK();
+    for (int64_t p = 0; p < g.npanels; ++p) {
+        const int64_t c0 = g.panel_c0(p); const int64_t nbw = g.panel_w(p);
+        const bool own = g.owner(p) == g.rank;
+        if (g.world > 1) {
+            DIST_HIP(hipMemcpyAsync(D->seg, v + c0, (size_t)nbw * sizeof(double), hipMemcpyDeviceToDevice, st));
+            int rc = ex_allreduce(ctx, D, D->seg, (size_t)nbw, 0, st); if (rc) return rc;
+            if (own) DIST_HIP(hipMemcpyAsync(v + c0, D->seg, (size_t)nbw * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+        if (own) {
+            int rc = fwd_panel(ctx, p, v); if (rc) return rc;
+            rc = diag_panel(ctx, p, v); if (rc) return rc;
+        }
+    }
+    for (int64_t p = g.npanels - 1; p >= 0; --p) {
+        const int64_t c0 = g.panel_c0(p); const int64_t nbw = g.panel_w(p);
+        if (g.owner(p) == g.rank) { int rc = bwd_panel(ctx, p, v); if (rc) return rc; }
+        int rc = ex_bcast(ctx, D, v + c0, (size_t)nbw * sizeof(double), g.owner(p), st); if (rc) return rc;
+    }
+    DIST_HIP(hipMemcpyAsync(x, v, (size_t)g.Npad * sizeof(double), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// y = Hc v over the ranks (v, y replicated Npad vectors)
+int matvec_dist(Ctx* ctx, DistState* D, const double* v, double* y) {
+    int rc = kkt_matvec_dev(ctx, v, y); if (rc) return rc;
+    return ex_allreduce(ctx, D, y, (size_t)ctx->g.Npad, 0, ctx->stream);
+}
+
+int solve_dist(Ctx* ctx, const double* rhs, double* dz, int flip, int refine, int memkind) {
+    const Geo& g = ctx->g;
+    DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
+    if (!ctx->factored) { ctx->err = "solve_dist: factor first"; return PYIPM_E_BADARG; }
+    if (!dz) { ctx->err = "solve_dist: null output"; return PYIPM_E_BADARG; }
+    hipStream_t st = ctx->stream;
+    DIST_HIP(hipEventRecord(ctx->ev[4], st));
+    ctx->forward_pending = false;
+    rc = solve_prepare(ctx, rhs, memkind); if (rc) return rc;          // v1 = v0 = b (replicated; pad zero)
+    rc = solve_dist_once(ctx, D, ctx->v1, ctx->v0); if (rc) return rc;
+    ctx->info_steps = 0; ctx->info_converged = 0; ctx->info_berr0 = -1.0; ctx->info_berr = -1.0;
+    const bool adaptive = refine < 0;
+    const int maxit = adaptive ? ctx->refine_max : refine;
+    double prev = -1.0;
+    for (int it = 0; it <= maxit; ++it) {
+        if (!adaptive && it == maxit) break;
+        rc = matvec_dist(ctx, D, ctx->v0, ctx->v2); if (rc) return rc;
+        hipLaunchKernelGGL(k_axpby, grid1(g.Npad), dim3(256), 0, st, ctx->v2, ctx->v1, ctx->v2, 1.0, -1.0, g.Npad);
+        DIST_KCHECK();
+        if (adaptive) {
+            double ss[2];
+            hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, st, ctx->partial, ctx->v2, ctx->v1, g.N);
+            DIST_KCHECK();
+            DIST_HIP(hipMemcpyAsync(ss, ctx->partial, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+            DIST_HIP(hipStreamSynchronize(st));
+            const double berr = ss[1] > 0.0 ? sqrt(ss[0] / ss[1]) : sqrt(ss[0]);     // identical on every rank: replicated vectors
+            if (it == 0) ctx->info_berr0 = berr;
+            ctx->info_berr = berr;
+            if (!(berr <= 1.0e300)) break;
+            if (berr <= ctx->refine_target) { ctx->info_converged = 1; break; }
+            if (it == maxit || (prev >= 0.0 && berr > 0.25 * prev)) break;
+            prev = berr;
+        }
+        rc = solve_dist_once(ctx, D, ctx->v2, ctx->vc); if (rc) return rc;
+        hipLaunchKernelGGL(k_axpby, grid1(g.Npad), dim3(256), 0, st, ctx->v0, ctx->v0, ctx->vc, 1.0, 1.0, g.Npad);
+        DIST_KCHECK();
+        ctx->info_steps = it + 1;
+    }
+    hipLaunchKernelGGL(k_copy_flip, grid1(g.N), dim3(256), 0, st, ctx->v2, ctx->v0, g.N, g.n + g.mi,
+                       (flip && (g.me + g.mi) > 0) ? 1 : 0);
+    DIST_KCHECK();
+    DIST_HIP(hipEventRecord(ctx->ev[5], st));
+    rc = copy_out(ctx, dz, ctx->v2, g.N, memkind); if (rc) return rc;
+    ctx->ev_solve_valid = true;
+    ctx->have_direction = (flip != 0) || (g.me + g.mi == 0);
+    return 0;
+}
+
+// g = -grad, complete on every rank (the ranks' shares summed)
+int residual_dist(Ctx* ctx) {
+    DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
+    rc = residual_dev(ctx); if (rc) return rc;
+    return ex_allreduce(ctx, D, ctx->rhs, (size_t)ctx->g.Npad, 0, ctx->stream);
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int pyipm_newton_rccl_library(const char* path) try {
+    g_rccl_path = path ? path : "";
+    return PYIPM_OK;
+} PYIPM_CATCH_NOH
+
+int pyipm_newton_set_exchange(pyipm_newton_ctx* h, pyipm_bcast_fn bcast, pyipm_allreduce_fn allreduce, void* user) try {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
+    D->bcast = bcast; D->allreduce = allreduce; D->user = user;
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+int pyipm_newton_comm_unique_id(void* id128) try {
+    if (!id128) return PYIPM_E_BADARG;
+    std::string err;
+    if (rccl_load(&err)) return PYIPM_E_COMM;
+    ncclUniqueId id;
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess) return PYIPM_E_COMM;
+    memcpy(id128, &id, sizeof(id));
+    return PYIPM_OK;
+} PYIPM_CATCH_NOH
+
+int pyipm_newton_comm_init(pyipm_newton_ctx* h, const void* id128) try {
+    if (check_ctx(h) || !id128) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
+    if (rccl_load(&ctx->err)) return PYIPM_E_COMM;
+    if (D->comm) { g_rccl.CommDestroy(D->comm); D->comm = nullptr; }
+    ncclUniqueId id; memcpy(&id, id128, sizeof(id));
+    ncclResult_t r = g_rccl.CommInitRank(&D->comm, ctx->g.world, id, ctx->g.rank);
+    if (r != ncclSuccess) { D->comm = nullptr; ctx->err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; }
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+int64_t pyipm_newton_owned_rows(pyipm_newton_ctx* h, int64_t* rows) try {
+    if (check_ctx(h)) return -1;
+    const Geo& g = C(h)->g;
+    const RowMap rm = make_rowmap(g, 1);
+    if (rows) for (int64_t r = 0; r < rm.nloc; ++r) rows[r] = rm.glob(r);
+    return rm.nloc;
+} catch (...) { return -1; }
+
+int pyipm_newton_stage_blocks_owned(pyipm_newton_ctx* h, const double* d2L_rows, int64_t ld_d2L, const double* Je_rows,
+                                    int64_t ld_Je, const double* Ji_rows, int64_t ld_Ji, int memkind) try {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    const int64_t nl = make_rowmap(g, 1).nloc;
+    int rc;
+    rc = stage_block(ctx, d2L_rows, nl, g.n, ld_d2L, memkind, &ctx->stg_d2L, &ctx->stg_d2L_sz, &ctx->d2L, &ctx->ld_d2L); if (rc) return rc;
+    rc = stage_block(ctx, Je_rows, g.me ? nl : 0, g.me, ld_Je, memkind, &ctx->stg_Je, &ctx->stg_Je_sz, &ctx->Je, &ctx->ld_Je); if (rc) return rc;
+    rc = stage_block(ctx, Ji_rows, g.mi ? nl : 0, g.mi, ld_Ji, memkind, &ctx->stg_Ji, &ctx->stg_Ji_sz, &ctx->Ji, &ctx->ld_Ji); if (rc) return rc;
+    ctx->sharded = g.world > 1 ? 1 : 0;
+    ctx->have_blocks = true;
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+int pyipm_newton_residual_dist(pyipm_newton_ctx* h, double* g_out, int memkind) try {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    int rc = residual_dist(ctx); if (rc) return rc;
+    return copy_out(ctx, g_out, ctx->rhs, ctx->g.N, memkind);
+} PYIPM_CATCH_H(h)
+
+int pyipm_newton_factor_dist(pyipm_newton_ctx* h, pyipm_factor_stats* stats) try {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    return factor_dist(ctx, stats);
+} PYIPM_CATCH_H(h)
+
+int pyipm_newton_solve_dist(pyipm_newton_ctx* h, const double* rhs, double* dz, int flip, int refine, int memkind) try {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    return solve_dist(ctx, rhs, dz, flip, refine, memkind);
+} PYIPM_CATCH_H(h)
+
+int pyipm_newton_kkt_matvec_dist(pyipm_newton_ctx* h, const double* v, double* y, int memkind) try {
+    if (check_ctx(h) || !v || !y) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
+    ctx->forward_pending = false;
+    hipLaunchKernelGGL(k_fill, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v1, 0.0, g.Npad); PYIPM_KCHECK();
+    rc = put_vec(ctx, ctx->v1, v, g.N, memkind); if (rc) return rc;
+    rc = matvec_dist(ctx, D, ctx->v1, ctx->vc); if (rc) return rc;
+    return copy_out(ctx, y, ctx->vc, g.N, memkind);
+} PYIPM_CATCH_H(h)
+
+int pyipm_newton_step_dist(pyipm_newton_ctx* h, double delta, double delta_c, int refine, double* dz,
+                           pyipm_factor_stats* stats, int memkind) try {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    if (!dz) { ctx->err = "step_dist: null output"; return PYIPM_E_BADARG; }
+    int rc = residual_dist(ctx); if (rc) return rc;
+    rc = pyipm_newton_assemble(h, delta, delta_c); if (rc) return rc;
+    rc = factor_dist(ctx, stats); if (rc) return rc;
+    return solve_dist(ctx, nullptr, dz, 1, refine, memkind);
+} PYIPM_CATCH_H(h)
+
+int pyipm_newton_dist_timings(pyipm_newton_ctx* h, double out[8]) try {
+    if (check_ctx(h) || !out) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
+    PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->ev_solve_valid) { float ms = 0.f; PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); D->t_solve = ms; }
+    out[0] = D->t_factor; out[1] = D->t_chain; out[2] = D->t_pack; out[3] = D->t_bcast; out[4] = D->t_unpack;
+    out[5] = D->t_solve; out[6] = (double)D->bytes_sent; out[7] = (double)D->n_msgs;
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+}  // extern "C"

@@ -9,9 +9,33 @@
 
 namespace pyipm {
 
+// Rows of the derivative blocks a rank works on.  Single rank: all n rows, identity.  Several ranks: the rows that
+// belong to the x-columns the rank owns (block-cyclic by panels of nb, as the KKT columns: column j of the lower
+// triangle is row j of triu(d2L) | Je | Ji), in local column order; `sharded` says the caller staged only those rows
+// (pyipm_newton_stage_blocks_owned), so a block row is addressed by the LOCAL index.
+struct RowMap {
+    int64_t nloc;                 // rows this rank works on
+    int nb, world, rank, sharded;
+    __host__ __device__ int64_t glob(int64_t r) const {
+        return world == 1 ? r : ((r / nb) * world + rank) * (int64_t)nb + r % nb;
+    }
+    __host__ __device__ int64_t brow(int64_t r) const { return sharded ? r : glob(r); }
+};
+inline RowMap make_rowmap(const Geo& g, int sharded) {
+    RowMap m; m.nb = g.nb; m.world = g.world; m.rank = g.rank; m.sharded = sharded;
+    int64_t c = 0;
+    for (int64_t p = g.rank; p < g.npanels; p += g.world) {
+        const int64_t c0 = p * (int64_t)g.nb;
+        if (c0 >= g.n) break;
+        c += (c0 + g.nb <= g.n) ? g.nb : g.n - c0;
+    }
+    m.nloc = g.world == 1 ? g.n : c;
+    return m;
+}
+
 // KKT entry (i, j), i >= j, in the reference's block order (pyipm.py:816-844 + reghess' shifts).
 __device__ __forceinline__ double kkt_entry(
-    int64_t i, int64_t j, const Geo& g,
+    int64_t i, int64_t j, int64_t jr, const Geo& g,      // jr: row of the derivative blocks that holds column j (j itself unless row-sharded)
     const double* __restrict__ d2L, int64_t ldh, const double* __restrict__ Je, int64_t ldje,
     const double* __restrict__ Ji, int64_t ldji, const double* __restrict__ s, const double* __restrict__ lda,
     double eps, double delta, double delta_c)
@@ -19,10 +43,10 @@ __device__ __forceinline__ double kkt_entry(
     const int64_t n = g.n, me = g.me, mi = g.mi, N = g.N;
     const int64_t o_s = n, o_e = n + mi, o_i = n + mi + me;
     if (j < n) {
-        if (i < n)        return d2L[j * ldh + i] + (i == j ? delta : 0.0);
+        if (i < n)        return d2L[jr * ldh + i] + (i == j ? delta : 0.0);
         if (i < o_e)      return 0.0;
-        if (i < o_i)      return Je[j * ldje + (i - o_e)];
-        if (i < N)        return Ji[j * ldji + (i - o_i)];
+        if (i < o_i)      return Je[jr * ldje + (i - o_e)];
+        if (i < N)        return Ji[jr * ldji + (i - o_i)];
         return 0.0;
     }
     if (j < o_e) {                                     // slack columns: Sigma and -I
@@ -57,7 +81,7 @@ __global__ __launch_bounds__(256) void k_assemble(
     const double* __restrict__ Je, int64_t ldje,
     const double* __restrict__ Ji, int64_t ldji,
     const double* __restrict__ s, const double* __restrict__ lda,
-    double eps, double delta, double delta_c, unsigned long long* __restrict__ anorm_bits)
+    double eps, double delta, double delta_c, unsigned long long* __restrict__ anorm_bits, int nt_store, int sharded)
 {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;          // even row; rows i, i+1
     const int64_t lc_base = (int64_t)blockIdx.y * 16;
@@ -72,18 +96,24 @@ __global__ __launch_bounds__(256) void k_assemble(
         const int64_t lp = lc / g.nb;
         const int64_t j = (lp * g.world + g.rank) * (int64_t)g.nb + (lc - lp * g.nb);
         if (i + 1 < j) continue;                      // both rows above the diagonal: not stored
+        const int64_t jr = sharded ? lc : j;          // row-sharded blocks are laid out in local column order
         dbl2_t v;
         if (vec_h && j < g.n && i + 1 < g.n && i >= j) {
-            v = *reinterpret_cast<const dbl2_t*>(&d2L[j * ldh + i]);
+            v = *reinterpret_cast<const dbl2_t*>(&d2L[jr * ldh + i]);
             if (i == j) v.x += delta;
             if (i + 1 == j) v.y += delta;
         } else {
-            v.x = (i >= j) ? kkt_entry(i, j, g, d2L, ldh, Je, ldje, Ji, ldji, s, lda, eps, delta, delta_c) : 0.0;
-            v.y = kkt_entry(i + 1, j, g, d2L, ldh, Je, ldje, Ji, ldji, s, lda, eps, delta, delta_c);
+            v.x = (i >= j) ? kkt_entry(i, j, jr, g, d2L, ldh, Je, ldje, Ji, ldji, s, lda, eps, delta, delta_c) : 0.0;
+            v.y = kkt_entry(i + 1, j, jr, g, d2L, ldh, Je, ldje, Ji, ldji, s, lda, eps, delta, delta_c);
         }
         amax = fmax(amax, fmax(fabs(v.x), fabs(v.y)));
-        if (i >= j) *reinterpret_cast<dbl2_t*>(&A[i + lc * ld]) = v;
-        else        A[(i + 1) + lc * ld] = v.y;       // the pair straddles the diagonal: store the lower one only
+        if (i >= j) {
+            // (non-temporal stores measured no faster, r02: 1.99 vs 1.95 ms at N = 32768 -- the kernel is store-bound)
+            if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<dbl2_t*>(&A[i + lc * ld]));
+            else          *reinterpret_cast<dbl2_t*>(&A[i + lc * ld]) = v;
+        } else {
+            A[(i + 1) + lc * ld] = v.y;               // the pair straddles the diagonal: store the lower one only
+        }
     }
     anorm_publish(anorm_bits, amax);
 }
@@ -102,19 +132,20 @@ __global__ __launch_bounds__(256) void k_rowdot2(
     double* __restrict__ out, const double* __restrict__ base, int64_t nrow,
     const double* __restrict__ M1, int64_t ld1, const double* __restrict__ x1, int64_t nc1,
     const double* __restrict__ M2, int64_t ld2, const double* __restrict__ x2, int64_t nc2,
-    int mode, int neg)
+    int mode, int neg, RowMap rm)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= nrow) return;
+    const int64_t jl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (jl >= nrow) return;
+    const int64_t j = rm.glob(jl), jb = rm.brow(jl);     // out / base index; row of the blocks
     double acc = 0.0;
     if (nc1 > 0) {
-        const double* r = M1 + j * ld1;
+        const double* r = M1 + jb * ld1;
         #pragma unroll 8
         for (int64_t a = lane; a < nc1; a += 64) acc += r[a] * x1[a];
     }
     if (nc2 > 0) {
-        const double* r = M2 + j * ld2;
+        const double* r = M2 + jb * ld2;
         #pragma unroll 8
         for (int64_t a = lane; a < nc2; a += 64) acc += r[a] * x2[a];
     }
@@ -145,12 +176,13 @@ __global__ __launch_bounds__(256) void k_residual_tail(
 // Upper-triangle symmetric product, row part:  y[j] = sum_{k>=j} U[j,k] v[k] + delta v[j]
 __global__ __launch_bounds__(256) void k_symv_row(
     double* __restrict__ y, const double* __restrict__ U, int64_t ldh, int64_t n,
-    const double* __restrict__ v, double delta)
+    const double* __restrict__ v, double delta, RowMap rm)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= n) return;
-    const double* r = U + j * ldh;
+    const int64_t jl = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (jl >= rm.nloc) return;
+    const int64_t j = rm.glob(jl);
+    const double* r = U + rm.brow(jl) * ldh;
     double acc = 0.0;
     for (int64_t k = j + lane; k < n; k += 64) acc += r[k] * v[k];
     acc = wave_sum(acc);
@@ -162,15 +194,23 @@ __global__ __launch_bounds__(256) void k_symv_row(
 // strict_upper != 0 restricts to j < a (the mirrored half of triu(d2L)).
 __global__ __launch_bounds__(256) void k_coldot_partial(
     double* __restrict__ part, const double* __restrict__ M, int64_t ldm, int64_t nrow, int64_t ncol,
-    const double* __restrict__ x, int64_t rows_per_chunk, int strict_upper)
+    const double* __restrict__ x, int64_t rows_per_chunk, int strict_upper, RowMap rm)
 {
     const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (a >= ncol) return;
-    const int64_t j0 = (int64_t)blockIdx.y * rows_per_chunk;
+    const int64_t j0 = (int64_t)blockIdx.y * rows_per_chunk;             // chunks of the rows this rank works on
     int64_t j1 = j0 + rows_per_chunk; if (j1 > nrow) j1 = nrow;
-    if (strict_upper && j1 > a) j1 = a;
     double acc = 0.0;
-    for (int64_t j = j0; j < j1; ++j) acc += M[j * ldm + a] * x[j];
+    if (rm.world == 1) {
+        if (strict_upper && j1 > a) j1 = a;
+        for (int64_t j = j0; j < j1; ++j) acc += M[j * ldm + a] * x[j];
+    } else {
+        for (int64_t jl = j0; jl < j1; ++jl) {
+            const int64_t j = rm.glob(jl);                                // (ascending in jl)
+            if (strict_upper && j >= a) break;
+            acc += M[rm.brow(jl) * ldm + a] * x[j];
+        }
+    }
     part[(int64_t)blockIdx.y * ncol + a] = acc;
 }
 

@@ -43,11 +43,11 @@ __global__ __launch_bounds__(256) void k_b_assemble(BatchPtrs bp, Geo g, double 
         const int64_t j = (int64_t)blockIdx.y * 16 + c;
         if (j >= g.Npad) break;
         if (i + 1 < j) continue;
-        const double v1 = kkt_entry(i + 1, j, g, d2L, bp.ldh, Je, bp.ldje, Ji, bp.ldji, s, lda, eps, delta, delta_c);
+        const double v1 = kkt_entry(i + 1, j, j, g, d2L, bp.ldh, Je, bp.ldje, Ji, bp.ldji, s, lda, eps, delta, delta_c);
         amax = fmax(amax, fabs(v1));
         if (i >= j) {
             dbl2_t v;
-            v.x = kkt_entry(i, j, g, d2L, bp.ldh, Je, bp.ldje, Ji, bp.ldji, s, lda, eps, delta, delta_c);
+            v.x = kkt_entry(i, j, j, g, d2L, bp.ldh, Je, bp.ldje, Ji, bp.ldji, s, lda, eps, delta, delta_c);
             v.y = v1;
             amax = fmax(amax, fabs(v.x));
             *reinterpret_cast<dbl2_t*>(&A[i + j * g.Npad]) = v;

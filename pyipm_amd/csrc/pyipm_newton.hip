@@ -45,9 +45,11 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
     const size_t ovc = cv.take((size_t)g.Npad * D);
     const size_t ovt = cv.take((size_t)(g.mi + 16) * D);
     const size_t oan = cv.take(64);
+    const size_t omi = cv.take((size_t)((g.ncols_local + g.nb - 1) / g.nb + 1) * (size_t)g.nb * (size_t)g.nb * D);
     if (base) {
         c->vc = (double*)(base + ovc); c->vt = (double*)(base + ovt);
         c->anorm = (unsigned long long*)(base + oan);
+        c->Minv = (double*)(base + omi);
         c->A = (double*)(base + oA); c->Wbuf = (double*)(base + oW); c->Lbuf = (double*)(base + oL);
         c->Dinv = (double*)(base + oD); c->Tsv = (double*)(base + oT); c->Tflag = (double*)(base + oTf); c->rhs = (double*)(base + orhs);
         c->v0 = (double*)(base + ov0); c->v1 = (double*)(base + ov1); c->v2 = (double*)(base + ov2);
@@ -489,6 +491,7 @@ int factor_begin(Ctx* ctx) {
     PYIPM_HIP(hipMemcpyAsync(ctx->dstats, &z, sizeof(z), hipMemcpyHostToDevice, ctx->stream));
     PYIPM_HIP(hipStreamSynchronize(ctx->stream));   // &z is a stack temporary
     ctx->n_trailing = 0; ctx->trailing_flops = 0.0; ctx->trailing_area = 0.0;
+    ctx->minv_valid = false;
     return 0;
 }
 
@@ -548,6 +551,7 @@ int diag_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr, int
 // part / pstride: partial-sum buffer for several right-hand sides (>= nchunk*nb doubles each); default = the handle's own
 int bwd_panel(Ctx* ctx, int64_t p, double* v, int nrhs = 1, int64_t vstride = 0, double* part = nullptr, int64_t pstride = 0) {
     const Geo& g = ctx->g;
+    const bool own_part = part == nullptr;
     if (!part) part = ctx->partial;
     const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
     const int nbw = (int)g.panel_w(p);
@@ -558,6 +562,21 @@ int bwd_panel(Ctx* ctx, int64_t p, double* v, int nrhs = 1, int64_t vstride = 0,
         hipLaunchKernelGGL(k_bwd_dot, dim3(nbw, nchunk, nrhs), dim3(256), 0, ctx->stream, ctx->A, g.Npad, lc0, g.nb,
                            c0 + nbw, g.Npad, v, part, vstride, pstride);
         PYIPM_KCHECK();
+    }
+    if (ctx->bwd_fused && nrhs == 1 && own_part) {
+        // the panel's own block through inv(Lb_pp)' (one dense product) instead of the one-block recursion
+        if (!ctx->minv_valid) {
+            const int64_t nlp = (g.ncols_local + g.nb - 1) / g.nb;
+            if (nlp > 0) {
+                hipLaunchKernelGGL(k_panel_inv, dim3((unsigned)nlp), dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->Minv, (int64_t)0);
+                PYIPM_KCHECK();
+            }
+            ctx->minv_valid = true;
+        }
+        hipLaunchKernelGGL(k_bwd_apply, dim3(1), dim3(1024), 0, ctx->stream, ctx->Minv + (p / g.world) * (int64_t)g.nb * g.nb,
+                           c0, nbw, g.nb, part, nchunk, v);
+        PYIPM_KCHECK();
+        return 0;
     }
     hipLaunchKernelGGL(k_bwd_diag, dim3(1, nrhs), dim3(nbw), nbw * sizeof(double), ctx->stream, ctx->A, g.Npad, lc0, c0, nbw,
                        g.nb, part, nchunk, v, vstride, pstride);
@@ -586,7 +605,7 @@ int cond_reduce(Ctx* ctx, const double* b, double* vc) {
     PYIPM_KCHECK();
     hipLaunchKernelGGL(k_rowdot2, grid1(g.n, 4), dim3(256), 0, ctx->stream, vc, b, g.n,
                        (const double*)nullptr, (int64_t)0, (const double*)nullptr, (int64_t)0,
-                       ctx->Ji, ctx->ld_Ji, ctx->vt, g.mi, 0, 0);
+                       ctx->Ji, ctx->ld_Ji, ctx->vt, g.mi, 0, 0, make_rowmap(g, 0));
     PYIPM_KCHECK();
     if (ctx->gc.Npad > g.n) {
         hipLaunchKernelGGL(k_cond_gather, grid1(ctx->gc.Npad - g.n), dim3(256), 0, ctx->stream, vc, b, g, ctx->gc.Npad,
@@ -602,7 +621,7 @@ int cond_expand(Ctx* ctx, const double* vc, double* v) {
     const int nchunk = 64;
     const int64_t rpc = (g.n + nchunk - 1) / nchunk;
     hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((g.mi + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
-                       ctx->partial, ctx->Ji, ctx->ld_Ji, g.n, g.mi, vc, rpc, 0);
+                       ctx->partial, ctx->Ji, ctx->ld_Ji, g.n, g.mi, vc, rpc, 0, make_rowmap(g, 0));
     PYIPM_KCHECK();
     hipLaunchKernelGGL(k_coldot_reduce, grid1(g.mi), dim3(256), 0, ctx->stream, ctx->vt, ctx->partial, g.mi, nchunk, 0);
     PYIPM_KCHECK();
@@ -624,47 +643,52 @@ int solve_inplace(Ctx* ctx, double* v, bool forward_done = false) {
     return cond_expand(ctx, ctx->vc, v);
 }
 
-// y = Hc v from the staged blocks (Npad vectors on the device)
+// y = Hc v from the staged blocks (Npad vectors on the device).  With several ranks every rank adds the terms of the
+// KKT columns it owns (row j of triu(d2L) | Je | Ji is column j of the lower triangle), rank 0 the element-wise s /
+// multiplier part; the caller sums y over the ranks (dist_impl.hpp).
 int kkt_matvec_dev(Ctx* ctx, const double* v, double* y) {
     const Geo& g = ctx->g;
     const int64_t n = g.n, me = g.me, mi = g.mi;
     if (!ctx->have_blocks || !ctx->have_vectors) { ctx->err = "matvec: stage blocks and vectors first"; return PYIPM_E_BADARG; }
-    // x block: row part of triu(d2L) + delta
-    hipLaunchKernelGGL(k_symv_row, grid1(n, 4), dim3(256), 0, ctx->stream, y, ctx->d2L, ctx->ld_d2L, n, v, ctx->delta);
-    PYIPM_KCHECK();
-    // + Je v_e + Ji v_i
-    if (me + mi > 0) {
-        hipLaunchKernelGGL(k_rowdot2, grid1(n, 4), dim3(256), 0, ctx->stream, y, (const double*)nullptr, n,
-                           ctx->Je, ctx->ld_Je, v + n + mi, me, ctx->Ji, ctx->ld_Ji, v + n + mi + me, mi, 1, 0);
+    const RowMap rm = make_rowmap(g, ctx->sharded);
+    const int64_t nl = rm.nloc;
+    if (g.world > 1) { hipLaunchKernelGGL(k_fill, grid1(g.Npad), dim3(256), 0, ctx->stream, y, 0.0, g.Npad); PYIPM_KCHECK(); }
+    const int nchunk = 64;
+    const int64_t rpc = (nl + nchunk - 1) / nchunk > 0 ? (nl + nchunk - 1) / nchunk : 1;
+    if (nl > 0) {
+        // x block: row part of triu(d2L) + delta
+        hipLaunchKernelGGL(k_symv_row, grid1(nl, 4), dim3(256), 0, ctx->stream, y, ctx->d2L, ctx->ld_d2L, n, v, ctx->delta, rm);
         PYIPM_KCHECK();
-    }
-    // + mirrored strict upper part of d2L (column walk, deterministic two-pass)
-    {
-        const int nchunk = 64;
-        const int64_t rpc = (n + nchunk - 1) / nchunk;
+        // + Je v_e + Ji v_i
+        if (me + mi > 0) {
+            hipLaunchKernelGGL(k_rowdot2, grid1(nl, 4), dim3(256), 0, ctx->stream, y, (const double*)nullptr, nl,
+                               ctx->Je, ctx->ld_Je, v + n + mi, me, ctx->Ji, ctx->ld_Ji, v + n + mi + me, mi, 1, 0, rm);
+            PYIPM_KCHECK();
+        }
+        // + mirrored strict upper part of d2L (column walk, deterministic two-pass)
         hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((n + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
-                           ctx->partial, ctx->d2L, ctx->ld_d2L, n, n, v, rpc, 1);
+                           ctx->partial, ctx->d2L, ctx->ld_d2L, nl, n, v, rpc, 1, rm);
         PYIPM_KCHECK();
         hipLaunchKernelGGL(k_coldot_reduce, grid1(n), dim3(256), 0, ctx->stream, y, ctx->partial, n, nchunk, 1);
         PYIPM_KCHECK();
     }
-    // s, lambda_e, lambda_i, pad: element-wise parts
-    hipLaunchKernelGGL(k_matvec_tail, grid1(g.Npad - n), dim3(256), 0, ctx->stream, y, v, g, ctx->s, ctx->lda,
-                       ctx->eps, ctx->delta_c);
-    PYIPM_KCHECK();
+    // s, lambda_e, lambda_i, pad: element-wise parts (one rank)
+    if (g.Npad > n && g.rank == 0) {                   // (nothing beyond the x block when me = mi = 0 and n is a multiple of 128)
+        hipLaunchKernelGGL(k_matvec_tail, grid1(g.Npad - n), dim3(256), 0, ctx->stream, y, v, g, ctx->s, ctx->lda,
+                           ctx->eps, ctx->delta_c);
+        PYIPM_KCHECK();
+    }
     // + Je' v_x , Ji' v_x
-    const int nchunk = 64;
-    const int64_t rpc = (n + nchunk - 1) / nchunk;
-    if (me > 0) {
+    if (me > 0 && nl > 0) {
         hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((me + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
-                           ctx->partial, ctx->Je, ctx->ld_Je, n, me, v, rpc, 0);
+                           ctx->partial, ctx->Je, ctx->ld_Je, nl, me, v, rpc, 0, rm);
         PYIPM_KCHECK();
         hipLaunchKernelGGL(k_coldot_reduce, grid1(me), dim3(256), 0, ctx->stream, y + n + mi, ctx->partial, me, nchunk, 1);
         PYIPM_KCHECK();
     }
-    if (mi > 0) {
+    if (mi > 0 && nl > 0) {
         hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((mi + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
-                           ctx->partial, ctx->Ji, ctx->ld_Ji, n, mi, v, rpc, 0);
+                           ctx->partial, ctx->Ji, ctx->ld_Ji, nl, mi, v, rpc, 0, rm);
         PYIPM_KCHECK();
         hipLaunchKernelGGL(k_coldot_reduce, grid1(mi), dim3(256), 0, ctx->stream, y + n + mi + me, ctx->partial, mi, nchunk, 1);
         PYIPM_KCHECK();
@@ -672,13 +696,19 @@ int kkt_matvec_dev(Ctx* ctx, const double* v, double* y) {
     return 0;
 }
 
+// g = -grad into ctx->rhs.  With several ranks: the x rows this rank owns and (rank 0) the s / multiplier rows, zero
+// elsewhere; the distributed driver sums it over the ranks.
 int residual_dev(Ctx* ctx) {
     const Geo& g = ctx->g;
     if (!ctx->have_blocks || !ctx->have_vectors) { ctx->err = "residual: stage blocks and vectors first"; return PYIPM_E_BADARG; }
-    hipLaunchKernelGGL(k_rowdot2, grid1(g.n, 4), dim3(256), 0, ctx->stream, ctx->rhs, ctx->df, g.n,
-                       ctx->Je, ctx->ld_Je, ctx->lda, g.me, ctx->Ji, ctx->ld_Ji, ctx->lda + g.me, g.mi, 0, 1);
-    PYIPM_KCHECK();
-    if (g.Npad > g.n) {
+    const RowMap rm = make_rowmap(g, ctx->sharded);
+    if (g.world > 1) { hipLaunchKernelGGL(k_fill, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->rhs, 0.0, g.Npad); PYIPM_KCHECK(); }
+    if (rm.nloc > 0) {
+        hipLaunchKernelGGL(k_rowdot2, grid1(rm.nloc, 4), dim3(256), 0, ctx->stream, ctx->rhs, ctx->df, rm.nloc,
+                           ctx->Je, ctx->ld_Je, ctx->lda, g.me, ctx->Ji, ctx->ld_Ji, ctx->lda + g.me, g.mi, 0, 1, rm);
+        PYIPM_KCHECK();
+    }
+    if (g.Npad > g.n && g.rank == 0) {
         hipLaunchKernelGGL(k_residual_tail, grid1(g.Npad - g.n), dim3(256), 0, ctx->stream, ctx->rhs, g, ctx->ce, ctx->ci,
                            ctx->s, ctx->lda, ctx->mu, ctx->eps);
         PYIPM_KCHECK();
@@ -739,7 +769,7 @@ int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
         dim3 grid((unsigned)((gc.Npad + 511) / 512), (unsigned)((gc.ncols_local + 15) / 16));
         PYIPM_HIP(hipMemsetAsync(ctx->anorm, 0, sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, gc.Npad, gc, ctx->d2L, ctx->ld_d2L,
-                           Jx, ldx, (const double*)nullptr, (int64_t)0, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm);
+                           Jx, ldx, (const double*)nullptr, (int64_t)0, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, 0);
         PYIPM_KCHECK();
         if (na > 0) {
             hipLaunchKernelGGL(k_cond_fix_diag, grid1(na), dim3(256), 0, ctx->stream, ctx->A, gc.Npad, g.n + g.me,
@@ -779,7 +809,7 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
     if (g.ncols_local > 0) {
         dim3 grid((unsigned)((g.Npad + 511) / 512), (unsigned)((g.ncols_local + 15) / 16));
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
-                           ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm);
+                           ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, ctx->sharded);
         PYIPM_KCHECK();
     }
     ctx->assembled = true; ctx->factored = false; ctx->forward_pending = false;
@@ -797,34 +827,6 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     if (g.world != 1) { ctx->err = "factor(): single-rank entry point; use the per-panel phases when world > 1"; return PYIPM_E_BADARG; }
     if (!ctx->assembled) { ctx->err = "factor: assemble first"; return PYIPM_E_BADARG; }
     ctx->per_panel_mode = false;
-    // Optional: run everything this function puts on the handle's stream (the bulk updates, above all) on a CU-masked
-    // stream that leaves `reserve_cus` CUs to the panel chain (side stream, unmasked): the chain's kernels then find
-    // free slots at once instead of waiting for a 250-us bulk block to retire.  Fenced by events at both ends.
-    struct StreamSwap {
-        Ctx* c; hipStream_t user; bool on = false;
-        ~StreamSwap() { if (on) { hipEventRecord(c->ev_bulk1, c->stream); hipStream_t b = c->stream; c->stream = user;
-                                  hipStreamWaitEvent(user, c->ev_bulk1, 0); (void)b; } }
-    } swap{ctx, ctx->stream};
-    if (ctx->reserve_cus > 0) {
-        const int key = ctx->reserve_cus * 4 + ctx->reserve_mode;
-        if (!ctx->bulk || ctx->bulk_key != key) {
-            if (ctx->bulk) { PYIPM_HIP(hipStreamSynchronize(ctx->bulk)); PYIPM_HIP(hipStreamDestroy(ctx->bulk)); ctx->bulk = nullptr; }
-            hipDeviceProp_t prop; PYIPM_HIP(hipGetDeviceProperties(&prop, ctx->device));
-            const int ncu = prop.multiProcessorCount, k = ctx->reserve_cus < ncu / 2 ? ctx->reserve_cus : ncu / 2;
-            std::vector<uint32_t> mask((size_t)((ncu + 31) / 32), 0xffffffffu);
-            for (int q = 0; q < k; ++q) {
-                const int bit = ctx->reserve_mode == 0 ? q : (int)((int64_t)q * ncu / k);
-                mask[(size_t)(bit / 32)] &= ~(1u << (bit % 32));
-            }
-            PYIPM_HIP(hipExtStreamCreateWithCUMask(&ctx->bulk, (uint32_t)mask.size(), mask.data()));
-            ctx->bulk_key = key;
-            if (!ctx->ev_bulk0) { PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_bulk0, hipEventDisableTiming));
-                                  PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_bulk1, hipEventDisableTiming)); }
-        }
-        PYIPM_HIP(hipEventRecord(ctx->ev_bulk0, ctx->stream));
-        PYIPM_HIP(hipStreamWaitEvent(ctx->bulk, ctx->ev_bulk0, 0));
-        ctx->stream = ctx->bulk; swap.on = true;
-    }
     int rc = factor_begin(ctx); if (rc) return rc;
     if (!ctx->side) {
         // panel kernels are latency-critical and tiny: highest dispatch priority, so they take the first
@@ -880,7 +882,12 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         PYIPM_HIP(hipEventRecord(ctx->ev_done[q], used));
         PYIPM_HIP(hipStreamWaitEvent(ctx->fwd, ctx->ev_done[q], 0));
         int r2 = fwd_panel(ctx, q, ctx->fwd_vec, ctx->fwd); if (r2) return r2;
-        return diag_panel(ctx, q, ctx->fwd_vec, ctx->fwd);
+        r2 = diag_panel(ctx, q, ctx->fwd_vec, ctx->fwd); if (r2) return r2;
+        if (ctx->bwd_fused) {               // inv(Lb_qq)' for the backward sweep, beside the factorisation (k_bwd_apply)
+            hipLaunchKernelGGL(k_panel_inv, dim3(1), dim3(256), 0, ctx->fwd, ctx->A, g.Npad, g, ctx->Minv, q);
+            PYIPM_KCHECK();
+        }
+        return 0;
     };
     for (int64_t q = 0; q < gsize(0); ++q) {
         rc = factor_panel(ctx, q, ctx->stream, true); if (rc) return rc;
@@ -957,6 +964,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         PYIPM_HIP(hipEventRecord(ctx->ev_fwd, ctx->fwd));
         PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fwd, 0));
         ctx->forward_fused = true;
+        if (ctx->bwd_fused) ctx->minv_valid = true;
     }
     PYIPM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->assembled = false;                 // storage now holds the factor
@@ -984,7 +992,10 @@ int factor_dispatch(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward) {
     return rc;
 }
 
+void dist_free(Ctx* ctx);        // dist_impl.hpp
+
 // a failed create releases whatever the handle already owns (events, a library-owned workspace) the way destroy does
+int dist_set_option(Ctx* ctx, const char* name, double value, bool* handled);      // dist_impl.hpp
 int create_fail(Ctx* ctx, int code) {
     pyipm_newton_destroy(reinterpret_cast<pyipm_newton_ctx*>(ctx));
     return code;
@@ -1151,10 +1162,8 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     for (auto& pr : ctx->ev_trailing) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (ctx->ev_head) hipEventDestroy(ctx->ev_head);
     if (ctx->ev_panel) hipEventDestroy(ctx->ev_panel);
+    dist_free(ctx);
     if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
-    if (ctx->bulk) { hipStreamSynchronize(ctx->bulk); hipStreamDestroy(ctx->bulk); }
-    if (ctx->ev_bulk0) hipEventDestroy(ctx->ev_bulk0);
-    if (ctx->ev_bulk1) hipEventDestroy(ctx->ev_bulk1);
     if (ctx->fwd) { hipStreamSynchronize(ctx->fwd); hipStreamDestroy(ctx->fwd); }
     if (ctx->ev_fwd) hipEventDestroy(ctx->ev_fwd);
     for (auto e : ctx->ev_done) hipEventDestroy(e);
@@ -1655,8 +1664,8 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "tail_group")) { ctx->tail_group = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "tail_cols")) { ctx->tail_cols = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "reserve_cus")) { ctx->reserve_cus = (int)value < 0 ? 0 : (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "reserve_mode")) { ctx->reserve_mode = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "bwd_fused")) { ctx->bwd_fused = (int)value != 0; return PYIPM_OK; }
+    { bool handled = false; int rc = dist_set_option(ctx, name, value, &handled); if (handled) return rc; }
     if (!strcmp(name, "inpanel32")) { ctx->inpanel32 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
@@ -1692,6 +1701,10 @@ int pyipm_mfma_f64_peak(int device, int iters, double* tflops) try {
 } PYIPM_CATCH_NOH
 
 }  // extern "C"
+
+// =================================================================================================
+// The distributed driver (per-panel schedule, sweeps and exchanges in C): same shared object.
+#include "dist_impl.hpp"
 
 // =================================================================================================
 // L-BFGS search direction (include/pyipm_lbfgs.h): same shared object, built on the machinery above.

@@ -13,12 +13,23 @@ exchange per panel:
         everyone:   rank-nb MFMA update of the columns it owns to the right of p
 
 Sending W (+ 128 KB of tile inverses) instead of W and L halves the bytes on the wire: each
-receiver recomputes L with ``nb/64`` small products.  The substitutions pass the vector
-along the owners: after each panel the owner broadcasts the part of the vector it changed.
+receiver recomputes L with ``nb/64`` small products.
 
-``core`` is any object with the per-panel interface of :class:`pyipm_amd.newton.NewtonCore`
-(the product backend, HIP); the CPU tests drive the same orchestration with a NumPy model
-backend over ``gloo``.
+The substitutions move nb-long segments only: the forward sweep sums the segment of panel p over the
+ranks (each rank keeps its own share of the running vector), the backward sweep broadcasts each resolved
+segment.
+
+Two drivers of the same schedule:
+
+* **native** (the product path for the HIP core): ``pyipm_newton_factor_dist / solve_dist / step_dist``
+  run the per-panel loop, the streams and the exchanges inside the library (``csrc/dist_impl.hpp``) -- no
+  interpreter between two panels.  This module only binds the exchange: a handle-owned RCCL communicator
+  when the process group's backend is ``nccl`` (the 128-byte id travels through ``torch.distributed``), or
+  two callbacks that stage through the host when it is ``gloo`` (tests: several ranks sharing one GPU).
+* **python** (``native=False``): the loop below over the per-panel C-ABI phases.  ``core`` is then any
+  object with the per-panel interface of :class:`pyipm_amd.newton.NewtonCore`; the CPU tests drive it with
+  a NumPy model backend over ``gloo`` (world 2/3/4/8), which is how the schedule itself is covered without
+  a GPU.
 """
 from __future__ import annotations
 
@@ -26,13 +37,14 @@ import numpy as np
 
 
 class DistNewton(object):
-    def __init__(self, core, group=None, stage_through_cpu=None):
+    def __init__(self, core, group=None, stage_through_cpu=None, native=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.core = core
         self.world, self.rank = int(core.world), int(core.rank)
         self.group = group
+        self.native = bool(hasattr(core, "factor_dist")) if native is None else bool(native)
         if self.world > 1:
             if not dist.is_initialized():
                 raise RuntimeError("torch.distributed must be initialised for world > 1")
@@ -51,6 +63,64 @@ class DistNewton(object):
         # bulk update runs on the main stream (HIP cores only; the NumPy model backend has no streams)
         self.overlap_owner = bool(getattr(core, "on_device", True)) and hasattr(core, "sync_stream")
         self._side = None
+        self._cb_error = None
+        if self.native and self.world > 1:
+            self._bind_exchange(backend)
+
+    # ------------------------------------------------------------------ native driver: the exchange
+    def _bind_exchange(self, backend):
+        """nccl: the handle gets its own RCCL communicator (id from rank 0 through the process group);
+        gloo: callbacks that stage each buffer through the host (several ranks may share one GPU)."""
+        import ctypes
+        import os
+        from .newton import ALLREDUCE_FN, BCAST_FN, _RawDeviceArray
+        torch, dist, core = self.torch, self.dist, self.core
+        if backend == "nccl":
+            lib = core.lib
+            path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if os.path.exists(path):
+                lib.pyipm_newton_rccl_library(path.encode())            # the RCCL torch itself runs on
+            idbuf = (ctypes.c_char * 128)()
+            if self.rank == 0:
+                rc = lib.pyipm_newton_comm_unique_id(ctypes.cast(idbuf, ctypes.c_void_p))
+                if rc:
+                    raise RuntimeError("pyipm_newton_comm_unique_id failed (%d)" % rc)
+            t = torch.tensor(list(bytes(idbuf)), dtype=torch.uint8, device=core.device)
+            dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            core.comm_init(bytes(t.cpu().tolist()))
+            return
+
+        def view(ptr, count):
+            return torch.as_tensor(_RawDeviceArray(ptr, count), device=core.device)
+
+        def bcast(user, ptr, nbytes, root, stream):
+            try:
+                t = view(ptr, nbytes // 8)
+                torch.cuda.synchronize(core.device)                     # the library enqueued the producer on `stream`
+                h = t.cpu()
+                dist.broadcast(h, src=root if self.group is None else dist.get_global_rank(self.group, root), group=self.group)
+                if self.rank != root:
+                    t.copy_(h)
+                    torch.cuda.synchronize(core.device)
+                return 0
+            except Exception as e:                                      # nothing may propagate through the C frames
+                self._cb_error = e
+                return 1
+
+        def allreduce(user, ptr, count, op, stream):
+            try:
+                t = view(ptr, count)
+                torch.cuda.synchronize(core.device)
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX if op else dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+                torch.cuda.synchronize(core.device)
+                return 0
+            except Exception as e:
+                self._cb_error = e
+                return 1
+
+        core.set_exchange(BCAST_FN(bcast), ALLREDUCE_FN(allreduce))
 
     # ------------------------------------------------------------------ helpers
     def owner(self, p):
@@ -79,14 +149,30 @@ class DistNewton(object):
 
     # ------------------------------------------------------------------ phases
     def factor(self):
+        if self.native:
+            st = self.core.factor_dist()
+            self.bytes_broadcast = self.core.dist_timings()["bytes"]
+            return st
         # world == 1 normally takes the lock-step loop; force_lookahead lets a single rank run the overlapped
         # schedule (side stream + asynchronous broadcasts) so it can be exercised on a one-GPU box
         if self.lookahead and (self.world > 1 or self.force_lookahead):
             return self._factor_lookahead()
         return self._factor_lockstep()
 
+    def _sync_anorm(self):
+        """Every rank perturbs alike: the scale of a static pivot is the largest assembled entry over ALL ranks."""
+        if self.world > 1 and hasattr(self.core, "anorm"):
+            t = self.core.anorm()
+            if self.stage:
+                h = t.cpu()
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX, group=self.group)
+                t.copy_(h)
+            else:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
+
     def _factor_lockstep(self):
         core = self.core
+        self._sync_anorm()
         core.factor_begin()
         for p in range(self.npanels):
             own = self.owner(p) == self.rank
@@ -112,6 +198,7 @@ class DistNewton(object):
         factors it and posts its broadcast asynchronously; every rank then runs the bulk of update p
         while that message is in flight (RCCL runs on its own stream)."""
         core, dist = self.core, self.dist
+        self._sync_anorm()
         core.factor_begin()
         np_ = self.npanels
         bufs = [core.new_buffer(core.panel_msg_numel(0)), core.new_buffer(core.panel_msg_numel(0))]
@@ -198,19 +285,55 @@ class DistNewton(object):
         return {"n_neg": int(sums[0]), "n_zero": int(sums[1]), "n_2x2": int(sums[2]), "n_pos": int(sums[3]),
                 "nonfinite": int(sums[4]), "d_max": mx[0], "growth": mx[1], "d_min": -mx[2]}
 
-    def solve(self, rhs, flip=True):
-        """rhs: length-N vector replicated on every rank (device tensor for the HIP core).
-        Returns dz replicated on every rank."""
+    def _allreduce_sum(self, t):
+        if self.world == 1:
+            return
+        if self.stage:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def residual(self):
+        """g = -grad, complete on every rank."""
         core = self.core
+        if self.native:
+            return core.residual_dist()
+        g = core.residual()
+        if getattr(core, "residual_is_partial", False):     # a HIP rank of several computes the rows it owns
+            self._allreduce_sum(g)
+        return g
+
+    def solve(self, rhs, flip=True, refine=0):
+        """rhs: length-N vector replicated on every rank (device tensor for the HIP core).
+        Returns dz replicated on every rank.  Forward: the owner of panel p needs the SUM over the ranks of the
+        segment [c0, c1) of their running vectors (each rank pushes the updates of the panels it owns into its own
+        vector) -- nb numbers; backward: each resolved segment is broadcast -- nb numbers."""
+        core = self.core
+        if self.native:
+            return core.solve_dist(rhs, flip=flip, refine=refine)
+        if refine:
+            raise NotImplementedError("refinement runs in the native driver (pyipm_newton_solve_dist)")
         v = core.new_buffer(self.Npad)
         v.zero_()
-        v[: self.N] = rhs
-        for p in range(self.npanels):                      # forward + block-diagonal, owner by owner
+        for p in range(self.rank, self.npanels, self.world):          # this rank's share of the right-hand side
             c0, c1 = self.panel_cols(p)
-            if self.owner(p) == self.rank:
+            hi = min(c1, self.N)
+            if hi > c0:
+                v[c0:hi] = rhs[c0:hi]
+        for p in range(self.npanels):                      # forward + block-diagonal
+            c0, c1 = self.panel_cols(p)
+            own = self.owner(p) == self.rank
+            if self.world > 1:
+                seg = v[c0:c1].clone()
+                self._allreduce_sum(seg)
+                self.bytes_broadcast += seg.numel() * 8
+                if own:
+                    v[c0:c1] = seg
+            if own:
                 core.fwd_panel(p, v)
                 core.diag_panel(p, v)
-            self._bcast(v[c0:], self.owner(p))
         for p in range(self.npanels - 1, -1, -1):          # backward
             c0, c1 = self.panel_cols(p)
             if self.owner(p) == self.rank:
@@ -223,11 +346,15 @@ class DistNewton(object):
 
     def step(self, delta=0.0, delta_c=0.0, refine=0):
         """residual + assemble + factor + solve + flip (pyipm.py:1717-1725) over all ranks."""
-        if refine:
-            raise NotImplementedError("iterative refinement is single-rank only for now")
         core = self.core
-        g = core.residual()
+        if self.native:
+            dz, st = core.step_dist(delta, delta_c, refine=refine)
+            self.bytes_broadcast = core.dist_timings()["bytes"]
+            if self._cb_error is not None:
+                raise self._cb_error
+            return dz, st
+        g = self.residual()
         core.assemble(delta, delta_c)
         st = self.factor()
-        dz = self.solve(g, flip=True)
+        dz = self.solve(g, flip=True, refine=refine)
         return dz, st

@@ -105,6 +105,19 @@ def load_library(path: str | None = None):
                                                       c_void_p, c_int64, c_int64]),
         "pyipm_newton_step_batched": (c_int, [ctxp, c_double, c_double, c_void_p, POINTER(FactorStats), c_int]),
         "pyipm_mfma_f64_peak": (c_int, [c_int, c_int, POINTER(c_double)]),
+        # distributed driver (dist_impl.hpp)
+        "pyipm_newton_set_exchange": (c_int, [ctxp, c_void_p, c_void_p, c_void_p]),
+        "pyipm_newton_rccl_library": (c_int, [c_char_p]),
+        "pyipm_newton_comm_unique_id": (c_int, [c_void_p]),
+        "pyipm_newton_comm_init": (c_int, [ctxp, c_void_p]),
+        "pyipm_newton_owned_rows": (c_int64, [ctxp, POINTER(c_int64)]),
+        "pyipm_newton_stage_blocks_owned": (c_int, [ctxp, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int]),
+        "pyipm_newton_residual_dist": (c_int, [ctxp, c_void_p, c_int]),
+        "pyipm_newton_factor_dist": (c_int, [ctxp, POINTER(FactorStats)]),
+        "pyipm_newton_solve_dist": (c_int, [ctxp, c_void_p, c_void_p, c_int, c_int, c_int]),
+        "pyipm_newton_kkt_matvec_dist": (c_int, [ctxp, c_void_p, c_void_p, c_int]),
+        "pyipm_newton_step_dist": (c_int, [ctxp, c_double, c_double, c_int, c_void_p, POINTER(FactorStats), c_int]),
+        "pyipm_newton_dist_timings": (c_int, [ctxp, POINTER(c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
@@ -128,6 +141,17 @@ def mfma_f64_peak(device: int = 0, iters: int = 20000) -> float:
     if rc:
         raise NewtonError("pyipm_mfma_f64_peak failed: %s" % ERRORS.get(rc, rc))
     return out.value
+
+
+BCAST_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p)
+
+
+class _RawDeviceArray(object):
+    """fp64 device memory at a raw address, as torch.as_tensor understands it."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": (int(count),), "typestr": "<f8", "version": 2}
 
 
 class NewtonCore(object):
@@ -358,6 +382,79 @@ class NewtonCore(object):
 
     def bwd_panel(self, p, v):
         self._ck(self.lib.pyipm_newton_bwd_panel(self.h, int(p), self._ptr(v)))
+
+    # -- distributed driver (the per-panel schedule runs inside the library; pyipm_amd.dist binds the exchange) -----
+    residual_is_partial = property(lambda self: self.world > 1)     # residual() of one rank of several: its share only
+
+    def owned_rows(self):
+        """Global indices of the block rows this rank works on (the x-columns it owns), in staging order."""
+        n = int(self.lib.pyipm_newton_owned_rows(self.h, None))
+        out = (c_int64 * max(n, 1))()
+        self.lib.pyipm_newton_owned_rows(self.h, out)
+        return np.array(out[:n], dtype=np.int64)
+
+    def stage_blocks_owned(self, d2L_rows, Je_rows=None, Ji_rows=None):
+        """Row-sharded staging: only ``owned_rows()`` of d2L (.., n), Je (.., me), Ji (.., mi)."""
+        self._use_current_stream()
+        n, me, mi = self.n, self.me, self.mi
+        r = len(self.owned_rows())
+        d2L = self._dev(d2L_rows, (r, n))
+        Je = self._dev(Je_rows, (r, me)) if me else None
+        Ji = self._dev(Ji_rows, (r, mi)) if mi else None
+        self._keep.update(d2L=d2L, Je=Je, Ji=Ji)
+        self._ck(self.lib.pyipm_newton_stage_blocks_owned(self.h, self._ptr(d2L), n, self._ptr(Je), max(me, 1),
+                                                          self._ptr(Ji), max(mi, 1), MEM_DEVICE))
+
+    def set_exchange(self, bcast_cb, allreduce_cb):
+        """ctypes callbacks (BCAST_FN / ALLREDUCE_FN); kept alive with the handle."""
+        self._cbs = (bcast_cb, allreduce_cb)
+        self._ck(self.lib.pyipm_newton_set_exchange(self.h, ctypes.cast(bcast_cb, c_void_p), ctypes.cast(allreduce_cb, c_void_p), None))
+
+    def comm_init(self, id128):
+        buf = (ctypes.c_char * 128).from_buffer_copy(bytes(id128))
+        self._ck(self.lib.pyipm_newton_comm_init(self.h, ctypes.cast(buf, c_void_p)))
+
+    def residual_dist(self):
+        self._use_current_stream()
+        g = self.torch.empty(self.N, dtype=self.torch.float64, device=self.device)
+        self._ck(self.lib.pyipm_newton_residual_dist(self.h, self._ptr(g), MEM_DEVICE))
+        return g
+
+    def factor_dist(self):
+        self._use_current_stream()
+        st = FactorStats()
+        rc = self.lib.pyipm_newton_factor_dist(self.h, ctypes.byref(st))
+        self._ck(rc, st.as_dict())
+        return st.as_dict()
+
+    def solve_dist(self, rhs=None, flip=True, refine=0):
+        self._use_current_stream()
+        dz = self.torch.empty(self.N, dtype=self.torch.float64, device=self.device)
+        r = None if rhs is None else self._dev(rhs, (self.N,))
+        self._ck(self.lib.pyipm_newton_solve_dist(self.h, self._ptr(r), self._ptr(dz), int(bool(flip)), int(refine), MEM_DEVICE))
+        return dz
+
+    def matvec_dist(self, v):
+        self._use_current_stream()
+        v = self._dev(v, (self.N,))
+        y = self.torch.empty(self.N, dtype=self.torch.float64, device=self.device)
+        self._ck(self.lib.pyipm_newton_kkt_matvec_dist(self.h, self._ptr(v), self._ptr(y), MEM_DEVICE))
+        return y
+
+    def step_dist(self, delta=0.0, delta_c=0.0, refine=0):
+        self._use_current_stream()
+        dz = self.torch.empty(self.N, dtype=self.torch.float64, device=self.device)
+        st = FactorStats()
+        rc = self.lib.pyipm_newton_step_dist(self.h, float(delta), float(delta_c), int(refine), self._ptr(dz),
+                                             ctypes.byref(st), MEM_DEVICE)
+        self._ck(rc, st.as_dict())
+        return dz, st.as_dict()
+
+    def dist_timings(self):
+        t = (c_double * 8)()
+        self._ck(self.lib.pyipm_newton_dist_timings(self.h, t))
+        return {"factor_ms": t[0], "chain_ms": t[1], "pack_ms": t[2], "bcast_ms": t[3], "unpack_ms": t[4], "solve_ms": t[5],
+                "bytes": int(t[6]), "messages": int(t[7])}
 
     # -- introspection ---------------------------------------------------------------------------
     def kkt_storage(self):

@@ -1,7 +1,9 @@
-"""GPU tests of the distributed per-panel HIP path.  The GPU box has ONE device, so world_size-2/3
-runs put every rank on cuda:0 and ride a gloo group with host staging (RCCL refuses duplicate
-devices); the HIP kernels, block-cyclic column maps, pack/unpack messages and the non-owner
-L-rebuild are exactly what the multi-GPU bench uses."""
+"""GPU tests of the distributed HIP path.  The GPU box has ONE device, so world_size-2/3 runs put every rank on
+cuda:0 and ride a gloo group with host staging (RCCL refuses duplicate devices).  What runs is what the multi-GPU
+bench runs: the library's own per-panel driver (pyipm_newton_step_dist: lookahead schedule, pack / unpack messages,
+the non-owner rebuild of L, segment sums and broadcasts of the sweeps) with the exchange bound to callbacks, the
+row-sharded staging, refinement across the ranks -- and, for comparison, the Python loop over the per-panel phases.
+A handle-owned RCCL communicator is exercised for real with a world of one rank."""
 import os
 import socket
 
@@ -22,7 +24,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, shape, nb, lookahead, out):
+def _worker(rank, world, port, shape, nb, mode, out):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -34,57 +36,98 @@ def _worker(rank, world, port, shape, nb, lookahead, out):
         n, me, mi, seed = shape
         qp = make_qp(n, me, mi, seed)
         core = NewtonCore(n, me, mi, device=0, nb=nb, world=world, rank=rank)
-        core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+        if mode == "native-sharded":                     # a rank stages only the rows of the x-columns it owns
+            rows = core.owned_rows()
+            core.stage_blocks_owned(qp["d2L"][rows], qp["Je"][rows] if me else None, qp["Ji"][rows] if mi else None)
+        else:
+            core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
         core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
-        drv = DistNewton(core)
-        drv.lookahead = lookahead
+        drv = DistNewton(core, native=mode.startswith("native"))
+        drv.lookahead = mode != "python-lockstep"
+        g = drv.residual().cpu().numpy()
         dz, st = drv.step(0.0, 0.0)
+        extra = {}
+        if mode.startswith("native"):
+            raw = dz.clone()
+            raw[n + mi:] *= -1.0
+            y = core.matvec_dist(raw)                     # Hc dz from the ranks' blocks, summed over the ranks
+            extra["berr"] = float((y.cpu() - torch.from_numpy(g)).norm() / np.linalg.norm(g))
+            dz_ref = core.solve_dist(flip=True, refine=-1)
+            extra["info"] = core.solve_info()
+            extra["refined_diff"] = float((dz_ref - dz).norm() / dz.norm())
+            extra["timings"] = core.dist_timings()
         torch.cuda.synchronize()
-        out[rank] = (dz.cpu().numpy(), st, core.ncols_local, drv.bytes_broadcast)
+        out[rank] = (dz.cpu().numpy(), st, core.ncols_local, drv.bytes_broadcast, g, extra)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lookahead", [False, True])
+def _factor_bytes(n, me, mi, nb):
+    """One message per panel that has rows below it, EXCEPT panels inside the slack block (every rank derives their
+    contribution from s / lambda locally); a panel inside the x block leaves the whole 128-row tiles of slack rows home."""
+    N = n + 2 * mi + me
+    Npad = ((N + 127) // 128) * 128
+    fact = 0
+    for p in range((Npad + nb - 1) // nb):
+        c0 = p * nb
+        w = min(nb, Npad - c0)
+        m = Npad - (c0 + w)
+        in_s = c0 >= n and c0 + w <= n + mi
+        if c0 + w <= n and mi:
+            m -= max(0, (n + mi) // 128 * 128 - (n + 127) // 128 * 128)
+        if m > 0 and not in_s:
+            fact += 8 * (m * w + 2 * (w // 64) * 4096 + w // 64)
+    return fact, Npad
+
+
+@pytest.mark.parametrize("mode", ["native", "native-sharded", "python-lockstep", "python-lookahead"])
 @pytest.mark.parametrize("world,shape,nb", [(2, (300, 100, 150, 7), 128), (2, (900, 200, 300, 8), 256),
                                             (3, (700, 150, 260, 9), 128), (2, (1400, 0, 400, 10), 128)])
-def test_two_ranks_one_gpu(world, shape, nb, lookahead):
+def test_ranks_sharing_one_gpu(world, shape, nb, mode):
     import torch.multiprocessing as mp
     n, me, mi, seed = shape
     N = n + 2 * mi + me
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), shape, nb, lookahead, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), shape, nb, mode, out), nprocs=world, join=True)
     qp = make_qp(n, me, mi, seed)
-    ref, _, _, _ = orc.newton_step(qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"],
-                                   qp["mu"], n, me, mi, regularise=False)
+    ref, _, _, gref = orc.newton_step(qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"],
+                                      qp["mu"], n, me, mi, regularise=False)
     cols = 0
     for r in range(world):
-        dz, st, ncl, _ = out[r]
+        dz, st, ncl, _, g, extra = out[r]
+        np.testing.assert_allclose(g, gref, rtol=0, atol=1e-13 * np.abs(gref).max())      # the ranks' shares, summed
         assert np.linalg.norm(dz - ref) / np.linalg.norm(ref) <= 1e-10
         assert st["n_neg"] == me + mi and st["n_zero"] == 0 and st["n_pos"] == N - me - mi
         cols += ncl
-    assert cols == ((N + 127) // 128) * 128
-    assert np.array_equal(out[0][0], out[1][0])          # every rank ends with the same direction, bit for bit
-    # wire traffic of the factorisation: one message per panel that has rows below it, EXCEPT panels inside the slack
-    # block (every rank derives their contribution from s / lambda locally); the substitutions add 8 bytes per entry
-    Npad = ((N + 127) // 128) * 128
-    fact = 0
-    for p in range(Npad // nb + (1 if Npad % nb else 0)):
-        c0 = p * nb
-        w = min(nb, Npad - c0)
-        m = Npad - (c0 + w)
-        in_s = c0 >= n and c0 + w <= n + mi
-        if c0 + w <= n and mi:                               # panel inside the x block: whole 128-row tiles of slack rows stay home
-            m -= max(0, (n + mi) // 128 * 128 - (n + 127) // 128 * 128)
-        if m > 0 and not in_s:
-            fact += 8 * (m * w + 2 * (w // 64) * 4096 + w // 64)
-    solve = 8 * sum((Npad - p * nb) + min(nb, Npad - p * nb) for p in range((Npad + nb - 1) // nb))
-    assert out[0][3] == fact + solve
+        if extra:
+            assert extra["berr"] <= 1e-12
+            assert extra["info"]["backward_error"] <= 1e-13 and extra["refined_diff"] <= 1e-10
+    fact, Npad = _factor_bytes(n, me, mi, nb)
+    assert cols == Npad
+    for r in range(1, world):
+        assert np.array_equal(out[0][0], out[r][0])      # every rank ends with the same direction, bit for bit
+    if mode.startswith("native"):
+        assert out[0][5]["timings"]["bytes"] == fact     # bytes of the factorisation's panel messages
+    else:
+        # the Python driver counts the sweeps too: nb numbers summed per panel forward, nb broadcast backward
+        assert out[0][3] == fact + 16 * Npad
+
+
+def test_native_and_python_drivers_agree_bitwise():
+    """Same kernels in the same order on every column: the direction does not depend on who drives the schedule."""
+    import torch.multiprocessing as mp
+    shape, nb, world = (900, 200, 300, 8), 256, 2
+    res = {}
+    for mode in ("native", "python-lookahead"):
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), shape, nb, mode, out), nprocs=world, join=True)
+        res[mode] = out[0][0]
+    assert np.array_equal(res["native"], res["python-lookahead"])
 
 
 def test_dist_driver_world1_matches_fused_step():
-    import torch
     from pyipm_amd.newton import NewtonCore
     from pyipm_amd.dist import DistNewton
     n, me, mi = 700, 200, 300
@@ -93,12 +136,20 @@ def test_dist_driver_world1_matches_fused_step():
     core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
     core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
     dz0, st0 = core.step(0.0, 0.0)
-    dz1, st1 = DistNewton(core).step(0.0, 0.0)
-    assert st0["n_neg"] == st1["n_neg"] == me + mi
-    assert float((dz0 - dz1).norm() / dz0.norm()) <= 1e-12
+    for native in (True, False):
+        dz1, st1 = DistNewton(core, native=native).step(0.0, 0.0)
+        assert st0["n_neg"] == st1["n_neg"] == me + mi
+        assert float((dz0 - dz1).norm() / dz0.norm()) <= 1e-12
+    core.set_option("dist_selfmsg", 1)                   # one rank, but every panel is packed and "sent"
+    core.set_option("profile", 1)
+    dz2, st2 = core.step_dist(0.0, 0.0)
+    tm = core.dist_timings()
+    fact, _ = _factor_bytes(n, me, mi, 256)
+    assert tm["bytes"] == fact and tm["messages"] > 0 and tm["pack_ms"] > 0.0 and tm["chain_ms"] > 0.0
+    assert float((dz0 - dz2).norm() / dz0.norm()) <= 1e-12
 
 
-def _nccl_worker(rank, port, shape, nb, out):
+def _rccl_worker(rank, port, shape, nb, out):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -106,33 +157,41 @@ def _nccl_worker(rank, port, shape, nb, out):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
+        import ctypes
         from pyipm_amd.newton import NewtonCore
-        from pyipm_amd.dist import DistNewton
         n, me, mi, seed = shape
         qp = make_qp(n, me, mi, seed)
         core = NewtonCore(n, me, mi, device=0, nb=nb)
         core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
         core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
         dz0, st0 = core.step(0.0, 0.0)
-        drv = DistNewton(core)
-        drv.force_lookahead = True          # overlapped schedule: side stream + asynchronous RCCL broadcasts
-        dz1, st1 = drv.step(0.0, 0.0)
-        dz2, st2 = drv.step(0.0, 0.0)       # buffers / streams reused on the second call
+        # handle-owned communicator: id from the library, communicator of one rank, every panel message
+        # really goes through ncclBroadcast on the collective stream, the statistics through ncclAllReduce
+        lib = core.lib
+        lib.pyipm_newton_rccl_library(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode())
+        idbuf = (ctypes.c_char * 128)()
+        assert lib.pyipm_newton_comm_unique_id(ctypes.cast(idbuf, ctypes.c_void_p)) == 0
+        core.comm_init(bytes(idbuf))
+        core.set_option("dist_selfmsg", 1)
+        core.set_option("profile", 1)
+        dz1, st1 = core.step_dist(0.0, 0.0)
+        dz2, st2 = core.step_dist(0.0, 0.0)             # buffers / streams / events reused on the second call
+        tm = core.dist_timings()
         torch.cuda.synchronize()
-        out[0] = (float((dz0 - dz1).norm() / dz0.norm()), float((dz1 - dz2).norm()), st1["n_neg"], drv.bytes_broadcast,
-                  dist.get_backend())
+        out[0] = (float((dz0 - dz1).norm() / dz0.norm()), float((dz1 - dz2).norm()), st1["n_neg"], tm, dist.get_backend())
     finally:
         dist.destroy_process_group()
 
 
-def test_overlapped_schedule_on_rccl_single_rank():
-    """The multi-GPU bench path (RCCL process group, asynchronous per-panel broadcast, owner factoring on a
-    side stream) run for real on the one GPU this box has: a world of one rank owns every panel."""
+def test_handle_owned_rccl_communicator_single_rank():
+    """The multi-GPU bench path -- RCCL communicator owned by the handle, asynchronous per-panel broadcasts on the
+    collective stream, owner factoring on the side stream -- run for real on the one GPU this box has."""
     import torch.multiprocessing as mp
     shape, nb = (900, 200, 300, 8), 256
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_nccl_worker, args=(_free_port(), shape, nb, out), nprocs=1, join=True)
-    err, rep, n_neg, nbytes, backend = out[0]
+    mp.spawn(_rccl_worker, args=(_free_port(), shape, nb, out), nprocs=1, join=True)
+    err, rep, n_neg, tm, backend = out[0]
     assert backend == "nccl"
-    assert err <= 1e-12 and rep == 0.0 and n_neg == shape[1] + shape[2] and nbytes > 0
+    assert err <= 1e-12 and rep == 0.0 and n_neg == shape[1] + shape[2]
+    assert tm["bytes"] == _factor_bytes(shape[0], shape[1], shape[2], nb)[0] and tm["bcast_ms"] > 0.0

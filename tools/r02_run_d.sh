@@ -1,0 +1,25 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r02d; mkdir -p $O
+( timeout 2400 python -m pytest tests -m gpu -q --durations=8 > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log )
+tail -22 $O/pytest.log
+B="timeout 600 python bench.py --no-cpu-baseline --steps 5 --warmup 2"
+$B > $O/bench_base.json 2> $O/bench_base.err
+$B --opt bwd_fused=0 > $O/bench_bwd0.json 2> $O/bench_bwd0.err
+$B --force-dist > $O/bench_fdist_native.json 2> $O/bench_fdist_native.err
+$B --force-dist --selfmsg > $O/bench_fdist_native_selfmsg.json 2> $O/bench_fdist_native_selfmsg.err
+$B --force-dist --python-driver --force-lookahead > $O/bench_fdist_python.json 2> $O/bench_fdist_python.err
+$B --force-dist --nb 512 > $O/bench_fdist_native_nb512.json 2> $O/bench_fdist_native_nb512.err
+C2="--nvar 2048 --neq 0 --nineq 2048 --steps 20 --warmup 3"
+$B $C2 > $O/cfg2_base.json 2> $O/cfg2_base.err
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r02d/*.json")):
+    try:
+        d = json.load(open(f)); p = d["phases_ms_per_step"]
+        print(f.split("/")[-1], "%.2f ms" % d["ms_per_step"], "upd %.1f TF/s" % d["roofline"]["achieved"],
+              "panel %.2f trailing %.2f solve %.2f asm %.2f" % (p["panel(tile+scale+in-panel)"], p["trailing"], p["solve"], p["assemble"]),
+              "berr", d.get("backward_error"), d.get("dist_phases_per_step"))
+    except Exception as e:
+        print(f, "FAILED", e, open(f.replace(".json", ".err")).read()[-600:])
+PY
