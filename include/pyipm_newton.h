@@ -165,6 +165,18 @@ int pyipm_newton_kkt_matvec(pyipm_newton_ctx* ctx, const double* v, double* y, i
 int pyipm_newton_step(pyipm_newton_ctx* ctx, double delta, double delta_c, int refine,
                       double* dz, pyipm_factor_stats* stats, int memkind);
 
+/* SURVEY.md section 8(f) rank 3 -- the derivative provider of the QP family on the device.  For
+ *   min 1/2 x'Qx + c'x  s.t.  Ax = b,  Gx - h >= 0
+ * the reference's compiled provider functions (pyipm.py:855-954: df, ce, ci; the J lambda terms of self.grad,
+ * :655-668) are products with the constant blocks stage_blocks already holds: d2L = Q (UPPER triangle read, as
+ * everywhere), Je = A', Ji = G'.  All pointers DEVICE memory; any output may be NULL.
+ *   block_products   : Qv = sym(triu(d2L)) v (n),  JeTv = Je' v (me),  JiTv = Ji' v (mi)     -- df, ce, ci, merit ray
+ *   block_products_t : out = Je le + Ji li (n; le / li may be NULL)                           -- dL/dx
+ *   provider_stats   : ms ("profile" = 1) and block bytes of the last call of each */
+int pyipm_newton_block_products(pyipm_newton_ctx* ctx, const double* v, double* Qv, double* JeTv, double* JiTv);
+int pyipm_newton_block_products_t(pyipm_newton_ctx* ctx, const double* le, const double* li, double* out);
+int pyipm_newton_provider_stats(pyipm_newton_ctx* ctx, double out[4]);
+
 /* SURVEY.md section 8(f) rank 1 — replaces the two IPM.step calls of the inner loop (pyipm.py:1408-1436,
  * 1737-1742): the largest alpha in [0,1] with v + alpha*dv >= (1-tau)*v, for v = s (dv = ds) and
  * v = lda_i (dv = dlda_i), from the staged s / lda and the direction of the last solve()/step() kept on

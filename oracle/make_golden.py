@@ -428,8 +428,35 @@ def main_pivot():
     assert out["delta_out"] > 0.0
 
 
+def main_qp_trace():
+    """tests/golden/qptrace_*.npz: the UNMODIFIED reference solving synthetic QPs end to end through its provider
+    contract (pyipm.py:855-954: f, df, ce, ci, the Jacobians as compiled functions), every iterate at the Newton-step
+    seam recorded -- what the device-resident QP loop (pyipm_amd/qp.py) has to retrace."""
+    os.makedirs(GOLD, exist_ok=True)
+    for (n, me, mi, seed, ktol) in [(40, 10, 24, 11, 1.0e-6), (64, 0, 48, 12, 1.0e-6), (48, 16, 0, 13, 1.0e-8)]:
+        qp = make_qp(n, me, mi, seed)
+        prob = qp_callables(qp)
+        p = build(prob, np.zeros(n), Ktol=ktol, verbosity=-1)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            x, s, lda, fval, kkt = p.solve()
+        d = {"n_iter": np.int64(len(p.trace)), "n": np.int64(n), "me": np.int64(me), "mi": np.int64(mi),
+             "seed": np.int64(seed), "Ktol": np.float64(ktol)}
+        for k in ("x", "s", "lda", "g", "dz_raw"):
+            d["it_" + k] = np.stack([t[k] for t in p.trace])
+        for k in ("mu", "mu_host", "delta_in", "delta_out"):
+            d["it_" + k] = np.array([t[k] for t in p.trace])
+        d.update(x=x, s=s, lda=lda, fval=np.float64(fval), signal=np.int64(p.signal))
+        for i, kk in enumerate(kkt):
+            d["kkt%d" % (i + 1)] = np.atleast_1d(np.array(kk, dtype=np.float64))
+        np.savez_compressed(os.path.join(GOLD, "qptrace_n%d_me%d_mi%d_s%d.npz" % (n, me, mi, seed)), **d)
+        print("qp trace n=%d me=%d mi=%d: %d Newton steps, signal %d, f = %.10g" % (n, me, mi, len(p.trace), p.signal, fval))
+
+
 if __name__ == "__main__":
-    if "--pivot" in sys.argv[1:]:
+    if "--qp-trace" in sys.argv[1:]:
+        main_qp_trace()
+    elif "--pivot" in sys.argv[1:]:
         main_pivot()
     elif "--lbfgs" in sys.argv[1:]:
         main_lbfgs()

@@ -165,6 +165,7 @@ struct Ctx {
     double trailing_flops = 0, trailing_area = 0; int64_t n_trailing = 0;   // area: matrix entries updated, summed over launches
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_trailing;   // reused event pool
     hipEvent_t ev[8] = {};
+    hipEvent_t ev_prov[4] = {}; bool prov_valid[2] = {false, false}; double prov_bytes[2] = {0.0, 0.0};   // provider products
     bool ev_assemble_valid = false, ev_solve_valid = false;
     int debug_fault = 0;                  // test hook: 1 / 2 = the next tile-list build throws std::bad_alloc / std::runtime_error
     std::string err;

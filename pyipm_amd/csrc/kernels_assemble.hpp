@@ -127,7 +127,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // y[j] (op)= sum_a M[j*ldm + a] * x[a]   for a in [0, ncol); one wave per row j.
 // Two matrices are fused so that K2 needs one pass.  mode: 0 -> out = base[j] - acc (then negated
-// if neg), used by the residual;  1 -> out[j] += acc.
+// if neg), used by the residual;  1 -> out[j] += acc;  2 -> out[j] = acc.
 __global__ __launch_bounds__(256) void k_rowdot2(
     double* __restrict__ out, const double* __restrict__ base, int64_t nrow,
     const double* __restrict__ M1, int64_t ld1, const double* __restrict__ x1, int64_t nc1,
@@ -151,8 +151,9 @@ __global__ __launch_bounds__(256) void k_rowdot2(
     }
     acc = wave_sum(acc);
     if (lane == 0) {
-        if (mode == 0) { double v = base[j] - acc; out[j] = neg ? -v : v; }
-        else           { out[j] += acc; }
+        if (mode == 0)      { double v = base[j] - acc; out[j] = neg ? -v : v; }
+        else if (mode == 1) { out[j] += acc; }
+        else                { out[j] = acc; }                 // mode 2: the plain product
     }
 }
 

@@ -254,7 +254,8 @@ __global__ __launch_bounds__(1024) void k_bwd_apply(const double* __restrict__ M
         ys[j] = v[c0 + j] - t;
     }
     __syncthreads();
-    const int parts = 1024 / nbw;                            // nbw in {64, 128, ..., 1024}: 16 ... 1 parts
+    int parts = 1024 / nbw;                                  // nbw in {128, 256, ..., 1024}
+    if (parts > nbw / 32) parts = nbw / 32;                  // a part is a whole number of 32-row load groups
     const int j = tid % nbw, pt = tid / nbw;
     double a = 0.0;
     if (pt < parts) {

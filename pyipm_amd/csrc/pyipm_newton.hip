@@ -9,7 +9,18 @@
 
 using namespace pyipm;
 
-#define PYIPM_SETERR_NEWTON(msg_) set_err_noexcept(reinterpret_cast<Ctx*>(h), (msg_))
+// An exception unwinds out of the middle of a schedule: kernels may still be running on the helper streams against
+// storage the next call will overwrite.  Drain them and drop the half-done state before reporting.
+static void quiesce_noexcept(Ctx* c) noexcept {
+    if (!c) return;
+    try {
+        if (c->side) hipStreamSynchronize(c->side);
+        if (c->fwd) hipStreamSynchronize(c->fwd);
+        if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
+        c->factored = false; c->forward_pending = false; c->forward_fused = false; c->minv_valid = false;
+    } catch (...) {}
+}
+#define PYIPM_SETERR_NEWTON(msg_) (quiesce_noexcept(reinterpret_cast<Ctx*>(h)), set_err_noexcept(reinterpret_cast<Ctx*>(h), (msg_)))
 #define PYIPM_CATCH_H(h_)  PYIPM_CATCH_CORE(PYIPM_SETERR_NEWTON, PYIPM_E_NOMEM, PYIPM_E_HIP)
 
 namespace {
@@ -1042,6 +1053,7 @@ int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t m
     carve_workspace(ctx, ctx->g, ctx->ws);
     if (hipMemset(ctx->anorm, 0, sizeof(unsigned long long)) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
+    for (int i = 0; i < 4; ++i) if (hipEventCreate(&ctx->ev_prov[i]) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     if (hipEventCreateWithFlags(&ctx->ev_fwd, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_head, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_panel, hipEventDisableTiming) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
@@ -1159,6 +1171,7 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 8; ++i) if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 4; ++i) if (ctx->ev_prov[i]) hipEventDestroy(ctx->ev_prov[i]);
     for (auto& pr : ctx->ev_trailing) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     if (ctx->ev_head) hipEventDestroy(ctx->ev_head);
     if (ctx->ev_panel) hipEventDestroy(ctx->ev_panel);
@@ -1428,6 +1441,87 @@ int pyipm_newton_rcond(pyipm_newton_ctx* h, int it_inv, int it_pow, double out[4
 int pyipm_newton_anorm(pyipm_newton_ctx* h, double** dev_ptr) try {
     if (check_ctx(h) || !dev_ptr) return PYIPM_E_BADARG;
     *dev_ptr = reinterpret_cast<double*>(C(h)->anorm);        // bits of a non-negative double ARE that double
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+// ---- QP family: the derivative provider's products on the device ------------------------------
+// The reference evaluates df = Q x + c, ce = A x - b, ci = G x - h and the Jacobian-transpose products of the KKT report
+// through compiled Aesara functions on the host (pyipm.py:855-954).  For a QP the blocks are constant and already staged,
+// so these are passes over the staged d2L (its UPPER triangle, as everywhere), Je and Ji.
+int pyipm_newton_block_products(pyipm_newton_ctx* h, const double* v, double* Qv, double* JeTv, double* JiTv) try {
+    if (check_ctx(h) || !v) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    if (g.world != 1 || ctx->sharded) { ctx->err = "block_products: single-rank handles with fully staged blocks"; return PYIPM_E_BADARG; }
+    if (!ctx->have_blocks) { ctx->err = "block_products: stage blocks first"; return PYIPM_E_BADARG; }
+    const RowMap rm = make_rowmap(g, 0);
+    const int64_t n = g.n, me = g.me, mi = g.mi;
+    const int nchunk = 64;
+    const int64_t rpc = (n + nchunk - 1) / nchunk;
+    if (ctx->profile) PYIPM_HIP(hipEventRecord(ctx->ev_prov[0], ctx->stream));
+    double bytes = 0.0;
+    if (Qv) {            // sym(triu(d2L)) v: row part + mirrored strict upper part, each one pass over the upper triangle
+        hipLaunchKernelGGL(k_symv_row, grid1(n, 4), dim3(256), 0, ctx->stream, Qv, ctx->d2L, ctx->ld_d2L, n, v, 0.0, rm);
+        PYIPM_KCHECK();
+        hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((n + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
+                           ctx->partial, ctx->d2L, ctx->ld_d2L, n, n, v, rpc, 1, rm);
+        PYIPM_KCHECK();
+        hipLaunchKernelGGL(k_coldot_reduce, grid1(n), dim3(256), 0, ctx->stream, Qv, ctx->partial, n, nchunk, 1);
+        PYIPM_KCHECK();
+        bytes += 8.0 * (double)n * (double)n;
+    }
+    if (JeTv && me > 0) {
+        hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((me + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
+                           ctx->partial, ctx->Je, ctx->ld_Je, n, me, v, rpc, 0, rm);
+        PYIPM_KCHECK();
+        hipLaunchKernelGGL(k_coldot_reduce, grid1(me), dim3(256), 0, ctx->stream, JeTv, ctx->partial, me, nchunk, 0);
+        PYIPM_KCHECK();
+        bytes += 8.0 * (double)n * (double)me;
+    }
+    if (JiTv && mi > 0) {
+        hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((mi + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
+                           ctx->partial, ctx->Ji, ctx->ld_Ji, n, mi, v, rpc, 0, rm);
+        PYIPM_KCHECK();
+        hipLaunchKernelGGL(k_coldot_reduce, grid1(mi), dim3(256), 0, ctx->stream, JiTv, ctx->partial, mi, nchunk, 0);
+        PYIPM_KCHECK();
+        bytes += 8.0 * (double)n * (double)mi;
+    }
+    if (ctx->profile) { PYIPM_HIP(hipEventRecord(ctx->ev_prov[1], ctx->stream)); ctx->prov_valid[0] = true; }
+    ctx->prov_bytes[0] = bytes;
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+// out (n) = Je le + Ji li  (either may be NULL): the Jacobian terms of dL/dx (pyipm.py:655-668)
+int pyipm_newton_block_products_t(pyipm_newton_ctx* h, const double* le, const double* li, double* out) try {
+    if (check_ctx(h) || !out) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    if (g.world != 1 || ctx->sharded) { ctx->err = "block_products_t: single-rank handles with fully staged blocks"; return PYIPM_E_BADARG; }
+    if (!ctx->have_blocks) { ctx->err = "block_products_t: stage blocks first"; return PYIPM_E_BADARG; }
+    const int64_t me = le ? g.me : 0, mi = li ? g.mi : 0;
+    if (ctx->profile) PYIPM_HIP(hipEventRecord(ctx->ev_prov[2], ctx->stream));
+    hipLaunchKernelGGL(k_rowdot2, grid1(g.n, 4), dim3(256), 0, ctx->stream, out, (const double*)nullptr, g.n,
+                       ctx->Je, ctx->ld_Je, le, me, ctx->Ji, ctx->ld_Ji, li, mi, 2, 0, make_rowmap(g, 0));
+    PYIPM_KCHECK();
+    if (ctx->profile) { PYIPM_HIP(hipEventRecord(ctx->ev_prov[3], ctx->stream)); ctx->prov_valid[1] = true; }
+    ctx->prov_bytes[1] = 8.0 * (double)g.n * (double)(me + mi);
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+// out[0] = ms of the last block_products call ("profile" = 1), out[1] = the bytes of the blocks it passed over,
+// out[2], out[3] = the same for block_products_t
+int pyipm_newton_provider_stats(pyipm_newton_ctx* h, double out[4]) try {
+    if (check_ctx(h) || !out) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 2; ++k) {
+        float ms = 0.f;
+        if (ctx->prov_valid[k]) PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev_prov[2 * k], ctx->ev_prov[2 * k + 1]));
+        out[2 * k] = ms; out[2 * k + 1] = ctx->prov_bytes[k];
+    }
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)
 

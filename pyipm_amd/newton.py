@@ -105,6 +105,9 @@ def load_library(path: str | None = None):
                                                       c_void_p, c_int64, c_int64]),
         "pyipm_newton_step_batched": (c_int, [ctxp, c_double, c_double, c_void_p, POINTER(FactorStats), c_int]),
         "pyipm_mfma_f64_peak": (c_int, [c_int, c_int, POINTER(c_double)]),
+        "pyipm_newton_block_products": (c_int, [ctxp, c_void_p, c_void_p, c_void_p, c_void_p]),
+        "pyipm_newton_block_products_t": (c_int, [ctxp, c_void_p, c_void_p, c_void_p]),
+        "pyipm_newton_provider_stats": (c_int, [ctxp, POINTER(c_double)]),
         # distributed driver (dist_impl.hpp)
         "pyipm_newton_set_exchange": (c_int, [ctxp, c_void_p, c_void_p, c_void_p]),
         "pyipm_newton_rccl_library": (c_int, [c_char_p]),
@@ -382,6 +385,32 @@ class NewtonCore(object):
 
     def bwd_panel(self, p, v):
         self._ck(self.lib.pyipm_newton_bwd_panel(self.h, int(p), self._ptr(v)))
+
+    # -- QP provider products on the staged blocks ------------------------------
+    def block_products(self, v, want=(True, True, True)):
+        """(Q v, Je' v, Ji' v) for a device vector v (n); entries not wanted (or of an empty block) are None."""
+        self._use_current_stream()
+        t = self.torch
+        v = self._dev(v, (self.n,))
+        mk = lambda k, on: t.empty(k, dtype=t.float64, device=self.device) if (on and k) else None    # noqa: E731
+        q, e, i = mk(self.n, want[0]), mk(self.me, want[1]), mk(self.mi, want[2])
+        self._ck(self.lib.pyipm_newton_block_products(self.h, self._ptr(v), self._ptr(q), self._ptr(e), self._ptr(i)))
+        return q, e, i
+
+    def block_products_t(self, le=None, li=None):
+        """Je le + Ji li (n)."""
+        self._use_current_stream()
+        t = self.torch
+        le = self._dev(le, (self.me,)) if (le is not None and self.me) else None
+        li = self._dev(li, (self.mi,)) if (li is not None and self.mi) else None
+        out = t.empty(self.n, dtype=t.float64, device=self.device)
+        self._ck(self.lib.pyipm_newton_block_products_t(self.h, self._ptr(le), self._ptr(li), self._ptr(out)))
+        return out
+
+    def provider_stats(self):
+        o = (c_double * 4)()
+        self._ck(self.lib.pyipm_newton_provider_stats(self.h, o))
+        return {"products_ms": o[0], "products_bytes": o[1], "products_t_ms": o[2], "products_t_bytes": o[3]}
 
     # -- distributed driver (the per-panel schedule runs inside the library; pyipm_amd.dist binds the exchange) -----
     residual_is_partial = property(lambda self: self.world > 1)     # residual() of one rank of several: its share only

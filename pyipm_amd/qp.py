@@ -17,7 +17,10 @@ barrier update, ``:958-991`` KKT report) with the provider and the iterate livin
   evaluations for one rejected step.  Along the ray the QP's merit function is a closed form in alpha (f quadratic,
   constraints affine), so a trial costs O(me + mi) after three GEMVs per iteration instead of a pass over Q, A, G.
 
-PyTorch supplies the device vectors and the GEMVs of the provider (plumbing); the Newton step
+PyTorch supplies the device vectors (plumbing).  The provider's products with the constant blocks -- Q x, A x,
+G x and the Jacobian terms of dL/dx, the counterpart of the reference's compiled ``df / ce / ci / grad`` functions
+(``pyipm.py:855-954``) -- are the library's own kernels on the blocks the Newton core already holds
+(``pyipm_newton_block_products`` / ``_t``: one call gives all three products of a vector), the Newton step
 itself is the HIP library.  No CPU fallback: constructing the solver without a GPU raises.
 
 ``lbfgs=m`` runs the reference's limited-memory mode (``pyipm.py:1633-1637, 1702-1713``) with the storage
@@ -62,8 +65,6 @@ class QPDeviceIPM(object):
         # Jacobians in the reference's layout: Je = dce (n x me), Ji = dci (n x mi)  (pyipm.py:486-501)
         self.Je = dv(Je).contiguous() if Je is not None else (dv(A).t().contiguous() if A is not None else None)
         self.Ji = dv(Ji).contiguous() if Ji is not None else (dv(G).t().contiguous() if G is not None else None)
-        self.JeT = self.Je.t().contiguous() if self.Je is not None else None
-        self.JiT = self.Ji.t().contiguous() if self.Ji is not None else None
         self.b, self.h = dv(b), dv(h)
         me = self.neq = 0 if self.Je is None else int(self.Je.shape[1])
         mi = self.nineq = 0 if self.Ji is None else int(self.Ji.shape[1])
@@ -83,21 +84,40 @@ class QPDeviceIPM(object):
             from .lbfgs import LbfgsCore
             if not 1 <= self.lbfgs <= 31:
                 raise ValueError("1 <= lbfgs <= 31")
-            self.backend = None
+            self.backend = self.core = None
+            # x @ J through stored transposes: a row-vector times a row-major matrix is rocBLAS' slow GEMV flavour
+            self.JeT = self.Je.t().contiguous() if self.Je is not None else None
+            self.JiT = self.Ji.t().contiguous() if self.Ji is not None else None
             self.lb = LbfgsCore(n, me, mi, self.lbfgs + 1, device=dev.index, nb=nb)     # storage reaches lbfgs+1 pairs
             self.lb.stage_jacobian(self.Je, self.Ji)                                    # linear constraints: once
         else:
             self.backend = HipNewtonBackend(n, me, mi, device=dev.index, nb=nb, refine=refine, device_step=True,
                                             condensed=condensed)
+            self.core = self.backend.core
+            self.core.stage_blocks(self.Q, self.Je, self.Ji)       # constant blocks: device pointers, staged once
+        self._pcache = (None, None)
+        self.trace = None                   # set to [] to record (x, s, lda, mu) at every Newton step
         self.signal = 0
         self.iter_count = 0
         self.timings = {"newton_s": 0.0, "search_s": 0.0, "n_phi": 0}
 
-    # ------------------------------------------------------------------ provider (device GEMVs)
+    # ------------------------------------------------------------------ provider (pyipm.py:855-954 on the device)
+    def _products(self, v):
+        """(Q v, Je' v, Ji' v): ONE call into the library for all three (cached for the last vector asked about)."""
+        key = (id(v), v._version)
+        if self._pcache[0] == key:
+            return self._pcache[1]
+        if self.core is not None:
+            out = self.core.block_products(v)
+        else:                                               # L-BFGS mode: no Newton core; Q may be factored
+            q = (self.Q @ v) if self.Q is not None else (self.Qd * v + self.QF @ (self.QF.t() @ v))
+            out = (q, self.JeT @ v if self.neq else None, self.JiT @ v if self.nineq else None)
+        self._pcache = (key, out)
+        self._pkeep = v                                     # keeps id(v) unique while cached
+        return out
+
     def Qx(self, x):
-        if self.Q is not None:
-            return self.Q @ x
-        return self.Qd * x + self.QF @ (self.QF.t() @ x)
+        return self._products(x)[0]
 
     def f(self, x):
         return float(0.5 * self.torch.dot(x, self.Qx(x)) + self.torch.dot(self.c, x))
@@ -105,13 +125,23 @@ class QPDeviceIPM(object):
     def df(self, x):
         return self.Qx(x) + self.c
 
-    # x @ J through the stored transposes: a row-vector times a row-major matrix is rocBLAS' slow GEMV flavour
-    # (28 ms for 8.6 GB), the transposed copy runs at HBM speed (1.7 ms)
     def ce(self, x):
-        return self.JeT @ x - self.b
+        return self._products(x)[1] - self.b
 
     def ci(self, x):
-        return self.JiT @ x - self.h
+        return self._products(x)[2] - self.h
+
+    def _jlam(self, lda):
+        """Je lda_e + Ji lda_i (n)."""
+        me, mi = self.neq, self.nineq
+        if self.core is not None:
+            return self.core.block_products_t(lda[:me] if me else None, lda[me:] if mi else None)
+        out = self.torch.zeros(self.nvar, dtype=self.torch.float64, device=self.device)
+        if me:
+            out = out + self.Je @ lda[:me]
+        if mi:
+            out = out + self.Ji @ lda[me:]
+        return out
 
     def _con(self, x, s):
         parts = []
@@ -125,10 +155,8 @@ class QPDeviceIPM(object):
         """KKT residual blocks (pyipm.py:655-668) as a list [gx, gs, ce, ci - s] of device vectors."""
         me, mi = self.neq, self.nineq
         gx = self.df(x)
-        if me:
-            gx = gx - self.Je @ lda[:me]
-        if mi:
-            gx = gx - self.Ji @ lda[me:]
+        if me or mi:
+            gx = gx - self._jlam(lda)
         return (gx, (lda[me:] - self.mu_host / (s + self.eps)) if mi else None,
                 self.ce(x) if me else None, (self.ci(x) - s) if mi else None)
 
@@ -159,13 +187,14 @@ class QPDeviceIPM(object):
         the last iterations, where evaluating phi twice and subtracting has cancelled everything."""
         torch = self.torch
         q0 = self.Qx(x0)
-        g1 = torch.dot(q0 + self.c, dx)
-        g2 = torch.dot(dx, self.Qx(dx))
         ce0 = self.ce(x0) if self.neq else None
-        dce = (self.JeT @ dx) if self.neq else None
         if self.nineq:
             r0 = self.ci(x0) - s0
-            dr = (self.JiT @ dx) - ds
+        g1 = torch.dot(q0 + self.c, dx)
+        qd, dce, dci = self._products(dx)                  # Q dx, A dx, G dx: one call
+        g2 = torch.dot(dx, qd)
+        if self.nineq:
+            dr = dci - ds
             rs = ds / s0
 
         def delta(a):
@@ -275,6 +304,8 @@ class QPDeviceIPM(object):
     def newton_direction(self, x, s, lda):
         """pyipm.py:1717-1725 on the device: the blocks are resident, the vectors are device GEMVs."""
         me, mi = self.neq, self.nineq
+        if self.trace is not None:
+            self.trace.append((x.cpu().numpy(), s.cpu().numpy(), lda.cpu().numpy(), float(self.mu_host)))
         dz, self.delta, self.last_stats = self.backend.direction(
             self.Q, self.Je, self.Ji, self.df(x), self.ce(x) if me else None, self.ci(x) if mi else None,
             s if mi else None, lda if (me or mi) else None, self.mu_host, self.delta, self.mu_host, self.eta,

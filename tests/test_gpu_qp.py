@@ -147,3 +147,57 @@ def test_device_lbfgs_factored_hessian_equals_dense():
     assert float((l2 - l1).norm()) <= 1e-6 * (1.0 + float(l1.norm()))
     with pytest.raises(ValueError):
         QPDeviceIPM(("diag+lowrank", d, F), qp["c"], verbosity=-1)          # exact Hessian needs the dense block
+
+
+# ---- SURVEY 8f rank 3 as a row of its own: the provider's products behind the C-ABI, pinned by the reference ----------
+def test_block_products_match_numpy():
+    """pyipm_newton_block_products / _t: (Q v, A v, G v) and Je le + Ji li from the staged blocks -- the products behind
+    the reference's compiled df / ce / ci / grad (pyipm.py:855-954, 655-668).  Only the UPPER triangle of Q is read."""
+    import torch
+    from pyipm_amd.newton import NewtonCore
+    rng = np.random.default_rng(7)
+    for (n, me, mi) in [(300, 70, 130), (257, 0, 65), (128, 33, 0), (1000, 1, 1)]:
+        qp = make_qp(n, me, mi, 3)
+        core = NewtonCore(n, me, mi, device=0)
+        Qjunk = np.triu(qp["Q"]) + np.tril(rng.standard_normal((n, n)), -1)        # junk below the diagonal: never read
+        core.stage_blocks(Qjunk, qp["Je"], qp["Ji"])
+        v = rng.standard_normal(n)
+        q, e, i = core.block_products(torch.from_numpy(v))
+        np.testing.assert_allclose(q.cpu().numpy(), qp["Q"] @ v, rtol=0, atol=1e-12 * np.abs(qp["Q"] @ v).max())
+        if me:
+            np.testing.assert_allclose(e.cpu().numpy(), qp["A"] @ v, rtol=0, atol=1e-13 * max(1.0, np.abs(qp["A"] @ v).max()))
+        else:
+            assert e is None
+        if mi:
+            np.testing.assert_allclose(i.cpu().numpy(), qp["G"] @ v, rtol=0, atol=1e-13 * max(1.0, np.abs(qp["G"] @ v).max()))
+        le, li = rng.standard_normal(me), rng.standard_normal(mi)
+        ref = (qp["Je"] @ le if me else 0.0) + (qp["Ji"] @ li if mi else 0.0)
+        out = core.block_products_t(le if me else None, li if mi else None).cpu().numpy()
+        np.testing.assert_allclose(out, ref * np.ones(n), rtol=0, atol=1e-13 * max(1.0, np.abs(ref).max()))
+        core.close()
+
+
+@pytest.mark.parametrize("name", ["n40_me10_mi24_s11", "n64_me0_mi48_s12", "n48_me16_mi0_s13"])
+def test_device_loop_retraces_the_reference_solve(name):
+    """tests/golden/qptrace_*.npz: the UNMODIFIED reference solving the QP through its provider contract
+    (oracle/make_golden.py --qp-trace).  The device-resident loop -- provider products, Newton step, closed-form step
+    lengths and merit ray all on the GPU -- visits the same iterates and stops at the same point."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "qptrace_%s.npz" % name))
+    n, me, mi, seed = int(d["n"]), int(d["me"]), int(d["mi"]), int(d["seed"])
+    qp = make_qp(n, me, mi, seed)
+    dev = _dev_ipm(qp, Ktol=float(d["Ktol"]))
+    dev.trace = []
+    x, s, lda, fval, kkt = dev.solve()
+    assert dev.signal == int(d["signal"]) == 1
+    assert len(dev.trace) == int(d["n_iter"])                       # same number of Newton steps
+    for it, (xi, si, li, mu) in enumerate(dev.trace):
+        tol = 1e-9 * (10.0 ** min(it, 3))                           # rounding differences compound slowly along the path
+        np.testing.assert_allclose(xi, d["it_x"][it], rtol=0, atol=tol * max(1.0, np.abs(d["it_x"][it]).max()))
+        if mi:
+            np.testing.assert_allclose(si, d["it_s"][it], rtol=0, atol=tol * max(1.0, np.abs(d["it_s"][it]).max()))
+        if me or mi:
+            np.testing.assert_allclose(li, d["it_lda"][it], rtol=0, atol=10 * tol * max(1.0, np.abs(d["it_lda"][it]).max()))
+        assert abs(mu - float(d["it_mu_host"][it])) <= 1e-9 * max(1.0, float(d["it_mu_host"][it]))
+    np.testing.assert_allclose(x.cpu().numpy(), d["x"], rtol=0, atol=1e-6 * max(1.0, np.abs(d["x"]).max()))
+    assert abs(fval - float(d["fval"])) <= 1e-7 * max(1.0, abs(float(d["fval"])))

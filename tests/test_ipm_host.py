@@ -136,3 +136,24 @@ def test_max_iterations_signal():
     ipm = make_ipm(2, be, niter=1, miter=2, verbosity=-1)      # Rosenbrock cannot finish in 2 steps
     ipm.solve()
     assert ipm.signal == -1 and len(be.calls) == 2
+
+
+@pytest.mark.parametrize("name", ["n40_me10_mi24_s11", "n64_me0_mi48_s12", "n48_me16_mi0_s13"])
+def test_host_loop_retraces_reference_qp_solve(name):
+    """tests/golden/qptrace_*.npz (oracle/make_golden.py --qp-trace): the unmodified reference solving a synthetic QP
+    through its provider contract (pyipm.py:855-954).  The restated host loop with the oracle as Newton backend visits
+    the same iterates; tests/test_gpu_qp.py asks the same of the device-resident loop."""
+    from pyipm_amd.problems import make_qp, qp_callables
+    d = np.load(os.path.join(GOLD, "qptrace_%s.npz" % name))
+    n, me, mi, seed = int(d["n"]), int(d["me"]), int(d["mi"]), int(d["seed"])
+    p = qp_callables(make_qp(n, me, mi, seed))
+    be = OracleBackend(n, me, mi)
+    ipm = IPM(x0=np.zeros(n), f=p["f"], df=p["df"], d2f=p["d2f"], ce=p["ce"], dce=p["dce"], d2ce=p["d2ce"],
+              ci=p["ci"], dci=p["dci"], d2ci=p["d2ci"], backend=be, Ktol=float(d["Ktol"]), verbosity=-1)
+    x, s, lda, fval, kkt = ipm.solve()
+    assert ipm.signal == int(d["signal"]) and len(be.calls) == int(d["n_iter"])
+    for it, c in enumerate(be.calls):
+        np.testing.assert_allclose(c["g"], d["it_g"][it], rtol=1e-7, atol=1e-10)
+        assert np.isclose(c["delta"], d["it_delta_out"][it], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(x, d["x"], rtol=1e-8, atol=1e-10)
+    assert np.isclose(float(fval), float(d["fval"]), rtol=1e-9, atol=1e-12)

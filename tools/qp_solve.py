@@ -41,6 +41,25 @@ def main():
            "condensed_fallback_reason": ipm.backend.condensed_fallback_reason, "solve_seconds": dt, "newton_seconds": ipm.timings["newton_s"],
            "search_seconds": ipm.timings["search_s"], "merit_evaluations": ipm.timings["n_phi"],
            "kkt_norms": list(kkt), "fval": f}
+    # the provider's products in isolation (pyipm_newton_block_products / _t): HIP-event time and HBM rate
+    core = ipm.core
+    core.set_option("profile", 1)
+    v = torch.randn(n, dtype=torch.float64, device=dev)
+    le = torch.randn(me, dtype=torch.float64, device=dev) if me else None
+    li = torch.randn(mi, dtype=torch.float64, device=dev) if mi else None
+    best = None
+    for _ in range(5):
+        core.block_products(v)
+        core.block_products_t(le, li)
+        st = core.provider_stats()
+        if best is None or st["products_ms"] + st["products_t_ms"] < best["products_ms"] + best["products_t_ms"]:
+            best = st
+    out["provider"] = {"block_products_ms": best["products_ms"], "block_products_GB_per_s": best["products_bytes"] / best["products_ms"] / 1e6,
+                       "block_products_t_ms": best["products_t_ms"],
+                       "block_products_t_GB_per_s": best["products_t_bytes"] / max(best["products_t_ms"], 1e-9) / 1e6,
+                       "peak_GB_per_s": 8000.0,
+                       "note": "Q v + A v + G v in one call (bytes = 8 (n^2 + n me + n mi): the upper triangle of Q is passed over twice, "
+                               "row part and mirrored part); Je le + Ji li in the other (8 n (me + mi) bytes)"}
     print(json.dumps(out))
 
 
