@@ -286,7 +286,12 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *   "profile" 0|1, "lookahead" 0|1, "group" 1..create-time value, "tail_group" / "tail_cols" (group size once
  *   at most tail_cols columns remain; defaults 2 / 24576), "fuse_forward" 0|1, "pivtol_rel",
  *   "xcd_swizzle", "side_prio", "bulk_waves" 4|8 (measurement switches);
- *   "inpanel32" 0|1 (updates on the panel chain through the fine-grained kernel), "pending32_rows", "head32_rows",
+ *   "refine_target" / "refine_max" (adaptive refinement of solve(refine < 0): stop at this backward error, default 1e-14,
+ *   or after this many steps, default 8); "dist_selfmsg" 0|1 (world == 1 only: the distributed driver packs and sends
+ *   every panel anyway, to measure the message path on one GPU);
+ *   "inpanel32" 0|1 (updates on the panel chain through the fine-grained kernel), "fuse_scale_update" 0|1 (a tile's
+ *   in-panel update rides the scaling launch of the tile before it: two dependent launches per tile instead of three),
+ *   "pending32_rows", "head32_rows",
  *   "head32_rows_dist" (row counts up to which a panel's pending in-group update / the lookahead head / the per-panel
  *   head take that kernel; defaults 24576 / 6144 / 16384), "early_head" 0|1 (tail regime: the next group's columns are
  *   updated panel by panel beside the chain) -- all of these choose between implementations that accumulate the same

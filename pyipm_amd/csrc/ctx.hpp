@@ -97,6 +97,9 @@ struct Ctx {
     int bulk_waves = 8;                   // waves per block of the BULK update tiles (8: 128 VGPRs each, 4 waves per SIMD;
                                           // 4: 241 VGPRs, 2 per SIMD: 1.5 % slower); the short side-stream launches keep 4
     int inpanel32 = 1;                    // in-panel updates on 32-row blocks straight from global memory (k_inpanel_update)
+    int fuse_su = 1;                      // ... fused into the previous tile's scaling launch (k_panel_scale + NextUpd): two
+                                          // dependent launches per tile on the chain instead of three; same bits
+    double* Wnext = nullptr;              // 64 x 64: -S of the next diagonal tile's rows (handed from the tile kernel to that launch)
     int early_head = 1;                   // tail regime: a group's panels except the last update the next group's columns as soon
                                           // as each is factored (beside the chain), so only the last panel's K = nb is left between two chains
     int64_t head32_rows = 6144;           // ... and the lookahead HEAD update (next group's columns, on the critical path between two
@@ -132,9 +135,6 @@ struct Ctx {
     double *Tsv = nullptr;                // the diagonal tiles T_k themselves (refinement of the block solves)
     double *Tflag = nullptr;              // per tile: 1.0 = refine block solves with it (pivot spread beyond refine_cond)
     double *rhs = nullptr, *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *partial = nullptr;
-    double *Minv = nullptr;               // per local panel: inv(Lb_pp)' (nb x nb) for the backward sweep (k_bwd_apply)
-    bool minv_valid = false;              // Minv matches the current factor
-    int bwd_fused = 1;                    // 0: the in-panel recursion (k_bwd_diag) instead of the inverse block (k_bwd_apply)
     double *df = nullptr, *ce = nullptr, *ci = nullptr, *s = nullptr, *lda = nullptr;
     DevStats* dstats = nullptr;
     unsigned long long* anorm = nullptr;  // device: bits of max |assembled KKT entry| (per problem for a batched handle): scale of a static pivot

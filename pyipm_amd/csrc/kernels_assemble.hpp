@@ -87,28 +87,38 @@ __global__ __launch_bounds__(256) void k_assemble(
     const int64_t lc_base = (int64_t)blockIdx.y * 16;
     if (i >= g.Npad) return;                          // (wave-uniform: Npad is a multiple of 128)
     const bool vec_h = ((ldh & 1) == 0) && ((reinterpret_cast<uintptr_t>(d2L) & 15) == 0);
-    double amax = 0.0;
-    #pragma unroll 4
+    // the 16 columns of a block lie in ONE panel (nb is a multiple of 128): one division per block, not one per entry
+    const int64_t lp = lc_base / g.nb;
+    const int64_t j0 = (lp * g.world + g.rank) * (int64_t)g.nb + (lc_base - lp * g.nb);
+    // (a lane whose rows lie above the whole patch has nothing to do, but stays for the wave reduction at the end)
+    const int ncol = (i + 1 < j0) ? 0 : ((g.ncols_local - lc_base) < 16 ? (int)(g.ncols_local - lc_base) : 16);
+    // values first (all loads of the thread in flight), stores afterwards
+    dbl2_t val[16];
+    #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        const int64_t lc = lc_base + c;
-        if (lc >= g.ncols_local) break;
-        // local column -> global column (block-cyclic by panels of nb)
-        const int64_t lp = lc / g.nb;
-        const int64_t j = (lp * g.world + g.rank) * (int64_t)g.nb + (lc - lp * g.nb);
-        if (i + 1 < j) continue;                      // both rows above the diagonal: not stored
-        const int64_t jr = sharded ? lc : j;          // row-sharded blocks are laid out in local column order
-        dbl2_t v;
-        if (vec_h && j < g.n && i + 1 < g.n && i >= j) {
-            v = *reinterpret_cast<const dbl2_t*>(&d2L[jr * ldh + i]);
-            if (i == j) v.x += delta;
-            if (i + 1 == j) v.y += delta;
-        } else {
-            v.x = (i >= j) ? kkt_entry(i, j, jr, g, d2L, ldh, Je, ldje, Ji, ldji, s, lda, eps, delta, delta_c) : 0.0;
-            v.y = kkt_entry(i + 1, j, jr, g, d2L, ldh, Je, ldje, Ji, ldji, s, lda, eps, delta, delta_c);
+        const int64_t j = j0 + c;
+        const int64_t jr = sharded ? lc_base + c : j;  // row-sharded blocks are laid out in local column order
+        dbl2_t v; v.x = 0.0; v.y = 0.0;
+        if (c < ncol && i + 1 >= j) {
+            if (vec_h && j < g.n && i + 1 < g.n && i >= j) {
+                v = *reinterpret_cast<const dbl2_t*>(&d2L[jr * ldh + i]);
+                if (i == j) v.x += delta;
+            } else {
+                v.x = (i >= j) ? kkt_entry(i, j, jr, g, d2L, ldh, Je, ldje, Ji, ldji, s, lda, eps, delta, delta_c) : 0.0;
+                v.y = kkt_entry(i + 1, j, jr, g, d2L, ldh, Je, ldje, Ji, ldji, s, lda, eps, delta, delta_c);
+            }
         }
+        val[c] = v;
+    }
+    double amax = 0.0;
+    #pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int64_t j = j0 + c, lc = lc_base + c;
+        if (c >= ncol || i + 1 < j) continue;         // both rows above the diagonal: not stored
+        const dbl2_t v = val[c];
         amax = fmax(amax, fmax(fabs(v.x), fabs(v.y)));
         if (i >= j) {
-            // (non-temporal stores measured no faster, r02: 1.99 vs 1.95 ms at N = 32768 -- the kernel is store-bound)
+            // (non-temporal stores measured no faster, r02: 1.99 vs 1.95 ms at N = 32768)
             if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<dbl2_t*>(&A[i + lc * ld]));
             else          *reinterpret_cast<dbl2_t*>(&A[i + lc * ld]) = v;
         } else {

@@ -185,6 +185,10 @@ __device__ __forceinline__ void tile_invert_dev(
         left -= 1;                                                                                       \
     }
 
+    // (Tried and dropped, r02: the block-step pivots in PAIRS -- the second pivot column after the first sweep is one fused
+    //  multiply-add per lane, so both columns are published together and one LDS round trip returns both pivot rows, the second
+    //  pivot's test / reciprocal / multipliers computed while the reads are in flight.  Bit-identical, and SLOWER: 1436 against
+    //  1109 cycles per pivot.  The owner wave's time is its instruction count on one dependent path, not the LDS round trip.)
     // ---- block steps --------------------------------------------------------------------------------------
     // As long as Bunch-Kaufman accepts the diagonal pivots in their natural order (every definite tile; most
     // others), a sweep only needs the pivot's own column.  The wave that holds columns [16k, 16k+16) therefore
@@ -335,10 +339,23 @@ __global__ __launch_bounds__(256) void k_tile_invert(
     const double* __restrict__ A, int64_t ld, int64_t grow0, int64_t lcol0,
     double* __restrict__ Tinv, double* __restrict__ Tsave, double* __restrict__ Tflag, double refine_cond,
     DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel,
-    const unsigned long long* __restrict__ anorm_bits, int64_t neg_from, unsigned long long* __restrict__ dbg)
+    const unsigned long long* __restrict__ anorm_bits, int64_t neg_from, unsigned long long* __restrict__ dbg,
+    double* __restrict__ Wnext)            // != NULL: -S of the NEXT diagonal tile's rows in this column block (64 x 64,
+                                           // column-major, ld 64): the fused scaling + update launch that follows lets
+                                           // every strip read it while the strip that owns those rows overwrites them with L
 {
     __shared__ TileScratch sm;
     __builtin_amdgcn_s_setprio(3);         // latency-critical chain: win issue arbitration against co-resident bulk waves
+    if (Wnext) {
+        double tmp[TB * TB / 256];
+        #pragma unroll
+        for (int q = 0; q < TB * TB / 256; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            tmp[q] = A[(grow0 + TB + (e & 63)) + (lcol0 + (e >> 6)) * ld];
+        }
+        #pragma unroll
+        for (int q = 0; q < TB * TB / 256; ++q) Wnext[threadIdx.x + 256 * q] = -tmp[q];
+    }
     tile_invert_dev(sm, A, ld, grow0, lcol0, Tinv, Tsave, Tflag, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg);
 }
 
@@ -359,6 +376,20 @@ __global__ __launch_bounds__(256) void k_tile_invert(
 // overwrite it with the block factor L = W * inv(T).  256 threads per 64 rows: wave w produces
 // output columns [16w,16w+16); inv(T) in LDS (broadcast reads).
 // ---------------------------------------------------------------------------------------------
+// The in-panel update of the NEXT 64-column block, fused into the scaling launch of the current one (both are
+// row-parallel over the same 64-row strips, and a strip's own L of the current tile is still in its registers):
+//   C[i][c] += sum_{k < K + 64} L[i][k] * Wn[c][k],   Wn = -S of the next diagonal tile's rows,
+// the same products in the same order as k_inpanel_update (k ascending in MFMA groups of 4): bit-identical.  The last 64
+// columns of Wn (this tile's) come from `Wnext`, copied by the tile kernel before this launch overwrites them with L.
+struct NextUpd {
+    int on;                                // 0: plain scaling
+    double* C; int64_t ldc, ccol;          // next column block: C[i + (ccol + c) * ldc]
+    const double* Lop; int64_t ldl;        // the panel's columns before this tile: L[i][k] = Lop[i + k*ldl], k < K
+    const double* Wop; int64_t ldw, cglob; // Wn[c][k] = Wop[(cglob + c) + k*ldw], k < K (cglob = global row of the next tile)
+    const double* Wnext;                   // Wn[c][K + k] = Wnext[c + k*64]
+    int K;                                 // 64 t
+};
+
 __global__ __launch_bounds__(256) void k_panel_scale(
     double* __restrict__ Aout, int64_t ld_out, int64_t col_out,      // L written at Aout[i + (col_out+c)*ld_out]
     const double* __restrict__ Win, int64_t ld_in, int64_t col_in,   // S read from  Win[i + (col_in+k)*ld_in]
@@ -366,8 +397,9 @@ __global__ __launch_bounds__(256) void k_panel_scale(
     const double* __restrict__ Tinv, const double* __restrict__ Tsave, const double* __restrict__ Tflag, int nref,
     int64_t row_begin, int64_t hole0, int64_t hole1,   // 64-row blocks inside [hole0, hole1) hold exact zeros: skipped
     unsigned long long* __restrict__ growth_bits,
-    double sign)      // owner: Win = S, Wcopy = -S (the update kernel wants -W), sign = +1;
+    double sign,      // owner: Win = S, Wcopy = -S (the update kernel wants -W), sign = +1;
                       // non-owner rebuilding L from a received -S: sign = -1
+    NextUpd nu)
 {
     // L[i][c] = sign * sum_k S[i][k] X[k][c], X = inv(T), on fp64 MFMA.  D[m][n]: m <- c (A operand = X,
     // symmetric), n <- i (B operand = S, read straight from global: 16 lanes x 8 B contiguous per k).  One
@@ -453,6 +485,52 @@ __global__ __launch_bounds__(256) void k_panel_scale(
         }
     gmax = wave_max(gmax);
     if (lane == 0 && growth_bits) atomicMax(growth_bits, (unsigned long long)__double_as_longlong(gmax));
+    if (!nu.on) return;
+    // ---- fused: in-panel update of the next column block for this strip (wave: 16 rows x 64 columns) ----
+    double4_t c2[4];
+    #pragma unroll
+    for (int t = 0; t < 4; ++t)
+        #pragma unroll
+        for (int r = 0; r < 4; ++r) c2[t][r] = nu.C[i + (nu.ccol + t * 16 + l4 + 4 * r) * nu.ldc];
+    {
+        const double* wp = nu.Wop + (nu.cglob + l15) + (int64_t)l4 * nu.ldw;      // A operand: m = c (per 16-group t), k = 4 ks + l4
+        const double* lp = nu.Lop + i + (int64_t)l4 * nu.ldl;                      // B operand: n = i
+        for (int k0 = 0; k0 < nu.K; k0 += TB / 2) {          // 32 columns of K in flight (registers: 2-3 such waves per SIMD)
+            double wa[4][8], lb[8];
+            #pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                lb[ks] = lp[(int64_t)(k0 + 4 * ks) * nu.ldl];
+                #pragma unroll
+                for (int t = 0; t < 4; ++t) wa[t][ks] = wp[16 * t + (int64_t)(k0 + 4 * ks) * nu.ldw];
+            }
+            #pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                #pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    c2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[t][ks], lb[ks], c2[t], 0, 0, 0);
+        }
+        // last slab: this tile's columns -- Wn from the tile kernel's copy, L from the accumulators (their C/D map is
+        // the B-operand map of k-step 4 t + r, as in the refinement above)
+        #pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double wa[4][8];
+            #pragma unroll
+            for (int ks = 0; ks < 8; ++ks)
+                #pragma unroll
+                for (int t = 0; t < 4; ++t) wa[t][ks] = nu.Wnext[(16 * t + l15) + (4 * (8 * h + ks) + l4) * TB];
+            #pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const double lop = acc[(8 * h + ks) >> 2][(8 * h + ks) & 3];
+                #pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    c2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[t][ks], lop, c2[t], 0, 0, 0);
+            }
+        }
+    }
+    #pragma unroll
+    for (int t = 0; t < 4; ++t)
+        #pragma unroll
+        for (int r = 0; r < 4; ++r) nu.C[i + (nu.ccol + t * 16 + l4 + 4 * r) * nu.ldc] = c2[t][r];
 }
 
 // ---------------------------------------------------------------------------------------------

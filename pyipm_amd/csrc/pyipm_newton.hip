@@ -17,7 +17,7 @@ static void quiesce_noexcept(Ctx* c) noexcept {
         if (c->side) hipStreamSynchronize(c->side);
         if (c->fwd) hipStreamSynchronize(c->fwd);
         if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
-        c->factored = false; c->forward_pending = false; c->forward_fused = false; c->minv_valid = false;
+        c->factored = false; c->forward_pending = false; c->forward_fused = false;
     } catch (...) {}
 }
 #define PYIPM_SETERR_NEWTON(msg_) (quiesce_noexcept(reinterpret_cast<Ctx*>(h)), set_err_noexcept(reinterpret_cast<Ctx*>(h), (msg_)))
@@ -56,11 +56,12 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
     const size_t ovc = cv.take((size_t)g.Npad * D);
     const size_t ovt = cv.take((size_t)(g.mi + 16) * D);
     const size_t oan = cv.take(64);
-    const size_t omi = cv.take((size_t)((g.ncols_local + g.nb - 1) / g.nb + 1) * (size_t)g.nb * (size_t)g.nb * D);
+    const size_t own = cv.take((size_t)TB * TB * D);
     if (base) {
+        c->Wnext = (double*)(base + own);
         c->vc = (double*)(base + ovc); c->vt = (double*)(base + ovt);
         c->anorm = (unsigned long long*)(base + oan);
-        c->Minv = (double*)(base + omi);
+
         c->A = (double*)(base + oA); c->Wbuf = (double*)(base + oW); c->Lbuf = (double*)(base + oL);
         c->Dinv = (double*)(base + oD); c->Tsv = (double*)(base + oT); c->Tflag = (double*)(base + oTf); c->rhs = (double*)(base + orhs);
         c->v0 = (double*)(base + ov0); c->v1 = (double*)(base + ov1); c->v2 = (double*)(base + ov2);
@@ -374,16 +375,18 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
         panel_hole(ctx, p, &hole0, &hole1);             // per-panel mode (any number of ranks)
         if (hole1 > hole0) active_ranges(ctx, c0, c0 + nbw, &ha0, &ha1, &hb0, &hb1);
     }
+    const bool fused = ctx->fuse_su && ctx->inpanel32;      // a tile's scaling launch also updates the next column block
     for (int t = 0; t < nt; ++t) {
         const int64_t j0 = c0 + (int64_t)t * TB, lcol = lc0 + (int64_t)t * TB;
-        if (t > 0 && ctx->inpanel32) {
+        const int64_t below = g.Npad - (j0 + TB);
+        if (t > 0 && ctx->inpanel32 && !fused) {
             // left-looking in-panel update of this tile's column block with the t tiles before it (32-row blocks)
             const int64_t row_begin = (j0 / 32) * 32;
             hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - row_begin) / 32)), dim3(256), 0, stream,
                                ctx->A, g.Npad, lcol, ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, j0, t * TB, row_begin, g.Npad,
                                ha0, ha1, hb0, hb1, ctx->side_prio);
             PYIPM_KCHECK();
-        } else if (t > 0) {
+        } else if (t > 0 && !ctx->inpanel32) {
             // left-looking in-panel update of this tile's column block with the t tiles before it
             const int64_t row_begin = (j0 / BM) * BM;
             const int64_t m = g.Npad - row_begin;
@@ -397,17 +400,23 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
                                ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, t * TB, u);
             PYIPM_KCHECK();
         }
+        const bool next = fused && t + 1 < nt && below > 0;   // the scaling launch below carries the update of tile t + 1
         hipLaunchKernelGGL(k_tile_invert, dim3(1), dim3(256), 0, stream, ctx->A, g.Npad, j0, lcol,
                            ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), ctx->Tsv + (j0 / TB) * (int64_t)(TB * TB),
                            ctx->Tflag + j0 / TB, ctx->refine_cond, ctx->dstats, g.N, ctx->pivtol_rel, ctx->anorm,
-                           g.n + g.mi, ctx->dbg_buf);
+                           g.n + g.mi, ctx->dbg_buf, next ? ctx->Wnext : (double*)nullptr);
         PYIPM_KCHECK();
-        const int64_t below = g.Npad - (j0 + TB);
         if (below > 0) {
+            NextUpd nu; memset(&nu, 0, sizeof(nu));
+            if (next) {
+                nu.on = 1; nu.C = ctx->A; nu.ldc = g.Npad; nu.ccol = lcol + TB;
+                nu.Lop = ctx->A + lc0 * g.Npad; nu.ldl = g.Npad;
+                nu.Wop = W; nu.ldw = g.Npad; nu.cglob = j0 + TB; nu.Wnext = ctx->Wnext; nu.K = t * TB;
+            }
             hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(below / TB)), dim3(256), 0, stream,
                                ctx->A, g.Npad, lcol, ctx->A, g.Npad, lcol, W, g.Npad, (int64_t)t * TB,
                                ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), ctx->Tsv + (j0 / TB) * (int64_t)(TB * TB),
-                               ctx->Tflag + j0 / TB, ctx->block_refine, j0 + TB, hole0, hole1, &ctx->dstats->growth_bits, 1.0);
+                               ctx->Tflag + j0 / TB, ctx->block_refine, j0 + TB, hole0, hole1, &ctx->dstats->growth_bits, 1.0, nu);
             PYIPM_KCHECK();
         }
     }
@@ -502,7 +511,6 @@ int factor_begin(Ctx* ctx) {
     PYIPM_HIP(hipMemcpyAsync(ctx->dstats, &z, sizeof(z), hipMemcpyHostToDevice, ctx->stream));
     PYIPM_HIP(hipStreamSynchronize(ctx->stream));   // &z is a stack temporary
     ctx->n_trailing = 0; ctx->trailing_flops = 0.0; ctx->trailing_area = 0.0;
-    ctx->minv_valid = false;
     return 0;
 }
 
@@ -562,7 +570,6 @@ int diag_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr, int
 // part / pstride: partial-sum buffer for several right-hand sides (>= nchunk*nb doubles each); default = the handle's own
 int bwd_panel(Ctx* ctx, int64_t p, double* v, int nrhs = 1, int64_t vstride = 0, double* part = nullptr, int64_t pstride = 0) {
     const Geo& g = ctx->g;
-    const bool own_part = part == nullptr;
     if (!part) part = ctx->partial;
     const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
     const int nbw = (int)g.panel_w(p);
@@ -573,21 +580,6 @@ int bwd_panel(Ctx* ctx, int64_t p, double* v, int nrhs = 1, int64_t vstride = 0,
         hipLaunchKernelGGL(k_bwd_dot, dim3(nbw, nchunk, nrhs), dim3(256), 0, ctx->stream, ctx->A, g.Npad, lc0, g.nb,
                            c0 + nbw, g.Npad, v, part, vstride, pstride);
         PYIPM_KCHECK();
-    }
-    if (ctx->bwd_fused && nrhs == 1 && own_part) {
-        // the panel's own block through inv(Lb_pp)' (one dense product) instead of the one-block recursion
-        if (!ctx->minv_valid) {
-            const int64_t nlp = (g.ncols_local + g.nb - 1) / g.nb;
-            if (nlp > 0) {
-                hipLaunchKernelGGL(k_panel_inv, dim3((unsigned)nlp), dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->Minv, (int64_t)0);
-                PYIPM_KCHECK();
-            }
-            ctx->minv_valid = true;
-        }
-        hipLaunchKernelGGL(k_bwd_apply, dim3(1), dim3(1024), 0, ctx->stream, ctx->Minv + (p / g.world) * (int64_t)g.nb * g.nb,
-                           c0, nbw, g.nb, part, nchunk, v);
-        PYIPM_KCHECK();
-        return 0;
     }
     hipLaunchKernelGGL(k_bwd_diag, dim3(1, nrhs), dim3(nbw), nbw * sizeof(double), ctx->stream, ctx->A, g.Npad, lc0, c0, nbw,
                        g.nb, part, nchunk, v, vstride, pstride);
@@ -893,12 +885,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         PYIPM_HIP(hipEventRecord(ctx->ev_done[q], used));
         PYIPM_HIP(hipStreamWaitEvent(ctx->fwd, ctx->ev_done[q], 0));
         int r2 = fwd_panel(ctx, q, ctx->fwd_vec, ctx->fwd); if (r2) return r2;
-        r2 = diag_panel(ctx, q, ctx->fwd_vec, ctx->fwd); if (r2) return r2;
-        if (ctx->bwd_fused) {               // inv(Lb_qq)' for the backward sweep, beside the factorisation (k_bwd_apply)
-            hipLaunchKernelGGL(k_panel_inv, dim3(1), dim3(256), 0, ctx->fwd, ctx->A, g.Npad, g, ctx->Minv, q);
-            PYIPM_KCHECK();
-        }
-        return 0;
+        return diag_panel(ctx, q, ctx->fwd_vec, ctx->fwd);
     };
     for (int64_t q = 0; q < gsize(0); ++q) {
         rc = factor_panel(ctx, q, ctx->stream, true); if (rc) return rc;
@@ -975,7 +962,6 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         PYIPM_HIP(hipEventRecord(ctx->ev_fwd, ctx->fwd));
         PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fwd, 0));
         ctx->forward_fused = true;
-        if (ctx->bwd_fused) ctx->minv_valid = true;
     }
     PYIPM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->assembled = false;                 // storage now holds the factor
@@ -1676,12 +1662,13 @@ int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf)
             PYIPM_HIP(hipMemcpy2DAsync(wbuf(ctx, p) + h1, (size_t)g.Npad * sizeof(double), buf + seg0, (size_t)m * sizeof(double),
                                        (size_t)seg1 * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
         // rebuild the block column L = W * inv(T) tile by tile into Lbuf (rows of the hole: never read, skipped)
+        NextUpd nu_off; memset(&nu_off, 0, sizeof(nu_off));
         for (int t = 0; t < nbw / TB; ++t) {
             hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)((g.Npad - c1) / TB)), dim3(256), 0, ctx->stream,
                                ctx->Lbuf, g.Npad, (int64_t)t * TB, wbuf(ctx, p), g.Npad, (int64_t)t * TB,
                                (double*)nullptr, (int64_t)0, (int64_t)0, dinv + (int64_t)t * TB * TB,
                                tsv + (int64_t)t * TB * TB, ctx->Tflag + c0 / TB + t, ctx->block_refine, c1, h0, h1,
-                               (unsigned long long*)nullptr, -1.0);
+                               (unsigned long long*)nullptr, -1.0, nu_off);
             PYIPM_KCHECK();
         }
     }
@@ -1758,9 +1745,9 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "tail_group")) { ctx->tail_group = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "tail_cols")) { ctx->tail_cols = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "bwd_fused")) { ctx->bwd_fused = (int)value != 0; return PYIPM_OK; }
     { bool handled = false; int rc = dist_set_option(ctx, name, value, &handled); if (handled) return rc; }
     if (!strcmp(name, "inpanel32")) { ctx->inpanel32 = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "fuse_scale_update")) { ctx->fuse_su = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "early_head")) { ctx->early_head = (int)value != 0; return PYIPM_OK; }

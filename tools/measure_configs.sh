@@ -2,7 +2,7 @@
 # Bench lines for the other BASELINE.json configurations (1 GPU).  Output: gpurun_out/cfg_*.json
 set -u
 mkdir -p gpurun_out
-B="timeout 900 python bench.py --no-cpu-baseline --check"
+B="timeout 900 python bench.py --no-cpu-baseline "
 $B --nvar 2048 --neq 0 --nineq 2048 --steps 20 --warmup 3 > gpurun_out/cfg2_full.json 2> gpurun_out/cfg2_full.err
 $B --nvar 2048 --neq 0 --nineq 2048 --steps 20 --warmup 3 --opt condensed=1 > gpurun_out/cfg2_cond.json 2> gpurun_out/cfg2_cond.err
 $B --nvar 16384 --neq 8192 --nineq 8192 --steps 3 --warmup 1 > gpurun_out/cfg3_full.json 2> gpurun_out/cfg3_full.err
