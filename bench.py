@@ -189,6 +189,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (tests/test_gpu_dist.py): several ranks on ONE GPU over gloo -- exercises this file's multi-rank path
+    # (row-sharded staging, the library's distributed driver with callback exchange, the JSON line) on a one-GPU box;
+    # RCCL itself refuses two ranks on one device.  Never set by the driver.
+    share_gpu = os.environ.get("PYIPM_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
@@ -200,7 +206,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
+        if share_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
     if args.nb == 0:
         args.nb = 256 if world == 1 else 512
@@ -266,7 +275,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -298,7 +307,7 @@ def main():
                                    % (n, me, mi, N, args.seed, args.nb, args.refine),
                        "kkt_dim": N, "n": n, "me": me, "mi": mi, "nb": args.nb,
                        "parallelism": "1D block-cyclic column panels over %d GPU(s)" % world,
-                       "pivoting": "Bunch-Kaufman restricted to 64x64 diagonal tiles (block pivots)"},
+                       "pivoting": "Bunch-Kaufman restricted to 64x64 diagonal tiles (block pivots); static pivots + refinement where a tile cannot pivot on its own"},
             "roofline": {"bound": "mfma", "kernel": "k_update<128> (fp64 MFMA trailing rank-nb update)",
                          "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(N, args.nb)[0],
@@ -339,7 +348,7 @@ def main():
             # panels (unpack), the sweeps; bytes / messages of the panel exchange
             out["dist_phases_per_step"] = {k: v / K for k, v in dist_ms.items()}
             out["dist_driver"] = "pyipm_newton_step_dist (per-panel schedule in C); exchange: %s" % (
-                "handle-owned RCCL communicator" if world > 1 else "none (one rank)")
+                "callbacks over gloo (test hook: ranks share a GPU)" if share_gpu else "handle-owned RCCL communicator" if world > 1 else "none (one rank)")
         if condensed:
             # same Newton direction from the (n+me)-dimensional condensed system; NOT the
             # headline configuration: the flop count of the step itself changes

@@ -60,6 +60,7 @@ struct DistState {
     ncclComm_t comm = nullptr;
     hipStream_t side = nullptr, cs = nullptr;          // owner's factor + pack stream (high priority); collectives
     hipEvent_t ev_fact[2] = {}, ev_msg[2] = {}, ev_free[2] = {}, ev_head = nullptr, ev_join = nullptr;
+    hipEvent_t ev_hop[2] = {};                         // a collective asked for on another stream is run on `cs` between these
     double* msg[2] = {nullptr, nullptr}; size_t msg_bytes = 0;
     double* seg = nullptr;                             // nb doubles: the panel segment of the forward sum
     double* vloc = nullptr;                            // Npad: this rank's share of the vector during the sweeps
@@ -104,6 +105,8 @@ int dist_state(Ctx* ctx, DistState** out) {
         }
         DIST_HIP(hipEventCreateWithFlags(&D->ev_head, hipEventDisableTiming));
         DIST_HIP(hipEventCreateWithFlags(&D->ev_join, hipEventDisableTiming));
+        DIST_HIP(hipEventCreateWithFlags(&D->ev_hop[0], hipEventDisableTiming));
+        DIST_HIP(hipEventCreateWithFlags(&D->ev_hop[1], hipEventDisableTiming));
         DIST_HIP(hipMalloc((void**)&D->seg, (size_t)g.nb * sizeof(double)));
         DIST_HIP(hipMalloc((void**)&D->vloc, (size_t)g.Npad * sizeof(double)));
         DIST_HIP(hipMalloc((void**)&D->small, 16 * sizeof(double)));
@@ -125,6 +128,7 @@ void dist_free(Ctx* ctx) {
     }
     if (D->ev_head) hipEventDestroy(D->ev_head);
     if (D->ev_join) hipEventDestroy(D->ev_join);
+    for (int b = 0; b < 2; ++b) if (D->ev_hop[b]) hipEventDestroy(D->ev_hop[b]);
     for (auto e : D->pool) hipEventDestroy(e);
     if (D->seg) hipFree(D->seg);
     if (D->vloc) hipFree(D->vloc);
@@ -146,12 +150,33 @@ int dist_set_option(Ctx* ctx, const char* name, double value, bool* handled) {
 }
 
 // ---- exchange -----------------------------------------------------------------------------------------------------
+// With a communicator of its own the library keeps ALL its collectives on ONE stream (`cs`), in the order they are issued:
+// operations of one communicator on two streams may otherwise run concurrently, which RCCL does not promise to survive.  A
+// collective asked for on another stream hops over: that stream's work so far -> cs -> back.
+struct CsHop {
+    Ctx* ctx; DistState* D; hipStream_t st; bool hop; int rc = 0;
+    CsHop(Ctx* c, DistState* d, hipStream_t s) : ctx(c), D(d), st(s), hop(d->comm != nullptr && s != d->cs) {
+        if (hop) {
+            if (hipEventRecord(D->ev_hop[0], st) != hipSuccess || hipStreamWaitEvent(D->cs, D->ev_hop[0], 0) != hipSuccess) rc = PYIPM_E_HIP;
+        }
+    }
+    hipStream_t stream() const { return hop ? D->cs : st; }
+    int done() {
+        if (hop && !rc) {
+            if (hipEventRecord(D->ev_hop[1], D->cs) != hipSuccess || hipStreamWaitEvent(st, D->ev_hop[1], 0) != hipSuccess) rc = PYIPM_E_HIP;
+        }
+        if (rc == PYIPM_E_HIP) ctx->err = "event hop to the collective stream failed";
+        return rc;
+    }
+};
+
 int ex_bcast(Ctx* ctx, DistState* D, void* buf, size_t bytes, int root, hipStream_t st) {
     if (bytes == 0) return 0;
     if (D->comm) {
-        ncclResult_t r = g_rccl.Broadcast(buf, buf, bytes / sizeof(double), ncclDouble, root, D->comm, st);
+        CsHop h(ctx, D, st); if (h.rc) return h.done();
+        ncclResult_t r = g_rccl.Broadcast(buf, buf, bytes / sizeof(double), ncclDouble, root, D->comm, h.stream());
         if (r != ncclSuccess) { ctx->err = std::string("ncclBroadcast: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; }
-        return 0;
+        return h.done();
     }
     if (ctx->g.world == 1) return 0;
     if (!D->bcast) { ctx->err = "no exchange installed: pyipm_newton_set_exchange or pyipm_newton_comm_init first"; return PYIPM_E_COMM; }
@@ -162,9 +187,10 @@ int ex_bcast(Ctx* ctx, DistState* D, void* buf, size_t bytes, int root, hipStrea
 int ex_allreduce(Ctx* ctx, DistState* D, double* buf, size_t count, int op, hipStream_t st) {
     if (count == 0) return 0;
     if (D->comm) {
-        ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclDouble, op ? ncclMax : ncclSum, D->comm, st);
+        CsHop h(ctx, D, st); if (h.rc) return h.done();
+        ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclDouble, op ? ncclMax : ncclSum, D->comm, h.stream());
         if (r != ncclSuccess) { ctx->err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; }
-        return 0;
+        return h.done();
     }
     if (ctx->g.world == 1) return 0;
     if (!D->allreduce) { ctx->err = "no exchange installed: pyipm_newton_set_exchange or pyipm_newton_comm_init first"; return PYIPM_E_COMM; }

@@ -195,3 +195,26 @@ def test_handle_owned_rccl_communicator_single_rank():
     assert backend == "nccl"
     assert err <= 1e-12 and rep == 0.0 and n_neg == shape[1] + shape[2]
     assert tm["bytes"] == _factor_bytes(shape[0], shape[1], shape[2], nb)[0] and tm["bcast_ms"] > 0.0
+
+
+def test_bench_multi_rank_path_on_one_gpu():
+    """bench.py launched the way the driver launches it for N > 1 (torch.distributed.run, one rank per process), with
+    both ranks on the one GPU over gloo (PYIPM_BENCH_SHARE_GPU=1): row-sharded staging, the library's distributed
+    driver, the JSON line with n_gpus = 2 and the per-phase timings."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYIPM_BENCH_SHARE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--nvar", "1536", "--neq", "256", "--nineq", "640", "--nb", "256", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["kkt_dim"] == 1536 + 2 * 640 + 256
+    assert d["backward_error"] <= 1e-12 and d["inertia"]["n_neg"] == 256 + 640 and d["inertia"]["n_zero"] == 0
+    ph = d["dist_phases_per_step"]
+    assert ph["messages"] > 0 and ph["bytes"] > 0 and ph["factor_ms"] > 0 and ph["chain_ms"] > 0

@@ -125,3 +125,30 @@ def test_solve_with_device_step_lengths(k):
     x, s, lda, fval, kkt = ipm.solve()
     assert ipm.signal == int(d["signal"]) and ipm.iter_count == int(d["n_iter"])
     np.testing.assert_allclose(x, d["x"], rtol=1e-7, atol=1e-9)
+
+
+def test_backend_follows_the_problem_shape_and_condensed_fallback_lasts_one_solve():
+    """compile() kept the backend of the first problem when force_recompile brought another shape,
+    and one condensed-form fallback disabled the condensed option for the backend's lifetime."""
+    from pyipm_amd.ipm import IPM
+    qa, qb = make_qp(40, 10, 20, 1), make_qp(64, 0, 48, 2)
+    pa, pb = qp_callables(qa), qp_callables(qb)
+    ipm = IPM(x0=np.zeros(40), f=pa["f"], df=pa["df"], d2f=pa["d2f"], ce=pa["ce"], dce=pa["dce"], d2ce=pa["d2ce"],
+              ci=pa["ci"], dci=pa["dci"], d2ci=pa["d2ci"], verbosity=-1, condensed=True, Ktol=1e-8, niter=30, miter=30)
+    xa = ipm.solve()[0]
+    assert ipm.signal == 1 and ipm.backend.shape() == (40, 10, 20)
+    first = ipm.backend
+    # pretend the condensed form failed once in that solve: the next solve must try it again
+    first.condensed_on = False
+    first.core.set_option("condensed", 0)
+    xa2 = ipm.solve()[0]
+    assert first.condensed_on and ipm.backend is first
+    np.testing.assert_allclose(xa2, xa, rtol=1e-8, atol=1e-10)
+    # another problem through the same object
+    for k in ("f", "df", "d2f", "ce", "dce", "d2ce", "ci", "dci", "d2ci"):
+        setattr(ipm, k, pb[k])
+    xb = ipm.solve(x0=np.zeros(64), force_recompile=True)[0]
+    assert ipm.backend is not first and ipm.backend.shape() == (64, 0, 48) and ipm.signal == 1
+    ref = IPM(x0=np.zeros(64), f=pb["f"], df=pb["df"], d2f=pb["d2f"], ci=pb["ci"], dci=pb["dci"], d2ci=pb["d2ci"],
+              verbosity=-1, Ktol=1e-8, niter=30, miter=30).solve()[0]
+    np.testing.assert_allclose(xb, ref, rtol=1e-6, atol=1e-8)
