@@ -33,6 +33,15 @@ __device__ __forceinline__ double wave_max(double v) { return __ockl_wfred_max_f
 
 #define PYIPM_BK_ALPHA 0.6403882032022076   /* (1+sqrt(17))/8 */
 
+// Timing experiments on the pivot loop (tools/tile_variants.sh builds extra libraries with -DPYIPM_TILE_EXPERIMENT=bits;
+// any bit set gives WRONG results -- the product build never defines it).  1: no separate pivot-lane path; 2: no
+// reciprocal; 4: the owner wave does not read its pivot row back from LDS; 8: no statistics.
+#ifndef PYIPM_TILE_EXPERIMENT
+#define PYIPM_TILE_EXPERIMENT 0
+#endif
+#define PYIPM_TX_PIVLANE (!(PYIPM_TILE_EXPERIMENT & 1))
+#define PYIPM_TX_RECIP(d_) ((PYIPM_TILE_EXPERIMENT & 2) ? (d_) : pivot_recip(d_))
+
 // 1/d for a pivot: v_rcp_f64 and two Newton steps (r += r (1 - d r)), four dependent fused multiply-adds behind a
 // quarter-rate instruction instead of the ~35-instruction IEEE division sequence -- which sat on the critical path of
 // every one of the N sequential pivots of a factorisation.  Error <= 1 ulp for normal d (the division gives 0.5); pivots
@@ -72,6 +81,7 @@ struct TileScratch {
     double stage[TB][TB + 1];
     double colbuf[2][2][TB];     // [parity][0: column p, 1: column r][row]  (column == row by symmetry)
     double sh_red[4];
+    double dsave[TB];            // the 1x1 pivots as they were used (static ones replaced): statistics are taken at the end
     double pcol[16][TB];         // block steps: the 16 pre-sweep pivot columns one wave publishes for the others
     int pcnt;                    // ... how many are out so far (polled), -1-n once it stopped after n (general path next)
 };
@@ -142,13 +152,21 @@ __device__ __forceinline__ void tile_invert_dev(
     // recovers the unperturbed solution by refinement against the KKT blocks (HipNewtonBackend.direction), or
     // regularises as reghess does when that does not converge (pyipm.py:1379-1403).
     const double pert = static_pivot(anorm_bits);
+    const double ptol = pivtol_rel * cmax0;             // this lane's rejection threshold, should it become the pivot
     const int neg_lim = (int)((neg_from - grow0) < 0 ? 0 : ((neg_from - grow0) > TB ? TB : (neg_from - grow0)));   // pivots >= this: expected negative
     const int nreal = (int)((Nreal - grow0) < 0 ? 0 : ((Nreal - grow0) > TB ? TB : (Nreal - grow0)));   // real rows in this tile
 
     unsigned long long mask = ~0ull;        // unswept set (identical in every thread)
     int left = TB, parity = 0;
-    int neg = 0, zero = 0, n2 = 0, bad = 0;
+    int neg = 0, zero = 0, n2 = 0, bad = 0;         // (2x2 pivots count here directly; 1x1 pivots at the end, from dsave)
     double dmin = 1.0e308, dmax = 0.0;
+    unsigned long long zmask = 0ull, m2mask = 0ull; // static 1x1 pivots; indices taken in 2x2 pivots
+    // (Tried and dropped, r02: "scaled rows" -- every later sweep acts linearly on a swept row, so the pivot lane can keep its
+    //  row unscaled, stay out of its own sweep's update and convert at the boundaries (publish entry x 1/d, scale once at the
+    //  end): one multiply per pivot instead of sixteen in a divergent branch, 996 -> 883 cycles per pivot.  But the replacement
+    //  row p := column p / d is also what RE-SYMMETRISES the working matrix at every pivot; without it the rounding asymmetry
+    //  between a row and its column accumulates, and dense tiles of condition 1e11 lose their inertia
+    //  (tests/test_gpu_condensed.py::test_ill_conditioned_tiles_keep_inertia).  Robustness kept, 10 % not taken.)
 
     // publish column `col` of the tile (== row `col`) from the wave that holds it: one full-wave store
 #define PYIPM_PUBLISH(col_, dst_)                                                            \
@@ -161,20 +179,19 @@ __device__ __forceinline__ void tile_invert_dev(
 #define PYIPM_SWEEP1(pv_, cpi_, cpj_, dpp_)                                                              \
     {                                                                                                    \
         double d = (dpp_);                                                                               \
-        const double ad = fabs(d);                                                                       \
-        const double pivtol = pivtol_rel * readlane_f64(cmax0, (pv_));                                   \
-        if (__builtin_expect(!(ad <= 1.0e308), 0)) bad = 1;          /* NaN or Inf */                    \
-        if (__builtin_expect(ad <= pivtol, 0)) {                                                         \
+        /* rejected?  lane pv_ compares its own entry with its own threshold (one vector compare, no broadcasts) */ \
+        if (__builtin_expect(__ballot(lane == (pv_) && fabs(cpi_) <= ptol) != 0ull, 0)) {                \
+            const double pivtol = readlane_f64(ptol, (pv_));                                             \
             const double t = pivtol > pert ? pivtol : pert;                                              \
             d = ((pv_) < neg_lim) ? t : -t;                      /* static pivot, expected sign */       \
-            if ((pv_) < nreal) { zero++; neg += (d < 0.0) ? 1 : 0; }                                     \
-        } else if ((pv_) < nreal) {                                                                      \
-            neg += (d < 0.0) ? 1 : 0;                                                                    \
-            dmin = fmin(dmin, ad); dmax = fmax(dmax, ad);                                                \
+            zmask |= 1ull << (pv_);                                                                      \
         }                                                                                                \
-        const double inv_d = pivot_recip(d);                                                             \
+        /* sign / magnitude / finiteness of the pivot are counted after the last sweep (10 % of the loop's      \
+           instructions were statistics on wave-uniform values); a wave that is not the column's owner notes it */ \
+        if (!(PYIPM_TILE_EXPERIMENT & 8) && wave == ((((pv_) >> 4) + 1) & 3) && lane == 0) sm.dsave[(pv_)] = d; \
+        const double inv_d = PYIPM_TX_RECIP(d);                                                          \
         const double lpi = (cpi_) * inv_d;                                                               \
-        if (lane == (pv_)) {                                     /* one lane: row p <- cp/d */            \
+        if (PYIPM_TX_PIVLANE && lane == (pv_)) {                 /* one lane: row p <- cp/d */            \
             _Pragma("unroll") for (int c = 0; c < 16; ++c) row[c] = (cpj_)[c] * inv_d;                   \
         } else {                                                                                         \
             _Pragma("unroll") for (int c = 0; c < 16; ++c) row[c] = fma(-lpi, (cpj_)[c], row[c]);        \
@@ -217,7 +234,7 @@ __device__ __forceinline__ void tile_invert_dev(
                 if (lane == 0) pcnt_store(j + 1);                     // LDS keeps a wave's stores in order
                 double cpj[16];                                       // own rows of the column: read back (8 wide reads
                 #pragma unroll                                        // beat 32 readlanes)
-                for (int c = 0; c < 16; ++c) cpj[c] = sm.pcol[j][cb + c];
+                for (int c = 0; c < 16; ++c) cpj[c] = (PYIPM_TILE_EXPERIMENT & 4) ? cpi + c : sm.pcol[j][cb + c];
                 PYIPM_SWEEP1(pv, cpi, cpj, dpp)
             }
             if (n < 16 && lane == 0) pcnt_store(-1 - n);
@@ -286,7 +303,7 @@ __device__ __forceinline__ void tile_invert_dev(
             const double tr = a + cc, disc = sqrt((a - cc) * (a - cc) + 4.0 * b * b);
             const double e1 = 0.5 * (tr + disc), e2 = 0.5 * (tr - disc);
             const double pivtol = pivtol_rel * fmax(readlane_f64(cmax0, p), readlane_f64(cmax0, q));
-            n2++;
+            n2++; m2mask |= (1ull << p) | (1ull << q);
             // a 2x2 block pivot has det < 0 by the BK test: one positive, one negative eigenvalue (e1 >= 0 >= e2)
             neg += 1;
             if (fabs(e1) <= pivtol) zero++; else { dmin = fmin(dmin, fabs(e1)); dmax = fmax(dmax, fabs(e1)); }
@@ -323,6 +340,16 @@ __device__ __forceinline__ void tile_invert_dev(
     #pragma unroll
     for (int c = 0; c < 16; ++c) Tinv[(cb + c) * TB + lane] = -row[c];
     if (dbg && tid == 0) { dbg[0] = clock64() - dbg_c0; dbg[1] = wall_clock64() - dbg_w0; dbg[2] += 1; }
+    __syncthreads();                                     // dsave complete
+    if (wave == 0) {                                     // statistics of the 1x1 pivots: lane p looks at pivot p
+        const double d = sm.dsave[lane], ad = fabs(d);
+        const bool is1 = ((m2mask >> lane) & 1ull) == 0ull, real = lane < nreal, stat = ((zmask >> lane) & 1ull) != 0ull;
+        if (__ballot(is1 && !(ad <= 1.0e308)) != 0ull) bad = 1;                       // NaN or Inf
+        neg += __popcll(__ballot(is1 && real && d < 0.0));                           // static pivots count by their sign
+        zero += __popcll(__ballot(is1 && real && stat));
+        dmin = fmin(dmin, -wave_max((is1 && real && !stat) ? -ad : -1.0e308));
+        dmax = fmax(dmax, wave_max((is1 && real && !stat) ? ad : 0.0));
+    }
     if (tid == 0) {
         // pivot spread of THIS tile ~ cond(T): the explicit inverse is accurate to cond*eps, so only tiles
         // beyond refine_cond (or with 2x2 pivots) pay for refined block solves.  A tile with a rejected pivot
