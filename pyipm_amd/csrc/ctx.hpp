@@ -100,6 +100,16 @@ struct Ctx {
     int fuse_su = 1;                      // ... fused into the previous tile's scaling launch (k_panel_scale + NextUpd): two
                                           // dependent launches per tile on the chain instead of three; same bits
     double* Wnext = nullptr;              // 64 x 64: -S of the next diagonal tile's rows (handed from the tile kernel to that launch)
+    int group_chain = 1;                  // single rank: the panels of a group are chained tile to tile (factor_group), the rows
+                                          // below the group's diagonal block follow on their own stream; same bits
+    hipStream_t rest = nullptr;           // ... that stream (high priority, created on first use)
+    std::vector<hipEvent_t> ev_band;      // panel (by offset in its group): its tiles are inverted and applied inside the diagonal block
+    hipEvent_t ev_join = nullptr, ev_main = nullptr;
+    int head_serial = 0;                  // ... and the bulk update of the group waits for it (instead of running beside it)
+    int head_on_side = 1;                 // the lookahead head runs on the stream of the chain it follows (no stream crossing between
+                                          // a group's chain, the head and the next chain); ordered against the main stream by an event
+    int tile_step = 1;                    // stepped panel schedule (kernels_panel.hpp): one launch per diagonal tile (the rows inside the
+                                          // diagonal block), one for the rows below it; panels of at most 4 tiles; same bits
     int early_head = 1;                   // tail regime: a group's panels except the last update the next group's columns as soon
                                           // as each is factored (beside the chain), so only the last panel's K = nb is left between two chains
     int64_t head32_rows = 6144;           // ... and the lookahead HEAD update (next group's columns, on the critical path between two

@@ -96,7 +96,8 @@ __device__ __forceinline__ void tile_invert_dev(
     DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel,
     const unsigned long long* __restrict__ anorm_bits,   // bits of max |assembled entry| (0 = unknown): scale of a static pivot
     int64_t neg_from,                          // global index from which pivots are expected negative (n + mi; pyipm.py:1381)
-    unsigned long long* __restrict__ dbg)      // diagnostics only (NULL normally)
+    unsigned long long* __restrict__ dbg,      // diagnostics only (NULL normally)
+    bool from_stage = false)                   // the caller has put the tile into sm.stage[i][j] (i >= j at least): no global read
 {
     double (&stage)[TB][TB + 1] = sm.stage;
     double (&colbuf)[2][2][TB] = sm.colbuf;
@@ -107,7 +108,8 @@ __device__ __forceinline__ void tile_invert_dev(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cb = wave * 16;
 
-    {   // coalesced read of the lower triangle: ALL 16 loads of a thread in flight before the first wait (the rolled loop
+    if (!from_stage) {
+        // coalesced read of the lower triangle: ALL 16 loads of a thread in flight before the first wait (the rolled loop
         // waited out one memory latency per trip, on the critical path of the whole factorisation)
         double tmp[TB * TB / 256];
         #pragma unroll

@@ -1,0 +1,243 @@
+// Panel factorisation, "stepped" schedule (round 2): one launch per diagonal tile, one for the rows below.
+//
+// What sits on the critical path of a panel is its 256 x 256 diagonal block: four tile inversions, each needing the
+// tile before it eliminated from its own 64 rows.  The first schedule ran, per tile, an inversion launch and a scaling (+
+// in-panel update) launch over ALL rows below -- two dependent launches per tile, the second one as long as its K loop
+// over the earlier tiles of the panel.  Here the rows are split by what waits for them:
+//   * k_tile_step, launch t: block 0 eliminates tile t-1 from the 64 rows of tile t (one scaling product, one K = 64
+//     update of the diagonal tile, operands from registers) and inverts that tile straight out of shared memory; blocks
+//     1.. do the same right-looking step for the other row tiles INSIDE the diagonal block.  One dependent launch per tile,
+//     four blocks at most.
+//   * k_panel_rest, once per panel: every 64-row strip below the diagonal block runs all (up to four) stages in one
+//     launch (the first schedule went over the slab once per tile, in separate launches that each waited for a tile).
+// Every entry sees the same operations in the same order as before (scaling = the k_panel_scale product and refinement;
+// updates = MFMA groups of 4 columns, ascending): the factor is bit for bit the one of the first schedule.
+#pragma once
+#include "kernels_factor.hpp"
+
+namespace pyipm {
+
+// L = S inv(T) for one 64-row strip (wave: 16 rows x 64 columns), nref refinement steps against T; the arithmetic of
+// k_panel_scale with sign = +1.  X holds inv(T) on entry (staged, synchronised) and on exit; sb = S in the B-operand map.
+__device__ __forceinline__ void strip_scale(double (&X)[TB][TB + 2], const double* __restrict__ Tinv,
+                                            const double* __restrict__ Tsave, int nref, const double (&sb)[16],
+                                            int tid, int l15, int l4, double4_t (&acc)[4])
+{
+    #pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    #pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+        #pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double a = X[t * 16 + l15][ks * 4 + l4];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sb[ks], acc[t], 0, 0, 0);
+        }
+    }
+    for (int it = 0; it < nref; ++it) {
+        __syncthreads();
+        PYIPM_STAGE_TILE(X, -1.0, Tsave)
+        __syncthreads();
+        double4_t res[4];                                            // R = S - L T
+        #pragma unroll
+        for (int t = 0; t < 4; ++t)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) res[t][r] = sb[4 * t + r];
+        #pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const double lop = acc[ks >> 2][ks & 3];
+            #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double a = X[t * 16 + l15][ks * 4 + l4];
+                res[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, lop, res[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        PYIPM_STAGE_TILE(X, 1.0, Tinv)
+        __syncthreads();
+        #pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {                            // L += R inv(T)
+            const double rop = res[ks >> 2][ks & 3];
+            #pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const double a = X[t * 16 + l15][ks * 4 + l4];
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, rop, acc[t], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// C[i][c] += sum_{k < 64} L[i][k] Wn[c][k] for the strip: L from the scaling accumulators (their C/D map is the B-operand
+// map), Wn[c][k] = wn[c + k * ldw] (the -S rows of the target column tile, 64 x 64).
+template <int KS = 8>                     // k-steps (of 4 columns) whose Wn operands are in flight together
+__device__ __forceinline__ void strip_update(double4_t (&c2)[4], const double4_t (&acc)[4], const double* __restrict__ wn,
+                                             int64_t ldw, int l15, int l4)
+{
+    #pragma unroll
+    for (int h = 0; h < 16 / KS; ++h) {
+        double wa[4][KS];
+        #pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            #pragma unroll
+            for (int t = 0; t < 4; ++t) wa[t][ks] = wn[(16 * t + l15) + (int64_t)(4 * (KS * h + ks) + l4) * ldw];
+        #pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const double lop = acc[(KS * h + ks) >> 2][(KS * h + ks) & 3];
+            #pragma unroll
+            for (int t = 0; t < 4; ++t)
+                c2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[t][ks], lop, c2[t], 0, 0, 0);
+        }
+    }
+}
+
+// Launch t of a diagonal block of nt tiles (t = 0 .. nt-1), grid = (nt - t, ny).  Block (b, y) works on row tile t + b.
+//   t = 0: block 0 inverts tile 0; block b > 0 saves -S of its rows in column tile 0 (W, read by the stages that follow).
+//   t > 0: stage t-1 for the rows of tile t + b: L = S inv(T[t-1]) -> A; column tiles t .. t+b of those rows += L Wn'
+//          (the ones with (v - t) % ny == y: a row tile far below the diagonal has many); -S of the now final column tile t
+//          -> W; block 0 (whose only column tile is the diagonal tile t) then inverts it.
+// The diagonal block is a panel's (nt = nb / 64, the per-panel schedule) or a whole group's (factor_group: the panels of a
+// group are then chained tile to tile, and what used to be the pending update between them happens here, stage by stage).
+__global__ __launch_bounds__(256, 2) void k_tile_step(
+    double* __restrict__ A, int64_t ld, int64_t c0, int64_t lc0, int t,      // block: first global / local column; the step
+    double* __restrict__ W, int64_t ldw,                                     // its -S buffer: W[row + k * ldw], k < 64 nt
+    double* __restrict__ Dinv, double* __restrict__ Tsv, double* __restrict__ Tflag,    // of the block's first tile
+    double refine_cond, int nref, DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel,
+    const unsigned long long* __restrict__ anorm_bits, int64_t neg_from, unsigned long long* __restrict__ dbg)
+{
+    __shared__ TileScratch sm;
+    // inv(T[t-1]) for the scaling lives where the tile inversion will put its stage (and the first bytes of colbuf): it is
+    // dead before the diagonal tile is written there
+    static_assert(sizeof(TileScratch) >= sizeof(double) * TB * (TB + 2), "X must fit into the tile scratch");
+    double (&X)[TB][TB + 2] = *reinterpret_cast<double (*)[TB][TB + 2]>(&sm);
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.x, y = blockIdx.y, ny = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t TT = (int64_t)TB * TB;
+    if (b == 0 && y != 0) return;
+    if (t == 0) {
+        if (b == 0) {
+            tile_invert_dev(sm, A, ld, c0, lc0, Dinv, Tsv, Tflag, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg);
+        } else if (y == 0) {
+            double tmp[TB * TB / 256];
+            const int64_t r0 = c0 + (int64_t)b * TB;
+            #pragma unroll
+            for (int q = 0; q < TB * TB / 256; ++q) {
+                const int e = tid + 256 * q;
+                tmp[q] = A[(r0 + (e & 63)) + (lc0 + (e >> 6)) * ld];
+            }
+            #pragma unroll
+            for (int q = 0; q < TB * TB / 256; ++q) {
+                const int e = tid + 256 * q;
+                W[(r0 + (e & 63)) + (int64_t)(e >> 6) * ldw] = -tmp[q];
+            }
+        }
+        return;
+    }
+    const int tp = t - 1, it = t + b;                                // the stage applied; this block's row tile
+    if (y > it - t) return;                                          // fewer column tiles than y-blocks
+    const int64_t i = c0 + (int64_t)it * TB + wave * 16 + l15;        // this lane's (global) row
+    if (nref > 0 && Tflag[tp] == 0.0) nref = 0;
+    PYIPM_STAGE_TILE(X, 1.0, Dinv + tp * TT)
+    double sb[16];
+    #pragma unroll
+    for (int ks = 0; ks < 16; ++ks) sb[ks] = -W[i + (int64_t)(tp * TB + ks * 4 + l4) * ldw];    // S from its saved negative: the
+    __syncthreads();                                     // y-blocks of a row tile all need it, and block y = 0 overwrites A with L
+    double4_t acc[4];
+    strip_scale(X, Dinv + tp * TT, Tsv + tp * TT, nref, sb, tid, l15, l4, acc);
+    if (y == 0) {
+        double gmax = 0.0;
+        #pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                A[i + (lc0 + tp * TB + tt * 16 + l4 + 4 * r) * ld] = acc[tt][r];
+                gmax = fmax(gmax, fabs(acc[tt][r]));
+            }
+        gmax = wave_max(gmax);
+        if (lane == 0) atomicMax(&st->growth_bits, (unsigned long long)__double_as_longlong(gmax));
+    }
+    if (b == 0) __syncthreads();                                     // every wave is done with X: the tile goes where it was
+    for (int v = t + y; v <= it; v += ny) {
+        double4_t c2[4];
+        #pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) c2[tt][r] = A[i + (lc0 + v * TB + tt * 16 + l4 + 4 * r) * ld];
+        strip_update(c2, acc, W + (c0 + (int64_t)v * TB) + (int64_t)(tp * TB) * ldw, ldw, l15, l4);
+        #pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = tt * 16 + l4 + 4 * r;
+                A[i + (lc0 + v * TB + c) * ld] = c2[tt][r];
+                if (b == 0) sm.stage[wave * 16 + l15][c] = c2[tt][r];             // (v == t == it: the diagonal tile)
+                else if (v == t) W[i + (int64_t)(t * TB + c) * ldw] = -c2[tt][r];
+            }
+    }
+    if (b == 0)
+        tile_invert_dev(sm, A, ld, c0 + (int64_t)t * TB, lc0 + (int64_t)t * TB, Dinv + t * TT, Tsv + t * TT, Tflag + t, refine_cond,
+                        st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg, /*from_stage=*/true);
+}
+
+// The rows below the diagonal block, 64 per block: all nt stages of the strip in one launch, right-looking.  The column
+// tile a stage scales is the last one the stage before it updated and stays in registers in between; the other column
+// tiles of the strip's 64 x 256 slab go through L2 (a whole slab in registers -- 128 of them -- plus the operands of the
+// refinement needs more than the 256 registers a strip can have if it is to fit beside a resident block of the bulk
+// update; the launch would then wait for whole CUs to drain).
+__global__ __launch_bounds__(256, 2) void k_panel_rest(
+    double* __restrict__ A, int64_t ld, int64_t c0, int64_t lc0, int nt, int64_t row_begin,
+    double* __restrict__ W, int64_t ldw,
+    const double* __restrict__ Dinv, const double* __restrict__ Tsv, const double* __restrict__ Tflag, int nref,
+    int64_t hole0, int64_t hole1, unsigned long long* __restrict__ growth_bits)
+{
+    __shared__ double X[TB][TB + 2];
+    const int64_t r0 = row_begin + (int64_t)blockIdx.x * TB;
+    if (r0 >= hole0 && r0 + TB <= hole1) return;          // rows identically zero (KKT structure): L = 0 already, W never read
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t TT = (int64_t)TB * TB;
+    const int64_t i = r0 + wave * 16 + l15;
+    double sb[16];                                         // S of the stage's column tile, B-operand map
+    #pragma unroll
+    for (int ks = 0; ks < 16; ++ks) sb[ks] = A[i + (lc0 + ks * 4 + l4) * ld];
+    double gmax = 0.0;
+    for (int t = 0; t < nt; ++t) {
+        if (t > 0) __syncthreads();                        // everyone is done with the previous inv(T)
+        PYIPM_STAGE_TILE(X, 1.0, Dinv + t * TT)
+        #pragma unroll
+        for (int ks = 0; ks < 16; ++ks) W[i + (int64_t)(t * TB + ks * 4 + l4) * ldw] = -sb[ks];
+        __syncthreads();
+        const int nr = (nref > 0 && Tflag[t] != 0.0) ? nref : 0;
+        double4_t acc[4];
+        strip_scale(X, Dinv + t * TT, Tsv + t * TT, nr, sb, tid, l15, l4, acc);
+        #pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                A[i + (lc0 + t * TB + tt * 16 + l4 + 4 * r) * ld] = acc[tt][r];
+                gmax = fmax(gmax, fabs(acc[tt][r]));
+            }
+        for (int v = nt - 1; v > t; --v) {                 // (independent entries: any order of the column tiles gives the same bits)
+            double4_t c2[4];
+            #pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) c2[tt][r] = A[i + (lc0 + v * TB + tt * 16 + l4 + 4 * r) * ld];
+            strip_update<4>(c2, acc, W + (c0 + (int64_t)v * TB) + (int64_t)(t * TB) * ldw, ldw, l15, l4);
+            if (v == t + 1) {                              // the next stage's tile: C/D map == B-operand map, stays in registers
+                #pragma unroll
+                for (int ks = 0; ks < 16; ++ks) sb[ks] = c2[ks >> 2][ks & 3];
+            } else {
+                #pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+                    #pragma unroll
+                    for (int r = 0; r < 4; ++r) A[i + (lc0 + v * TB + tt * 16 + l4 + 4 * r) * ld] = c2[tt][r];
+            }
+        }
+    }
+    gmax = wave_max(gmax);
+    if (lane == 0 && growth_bits) atomicMax(growth_bits, (unsigned long long)__double_as_longlong(gmax));
+}
+
+}  // namespace pyipm

@@ -2,8 +2,11 @@
 // gfx950 only; no CUDA path, no CPU fallback.  Host-side orchestration of the HIP kernels in
 // kernels_*.hpp.  Replaces /root/reference/pyipm.py:1717-1725 (see the header for the mapping).
 #include "ctx.hpp"
+#include <algorithm>
+#include <functional>
 #include "kernels_assemble.hpp"
 #include "kernels_factor.hpp"
+#include "kernels_panel.hpp"
 #include "kernels_solve.hpp"
 #include "kernels_batched.hpp"
 
@@ -16,6 +19,7 @@ static void quiesce_noexcept(Ctx* c) noexcept {
     try {
         if (c->side) hipStreamSynchronize(c->side);
         if (c->fwd) hipStreamSynchronize(c->fwd);
+        if (c->rest) hipStreamSynchronize(c->rest);
         if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
         c->factored = false; c->forward_pending = false; c->forward_fused = false;
     } catch (...) {}
@@ -375,6 +379,25 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
         panel_hole(ctx, p, &hole0, &hole1);             // per-panel mode (any number of ranks)
         if (hole1 > hole0) active_ranges(ctx, c0, c0 + nbw, &ha0, &ha1, &hb0, &hb1);
     }
+    if (ctx->tile_step && ctx->inpanel32 && nt <= 4) {
+        // stepped schedule: launch t inverts tile t (after eliminating tile t - 1 from the rows of the diagonal block), one
+        // more launch runs all stages for the rows below the diagonal block
+        double* Dv = ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB);
+        double* Ts = ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB);
+        for (int t = 0; t < nt; ++t) {
+            hipLaunchKernelGGL(k_tile_step, dim3((unsigned)(nt - t)), dim3(256), 0, stream, ctx->A, g.Npad, c0, lc0, t, W, g.Npad,
+                               Dv, Ts, ctx->Tflag + c0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats, g.N, ctx->pivtol_rel,
+                               ctx->anorm, g.n + g.mi, ctx->dbg_buf);
+            PYIPM_KCHECK();
+        }
+        const int64_t rb = c0 + nbw;
+        if (g.Npad > rb) {
+            hipLaunchKernelGGL(k_panel_rest, dim3((unsigned)((g.Npad - rb) / TB)), dim3(256), 0, stream, ctx->A, g.Npad, c0, lc0, nt, rb,
+                               W, g.Npad, Dv, Ts, ctx->Tflag + c0 / TB, ctx->block_refine, hole0, hole1, &ctx->dstats->growth_bits);
+            PYIPM_KCHECK();
+        }
+        return 0;
+    }
     const bool fused = ctx->fuse_su && ctx->inpanel32;      // a tile's scaling launch also updates the next column block
     for (int t = 0; t < nt; ++t) {
         const int64_t j0 = c0 + (int64_t)t * TB, lcol = lc0 + (int64_t)t * TB;
@@ -419,6 +442,87 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
                                ctx->Tflag + j0 / TB, ctx->block_refine, j0 + TB, hole0, hole1, &ctx->dstats->growth_bits, 1.0, nu);
             PYIPM_KCHECK();
         }
+    }
+    return 0;
+}
+
+// One group of panels of the single-rank schedule, chained tile to tile (kernels_panel.hpp).  The diagonal block of the
+// WHOLE group (n0 * nb columns) runs as one sequence of k_tile_step launches on `chain`: a tile waits for nothing but the
+// tile before it, and what the per-panel schedule did between two panels of a group (the pending update of the next
+// panel's columns, the scaling of all rows below) no longer sits between two tile inversions.  The rows below the
+// diagonal block follow on ctx->rest, panel by panel: all stages of the panel (k_panel_rest), then the panel's
+// contribution to the later panels of the group (right-looking: the pending update, one source panel at a time --
+// the same products in the same order).  on_done(q, stream): panel q is complete once `stream` reaches this point.
+int factor_group(Ctx* ctx, int64_t p0, int64_t n0, hipStream_t chain, const std::function<int(int64_t, hipStream_t)>& on_done) {
+    const Geo& g = ctx->g;
+    std::vector<int> toff((size_t)n0 + 1, 0);           // first tile of each panel inside the group (the matrix's last panel may be narrower)
+    for (int64_t k = 0; k < n0; ++k) toff[(size_t)k + 1] = toff[(size_t)k] + (int)(g.panel_w(p0 + k) / TB);
+    const int nT = toff[(size_t)n0];
+    const int64_t gc0 = g.panel_c0(p0), glc0 = g.local_c0(p0), gend = gc0 + (int64_t)nT * TB;
+    const int64_t TT = (int64_t)TB * TB;
+    if (!ctx->rest) {
+        int lo = 0, hi = 0;
+        PYIPM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        PYIPM_HIP(hipStreamCreateWithPriority(&ctx->rest, hipStreamNonBlocking, hi));
+    }
+    if (!ctx->ev_join) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    while ((int64_t)ctx->ev_band.size() < n0) { hipEvent_t e; PYIPM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_band.push_back(e); }
+    double* Wg = wbuf(ctx, p0);
+    double* Dv = ctx->Dinv + (gc0 / TB) * TT;
+    double* Ts = ctx->Tsv + (gc0 / TB) * TT;
+    for (int j = 0, kp = 1; j < nT; ++j) {
+        int ny = (nT - j + 4) / 5; if (ny < 1) ny = 1; if (ny > 4) ny = 4;     // <= ~5 column tiles per block
+        hipLaunchKernelGGL(k_tile_step, dim3((unsigned)(nT - j), (unsigned)ny), dim3(256), 0, chain, ctx->A, g.Npad, gc0, glc0, j,
+                           Wg, g.Npad, Dv, Ts, ctx->Tflag + gc0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats, g.N,
+                           ctx->pivtol_rel, ctx->anorm, g.n + g.mi, ctx->dbg_buf);
+        PYIPM_KCHECK();
+        // panel q's columns are final inside the diagonal block once the first tile of panel q + 1 has applied its last stage
+        if (kp < n0 && j == toff[(size_t)kp]) { PYIPM_HIP(hipEventRecord(ctx->ev_band[(size_t)(kp - 1)], chain)); ++kp; }
+    }
+    const size_t gi = (size_t)ctx->grp_of[(size_t)p0];
+    const bool grp_in_x = !ctx->grp_x.empty() && ctx->grp_x[gi];
+    for (int64_t k = 0; k < n0; ++k) {
+        const int64_t q = p0 + k, c0 = g.panel_c0(q), lc0 = g.local_c0(q);
+        const int nt = (int)(g.panel_w(q) / TB);
+        // the last panel's rows are what the next group waits for: they stay on the chain's stream (a dependency across
+        // streams costs 10-30 us when the waiting side is idle), behind the other panels' work on ctx->rest
+        hipStream_t rs = ctx->rest;
+        if (k + 1 == n0) {
+            PYIPM_HIP(hipEventRecord(ctx->ev_join, ctx->rest));
+            PYIPM_HIP(hipStreamWaitEvent(chain, ctx->ev_join, 0));
+            rs = chain;
+        } else {
+            PYIPM_HIP(hipStreamWaitEvent(ctx->rest, ctx->ev_band[(size_t)k], 0));
+        }
+        if (g.Npad > gend) {
+            int64_t hole0 = 0, hole1 = 0;
+            if (ctx->skip_zeros && g.mi > 0 && grp_in_x) {
+                hole0 = (g.n + BM - 1) / BM * BM; hole1 = (g.n + g.mi) / BM * BM;
+                if (hole1 < hole0) hole1 = hole0;
+            }
+            hipLaunchKernelGGL(k_panel_rest, dim3((unsigned)((g.Npad - gend) / TB)), dim3(256), 0, rs, ctx->A, g.Npad, c0, lc0, nt,
+                               gend, wbuf(ctx, q), g.Npad, ctx->Dinv + (c0 / TB) * TT, ctx->Tsv + (c0 / TB) * TT, ctx->Tflag + c0 / TB,
+                               ctx->block_refine, hole0, hole1, &ctx->dstats->growth_bits);
+            PYIPM_KCHECK();
+            if (k + 1 < n0) {
+                // this panel's contribution to the later panels of the group, rows below the diagonal block
+                const int K = (int)g.panel_w(q);
+                const int64_t tc0 = g.panel_c0(q + 1), ncols = (int64_t)(nT - toff[(size_t)k + 1]) * TB;
+                if (g.Npad - tc0 <= ctx->pending32_rows) {
+                    int64_t pa0, pa1, pb0, pb1;
+                    active_ranges(ctx, c0, c0 + K, &pa0, &pa1, &pb0, &pb1);
+                    hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - gend) / 32), (unsigned)(ncols / TB)), dim3(256), 0,
+                                       rs, ctx->A, g.Npad, g.local_c0(q + 1), ctx->A + lc0 * g.Npad, g.Npad, wbuf(ctx, q), g.Npad,
+                                       tc0, K, gend, g.Npad, pa0, pa1, pb0, pb1, ctx->side_prio);
+                    PYIPM_KCHECK();
+                } else {
+                    int rc = launch_update128(ctx, rs, ctx->A + lc0 * g.Npad, g.Npad, wbuf(ctx, q), K, gend, q + 1, n0 - 1 - k,
+                                              /*bulk=*/false, 0, 0, 0, c0);
+                    if (rc) return rc;
+                }
+            }
+        }
+        int rc = on_done(q, rs); if (rc) return rc;
     }
     return 0;
 }
@@ -519,11 +623,21 @@ int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
     PYIPM_HIP(hipMemcpyAsync(&z, ctx->dstats, sizeof(z), hipMemcpyDeviceToHost, ctx->stream));
     PYIPM_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->profile) {
-        double ms = 0.0;
+        // time during which SOME update launch ran: the launches of the main stream are serial, a lookahead head on the
+        // side stream may overlap the bulk update that follows it -- union of the intervals, not their sum
+        std::vector<std::pair<float, float>> iv;
         for (int64_t i = 0; i < ctx->n_trailing; ++i) {
-            float t = 0.f;
-            PYIPM_HIP(hipEventElapsedTime(&t, ctx->ev_trailing[i].first, ctx->ev_trailing[i].second));
-            ms += t;
+            float a = 0.f, d = 0.f;
+            PYIPM_HIP(hipEventElapsedTime(&a, ctx->ev_trailing[0].first, ctx->ev_trailing[i].first));
+            PYIPM_HIP(hipEventElapsedTime(&d, ctx->ev_trailing[i].first, ctx->ev_trailing[i].second));
+            iv.push_back({a, a + d});
+        }
+        std::sort(iv.begin(), iv.end());
+        double ms = 0.0; float hi = -1.0e30f;
+        for (auto& x : iv) {
+            if (x.second <= hi) continue;
+            ms += x.second - (x.first > hi ? x.first : hi);
+            hi = x.second;
         }
         ctx->t_trailing = ms;
     }
@@ -887,10 +1001,29 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         int r2 = fwd_panel(ctx, q, ctx->fwd_vec, ctx->fwd); if (r2) return r2;
         return diag_panel(ctx, q, ctx->fwd_vec, ctx->fwd);
     };
-    for (int64_t q = 0; q < gsize(0); ++q) {
-        rc = factor_panel(ctx, q, ctx->stream, true); if (rc) return rc;
-        rc = after_panel(q, ctx->stream); if (rc) return rc;
-    }
+    // all panels of one group on stream S; with_early: every panel but the last records the event its early head waits for
+    auto run_group = [&](int64_t grp, hipStream_t S, bool with_early) -> int {
+        const int64_t pA = ctx->grp_first[(size_t)grp], nA = gsize(grp);
+        auto done = [&](int64_t q, hipStream_t used) -> int {
+            int r2 = after_panel(q, used); if (r2) return r2;
+            if (with_early && q + 1 < pA + nA) {
+                while (ctx->ev_early.size() <= (size_t)(q - pA)) {
+                    hipEvent_t e; PYIPM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_early.push_back(e);
+                }
+                PYIPM_HIP(hipEventRecord(ctx->ev_early[(size_t)(q - pA)], used));
+            }
+            return 0;
+        };
+        const bool fast = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)grp];
+        if (ctx->group_chain && ctx->inpanel32 && !fast && nA * (g.nb / TB) <= 32 && g.nb % 128 == 0)
+            return factor_group(ctx, pA, nA, S, done);
+        for (int64_t q = pA; q < pA + nA; ++q) {
+            int r2 = factor_panel(ctx, q, S, true); if (r2) return r2;
+            r2 = done(q, S); if (r2) return r2;
+        }
+        return 0;
+    };
+    rc = run_group(0, ctx->stream, false); if (rc) return rc;
     std::vector<char> early((size_t)np, 0);       // panel's contribution to the NEXT group's columns already applied
     for (int64_t grp = 0; grp + 1 < ngroups; ++grp) {
         const int64_t p0 = ctx->grp_first[(size_t)grp], n0 = gsize(grp), p1 = p0 + n0, n1 = gsize(grp + 1);
@@ -899,7 +1032,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             // contribution an early head has not applied yet (see below).
             const int64_t hc0 = g.panel_c0(p1);
             const bool fast_src = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)grp];
-            auto head_from = [&](int64_t q0, int64_t nq, int64_t tp, int64_t tn) -> int {
+            auto head_from = [&](int64_t q0, int64_t nq, int64_t tp, int64_t tn, hipStream_t hs) -> int {
                 const int64_t tc0 = g.panel_c0(tp);
                 if (ctx->inpanel32 && !fast_src && g.Npad - tc0 <= ctx->head32_rows) {
                     int K = 0; int64_t cols = 0;
@@ -909,53 +1042,58 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
                     active_ranges(ctx, g.panel_c0(q0), g.panel_c0(q0) + K, &pa0, &pa1, &pb0, &pb1);
                     // W of a panel inside its group's buffer: wbuf(q0) addresses it (column offset of q0 in the group)
                     hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - tc0) / 32), (unsigned)(cols / TB)), dim3(256), 0,
-                                       ctx->stream, ctx->A, g.Npad, g.local_c0(tp), ctx->A + g.local_c0(q0) * g.Npad, g.Npad,
+                                       hs, ctx->A, g.Npad, g.local_c0(tp), ctx->A + g.local_c0(q0) * g.Npad, g.Npad,
                                        wbuf(ctx, q0), g.Npad, tc0, K, tc0, g.Npad, pa0, pa1, pb0, pb1, ctx->side_prio);
                     PYIPM_KCHECK();
                     return 0;
                 }
-                return timed_update(ctx, q0, nq, tp, tn);
+                return timed_update(ctx, q0, nq, tp, tn, hs);
             };
+            // The head follows the chain of this group on ITS stream when that is the side stream (every group but the first):
+            // chain -> head -> next chain then never cross streams.  It touches the columns the bulk update of the group before
+            // (and the early heads) touched on the main stream: ordered by one event, normally long complete.
+            hipStream_t hs = ctx->stream;
+            if (grp > 0 && ctx->head_on_side) {
+                if (!ctx->ev_main) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+                PYIPM_HIP(hipEventRecord(ctx->ev_main, ctx->stream));
+                PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_main, 0));
+                hs = ctx->side;
+            }
             {
                 int64_t q = p0;
                 while (q < p0 + n0 && early[(size_t)q]) ++q;                       // applied early (always a prefix of the group)
-                if (q < p0 + n0) { rc = head_from(q, p0 + n0 - q, p1, n1); if (rc) return rc; }
+                if (q < p0 + n0) { rc = head_from(q, p0 + n0 - q, p1, n1, hs); if (rc) return rc; }
             }
             (void)hc0;
-            PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
-            PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_head, 0));
+            if (hs == ctx->stream) {
+                PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
+                PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_head, 0));
+            } else if (ctx->head_serial) {
+                // the bulk update of this group starts behind the head instead of beside it (the head is what the next chain
+                // waits for; sharing the GPU with the bulk launch stretches it)
+                PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->side));
+                PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_head, 0));
+            }
             // early heads: in the tail regime the panels of the NEXT group except its last one update the group after it
             // as soon as each is factored, on the main stream behind this group's bulk update
             const bool nxt_fast = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)(grp + 1)];
             const bool do_early = ctx->early_head && grp + 2 < ngroups && n1 >= 2 && !nxt_fast && !fast_src &&
                                   g.Npad - g.panel_c0(p1) <= ctx->tail_cols;
-            for (int64_t q = p1; q < p1 + n1; ++q) {
-                rc = factor_panel(ctx, q, ctx->side, true); if (rc) return rc;
-                rc = after_panel(q, ctx->side); if (rc) return rc;
-                if (do_early && q + 1 < p1 + n1) {
-                    while (ctx->ev_early.size() <= (size_t)(q - p1)) {
-                        hipEvent_t e; PYIPM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_early.push_back(e);
-                    }
-                    PYIPM_HIP(hipEventRecord(ctx->ev_early[(size_t)(q - p1)], ctx->side));
-                }
-            }
+            rc = run_group(grp + 1, ctx->side, do_early); if (rc) return rc;
             PYIPM_HIP(hipEventRecord(ctx->ev_panel, ctx->side));
             rc = timed_update(ctx, p0, n0, p1 + n1, np - (p1 + n1)); if (rc) return rc;   // bulk (overlaps the side stream)
             if (do_early) {
                 const int64_t p2 = p1 + n1, n2 = gsize(grp + 2);
                 for (int64_t q = p1; q + 1 < p1 + n1; ++q) {
                     PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_early[(size_t)(q - p1)], 0));
-                    rc = head_from(q, 1, p2, n2); if (rc) return rc;
+                    rc = head_from(q, 1, p2, n2, ctx->stream); if (rc) return rc;
                     early[(size_t)q] = 1;
                 }
             }
             PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
         } else {
             rc = timed_update(ctx, p0, n0, p1, np - p1); if (rc) return rc;
-            for (int64_t q = p1; q < p1 + n1; ++q) {
-                rc = factor_panel(ctx, q, ctx->stream, true); if (rc) return rc;
-                rc = after_panel(q, ctx->stream); if (rc) return rc;
-            }
+            rc = run_group(grp + 1, ctx->stream, false); if (rc) return rc;
         }
     }
     if (fuse_forward) {                     // join: the main stream continues after the forward pass
@@ -1164,7 +1302,11 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     dist_free(ctx);
     if (ctx->side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); }
     if (ctx->fwd) { hipStreamSynchronize(ctx->fwd); hipStreamDestroy(ctx->fwd); }
+    if (ctx->rest) { hipStreamSynchronize(ctx->rest); hipStreamDestroy(ctx->rest); }
     if (ctx->ev_fwd) hipEventDestroy(ctx->ev_fwd);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_main) hipEventDestroy(ctx->ev_main);
+    for (auto e : ctx->ev_band) hipEventDestroy(e);
     for (auto e : ctx->ev_done) hipEventDestroy(e);
     for (auto e : ctx->ev_early) hipEventDestroy(e);
     if (ctx->stg_d2L) hipFree(ctx->stg_d2L);
@@ -1748,6 +1890,10 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     { bool handled = false; int rc = dist_set_option(ctx, name, value, &handled); if (handled) return rc; }
     if (!strcmp(name, "inpanel32")) { ctx->inpanel32 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "fuse_scale_update")) { ctx->fuse_su = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "tile_step")) { ctx->tile_step = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "group_chain")) { ctx->group_chain = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "head_on_side")) { ctx->head_on_side = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "head_serial")) { ctx->head_serial = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "early_head")) { ctx->early_head = (int)value != 0; return PYIPM_OK; }
