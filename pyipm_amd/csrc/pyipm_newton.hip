@@ -1054,9 +1054,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             // (and the early heads) touched on the main stream: ordered by one event, normally long complete.
             hipStream_t hs = ctx->stream;
             if (grp > 0 && ctx->head_on_side) {
-                if (!ctx->ev_main) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
-                PYIPM_HIP(hipEventRecord(ctx->ev_main, ctx->stream));
-                PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_main, 0));
+                PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_main, 0));    // (recorded at the end of the iteration before)
                 hs = ctx->side;
             }
             {
@@ -1090,6 +1088,11 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
                     early[(size_t)q] = 1;
                 }
             }
+            // what the next head must not overtake on the main stream: this group's bulk update and the early heads -- recorded
+            // BEFORE the main stream starts waiting for the side stream (the head would otherwise wait for its own stream,
+            // two stream crossings for nothing)
+            if (!ctx->ev_main) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+            PYIPM_HIP(hipEventRecord(ctx->ev_main, ctx->stream));
             PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
         } else {
             rc = timed_update(ctx, p0, n0, p1, np - p1); if (rc) return rc;

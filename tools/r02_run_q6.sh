@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r02q; mkdir -p $O
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d $R/$O/prof -o c2 -- python $R/bench.py --no-cpu-baseline --nvar 2048 --neq 0 --nineq 2048 --steps 3 --warmup 2 $@ > $R/$O/c2.json 2> $R/$O/c2.err
+cd $R
+DB=$(find $O/prof -name "*.db" | head -1)
+python tools/chain_timeline.py $DB 500 $O/c2_timeline.txt
+rm -rf $O/prof
