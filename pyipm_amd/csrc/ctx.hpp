@@ -90,7 +90,7 @@ struct Ctx {
     std::map<std::vector<int64_t>, TileList> tile_lists;   // compact tile orders of the bulk launches (geometry repeats every step)
     int skip_zeros = 1;                   // trailing updates skip tiles that the KKT block structure makes exact zeros
     int group = 1;                        // panels per bulk trailing update
-    int tail_group = 2;                   // group size once at most tail_cols columns remain: there the panel chain outlasts
+    int tail_group = 4;                   // group size once at most tail_cols columns remain: there the panel chain outlasts
     int64_t tail_cols = 24576;            // the bulk update, and shorter groups move in-group update work off the chain
     std::vector<int> grp_of, grp_off;     // per panel: group id and offset inside the group (built by factor_all)
     std::vector<int64_t> grp_first;       // per group: first panel (+ one past the last group)
@@ -108,6 +108,7 @@ struct Ctx {
     int head_serial = 0;                  // ... and the bulk update of the group waits for it (instead of running beside it)
     int head_on_side = 1;                 // the lookahead head runs on the stream of the chain it follows (no stream crossing between
                                           // a group's chain, the head and the next chain); ordered against the main stream by an event
+    int bwd_diag4 = 1;                    // in-panel backward substitution on 1024 threads through shared memory (k_bwd_diag4)
     int tile_step = 1;                    // stepped panel schedule (kernels_panel.hpp): one launch per diagonal tile (the rows inside the
                                           // diagonal block), one for the rows below it; panels of at most 4 tiles; same bits
     int early_head = 1;                   // tail regime: a group's panels except the last update the next group's columns as soon

@@ -174,6 +174,70 @@ __global__ void k_bwd_diag(const double* __restrict__ A, int64_t ld, int64_t lc0
     v[c0 + tid] = x[tid];
 }
 
+// In-panel backward substitution on 1024 threads (panels of at most 4 tiles).  k_bwd_diag lets thread k walk down column k
+// of every tile -- 64 loads per step that no other thread shares a cache line with, three dependent steps: ~9 us, half of
+// the backward sweep.  Here the six in-panel tiles are requested up front, coalesced (lane = row), and go through shared
+// memory once per step, where thread (column j, row quarter q) reads them transposed: a step is 16 multiply-adds and two
+// barriers.  (A first attempt -- one launch per panel with the far-row dots of the NEXT panel riding along, wave w reducing
+// 64 rows of column w, w + 16, ... -- took 20-50 us per launch: 52 wave reductions per wave are ~9 us of DPP traffic
+// alone, and 1024-thread dot blocks stream at half the rate of k_bwd_dot's.)
+__global__ __launch_bounds__(1024) void k_bwd_diag4(const double* __restrict__ A, int64_t ld, int64_t lc0, int64_t c0,
+                                                    int nbw, int nb, const double* __restrict__ part, int nchunk,
+                                                    double* __restrict__ v, int64_t vstride, int64_t pstride)
+{
+    __shared__ double Ls[3][TB][TB + 1];             // the tiles of the current step, [t][i][j]
+    __shared__ double x[4 * TB], ps[4][4 * TB];
+    const int tid = threadIdx.x, k = tid & 255, q = tid >> 8;
+    v += (int64_t)blockIdx.y * vstride;
+    part += (int64_t)blockIdx.y * pstride;
+    const int nt = nbw / TB;
+    // tiles (u, t), t < u <= 3, in the order (1,0) (2,0) (2,1) (3,0) (3,1) (3,2); element e = tid + 1024 r: row e & 63, column e >> 6
+    double lt[6][4];
+    {
+        int idx = 0;
+        #pragma unroll
+        for (int u = 1; u <= 3; ++u)
+            #pragma unroll
+            for (int t = 0; t < u; ++t, ++idx)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int e = tid + 1024 * r;
+                    lt[idx][r] = (u < nt) ? A[(c0 + (int64_t)u * TB + (e & 63)) + (lc0 + t * TB + (e >> 6)) * ld] : 0.0;
+                }
+    }
+    {   // partial sums of the rows below: four interleaved chains per column, combined in a fixed order
+        double t = 0.0;
+        if (k < nbw) for (int c = q; c < nchunk; c += 4) t += part[(int64_t)c * nb + k];
+        ps[q][k] = t;
+    }
+    __syncthreads();
+    if (tid < nbw) x[tid] = v[c0 + tid] - ((ps[0][tid] + ps[1][tid]) + (ps[2][tid] + ps[3][tid]));
+    #pragma unroll
+    for (int u = 3; u >= 1; --u) {
+        if (u < nt) {
+            const int base = u * (u - 1) / 2;              // first tile of step u in lt[]
+            #pragma unroll
+            for (int t = 0; t < 3; ++t)
+                if (t < u) {
+                    #pragma unroll
+                    for (int r = 0; r < 4; ++r) { const int e = tid + 1024 * r; Ls[t][e & 63][e >> 6] = lt[base + t][r]; }
+                }
+            __syncthreads();                                // tiles staged, x of tile u final
+            double acc = 0.0;
+            if (k < u * TB) {
+                const int t = k >> 6, j = k & 63;
+                #pragma unroll
+                for (int i = 0; i < 16; ++i) acc = fma(Ls[t][16 * q + i][j], x[u * TB + 16 * q + i], acc);
+            }
+            ps[q][k] = acc;
+            __syncthreads();
+            if (tid < u * TB) x[tid] -= (ps[0][tid] + ps[1][tid]) + (ps[2][tid] + ps[3][tid]);
+        }
+    }
+    __syncthreads();
+    if (tid < nbw) v[c0 + tid] = x[tid];
+}
+
 // (Tried and dropped, r02, to shorten the backward sweep -- 2.6 ms exposed at N = 32768, 128 x (k_bwd_dot 9 us + k_bwd_diag 11 us):
 //  (a) dots and in-panel block in ONE launch with an arrival counter: the few fat blocks that keep the atomics cheap stream
 //      at a fraction of k_bwd_dot's rate, 8.1 ms;  (b) the in-panel recursion replaced by a dense product with the inverse

@@ -695,8 +695,12 @@ int bwd_panel(Ctx* ctx, int64_t p, double* v, int nrhs = 1, int64_t vstride = 0,
                            c0 + nbw, g.Npad, v, part, vstride, pstride);
         PYIPM_KCHECK();
     }
-    hipLaunchKernelGGL(k_bwd_diag, dim3(1, nrhs), dim3(nbw), nbw * sizeof(double), ctx->stream, ctx->A, g.Npad, lc0, c0, nbw,
-                       g.nb, part, nchunk, v, vstride, pstride);
+    if (ctx->bwd_diag4 && nbw <= 4 * TB)
+        hipLaunchKernelGGL(k_bwd_diag4, dim3(1, nrhs), dim3(1024), 0, ctx->stream, ctx->A, g.Npad, lc0, c0, nbw,
+                           g.nb, part, nchunk, v, vstride, pstride);
+    else
+        hipLaunchKernelGGL(k_bwd_diag, dim3(1, nrhs), dim3(nbw), nbw * sizeof(double), ctx->stream, ctx->A, g.Npad, lc0, c0, nbw,
+                           g.nb, part, nchunk, v, vstride, pstride);
     PYIPM_KCHECK();
     return 0;
 }
@@ -1895,6 +1899,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "fuse_scale_update")) { ctx->fuse_su = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile_step")) { ctx->tile_step = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "group_chain")) { ctx->group_chain = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "bwd_diag4")) { ctx->bwd_diag4 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "head_on_side")) { ctx->head_on_side = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "head_serial")) { ctx->head_serial = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
