@@ -105,6 +105,7 @@ struct Ctx {
     hipStream_t rest = nullptr;           // ... that stream (high priority, created on first use)
     std::vector<hipEvent_t> ev_band;      // panel (by offset in its group): its tiles are inverted and applied inside the diagonal block
     hipEvent_t ev_join = nullptr, ev_main = nullptr;
+    int fast_on_main = 1;                 // groups inside the slack block (closed form) run on the main stream, not through the lookahead
     int head_serial = 0;                  // ... and the bulk update of the group waits for it (instead of running beside it)
     int head_on_side = 1;                 // the lookahead head runs on the stream of the chain it follows (no stream crossing between
                                           // a group's chain, the head and the next chain); ordered against the main stream by an event

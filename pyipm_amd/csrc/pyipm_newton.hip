@@ -379,13 +379,14 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
         panel_hole(ctx, p, &hole0, &hole1);             // per-panel mode (any number of ranks)
         if (hole1 > hole0) active_ranges(ctx, c0, c0 + nbw, &ha0, &ha1, &hb0, &hb1);
     }
-    if (ctx->tile_step && ctx->inpanel32 && nt <= 4) {
+    if (ctx->tile_step && ctx->inpanel32 && nt <= 16) {
         // stepped schedule: launch t inverts tile t (after eliminating tile t - 1 from the rows of the diagonal block), one
         // more launch runs all stages for the rows below the diagonal block
         double* Dv = ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB);
         double* Ts = ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB);
         for (int t = 0; t < nt; ++t) {
-            hipLaunchKernelGGL(k_tile_step, dim3((unsigned)(nt - t)), dim3(256), 0, stream, ctx->A, g.Npad, c0, lc0, t, W, g.Npad,
+            int ny = (nt - t + 4) / 5; if (ny < 1) ny = 1; if (ny > 4) ny = 4;
+            hipLaunchKernelGGL(k_tile_step, dim3((unsigned)(nt - t), (unsigned)ny), dim3(256), 0, stream, ctx->A, g.Npad, c0, lc0, t, W, g.Npad,
                                Dv, Ts, ctx->Tflag + c0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats, g.N, ctx->pivtol_rel,
                                ctx->anorm, g.n + g.mi, ctx->dbg_buf);
             PYIPM_KCHECK();
@@ -1056,8 +1057,13 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             // The head follows the chain of this group on ITS stream when that is the side stream (every group but the first):
             // chain -> head -> next chain then never cross streams.  It touches the columns the bulk update of the group before
             // (and the early heads) touched on the main stream: ordered by one event, normally long complete.
+            // A next group inside the slack block is a handful of microsecond launches (closed form): it runs on the main stream,
+            // head included -- sending it through the side stream cost two stream crossings per group, 50-240 us each time for
+            // 30 us of work (config 2: 0.6 of 3.6 ms).
+            const bool nxt_fast = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)(grp + 1)];
+            hipStream_t cs = (nxt_fast && ctx->fast_on_main) ? ctx->stream : ctx->side;      // where the next group runs
             hipStream_t hs = ctx->stream;
-            if (grp > 0 && ctx->head_on_side) {
+            if (grp > 0 && ctx->head_on_side && cs == ctx->side) {
                 PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_main, 0));    // (recorded at the end of the iteration before)
                 hs = ctx->side;
             }
@@ -1067,10 +1073,10 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
                 if (q < p0 + n0) { rc = head_from(q, p0 + n0 - q, p1, n1, hs); if (rc) return rc; }
             }
             (void)hc0;
-            if (hs == ctx->stream) {
+            if (hs == ctx->stream && cs == ctx->side) {
                 PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
                 PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_head, 0));
-            } else if (ctx->head_serial) {
+            } else if (hs == ctx->side && ctx->head_serial) {
                 // the bulk update of this group starts behind the head instead of beside it (the head is what the next chain
                 // waits for; sharing the GPU with the bulk launch stretches it)
                 PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->side));
@@ -1078,11 +1084,10 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             }
             // early heads: in the tail regime the panels of the NEXT group except its last one update the group after it
             // as soon as each is factored, on the main stream behind this group's bulk update
-            const bool nxt_fast = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)(grp + 1)];
             const bool do_early = ctx->early_head && grp + 2 < ngroups && n1 >= 2 && !nxt_fast && !fast_src &&
                                   g.Npad - g.panel_c0(p1) <= ctx->tail_cols;
-            rc = run_group(grp + 1, ctx->side, do_early); if (rc) return rc;
-            PYIPM_HIP(hipEventRecord(ctx->ev_panel, ctx->side));
+            rc = run_group(grp + 1, cs, do_early); if (rc) return rc;
+            PYIPM_HIP(hipEventRecord(ctx->ev_panel, cs));
             rc = timed_update(ctx, p0, n0, p1 + n1, np - (p1 + n1)); if (rc) return rc;   // bulk (overlaps the side stream)
             if (do_early) {
                 const int64_t p2 = p1 + n1, n2 = gsize(grp + 2);
@@ -1901,6 +1906,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "group_chain")) { ctx->group_chain = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "bwd_diag4")) { ctx->bwd_diag4 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "head_on_side")) { ctx->head_on_side = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "fast_on_main")) { ctx->fast_on_main = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "head_serial")) { ctx->head_serial = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
