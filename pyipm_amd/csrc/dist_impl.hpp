@@ -59,6 +59,9 @@ struct DistState {
     pyipm_bcast_fn bcast = nullptr; pyipm_allreduce_fn allreduce = nullptr; void* user = nullptr;
     ncclComm_t comm = nullptr;
     hipStream_t side = nullptr, cs = nullptr;          // owner's factor + pack stream (high priority); collectives
+    hipStream_t fws = nullptr;                         // the forward substitution that trails the factorisation (step_dist)
+    hipEvent_t ev_fw = nullptr;
+    bool fwd_done = false;                             // vloc holds the forward pass of the staged right-hand side
     hipEvent_t ev_fact[2] = {}, ev_msg[2] = {}, ev_free[2] = {}, ev_head = nullptr, ev_join = nullptr;
     hipEvent_t ev_hop[2] = {};                         // a collective asked for on another stream is run on `cs` between these
     double* msg[2] = {nullptr, nullptr}; size_t msg_bytes = 0;
@@ -120,6 +123,8 @@ void dist_free(Ctx* ctx) {
     if (!D) return;
     if (D->side) { hipStreamSynchronize(D->side); hipStreamDestroy(D->side); }
     if (D->cs) { hipStreamSynchronize(D->cs); hipStreamDestroy(D->cs); }
+    if (D->fws) { hipStreamSynchronize(D->fws); hipStreamDestroy(D->fws); }
+    if (D->ev_fw) hipEventDestroy(D->ev_fw);
     for (int b = 0; b < 2; ++b) {
         if (D->ev_fact[b]) hipEventDestroy(D->ev_fact[b]);
         if (D->ev_msg[b]) hipEventDestroy(D->ev_msg[b]);
@@ -248,7 +253,11 @@ int update_range(Ctx* ctx, int64_t p, int64_t first, int64_t count, hipStream_t 
 // The factorisation across the ranks: one-panel lookahead.  As soon as panel p has arrived, the owner of p+1 updates
 // only panel p+1 (head), factors and packs it on the side stream and starts its broadcast on the collective stream;
 // every rank runs its share of the bulk update of p on the main stream meanwhile.
-int factor_dist(Ctx* ctx, pyipm_factor_stats* stats) {
+// fwd_b != NULL (step_dist): the forward substitution of that right-hand side (replicated, Npad) trails the factorisation on
+// its own stream -- y_p needs nothing but panel p factored on its owner and the segment sum of the panels before it -- and
+// the solve that follows starts at the backward sweep (D->fwd_done).  The segment sums go through the collective stream
+// like every other exchange, at the same place of the loop on every rank.
+int factor_dist(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b = nullptr) {
     const Geo& g = ctx->g;
     if (!ctx->assembled) { ctx->err = "factor_dist: assemble first"; return PYIPM_E_BADARG; }
     if (ctx->cond_active) { ctx->err = "factor_dist: the condensed option is single-rank (use factor())"; return PYIPM_E_BADARG; }
@@ -273,6 +282,34 @@ int factor_dist(Ctx* ctx, pyipm_factor_stats* stats) {
     }
     std::vector<char> has_msg((size_t)np, 0), on_side((size_t)np, 0);
     auto below = [&](int64_t p) { return g.Npad - (g.panel_c0(p) + g.panel_w(p)); };
+    D->fwd_done = false;
+    if (fwd_b) {
+        if (!D->fws) DIST_HIP(hipStreamCreateWithFlags(&D->fws, hipStreamNonBlocking));
+        if (!D->ev_fw) DIST_HIP(hipEventCreateWithFlags(&D->ev_fw, hipEventDisableTiming));
+        while ((int64_t)ctx->ev_done.size() < np) { hipEvent_t e; DIST_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_done.push_back(e); }
+        DIST_HIP(hipEventRecord(D->ev_fw, main));                       // the right-hand side was produced on the main stream
+        DIST_HIP(hipStreamWaitEvent(D->fws, D->ev_fw, 0));
+        hipLaunchKernelGGL(k_mask_owned, grid1(g.Npad), dim3(256), 0, D->fws, D->vloc, fwd_b, g);
+        DIST_KCHECK();
+    }
+    // forward substitution of panel p (all ranks: the segment sum; owner: the panel's own part)
+    auto fwd_step = [&](int64_t p) -> int {
+        if (!fwd_b) return 0;
+        const int64_t c0 = g.panel_c0(p); const int64_t nbw = g.panel_w(p);
+        const bool own = g.owner(p) == g.rank;
+        double* v = D->vloc;
+        if (g.world > 1) {
+            DIST_HIP(hipMemcpyAsync(D->seg, v + c0, (size_t)nbw * sizeof(double), hipMemcpyDeviceToDevice, D->fws));
+            int r = ex_allreduce(ctx, D, D->seg, (size_t)nbw, 0, D->fws); if (r) return r;
+            if (own) DIST_HIP(hipMemcpyAsync(v + c0, D->seg, (size_t)nbw * sizeof(double), hipMemcpyDeviceToDevice, D->fws));
+        }
+        if (own) {
+            DIST_HIP(hipStreamWaitEvent(D->fws, ctx->ev_done[(size_t)p], 0));      // panel p factored
+            int r = fwd_panel(ctx, p, v, D->fws); if (r) return r;
+            r = diag_panel(ctx, p, v, D->fws); if (r) return r;
+        }
+        return 0;
+    };
 
     // factor (owner) + start the broadcast of panel p; fst = the stream the owner factors on
     auto post = [&](int64_t p, hipStream_t fst) -> int {
@@ -283,6 +320,7 @@ int factor_dist(Ctx* ctx, pyipm_factor_stats* stats) {
             size_t sp; r = span_begin(ctx, D, 0, fst, &sp); if (r) return r;
             r = factor_panel(ctx, p, fst, false); if (r) return r;
             r = span_end(ctx, D, sp, fst); if (r) return r;
+            if (fwd_b) DIST_HIP(hipEventRecord(ctx->ev_done[(size_t)p], fst));
         }
         const size_t bytes = (wire && below(p) > 0) ? dist_msg_bytes(ctx, p) : 0;
         has_msg[(size_t)p] = bytes > 0;
@@ -309,6 +347,7 @@ int factor_dist(Ctx* ctx, pyipm_factor_stats* stats) {
     };
 
     rc = post(0, main); if (rc) return rc;
+    int64_t fwd_next = 0;                                               // first panel whose forward step is not enqueued yet
     for (int64_t p = 0; p < np; ++p) {
         if (below(p) <= 0) break;
         const int b = (int)(p & 1);
@@ -335,6 +374,16 @@ int factor_dist(Ctx* ctx, pyipm_factor_stats* stats) {
             }
             rc = update_range(ctx, p, nxt + 1, np, main); if (rc) return rc;              // ... while everyone runs the bulk of update p
         }
+        // last in the iteration: the host submits the next panel's chain first (in the chain-bound tail the GPU is
+        // waiting for exactly those launches; with the forward step submitted ahead of them the factorisation grew by as
+        // much as the sweep shrank)
+        rc = fwd_step(p); if (rc) return rc;
+        fwd_next = p + 1;
+    }
+    for (int64_t p = fwd_next; p < np; ++p) { rc = fwd_step(p); if (rc) return rc; }
+    if (fwd_b) {
+        DIST_HIP(hipEventRecord(D->ev_fw, D->fws)); DIST_HIP(hipStreamWaitEvent(main, D->ev_fw, 0));
+        D->fwd_done = true;
     }
     // join the helper streams (the last panel may have been factored on the side stream; messages in flight)
     DIST_HIP(hipEventRecord(D->ev_join, side)); DIST_HIP(hipStreamWaitEvent(main, D->ev_join, 0));
@@ -376,13 +425,15 @@ int factor_dist(Ctx* ctx, pyipm_factor_stats* stats) {
 // Forward: rank r keeps vloc_r with sum_r vloc_r = b - (updates applied so far); the owner of panel p needs the SUM of
 // the segment [c0, c1) -- one nb-long all-reduce -- resolves it and pushes its update into its own vloc.  No vector
 // travels.  Backward: the owner needs every x below, so each resolved segment is broadcast (nb doubles).
-int solve_dist_once(Ctx* ctx, DistState* D, const double* b, double* x) {
+int solve_dist_once(Ctx* ctx, DistState* D, const double* b, double* x, bool forward_done = false) {
     const Geo& g = ctx->g;
     hipStream_t st = ctx->stream;
     double* v = D->vloc;
-    hipLaunchKernelGGL(k_mask_owned, grid1(g.Npad), dim3(256), 0, st, v, b, g);
-    DIST_KCHECK();
-    for (int64_t p = 0; p < g.npanels; ++p) {
+    if (!forward_done) {
+        hipLaunchKernelGGL(k_mask_owned, grid1(g.Npad), dim3(256), 0, st, v, b, g);
+        DIST_KCHECK();
+    }
+    for (int64_t p = 0; p < g.npanels && !forward_done; ++p) {
         const int64_t c0 = g.panel_c0(p); const int64_t nbw = g.panel_w(p);
         const bool own = g.owner(p) == g.rank;
         if (g.world > 1) {
@@ -419,7 +470,9 @@ int solve_dist(Ctx* ctx, const double* rhs, double* dz, int flip, int refine, in
     DIST_HIP(hipEventRecord(ctx->ev[4], st));
     ctx->forward_pending = false;
     rc = solve_prepare(ctx, rhs, memkind); if (rc) return rc;          // v1 = v0 = b (replicated; pad zero)
-    rc = solve_dist_once(ctx, D, ctx->v1, ctx->v0); if (rc) return rc;
+    const bool fwd_done = D->fwd_done && rhs == nullptr;                // the staged right-hand side went forward under the factorisation
+    D->fwd_done = false;
+    rc = solve_dist_once(ctx, D, ctx->v1, ctx->v0, fwd_done); if (rc) return rc;
     ctx->info_steps = 0; ctx->info_converged = 0; ctx->info_berr0 = -1.0; ctx->info_berr = -1.0;
     const bool adaptive = refine < 0;
     const int maxit = adaptive ? ctx->refine_max : refine;
@@ -580,7 +633,7 @@ int pyipm_newton_step_dist(pyipm_newton_ctx* h, double delta, double delta_c, in
     if (!dz) { ctx->err = "step_dist: null output"; return PYIPM_E_BADARG; }
     int rc = residual_dist(ctx); if (rc) return rc;
     rc = pyipm_newton_assemble(h, delta, delta_c); if (rc) return rc;
-    rc = factor_dist(ctx, stats); if (rc) return rc;
+    rc = factor_dist(ctx, stats, ctx->fuse_forward ? ctx->rhs : nullptr); if (rc) return rc;
     return solve_dist(ctx, nullptr, dz, 1, refine, memkind);
 } PYIPM_CATCH_H(h)
 

@@ -20,6 +20,7 @@ static void quiesce_noexcept(Ctx* c) noexcept {
         if (c->side) hipStreamSynchronize(c->side);
         if (c->fwd) hipStreamSynchronize(c->fwd);
         if (c->rest) hipStreamSynchronize(c->rest);
+        if (c->dist) hipDeviceSynchronize();            // the distributed driver's own streams
         if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
         c->factored = false; c->forward_pending = false; c->forward_fused = false;
     } catch (...) {}
