@@ -319,6 +319,10 @@ def main():
                          "frac_of_measured_peak": (ach / peak_meas) if peak_meas else None},
             "phases_ms_per_step": {"assemble": assemble_ms / K, "panel(tile+scale+in-panel)": panel_ms / K,
                                    "trailing": trailing_ms / K, "solve": solve_ms / K},
+            "phases_note": "trailing = sum of the bulk update launches' HIP-event durations on the main stream (what a kernel "
+                           "trace adds up for k_update<128,true,8>); panel = the rest of the factorisation: the tile chain where "
+                           "no bulk launch runs, including the lookahead heads, which ride the chain's stream as "
+                           "k_update<128,true,4> and are not part of the roofline figures",
             "hbm_bound_kernels": {
                 "assemble_K1": {"algorithmic_bytes": 4.0 * N * N + 8.0 * (n * n / 2.0 + n * me + n * mi),
                                 "GB_per_s": (4.0 * N * N + 8.0 * (n * n / 2.0 + n * me + n * mi)) / max(assemble_ms / K, 1e-9) / 1e6,

@@ -268,7 +268,9 @@ int pyipm_newton_step_batched(pyipm_newton_ctx* ctx, double delta, double delta_
 /* Device pointer + leading dimension of the local KKT storage (column-major lower). */
 int pyipm_newton_kkt_storage(pyipm_newton_ctx* ctx, double** ptr, int64_t* ld, int64_t* ncols);
 /* Time (ms, HIP events on the handle's stream) of the phases of the last factor/solve call:
- * out[0]=assemble, [1]=panel work, [2]=trailing updates, [3]=solve, [4]=#trailing launches,
+ * out[0]=assemble, [1]=panel work (factor time during which no update launch ran), [2]=trailing updates (sum of the launches'
+ * durations -- a lookahead head on the side stream may overlap the bulk launch behind it, so [1]+[2] can exceed [6]),
+ * [3]=solve, [4]=#trailing launches,
  * [5]=algorithmic flops of those launches, [6]=factor, [7]=Ji Sigma Ji' launch (condensed option) or, for the
  * full system, the number of matrix entries those launches update (their C-tile traffic is 16 B each). */
 int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
@@ -284,13 +286,19 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *                    L T = S / T z = y for diagonal tiles whose pivot spread exceeds refine_cond (the tile
  *                    inverses are explicit).
  *   "profile" 0|1, "lookahead" 0|1, "group" 1..create-time value, "tail_group" / "tail_cols" (group size once
- *   at most tail_cols columns remain; defaults 2 / 24576), "fuse_forward" 0|1, "pivtol_rel",
+ *   at most tail_cols columns remain; defaults 4 (= no shorter groups) / 24576), "fuse_forward" 0|1, "pivtol_rel",
  *   "xcd_swizzle", "side_prio", "bulk_waves" 4|8 (measurement switches);
  *   "refine_target" / "refine_max" (adaptive refinement of solve(refine < 0): stop at this backward error, default 1e-14,
  *   or after this many steps, default 8); "dist_selfmsg" 0|1 (world == 1 only: the distributed driver packs and sends
  *   every panel anyway, to measure the message path on one GPU);
- *   "inpanel32" 0|1 (updates on the panel chain through the fine-grained kernel), "fuse_scale_update" 0|1 (a tile's
- *   in-panel update rides the scaling launch of the tile before it: two dependent launches per tile instead of three),
+ *   "group_chain" 0|1 (single rank: the panels of a group run as one tile-to-tile sequence of k_tile_step launches, the
+ *   rows below the group's diagonal block follow on their own stream -- DESIGN.md section 3), "tile_step" 0|1 (the same
+ *   pair of kernels panel by panel: what the per-panel / multi-GPU driver uses), "head_on_side" 0|1 (the lookahead head on
+ *   the stream of the chain it follows), "head_serial" 0|1 (the group's bulk update waits for that head), "fast_on_main"
+ *   0|1 (groups inside the slack block run on the main stream), "bwd_diag4" 0|1 (in-panel backward substitution on 1024
+ *   threads through shared memory),
+ *   "inpanel32" 0|1 (updates on the panel chain through the fine-grained kernel), "fuse_scale_update" 0|1 (tile-by-tile
+ *   schedule, group_chain = tile_step = 0: a tile's in-panel update rides the scaling launch of the tile before it),
  *   "pending32_rows", "head32_rows",
  *   "head32_rows_dist" (row counts up to which a panel's pending in-group update / the lookahead head / the per-panel
  *   head take that kernel; defaults 24576 / 6144 / 16384), "early_head" 0|1 (tail regime: the next group's columns are

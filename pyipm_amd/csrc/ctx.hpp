@@ -105,6 +105,9 @@ struct Ctx {
     hipStream_t rest = nullptr;           // ... that stream (high priority, created on first use)
     std::vector<hipEvent_t> ev_band;      // panel (by offset in its group): its tiles are inverted and applied inside the diagonal block
     hipEvent_t ev_join = nullptr, ev_main = nullptr;
+    int head_waves = 4;                   // waves per block of a lookahead head launched on the chain's stream (4: k_update<128,true,4>,
+                                          // its own line in a kernel trace; 8: the bulk instance)
+    int rest_prio = 1;                    // ctx->rest is a high-priority stream (set before the first factorisation)
     int fast_on_main = 1;                 // groups inside the slack block (closed form) run on the main stream, not through the lookahead
     int head_serial = 0;                  // ... and the bulk update of the group waits for it (instead of running beside it)
     int head_on_side = 1;                 // the lookahead head runs on the stream of the chain it follows (no stream crossing between
@@ -174,6 +177,7 @@ struct Ctx {
     int profile = 0;
     // timings of last calls (ms)
     double t_assemble = 0, t_panel = 0, t_trailing = 0, t_solve = 0, t_factor = 0;
+    double t_trailing_union = 0; int64_t n_trailing_real = 0;   // time with some update launch running (launches may overlap); launches that did work
     double trailing_flops = 0, trailing_area = 0; int64_t n_trailing = 0;   // area: matrix entries updated, summed over launches
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_trailing;   // reused event pool
     hipEvent_t ev[8] = {};

@@ -271,7 +271,7 @@ int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, uns
 int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ldl, const double* Wop, int K,
                      int64_t row_begin, int64_t first_lp, int64_t n_lp, bool bulk = true,
                      int64_t ldw = 0, int64_t row_end = 0, int64_t col_end = 0, int64_t src_c0 = -1,
-                     int ksplit = 1, int64_t ks_cstride = 0) {
+                     int ksplit = 1, int64_t ks_cstride = 0, int waves = 0) {      // waves: 0 = the handle's bulk_waves
     const Geo& g = ctx->g;
     if (ldw <= 0) ldw = g.Npad;
     if (row_end <= 0) row_end = g.Npad;
@@ -296,7 +296,7 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
         if (ntiles == 0) return 0;
         dim3 grid(ntiles, (unsigned)ksplit);             // K is the length of ONE split
         if (ksplit > 1) u.ks_cstride = ks_cstride;
-        if (ctx->bulk_waves == 8)
+        if ((waves ? waves : ctx->bulk_waves) == 8)
             hipLaunchKernelGGL((k_update<128, true, 8>), grid, dim3(512), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
         else
             hipLaunchKernelGGL((k_update<128, true>), grid, dim3(256), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
@@ -465,7 +465,7 @@ int factor_group(Ctx* ctx, int64_t p0, int64_t n0, hipStream_t chain, const std:
     if (!ctx->rest) {
         int lo = 0, hi = 0;
         PYIPM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        PYIPM_HIP(hipStreamCreateWithPriority(&ctx->rest, hipStreamNonBlocking, hi));
+        PYIPM_HIP(hipStreamCreateWithPriority(&ctx->rest, hipStreamNonBlocking, ctx->rest_prio ? hi : lo));
     }
     if (!ctx->ev_join) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     while ((int64_t)ctx->ev_band.size() < n0) { hipEvent_t e; PYIPM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_band.push_back(e); }
@@ -561,8 +561,12 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
     const int64_t q0 = first_lp * g.world + g.rank;           // first global panel updated
     const int64_t row_begin = g.panel_c0(q0);
     if (row_begin >= g.Npad) return 0;
+    // A launch on another stream than the handle's is a lookahead head riding the chain's stream: it overlaps the bulk launch
+    // on the main stream, so its duration says nothing about the kernel's rate -- it is not part of the "trailing" figures
+    // (time, flops, launches), and it uses the 4-wave instance of the kernel so that a kernel trace keeps the two apart.
+    const bool chain_side = stream != ctx->stream && !ctx->per_panel_mode;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->profile) {
+    if (ctx->profile && !chain_side) {
         if ((size_t)ctx->n_trailing >= ctx->ev_trailing.size()) {
             hipEvent_t a, b;
             PYIPM_HIP(hipEventCreate(&a)); PYIPM_HIP(hipEventCreate(&b));
@@ -581,9 +585,10 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
         PYIPM_KCHECK();
     } else {
         int rc = launch_update128(ctx, stream, Lop, g.Npad, wbuf(ctx, p0), K, row_begin, first_lp, n_lp, true, 0, 0, 0,
-                                  g.panel_c0(p0));
+                                  g.panel_c0(p0), 1, 0, chain_side ? ctx->head_waves : 0);
         if (rc) return rc;
     }
+    if (chain_side) return 0;
     if (ctx->profile) PYIPM_HIP(hipEventRecord(e1, stream));
     // algorithmic flops of this launch: 2*K per lower-triangle entry of the updated local columns
     // (entries the KKT block structure leaves at zero are not counted: the launch skips their tiles)
@@ -635,13 +640,19 @@ int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
             iv.push_back({a, a + d});
         }
         std::sort(iv.begin(), iv.end());
-        double ms = 0.0; float hi = -1.0e30f;
+        double uni = 0.0, sum = 0.0; float hi = -1.0e30f;
+        int64_t nreal = 0;
         for (auto& x : iv) {
+            sum += x.second - x.first;
+            if (x.second - x.first > 0.03f) ++nreal;           // (a launch whose tile list came out empty leaves two events a few
+                                                               //  microseconds apart; the shortest real launch takes 70 us)
             if (x.second <= hi) continue;
-            ms += x.second - (x.first > hi ? x.first : hi);
+            uni += x.second - (x.first > hi ? x.first : hi);
             hi = x.second;
         }
-        ctx->t_trailing = ms;
+        ctx->t_trailing = sum;                               // what a kernel trace adds up for the same launches
+        ctx->t_trailing_union = uni;
+        ctx->n_trailing_real = nreal;
     }
     ctx->factored = true;
     if (stats) {
@@ -1120,7 +1131,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     float ms = 0.f;
     PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
     ctx->t_factor = ms;
-    ctx->t_panel = ctx->profile ? (ms - ctx->t_trailing) : 0.0;    // exposed (non-overlapped) panel time
+    ctx->t_panel = ctx->profile ? (ms - ctx->t_trailing_union) : 0.0;    // exposed panel time: no update launch running
     return rc;
 }
 
@@ -1870,7 +1881,7 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* h, double out[8]) try {
     if (ctx->ev_assemble_valid) { float ms = 0.f; PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->t_assemble = ms; }
     if (ctx->ev_solve_valid) { float ms = 0.f; PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->t_solve = ms; }
     out[0] = ctx->t_assemble; out[1] = ctx->t_panel; out[2] = ctx->t_trailing; out[3] = ctx->t_solve;
-    out[4] = (double)ctx->n_trailing; out[5] = ctx->trailing_flops; out[6] = ctx->t_factor;
+    out[4] = (double)(ctx->n_trailing_real > 0 ? ctx->n_trailing_real : ctx->n_trailing); out[5] = ctx->trailing_flops; out[6] = ctx->t_factor;
     out[7] = ctx->cond_active ? ctx->t_gram : ctx->trailing_area;   // full system: entries updated by the trailing launches
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)
@@ -1908,6 +1919,8 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "bwd_diag4")) { ctx->bwd_diag4 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "head_on_side")) { ctx->head_on_side = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "fast_on_main")) { ctx->fast_on_main = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "rest_prio")) { ctx->rest_prio = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "head_waves")) { ctx->head_waves = ((int)value == 8) ? 8 : 4; return PYIPM_OK; }
     if (!strcmp(name, "head_serial")) { ctx->head_serial = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }

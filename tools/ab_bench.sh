@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B on one box: each variant several times, interleaved
+# A/B on one box (boxes differ by +-3 %): every argument is one set of bench.py options; each variant runs three times,
+# interleaved.  Prints ms/step (exposed panel ms) per run.  usage: tools/ab_bench.sh "" "--opt group_chain=0" ...
 set -u
 O=gpurun_out/r02q; mkdir -p $O
 B="timeout 600 python bench.py --no-cpu-baseline --steps 6 --warmup 2"

@@ -1,4 +1,6 @@
 #!/bin/bash
+# Kernel trace of config 2 (chain-bound) -> gpurun_out/r02q/c2_timeline.txt: every launch of the last steps in start order
+# with its duration and the gap to the previous launch of the same queue (tools/chain_timeline.py).  Extra args go to bench.py.
 set -u
 O=gpurun_out/r02q; mkdir -p $O
 R=$GRAFT_REPO_ROOT

@@ -7,7 +7,7 @@ for name in ['sq1', 'sq2', 'tcc1', 'tcc2']:
     rows = list(csv.DictReader(open(f'{src}/{name}/{name}_counter_collection.csv')))
     by = collections.defaultdict(dict)
     for r in rows:
-        if 'k_update<128, true' in r['Kernel_Name']:
+        if 'k_update<128, true, 8>' in r['Kernel_Name']:   # the bulk launches (heads on the chain's stream are <128, true, 4>)
             by[r['Dispatch_Id']][r['Counter_Name']] = float(r['Counter_Value'])
     tot = collections.Counter()
     for k in by:
