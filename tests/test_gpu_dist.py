@@ -147,6 +147,16 @@ def test_dist_driver_world1_matches_fused_step():
     fact, _ = _factor_bytes(n, me, mi, 256)
     assert tm["bytes"] == fact and tm["messages"] > 0 and tm["pack_ms"] > 0.0 and tm["chain_ms"] > 0.0
     assert float((dz0 - dz2).norm() / dz0.norm()) <= 1e-12
+    # the forward sweep that trails the factorisation (step_dist) runs the same kernels in the same order as the sweep of
+    # solve_dist: the same bits, and the solve that follows is shorter by that sweep
+    import torch
+    core.set_option("fuse_forward", 0)
+    dz3, _ = core.step_dist(0.0, 0.0)
+    tm3 = core.dist_timings()
+    core.set_option("fuse_forward", 1)
+    dz4, _ = core.step_dist(0.0, 0.0)
+    assert torch.equal(dz2, dz3) and torch.equal(dz3, dz4)
+    assert core.dist_timings()["solve_ms"] < tm3["solve_ms"]
 
 
 def _rccl_worker(rank, port, shape, nb, out):

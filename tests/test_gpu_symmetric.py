@@ -168,3 +168,26 @@ def test_chain_kernel_choices_are_bitwise_neutral(shape, nb):
         assert st == base[1], opts
     ref = out[-1][0]
     assert float((ref - base[0]).norm() / base[0].norm()) <= 1e-12
+
+
+def test_backward_sweep_kernels_agree():
+    """The in-panel backward recursion has two implementations (k_bwd_diag: one thread per column; k_bwd_diag4: 1024
+    threads, tiles through shared memory, partial sums combined in a different order): equal to rounding, and both
+    solve the system."""
+    from pyipm_amd.newton import NewtonCore
+    from pyipm_amd.problems import make_qp
+    n, me, mi = 1500, 300, 500
+    qp = make_qp(n, me, mi, 11)
+    out = []
+    for d4 in (0, 1):
+        core = NewtonCore(n, me, mi, device=0)
+        core.set_option("bwd_diag4", d4)
+        core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+        core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+        dz, st = core.step(0.0, 0.0)
+        g = core.residual()
+        raw = core.solve(flip=False)
+        out.append((dz.clone(), float((core.matvec(raw) - g).norm() / g.norm())))
+        core.close()
+    assert float((out[0][0] - out[1][0]).norm() / out[0][0].norm()) <= 1e-13
+    assert out[0][1] <= 1e-12 and out[1][1] <= 1e-12
