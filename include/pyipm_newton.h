@@ -292,7 +292,8 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *   or after this many steps, default 8); "dist_selfmsg" 0|1 (world == 1 only: the distributed driver packs and sends
  *   every panel anyway, to measure the message path on one GPU);
  *   "group_chain" 0|1 (single rank: the panels of a group run as one tile-to-tile sequence of k_tile_step launches, the
- *   rows below the group's diagonal block follow on their own stream -- DESIGN.md section 3), "tile_step" 0|1 (the same
+ *   rows below the group's diagonal block follow on their own stream -- DESIGN.md section 3; "pending_left_rows": their
+ *   in-group updates are applied left-looking while more rows than this remain, default 12288, -1 never), "tile_step" 0|1 (the same
  *   pair of kernels panel by panel: what the per-panel / multi-GPU driver uses), "head_on_side" 0|1 (the lookahead head on
  *   the stream of the chain it follows), "head_serial" 0|1 (the group's bulk update waits for that head), "fast_on_main"
  *   0|1 (groups inside the slack block run on the main stream), "bwd_diag4" 0|1 (in-panel backward substitution on 1024

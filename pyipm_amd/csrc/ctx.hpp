@@ -107,6 +107,8 @@ struct Ctx {
     hipEvent_t ev_join = nullptr, ev_main = nullptr;
     int head_waves = 4;                   // waves per block of a lookahead head launched on the chain's stream (4: k_update<128,true,4>,
                                           // its own line in a kernel trace; 8: the bulk instance)
+    int64_t pending_left_rows = 12288;    // group chain: left-looking in-group updates of the rows below the diagonal block while more
+                                          // rows than this remain below it (-1: never)
     int rest_prio = 1;                    // ctx->rest is a high-priority stream (set before the first factorisation)
     int fast_on_main = 1;                 // groups inside the slack block (closed form) run on the main stream, not through the lookahead
     int head_serial = 0;                  // ... and the bulk update of the group waits for it (instead of running beside it)

@@ -496,6 +496,16 @@ int factor_group(Ctx* ctx, int64_t p0, int64_t n0, hipStream_t chain, const std:
         } else {
             PYIPM_HIP(hipStreamWaitEvent(ctx->rest, ctx->ev_band[(size_t)k], 0));
         }
+        // Where the bulk update is the bound (many rows below), the in-group updates of the rows below the diagonal block
+        // are applied LEFT-looking -- all earlier panels of the group at once (K up to 768), right before the panel's own
+        // stages -- instead of panel by panel: half the read-modify-write passes over those rows and longer K per launch.
+        // In the tail the panel-by-panel form keeps only the last panel's stages behind the chain.  Same bits either way.
+        const bool left = ctx->pending_left_rows >= 0 && g.Npad - gend > ctx->pending_left_rows;
+        if (g.Npad > gend && left && k > 0) {
+            const int K = toff[(size_t)k] * TB;
+            int rc = launch_update128(ctx, rs, ctx->A + glc0 * g.Npad, g.Npad, Wg, K, gend, q, 1, /*bulk=*/false, 0, 0, 0, gc0);
+            if (rc) return rc;
+        }
         if (g.Npad > gend) {
             int64_t hole0 = 0, hole1 = 0;
             if (ctx->skip_zeros && g.mi > 0 && grp_in_x) {
@@ -506,7 +516,7 @@ int factor_group(Ctx* ctx, int64_t p0, int64_t n0, hipStream_t chain, const std:
                                gend, wbuf(ctx, q), g.Npad, ctx->Dinv + (c0 / TB) * TT, ctx->Tsv + (c0 / TB) * TT, ctx->Tflag + c0 / TB,
                                ctx->block_refine, hole0, hole1, &ctx->dstats->growth_bits);
             PYIPM_KCHECK();
-            if (k + 1 < n0) {
+            if (k + 1 < n0 && !left) {
                 // this panel's contribution to the later panels of the group, rows below the diagonal block
                 const int K = (int)g.panel_w(q);
                 const int64_t tc0 = g.panel_c0(q + 1), ncols = (int64_t)(nT - toff[(size_t)k + 1]) * TB;
@@ -1920,6 +1930,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "head_on_side")) { ctx->head_on_side = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "fast_on_main")) { ctx->fast_on_main = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "rest_prio")) { ctx->rest_prio = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "pending_left_rows")) { ctx->pending_left_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "head_waves")) { ctx->head_waves = ((int)value == 8) ? 8 : 4; return PYIPM_OK; }
     if (!strcmp(name, "head_serial")) { ctx->head_serial = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }

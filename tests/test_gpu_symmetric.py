@@ -138,7 +138,8 @@ def test_structural_zero_skipping_is_bitwise_neutral(shape, nb):
 def test_chain_kernel_choices_are_bitwise_neutral(shape, nb):
     """The updates that sit on the panel chain have two implementations (k_inpanel_update: 32 x 64 blocks straight from
     global memory; k_update: LDS-staged 128-wide tiles) chosen by how many rows remain, the panels of a group are chained tile to tile
-    (group_chain, kernels_panel.hpp), or a panel is factored by the stepped schedule on its own (tile_step: one launch per
+    (group_chain, kernels_panel.hpp; the in-group updates of the rows below the group's diagonal block left-looking or panel
+    by panel, pending_left_rows), or a panel is factored by the stepped schedule on its own (tile_step: one launch per
     diagonal tile + one for the rows below) or tile by tile
     with an inversion and a scaling launch over all rows (where the in-panel update of a tile can ride the scaling launch
     of the tile before it, fuse_scale_update), and the lookahead head can be applied panel by panel (early_head).  All of them accumulate the same products in the same order: every combination
@@ -149,7 +150,8 @@ def test_chain_kernel_choices_are_bitwise_neutral(shape, nb):
     n, me, mi, seed = shape
     qp = make_qp(n, me, mi, seed)
     out = []
-    for opts in ({}, {"group_chain": 0}, {"group_chain": 0, "tile_step": 0}, {"group_chain": 0, "tile_step": 0, "inpanel32": 0},
+    for opts in ({}, {"pending_left_rows": 0}, {"pending_left_rows": -1}, {"group_chain": 0}, {"group_chain": 0, "tile_step": 0},
+                 {"group_chain": 0, "tile_step": 0, "inpanel32": 0},
                  {"group_chain": 0, "tile_step": 0, "fuse_scale_update": 0}, {"early_head": 0}, {"head32_rows": 0, "pending32_rows": 0},
                  {"head32_rows": 1 << 20, "pending32_rows": 1 << 20}, {"tail_cols": 1024, "early_head": 1}):
         core = NewtonCore(n, me, mi, device=0, nb=nb)
