@@ -1,14 +1,17 @@
-// Panel factorisation, "stepped" schedule (round 2): one launch per diagonal tile, one for the rows below.
+// Factorisation of a diagonal block, "stepped" schedule (round 2): one launch per diagonal tile, one launch per panel for
+// the rows below.
 //
-// What sits on the critical path of a panel is its 256 x 256 diagonal block: four tile inversions, each needing the
-// tile before it eliminated from its own 64 rows.  The first schedule ran, per tile, an inversion launch and a scaling (+
-// in-panel update) launch over ALL rows below -- two dependent launches per tile, the second one as long as its K loop
-// over the earlier tiles of the panel.  Here the rows are split by what waits for them:
+// What sits on the critical path is the sequence of tile inversions of a diagonal block -- a panel's (256 x 256, the
+// per-panel / multi-GPU driver) or a whole group's (1024 x 1024, factor_group: the single-rank schedule) -- each tile
+// needing the tile before it eliminated from its own 64 rows.  The first schedule ran, per tile, an inversion launch and
+// a scaling (+ in-panel update) launch over ALL rows below -- two dependent launches per tile, the second one as long as
+// its K loop over the earlier tiles of the panel -- and a pending update between two panels of a group.  Here the rows are
+// split by what waits for them:
 //   * k_tile_step, launch t: block 0 eliminates tile t-1 from the 64 rows of tile t (one scaling product, one K = 64
 //     update of the diagonal tile, operands from registers) and inverts that tile straight out of shared memory; blocks
-//     1.. do the same right-looking step for the other row tiles INSIDE the diagonal block.  One dependent launch per tile,
-//     four blocks at most.
-//   * k_panel_rest, once per panel: every 64-row strip below the diagonal block runs all (up to four) stages in one
+//     1.. do the same right-looking step for the other row tiles INSIDE the diagonal block (a far row tile's column
+//     tiles split over grid.y).  One dependent launch per tile.
+//   * k_panel_rest, once per panel: every 64-row strip below the diagonal block runs all of the panel's stages in one
 //     launch (the first schedule went over the slab once per tile, in separate launches that each waited for a tile).
 // Every entry sees the same operations in the same order as before (scaling = the k_panel_scale product and refinement;
 // updates = MFMA groups of 4 columns, ascending): the factor is bit for bit the one of the first schedule.
