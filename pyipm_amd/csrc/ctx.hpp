@@ -109,6 +109,8 @@ struct Ctx {
                                           // its own line in a kernel trace; 8: the bulk instance)
     int64_t pending_left_rows = 12288;    // group chain: left-looking in-group updates of the rows below the diagonal block while more
                                           // rows than this remain below it (-1: never)
+    int keep_zeros = 1;                   // K1 does not store again the zeros nothing can fill in (k_assemble, zeros_in_place)
+    bool zeros_clean = false;             // ... which requires that the last writer of those places was a full assembly
     int rest_prio = 1;                    // ctx->rest is a high-priority stream (set before the first factorisation)
     int fast_on_main = 1;                 // groups inside the slack block (closed form) run on the main stream, not through the lookahead
     int head_serial = 0;                  // ... and the bulk update of the group waits for it (instead of running beside it)

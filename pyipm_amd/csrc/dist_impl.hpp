@@ -264,6 +264,7 @@ int factor_dist(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b = nullp
     DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
     ctx->grp_of.clear(); ctx->grp_off.clear(); ctx->grp_fast.clear(); ctx->grp_x.clear();
     ctx->per_panel_mode = true;
+    ctx->zeros_clean = false;
     rc = factor_begin(ctx); if (rc) return rc;
     D->used = 0; D->spans.clear(); D->bytes_sent = 0; D->n_msgs = 0;
     hipStream_t main = ctx->stream, side = D->side, cs = D->cs;

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void k_assemble(
     const double* __restrict__ Je, int64_t ldje,
     const double* __restrict__ Ji, int64_t ldji,
     const double* __restrict__ s, const double* __restrict__ lda,
-    double eps, double delta, double delta_c, unsigned long long* __restrict__ anorm_bits, int nt_store, int sharded)
+    double eps, double delta, double delta_c, unsigned long long* __restrict__ anorm_bits, int nt_store, int sharded,
+    int zeros_in_place)      // the storage still holds the zeros of an earlier assembly wherever nothing can ever fill in
 {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;          // even row; rows i, i+1
     const int64_t lc_base = (int64_t)blockIdx.y * 16;
@@ -90,6 +91,23 @@ __global__ __launch_bounds__(256) void k_assemble(
     // the 16 columns of a block lie in ONE panel (nb is a multiple of 128): one division per block, not one per entry
     const int64_t lp = lc_base / g.nb;
     const int64_t j0 = (lp * g.world + g.rank) * (int64_t)g.nb + (lc_base - lp * g.nb);
+    if ((int64_t)blockIdx.x * 512 + 512 <= j0) return;     // the whole patch lies above the diagonal: nothing is stored there
+    if (zeros_in_place) {
+        // Zeros for ever (pyipm.py:824-842 and the elimination order x, s, lambda_e, lambda_i): the (s, x) block; below the
+        // diagonal of the (s, s) block; the (lambda_e, s) block; the (lambda_i, s) block off its diagonal of -1.  Nothing
+        // fills them in -- every update that reaches them adds an exact zero -- so once written they need no second
+        // store (34 % of the lower triangle at the benchmark shape).  Decided per 512 x 16 patch, block-uniform.
+        const int64_t r0 = (int64_t)blockIdx.x * 512, r1 = r0 + 512;           // rows [r0, r1), columns [j0, j0 + 16)
+        const int64_t o_s = g.n, o_e = g.n + g.mi, o_i = o_e + g.me;
+        if (j0 + 16 <= o_s && r0 >= o_s && r1 <= o_e) return;                  // (s, x)
+        if (j0 >= o_s && j0 + 16 <= o_e) {
+            if (r0 > j0 + 15 && r1 <= o_i) return;                             // (s, s) below the patch's diagonal entries, (lambda_e, s)
+            if (r0 >= o_i && r1 <= g.N) {
+                const int64_t d0 = o_i + (j0 - o_s);                           // rows of the patch's -1 entries: [d0, d0 + 16)
+                if (r1 <= d0 || r0 >= d0 + 16) return;
+            }
+        }
+    }
     // (a lane whose rows lie above the whole patch has nothing to do, but stays for the wave reduction at the end)
     const int ncol = (i + 1 < j0) ? 0 : ((g.ncols_local - lc_base) < 16 ? (int)(g.ncols_local - lc_base) : 16);
     // values first (all loads of the thread in flight), stores afterwards

@@ -22,7 +22,7 @@ static void quiesce_noexcept(Ctx* c) noexcept {
         if (c->rest) hipStreamSynchronize(c->rest);
         if (c->dist) hipDeviceSynchronize();            // the distributed driver's own streams
         if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
-        c->factored = false; c->forward_pending = false; c->forward_fused = false;
+        c->factored = false; c->forward_pending = false; c->forward_fused = false; c->zeros_clean = false;
     } catch (...) {}
 }
 #define PYIPM_SETERR_NEWTON(msg_) (quiesce_noexcept(reinterpret_cast<Ctx*>(h)), set_err_noexcept(reinterpret_cast<Ctx*>(h), (msg_)))
@@ -671,7 +671,7 @@ int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
         long long gb = (long long)z.growth_bits; double gr; memcpy(&gr, &gb, sizeof(gr));
         stats->growth = gr; stats->nonfinite = z.nonfinite;
     }
-    if (z.nonfinite) { ctx->err = "NaN/Inf met during factorisation"; return PYIPM_E_NONFINITE; }
+    if (z.nonfinite) { ctx->zeros_clean = false; ctx->err = "NaN/Inf met during factorisation"; return PYIPM_E_NONFINITE; }
     return 0;
 }
 
@@ -913,7 +913,7 @@ int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
         dim3 grid((unsigned)((gc.Npad + 511) / 512), (unsigned)((gc.ncols_local + 15) / 16));
         PYIPM_HIP(hipMemsetAsync(ctx->anorm, 0, sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, gc.Npad, gc, ctx->d2L, ctx->ld_d2L,
-                           Jx, ldx, (const double*)nullptr, (int64_t)0, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, 0);
+                           Jx, ldx, (const double*)nullptr, (int64_t)0, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, 0, 0);
         PYIPM_KCHECK();
         if (na > 0) {
             hipLaunchKernelGGL(k_cond_fix_diag, grid1(na), dim3(256), 0, ctx->stream, ctx->A, gc.Npad, g.n + g.me,
@@ -943,6 +943,7 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
     if (!ctx->have_blocks || !ctx->have_vectors) { ctx->err = "assemble: stage blocks and vectors first"; return PYIPM_E_BADARG; }
     ctx->delta = delta; ctx->delta_c = delta_c;
     if (ctx->condensed && g.world == 1 && g.mi > 0) {
+        ctx->zeros_clean = false;                       // the condensed system lives in the same storage with another layout
         int rc = assemble_condensed(ctx, delta, delta_c); if (rc) return rc;
         ctx->cond_active = true;
         ctx->assembled = true; ctx->factored = false; ctx->forward_pending = false;
@@ -953,9 +954,13 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
     if (g.ncols_local > 0) {
         dim3 grid((unsigned)((g.Npad + 511) / 512), (unsigned)((g.ncols_local + 15) / 16));
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
-                           ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, ctx->sharded);
+                           ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, ctx->sharded,
+                           (ctx->keep_zeros && ctx->zeros_clean && g.world == 1 && g.mi > 0) ? 1 : 0);
         PYIPM_KCHECK();
     }
+    // the zeros of this assembly survive a factorisation of finite numbers (every update that reaches them adds an exact zero);
+    // whatever else may write into the storage clears the flag (zeros_dirty)
+    ctx->zeros_clean = g.world == 1;
     ctx->assembled = true; ctx->factored = false; ctx->forward_pending = false;
     return 0;
 }
@@ -1446,6 +1451,7 @@ int pyipm_newton_factor(pyipm_newton_ctx* h, pyipm_factor_stats* stats) try {
     const bool fuse = ctx->fuse_forward && ctx->have_rhs && ctx->g.world == 1 && ctx->assembled;
     if (fuse) { int rc = solve_prepare(ctx, nullptr, PYIPM_MEM_DEVICE, true); if (rc) return rc; }
     int rc = factor_dispatch(ctx, stats, fuse);
+    if (rc) ctx->zeros_clean = false;
     ctx->forward_pending = (rc == 0 || rc == PYIPM_E_NONFINITE) ? (fuse && ctx->forward_fused) : false;
     return rc;
 } PYIPM_CATCH_H(h)
@@ -1698,7 +1704,7 @@ int pyipm_newton_step(pyipm_newton_ctx* h, double delta, double delta_c, int ref
     rc = pyipm_newton_assemble(h, delta, delta_c); if (rc) return rc;
     const bool fuse = ctx->fuse_forward != 0;
     if (fuse) { rc = solve_prepare(ctx, nullptr, memkind, true); if (rc) return rc; }     // v0 = v1 = g before factoring
-    rc = factor_dispatch(ctx, stats, fuse); if (rc) return rc;
+    rc = factor_dispatch(ctx, stats, fuse); if (rc) { ctx->zeros_clean = false; return rc; }
     ctx->forward_pending = false;
     PYIPM_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
     if (!fuse) { rc = solve_prepare(ctx, nullptr, memkind); if (rc) return rc; }
@@ -1734,6 +1740,7 @@ int pyipm_newton_factor_begin(pyipm_newton_ctx* h) try {
     if (ctx->cond_active) { ctx->err = "per-panel phases do not apply to the condensed system; use factor()"; return PYIPM_E_BADARG; }
     ctx->grp_of.clear(); ctx->grp_off.clear(); ctx->grp_fast.clear(); ctx->grp_x.clear();      // per-panel phases: uniform group map, dense panels
     ctx->per_panel_mode = true;
+    ctx->zeros_clean = false;                           // (the caller drives the panels: no promise about what gets written)
     return factor_begin(ctx);
 } PYIPM_CATCH_H(h)
 int pyipm_newton_factor_end(pyipm_newton_ctx* h, pyipm_factor_stats* stats) try {
@@ -1877,7 +1884,7 @@ int pyipm_newton_bwd_panel(pyipm_newton_ctx* h, int64_t p, double* v) try {
 int pyipm_newton_kkt_storage(pyipm_newton_ctx* h, double** ptr, int64_t* ld, int64_t* ncols) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
-    if (ptr) *ptr = ctx->A;
+    if (ptr) { *ptr = ctx->A; ctx->zeros_clean = false; }      // the caller may write through it
     if (ld) *ld = ctx->cond_active ? ctx->gc.Npad : ctx->g.Npad;
     if (ncols) *ncols = ctx->cond_active ? ctx->gc.ncols_local : ctx->g.ncols_local;
     return PYIPM_OK;
@@ -1930,6 +1937,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "head_on_side")) { ctx->head_on_side = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "fast_on_main")) { ctx->fast_on_main = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "rest_prio")) { ctx->rest_prio = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "keep_zeros")) { ctx->keep_zeros = (int)value != 0; ctx->zeros_clean = false; return PYIPM_OK; }
     if (!strcmp(name, "pending_left_rows")) { ctx->pending_left_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "head_waves")) { ctx->head_waves = ((int)value == 8) ? 8 : 4; return PYIPM_OK; }
     if (!strcmp(name, "head_serial")) { ctx->head_serial = (int)value != 0; return PYIPM_OK; }

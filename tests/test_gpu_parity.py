@@ -228,6 +228,51 @@ def test_baseline_config2_exact_vs_oracle():
     assert np.array_equal(np.triu(A[:6144, :6144]), np.triu(Hc))
 
 
+@pytest.mark.parametrize("shape,nb", [((2048, 512, 1536, 3), 256), ((1100, 300, 1700, 4), 128), ((1536, 0, 2048, 5), 256)])
+def test_assembly_keeps_only_zeros_nothing_can_fill(shape, nb):
+    """K1 does not store again the zeros of the (s,x), (s,s), (lambda_e,s) and (lambda_i,s) blocks that no elimination step
+    can fill in (k_assemble, zeros_in_place): after a factorisation the storage must still hold exact zeros there, so the
+    next assembly is bit for bit triu(H) again -- also after a factorisation that met NaN, after the condensed system used
+    the same storage, and with the option off."""
+    n, me, mi, seed = shape
+    qp = make_qp(n, me, mi, seed)
+    rng = np.random.default_rng(seed)
+    core = _core(n, me, mi, nb=nb)
+    N = core.N
+    core.stage_blocks(qp["d2L"], qp["Je"] if me else None, qp["Ji"])
+
+    def check(s_vec, lam):
+        core.stage_vectors(qp["df"], qp["ce"] if me else None, qp["ci"], s_vec, lam, mu=qp["mu"])
+        core.assemble(0.0, 0.0)
+        H = orc.kkt_matrix(qp["d2L"], qp["Je"], qp["Ji"], s_vec, lam, n, me, mi)
+        S = core.kkt_storage().cpu().numpy()              # (handing out the pointer makes the NEXT assembly a full one)
+        assert np.array_equal(np.triu(S[:N, :N]), np.triu(H))
+
+    def step(s_vec, lam):
+        core.stage_vectors(qp["df"], qp["ce"] if me else None, qp["ci"], s_vec, lam, mu=qp["mu"])
+        return core.step(0.0, 0.0)
+
+    s0, l0 = qp["s"], qp["lam"]
+    step(s0, l0)                                             # full assembly + factorisation
+    s1 = s0 * rng.uniform(0.5, 2.0, mi); l1 = l0.copy(); l1[me:] *= rng.uniform(0.5, 2.0, mi)
+    step(s1, l1)                                             # assembly with the zeros left in place + factorisation
+    check(s0, l0)                                            # ... and again: must be triu(H) bit for bit
+    step(s1, l1); step(s0, l0)
+    sbad = s0.copy(); sbad[mi // 2] = np.nan
+    with pytest.raises(Exception):
+        step(sbad, l0)                                       # NaN reaches the factorisation: the zeros are not trusted any more
+    check(s1, l1)
+    step(s0, l0)
+    core.set_option("condensed", 1)
+    step(s1, l1)                                             # the condensed system overwrites the storage with another layout
+    core.set_option("condensed", 0)
+    step(s0, l0)
+    check(s1, l1)
+    core.set_option("keep_zeros", 0)
+    step(s0, l0)
+    check(s1, l1)
+
+
 def test_baseline_config3_properties():
     """BASELINE.json configs[2]: n=16384, 8192 eq + 8192 ineq -> KKT dim N = n + 2*mi + me = 40960
     (the reference formula, pyipm.py:824-825; BASELINE.json's '~49k' is approximate).  13.4 GB of KKT
