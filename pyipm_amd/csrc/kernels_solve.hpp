@@ -41,9 +41,14 @@ __global__ void k_fwd_diag(const double* __restrict__ A, int64_t ld, int64_t lc0
 // Rows below the panel:  v[i] -= sum_{k<nbw} A[i, lc0+k] * v[c0+k].   One thread per row.
 __global__ __launch_bounds__(256) void k_fwd_gemv(const double* __restrict__ A, int64_t ld, int64_t lc0,
                                                   int64_t c0, int nbw, int64_t row_begin, int64_t Npad,
-                                                  double* __restrict__ v, int64_t vstride)
+                                                  double* __restrict__ v, int64_t vstride,
+                                                  int64_t a0, int64_t a1, int64_t b0, int64_t b1)   // rows where L can be non-zero
 {
     extern __shared__ double y[];
+    {   // structural zeros of the KKT factor (active_ranges): these rows of L are exact zeros, nothing to subtract
+        const int64_t i0 = row_begin + (int64_t)blockIdx.x * 256, i1 = i0 + 256;
+        if (!((i1 > a0 && i0 < a1) || (i1 > b0 && i0 < b1))) return;
+    }
     v += (int64_t)blockIdx.y * vstride;
     for (int k = threadIdx.x; k < nbw; k += 256) y[k] = v[c0 + k];
     __syncthreads();
@@ -103,7 +108,8 @@ __global__ __launch_bounds__(64) void k_diag_apply(const double* __restrict__ Di
 __global__ __launch_bounds__(256) void k_bwd_dot(const double* __restrict__ A, int64_t ld, int64_t lc0,
                                                  int nb, int64_t row_begin, int64_t Npad,
                                                  const double* __restrict__ v, double* __restrict__ part,
-                                                 int64_t vstride, int64_t pstride)
+                                                 int64_t vstride, int64_t pstride,
+                                                 int64_t a0, int64_t a1, int64_t b0, int64_t b1)     // rows where L can be non-zero
 {
     __shared__ double red[4];
     v += (int64_t)blockIdx.z * vstride;
@@ -111,6 +117,10 @@ __global__ __launch_bounds__(256) void k_bwd_dot(const double* __restrict__ A, i
     const int k = blockIdx.x;
     const int64_t r0 = row_begin + (int64_t)blockIdx.y * ROWCHUNK;
     int64_t r1 = r0 + ROWCHUNK; if (r1 > Npad) r1 = Npad;
+    if (!((r1 > a0 && r0 < a1) || (r1 > b0 && r0 < b1))) {          // a chunk of structural zeros (active_ranges)
+        if (threadIdx.x == 0) part[(int64_t)blockIdx.y * nb + k] = 0.0;
+        return;
+    }
     const double* col = A + (lc0 + k) * ld;
     // all loads of a thread in flight at once (a rolled loop waits out the memory latency every trip), 16 bytes each:
     // a thread takes rows (2 t, 2 t + 1) + 512 u -- row_begin, ROWCHUNK and the leading dimension are even, so the pairs

@@ -686,8 +686,10 @@ int fwd_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr, int 
     PYIPM_KCHECK();
     const int64_t below = g.Npad - (c0 + nbw);
     if (below > 0) {
+        int64_t a0, a1, b0, b1;
+        active_ranges(ctx, c0, c0 + nbw, &a0, &a1, &b0, &b1);
         hipLaunchKernelGGL(k_fwd_gemv, dim3(grid1(below).x, nrhs), dim3(256), nbw * sizeof(double), stream, ctx->A, g.Npad, lc0, c0,
-                           nbw, c0 + nbw, g.Npad, v, vstride);
+                           nbw, c0 + nbw, g.Npad, v, vstride, a0, a1, b0, b1);
         PYIPM_KCHECK();
     }
     return 0;
@@ -714,8 +716,10 @@ int bwd_panel(Ctx* ctx, int64_t p, double* v, int nrhs = 1, int64_t vstride = 0,
     int nchunk = 0;
     if (below > 0) {
         nchunk = (int)((below + ROWCHUNK - 1) / ROWCHUNK);
+        int64_t a0, a1, b0, b1;
+        active_ranges(ctx, c0, c0 + nbw, &a0, &a1, &b0, &b1);
         hipLaunchKernelGGL(k_bwd_dot, dim3(nbw, nchunk, nrhs), dim3(256), 0, ctx->stream, ctx->A, g.Npad, lc0, g.nb,
-                           c0 + nbw, g.Npad, v, part, vstride, pstride);
+                           c0 + nbw, g.Npad, v, part, vstride, pstride, a0, a1, b0, b1);
         PYIPM_KCHECK();
     }
     if (ctx->bwd_diag4 && nbw <= 4 * TB)
