@@ -265,7 +265,9 @@ int pyipm_newton_step_batched(pyipm_newton_ctx* ctx, double delta, double delta_
 
 /* ---- introspection for tests / bench ------------------------------------------------------ */
 
-/* Device pointer + leading dimension of the local KKT storage (column-major lower). */
+/* Device pointer + leading dimension of the local KKT storage (column-major lower).  The caller may write through the
+ * pointer: handing it out makes the next assemble() store every entry again (otherwise the zeros that no elimination step can
+ * fill in are left in place from one assembly to the next, option "keep_zeros"). */
 int pyipm_newton_kkt_storage(pyipm_newton_ctx* ctx, double** ptr, int64_t* ld, int64_t* ncols);
 /* Time (ms, HIP events on the handle's stream) of the phases of the last factor/solve call:
  * out[0]=assemble, [1]=panel work (factor time during which no update launch ran), [2]=trailing updates (sum of the launches'
@@ -297,7 +299,8 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *   pair of kernels panel by panel: what the per-panel / multi-GPU driver uses), "head_on_side" 0|1 (the lookahead head on
  *   the stream of the chain it follows), "head_serial" 0|1 (the group's bulk update waits for that head), "fast_on_main"
  *   0|1 (groups inside the slack block run on the main stream), "bwd_diag4" 0|1 (in-panel backward substitution on 1024
- *   threads through shared memory),
+ *   threads through shared memory), "keep_zeros" 0|1 (K1 leaves in place the zeros of the (s,x), (s,s), (lambda_e,s),
+ *   (lambda_i,s) blocks that nothing can fill in; single rank), "head_waves" 4|8,
  *   "inpanel32" 0|1 (updates on the panel chain through the fine-grained kernel), "fuse_scale_update" 0|1 (tile-by-tile
  *   schedule, group_chain = tile_step = 0: a tile's in-panel update rides the scaling launch of the tile before it),
  *   "pending32_rows", "head32_rows",
