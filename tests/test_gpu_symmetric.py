@@ -193,3 +193,35 @@ def test_backward_sweep_kernels_agree():
         core.close()
     assert float((out[0][0] - out[1][0]).norm() / out[0][0].norm()) <= 1e-13
     assert out[0][1] <= 1e-12 and out[1][1] <= 1e-12
+
+
+def test_random_schedule_options_give_the_same_bits():
+    """The schedule of a factorisation -- which stream runs what, in how many launches, how much is looked ahead, what is
+    skipped as structurally zero, whether zeros are left in place between assemblies -- must never show in the result.
+    Random combinations of the scheduling options, three steps in a row on one handle each (stale state and races show up
+    as run-to-run differences): every direction equals the default configuration's bit for bit."""
+    import random
+    import torch
+    from pyipm_amd.newton import NewtonCore
+    from pyipm_amd.problems import make_qp
+    rnd = random.Random(7)
+    space = {"lookahead": [0, 1], "group_chain": [0, 1], "head_on_side": [0, 1], "fast_on_main": [0, 1], "early_head": [0, 1],
+             "pending_left_rows": [-1, 0, 12288], "fuse_forward": [0, 1], "keep_zeros": [0, 1], "skip_zeros": [0, 1],
+             "head_serial": [0, 1], "tile_step": [0, 1], "head32_rows": [0, 6144, 1 << 20], "pending32_rows": [0, 24576]}
+    for shape, nb in (((3000, 700, 1200, 3), 256), ((1900, 300, 900, 9), 128), ((5000, 1000, 2500, 11), 256)):
+        n, me, mi, seed = shape
+        qp = make_qp(n, me, mi, seed)
+        ref = None
+        for trial in range(10):
+            opts = {} if trial == 0 else {k: rnd.choice(v) for k, v in space.items() if rnd.random() < 0.6}
+            core = NewtonCore(n, me, mi, device=0, nb=nb)
+            for k, v in opts.items():
+                core.set_option(k, v)
+            core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+            core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+            for rep in range(3):
+                dz, st = core.step(0.0, 0.0)
+                if ref is None:
+                    ref = dz.clone()
+                assert torch.equal(dz, ref), (shape, nb, opts, rep)
+            core.close()
