@@ -297,7 +297,8 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *   rows below the group's diagonal block follow on their own stream -- DESIGN.md section 3; "pending_left_rows": their
  *   in-group updates are applied left-looking while more rows than this remain, default 12288, -1 never), "tile_step" 0|1 (the same
  *   pair of kernels panel by panel: what the per-panel / multi-GPU driver uses), "head_on_side" 0|1 (the lookahead head on
- *   the stream of the chain it follows), "head_serial" 0|1 (the group's bulk update waits for that head), "fast_on_main"
+ *   the stream of the chain it follows), "head_serial" 0|1 (the group's bulk update waits for that head), "head_split" 0|1
+ *   (chain-bound regime: the head's rows below the target group's diagonal block run on the rows stream), "fast_on_main"
  *   0|1 (groups inside the slack block run on the main stream), "bwd_diag4" 0|1 (in-panel backward substitution on 1024
  *   threads through shared memory), "keep_zeros" 0|1 (K1 leaves in place the zeros of the (s,x), (s,s), (lambda_e,s),
  *   (lambda_i,s) blocks that nothing can fill in; single rank), "head_waves" 4|8,

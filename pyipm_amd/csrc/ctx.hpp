@@ -104,7 +104,9 @@ struct Ctx {
                                           // below the group's diagonal block follow on their own stream; same bits
     hipStream_t rest = nullptr;           // ... that stream (high priority, created on first use)
     std::vector<hipEvent_t> ev_band;      // panel (by offset in its group): its tiles are inverted and applied inside the diagonal block
-    hipEvent_t ev_join = nullptr, ev_main = nullptr;
+    hipEvent_t ev_join = nullptr, ev_main = nullptr, ev_split = nullptr;
+    int head_split = 1;                   // the lookahead head in two launches: the target group's diagonal block on the chain's stream,
+                                          // the rows below it on ctx->rest (first read there)
     int head_waves = 4;                   // waves per block of a lookahead head launched on the chain's stream (4: k_update<128,true,4>,
                                           // its own line in a kernel trace; 8: the bulk instance)
     int64_t pending_left_rows = 12288;    // group chain: left-looking in-group updates of the rows below the diagonal block while more

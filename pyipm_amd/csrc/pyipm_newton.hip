@@ -448,6 +448,15 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
     return 0;
 }
 
+int ensure_rest_stream(Ctx* ctx) {
+    if (!ctx->rest) {
+        int lo = 0, hi = 0;
+        PYIPM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        PYIPM_HIP(hipStreamCreateWithPriority(&ctx->rest, hipStreamNonBlocking, ctx->rest_prio ? hi : lo));
+    }
+    return 0;
+}
+
 // One group of panels of the single-rank schedule, chained tile to tile (kernels_panel.hpp).  The diagonal block of the
 // WHOLE group (n0 * nb columns) runs as one sequence of k_tile_step launches on `chain`: a tile waits for nothing but the
 // tile before it, and what the per-panel schedule did between two panels of a group (the pending update of the next
@@ -462,11 +471,7 @@ int factor_group(Ctx* ctx, int64_t p0, int64_t n0, hipStream_t chain, const std:
     const int nT = toff[(size_t)n0];
     const int64_t gc0 = g.panel_c0(p0), glc0 = g.local_c0(p0), gend = gc0 + (int64_t)nT * TB;
     const int64_t TT = (int64_t)TB * TB;
-    if (!ctx->rest) {
-        int lo = 0, hi = 0;
-        PYIPM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        PYIPM_HIP(hipStreamCreateWithPriority(&ctx->rest, hipStreamNonBlocking, ctx->rest_prio ? hi : lo));
-    }
+    { int r0 = ensure_rest_stream(ctx); if (r0) return r0; }
     if (!ctx->ev_join) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     while ((int64_t)ctx->ev_band.size() < n0) { hipEvent_t e; PYIPM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_band.push_back(e); }
     double* Wg = wbuf(ctx, p0);
@@ -1037,6 +1042,11 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         int r2 = fwd_panel(ctx, q, ctx->fwd_vec, ctx->fwd); if (r2) return r2;
         return diag_panel(ctx, q, ctx->fwd_vec, ctx->fwd);
     };
+    // does group grp run as a tile chain (factor_group)?
+    auto chain_group = [&](int64_t grp) -> bool {
+        const bool fast = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)grp];
+        return ctx->group_chain && ctx->inpanel32 && !fast && gsize(grp) * (g.nb / TB) <= 32 && g.nb % 128 == 0;
+    };
     // all panels of one group on stream S; with_early: every panel but the last records the event its early head waits for
     auto run_group = [&](int64_t grp, hipStream_t S, bool with_early) -> int {
         const int64_t pA = ctx->grp_first[(size_t)grp], nA = gsize(grp);
@@ -1050,9 +1060,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             }
             return 0;
         };
-        const bool fast = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)grp];
-        if (ctx->group_chain && ctx->inpanel32 && !fast && nA * (g.nb / TB) <= 32 && g.nb % 128 == 0)
-            return factor_group(ctx, pA, nA, S, done);
+        if (chain_group(grp)) return factor_group(ctx, pA, nA, S, done);
         for (int64_t q = pA; q < pA + nA; ++q) {
             int r2 = factor_panel(ctx, q, S, true); if (r2) return r2;
             r2 = done(q, S); if (r2) return r2;
@@ -1068,8 +1076,42 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             // contribution an early head has not applied yet (see below).
             const int64_t hc0 = g.panel_c0(p1);
             const bool fast_src = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)grp];
-            auto head_from = [&](int64_t q0, int64_t nq, int64_t tp, int64_t tn, hipStream_t hs) -> int {
+            auto head_from = [&](int64_t q0, int64_t nq, int64_t tp, int64_t tn, hipStream_t hs, bool split = false) -> int {
                 const int64_t tc0 = g.panel_c0(tp);
+                if (split && ctx->inpanel32 && !fast_src && g.Npad - tc0 <= ctx->head32_rows) {      // (where the chain is the bound)
+                    // The chain of the target group needs the head only inside that group's diagonal block (rows [tc0, tend));
+                    // the rows below it are first read by the group's rows stream.  Two launches: the block on the chain's
+                    // stream, the rest on ctx->rest behind it -- the same entries, the same operations.
+                    int K = 0; int64_t cols = 0;
+                    for (int64_t q = q0; q < q0 + nq; ++q) K += (int)g.panel_w(q);
+                    for (int64_t q = tp; q < tp + tn; ++q) cols += g.panel_w(q);
+                    const int64_t tend = tc0 + cols;
+                    int64_t pa0, pa1, pb0, pb1;
+                    active_ranges(ctx, g.panel_c0(q0), g.panel_c0(q0) + K, &pa0, &pa1, &pb0, &pb1);
+                    if (tend < g.Npad) {
+                        int r2 = ensure_rest_stream(ctx); if (r2) return r2;
+                        if (!ctx->ev_split) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_split, hipEventDisableTiming));
+                        PYIPM_HIP(hipEventRecord(ctx->ev_split, hs));          // the source group is complete, the main stream's
+                        PYIPM_HIP(hipStreamWaitEvent(ctx->rest, ctx->ev_split, 0));   // earlier updates of these columns are ordered
+                    }
+                    hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)(cols / 32), (unsigned)(cols / TB)), dim3(256), 0,
+                                       hs, ctx->A, g.Npad, g.local_c0(tp), ctx->A + g.local_c0(q0) * g.Npad, g.Npad,
+                                       wbuf(ctx, q0), g.Npad, tc0, K, tc0, g.Npad, pa0, pa1, pb0, pb1, ctx->side_prio);
+                    PYIPM_KCHECK();
+                    if (tend < g.Npad) {
+                        if (g.Npad - tend <= ctx->head32_rows) {
+                            hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - tend) / 32), (unsigned)(cols / TB)), dim3(256), 0,
+                                               ctx->rest, ctx->A, g.Npad, g.local_c0(tp), ctx->A + g.local_c0(q0) * g.Npad, g.Npad,
+                                               wbuf(ctx, q0), g.Npad, tc0, K, tend, g.Npad, pa0, pa1, pb0, pb1, ctx->side_prio);
+                            PYIPM_KCHECK();
+                        } else {
+                            int r2 = launch_update128(ctx, ctx->rest, ctx->A + g.local_c0(q0) * g.Npad, g.Npad, wbuf(ctx, q0), K, tend, tp, tn,
+                                                      /*bulk=*/true, 0, 0, 0, g.panel_c0(q0), 1, 0, ctx->head_waves);
+                            if (r2) return r2;
+                        }
+                    }
+                    return 0;
+                }
                 if (ctx->inpanel32 && !fast_src && g.Npad - tc0 <= ctx->head32_rows) {
                     int K = 0; int64_t cols = 0;
                     for (int64_t q = q0; q < q0 + nq; ++q) K += (int)g.panel_w(q);
@@ -1101,7 +1143,8 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             {
                 int64_t q = p0;
                 while (q < p0 + n0 && early[(size_t)q]) ++q;                       // applied early (always a prefix of the group)
-                if (q < p0 + n0) { rc = head_from(q, p0 + n0 - q, p1, n1, hs); if (rc) return rc; }
+                const bool split = ctx->head_split && chain_group(grp + 1) && cs != ctx->stream;
+                if (q < p0 + n0) { rc = head_from(q, p0 + n0 - q, p1, n1, hs, split); if (rc) return rc; }
             }
             (void)hc0;
             if (hs == ctx->stream && cs == ctx->side) {
@@ -1348,6 +1391,7 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     if (ctx->rest) { hipStreamSynchronize(ctx->rest); hipStreamDestroy(ctx->rest); }
     if (ctx->ev_fwd) hipEventDestroy(ctx->ev_fwd);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_split) hipEventDestroy(ctx->ev_split);
     if (ctx->ev_main) hipEventDestroy(ctx->ev_main);
     for (auto e : ctx->ev_band) hipEventDestroy(e);
     for (auto e : ctx->ev_done) hipEventDestroy(e);
@@ -1939,6 +1983,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "group_chain")) { ctx->group_chain = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "bwd_diag4")) { ctx->bwd_diag4 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "head_on_side")) { ctx->head_on_side = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "head_split")) { ctx->head_split = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "fast_on_main")) { ctx->fast_on_main = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "rest_prio")) { ctx->rest_prio = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "keep_zeros")) { ctx->keep_zeros = (int)value != 0; ctx->zeros_clean = false; return PYIPM_OK; }
