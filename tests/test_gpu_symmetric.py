@@ -208,7 +208,8 @@ def test_random_schedule_options_give_the_same_bits():
     space = {"lookahead": [0, 1], "group_chain": [0, 1], "head_on_side": [0, 1], "fast_on_main": [0, 1], "early_head": [0, 1],
              "pending_left_rows": [-1, 0, 12288], "fuse_forward": [0, 1], "keep_zeros": [0, 1], "skip_zeros": [0, 1],
              "head_serial": [0, 1], "head_split": [0, 1], "tile_step": [0, 1], "head32_rows": [0, 6144, 1 << 20], "pending32_rows": [0, 24576]}
-    for shape, nb in (((3000, 700, 1200, 3), 256), ((1900, 300, 900, 9), 128), ((5000, 1000, 2500, 11), 256)):
+    for shape, nb in (((3000, 700, 1200, 3), 256), ((1900, 300, 900, 9), 128), ((5000, 1000, 2500, 11), 256),
+                      ((1000, 300, 900, 2), 256)):       # (the last one: a lone 128-wide panel as last group, n off every tile boundary)
         n, me, mi, seed = shape
         qp = make_qp(n, me, mi, seed)
         ref = None
@@ -223,5 +224,8 @@ def test_random_schedule_options_give_the_same_bits():
                 dz, st = core.step(0.0, 0.0)
                 if ref is None:
                     ref = dz.clone()
+                    raw = dz.clone(); raw[n + mi:] *= -1.0            # ... and the default is RIGHT: |Hc dz - g| / |g| from the blocks
+                    gres = core.residual()
+                    assert float((core.matvec(raw) - gres).norm() / gres.norm()) <= 1e-12, (shape, nb)
                 assert torch.equal(dz, ref), (shape, nb, opts, rep)
             core.close()
