@@ -307,7 +307,7 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *   "pending32_rows", "head32_rows",
  *   "head32_rows_dist" (row counts up to which a panel's pending in-group update / the lookahead head / the per-panel
  *   head take that kernel; defaults 24576 / 6144 / 16384), "early_head" 0|1 (tail regime: the next group's columns are
- *   updated panel by panel beside the chain) -- all of these choose between implementations that accumulate the same
+ *   updated panel by panel beside the chain; default 0 since the head is split) -- all of these choose between implementations that accumulate the same
  *   products in the same order: the results are bit-identical (tests/test_gpu_symmetric.py). */
 int pyipm_newton_set_option(pyipm_newton_ctx* ctx, const char* name, double value);
 

@@ -121,8 +121,9 @@ struct Ctx {
     int bwd_diag4 = 1;                    // in-panel backward substitution on 1024 threads through shared memory (k_bwd_diag4)
     int tile_step = 1;                    // stepped panel schedule (kernels_panel.hpp): one launch per diagonal tile (the rows inside the
                                           // diagonal block), one for the rows below it; panels of at most 4 tiles; same bits
-    int early_head = 1;                   // tail regime: a group's panels except the last update the next group's columns as soon
-                                          // as each is factored (beside the chain), so only the last panel's K = nb is left between two chains
+    int early_head = 0;                   // tail regime: a group's panels except the last update the next group's columns as soon
+                                          // as each is factored (beside the chain), so only the last panel's K = nb is left between two chains.
+                                          // Off since the head became two launches (head_split): it then costs 1 % (108.2 vs 109.4 ms)
     int64_t head32_rows = 6144;           // ... and the lookahead HEAD update (next group's columns, on the critical path between two
                                           // groups' chains: one 128x128 tile at K = 512 takes 132 us however few tiles there are)
     bool per_panel_mode = false;          // the per-panel phases (pyipm_newton_factor_begin ...) drive this factorisation

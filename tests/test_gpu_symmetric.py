@@ -152,7 +152,7 @@ def test_chain_kernel_choices_are_bitwise_neutral(shape, nb):
     out = []
     for opts in ({}, {"pending_left_rows": 0}, {"pending_left_rows": -1}, {"group_chain": 0}, {"group_chain": 0, "tile_step": 0},
                  {"group_chain": 0, "tile_step": 0, "inpanel32": 0},
-                 {"group_chain": 0, "tile_step": 0, "fuse_scale_update": 0}, {"early_head": 0}, {"head32_rows": 0, "pending32_rows": 0},
+                 {"group_chain": 0, "tile_step": 0, "fuse_scale_update": 0}, {"early_head": 1}, {"head32_rows": 0, "pending32_rows": 0},
                  {"head32_rows": 1 << 20, "pending32_rows": 1 << 20}, {"tail_cols": 1024, "early_head": 1}):
         core = NewtonCore(n, me, mi, device=0, nb=nb)
         for k, v in opts.items():
