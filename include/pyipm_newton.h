@@ -227,6 +227,9 @@ int pyipm_newton_set_exchange(pyipm_newton_ctx* ctx, pyipm_bcast_fn bcast, pyipm
 int pyipm_newton_rccl_library(const char* path);
 int pyipm_newton_comm_unique_id(void* id128);
 int pyipm_newton_comm_init(pyipm_newton_ctx* ctx, const void* id128);
+/* Number of ranks of the handle's RCCL communicator as RCCL itself reports it (ncclCommCount); 0 = no communicator
+ * (callback exchange or single rank), negative = error.  bench.py prints it so that a multi-GPU line proves RCCL saw N ranks. */
+int pyipm_newton_comm_ranks(pyipm_newton_ctx* ctx);
 /* Row-sharded staging: a rank assembles only the KKT columns it owns, and column j (j < n) of the lower triangle is
  * row j of triu(d2L) | Je | Ji -- so it needs only those rows.  owned_rows returns their number and (rows != NULL)
  * their global indices in the order the arrays must hold them (= the rank's local column order).  After
@@ -266,8 +269,10 @@ int pyipm_newton_step_batched(pyipm_newton_ctx* ctx, double delta, double delta_
 /* ---- introspection for tests / bench ------------------------------------------------------ */
 
 /* Device pointer + leading dimension of the local KKT storage (column-major lower).  The caller may write through the
- * pointer: handing it out makes the next assemble() store every entry again (otherwise the zeros that no elimination step can
- * fill in are left in place from one assembly to the next, option "keep_zeros"). */
+ * pointer: handing it out makes EVERY following assemble() store every entry again (otherwise the zeros that no elimination
+ * step can fill in are left in place from one assembly to the next, option "keep_zeros") -- the holder of the pointer may
+ * write at any later time, so the shortcut stays off for this handle until set_option("keep_zeros", 1) is called again
+ * (a promise that nothing writes through the pointer any more). */
 int pyipm_newton_kkt_storage(pyipm_newton_ctx* ctx, double** ptr, int64_t* ld, int64_t* ncols);
 /* Time (ms, HIP events on the handle's stream) of the phases of the last factor/solve call:
  * out[0]=assemble, [1]=panel work (factor time during which no update launch ran), [2]=trailing updates (sum of the launches'

@@ -113,6 +113,8 @@ struct Ctx {
                                           // rows than this remain below it (-1: never)
     int keep_zeros = 1;                   // K1 does not store again the zeros nothing can fill in (k_assemble, zeros_in_place)
     bool zeros_clean = false;             // ... which requires that the last writer of those places was a full assembly
+    bool storage_exported = false;        // kkt_storage() handed the pointer out: a holder may write into those zeros at any time,
+                                          // so every assembly is a full one until set_option("keep_zeros") is called again
     int rest_prio = 1;                    // ctx->rest is a high-priority stream (set before the first factorisation)
     int fast_on_main = 1;                 // groups inside the slack block (closed form) run on the main stream, not through the lookahead
     int head_serial = 0;                  // ... and the bulk update of the group waits for it (instead of running beside it)
@@ -157,6 +159,7 @@ struct Ctx {
     double *Tsv = nullptr;                // the diagonal tiles T_k themselves (refinement of the block solves)
     double *Tflag = nullptr;              // per tile: 1.0 = refine block solves with it (pivot spread beyond refine_cond)
     double *rhs = nullptr, *v0 = nullptr, *v1 = nullptr, *v2 = nullptr, *partial = nullptr;
+    double *v3 = nullptr;                 // adaptive refinement: the iterate before the last correction (a step that made it worse is taken back)
     double *df = nullptr, *ce = nullptr, *ci = nullptr, *s = nullptr, *lda = nullptr;
     DevStats* dstats = nullptr;
     unsigned long long* anorm = nullptr;  // device: bits of max |assembled KKT entry| (per problem for a batched handle): scale of a static pivot

@@ -19,6 +19,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -41,6 +42,7 @@ int rccl_load(std::string* err) {
     a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    a.CommCount = (decltype(a.CommCount))dlsym(lib, "ncclCommCount");
     a.Broadcast = (decltype(a.Broadcast))dlsym(lib, "ncclBroadcast");
     a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
@@ -492,10 +494,16 @@ int solve_dist(Ctx* ctx, const double* rhs, double* dz, int flip, int refine, in
             const double berr = ss[1] > 0.0 ? sqrt(ss[0] / ss[1]) : sqrt(ss[0]);     // identical on every rank: replicated vectors
             if (it == 0) ctx->info_berr0 = berr;
             ctx->info_berr = berr;
+            if (prev >= 0.0 && !(berr <= prev)) {                             // the last step made it worse: take it back
+                DIST_HIP(hipMemcpyAsync(ctx->v0, ctx->v3, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, st));
+                ctx->info_berr = prev; ctx->info_steps = it - 1;
+                break;
+            }
             if (!(berr <= 1.0e300)) break;
             if (berr <= ctx->refine_target) { ctx->info_converged = 1; break; }
             if (it == maxit || (prev >= 0.0 && berr > 0.25 * prev)) break;
             prev = berr;
+            DIST_HIP(hipMemcpyAsync(ctx->v3, ctx->v0, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, st));
         }
         rc = solve_dist_once(ctx, D, ctx->v2, ctx->vc); if (rc) return rc;
         hipLaunchKernelGGL(k_axpby, grid1(g.Npad), dim3(256), 0, st, ctx->v0, ctx->v0, ctx->vc, 1.0, 1.0, g.Npad);
@@ -561,6 +569,17 @@ int pyipm_newton_comm_init(pyipm_newton_ctx* h, const void* id128) try {
     ncclResult_t r = g_rccl.CommInitRank(&D->comm, ctx->g.world, id, ctx->g.rank);
     if (r != ncclSuccess) { D->comm = nullptr; ctx->err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; }
     return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+int pyipm_newton_comm_ranks(pyipm_newton_ctx* h) try {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    if (!ctx->dist || !ctx->dist->comm) return 0;
+    if (!g_rccl.CommCount) { ctx->err = "RCCL library lacks ncclCommCount"; return PYIPM_E_COMM; }
+    int n = 0;
+    ncclResult_t r = g_rccl.CommCount(ctx->dist->comm, &n);
+    if (r != ncclSuccess) { ctx->err = std::string("ncclCommCount: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; }
+    return n;
 } PYIPM_CATCH_H(h)
 
 int64_t pyipm_newton_owned_rows(pyipm_newton_ctx* h, int64_t* rows) try {

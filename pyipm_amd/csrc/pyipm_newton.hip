@@ -46,6 +46,7 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
     const size_t ov0 = cv.take((size_t)g.Npad * D);
     const size_t ov1 = cv.take((size_t)g.Npad * D);
     const size_t ov2 = cv.take((size_t)g.Npad * D);
+    const size_t ov3 = cv.take((size_t)g.Npad * D);
     const size_t nchunk = (size_t)((g.Npad + ROWCHUNK - 1) / ROWCHUNK) + 1;
     size_t npart = nchunk * (size_t)g.nb;
     const size_t cd_chunks = 64;                       // column-dot partials for the mat-vec
@@ -70,6 +71,7 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
         c->A = (double*)(base + oA); c->Wbuf = (double*)(base + oW); c->Lbuf = (double*)(base + oL);
         c->Dinv = (double*)(base + oD); c->Tsv = (double*)(base + oT); c->Tflag = (double*)(base + oTf); c->rhs = (double*)(base + orhs);
         c->v0 = (double*)(base + ov0); c->v1 = (double*)(base + ov1); c->v2 = (double*)(base + ov2);
+        c->v3 = (double*)(base + ov3);
         c->partial = (double*)(base + op);
         c->df = (double*)(base + odf); c->ce = (double*)(base + oce); c->ci = (double*)(base + oci);
         c->s = (double*)(base + os); c->lda = (double*)(base + ol);
@@ -964,7 +966,7 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
         dim3 grid((unsigned)((g.Npad + 511) / 512), (unsigned)((g.ncols_local + 15) / 16));
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
                            ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, ctx->sharded,
-                           (ctx->keep_zeros && ctx->zeros_clean && g.world == 1 && g.mi > 0) ? 1 : 0);
+                           (ctx->keep_zeros && !ctx->storage_exported && ctx->zeros_clean && g.world == 1 && g.mi > 0) ? 1 : 0);
         PYIPM_KCHECK();
     }
     // the zeros of this assembly survive a factorisation of finite numbers (every update that reaches them adds an exact zero);
@@ -1545,10 +1547,16 @@ static int solve_finish(Ctx* ctx, double* dz, int flip, int refine, int memkind,
             const double berr = ss[1] > 0.0 ? sqrt(ss[0] / ss[1]) : sqrt(ss[0]);
             if (it == 0) ctx->info_berr0 = berr;
             ctx->info_berr = berr;
+            if (prev >= 0.0 && !(berr <= prev)) {                             // the last step made it worse (or NaN): take it back
+                PYIPM_HIP(hipMemcpyAsync(ctx->v0, ctx->v3, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                ctx->info_berr = prev; ctx->info_steps = it - 1;
+                break;
+            }
             if (!(berr <= 1.0e300)) break;                                    // NaN / Inf: nothing to refine
             if (berr <= ctx->refine_target) { ctx->info_converged = 1; break; }
             if (it == maxit || (prev >= 0.0 && berr > 0.25 * prev)) break;    // out of budget / stagnating
             prev = berr;
+            PYIPM_HIP(hipMemcpyAsync(ctx->v3, ctx->v0, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));   // the iterate this error belongs to
         }
         rc = solve_inplace(ctx, ctx->v2); if (rc) return rc;
         hipLaunchKernelGGL(k_axpby, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v0, ctx->v0, ctx->v2, 1.0, 1.0, g.Npad);
@@ -1932,7 +1940,8 @@ int pyipm_newton_bwd_panel(pyipm_newton_ctx* h, int64_t p, double* v) try {
 int pyipm_newton_kkt_storage(pyipm_newton_ctx* h, double** ptr, int64_t* ld, int64_t* ncols) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
-    if (ptr) { *ptr = ctx->A; ctx->zeros_clean = false; }      // the caller may write through it
+    if (ptr) { *ptr = ctx->A; ctx->zeros_clean = false; ctx->storage_exported = true; }   // the caller may write through it, now or
+                                                                // later: every assembly is a full one until "keep_zeros" is set again
     if (ld) *ld = ctx->cond_active ? ctx->gc.Npad : ctx->g.Npad;
     if (ncols) *ncols = ctx->cond_active ? ctx->gc.ncols_local : ctx->g.ncols_local;
     return PYIPM_OK;
@@ -1986,7 +1995,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "head_split")) { ctx->head_split = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "fast_on_main")) { ctx->fast_on_main = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "rest_prio")) { ctx->rest_prio = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "keep_zeros")) { ctx->keep_zeros = (int)value != 0; ctx->zeros_clean = false; return PYIPM_OK; }
+    if (!strcmp(name, "keep_zeros")) { ctx->keep_zeros = (int)value != 0; ctx->zeros_clean = false; ctx->storage_exported = false; return PYIPM_OK; }
     if (!strcmp(name, "pending_left_rows")) { ctx->pending_left_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "head_waves")) { ctx->head_waves = ((int)value == 8) ? 8 : 4; return PYIPM_OK; }
     if (!strcmp(name, "head_serial")) { ctx->head_serial = (int)value != 0; return PYIPM_OK; }

@@ -147,10 +147,27 @@ class DistNewton(object):
             self._msg = self.core.new_buffer(max(numel, self.core.panel_msg_numel(0)))
         return self._msg[:numel]
 
+    def _native(self, fn, *args, **kw):
+        """Run a native distributed entry point.  An exception raised inside an exchange callback cannot cross the C
+        frames: the callback stores it and returns non-zero, the library reports PYIPM_E_COMM.  Here the stored
+        exception is re-raised as the cause (and cleared, so it cannot resurface after a later, successful call)."""
+        from .newton import NewtonError
+        try:
+            out = fn(*args, **kw)
+        except NewtonError as e:
+            cb, self._cb_error = self._cb_error, None
+            if cb is not None:
+                raise cb from e
+            raise
+        cb, self._cb_error = self._cb_error, None
+        if cb is not None:
+            raise cb
+        return out
+
     # ------------------------------------------------------------------ phases
     def factor(self):
         if self.native:
-            st = self.core.factor_dist()
+            st = self._native(self.core.factor_dist)
             self.bytes_broadcast = self.core.dist_timings()["bytes"]
             return st
         # world == 1 normally takes the lock-step loop; force_lookahead lets a single rank run the overlapped
@@ -299,7 +316,7 @@ class DistNewton(object):
         """g = -grad, complete on every rank."""
         core = self.core
         if self.native:
-            return core.residual_dist()
+            return self._native(core.residual_dist)
         g = core.residual()
         if getattr(core, "residual_is_partial", False):     # a HIP rank of several computes the rows it owns
             self._allreduce_sum(g)
@@ -312,7 +329,7 @@ class DistNewton(object):
         vector) -- nb numbers; backward: each resolved segment is broadcast -- nb numbers."""
         core = self.core
         if self.native:
-            return core.solve_dist(rhs, flip=flip, refine=refine)
+            return self._native(core.solve_dist, rhs, flip=flip, refine=refine)
         if refine:
             raise NotImplementedError("refinement runs in the native driver (pyipm_newton_solve_dist)")
         v = core.new_buffer(self.Npad)
@@ -348,10 +365,8 @@ class DistNewton(object):
         """residual + assemble + factor + solve + flip (pyipm.py:1717-1725) over all ranks."""
         core = self.core
         if self.native:
-            dz, st = core.step_dist(delta, delta_c, refine=refine)
+            dz, st = self._native(core.step_dist, delta, delta_c, refine=refine)
             self.bytes_broadcast = core.dist_timings()["bytes"]
-            if self._cb_error is not None:
-                raise self._cb_error
             return dz, st
         g = self.residual()
         core.assemble(delta, delta_c)

@@ -65,6 +65,7 @@ class HipNewtonBackend(object):
         self.max_shift_tries = max_shift_tries
         self.n_factor = 0
         self.n_static = 0                   # directions recovered from a statically pivoted factor
+        self.n_unconverged = 0              # refined solves that missed berr_tol and were sent to the shift branch
         self.last_solve_info = None
 
     def shape(self):
@@ -166,8 +167,14 @@ class HipNewtonBackend(object):
         singular = self._singular(st, eps)
         dz = None
         if not singular and st["n_neg"] == need:
-            dz, _ = self._solve(st)
-            if st["n_zero"] > 0:
+            dz, converged = self._solve(st)
+            if not converged:
+                # a statically pivoted / 2x2 / high-growth factor whose refinement against the blocks stalls above
+                # berr_tol solves a nearby system, not this one: what the reference's LU would flag as rcond <= eps.
+                # Take the branch reghess takes then (pyipm.py:1379-1403) instead of returning the direction silently.
+                self.n_unconverged += 1
+                dz, singular = None, True
+            elif st["n_zero"] > 0:
                 self.n_static += 1         # reference: LU over the whole matrix, no shift (pyipm.py:1381 not taken)
         if dz is None:
             delta_c = reg_coef * eta * (mu_host ** beta) if (singular and self.me) else 0.0
@@ -182,7 +189,21 @@ class HipNewtonBackend(object):
                 if tries > self.max_shift_tries:
                     raise RuntimeError("inertia not corrected after %d diagonal shifts" % tries)
                 delta *= 10.0
-            dz, _ = self._solve(st)
+            dz, converged = self._solve(st)
+            while not converged:
+                # still no direction that satisfies the blocks: the shift has not made the factor trustworthy yet.
+                # Larger shift (the reference's delta *= 10 loop, :1399-1403), then give up loudly.
+                self.n_unconverged += 1
+                tries += 1
+                if tries > self.max_shift_tries:
+                    raise RuntimeError("refined solve did not reach backward error %.1e after %d diagonal shifts (last: %s)"
+                                       % (self.berr_tol, tries, self.last_solve_info))
+                delta *= 10.0
+                core.assemble(delta, delta_c)
+                st = self._factor()
+                if st["n_neg"] != need or st["nonfinite"]:
+                    continue
+                dz, converged = self._solve(st)
         if not as_tensor:
             dz = dz.cpu().numpy()
         return dz, float(delta), st

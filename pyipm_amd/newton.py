@@ -113,6 +113,7 @@ def load_library(path: str | None = None):
         "pyipm_newton_rccl_library": (c_int, [c_char_p]),
         "pyipm_newton_comm_unique_id": (c_int, [c_void_p]),
         "pyipm_newton_comm_init": (c_int, [ctxp, c_void_p]),
+        "pyipm_newton_comm_ranks": (c_int, [ctxp]),
         "pyipm_newton_owned_rows": (c_int64, [ctxp, POINTER(c_int64)]),
         "pyipm_newton_stage_blocks_owned": (c_int, [ctxp, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int]),
         "pyipm_newton_residual_dist": (c_int, [ctxp, c_void_p, c_int]),
@@ -442,6 +443,13 @@ class NewtonCore(object):
     def comm_init(self, id128):
         buf = (ctypes.c_char * 128).from_buffer_copy(bytes(id128))
         self._ck(self.lib.pyipm_newton_comm_init(self.h, ctypes.cast(buf, c_void_p)))
+
+    def comm_ranks(self):
+        """Ranks of the handle-owned RCCL communicator as RCCL reports them (0: none)."""
+        r = self.lib.pyipm_newton_comm_ranks(self.h)
+        if r < 0:
+            self._ck(r)
+        return int(r)
 
     def residual_dist(self):
         self._use_current_stream()

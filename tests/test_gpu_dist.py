@@ -228,3 +228,86 @@ def test_bench_multi_rank_path_on_one_gpu():
     assert d["backward_error"] <= 1e-12 and d["inertia"]["n_neg"] == 256 + 640 and d["inertia"]["n_zero"] == 0
     ph = d["dist_phases_per_step"]
     assert ph["messages"] > 0 and ph["bytes"] > 0 and ph["factor_ms"] > 0 and ph["chain_ms"] > 0
+
+
+def _rccl_world_worker(rank, world, port, shape, nb, out):
+    """One rank per GPU, nccl process group, handle-owned RCCL communicator (what bench.py --gpus N runs)."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        from pyipm_amd.newton import NewtonCore
+        from pyipm_amd.dist import DistNewton
+        n, me, mi, seed = shape
+        qp = make_qp(n, me, mi, seed)
+        core = NewtonCore(n, me, mi, device=rank, nb=nb, world=world, rank=rank)
+        rows = core.owned_rows()
+        core.stage_blocks_owned(qp["d2L"][rows], qp["Je"][rows] if me else None, qp["Ji"][rows] if mi else None)
+        core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+        core.set_option("profile", 1)
+        drv = DistNewton(core, native=True)
+        dz, st = drv.step(0.0, 0.0)
+        dz2, _ = drv.step(0.0, 0.0)
+        tm = core.dist_timings()
+        torch.cuda.synchronize()
+        out[rank] = (dz.cpu().numpy(), float((dz - dz2).norm()), st, core.comm_ranks(), tm)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_rccl_world_matches_single_rank(world):
+    """Runs wherever the box has at least `world` GPUs (skips on the one-GPU development box): handle-owned RCCL
+    communicator over `world` real devices, direction equal to the one-rank direction to 1e-12, RCCL itself
+    counting `world` ranks, bytes on the wire as predicted."""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs, box has %d" % (world, torch.cuda.device_count()))
+    from pyipm_amd.newton import NewtonCore
+    shape, nb = (1500, 300, 500, 8), 256
+    n, me, mi, seed = shape
+    qp = make_qp(n, me, mi, seed)
+    core = NewtonCore(n, me, mi, device=0, nb=nb)
+    core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    dz0, st0 = core.step(0.0, 0.0)
+    dz0 = dz0.cpu().numpy()
+    del core
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_world_worker, args=(world, _free_port(), shape, nb, out), nprocs=world, join=True)
+    for r in range(world):
+        dz, rep, st, ranks, tm = out[r]
+        assert ranks == world
+        assert np.linalg.norm(dz - dz0) <= 1e-12 * np.linalg.norm(dz0)
+        assert rep == 0.0 and st["n_neg"] == me + mi and st["n_zero"] == 0
+        assert tm["bytes"] == _factor_bytes(n, me, mi, nb)[0]      # every rank takes part in every broadcast
+
+
+def test_bench_self_launches_for_several_gpus():
+    """`python bench.py --gpus 2` with no launcher around it starts its own ranks (it used to exit).  On a
+    one-GPU box both ranks share the device over gloo; on a multi-GPU box this is the real RCCL path and the line
+    says how many ranks RCCL counted."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    multi = torch.cuda.device_count() >= 2
+    if not multi:
+        env["PYIPM_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--nvar", "1536", "--neq", "256", "--nineq", "640", "--nb", "256", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["backward_error"] <= 1e-12
+    assert d["rccl_ranks"] == (2 if multi else 0)

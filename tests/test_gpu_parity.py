@@ -245,13 +245,16 @@ def test_assembly_keeps_only_zeros_nothing_can_fill(shape, nb):
         core.stage_vectors(qp["df"], qp["ce"] if me else None, qp["ci"], s_vec, lam, mu=qp["mu"])
         core.assemble(0.0, 0.0)
         H = orc.kkt_matrix(qp["d2L"], qp["Je"], qp["Ji"], s_vec, lam, n, me, mi)
-        S = core.kkt_storage().cpu().numpy()              # (handing out the pointer makes the NEXT assembly a full one)
+        S = core.kkt_storage().cpu().numpy()              # (handing out the pointer makes every later assembly a full one
         assert np.array_equal(np.triu(S[:N, :N]), np.triu(H))
+        if keep[0]:
+            core.set_option("keep_zeros", 1)              #  until the option is set again: nothing holds the pointer any more)
 
     def step(s_vec, lam):
         core.stage_vectors(qp["df"], qp["ce"] if me else None, qp["ci"], s_vec, lam, mu=qp["mu"])
         return core.step(0.0, 0.0)
 
+    keep = [True]
     s0, l0 = qp["s"], qp["lam"]
     step(s0, l0)                                             # full assembly + factorisation
     s1 = s0 * rng.uniform(0.5, 2.0, mi); l1 = l0.copy(); l1[me:] *= rng.uniform(0.5, 2.0, mi)
@@ -269,6 +272,7 @@ def test_assembly_keeps_only_zeros_nothing_can_fill(shape, nb):
     step(s0, l0)
     check(s1, l1)
     core.set_option("keep_zeros", 0)
+    keep[0] = False
     step(s0, l0)
     check(s1, l1)
 
@@ -393,3 +397,27 @@ def test_ragged_multi_group_shapes_vs_oracle(n, me, mi, nb, tail_cols):
         core.close()
     assert torch.equal(out[0], out[1])
     assert relerr(out[0].cpu().numpy(), ref) <= 1e-9
+
+
+def test_exported_storage_pointer_disables_zero_keeping_for_good():
+    """a caller that keeps the tensor from kkt_storage() and writes into the structurally zero blocks LATER
+    must not corrupt the assemblies that follow: once the pointer is out every assembly stores every entry, until the
+    option is set again."""
+    n, me, mi, seed = 320, 64, 192, 5
+    qp = make_qp(n, me, mi, seed)
+    core = _core(n, me, mi, nb=256)
+    core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    dz0, _ = core.step(0.0, 0.0)
+    dz1, _ = core.step(0.0, 0.0)                             # zeros kept in place
+    assert torch_equal(dz0, dz1)
+    S = core.kkt_storage()                                   # a view the caller keeps
+    core.step(0.0, 0.0)                                      # full assembly (the old behaviour re-armed the shortcut here)
+    S[:n, n:n + mi] = 7.0                                    # rows = columns of the lower triangle: the (s,x) block
+    dz2, _ = core.step(0.0, 0.0)
+    assert torch_equal(dz0, dz2)
+
+
+def torch_equal(a, b):
+    import torch
+    return bool(torch.equal(a, b))

@@ -177,3 +177,34 @@ def test_batched_handle_static_pivots_stay_finite():
         assert stats[b]["n_zero"] == (0 if b == 1 else n)
     ref, _, _, _ = orc.newton_step(H[1], None, Ji[1], df[1], None, ci[1], s[1], lam[1], 0.2, n, me, mi)
     assert relerr(dz[1], ref) <= 1e-10
+
+
+def test_unconverged_refinement_takes_the_shift_branch():
+    """ADVICE r2 / VERDICT r2 item 4: a refined solve that misses berr_tol must never be returned silently.  Forced
+    here on the LP fixture (every x pivot static): with a bar the refinement cannot meet the first direction is sent
+    to the delta / delta_c branch reghess takes on rcond <= eps (pyipm.py:1379-1403); with a bar nothing ever meets
+    the backend gives up loudly after its shift budget."""
+    from pyipm_amd.ipm import HipNewtonBackend
+    d, n, me, mi, b = _load("lp")
+    be = HipNewtonBackend(n, me, mi, device=0, max_shift_tries=3)
+    calls = {"n": 0}
+    solve = be._solve
+
+    def first_one_fails(st):
+        dz, ok = solve(st)
+        calls["n"] += 1
+        return dz, ok and calls["n"] > 1
+
+    be._solve = first_one_fails
+    dz, delta, st = _direction(be, d, b)
+    assert be.n_unconverged == 1 and calls["n"] == 2
+    assert delta == pytest.approx(np.sqrt(EPS))                    # delta0: the first shift of the reference's branch
+    assert st["n_neg"] == me + mi and np.isfinite(dz).all()
+    assert relerr(dz, d["dz"]) <= 1e-5                             # the shifted system's direction: close, not equal
+
+    be2 = HipNewtonBackend(n, me, mi, device=0, max_shift_tries=3)
+    be2.berr_tol = 0.0                                             # nothing converges
+    be2._at_risk = lambda st: True
+    with pytest.raises(RuntimeError, match="refined solve did not reach"):
+        _direction(be2, d, b)
+    assert be2.n_unconverged >= 3
