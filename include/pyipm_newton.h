@@ -216,7 +216,13 @@ int pyipm_newton_bwd_panel(pyipm_newton_ctx* ctx, int64_t p, double* v);
  * Exchange, variant 1 -- caller-supplied collectives (like pyipm_lbfgs_set_allreduce).  A callback must leave its
  * result ordered on `stream` (a hipStream_t): enqueue on it, or complete before returning.  bcast: `bytes` bytes at
  * dev_buf from rank `root` to every rank, in place.  allreduce: `count` doubles in place, op 0 = sum, 1 = max.
- * Non-zero return = failure (PYIPM_E_COMM). */
+ * Non-zero return = failure (PYIPM_E_COMM).
+ * STREAMS: the callbacks are invoked with DIFFERENT streams -- the collective stream for panel broadcasts, the stream of
+ * the trailing forward substitution for its segment sums, the handle's stream for statistics and the static-pivot scale --
+ * and operations on those streams may be in flight at the same time.  A transport whose communicator must not run two
+ * operations concurrently (NCCL / RCCL: one communicator, one stream at a time) has to serialise them itself, e.g. by
+ * hopping every call through one stream of its own with a pair of events (what the library does for the communicator it
+ * owns, variant 2), or by completing each call before it returns. */
 typedef int (*pyipm_bcast_fn)(void* user, void* dev_buf, size_t bytes, int root, void* stream);
 typedef int (*pyipm_allreduce_fn)(void* user, double* dev_buf, size_t count, int op, void* stream);
 int pyipm_newton_set_exchange(pyipm_newton_ctx* ctx, pyipm_bcast_fn bcast, pyipm_allreduce_fn allreduce, void* user);
