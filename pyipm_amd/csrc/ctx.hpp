@@ -182,6 +182,8 @@ struct Ctx {
     int refine_max = 8;                   // ... or after this many steps, or when a step gains less than 4x
     // options
     double pivtol_rel = 1e-14;
+    int tile_blocked = 1;                 // tile inversion 16 pivots at a time while Bunch-Kaufman would accept them in natural order
+                                          // (tile_blocked.hpp); 0: the single sweeps of rounds 1-2 only
     int block_refine = 2;                 // refinement steps of L T = S in the panel scaling and of T z = y in the solves
     double refine_cond = 1.0e3;           // ... applied to tiles whose pivot spread dmax/dmin exceeds this
     int profile = 0;

@@ -95,7 +95,7 @@ __device__ __forceinline__ bool rows_active(const Geo& g, int64_t slo, int64_t s
 }
 
 // Factor one problem per workgroup.  grid B, 256 threads.
-__global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double refine_cond, int nref, double pivtol_rel)
+__global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double refine_cond, int nref, double pivtol_rel, int blocked)
 {
     __shared__ TileScratch sm;
     __shared__ double X[TB][TB + 2];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double re
         __syncthreads();
         // (2) the block pivot
         tile_invert_dev(sm, A, ld, j0, j0, Tinv + (int64_t)t * TB * TB, Tsave + (int64_t)t * TB * TB, Tflag + t,
-                        refine_cond, st, g.N, pivtol_rel, bp.anorm + bi, g.n + g.mi, nullptr);
+                        refine_cond, st, g.N, pivtol_rel, bp.anorm + bi, g.n + g.mi, nullptr, false, blocked != 0);
         __syncthreads();
         // (3) rows below: keep -S' in the upper blocks, overwrite S with L = S X (refined when the tile is flagged)
         if (t + 1 < nt) {

@@ -8,6 +8,7 @@
 //   trailing update  A22 -= Lb21 * W21'.
 #pragma once
 #include "ctx.hpp"
+#include "tile_blocked.hpp"
 
 namespace pyipm {
 
@@ -82,9 +83,16 @@ struct TileScratch {
     double colbuf[2][2][TB];     // [parity][0: column p, 1: column r][row]  (column == row by symmetry)
     double sh_red[4];
     double dsave[TB];            // the 1x1 pivots as they were used (static ones replaced): statistics are taken at the end
-    double pcol[16][TB];         // block steps: the 16 pre-sweep pivot columns one wave publishes for the others
+    union {
+        double pcol[16][TB];     // block steps: the 16 pre-sweep pivot columns one wave publishes for the others
+        struct {                 // before them (never at the same time: barriers in between)
+            BlockedScratch bs;   //   the blocked fast path (tile_blocked.hpp)
+            double xmax[4][TB];  //   cross-wave exchange of the row maxima (the stage itself stays intact for the fast path)
+        } f;
+    };
     int pcnt;                    // ... how many are out so far (polled), -1-n once it stopped after n (general path next)
 };
+static_assert(sizeof(BlockedScratch) + 4 * TB * sizeof(double) <= 16 * TB * sizeof(double), "fast-path scratch must fit into pcol");
 
 // The sweep inversion itself; called by k_tile_invert (one tile of the big factorisation) and by the
 // batched small-system kernel (every tile of one problem, one workgroup per problem).
@@ -97,7 +105,8 @@ __device__ __forceinline__ void tile_invert_dev(
     const unsigned long long* __restrict__ anorm_bits,   // bits of max |assembled entry| (0 = unknown): scale of a static pivot
     int64_t neg_from,                          // global index from which pivots are expected negative (n + mi; pyipm.py:1381)
     unsigned long long* __restrict__ dbg,      // diagnostics only (NULL normally)
-    bool from_stage = false)                   // the caller has put the tile into sm.stage[i][j] (i >= j at least): no global read
+    bool from_stage = false,                   // the caller has put the tile into sm.stage[i][j] (i >= j at least): no global read
+    bool blocked = true)                       // try the blocked fast path first (tile_blocked.hpp); false: the sweeps of rounds 1-2 only
 {
     double (&stage)[TB][TB + 1] = sm.stage;
     double (&colbuf)[2][2][TB] = sm.colbuf;
@@ -137,14 +146,11 @@ __device__ __forceinline__ void tile_invert_dev(
     // A pivot counts as rejected only when it has shrunk below pivtol_rel x its OWN column's original
     // magnitude (cancellation), so a badly scaled but perfectly regular tile (Sigma entries spanning
     // 1e-8..1e8 late in an interior-point run) is left alone.
-    colbuf[0][0][lane] = 0.0;                          // reuse as scratch for the cross-wave row maximum
-    __syncthreads();
-    stage[wave][lane] = amax;                           // stage[] is free again (rows already in registers)
-    __syncthreads();
-    const double cmax0 = fmax(fmax(stage[0][lane], stage[1][lane]), fmax(stage[2][lane], stage[3][lane]));
+    sm.f.xmax[wave][lane] = amax;
     amax = wave_max(amax);
     if (lane == 0) sh_red[wave] = amax;
     __syncthreads();
+    const double cmax0 = fmax(fmax(sm.f.xmax[0][lane], sm.f.xmax[1][lane]), fmax(sm.f.xmax[2][lane], sm.f.xmax[3][lane]));
     const double scale = fmax(fmax(sh_red[0], sh_red[1]), fmax(sh_red[2], sh_red[3]));
     const double inv_scale = scale > 0.0 ? 1.0 / scale : 0.0;
     // Static pivot (GESP, as in SuperLU_DIST): a pivot that BK cannot avoid inside the tile and that has cancelled to
@@ -158,8 +164,23 @@ __device__ __forceinline__ void tile_invert_dev(
     const int neg_lim = (int)((neg_from - grow0) < 0 ? 0 : ((neg_from - grow0) > TB ? TB : (neg_from - grow0)));   // pivots >= this: expected negative
     const int nreal = (int)((Nreal - grow0) < 0 ? 0 : ((Nreal - grow0) > TB ? TB : (Nreal - grow0)));   // real rows in this tile
 
-    unsigned long long mask = ~0ull;        // unswept set (identical in every thread)
-    int left = TB, parity = 0;
+    // ---- blocked fast path: 16 pivots at a time in natural order while Bunch-Kaufman would have accepted them ----
+    int kb_done = 0;
+    if (blocked) {
+        if (wave == 0) sm.f.bs.ptol[lane] = ptol;
+        if (tid == 0) sm.f.bs.fail = 0;
+        __syncthreads();
+        if (dbg && tid == 0) dbg[4] = clock64() - dbg_c0;
+        kb_done = tile_blocked_sweep(stage, sm.f.bs, sm.dsave, dbg);
+        if (dbg && tid == 0) { dbg[5] = clock64() - dbg_c0; dbg[6] = dbg_c0; }
+        #pragma unroll
+        for (int c = 0; c < 16; ++c) {                 // the working matrix as it stands, back in the sweep layout
+            const int j = cb + c;
+            row[c] = (lane >= j) ? stage[lane][j] : stage[j][lane];
+        }
+    }
+    unsigned long long mask = kb_done >= 4 ? 0ull : (~0ull << (16 * kb_done));   // unswept set (identical in every thread)
+    int left = TB - 16 * kb_done, parity = 0;
     int neg = 0, zero = 0, n2 = 0, bad = 0;         // (2x2 pivots count here directly; 1x1 pivots at the end, from dsave)
     double dmin = 1.0e308, dmax = 0.0;
     unsigned long long zmask = 0ull, m2mask = 0ull; // static 1x1 pivots; indices taken in 2x2 pivots
@@ -222,7 +243,7 @@ __device__ __forceinline__ void tile_invert_dev(
     auto pcnt_store = [&](int v) { asm volatile("ds_write_b32 %0, %1" :: "v"(pcnt_lds), "v"(v) : "memory"); };
     auto pcnt_load = [&]() { int v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pcnt_lds) : "memory");
                              return __builtin_amdgcn_readfirstlane(v); };
-    for (int k = 0; k < 4 && left > 0; ++k) {
+    for (int k = kb_done; k < 4 && left > 0; ++k) {
         if (tid == 0) sm.pcnt = 0;
         __syncthreads();
         int n = 16;
@@ -369,9 +390,10 @@ __global__ __launch_bounds__(256) void k_tile_invert(
     double* __restrict__ Tinv, double* __restrict__ Tsave, double* __restrict__ Tflag, double refine_cond,
     DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel,
     const unsigned long long* __restrict__ anorm_bits, int64_t neg_from, unsigned long long* __restrict__ dbg,
-    double* __restrict__ Wnext)            // != NULL: -S of the NEXT diagonal tile's rows in this column block (64 x 64,
+    double* __restrict__ Wnext,            // != NULL: -S of the NEXT diagonal tile's rows in this column block (64 x 64,
                                            // column-major, ld 64): the fused scaling + update launch that follows lets
                                            // every strip read it while the strip that owns those rows overwrites them with L
+    int blocked)                           // fast path of tile_blocked.hpp on / off
 {
     __shared__ TileScratch sm;
     __builtin_amdgcn_s_setprio(3);         // latency-critical chain: win issue arbitration against co-resident bulk waves
@@ -385,7 +407,8 @@ __global__ __launch_bounds__(256) void k_tile_invert(
         #pragma unroll
         for (int q = 0; q < TB * TB / 256; ++q) Wnext[threadIdx.x + 256 * q] = -tmp[q];
     }
-    tile_invert_dev(sm, A, ld, grow0, lcol0, Tinv, Tsave, Tflag, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg);
+    tile_invert_dev(sm, A, ld, grow0, lcol0, Tinv, Tsave, Tflag, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg,
+                    false, blocked != 0);
 }
 
 // 64x64 tile (global, row-major [k][c]) -> LDS array dst_[k][c], scaled: the 16 loads of a thread are issued together

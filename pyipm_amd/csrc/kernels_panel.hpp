@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_step(
     double* __restrict__ W, int64_t ldw,                                     // its -S buffer: W[row + k * ldw], k < 64 nt
     double* __restrict__ Dinv, double* __restrict__ Tsv, double* __restrict__ Tflag,    // of the block's first tile
     double refine_cond, int nref, DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel,
-    const unsigned long long* __restrict__ anorm_bits, int64_t neg_from, unsigned long long* __restrict__ dbg)
+    const unsigned long long* __restrict__ anorm_bits, int64_t neg_from, unsigned long long* __restrict__ dbg, int blocked)
 {
     __shared__ TileScratch sm;
     // inv(T[t-1]) for the scaling lives where the tile inversion will put its stage (and the first bytes of colbuf): it is
@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256, 2) void k_tile_step(
     if (b == 0 && y != 0) return;
     if (t == 0) {
         if (b == 0) {
-            tile_invert_dev(sm, A, ld, c0, lc0, Dinv, Tsv, Tflag, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg);
+            tile_invert_dev(sm, A, ld, c0, lc0, Dinv, Tsv, Tflag, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg,
+                            false, blocked != 0);
         } else if (y == 0) {
             double tmp[TB * TB / 256];
             const int64_t r0 = c0 + (int64_t)b * TB;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_step(
     }
     if (b == 0)
         tile_invert_dev(sm, A, ld, c0 + (int64_t)t * TB, lc0 + (int64_t)t * TB, Dinv + t * TT, Tsv + t * TT, Tflag + t, refine_cond,
-                        st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg, /*from_stage=*/true);
+                        st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg, /*from_stage=*/true, blocked != 0);
 }
 
 // The rows below the diagonal block, 64 per block: all nt stages of the strip in one launch, right-looking.  The column

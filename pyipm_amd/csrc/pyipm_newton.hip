@@ -391,7 +391,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
             int ny = (nt - t + 4) / 5; if (ny < 1) ny = 1; if (ny > 4) ny = 4;
             hipLaunchKernelGGL(k_tile_step, dim3((unsigned)(nt - t), (unsigned)ny), dim3(256), 0, stream, ctx->A, g.Npad, c0, lc0, t, W, g.Npad,
                                Dv, Ts, ctx->Tflag + c0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats, g.N, ctx->pivtol_rel,
-                               ctx->anorm, g.n + g.mi, ctx->dbg_buf);
+                               ctx->anorm, g.n + g.mi, ctx->dbg_buf, ctx->tile_blocked);
             PYIPM_KCHECK();
         }
         const int64_t rb = c0 + nbw;
@@ -431,7 +431,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
         hipLaunchKernelGGL(k_tile_invert, dim3(1), dim3(256), 0, stream, ctx->A, g.Npad, j0, lcol,
                            ctx->Dinv + (j0 / TB) * (int64_t)(TB * TB), ctx->Tsv + (j0 / TB) * (int64_t)(TB * TB),
                            ctx->Tflag + j0 / TB, ctx->refine_cond, ctx->dstats, g.N, ctx->pivtol_rel, ctx->anorm,
-                           g.n + g.mi, ctx->dbg_buf, next ? ctx->Wnext : (double*)nullptr);
+                           g.n + g.mi, ctx->dbg_buf, next ? ctx->Wnext : (double*)nullptr, ctx->tile_blocked);
         PYIPM_KCHECK();
         if (below > 0) {
             NextUpd nu; memset(&nu, 0, sizeof(nu));
@@ -483,7 +483,7 @@ int factor_group(Ctx* ctx, int64_t p0, int64_t n0, hipStream_t chain, const std:
         int ny = (nT - j + 4) / 5; if (ny < 1) ny = 1; if (ny > 4) ny = 4;     // <= ~5 column tiles per block
         hipLaunchKernelGGL(k_tile_step, dim3((unsigned)(nT - j), (unsigned)ny), dim3(256), 0, chain, ctx->A, g.Npad, gc0, glc0, j,
                            Wg, g.Npad, Dv, Ts, ctx->Tflag + gc0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats, g.N,
-                           ctx->pivtol_rel, ctx->anorm, g.n + g.mi, ctx->dbg_buf);
+                           ctx->pivtol_rel, ctx->anorm, g.n + g.mi, ctx->dbg_buf, ctx->tile_blocked);
         PYIPM_KCHECK();
         // panel q's columns are final inside the diagonal block once the first tile of panel q + 1 has applied its last stage
         if (kp < n0 && j == toff[(size_t)kp]) { PYIPM_HIP(hipEventRecord(ctx->ev_band[(size_t)(kp - 1)], chain)); ++kp; }
@@ -1347,7 +1347,7 @@ int pyipm_newton_step_batched(pyipm_newton_ctx* h, double delta, double delta_c,
         hipLaunchKernelGGL(k_b_assemble, grid, dim3(256), 0, ctx->stream, bp, g, ctx->eps, delta, delta_c);
         PYIPM_KCHECK();
     }
-    hipLaunchKernelGGL(k_b_factor, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->refine_cond, ctx->block_refine, ctx->pivtol_rel);
+    hipLaunchKernelGGL(k_b_factor, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->refine_cond, ctx->block_refine, ctx->pivtol_rel, ctx->tile_blocked);
     PYIPM_KCHECK();
     double* out_dev = (memkind == PYIPM_MEM_DEVICE) ? dz : ctx->v2;
     hipLaunchKernelGGL(k_b_solve, dim3(B), dim3((unsigned)g.Npad), 2 * g.Npad * sizeof(double), ctx->stream, bp, g,
@@ -1964,6 +1964,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (check_ctx(h) || !name) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
+    if (!strcmp(name, "tile_blocked")) { ctx->tile_blocked = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "profile")) { ctx->profile = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "debug_fault")) { ctx->debug_fault = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "refine_target")) { ctx->refine_target = value; return PYIPM_OK; }

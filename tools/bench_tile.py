@@ -10,6 +10,8 @@ qp = make_qp(n, me, mi, 1)
 core = NewtonCore(n, me, mi, device=0)
 core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"]); core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
 core.set_option("lookahead", 0)
+if len(sys.argv) > 1:
+    core.set_option("tile_blocked", float(sys.argv[1]))
 ts = []
 for rep in range(6):
     core.assemble(0.0, 0.0); torch.cuda.synchronize()
