@@ -48,50 +48,52 @@ __device__ __forceinline__ double blocked_recip(double d) {
     return r;
 }
 
-// One block sweep, micro-block KB (compile time: every shared-memory address is then a per-lane base -- computed once
-// per tile -- plus an immediate; with the block index in a register the address arithmetic alone was ~200 instructions
-// per block, and a single wave issues one instruction per ~5 cycles whatever it is).  Returns false (uniform) when the
-// block was NOT committed.
+// Per-lane constants of a tile's blocked sweep, computed once (every shared-memory address of the four blocks is one of
+// these bases plus an immediate; a single wave issues one instruction per ~5 cycles whatever it is, so the ~200
+// instructions of address arithmetic and operand masks per block were a quarter of its time).
+struct BlockedLane {
+    int aoff[16];               // bytes: entry (i15, c) of a diagonal micro-block relative to its corner (lower-valid storage)
+    int oRow, oCol;             // bytes: &stage[i15][q], &stage[q][i15]
+    int oRowT, oColT;           // ... of the wave's own row tile: &stage[16 t + i15][q], &stage[q][16 t + i15]
+    double mlt[4], mgt[4], meq[4];   // 1.0 / 0.0: (4 s + q < i15), (4 s + q > i15), (4 s + q == i15)
+};
+
+// One block sweep, micro-block KB (compile time).  Returns false (uniform) when the block was NOT committed.
 template <int KB, int STRIDE>
 __device__ __forceinline__ bool tile_blocked_block(double (&stage)[TB][STRIDE], BlockedScratch& bs, double* __restrict__ dsave,
-                                                   const int (&aoff)[16], unsigned long long* __restrict__ dbg)
+                                                   const BlockedLane& L, unsigned long long* __restrict__ dbg)
 {
 #define PYIPM_TB_STAMP(ph_) if (dbg && lane == 0) dbg[8 + 32 * KB + 8 * wave + (ph_)] = clock64();
+#define PYIPM_TB_LD(off_) (*reinterpret_cast<const double*>(sb + (off_)))
+#define PYIPM_TB_ST(off_) (*reinterpret_cast<double*>(sb + (off_)))
     constexpr int k0 = 16 * KB;
+    constexpr int D8 = (int)sizeof(double), S8 = STRIDE * D8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i15 = lane & 15, q = lane >> 4;
     const int t = wave;                                // this wave's 16-row tile
-    const char* sbase = reinterpret_cast<const char*>(&stage[0][0]) + (size_t)k0 * (STRIDE + 1) * sizeof(double);
+    char* sb = reinterpret_cast<char*>(&stage[0][0]);
     // ---- operands: everything the block needs from the working matrix is requested BEFORE the elimination (none of it
-    //      depends on it), so that the only LDS round trip left behind the dependent chain is M's transpose ----
-    double a[16];                                      // the micro-block: lanes 0..15 of every wave (the other three 16-lane
-    #pragma unroll                                     // rows run the elimination on zeros: nothing of theirs is used)
-    for (int c = 0; c < 16; ++c) a[c] = 0.0;
-    if (q == 0) {
-        #pragma unroll
-        for (int c = 0; c < 16; ++c) a[c] = *reinterpret_cast<const double*>(sbase + aoff[c]);
-    }
+    //      depends on it), so that the only LDS round trip left behind the dependent chain is M's transpose.  Loads are
+    //      unconditional (a tile the wave does not use costs one instruction to load and one to define otherwise) ----
+    double a[16];                                      // the micro-block, redundantly in every wave and every 16-lane row
+    #pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = PYIPM_TB_LD(L.aoff[c] + k0 * (S8 + D8));
     double bW[4][4];                                   // bW[t'][s] = W[16 t' + i15][k0 + 4 s + q]  (W = B[., K], lower-valid storage)
     double4_tb Cn[4];                                  // tiles (t, t'), t' <= t: C[i = 16 t + i15][j = 16 t' + q + 4 rr]
     #pragma unroll
     for (int tp = 0; tp < 4; ++tp) {
         #pragma unroll
-        for (int s = 0; s < 4; ++s) bW[tp][s] = 0.0;
-        Cn[tp] = (double4_tb){0.0, 0.0, 0.0, 0.0};
-        if (tp == KB) continue;
-        if (tp <= t) {                                 // (uniform)
-            #pragma unroll
-            for (int s = 0; s < 4; ++s)
-                bW[tp][s] = tp > KB ? stage[16 * tp + i15][k0 + 4 * s + q] : stage[k0 + 4 * s + q][16 * tp + i15];
-            #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                Cn[tp][rr] = stage[16 * t + i15][16 * tp + q + 4 * rr];            // (above the diagonal: junk, never read back)
-        }
+        for (int s = 0; s < 4; ++s)
+            bW[tp][s] = tp > KB ? PYIPM_TB_LD(L.oRow + 16 * tp * S8 + (k0 + 4 * s) * D8)
+                                : PYIPM_TB_LD(L.oCol + (k0 + 4 * s) * S8 + 16 * tp * D8);          // (t' == KB: unused)
+        #pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Cn[tp][rr] = PYIPM_TB_LD(L.oRowT + (16 * tp + 4 * rr) * D8);  // (above the diagonal: junk)
     }
-    double bWt[4];                                     // the wave's own rows of W (B operand of U); for t == KB the micro-block: U D^-1 = L
+    double bWt[4];                                     // the wave's own rows of W (B operand of U)
     #pragma unroll
-    for (int s = 0; s < 4; ++s) bWt[s] = t >= KB ? stage[16 * t + i15][k0 + 4 * s + q] : stage[k0 + 4 * s + q][16 * t + i15];
+    for (int s = 0; s < 4; ++s)
+        bWt[s] = t >= KB ? PYIPM_TB_LD(L.oRowT + (k0 + 4 * s) * D8) : PYIPM_TB_LD(L.oColT + (k0 + 4 * s) * S8);
     double pt4[4];
     #pragma unroll
     for (int s = 0; s < 4; ++s) pt4[s] = bs.ptol[k0 + 4 * s + q];
@@ -116,90 +118,96 @@ __device__ __forceinline__ bool tile_blocked_block(double (&stage)[TB][STRIDE], 
     }
     // branch-free from here to the vote: flags are accumulated with bitwise operators (|| made hipcc emit ~60
     // exec-mask branches)
-    int bad = (int)(q == 0) & (int)!(lmax <= PYIPM_BK_INV_ALPHA);               // multipliers inside the micro-block
+    int bad = (int)!(lmax <= PYIPM_BK_INV_ALPHA);                               // multipliers inside the micro-block
     double rsel[4], dsel[4], aM[4], aMT[4];            // 1 / d[4 s + q], d[4 s + q], M[i15][4 s + q], M[4 s + q][i15]
     #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int c = 4 * s + q;
         const double v = bs.Ms[i15][c], w = bs.Ms[c][i15];
         dsel[s] = bs.Ds[c];
-        aM[s] = c < i15 ? v : (c == i15 ? 1.0 : 0.0);
-        aMT[s] = i15 < c ? w : (c == i15 ? 1.0 : 0.0);
+        aM[s] = fma(v, L.mlt[s], L.meq[s]);            // unit lower triangular: what the lanes hold above the diagonal is
+        aMT[s] = fma(w, L.mgt[s], L.meq[s]);           // finite junk of the elimination, times zero
     }
-    double4_tb U = {0.0, 0.0, 0.0, 0.0};
-    #pragma unroll
-    for (int s = 0; s < 4; ++s) U = __builtin_amdgcn_mfma_f64_16x16x4f64(aM[s], bWt[s], U, 0, 0, 0);
+    // (each product: two independent accumulators of two k-steps -- a chain of four dependent MFMAs costs ~85 cycles a link)
+    double4_tb U = {0.0, 0.0, 0.0, 0.0}, U2 = {0.0, 0.0, 0.0, 0.0};
+    U  = __builtin_amdgcn_mfma_f64_16x16x4f64(aM[0], bWt[0], U, 0, 0, 0);
+    U2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aM[2], bWt[2], U2, 0, 0, 0);
+    U  = __builtin_amdgcn_mfma_f64_16x16x4f64(aM[1], bWt[1], U, 0, 0, 0);
+    U2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aM[3], bWt[3], U2, 0, 0, 0);
     #pragma unroll
     for (int s = 0; s < 4; ++s) {
         rsel[s] = blocked_recip(dsel[s]);              // the elimination's own sequence: the same bits as its r
         bad |= (int)!(fabs(dsel[s]) > pt4[s]) | (int)!(fabs(dsel[s]) <= 1.0e300);          // the 16 pivots, four per 16-lane row
     }
     if (dbg) { asm volatile("" :: "v"(U[0])); PYIPM_TB_STAMP(5) }
-    double4_tb X = {0.0, 0.0, 0.0, 0.0};               // t != KB: X[i = i15][c = q + 4 r];  t == KB: -inv(P)[b = i15][a = q + 4 r]
-    if (t != KB) {
-        double Lr[4];
-        const double lim = t > KB ? PYIPM_BK_INV_ALPHA : 1.0e300;                // rows not yet eliminated: the Bunch-Kaufman bound
-        #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            Lr[rr] = U[rr] * rsel[rr];
-            bad |= (int)!(fabs(Lr[rr]) <= lim);
-        }
-        #pragma unroll
-        for (int s = 0; s < 4; ++s) X = __builtin_amdgcn_mfma_f64_16x16x4f64(aMT[s], Lr[s], X, 0, 0, 0);
-        // the tiles of the row, k-step by k-step: consecutive MFMAs belong to different tiles (independent accumulators; a
-        // tile at a time is a chain of four dependent ones at ~85 cycles each)
-        #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const double xn = -X[s];
-            #pragma unroll
-            for (int tp = 0; tp < 4; ++tp) {
-                if (tp == KB) continue;
-                if (tp <= t)                           // (uniform)
-                    Cn[tp] = __builtin_amdgcn_mfma_f64_16x16x4f64(bW[tp][s], xn, Cn[tp], 0, 0, 0);
-            }
-        }
-    } else {
-        // the micro-block's own rows: U D^-1 = L, the multipliers of the elimination (unit lower triangular; above the
-        // diagonal: junk) -- nothing to check here that lmax has not seen; -inv(P) = -M' D^-1 M
-        #pragma unroll
-        for (int s = 0; s < 4; ++s) X = __builtin_amdgcn_mfma_f64_16x16x4f64(aMT[s] * rsel[s], -aMT[s], X, 0, 0, 0);
-    }
+    // One instruction stream for all four waves.  The wave that holds the micro-block's own rows (t == KB) puts
+    // -inv(P) = -M' D^-1 M where the others put X = Lr M: same MFMA slots, operands chosen by a uniform select.  Its tile
+    // updates then work on junk and are not stored; tiles above the diagonal (t' > t) are updated and stored as junk by
+    // everyone -- nobody reads above the diagonal -- so that the slowest wave's twelve update MFMAs are simply everybody's
+    // (a uniform branch per tile cost a register copy per accumulator and bought no time: the barrier waits for the
+    // slowest wave anyway).
+    const bool isK = t == KB;
+    double Lr[4];
+    const double lim = t > KB ? PYIPM_BK_INV_ALPHA : 1.0e300;                    // rows not yet eliminated: the Bunch-Kaufman bound
     #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) bad |= (int)!(fabs(X[rr]) <= 1.0e300);
+    for (int rr = 0; rr < 4; ++rr) {
+        Lr[rr] = (U[rr] + U2[rr]) * rsel[rr];
+        bad |= (int)!isK & (int)!(fabs(Lr[rr]) <= lim);
+    }
+    double xa[4], xb[4];
+    #pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        xa[s] = isK ? aMT[s] * rsel[s] : aMT[s];
+        xb[s] = isK ? -aMT[s] : Lr[s];
+    }
+    double4_tb X = {0.0, 0.0, 0.0, 0.0}, X2 = {0.0, 0.0, 0.0, 0.0};   // t != KB: X[i = i15][c = q + 4 r];  t == KB: -inv(P)[b = i15][a = q + 4 r]
+    X  = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[0], xb[0], X, 0, 0, 0);
+    X2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[2], xb[2], X2, 0, 0, 0);
+    X  = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[1], xb[1], X, 0, 0, 0);
+    X2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[3], xb[3], X2, 0, 0, 0);
+    #pragma unroll
+    for (int rr = 0; rr < 4; ++rr) { X[rr] += X2[rr]; bad |= (int)!(fabs(X[rr]) <= 1.0e300); }
+    // the tiles of the row, k-step by k-step: consecutive MFMAs belong to different tiles (independent accumulators)
+    #pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const double xn = -X[s];
+        #pragma unroll
+        for (int tp = 0; tp < 4; ++tp)
+            if (tp != KB) Cn[tp] = __builtin_amdgcn_mfma_f64_16x16x4f64(bW[tp][s], xn, Cn[tp], 0, 0, 0);
+    }
     if (dbg) { asm volatile("" :: "v"(X[0]), "v"(Cn[0][0]), "v"(Cn[3][3])); PYIPM_TB_STAMP(2) }
     if (__ballot(bad != 0) != 0ull && lane == 0) bs.fail = 1;
     __syncthreads();                                   // everyone has read W; the verdict is in
     PYIPM_TB_STAMP(6)
     if (bs.fail) return false;                         // (uniform) nothing of this block has been written
-    // ---- commit (only the lower triangle of the working matrix is ever read: what lands above the diagonal of a
-    //      diagonal tile is junk nobody looks at, so no store needs a per-lane predicate) ----
-    if (t != KB) {
+    // ---- commit (only the lower triangle of the working matrix is ever read: what lands above the diagonal is junk
+    //      nobody looks at, so no store needs a per-lane predicate) ----
+    {
+        // X: stage[16 t + i15][k0 + q + 4 rr] for t >= KB (t == KB: the diagonal block), stage[k0 + q + 4 rr][16 t + i15] below
+        const int xo = t >= KB ? L.oRowT + k0 * D8 : L.oColT + k0 * S8;
         #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            const int c = q + 4 * rr;
-            if (t > KB) stage[16 * t + i15][k0 + c] = X[rr];
-            else        stage[k0 + c][16 * t + i15] = X[rr];
+            if (t >= KB) PYIPM_TB_ST(xo + 4 * rr * D8) = X[rr];
+            else         PYIPM_TB_ST(xo + 4 * rr * S8) = X[rr];
         }
+    }
+    if (!isK) {                                        // (the rows of the micro-block receive the other waves' X', nothing else)
         #pragma unroll
         for (int tp = 0; tp < 4; ++tp) {
             if (tp == KB) continue;
-            if (tp <= t) {
-                #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) stage[16 * t + i15][16 * tp + q + 4 * rr] = Cn[tp][rr];
-            }
+            #pragma unroll
+            for (int rr = 0; rr < 4; ++rr) PYIPM_TB_ST(L.oRowT + (16 * tp + 4 * rr) * D8) = Cn[tp][rr];
         }
-    } else {
-        #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) stage[k0 + i15][k0 + q + 4 * rr] = X[rr];
-        if (i15 < 4) {
-            const long long n0 = i15 == 0 ? -1ll : 0ll, n1 = i15 == 1 ? -1ll : 0ll, n2 = i15 == 2 ? -1ll : 0ll, n3 = i15 == 3 ? -1ll : 0ll;
-            dsave[k0 + 4 * i15 + q] = __longlong_as_double((n0 & __double_as_longlong(dsel[0])) | (n1 & __double_as_longlong(dsel[1])) |
-                                                           (n2 & __double_as_longlong(dsel[2])) | (n3 & __double_as_longlong(dsel[3])));
-        }
+    } else if (i15 < 4) {
+        const long long n0 = i15 == 0 ? -1ll : 0ll, n1 = i15 == 1 ? -1ll : 0ll, n2 = i15 == 2 ? -1ll : 0ll, n3 = i15 == 3 ? -1ll : 0ll;
+        dsave[k0 + 4 * i15 + q] = __longlong_as_double((n0 & __double_as_longlong(dsel[0])) | (n1 & __double_as_longlong(dsel[1])) |
+                                                       (n2 & __double_as_longlong(dsel[2])) | (n3 & __double_as_longlong(dsel[3])));
     }
     __syncthreads();
     PYIPM_TB_STAMP(3)
 #undef PYIPM_TB_STAMP
+#undef PYIPM_TB_LD
+#undef PYIPM_TB_ST
     return true;
 }
 
@@ -210,14 +218,23 @@ template <int STRIDE>
 __device__ __forceinline__ int tile_blocked_sweep(double (&stage)[TB][STRIDE], BlockedScratch& bs, double* __restrict__ dsave,
                                                   unsigned long long* __restrict__ dbg = nullptr)    // diagnostics: dbg[8 + 32 kb + 8 wave + phase] = clock
 {
-    const int i15 = threadIdx.x & 15;
-    int aoff[16];                                      // byte offset of entry (i15, c) of a diagonal micro-block relative to its corner
+    const int lane = threadIdx.x & 63, i15 = lane & 15, q = lane >> 4;
+    const int t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int D8 = (int)sizeof(double), S8 = STRIDE * D8;
+    BlockedLane L;
     #pragma unroll
-    for (int c = 0; c < 16; ++c) aoff[c] = (int)sizeof(double) * (c <= i15 ? i15 * STRIDE + c : c * STRIDE + i15);
-    if (!tile_blocked_block<0>(stage, bs, dsave, aoff, dbg)) return 0;
-    if (!tile_blocked_block<1>(stage, bs, dsave, aoff, dbg)) return 1;
-    if (!tile_blocked_block<2>(stage, bs, dsave, aoff, dbg)) return 2;
-    if (!tile_blocked_block<3>(stage, bs, dsave, aoff, dbg)) return 3;
+    for (int c = 0; c < 16; ++c) L.aoff[c] = c <= i15 ? i15 * S8 + c * D8 : c * S8 + i15 * D8;
+    L.oRow = i15 * S8 + q * D8;  L.oCol = q * S8 + i15 * D8;
+    L.oRowT = L.oRow + 16 * t * S8;  L.oColT = L.oCol + 16 * t * D8;
+    #pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = 4 * s + q;
+        L.mlt[s] = c < i15 ? 1.0 : 0.0;  L.mgt[s] = c > i15 ? 1.0 : 0.0;  L.meq[s] = c == i15 ? 1.0 : 0.0;
+    }
+    if (!tile_blocked_block<0>(stage, bs, dsave, L, dbg)) return 0;
+    if (!tile_blocked_block<1>(stage, bs, dsave, L, dbg)) return 1;
+    if (!tile_blocked_block<2>(stage, bs, dsave, L, dbg)) return 2;
+    if (!tile_blocked_block<3>(stage, bs, dsave, L, dbg)) return 3;
     return 4;
 }
 

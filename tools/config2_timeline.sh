@@ -2,7 +2,7 @@
 # Kernel trace of config 2 (chain-bound) -> gpurun_out/r02q/c2_timeline.txt: every launch of the last steps in start order
 # with its duration and the gap to the previous launch of the same queue (tools/chain_timeline.py).  Extra args go to bench.py.
 set -u
-O=gpurun_out/r02q; mkdir -p $O
+O=gpurun_out/${OUTDIR:-r03q}; mkdir -p $O
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $R/$O/prof -o c2 -- python $R/bench.py --no-cpu-baseline --nvar 2048 --neq 0 --nineq 2048 --steps 3 --warmup 2 $@ > $R/$O/c2.json 2> $R/$O/c2.err
