@@ -133,6 +133,10 @@ struct Ctx {
                                           // next panel, always on the critical path there) while at most this many rows remain
     int64_t pending32_rows = 24576;       // ... and a panel's pending in-group update too while at most this many rows remain
                                           // (128x128 tiles keep one CU busy for 27 us per 256 columns of K, on the chain)
+    int bulk_bn = 128;                    // column width of a bulk update tile: 128 (default), or 256 = 128 x 256 per block (8 waves x 64 x 64,
+                                          // one block per CU): 20 % less L2-miss traffic, the same step time, and a chain kernel waits twice
+                                          // as long for a slot beside it (tools/contention_probe.py) -- measured r03, kept as an option
+    int bulk_bn_min_k = 512;              // ... for launches with at least this K (shorter ones keep 128 x 128: twice the blocks)
     int xcd_swizzle = 1;
     int side_prio = 1;                    // raise wave priority in panel-chain update launches
     unsigned long long* dbg_buf = nullptr;   // diagnostics only

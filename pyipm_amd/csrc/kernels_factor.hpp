@@ -771,8 +771,12 @@ inline int64_t upd_super_count(const UpdGeo& u) {
     return tot;
 }
 
+// BN = 256 (bulk launches, round 3): a block works on 128 x 256 -- each of its 8 waves on 64 x 64 (16 accumulator tiles, 8
+// fragment reads per 16 MFMAs instead of 6 per 8), one block of 107 KB of LDS per CU (two waves per SIMD, 256 registers
+// each): operand bytes per flop from L2 down by a quarter, half as many C-tile prologues per flop.  The products reach every
+// entry in the same order as with BN = 128: the same bits.
 template <int BN, bool SWZ, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW / 2) void k_update(
+__global__ __launch_bounds__(NW * 64, (BN >= 256 ? 2 : NW / 2)) void k_update(
     double* __restrict__ C, int64_t ldc,
     const double* __restrict__ Lop, int64_t ldl,
     const double* __restrict__ Wop, int64_t ldw,

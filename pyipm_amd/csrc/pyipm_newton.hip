@@ -207,13 +207,13 @@ double active_area(int64_t row_begin, int64_t Npad, int64_t j0, int64_t j1, int6
 // every block; tiles that are out of range, above the diagonal or structurally zero are dropped, the eight
 // per-XCD sequences (block b runs on XCD b % 8) are levelled by moving the tails of long ones to short ones,
 // and the result is interleaved back into launch order.  Cached per geometry: it repeats every step.
-int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, unsigned* count) {
+int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, unsigned* count, int bn = 128) {
     if (ctx->debug_fault) {                             // test hook (tests/test_gpu_host_abi.py): the containers below can throw
         const int k = ctx->debug_fault; ctx->debug_fault = 0;
         if (k == 1) throw std::bad_alloc();
         throw std::runtime_error("injected fault");
     }
-    std::vector<int64_t> key = {u.row_begin, u.Npad, u.first_lp, u.nrt, u.nct, u.a0, u.a1, u.b0, u.b1, u.nb, u.rt_min0, u.rt_step};
+    std::vector<int64_t> key = {u.row_begin, u.Npad, u.first_lp, u.nrt, u.nct, u.a0, u.a1, u.b0, u.b1, u.nb, u.rt_min0, u.rt_step, bn};
     auto it = ctx->tile_lists.find(key);
     if (it != ctx->tile_lists.end()) { *dev = it->second.dev; *count = it->second.count; return 0; }
     if (ctx->tile_lists.size() >= 1024) {              // geometries that keep changing (condensed option: |A| varies): start over
@@ -240,12 +240,12 @@ int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, uns
         const int64_t rt = (int64_t)sI * SUPER + (within & (SUPER - 1)), ct = (int64_t)sJ * SUPER + (within >> 3);
         if (rt >= u.nrt || ct >= u.nct) continue;
         int64_t jglob, jloc;
-        upd_col<128>(u, ct, jglob, jloc);
+        if (bn == 256) upd_col<256>(u, ct, jglob, jloc); else upd_col<128>(u, ct, jglob, jloc);
         if (jglob >= u.Npad) continue;
         const int64_t i0 = u.row_begin + rt * BM;
         if (i0 + BM <= jglob) continue;
         const bool ri = (i0 + BM > u.a0 && i0 < u.a1) || (i0 + BM > u.b0 && i0 < u.b1);
-        const bool ci = (jglob + 128 > u.a0 && jglob < u.a1) || (jglob + 128 > u.b0 && jglob < u.b1);
+        const bool ci = (jglob + bn > u.a0 && jglob < u.a1) || (jglob + bn > u.b0 && jglob < u.b1);
         if (!(ri && ci)) continue;
         seq[xcd].push_back((unsigned)rt | ((unsigned)ct << 16));
     }
@@ -289,6 +289,21 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     u.rt_min0 = 0; u.rt_step = 0; u.tiles = nullptr; u.ks_cstride = 0;
     if (src_c0 >= 0) active_ranges(ctx, src_c0, src_c0 + K, &u.a0, &u.a1, &u.b0, &u.b1);
     else { u.a0 = 0; u.a1 = g.Npad; u.b0 = 0; u.b1 = 0; }
+    const int use_waves = waves ? waves : ctx->bulk_waves;
+    if (ctx->xcd_swizzle && bulk && ctx->bulk_bn == 256 && use_waves == 8 && waves == 0 && ksplit == 1 && g.nb % 256 == 0 &&
+        K >= ctx->bulk_bn_min_k) {
+        // 128 x 256 tiles (the K = 1024 bulk launches of the single-rank schedule, the K = nb launches of the per-panel one)
+        u.nct = (int)(n_lp * (g.nb / 256));
+        upd_fill_affine<256>(u);
+        const int64_t nsup = upd_super_count<256>(u);
+        if (nsup <= 0) return 0;
+        unsigned ntiles = 0;
+        int rc = tile_list(ctx, u, nsup, &u.tiles, &ntiles, 256); if (rc) return rc;
+        if (ntiles == 0) return 0;
+        hipLaunchKernelGGL((k_update<256, true, 8>), dim3(ntiles), dim3(512), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
+        PYIPM_KCHECK();
+        return 0;
+    }
     if (ctx->xcd_swizzle && bulk && upd_swizzle_ok<128>(u)) {
         upd_fill_affine<128>(u);
         const int64_t nsup = upd_super_count<128>(u);
@@ -298,7 +313,7 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
         if (ntiles == 0) return 0;
         dim3 grid(ntiles, (unsigned)ksplit);             // K is the length of ONE split
         if (ksplit > 1) u.ks_cstride = ks_cstride;
-        if ((waves ? waves : ctx->bulk_waves) == 8)
+        if (use_waves == 8)
             hipLaunchKernelGGL((k_update<128, true, 8>), grid, dim3(512), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
         else
             hipLaunchKernelGGL((k_update<128, true>), grid, dim3(256), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
@@ -1964,6 +1979,8 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (check_ctx(h) || !name) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
+    if (!strcmp(name, "bulk_bn")) { ctx->bulk_bn = (int)value == 256 ? 256 : 128; return PYIPM_OK; }
+    if (!strcmp(name, "bulk_bn_min_k")) { ctx->bulk_bn_min_k = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "tile_blocked")) { ctx->tile_blocked = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "profile")) { ctx->profile = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "debug_fault")) { ctx->debug_fault = (int)value; return PYIPM_OK; }

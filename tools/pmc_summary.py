@@ -2,12 +2,13 @@
 """Summarise tools/pmc_update.sh output for the bulk trailing-update kernel into a JSON file."""
 import csv, collections, json, sys
 src, dst, steps = sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 2
+KERNEL = sys.argv[4] if len(sys.argv) > 4 else 'k_update<128, true, 8>'   # the bulk launches (heads on the chain's stream are <128, true, 4>)
 out = {}
 for name in ['sq1', 'sq2', 'tcc1', 'tcc2']:
     rows = list(csv.DictReader(open(f'{src}/{name}/{name}_counter_collection.csv')))
     by = collections.defaultdict(dict)
     for r in rows:
-        if 'k_update<128, true, 8>' in r['Kernel_Name']:   # the bulk launches (heads on the chain's stream are <128, true, 4>)
+        if KERNEL in r['Kernel_Name']:
             by[r['Dispatch_Id']][r['Counter_Name']] = float(r['Counter_Value'])
     tot = collections.Counter()
     for k in by:
@@ -19,7 +20,7 @@ fetch = out['tcc1']['FETCH_SIZE'] * 1024
 write = out['tcc2']['WRITE_SIZE'] * 1024
 gui = out['tcc1']['GRBM_GUI_ACTIVE'] / 8
 summary = {
-    'kernel': 'k_update<128,true,8> (all main-stream launches, bench.py --steps 1 --warmup 1 => %d steps)' % steps,
+    'kernel': '%s (all main-stream launches, bench.py --steps 1 --warmup 1 => %d steps)' % (KERNEL, steps),
     'launches': n,
     'units': 'FETCH_SIZE/WRITE_SIZE counters are KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); '
              'WRITE_SIZE matches the algorithmic C-tile store volume within 4% uncorrected',
