@@ -132,13 +132,19 @@ def sweep_invert(T, pivtol_rel=1e-14, anorm=0.0, neg_lim=None):
 class BlockLDL(object):
     """Dense block-LDL' of a symmetric matrix with tile size ``tb`` (device: 64)."""
 
-    def __init__(self, A, tb=64, nreal=None, refine=1, neg_from=None):
+    def __init__(self, A, tb=64, nreal=None, refine=1, neg_from=None, sigma_from=None):
         """``neg_from``: index from which pivots are expected negative (n + mi of a KKT matrix): the sign a static
-        pivot takes.  ``stats['zero']`` counts static pivots; they are also in neg / (N - neg) by their sign."""
+        pivot takes.  ``stats['zero']`` counts static pivots; they are also in neg / (N - neg) by their sign.
+        ``sigma_from``: first index of the slack block (n): its diagonal, Sigma, stays out of the scale of a static pivot
+        as on the device (k_assemble)."""
         A = np.array(A, dtype=np.float64)
         N = A.shape[0]
         self.A0 = np.tril(A) + np.tril(A, -1).T
-        anorm = float(np.abs(A).max()) if A.size else 0.0
+        B = np.abs(A)
+        if sigma_from is not None and neg_from is not None and A.size:
+            idx = np.arange(int(sigma_from), int(min(neg_from, N)))
+            B = B.copy(); B[idx, idx] = 0.0
+        anorm = float(B.max()) if A.size else 0.0
         if neg_from is None:
             neg_from = np.inf
         self.N = N

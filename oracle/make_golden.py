@@ -453,8 +453,74 @@ def main_qp_trace():
         print("qp trace n=%d me=%d mi=%d: %d Newton steps, signal %d, f = %.10g" % (n, me, mi, len(p.trace), p.signal, fval))
 
 
+def lp_problem(n, mi_extra, seed):
+    """min c'x  s.t.  G x - h >= 0: `mi_extra` random half-spaces around a strictly feasible point plus the box
+    |x_i| <= 4 (so the LP is bounded) -- d2L == 0, mi = 2 n + mi_extra >= n."""
+    rng = np.random.default_rng(seed)
+    xf = rng.uniform(-1.0, 1.0, n)
+    Gr = rng.standard_normal((mi_extra, n)) / np.sqrt(n)
+    G = np.vstack([Gr, np.eye(n), -np.eye(n)])
+    h = np.concatenate([Gr @ xf - rng.uniform(0.5, 1.5, mi_extra), -4.0 * np.ones(n), -4.0 * np.ones(n)])
+    c = rng.standard_normal(n)
+    return G, h, c, xf
+
+
+def main_lp_trace():
+    """tests/golden/lptrace_*.npz: the UNMODIFIED reference solving an LP end to end (d2L == 0: every x pivot of the device
+    is a static pivot, at EVERY iterate, also the late ones where Sigma spans many decades), every iterate at the
+    Newton-step seam recorded; and pivot_lp_late.npz: the single step of that trace with the widest Sigma (VERDICT r2
+    item 4).  The reference's LU pivots over the whole matrix (pyipm.py:18-20) and never shifts here (pyipm.py:1381)."""
+    os.makedirs(GOLD, exist_ok=True)
+    n, mi_extra, seed = 128, 64, 31
+    G, h, c, xf = lp_problem(n, mi_extra, seed)
+    mi = G.shape[0]
+    Z = np.zeros((n, n))
+    GT = np.ascontiguousarray(G.T)
+    prob = {"nvar": n, "neq": 0, "nineq": mi, "f": lambda x: c @ x, "df": lambda x: c.copy(), "d2f": lambda x: Z,
+            "ce": None, "dce": None, "d2ce": None,
+            "ci": lambda x: G @ x - h, "dci": lambda x: GT, "d2ci": lambda x, lda: Z}
+    p = build(prob, xf, Ktol=1.0e-8, verbosity=-1)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        x, s, lda, fval, kkt = p.solve()
+    d = {"n_iter": np.int64(len(p.trace)), "n": np.int64(n), "me": np.int64(0), "mi": np.int64(mi), "seed": np.int64(seed),
+         "Ktol": np.float64(1.0e-8), "G": G, "h": h, "c": c, "x0": xf}
+    for k in ("x", "s", "lda", "g", "dz_raw"):
+        d["it_" + k] = np.stack([t[k] for t in p.trace])
+    for k in ("mu", "mu_host", "delta_in", "delta_out"):
+        d["it_" + k] = np.array([t[k] for t in p.trace])
+    spread, neg, rcond = [], [], []
+    for t in p.trace:
+        sig = t["lda"] / (t["s"] + np.finfo(np.float64).eps)
+        spread.append(sig.max() / sig.min())
+        w = np.linalg.eigvalsh(t["Hc"])
+        neg.append(int((w < 0).sum())); rcond.append(np.abs(w).min() / np.abs(w).max())
+    d["it_sigma_spread"] = np.array(spread); d["it_neg"] = np.array(neg); d["it_rcond"] = np.array(rcond)
+    d.update(x=x, s=s, lda=lda, fval=np.float64(fval), signal=np.int64(p.signal))
+    for i, kk in enumerate(kkt):
+        d["kkt%d" % (i + 1)] = np.atleast_1d(np.array(kk, dtype=np.float64))
+    np.savez_compressed(os.path.join(GOLD, "lptrace_n%d_mi%d_s%d.npz" % (n, mi, seed)), **d)
+    print("lp trace n=%d mi=%d: %d Newton steps, signal %d, f = %.10g, shifts %d, Sigma spread up to %.2e, rcond down to %.2e"
+          % (n, mi, len(p.trace), p.signal, fval, int((d["it_delta_out"] > 0).sum()), max(spread), min(rcond)))
+    # the late single step: widest Sigma among the iterates the reference left unshifted
+    ok = [i for i in range(len(p.trace)) if d["it_delta_out"][i] == 0.0]
+    i = max(ok, key=lambda j: spread[j])
+    t = p.trace[i]
+    out = {"name": np.array("lp_late"), "nvar": np.int64(n), "neq": np.int64(0), "nineq": np.int64(mi), "seed": np.int64(seed),
+           "Q": Z, "A": np.zeros((0, n)), "G": G, "c": c, "b": np.zeros(0), "h": h, "x": t["x"], "s": t["s"], "lda": t["lda"],
+           "mu": np.float64(t["mu"]), "mu_host": np.float64(t["mu_host"]), "delta_in": np.float64(t["delta_in"]),
+           "delta_out": np.float64(t["delta_out"]), "g": t["g"], "dz_raw": t["dz_raw"], "dz": flipped(t["dz_raw"], n, mi, 0),
+           "neg": np.int64(neg[i]), "rcond": np.float64(rcond[i]), "sigma_spread": np.float64(spread[i]), "iterate": np.int64(i),
+           "H_rowsum": t["H"].sum(axis=1), "Hc_diag": np.diag(t["Hc"]).copy()}
+    np.savez_compressed(os.path.join(GOLD, "pivot_lp_late.npz"), **out)
+    print("pivot lp_late: iterate %d of %d, Sigma spread %.2e, rcond %.2e, neg %d (need %d), delta_in %g"
+          % (i, len(p.trace), spread[i], rcond[i], neg[i], mi, t["delta_in"]))
+
+
 if __name__ == "__main__":
-    if "--qp-trace" in sys.argv[1:]:
+    if "--lp-trace" in sys.argv[1:]:
+        main_lp_trace()
+    elif "--qp-trace" in sys.argv[1:]:
         main_qp_trace()
     elif "--pivot" in sys.argv[1:]:
         main_pivot()

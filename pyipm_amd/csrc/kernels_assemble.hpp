@@ -134,7 +134,14 @@ __global__ __launch_bounds__(256) void k_assemble(
         const int64_t j = j0 + c, lc = lc_base + c;
         if (c >= ncol || i + 1 < j) continue;         // both rows above the diagonal: not stored
         const dbl2_t v = val[c];
-        amax = fmax(amax, fmax(fabs(v.x), fabs(v.y)));
+        {   // the scale of a static pivot leaves Sigma = lambda_i / (s + eps) out: late in an interior-point run those entries span
+            // 1e-10 .. 1e+10 while the rows a static pivot lands in (zero Hessian rows: LPs, linear variables) keep the scale of
+            // their Jacobian entries.  With Sigma in, the "perturbation" of iterate 8 of an LP was 0.005 on rows of norm 1 --
+            // the reference (pyipm.py:18-20, LU over the whole matrix) solves that system unshifted; found by the LP trace
+            // fixture of round 3 (tests/test_gpu_pivoting.py).
+            const bool sig = j >= g.n && j < g.n + g.mi;
+            amax = fmax(amax, fmax((sig && i == j) ? 0.0 : fabs(v.x), (sig && i + 1 == j) ? 0.0 : fabs(v.y)));
+        }
         if (i >= j) {
             // (non-temporal stores measured no faster, r02: 1.99 vs 1.95 ms at N = 32768)
             if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<dbl2_t*>(&A[i + lc * ld]));

@@ -44,12 +44,13 @@ __global__ __launch_bounds__(256) void k_b_assemble(BatchPtrs bp, Geo g, double 
         if (j >= g.Npad) break;
         if (i + 1 < j) continue;
         const double v1 = kkt_entry(i + 1, j, j, g, d2L, bp.ldh, Je, bp.ldje, Ji, bp.ldji, s, lda, eps, delta, delta_c);
-        amax = fmax(amax, fabs(v1));
+        const bool sig = j >= g.n && j < g.n + g.mi;   // (Sigma stays out of the static-pivot scale: see k_assemble)
+        amax = fmax(amax, (sig && i + 1 == j) ? 0.0 : fabs(v1));
         if (i >= j) {
             dbl2_t v;
             v.x = kkt_entry(i, j, j, g, d2L, bp.ldh, Je, bp.ldje, Ji, bp.ldji, s, lda, eps, delta, delta_c);
             v.y = v1;
-            amax = fmax(amax, fabs(v.x));
+            amax = fmax(amax, (sig && i == j) ? 0.0 : fabs(v.x));
             *reinterpret_cast<dbl2_t*>(&A[i + j * g.Npad]) = v;
         } else {
             A[(i + 1) + j * g.Npad] = v1;

@@ -208,3 +208,88 @@ def test_unconverged_refinement_takes_the_shift_branch():
     with pytest.raises(RuntimeError, match="refined solve did not reach"):
         _direction(be2, d, b)
     assert be2.n_unconverged >= 3
+
+
+# ---- static pivots where they hurt -- a whole LP solve of the reference, late iterates included ------
+def _lp_trace():
+    d = np.load(os.path.join(GOLD, "lptrace_n128_mi320_s31.npz"))
+    n, mi = int(d["n"]), int(d["mi"])
+    G, h, c = d["G"], d["h"], d["c"]
+    return d, n, mi, G, h, c, np.ascontiguousarray(G.T), np.zeros((n, n))
+
+
+def test_every_direction_of_the_reference_lp_solve():
+    """tests/golden/lptrace_*.npz (oracle/make_golden.py --lp-trace): the UNMODIFIED reference solving an LP with 128
+    variables and 320 inequalities -- d2L == 0, so all 128 x pivots of the device are static pivots at EVERY one of
+    its 18 iterates, the last ones with Sigma spanning 21 decades and rcond(Hc) = 1.4e-12.  Iterate by iterate: the
+    same "no shift" decision as reghess (pyipm.py:1381), the reference's inertia, a direction that satisfies the
+    blocks to 1e-11, and agreement with the reference's LU direction to what the conditioning of the system allows
+    (its own LU carries an error of ~eps/rcond: 1e-10 while rcond >= 1e-6, eps/rcond x 50 beyond)."""
+    from pyipm_amd.ipm import HipNewtonBackend
+    d, n, mi, G, h, c, GT, Z = _lp_trace()
+    be = HipNewtonBackend(n, 0, mi, device=0)
+    worst = 0.0
+    for it in range(int(d["n_iter"])):
+        x, s, lda = d["it_x"][it], d["it_s"][it], d["it_lda"][it]
+        dz, delta, st = be.direction(Z, None, GT, c, None, G @ x - h, s, lda, float(d["it_mu"][it]), float(d["it_delta_in"][it]),
+                                     float(d["it_mu_host"][it]), 1e-4, 0.4, np.sqrt(EPS), np.sqrt(EPS), EPS)
+        assert delta == 0.0 == float(d["it_delta_out"][it]), (it, delta)
+        assert st["n_neg"] == mi == int(d["it_neg"][it]) and st["n_zero"] == n and st["nonfinite"] == 0
+        g = d["it_g"][it]
+        np.testing.assert_allclose(be.core.residual().cpu().numpy(), g, rtol=0, atol=1e-13 * np.abs(g).max())
+        info = be.last_solve_info
+        assert info["converged"] and info["backward_error"] <= 1e-11, (it, info)
+        ref = d["it_dz_raw"][it].copy()
+        ref[n + mi:] *= -1.0                                          # pyipm.py:1723-1725
+        tol = max(1e-10, 50.0 * EPS / float(d["it_rcond"][it]))
+        e = relerr(dz, ref)
+        assert e <= tol, (it, e, tol, float(d["it_rcond"][it]), float(d["it_sigma_spread"][it]))
+        worst = max(worst, e / tol)
+    assert be.n_static == int(d["n_iter"]) and be.n_unconverged == 0
+
+
+def test_late_lp_iterate_single_step_fixture():
+    """pivot_lp_late.npz: the step of that solve with the widest Sigma (3e21) as a single-step fixture in the format of
+    the other pivot_* fixtures -- static pivots together with Sigma spanning >= 1e12, which none of them had."""
+    from pyipm_amd.ipm import HipNewtonBackend
+    d, n, me, mi, b = _load("lp_late")
+    assert float(d["sigma_spread"]) >= 1e12 and float(d["delta_out"]) == 0.0
+    be = HipNewtonBackend(n, me, mi, device=0)
+    dz, delta, st = _direction(be, d, b, float(d["delta_in"]))
+    assert delta == 0.0 and st["n_neg"] == mi == int(d["neg"]) and st["n_zero"] == n
+    assert be.last_solve_info["converged"] and be.last_solve_info["backward_error"] <= 1e-11
+    assert relerr(dz, d["dz"]) <= max(1e-10, 50.0 * EPS / float(d["rcond"]))
+    # ... and the direction satisfies the reference's own matrix: Hc dz_raw = g with Hc rebuilt by the oracle
+    H = orc.kkt_matrix(b["d2L"], None, b["Ji"], d["s"], d["lda"], n, me, mi)
+    raw = dz.copy(); raw[n + mi:] *= -1.0
+    assert np.linalg.norm(H @ raw - d["g"]) <= 1e-10 * np.linalg.norm(d["g"])
+
+
+def test_ipm_retraces_the_reference_lp_solve():
+    """The host loop on the HIP backend from the reference's starting point: same number of Newton steps, same signal,
+    the iterates of the reference to what the conditioning along the path allows, the same optimum."""
+    from pyipm_amd.ipm import IPM
+    d, n, mi, G, h, c, GT, Z = _lp_trace()
+    prob = dict(f=lambda x: float(c @ x), df=lambda x: c.copy(), d2f=lambda x: Z,
+                ci=lambda x: G @ x - h, dci=lambda x: GT, d2ci=lambda x, lda: Z)
+    p = IPM(x0=d["x0"].copy(), verbosity=-1, Ktol=float(d["Ktol"]), **prob)
+    p.compile(nvar=n)
+    seen = []
+    direction = p.backend.direction
+
+    def spy(*a, **k):
+        seen.append((np.array(a[6]), np.array(a[7])))                # s, lda handed to the step
+        return direction(*a, **k)
+
+    p.backend.direction = spy
+    x, s, lda, fval, kkt = p.solve()
+    assert p.signal == int(d["signal"]) == 1
+    assert len(seen) == int(d["n_iter"])
+    acc = 1e-9
+    for it, (si, li) in enumerate(seen):
+        acc = max(acc, 100.0 * EPS / float(d["it_rcond"][max(it - 1, 0)]))    # errors of the previous direction carry over
+        np.testing.assert_allclose(si, d["it_s"][it], rtol=0, atol=acc * max(1.0, np.abs(d["it_s"][it]).max()))
+        np.testing.assert_allclose(li, d["it_lda"][it], rtol=0, atol=acc * max(1.0, np.abs(d["it_lda"][it]).max()))
+    assert abs(fval - float(d["fval"])) <= 1e-7 * max(1.0, abs(float(d["fval"])))
+    np.testing.assert_allclose(x, d["x"], rtol=0, atol=1e-5 * max(1.0, np.abs(d["x"]).max()))
+    assert p.backend.n_static == int(d["n_iter"]) and p.backend.n_unconverged == 0

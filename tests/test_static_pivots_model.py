@@ -58,7 +58,7 @@ def test_singular_x_tiles_are_pivoted_statically_and_refined_to_the_lu_answer(na
     w = np.linalg.eigvalsh(K)
     # what the reference would decide (pyipm.py:1378-1381): inertia right, rcond fine -> no shift
     assert int((w < -np.finfo(float).eps).sum()) == me + mi and np.abs(w).min() / np.abs(w).max() > 1e-6
-    f = BlockLDL(K, neg_from=n + mi)
+    f = BlockLDL(K, neg_from=n + mi, sigma_from=n)
     assert np.isfinite(f.M).all()                                  # the factor used to overflow here
     assert f.stats["neg"] == me + mi                               # same inertia as the eigenvalues
     if name in ("lp", "lp_eq"):
@@ -95,5 +95,5 @@ def test_regular_matrices_are_untouched():
     n, me, mi = 96, 32, 48
     qp = make_qp(n, me, mi, seed=2)
     H = orc.kkt_matrix(qp["d2L"], qp["Je"], qp["Ji"], qp["s"], qp["lam"], n, me, mi)
-    f = BlockLDL(H, neg_from=n + mi)
+    f = BlockLDL(H, neg_from=n + mi, sigma_from=n)
     assert f.stats["zero"] == 0 and f.stats["neg"] == me + mi
