@@ -117,7 +117,8 @@ struct Ctx {
                                           // so every assembly is a full one until set_option("keep_zeros") is called again
     int rest_prio = 1;                    // ctx->rest is a high-priority stream (set before the first factorisation)
     int fast_on_main = 1;                 // groups inside the slack block (closed form) run on the main stream, not through the lookahead
-    int head_serial = 0;                  // ... and the bulk update of the group waits for it (instead of running beside it)
+    int head_serial = 0;                  // ... and the bulk update of the group waits for it (instead of running beside it): 0 never,
+                                          // 1 always, 2 in the chain-bound phase only (at most persist_rows rows left); measured r03: 107.3 / 107.6 ms for 2 / 0 -- noise
     int head_on_side = 1;                 // the lookahead head runs on the stream of the chain it follows (no stream crossing between
                                           // a group's chain, the head and the next chain); ordered against the main stream by an event
     int bwd_diag4 = 1;                    // in-panel backward substitution on 1024 threads through shared memory (k_bwd_diag4)
@@ -133,6 +134,9 @@ struct Ctx {
                                           // next panel, always on the critical path there) while at most this many rows remain
     int64_t pending32_rows = 24576;       // ... and a panel's pending in-group update too while at most this many rows remain
                                           // (128x128 tiles keep one CU busy for 27 us per 256 columns of K, on the chain)
+    int reserve_cus = 16;                 // chain-bound phases: bulk updates run as persistent launches that leave this many CUs
+    int64_t persist_rows = 12288;         // free for the panel chain -- while at most this many rows remain (single rank), always in
+    int num_cus = 256;                    // the per-panel schedule; 0 = ordinary launches everywhere.  num_cus: of this device
     int bulk_bn = 128;                    // column width of a bulk update tile: 128 (default), or 256 = 128 x 256 per block (8 waves x 64 x 64,
                                           // one block per CU): 20 % less L2-miss traffic, the same step time, and a chain kernel waits twice
                                           // as long for a slot beside it (tools/contention_probe.py) -- measured r03, kept as an option

@@ -730,6 +730,7 @@ struct UpdGeo {
     unsigned long long* dbg;               // diagnostics only (NULL in normal operation): per-block timeline
     const unsigned* tiles;                 // swizzled launches: block b works on tile (tiles[b] & 0xffff, tiles[b] >> 16), built on
                                            // the host in the XCD-aware order below with every empty tile left out; NULL = decode here
+    unsigned persist;                      // != 0: a persistent launch over a tile list of this many entries (see k_update)
     int64_t ks_cstride;                    // split-K launches (grid.y = splits, tile-list order only): split y accumulates its K
                                            // columns of the operands into C + y*ks_cstride; 0 = one split (every KKT launch)
 };
@@ -793,11 +794,13 @@ __global__ __launch_bounds__(NW * 64, (BN >= 256 ? 2 : NW / 2)) void k_update(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (u.prio) __builtin_amdgcn_s_setprio(3);     // panel-chain launches (side stream)
     const int64_t Npad = u.Npad;
+    // One tile of the launch; `ent` = its entry in the tile list (= blockIdx.x of an ordinary launch).
+    auto one_tile = [&](const unsigned ent) {
     int64_t rt, ct;
     if (SWZ && u.tiles) {
         // split-K launches rotate the XCD sequences by the split index: a list shorter than 8 real entries
         // per round (few output tiles) would otherwise put every split's blocks on the same XCDs
-        const unsigned b = u.ks_cstride ? ((blockIdx.x & ~7u) | ((blockIdx.x + blockIdx.y) & 7u)) : blockIdx.x;
+        const unsigned b = u.ks_cstride ? ((ent & ~7u) | ((ent + blockIdx.y) & 7u)) : ent;
         const unsigned code = u.tiles[b];
         if (code == 0xffffffffu) return;               // padding of a shorter XCD sequence
         rt = code & 0xffffu; ct = code >> 16;
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(NW * 64, (BN >= 256 ? 2 : NW / 2)) void k_update(
     } else if (SWZ) {
         // XCD-aware order: block b runs on XCD b%8 (observed dispatch); each XCD walks its own
         // sequence of 8x8 super-tiles so the 16 operand tiles of a super-tile are reused from its L2.
-        const unsigned b = blockIdx.x;
+        const unsigned b = ent;
         const int xcd = (int)(b & 7u);
         const unsigned slot = b >> 3;
         int sidx = (int)((slot >> 6) * 8u) + xcd;            // / (SUPER*SUPER)
@@ -945,7 +948,7 @@ __global__ __launch_bounds__(NW * 64, (BN >= 256 ? 2 : NW / 2)) void k_update(
             for (int r = 0; r < 4; ++r)
                 C[(i0 + wi + ti * 16 + l15) + (jloc + wj + tj * 16 + l4 + 4 * r) * ldc] = acc[tj][ti][r];
     if (u.dbg && tid == 0) {
-        const unsigned lin = SWZ ? blockIdx.x : blockIdx.x + gridDim.x * blockIdx.y;
+        const unsigned lin = SWZ ? ent : blockIdx.x + gridDim.x * blockIdx.y;
         unsigned long long* d = u.dbg + 8ull * lin;
         const unsigned long long ts3 = wall_clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // diagnostics: when have this wave's stores drained?
@@ -953,6 +956,20 @@ __global__ __launch_bounds__(NW * 64, (BN >= 256 ? 2 : NW / 2)) void k_update(
         d[4] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);          // HW_ID low 16 bits... (size field = 15+1)
         d[5] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);          // XCC_ID
         d[6] = wall_clock64() - ts3; d[7] = ct;
+    }
+    };   // one_tile
+    // Persistent launches (u.persist = length of the tile list; chain-bound phases and the per-panel schedule): fewer
+    // blocks than the GPU has slots walk the list with stride gridDim.x -- a multiple of 8, so a block stays on its XCD's
+    // sequence -- and the slots they leave empty are there for the panel chain the moment it needs them.  An ordinary
+    // launch fills every CU with blocks that all retire together one tile time (~250 us) later: a chain kernel launched in
+    // between waits for that (tools/contention_probe.py, tools/ubench/contention.hip), three to six times per group.
+    if (SWZ && u.tiles && u.persist) {
+        for (unsigned e = blockIdx.x; e < u.persist; e += gridDim.x) {
+            one_tile(e);
+            __syncthreads();                           // the staging buffers are the next tile's
+        }
+    } else {
+        one_tile(blockIdx.x);
     }
 }
 

@@ -286,7 +286,7 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     u.nrt = (int)(m / BM); u.nct = (int)(n_lp * (g.nb / 128));
     u.dbg = ctx->dbg_buf;
     u.prio = bulk ? 0 : ctx->side_prio;
-    u.rt_min0 = 0; u.rt_step = 0; u.tiles = nullptr; u.ks_cstride = 0;
+    u.rt_min0 = 0; u.rt_step = 0; u.tiles = nullptr; u.ks_cstride = 0; u.persist = 0;
     if (src_c0 >= 0) active_ranges(ctx, src_c0, src_c0 + K, &u.a0, &u.a1, &u.b0, &u.b1);
     else { u.a0 = 0; u.a1 = g.Npad; u.b0 = 0; u.b1 = 0; }
     const int use_waves = waves ? waves : ctx->bulk_waves;
@@ -313,6 +313,12 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
         if (ntiles == 0) return 0;
         dim3 grid(ntiles, (unsigned)ksplit);             // K is the length of ONE split
         if (ksplit > 1) u.ks_cstride = ks_cstride;
+        if (use_waves == 8 && waves == 0 && ksplit == 1 && ctx->reserve_cus > 0 &&
+            (ctx->per_panel_mode || m <= ctx->persist_rows)) {
+            // chain-bound phase: leave `reserve_cus` CUs without update blocks (two 8-wave blocks fill one)
+            const unsigned slots = (unsigned)(2 * (ctx->num_cus - ctx->reserve_cus)) & ~7u;
+            if (slots >= 8 && ntiles > slots) { u.persist = ntiles; grid.x = slots; }
+        }
         if (use_waves == 8)
             hipLaunchKernelGGL((k_update<128, true, 8>), grid, dim3(512), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
         else
@@ -1167,7 +1173,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             if (hs == ctx->stream && cs == ctx->side) {
                 PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
                 PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_head, 0));
-            } else if (hs == ctx->side && ctx->head_serial) {
+            } else if (hs == ctx->side && (ctx->head_serial == 1 || (ctx->head_serial == 2 && g.Npad - g.panel_c0(p1) <= ctx->persist_rows))) {
                 // the bulk update of this group starts behind the head instead of beside it (the head is what the next chain
                 // waits for; sharing the GPU with the bulk launch stretches it)
                 PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->side));
@@ -1268,6 +1274,7 @@ int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t m
     ctx->device = device;
     ctx->stream = (hipStream_t)stream;
     if (hipSetDevice(device) != hipSuccess) return create_fail(ctx, PYIPM_E_NODEVICE);
+    { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) ctx->num_cus = ncu; }
     const size_t need = carve_workspace(nullptr, ctx->g, nullptr);
     if (workspace) {
         if (workspace_bytes < need) return create_fail(ctx, PYIPM_E_NOMEM);
@@ -1979,6 +1986,8 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (check_ctx(h) || !name) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
+    if (!strcmp(name, "reserve_cus")) { ctx->reserve_cus = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "persist_rows")) { ctx->persist_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "bulk_bn")) { ctx->bulk_bn = (int)value == 256 ? 256 : 128; return PYIPM_OK; }
     if (!strcmp(name, "bulk_bn_min_k")) { ctx->bulk_bn_min_k = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "tile_blocked")) { ctx->tile_blocked = (int)value != 0; return PYIPM_OK; }
@@ -2016,7 +2025,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "keep_zeros")) { ctx->keep_zeros = (int)value != 0; ctx->zeros_clean = false; ctx->storage_exported = false; return PYIPM_OK; }
     if (!strcmp(name, "pending_left_rows")) { ctx->pending_left_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "head_waves")) { ctx->head_waves = ((int)value == 8) ? 8 : 4; return PYIPM_OK; }
-    if (!strcmp(name, "head_serial")) { ctx->head_serial = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "head_serial")) { ctx->head_serial = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "early_head")) { ctx->early_head = (int)value != 0; return PYIPM_OK; }
