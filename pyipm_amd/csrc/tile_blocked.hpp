@@ -97,13 +97,11 @@ __device__ __forceinline__ bool tile_blocked_block(double (&stage)[TB][STRIDE], 
     double pt4[4];
     #pragma unroll
     for (int s = 0; s < 4; ++s) pt4[s] = bs.ptol[k0 + 4 * s + q];
-    double d[16], r[16], lmax = 0.0, ctr = (double)i15, t_, u_, mk_;
+    double d[16], r, lmax = 0.0, ctr = (double)i15, t_, u_, mk_;
     if (dbg) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PYIPM_TB_STAMP(0) }
     // (the statements clobber "memory": the loads above stay above, the stores below stay below)
     PYIPM_MICROBLOCK_ASM_0(a, d, r, lmax, ctr, t_, u_, mk_);
     PYIPM_MICROBLOCK_ASM_1(a, d, r, lmax, ctr, t_, u_, mk_);
-    PYIPM_MICROBLOCK_ASM_2(a, d, r, lmax, ctr, t_, u_, mk_);
-    PYIPM_MICROBLOCK_ASM_3(a, d, r, lmax, ctr, t_, u_, mk_);
     PYIPM_TB_STAMP(1)
     (void)r;
     // M' and the pivots go through shared memory (lane j's register i15 is what lane i15 needs); every wave writes the

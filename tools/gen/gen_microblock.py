@@ -20,18 +20,22 @@ interleaving the previous pivot's remaining updates with the next pivot's depend
 the chain mov_dpp -> rcp -> 4 fma -> mul -> first fmac is ~8 dependent DP instructions, the 14 other updates and the
 bookkeeping fill its latency).
 
-Operands per statement: %0..%15 a[], %16..%19 d[4], %20..%23 r[4], %24 lmax, %25 ctr, %26 t, %27 u, %28 mk.
+Two statements of eight pivots each (an asm statement takes at most 30 operands; the fewer statements, the fewer pivots
+start with nothing to interleave: 4 x 4 pivots took 2180 cycles per micro-block, 2 x 8 take less).
+Operands per statement: %0..%15 a[], %16..%23 d[8], %24 lmax, %25 ctr, %26 t, %27 u, %28 mk, %29 r (1/d of the pivot in
+flight: dead once its multiplier column is out, so one register serves all pivots).
 """
 import os
 
 A = lambda c: "%%%d" % c
-LMAX, CTR, T, U, MK = "%24", "%25", "%26", "%27", "%28"
+LMAX, CTR, T, U, MK, R = "%24", "%25", "%26", "%27", "%28", "%29"
+NP = 8            # pivots per statement
 
 
 def chain(J, b):
     """dependent chain of pivot J (block-local d/r operands), as a list of instructions"""
-    d = "%%%d" % (16 + (J - 4 * b))
-    r = "%%%d" % (20 + (J - 4 * b))
+    d = "%%%d" % (16 + (J - NP * b))
+    r = R
     return [
         "v_mov_b64_dpp %s, %s row_newbcast:%d row_mask:0xf bank_mask:0xf" % (d, A(J), J),
         "v_rcp_f64 %s, %s" % (r, d),
@@ -59,15 +63,15 @@ def updates(J):
 
 
 def block(b):
-    """Four pivots.  Order: for each pivot J: first update of J-1 is already out (it is issued right after the multiplier);
+    """NP pivots.  Order: for each pivot J: first update of J-1 is already out (it is issued right after the multiplier);
     then  pre(J), chain(J) with the REST of pivot J-1's updates interleaved between the chain's dependent instructions."""
     out = ["s_nop 1"]
     pending = []                                       # updates of the previous pivot not yet issued
-    for J in range(4 * b, 4 * b + 4):
+    for J in range(NP * b, NP * b + NP):
         ch = chain(J, b)
         pr = pre(J)
         # the chain's instructions with fillers between them
-        fill = pending + ["v_max_f64 %s, %s, |%s|" % (LMAX, LMAX, A(J - 1))] if J > 4 * b else []
+        fill = pending + ["v_max_f64 %s, %s, |%s|" % (LMAX, LMAX, A(J - 1))] if J > NP * b else []
         seq = []
         seq += pr                                      # 3 instructions: also the DPP distance after the update that wrote a[J]
         k = 0
@@ -87,23 +91,22 @@ def block(b):
         out.append(ups[0])                             # column J+1 first: the next pivot's column
         pending = ups[1:]
     out += pending
-    out.append("v_max_f64 %s, %s, |%s|" % (LMAX, LMAX, A(4 * b + 3)))
+    out.append("v_max_f64 %s, %s, |%s|" % (LMAX, LMAX, A(NP * b + NP - 1)))
     return out
 
 
 def emit():
     lines = ["// GENERATED by tools/gen/gen_microblock.py -- do not edit.  See that file for what this is.",
              "// clang-format off"]
-    for b in range(4):
+    for b in range(16 // NP):
         ins = block(b)
         lines.append("#define PYIPM_MICROBLOCK_ASM_%d(a, d, r, lmax, ctr, t, u, mk) \\" % b)
         lines.append("    asm volatile( \\")
         for s in ins:
             lines.append('        "%s\\n\\t" \\' % s)
         ops_out = ", ".join('"+v"(a[%d])' % c for c in range(16))
-        ops_out += ", " + ", ".join('"=&v"(d[%d])' % (4 * b + k) for k in range(4))
-        ops_out += ", " + ", ".join('"=&v"(r[%d])' % (4 * b + k) for k in range(4))
-        ops_out += ', "+v"(lmax), "+v"(ctr), "=&v"(t), "=&v"(u), "=&v"(mk)'
+        ops_out += ", " + ", ".join('"=&v"(d[%d])' % (NP * b + k) for k in range(NP))
+        ops_out += ', "+v"(lmax), "+v"(ctr), "=&v"(t), "=&v"(u), "=&v"(mk), "=&v"(r)'
         lines.append("        : %s \\" % ops_out)
         lines.append('        : : "memory")')
         lines.append("")
