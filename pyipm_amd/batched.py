@@ -49,6 +49,17 @@ class BatchedNewton(object):
         if rc:
             raise NewtonError("pyipm_newton_create_batched failed: %s" % ERRORS.get(rc, rc))
         self.h, self.batch = h, batch
+        for k, v in getattr(self, "_opts", {}).items():
+            self._ck(self.lib.pyipm_newton_set_option(self.h, k.encode(), v))
+
+    def set_option(self, name, value):
+        """Same options as ``NewtonCore.set_option`` where they apply (e.g. ``tile_blocked``); kept for the handle that the
+        first ``step_all`` creates (its size is the batch's)."""
+        if not hasattr(self, "_opts"):
+            self._opts = {}
+        self._opts[name] = float(value)
+        if getattr(self, "h", None):
+            self._ck(self.lib.pyipm_newton_set_option(self.h, name.encode(), float(value)))
 
     def _ck(self, rc):
         if rc:

@@ -1329,6 +1329,8 @@ int pyipm_newton_create_batched(pyipm_newton_ctx** out, int64_t n, int64_t me, i
     ctx->ws_bytes = need;
     carve_batched(ctx, g, batch, ctx->ws);
     ctx->batched = true;
+    ctx->tile_blocked = 0;               // throughput-bound (two problems per CU, every CU busy): the blocked inversion's register and
+                                          // LDS appetite costs more there than its shorter chain gains (512 x N=768: 4.42 vs 4.04 ms, r03)
     if (hipMemset(ctx->anorm, 0, (size_t)batch * sizeof(unsigned long long)) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     *out = reinterpret_cast<pyipm_newton_ctx*>(ctx);

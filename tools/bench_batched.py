@@ -15,8 +15,9 @@ df = torch.randn(B, n, dtype=torch.float64, device="cuda", generator=gen)
 s = torch.rand(B, mi, dtype=torch.float64, device="cuda", generator=gen) * 1.5 + 0.5
 lam = torch.rand(B, mi, dtype=torch.float64, device="cuda", generator=gen) * 1.5 + 0.5
 ci = s + 0.1 * torch.randn(B, mi, dtype=torch.float64, device="cuda", generator=gen)
-for workers in [0]:
+for blocked in [1, 0]:
     bn = BatchedNewton(n, me, mi)
+    bn.set_option("tile_blocked", blocked)
     bn.step_all(Q, None, Ji, df, None, ci, s, lam)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -24,5 +25,6 @@ for workers in [0]:
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ok = all(x["n_neg"] == mi and x["n_zero"] == 0 for x in st)
+    print("tile_blocked=%d: " % blocked, end="")
     print("%d problems in %.2f ms -> %.0f Newton steps/s (inertia ok: %s)" % (B, dt * 1e3, B / dt, ok))
     bn.close()
