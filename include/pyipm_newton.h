@@ -318,8 +318,14 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *   "pending32_rows", "head32_rows",
  *   "head32_rows_dist" (row counts up to which a panel's pending in-group update / the lookahead head / the per-panel
  *   head take that kernel; defaults 24576 / 6144 / 16384), "early_head" 0|1 (tail regime: the next group's columns are
- *   updated panel by panel beside the chain; default 0 since the head is split) -- all of these choose between implementations that accumulate the same
- *   products in the same order: the results are bit-identical (tests/test_gpu_symmetric.py). */
+ *   updated panel by panel beside the chain; default 0 since the head is split), "bulk_bn" 128|256 (bulk update tiles of
+ *   128 x 128 or 128 x 256), "reserve_cus" / "persist_rows" (chain-bound phase -- at most persist_rows rows left, default
+ *   12288: the bulk update runs as a persistent launch that leaves reserve_cus CUs, default 16,
+ *   to the panel chain; 0 = ordinary launches) -- all of these choose between implementations that accumulate the same
+ *   products in the same order: the results are bit-identical (tests/test_gpu_symmetric.py);
+ *   "tile_blocked" 0|1 (default 1; batched handles 0): the 64 x 64 tile inversion 16 pivots at a time (in-register LDL' of the
+ *   micro-block + fp64 MFMA block sweeps, Bunch-Kaufman verified afterwards, fallback to the single sweeps: DESIGN.md
+ *   section 3) -- same pivots and inertia, a different order of rounding than the single sweeps (not bit-identical). */
 int pyipm_newton_set_option(pyipm_newton_ctx* ctx, const char* name, double value);
 
 /* fp64 MFMA peak micro-benchmark: register-resident v_mfma_f64_16x16x4_f64 only.

@@ -135,8 +135,8 @@ struct Ctx {
     int64_t pending32_rows = 24576;       // ... and a panel's pending in-group update too while at most this many rows remain
                                           // (128x128 tiles keep one CU busy for 27 us per 256 columns of K, on the chain)
     int reserve_cus = 16;                 // chain-bound phases: bulk updates run as persistent launches that leave this many CUs
-    int64_t persist_rows = 12288;         // free for the panel chain -- while at most this many rows remain (single rank), always in
-    int num_cus = 256;                    // the per-panel schedule; 0 = ordinary launches everywhere.  num_cus: of this device
+    int64_t persist_rows = 12288;         // free for the panel chain -- while at most this many rows remain (on one rank the per-panel schedule with it
+    int num_cus = 256;                    // everywhere took 140 instead of 120 ms); 0 = ordinary launches everywhere.  num_cus: of this device
     int bulk_bn = 128;                    // column width of a bulk update tile: 128 (default), or 256 = 128 x 256 per block (8 waves x 64 x 64,
                                           // one block per CU): 20 % less L2-miss traffic, the same step time, and a chain kernel waits twice
                                           // as long for a slot beside it (tools/contention_probe.py) -- measured r03, kept as an option

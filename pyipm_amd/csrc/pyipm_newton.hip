@@ -314,7 +314,7 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
         dim3 grid(ntiles, (unsigned)ksplit);             // K is the length of ONE split
         if (ksplit > 1) u.ks_cstride = ks_cstride;
         if (use_waves == 8 && waves == 0 && ksplit == 1 && ctx->reserve_cus > 0 &&
-            (ctx->per_panel_mode || m <= ctx->persist_rows)) {
+            m <= ctx->persist_rows) {
             // chain-bound phase: leave `reserve_cus` CUs without update blocks (two 8-wave blocks fill one)
             const unsigned slots = (unsigned)(2 * (ctx->num_cus - ctx->reserve_cus)) & ~7u;
             if (slots >= 8 && ntiles > slots) { u.persist = ntiles; grid.x = slots; }

@@ -18,12 +18,13 @@ for name in ("tcc1", "tcc2", "sq1"):
 out = {}
 for k, c in tot.items():
     fetch, write = 2.0 * 1024.0 * c["FETCH_SIZE"], 1024.0 * c["WRITE_SIZE"]
-    busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CYCLES"] if c["SQ_BUSY_CYCLES"] else None
-    out[k] = {"launches": calls[k], "hbm_read_bytes": fetch, "hbm_write_bytes": write,
-              "mfma_busy_over_sq_busy": busy, "f64_mfma_flops": 512.0 * c["SQ_INSTS_VALU_MFMA_MOPS_F64"]}
+    # as tools/pmc_summary.py: SQ_VALU_MFMA_BUSY_CYCLES over GRBM_GUI_ACTIVE x 128 (kernel cycles from the FETCH pass of the same run)
+    busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 128.0) if c["GRBM_GUI_ACTIVE"] else None
+    out[k] = {"launches": calls[k], "hbm_read_bytes": fetch, "hbm_write_bytes": write, "GRBM_GUI_ACTIVE": c["GRBM_GUI_ACTIVE"],
+              "mfma_busy_frac_of_kernel_cycles": busy, "f64_mfma_flops": 512.0 * c["SQ_INSTS_VALU_MFMA_MOPS_F64"]}
 top = sorted(out.items(), key=lambda kv: -(kv[1]["hbm_read_bytes"] + kv[1]["hbm_write_bytes"]))
 json.dump({"units": "bytes over all launches of the run (warm-up included); FETCH_SIZE x2 (gfx950), counters in KB", "kernels": dict(top)},
           open(dst, "w"), indent=1)
 for k, v in top[:8]:
     print("%-40s launches %5d read %.3e B write %.3e B mfma_busy %s flops %.3e" % (k[:40], v["launches"], v["hbm_read_bytes"], v["hbm_write_bytes"],
-                                                                                 "%.2f" % v["mfma_busy_over_sq_busy"] if v["mfma_busy_over_sq_busy"] is not None else "-", v["f64_mfma_flops"]))
+                                                                                 "%.2f" % v["mfma_busy_frac_of_kernel_cycles"] if v["mfma_busy_frac_of_kernel_cycles"] is not None else "-", v["f64_mfma_flops"]))
