@@ -172,7 +172,7 @@ __device__ __forceinline__ void tile_invert_dev(
         __syncthreads();
         if (dbg && tid == 0) dbg[4] = clock64() - dbg_c0;
         kb_done = tile_blocked_sweep(stage, sm.f.bs, sm.dsave, dbg);
-        if (dbg && tid == 0) { dbg[5] = clock64() - dbg_c0; dbg[6] = dbg_c0; }
+        if (dbg && tid == 0) { dbg[5] = clock64() - dbg_c0; dbg[6] = dbg_c0; dbg[7] += (unsigned long long)kb_done; }   // (micro-blocks committed, summed over tiles)
         #pragma unroll
         for (int c = 0; c < 16; ++c) {                 // the working matrix as it stands, back in the sweep layout
             const int j = cb + c;
