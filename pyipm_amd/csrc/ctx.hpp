@@ -86,7 +86,7 @@ struct Ctx {
     int s_fast = 1;                       // panels inside the slack block: closed-form elimination (k_s_panel)
     std::vector<char> grp_fast;           // per group: every panel of it takes that path (built by factor_all)
     std::vector<char> grp_x;              // per group: lies inside the x block (its chain kernels may skip the slack rows)
-    struct TileList { unsigned* dev = nullptr; unsigned count = 0; };
+    struct TileList { unsigned* dev = nullptr; unsigned count = 0; unsigned head_count = 0; };
     std::map<std::vector<int64_t>, TileList> tile_lists;   // compact tile orders of the bulk launches (geometry repeats every step)
     int skip_zeros = 1;                   // trailing updates skip tiles that the KKT block structure makes exact zeros
     int group = 1;                        // panels per bulk trailing update
@@ -134,6 +134,10 @@ struct Ctx {
                                           // next panel, always on the critical path there) while at most this many rows remain
     int64_t pending32_rows = 24576;       // ... and a panel's pending in-group update too while at most this many rows remain
                                           // (128x128 tiles keep one CU busy for 27 us per 256 columns of K, on the chain)
+    int fused_head = 0;                   // (measured r03: 106.55 vs 106.2 ms -- no gain, off) bulk-bound phase: the lookahead head is the first tiles of the bulk launch itself (they bump a
+                                          // device counter the next chain waits for) instead of a second MFMA kernel beside it
+    unsigned* head_counters = nullptr;    // one per group (device), zeroed by factor_begin; [n] = error flag of k_wait_counter
+    size_t n_head_counters = 0;
     int reserve_cus = 16;                 // chain-bound phases: bulk updates run as persistent launches that leave this many CUs
     int64_t persist_rows = 12288;         // free for the panel chain -- while at most this many rows remain (on one rank the per-panel schedule with it
     int num_cus = 256;                    // everywhere took 140 instead of 120 ms); 0 = ordinary launches everywhere.  num_cus: of this device

@@ -730,7 +730,9 @@ struct UpdGeo {
     unsigned long long* dbg;               // diagnostics only (NULL in normal operation): per-block timeline
     const unsigned* tiles;                 // swizzled launches: block b works on tile (tiles[b] & 0xffff, tiles[b] >> 16), built on
                                            // the host in the XCD-aware order below with every empty tile left out; NULL = decode here
-    unsigned persist;                      // != 0: a persistent launch over a tile list of this many entries (see k_update)
+    unsigned persist = 0;                  // != 0: a persistent launch over a tile list of this many entries (see k_update)
+    int head_ct = 0;                       // > 0 (fused head, round 3): column tiles [0, head_ct) are the NEXT group's columns; their tiles
+    unsigned* head_counter = nullptr;      // come first in the list, and every one of them bumps *head_counter once its C tile is stored
     int64_t ks_cstride;                    // split-K launches (grid.y = splits, tile-list order only): split y accumulates its K
                                            // columns of the operands into C + y*ks_cstride; 0 = one split (every KKT launch)
 };
@@ -947,6 +949,13 @@ __global__ __launch_bounds__(NW * 64, (BN >= 256 ? 2 : NW / 2)) void k_update(
             #pragma unroll
             for (int r = 0; r < 4; ++r)
                 C[(i0 + wi + ti * 16 + l15) + (jloc + wj + tj * 16 + l4 + 4 * r) * ldc] = acc[tj][ti][r];
+    if (SWZ && u.head_ct > 0 && ct < u.head_ct) {
+        // fused head: this tile belongs to the columns the next group's chain is waiting for (k_wait_counter on its stream).
+        // Barrier: every thread's stores are issued; device-scope release by one thread (writes the XCD's L2 back: the
+        // reader is a later kernel on any XCD, which invalidates at its start); then the count.
+        __syncthreads();
+        if (tid == 0) { __threadfence(); atomicAdd(u.head_counter, 1u); }
+    }
     if (u.dbg && tid == 0) {
         const unsigned lin = SWZ ? ent : blockIdx.x + gridDim.x * blockIdx.y;
         unsigned long long* d = u.dbg + 8ull * lin;
@@ -971,6 +980,21 @@ __global__ __launch_bounds__(NW * 64, (BN >= 256 ? 2 : NW / 2)) void k_update(
     } else {
         one_tile(blockIdx.x);
     }
+}
+
+// Fused head: the chain of the next group starts behind this one-wave kernel, which returns once `expected` head tiles of
+// the bulk launch on the other stream have been stored (or after `timeout` ticks of the 100 MHz clock: *err = 1 and the
+// factorisation reports it -- a hang would cost the whole GPU).
+__global__ __launch_bounds__(64) void k_wait_counter(const unsigned* __restrict__ ctr, unsigned expected, unsigned long long timeout,
+                                                     int* __restrict__ err)
+{
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < expected) {
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > timeout) { *err = 1; break; }
+    }
+    __threadfence();
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -207,15 +207,18 @@ double active_area(int64_t row_begin, int64_t Npad, int64_t j0, int64_t j1, int6
 // every block; tiles that are out of range, above the diagonal or structurally zero are dropped, the eight
 // per-XCD sequences (block b runs on XCD b % 8) are levelled by moving the tails of long ones to short ones,
 // and the result is interleaved back into launch order.  Cached per geometry: it repeats every step.
-int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, unsigned* count, int bn = 128) {
+int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, unsigned* count, int bn = 128,
+              unsigned* head_count = nullptr) {
     if (ctx->debug_fault) {                             // test hook (tests/test_gpu_host_abi.py): the containers below can throw
         const int k = ctx->debug_fault; ctx->debug_fault = 0;
         if (k == 1) throw std::bad_alloc();
         throw std::runtime_error("injected fault");
     }
-    std::vector<int64_t> key = {u.row_begin, u.Npad, u.first_lp, u.nrt, u.nct, u.a0, u.a1, u.b0, u.b1, u.nb, u.rt_min0, u.rt_step, bn};
+    std::vector<int64_t> key = {u.row_begin, u.Npad, u.first_lp, u.nrt, u.nct, u.a0, u.a1, u.b0, u.b1, u.nb, u.rt_min0, u.rt_step, bn, u.head_ct};
     auto it = ctx->tile_lists.find(key);
-    if (it != ctx->tile_lists.end()) { *dev = it->second.dev; *count = it->second.count; return 0; }
+    if (it != ctx->tile_lists.end()) {
+        *dev = it->second.dev; *count = it->second.count; if (head_count) *head_count = it->second.head_count; return 0;
+    }
     if (ctx->tile_lists.size() >= 1024) {              // geometries that keep changing (condensed option: |A| varies): start over
         PYIPM_HIP(hipDeviceSynchronize());
         for (auto& kv : ctx->tile_lists) if (kv.second.dev) hipFree(kv.second.dev);
@@ -249,22 +252,30 @@ int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, uns
         if (!(ri && ci)) continue;
         seq[xcd].push_back((unsigned)rt | ((unsigned)ct << 16));
     }
+    unsigned nhead = 0;
+    if (u.head_ct > 0)                                  // fused head: the next group's columns first, on every XCD's sequence
+        for (auto& v : seq) {
+            std::stable_partition(v.begin(), v.end(), [&](unsigned c) { return (int)(c >> 16) < u.head_ct; });
+            for (unsigned c : v) nhead += (int)(c >> 16) < u.head_ct;
+        }
     size_t total = 0;
     for (auto& v : seq) total += v.size();
     const size_t target = (total + 7) / 8;
     std::vector<unsigned> spare;
     for (auto& v : seq) while (v.size() > target) { spare.push_back(v.back()); v.pop_back(); }
     for (auto& v : seq) while (v.size() < target && !spare.empty()) { v.push_back(spare.back()); spare.pop_back(); }
+    if (u.head_ct > 0)                                  // (levelling appends moved tails: keep the head tiles in front)
+        for (auto& v : seq) std::stable_partition(v.begin(), v.end(), [&](unsigned c) { return (int)(c >> 16) < u.head_ct; });
     std::vector<unsigned> list(8 * target, 0xffffffffu);
     for (int x = 0; x < 8; ++x) for (size_t j = 0; j < seq[x].size(); ++j) list[8 * j + x] = seq[x][j];
     Ctx::TileList tl;
-    tl.count = (unsigned)list.size();
+    tl.count = (unsigned)list.size(); tl.head_count = nhead;
     if (tl.count) {
         PYIPM_HIP(hipMalloc((void**)&tl.dev, list.size() * sizeof(unsigned)));
         PYIPM_HIP(hipMemcpy(tl.dev, list.data(), list.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     }
     ctx->tile_lists[key] = tl;
-    *dev = tl.dev; *count = tl.count;
+    *dev = tl.dev; *count = tl.count; if (head_count) *head_count = nhead;
     return 0;
 }
 
@@ -273,7 +284,8 @@ int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, uns
 int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ldl, const double* Wop, int K,
                      int64_t row_begin, int64_t first_lp, int64_t n_lp, bool bulk = true,
                      int64_t ldw = 0, int64_t row_end = 0, int64_t col_end = 0, int64_t src_c0 = -1,
-                     int ksplit = 1, int64_t ks_cstride = 0, int waves = 0) {      // waves: 0 = the handle's bulk_waves
+                     int ksplit = 1, int64_t ks_cstride = 0, int waves = 0,        // waves: 0 = the handle's bulk_waves
+                     int head_ct = 0, unsigned* head_counter = nullptr, unsigned* head_count = nullptr, bool list_only = false) {
     const Geo& g = ctx->g;
     if (ldw <= 0) ldw = g.Npad;
     if (row_end <= 0) row_end = g.Npad;
@@ -287,11 +299,12 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     u.dbg = ctx->dbg_buf;
     u.prio = bulk ? 0 : ctx->side_prio;
     u.rt_min0 = 0; u.rt_step = 0; u.tiles = nullptr; u.ks_cstride = 0; u.persist = 0;
+    u.head_ct = head_ct; u.head_counter = head_counter;
     if (src_c0 >= 0) active_ranges(ctx, src_c0, src_c0 + K, &u.a0, &u.a1, &u.b0, &u.b1);
     else { u.a0 = 0; u.a1 = g.Npad; u.b0 = 0; u.b1 = 0; }
     const int use_waves = waves ? waves : ctx->bulk_waves;
     if (ctx->xcd_swizzle && bulk && ctx->bulk_bn == 256 && use_waves == 8 && waves == 0 && ksplit == 1 && g.nb % 256 == 0 &&
-        K >= ctx->bulk_bn_min_k) {
+        K >= ctx->bulk_bn_min_k && head_ct == 0) {
         // 128 x 256 tiles (the K = 1024 bulk launches of the single-rank schedule, the K = nb launches of the per-panel one)
         u.nct = (int)(n_lp * (g.nb / 256));
         upd_fill_affine<256>(u);
@@ -309,8 +322,8 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
         const int64_t nsup = upd_super_count<128>(u);
         if (nsup <= 0) return 0;
         unsigned ntiles = 0;
-        int rc = tile_list(ctx, u, nsup, &u.tiles, &ntiles); if (rc) return rc;
-        if (ntiles == 0) return 0;
+        int rc = tile_list(ctx, u, nsup, &u.tiles, &ntiles, 128, head_count); if (rc) return rc;
+        if (list_only || ntiles == 0) return 0;
         dim3 grid(ntiles, (unsigned)ksplit);             // K is the length of ONE split
         if (ksplit > 1) u.ks_cstride = ks_cstride;
         if (use_waves == 8 && waves == 0 && ksplit == 1 && ctx->reserve_cus > 0 &&
@@ -569,7 +582,8 @@ int factor_group(Ctx* ctx, int64_t p0, int64_t n0, hipStream_t chain, const std:
 
 // One bulk k_update<128> launch: panels [p0, p0+np) (contiguous, same rank) applied with K = their total
 // width to local panels [first_lp, first_lp+n_lp); timed with HIP events on the handle's stream.
-int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_lp, hipStream_t stream = nullptr) {
+int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_lp, hipStream_t stream = nullptr,
+                 int head_ct = 0, unsigned* head_counter = nullptr, unsigned* head_count = nullptr, bool list_only = false) {
     const Geo& g = ctx->g;
     if (!stream) stream = ctx->stream;
     if (n_lp <= 0) return 0;
@@ -603,6 +617,9 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
     // on the main stream, so its duration says nothing about the kernel's rate -- it is not part of the "trailing" figures
     // (time, flops, launches), and it uses the 4-wave instance of the kernel so that a kernel trace keeps the two apart.
     const bool chain_side = stream != ctx->stream && !ctx->per_panel_mode;
+    if (list_only)                                      // fused head: only build / look up the tile list (how many head tiles?)
+        return launch_update128(ctx, stream, Lop, g.Npad, wbuf(ctx, p0), K, row_begin, first_lp, n_lp, true, 0, 0, 0,
+                                g.panel_c0(p0), 1, 0, 0, head_ct, head_counter, head_count, true);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->profile && !chain_side) {
         if ((size_t)ctx->n_trailing >= ctx->ev_trailing.size()) {
@@ -623,7 +640,7 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
         PYIPM_KCHECK();
     } else {
         int rc = launch_update128(ctx, stream, Lop, g.Npad, wbuf(ctx, p0), K, row_begin, first_lp, n_lp, true, 0, 0, 0,
-                                  g.panel_c0(p0), 1, 0, chain_side ? ctx->head_waves : 0);
+                                  g.panel_c0(p0), 1, 0, chain_side ? ctx->head_waves : 0, head_ct, head_counter, head_count);
         if (rc) return rc;
     }
     if (chain_side) return 0;
@@ -658,6 +675,12 @@ int trailing_update(Ctx* ctx, int64_t p) {
 int factor_begin(Ctx* ctx) {
     DevStats z; memset(&z, 0, sizeof(z)); z.d_min = 1.0e308; z.d_max = 0.0;
     PYIPM_HIP(hipMemcpyAsync(ctx->dstats, &z, sizeof(z), hipMemcpyHostToDevice, ctx->stream));
+    if (!ctx->head_counters) {                      // fused heads: one counter per group + the error flag of k_wait_counter
+        PYIPM_HIP(hipMalloc((void**)&ctx->head_counters, (256 + 1) * sizeof(unsigned)));
+        ctx->n_head_counters = 256;
+    }
+    // (every stream of the handle is idle here: the factorisation before joined them and was waited for)
+    PYIPM_HIP(hipMemsetAsync(ctx->head_counters, 0, (ctx->n_head_counters + 1) * sizeof(unsigned), ctx->stream));
     PYIPM_HIP(hipStreamSynchronize(ctx->stream));   // &z is a stack temporary
     ctx->n_trailing = 0; ctx->trailing_flops = 0.0; ctx->trailing_area = 0.0;
     return 0;
@@ -665,8 +688,12 @@ int factor_begin(Ctx* ctx) {
 
 int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
     DevStats z;
+    int wait_err = 0;
     PYIPM_HIP(hipMemcpyAsync(&z, ctx->dstats, sizeof(z), hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->head_counters)
+        PYIPM_HIP(hipMemcpyAsync(&wait_err, ctx->head_counters + ctx->n_head_counters, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+    if (wait_err) { ctx->err = "fused head: the next group's chain gave up waiting for the bulk update's head tiles"; return PYIPM_E_HIP; }
     if (ctx->profile) {
         // time during which SOME update launch ran: the launches of the main stream are serial, a lookahead head on the
         // side stream may overlap the bulk update that follows it -- union of the intervals, not their sum
@@ -1159,6 +1186,39 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             const bool nxt_fast = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)(grp + 1)];
             hipStream_t cs = (nxt_fast && ctx->fast_on_main) ? ctx->stream : ctx->side;      // where the next group runs
             hipStream_t hs = ctx->stream;
+            // Fused head (round 3, bulk-bound phase): no head launch at all.  The bulk update of this group also covers the
+            // next group's columns, with THEIR tiles first in its list; each of them bumps a device counter when its C tile
+            // is stored, and the next group's chain starts behind a one-wave kernel that waits for the count.  The head was
+            // 10 % of the update flops running as a second MFMA kernel beside the bulk launch (bulk 54 TF/s with it, 65
+            // without); as the first tiles of the bulk launch it runs at the bulk kernel's own rate.
+            bool fused = false;
+            {
+                bool any_early = false;
+                for (int64_t q = p0; q < p0 + n0; ++q) any_early = any_early || early[(size_t)q];
+                fused = ctx->fused_head && ctx->xcd_swizzle && ctx->bulk_waves == 8 && ctx->bulk_bn == 128 && !fast_src && !nxt_fast &&
+                        cs == ctx->side && !any_early && g.world == 1 && g.Npad - g.panel_c0(p1) > ctx->persist_rows &&
+                        (size_t)grp < ctx->n_head_counters;
+            }
+            if (fused) {
+                unsigned nhead = 0;
+                unsigned* ctr = ctx->head_counters + grp;
+                const int hct = (int)(n1 * (g.nb / 128));
+                rc = timed_update(ctx, p0, n0, p1, np - p1, nullptr, hct, ctr, &nhead, /*list_only=*/true); if (rc) return rc;
+                if (nhead == 0) fused = false;
+                else {
+                    hipLaunchKernelGGL(k_wait_counter, dim3(1), dim3(64), 0, cs, ctr, nhead, (unsigned long long)3.0e8,     // 3 s
+                                       reinterpret_cast<int*>(ctx->head_counters + ctx->n_head_counters));
+                    PYIPM_KCHECK();
+                    const bool do_early_f = false;
+                    rc = run_group(grp + 1, cs, do_early_f); if (rc) return rc;
+                    PYIPM_HIP(hipEventRecord(ctx->ev_panel, cs));
+                    rc = timed_update(ctx, p0, n0, p1, np - p1, nullptr, hct, ctr, &nhead); if (rc) return rc;   // bulk incl. the head tiles
+                    if (!ctx->ev_main) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+                    PYIPM_HIP(hipEventRecord(ctx->ev_main, ctx->stream));
+                    PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
+                    continue;
+                }
+            }
             if (grp > 0 && ctx->head_on_side && cs == ctx->side) {
                 PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_main, 0));    // (recorded at the end of the iteration before)
                 hs = ctx->side;
@@ -1429,6 +1489,7 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     if (ctx->JT) hipFree(ctx->JT);
     if (ctx->Jx) hipFree(ctx->Jx);
     if (ctx->cond_pos) hipFree(ctx->cond_pos);
+    if (ctx->head_counters) hipFree(ctx->head_counters);
     if (ctx->own_ws && ctx->ws) hipFree(ctx->ws);
     delete ctx;
     return PYIPM_OK;
@@ -1988,6 +2049,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (check_ctx(h) || !name) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
+    if (!strcmp(name, "fused_head")) { ctx->fused_head = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "reserve_cus")) { ctx->reserve_cus = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "persist_rows")) { ctx->persist_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "bulk_bn")) { ctx->bulk_bn = (int)value == 256 ? 256 : 128; return PYIPM_OK; }

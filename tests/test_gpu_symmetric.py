@@ -207,7 +207,10 @@ def test_random_schedule_options_give_the_same_bits():
     rnd = random.Random(7)
     space = {"lookahead": [0, 1], "group_chain": [0, 1], "head_on_side": [0, 1], "fast_on_main": [0, 1], "early_head": [0, 1],
              "pending_left_rows": [-1, 0, 12288], "fuse_forward": [0, 1], "keep_zeros": [0, 1], "skip_zeros": [0, 1],
-             "head_serial": [0, 1], "head_split": [0, 1], "tile_step": [0, 1], "head32_rows": [0, 6144, 1 << 20], "pending32_rows": [0, 24576]}
+             "head_serial": [0, 1, 2], "head_split": [0, 1], "tile_step": [0, 1], "head32_rows": [0, 6144, 1 << 20], "pending32_rows": [0, 24576],
+             # round 3: 128 x 256 bulk tiles, persistent bulk launches that leave CUs to the chain, the head as the first tiles
+             # of the bulk launch (device-side counter + wait kernel)
+             "bulk_bn": [128, 256], "reserve_cus": [0, 16, 64], "persist_rows": [0, 4096, 1 << 20], "fused_head": [0, 1]}
     for shape, nb in (((3000, 700, 1200, 3), 256), ((1900, 300, 900, 9), 128), ((5000, 1000, 2500, 11), 256),
                       ((1000, 300, 900, 2), 256)):       # (the last one: a lone 128-wide panel as last group, n off every tile boundary)
         n, me, mi, seed = shape
