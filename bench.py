@@ -142,12 +142,12 @@ def pmc_traffic(N, nb):
     FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md; tools/pmc_update.sh,
     tools/pmc_summary.py).  Counters cannot be collected inside this process, so the figure is attached
     only for the configuration it was measured on; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r02_z_pmc_update.json")
+    path = os.path.join(ROOT, "profiles", "r03_z_pmc_update.json")
     if N != 32768 or nb != 256 or os.environ.get("PYIPM_NEWTON_GROUP") not in (None, "4") or not os.path.exists(path):
         return None, None
     try:
         d = json.load(open(path))
-        return float(d["hbm_bytes_per_launch_corrected"]), "profiles/r02_z_pmc_update.json (separate --pmc passes of this command)"
+        return float(d["hbm_bytes_per_launch_corrected"]), "profiles/r03_z_pmc_update.json (separate --pmc passes of this command)"
     except Exception:
         return None, None
 
