@@ -238,7 +238,11 @@ def main():
     N = n + 2 * mi + me
     qp = make_qp_device(n, me, mi, args.seed, device)
     core = NewtonCore(n, me, mi, device=local_rank, nb=args.nb, world=world, rank=rank)
-    if world > 1:
+    want_condensed = any(kv.split("=")[0] == "condensed" and float(kv.split("=")[1]) != 0 for kv in args.opt) and mi > 0
+    if world > 1 and want_condensed:
+        # the condensed option across ranks takes the full blocks on every rank (a column of Ji Sigma Ji' needs every row of Ji)
+        core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    elif world > 1:
         # row-sharded staging: a rank assembles only the KKT columns it owns, i.e. it needs only those rows of
         # d2L / Je / Ji (every rank generated the same matrices from the same seed; the full copies are dropped)
         rows = torch.from_numpy(core.owned_rows()).to(device)

@@ -288,7 +288,9 @@ int pyipm_newton_kkt_storage(pyipm_newton_ctx* ctx, double** ptr, int64_t* ld, i
  * full system, the number of matrix entries those launches update (their C-tile traffic is 16 B each). */
 int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
 /* Options (all default to the measured-best setting):
- *   "condensed" 0|1  single-rank handles with mi > 0: assemble/factor/solve work on the condensed system
+ *   "condensed" 0|1  handles with mi > 0 (several ranks since round 3: with the FULL blocks staged on every rank --
+ *                    stage_blocks, not stage_blocks_owned -- assemble / factor_dist / solve_dist / step_dist work on it too,
+ *                    same 1-D block-cyclic map on the smaller matrix): assemble/factor/solve work on the condensed system
  *                    [[d2L + delta I + Ji Sigma Ji', Je], [Je', -delta_c I]] of dimension n+me (s and lambda_i
  *                    eliminated analytically).  Same inputs, same outputs (full [dx|ds|dle|dli], inertia of the
  *                    full matrix); kkt_storage then exposes the condensed matrix.

@@ -134,6 +134,8 @@ struct Ctx {
                                           // next panel, always on the critical path there) while at most this many rows remain
     int64_t pending32_rows = 24576;       // ... and a panel's pending in-group update too while at most this many rows remain
                                           // (128x128 tiles keep one CU busy for 27 us per 256 columns of K, on the chain)
+    int64_t head_split_rows = 0;          // the head in two launches (head_split) while at most this many rows remain, whatever kernel
+                                          // the rows below the diagonal block then take (head32_rows decides that)
     int fused_head = 0;                   // (measured r03: 106.55 vs 106.2 ms -- no gain, off) bulk-bound phase: the lookahead head is the first tiles of the bulk launch itself (they bump a
                                           // device counter the next chain waits for) instead of a second MFMA kernel beside it
     unsigned* head_counters = nullptr;    // one per group (device), zeroed by factor_begin; [n] = error flag of k_wait_counter

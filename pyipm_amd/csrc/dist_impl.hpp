@@ -259,10 +259,24 @@ int update_range(Ctx* ctx, int64_t p, int64_t first, int64_t count, hipStream_t 
 // its own stream -- y_p needs nothing but panel p factored on its owner and the segment sum of the panels before it -- and
 // the solve that follows starts at the backward sweep (D->fwd_done).  The segment sums go through the collective stream
 // like every other exchange, at the same place of the loop on every rank.
+int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b);
+
+// The condensed option across ranks (round 3): the same per-panel schedule on the condensed geometry -- (n + me + |active
+// rows|) columns in the same 1-D block-cyclic map -- with the inertia of the eliminated (s, lambda_i) pairs added as in the
+// single-rank path (one positive and one negative eigenvalue each).  The forward substitution does not trail this
+// factorisation (its right-hand side is the reduced one: solve_dist reduces, sweeps and expands).
 int factor_dist(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b = nullptr) {
-    const Geo& g = ctx->g;
     if (!ctx->assembled) { ctx->err = "factor_dist: assemble first"; return PYIPM_E_BADARG; }
-    if (ctx->cond_active) { ctx->err = "factor_dist: the condensed option is single-rank (use factor())"; return PYIPM_E_BADARG; }
+    if (!ctx->cond_active) return factor_dist_geo(ctx, stats, fwd_b);
+    pyipm_factor_stats local; if (!stats) stats = &local;
+    int rc;
+    { GeoSwap sw(ctx, ctx->gc); rc = factor_dist_geo(ctx, stats, nullptr); }
+    stats->n_neg += ctx->g.mi - ctx->cond_na; stats->n_pos += ctx->g.mi;
+    return rc;
+}
+
+int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
+    const Geo& g = ctx->g;
     DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
     ctx->grp_of.clear(); ctx->grp_off.clear(); ctx->grp_fast.clear(); ctx->grp_x.clear();
     ctx->per_panel_mode = true;
@@ -464,6 +478,18 @@ int matvec_dist(Ctx* ctx, DistState* D, const double* v, double* y) {
     return ex_allreduce(ctx, D, y, (size_t)ctx->g.Npad, 0, ctx->stream);
 }
 
+// x := Hc^{-1} b for whichever system was factored: with the condensed factor reduce the right-hand side (every rank, from
+// the full blocks: replicated), run the distributed sweeps on the condensed geometry, expand.
+int solve_dist_any(Ctx* ctx, DistState* D, const double* b, double* x, bool forward_done) {
+    if (!ctx->cond_active) return solve_dist_once(ctx, D, b, x, forward_done);
+    const Geo& g = ctx->g;
+    int rc = cond_reduce(ctx, b, ctx->vc); if (rc) return rc;
+    { GeoSwap sw(ctx, ctx->gc); rc = solve_dist_once(ctx, D, ctx->vc, ctx->vc, false); }
+    if (rc) return rc;
+    if (x != b) DIST_HIP(hipMemcpyAsync(x, b, (size_t)g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return cond_expand(ctx, ctx->vc, x);             // (x holds the right-hand side on entry: its s / lambda_i parts are read)
+}
+
 int solve_dist(Ctx* ctx, const double* rhs, double* dz, int flip, int refine, int memkind) {
     const Geo& g = ctx->g;
     DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
@@ -475,7 +501,8 @@ int solve_dist(Ctx* ctx, const double* rhs, double* dz, int flip, int refine, in
     rc = solve_prepare(ctx, rhs, memkind); if (rc) return rc;          // v1 = v0 = b (replicated; pad zero)
     const bool fwd_done = D->fwd_done && rhs == nullptr;                // the staged right-hand side went forward under the factorisation
     D->fwd_done = false;
-    rc = solve_dist_once(ctx, D, ctx->v1, ctx->v0, fwd_done); if (rc) return rc;
+    rc = solve_dist_any(ctx, D, ctx->v1, ctx->v0, fwd_done); if (rc) return rc;
+    if (ctx->cond_active && refine >= 0 && refine < ctx->cond_min_refine) refine = ctx->cond_min_refine;
     ctx->info_steps = 0; ctx->info_converged = 0; ctx->info_berr0 = -1.0; ctx->info_berr = -1.0;
     const bool adaptive = refine < 0;
     const int maxit = adaptive ? ctx->refine_max : refine;
@@ -505,8 +532,9 @@ int solve_dist(Ctx* ctx, const double* rhs, double* dz, int flip, int refine, in
             prev = berr;
             DIST_HIP(hipMemcpyAsync(ctx->v3, ctx->v0, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, st));
         }
-        rc = solve_dist_once(ctx, D, ctx->v2, ctx->vc); if (rc) return rc;
-        hipLaunchKernelGGL(k_axpby, grid1(g.Npad), dim3(256), 0, st, ctx->v0, ctx->v0, ctx->vc, 1.0, 1.0, g.Npad);
+        // (the correction goes through v3's neighbour-free scratch: vc is the condensed solve's own vector)
+        rc = solve_dist_any(ctx, D, ctx->v2, ctx->v2, false); if (rc) return rc;
+        hipLaunchKernelGGL(k_axpby, grid1(g.Npad), dim3(256), 0, st, ctx->v0, ctx->v0, ctx->v2, 1.0, 1.0, g.Npad);
         DIST_KCHECK();
         ctx->info_steps = it + 1;
     }

@@ -372,12 +372,16 @@ __global__ __launch_bounds__(256) void k_cond_gather_J(double* __restrict__ Jx, 
 // diagonal of the lambda_A rows: -1 / Sigma_k
 __global__ __launch_bounds__(256) void k_cond_fix_diag(double* __restrict__ A, int64_t ld, int64_t r0,
                                                        const int* __restrict__ idx, int64_t na,
-                                                       const double* __restrict__ s, const double* __restrict__ lda_i, double eps)
+                                                       const double* __restrict__ s, const double* __restrict__ lda_i, double eps,
+                                                       Geo gc)        // the condensed geometry: a rank stores the columns it owns
 {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= na) return;
     const int k = idx[j];
-    A[(r0 + j) * (ld + 1)] = -(s[k] + eps) / lda_i[k];
+    const int64_t col = r0 + j, q = col / gc.nb;
+    if (gc.owner(q) != gc.rank) return;
+    const int64_t lcol = (q / gc.world) * (int64_t)gc.nb + (col - q * gc.nb);
+    A[col + lcol * ld] = -(s[k] + eps) / lda_i[k];
 }
 
 // JT[i + k*ldt] = Ji[i][k]  and  WT[i + k*ldt] = Sigma_k Ji[i][k]  (i < n, k in I; zero elsewhere up to

@@ -801,6 +801,9 @@ int solve_plain(Ctx* ctx, double* v, bool forward_done, int nrhs = 1, int64_t vs
 
 // ---- condensed option: right-hand side reduction and solution expansion --------------------------
 // vc <- [ b_x + Ji (Sigma b_i + b_s) ; b_e ; 0 ]   from a full-order right-hand side b
+// (every rank of a distributed run does both over ALL rows: the vectors are replicated and the blocks fully staged)
+static RowMap all_rows(const Geo& g) { Geo g1 = g; g1.world = 1; g1.rank = 0; return make_rowmap(g1, 0); }
+
 int cond_reduce(Ctx* ctx, const double* b, double* vc) {
     const Geo& g = ctx->g;
     hipLaunchKernelGGL(k_cond_t, grid1(g.mi), dim3(256), 0, ctx->stream, ctx->vt, b, g, ctx->s, ctx->lda + g.me, ctx->eps,
@@ -808,7 +811,7 @@ int cond_reduce(Ctx* ctx, const double* b, double* vc) {
     PYIPM_KCHECK();
     hipLaunchKernelGGL(k_rowdot2, grid1(g.n, 4), dim3(256), 0, ctx->stream, vc, b, g.n,
                        (const double*)nullptr, (int64_t)0, (const double*)nullptr, (int64_t)0,
-                       ctx->Ji, ctx->ld_Ji, ctx->vt, g.mi, 0, 0, make_rowmap(g, 0));
+                       ctx->Ji, ctx->ld_Ji, ctx->vt, g.mi, 0, 0, all_rows(g));
     PYIPM_KCHECK();
     if (ctx->gc.Npad > g.n) {
         hipLaunchKernelGGL(k_cond_gather, grid1(ctx->gc.Npad - g.n), dim3(256), 0, ctx->stream, vc, b, g, ctx->gc.Npad,
@@ -824,7 +827,7 @@ int cond_expand(Ctx* ctx, const double* vc, double* v) {
     const int nchunk = 64;
     const int64_t rpc = (g.n + nchunk - 1) / nchunk;
     hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((g.mi + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
-                       ctx->partial, ctx->Ji, ctx->ld_Ji, g.n, g.mi, vc, rpc, 0, make_rowmap(g, 0));
+                       ctx->partial, ctx->Ji, ctx->ld_Ji, g.n, g.mi, vc, rpc, 0, all_rows(g));
     PYIPM_KCHECK();
     hipLaunchKernelGGL(k_coldot_reduce, grid1(g.mi), dim3(256), 0, ctx->stream, ctx->vt, ctx->partial, g.mi, nchunk, 0);
     PYIPM_KCHECK();
@@ -949,7 +952,7 @@ int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
     PYIPM_HIP(hipMemcpyAsync(&na, ctx->cond_cnt, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PYIPM_HIP(hipStreamSynchronize(ctx->stream));
     ctx->cond_na = na;
-    ctx->gc = make_geo(g.n, g.me + na, 0, g.nb, 1, 0);
+    ctx->gc = make_geo(g.n, g.me + na, 0, g.nb, g.world, g.rank);     // (several ranks: the same 1-D block-cyclic map, fewer panels)
     const Geo& gc = ctx->gc;
     const int64_t mx = g.me + na;
     ctx->WT = ctx->JT + (size_t)ldt * (size_t)mi_pad;
@@ -976,7 +979,7 @@ int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
         PYIPM_KCHECK();
         if (na > 0) {
             hipLaunchKernelGGL(k_cond_fix_diag, grid1(na), dim3(256), 0, ctx->stream, ctx->A, gc.Npad, g.n + g.me,
-                               ctx->cond_idx, (int64_t)na, ctx->s, ctx->lda + g.me, ctx->eps);
+                               ctx->cond_idx, (int64_t)na, ctx->s, ctx->lda + g.me, ctx->eps, gc);
             PYIPM_KCHECK();
         }
     }
@@ -989,7 +992,10 @@ int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
     if (ctx->profile) PYIPM_HIP(hipEventRecord(ctx->ev[6], ctx->stream));
     {
         GeoSwap sw(ctx, gc);
-        int rc = launch_update128(ctx, ctx->stream, ctx->JT, ldt, ctx->WT, (int)mi_pad, 0, 0, (nx + gc.nb - 1) / gc.nb,
+        // Gram update of the x-x block: the panels below column nx, of which a rank holds every world-th (its local panels
+        // 0 .. ceil(#panels / world) - 1; a local panel past the block is cut off by col_end)
+        const int64_t npx = (nx + gc.nb - 1) / gc.nb;
+        int rc = launch_update128(ctx, ctx->stream, ctx->JT, ldt, ctx->WT, (int)mi_pad, 0, 0, (npx + gc.world - 1) / gc.world,
                                   true, ldt, nx, nx);
         if (rc) return rc;
     }
@@ -1001,7 +1007,12 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
     const Geo& g = ctx->g;
     if (!ctx->have_blocks || !ctx->have_vectors) { ctx->err = "assemble: stage blocks and vectors first"; return PYIPM_E_BADARG; }
     ctx->delta = delta; ctx->delta_c = delta_c;
-    if (ctx->condensed && g.world == 1 && g.mi > 0) {
+    if (ctx->condensed && g.mi > 0 && g.world > 1 && ctx->sharded) {
+        ctx->err = "condensed option across ranks needs the full blocks on every rank (stage_blocks, not stage_blocks_owned): "
+                   "a column of Ji Sigma Ji' takes every row of Ji";
+        return PYIPM_E_BADARG;
+    }
+    if (ctx->condensed && g.mi > 0) {
         ctx->zeros_clean = false;                       // the condensed system lives in the same storage with another layout
         int rc = assemble_condensed(ctx, delta, delta_c); if (rc) return rc;
         ctx->cond_active = true;
@@ -1128,7 +1139,8 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             const bool fast_src = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)grp];
             auto head_from = [&](int64_t q0, int64_t nq, int64_t tp, int64_t tn, hipStream_t hs, bool split = false) -> int {
                 const int64_t tc0 = g.panel_c0(tp);
-                if (split && ctx->inpanel32 && !fast_src && g.Npad - tc0 <= ctx->head32_rows) {      // (where the chain is the bound)
+                if (split && ctx->inpanel32 && !fast_src &&
+                    g.Npad - tc0 <= (ctx->head32_rows > ctx->head_split_rows ? ctx->head32_rows : ctx->head_split_rows)) {   // (where the chain is the bound)
                     // The chain of the target group needs the head only inside that group's diagonal block (rows [tc0, tend));
                     // the rows below it are first read by the group's rows stream.  Two launches: the block on the chain's
                     // stream, the rest on ctx->rest behind it -- the same entries, the same operations.
@@ -2049,6 +2061,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (check_ctx(h) || !name) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
+    if (!strcmp(name, "head_split_rows")) { ctx->head_split_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "fused_head")) { ctx->fused_head = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "reserve_cus")) { ctx->reserve_cus = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "persist_rows")) { ctx->persist_rows = (int64_t)value; return PYIPM_OK; }
@@ -2062,8 +2075,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "refine_cond")) { ctx->refine_cond = value; return PYIPM_OK; }
     if (!strcmp(name, "block_refine")) { int v = (int)value; ctx->block_refine = v < 0 ? 0 : (v > 3 ? 3 : v); return PYIPM_OK; }
     if (!strcmp(name, "condensed")) {
-        if (value != 0 && ctx->g.world != 1) { ctx->err = "condensed: single-rank handles only"; return PYIPM_E_BADARG; }
-        ctx->condensed = (int)value; return PYIPM_OK; }
+        ctx->condensed = (int)value; return PYIPM_OK; }       // (several ranks: full blocks on every rank, see assemble)
     if (!strcmp(name, "condensed_sigma_max")) { ctx->cond_sigma_max = value; return PYIPM_OK; }
     if (!strcmp(name, "condensed_refine")) { ctx->cond_min_refine = (int)value < 0 ? 0 : (int)value; return PYIPM_OK; }
     if (!strcmp(name, "lookahead")) { ctx->lookahead = (int)value != 0; return PYIPM_OK; }

@@ -311,3 +311,87 @@ def test_bench_self_launches_for_several_gpus():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["backward_error"] <= 1e-12
     assert d["rccl_ranks"] == (2 if multi else 0)
+
+
+def _cond_worker(rank, world, port, shape, nb, out):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pyipm_amd.newton import NewtonCore
+        from pyipm_amd.dist import DistNewton
+        n, me, mi, seed = shape
+        qp = make_qp(n, me, mi, seed)
+        core = NewtonCore(n, me, mi, device=0, nb=nb, world=world, rank=rank)
+        core.set_option("condensed", 1)
+        core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])                 # full blocks: a column of Ji Sigma Ji' takes every row of Ji
+        core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+        drv = DistNewton(core, native=True)
+        g = drv.residual()
+        dz, st = drv.step(0.0, 0.0, refine=1)
+        raw = dz.clone()
+        raw[n + mi:] *= -1.0
+        berr = float((core.matvec_dist(raw) - g).norm() / g.norm())
+        dz2 = core.solve_dist(flip=True, refine=-1)
+        torch.cuda.synchronize()
+        out[rank] = (dz.cpu().numpy(), st, core.ncols_local, berr, core.solve_info(), dz2.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape,nb", [(2, (900, 200, 300, 8), 256), (3, (700, 150, 260, 9), 128), (2, (1400, 0, 400, 10), 128)])
+def test_condensed_option_across_ranks(world, shape, nb):
+    """SURVEY 8f rank 2 x 8e (missing 3): the condensed KKT system [[H + Ji Sigma Ji', Je], [Je', 0]] factored by the
+    per-panel schedule over several ranks (sharing the one GPU here, exchange over gloo callbacks): every rank assembles the
+    columns it owns -- the Gram launch included --, the sweeps run on the condensed geometry between a replicated reduce and
+    expand, refinement against the full blocks across the ranks.  Direction of the FULL system <= 1e-10 of the oracle's,
+    full-system inertia, the one-rank condensed direction to rounding."""
+    import torch.multiprocessing as mp
+    from pyipm_amd.newton import NewtonCore
+    n, me, mi, seed = shape
+    N = n + 2 * mi + me
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_cond_worker, args=(world, _free_port(), shape, nb, out), nprocs=world, join=True)
+    qp = make_qp(n, me, mi, seed)
+    ref, _, _, _ = orc.newton_step(qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"],
+                                   qp["mu"], n, me, mi, regularise=False)
+    one = NewtonCore(n, me, mi, device=0, nb=nb)
+    one.set_option("condensed", 1)
+    one.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    one.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    dz1, st1 = one.step(0.0, 0.0, refine=1)
+    dz1 = dz1.cpu().numpy()
+    cols = 0
+    out = {r: out[r] for r in range(world)}
+    for r in range(world):
+        dz, st, ncl, berr, info, dz2 = out[r]
+        assert np.linalg.norm(dz - ref) / np.linalg.norm(ref) <= 1e-10
+        assert np.linalg.norm(dz - dz1) / np.linalg.norm(dz1) <= 1e-12
+        assert (st["n_neg"], st["n_pos"], st["n_zero"]) == (me + mi, N - me - mi, 0) == (st1["n_neg"], st1["n_pos"], st1["n_zero"])
+        assert berr <= 1e-12 and info["converged"] and info["backward_error"] <= 1e-13
+        assert np.linalg.norm(dz2 - ref) / np.linalg.norm(ref) <= 1e-10
+        cols += ncl
+    for r in range(1, world):
+        assert np.array_equal(out[0][0], out[r][0])
+    one.close()                                       # (a handle left to the garbage collector would be destroyed a second time
+                                                      #  in the fork that the next test's mp.Manager() makes of this process)
+
+
+def test_condensed_across_ranks_needs_full_blocks():
+    """Row-sharded staging cannot feed the Gram launch (a column of Ji Sigma Ji' takes every row of Ji): a clear error."""
+    from pyipm_amd.newton import NewtonCore, NewtonError
+    n, me, mi = 600, 100, 200
+    qp = make_qp(n, me, mi, 3)
+    c2 = NewtonCore(n, me, mi, device=0, nb=128, world=2, rank=0)
+    try:
+        c2.set_option("condensed", 1)
+        rows = c2.owned_rows()
+        c2.stage_blocks_owned(qp["d2L"][rows], qp["Je"][rows], qp["Ji"][rows])
+        c2.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+        with pytest.raises(NewtonError, match="full blocks"):
+            c2.assemble(0.0, 0.0)
+    finally:
+        c2.close()
