@@ -176,6 +176,14 @@ int pyipm_newton_step(pyipm_newton_ctx* ctx, double delta, double delta_c, int r
 int pyipm_newton_block_products(pyipm_newton_ctx* ctx, const double* v, double* Qv, double* JeTv, double* JiTv);
 int pyipm_newton_block_products_t(pyipm_newton_ctx* ctx, const double* le, const double* li, double* out);
 int pyipm_newton_provider_stats(pyipm_newton_ctx* ctx, double out[4]);
+/* A provider-only handle (round 3): the same staging calls, block products, residual and kkt_matvec, but no KKT storage,
+ * no W buffers and no tile inverses -- O(N) workspace instead of O(N^2) -- for callers that never factor the KKT matrix
+ * (the limited-memory mode, pyipm.py:1007-1246: QPDeviceIPM(lbfgs=m) forms df, ce, ci and the J lambda terms through it).
+ * stage_blocks may pass d2L = NULL (a factored Hessian model: Jacobian products only; block_products then needs
+ * Qv = NULL).  assemble / factor / solve / step return PYIPM_E_BADARG. */
+size_t pyipm_newton_workspace_bytes_provider(int64_t n, int64_t me, int64_t mi);
+int pyipm_newton_create_provider(pyipm_newton_ctx** ctx, int64_t n, int64_t me, int64_t mi, int device,
+                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* SURVEY.md section 8(f) rank 1 — replaces the two IPM.step calls of the inner loop (pyipm.py:1408-1436,
  * 1737-1742): the largest alpha in [0,1] with v + alpha*dv >= (1-tau)*v, for v = s (dv = ds) and

@@ -166,6 +166,7 @@ struct Ctx {
     double *vc = nullptr, *vt = nullptr;  // condensed vector / mi-sized temporary (carved)
     double* fwd_vec = nullptr;            // vector the fused forward substitution runs on
     double t_gram = 0;                    // ms of the Ji Sigma Ji' launch (profile)
+    bool provider_only = false;           // pyipm_newton_create_provider: staged blocks + vectors, products and residuals; no factorisation
     bool own_ws = false;
     char* ws = nullptr; size_t ws_bytes = 0;
     // carved from workspace

@@ -33,14 +33,16 @@ namespace {
 struct Carve { size_t off = 0; size_t take(size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; } };
 
 // Workspace layout; returns total bytes.  When base != nullptr also sets the pointers.
-size_t carve_workspace(Ctx* c, const Geo& g, char* base) {
+size_t carve_workspace(Ctx* c, const Geo& g, char* base, bool provider_only = false) {
     Carve cv;
     const size_t D = sizeof(double);
-    const size_t oA = cv.take((size_t)g.Npad * (size_t)(g.ncols_local > 0 ? g.ncols_local : 1) * D);
-    const size_t oW = cv.take(3 * (size_t)default_group(g.world) * (size_t)g.Npad * g.nb * D);   // -W of a panel group, three rotating buffers (group g+1 is written while g is read)
+    // (a provider-only handle -- pyipm_newton_create_provider: block products and residuals, no factorisation -- has no KKT
+    //  storage, no W buffers, no tile inverses: N^2 x 8 bytes that an L-BFGS run never needs)
+    const size_t oA = cv.take(provider_only ? 256 : (size_t)g.Npad * (size_t)(g.ncols_local > 0 ? g.ncols_local : 1) * D);
+    const size_t oW = cv.take(provider_only ? 256 : 3 * (size_t)default_group(g.world) * (size_t)g.Npad * g.nb * D);   // -W of a panel group, three rotating buffers (group g+1 is written while g is read)
     const size_t oL = cv.take(g.world > 1 ? (size_t)g.Npad * g.nb * D : 256);
-    const size_t oD = cv.take((size_t)(g.Npad / TB) * TB * TB * D);
-    const size_t oT = cv.take((size_t)(g.Npad / TB) * TB * TB * D);
+    const size_t oD = cv.take(provider_only ? 256 : (size_t)(g.Npad / TB) * TB * TB * D);
+    const size_t oT = cv.take(provider_only ? 256 : (size_t)(g.Npad / TB) * TB * TB * D);
     const size_t oTf = cv.take((size_t)(g.Npad / TB + 1) * D);
     const size_t orhs = cv.take((size_t)g.Npad * D);
     const size_t ov0 = cv.take((size_t)g.Npad * D);
@@ -1005,6 +1007,7 @@ int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
 
 int assemble_dev(Ctx* ctx, double delta, double delta_c) {
     const Geo& g = ctx->g;
+    if (ctx->provider_only) { ctx->err = "a provider-only handle has no KKT storage: block products and residuals only"; return PYIPM_E_BADARG; }
     if (!ctx->have_blocks || !ctx->have_vectors) { ctx->err = "assemble: stage blocks and vectors first"; return PYIPM_E_BADARG; }
     ctx->delta = delta; ctx->delta_c = delta_c;
     if (ctx->condensed && g.mi > 0 && g.world > 1 && ctx->sharded) {
@@ -1330,8 +1333,27 @@ size_t pyipm_newton_workspace_bytes(int64_t n, int64_t me, int64_t mi, int nb, i
     return carve_workspace(nullptr, g, nullptr);
 } PYIPM_CATCH_SIZE
 
+static int create_impl(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t mi, int nb, int device,
+                       int world, int rank, void* workspace, size_t workspace_bytes, void* stream, bool provider_only);
+
 int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t mi, int nb, int device,
                         int world, int rank, void* workspace, size_t workspace_bytes, void* stream) try {
+    return create_impl(out, n, me, mi, nb, device, world, rank, workspace, workspace_bytes, stream, false);
+} PYIPM_CATCH_NOH
+
+size_t pyipm_newton_workspace_bytes_provider(int64_t n, int64_t me, int64_t mi) try {
+    if (n <= 0 || me < 0 || mi < 0) return 0;
+    Geo g = make_geo(n, me, mi, 256, 1, 0);
+    return carve_workspace(nullptr, g, nullptr, true);
+} PYIPM_CATCH_SIZE
+
+int pyipm_newton_create_provider(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t mi, int device,
+                                 void* workspace, size_t workspace_bytes, void* stream) try {
+    return create_impl(out, n, me, mi, 256, device, 1, 0, workspace, workspace_bytes, stream, true);
+} PYIPM_CATCH_NOH
+
+static int create_impl(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t mi, int nb, int device,
+                       int world, int rank, void* workspace, size_t workspace_bytes, void* stream, bool provider_only) {
     if (!out) return PYIPM_E_BADARG;
     *out = nullptr;
     if (n <= 0 || me < 0 || mi < 0 || world < 1 || rank < 0 || rank >= world) return PYIPM_E_BADARG;
@@ -1347,7 +1369,8 @@ int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t m
     ctx->stream = (hipStream_t)stream;
     if (hipSetDevice(device) != hipSuccess) return create_fail(ctx, PYIPM_E_NODEVICE);
     { int ncu = 0; if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) ctx->num_cus = ncu; }
-    const size_t need = carve_workspace(nullptr, ctx->g, nullptr);
+    ctx->provider_only = provider_only;
+    const size_t need = carve_workspace(nullptr, ctx->g, nullptr, provider_only);
     if (workspace) {
         if (workspace_bytes < need) return create_fail(ctx, PYIPM_E_NOMEM);
         ctx->ws = (char*)workspace; ctx->own_ws = false;
@@ -1356,7 +1379,7 @@ int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t m
         ctx->own_ws = true;
     }
     ctx->ws_bytes = need;
-    carve_workspace(ctx, ctx->g, ctx->ws);
+    carve_workspace(ctx, ctx->g, ctx->ws, provider_only);
     if (hipMemset(ctx->anorm, 0, sizeof(unsigned long long)) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     for (int i = 0; i < 4; ++i) if (hipEventCreate(&ctx->ev_prov[i]) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
@@ -1365,7 +1388,7 @@ int pyipm_newton_create(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t m
         hipEventCreateWithFlags(&ctx->ev_panel, hipEventDisableTiming) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     *out = reinterpret_cast<pyipm_newton_ctx*>(ctx);
     return PYIPM_OK;
-} PYIPM_CATCH_NOH
+}
 
 size_t pyipm_newton_workspace_bytes_batched(int64_t n, int64_t me, int64_t mi, int batch) try {
     if (n <= 0 || me < 0 || mi < 0 || batch < 1) return 0;
@@ -1533,7 +1556,8 @@ int pyipm_newton_stage_blocks(pyipm_newton_ctx* h, const double* d2L, int64_t ld
     if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     int rc;
-    rc = stage_block(ctx, d2L, g.n, g.n, ld_d2L, memkind, &ctx->stg_d2L, &ctx->stg_d2L_sz, &ctx->d2L, &ctx->ld_d2L); if (rc) return rc;
+    if (!d2L && ctx->provider_only) { ctx->d2L = nullptr; ctx->ld_d2L = g.n; }     // (a factored Hessian model: only the Jacobian products)
+    else { rc = stage_block(ctx, d2L, g.n, g.n, ld_d2L, memkind, &ctx->stg_d2L, &ctx->stg_d2L_sz, &ctx->d2L, &ctx->ld_d2L); if (rc) return rc; }
     rc = stage_block(ctx, Je, g.me ? g.n : 0, g.me, ld_Je, memkind, &ctx->stg_Je, &ctx->stg_Je_sz, &ctx->Je, &ctx->ld_Je); if (rc) return rc;
     rc = stage_block(ctx, Ji, g.mi ? g.n : 0, g.mi, ld_Ji, memkind, &ctx->stg_Ji, &ctx->stg_Ji_sz, &ctx->Ji, &ctx->ld_Ji); if (rc) return rc;
     ctx->have_blocks = true;
@@ -1776,6 +1800,7 @@ int pyipm_newton_block_products(pyipm_newton_ctx* h, const double* v, double* Qv
     PYIPM_HIP(hipSetDevice(ctx->device));
     if (g.world != 1 || ctx->sharded) { ctx->err = "block_products: single-rank handles with fully staged blocks"; return PYIPM_E_BADARG; }
     if (!ctx->have_blocks) { ctx->err = "block_products: stage blocks first"; return PYIPM_E_BADARG; }
+    if (Qv && !ctx->d2L) { ctx->err = "block_products: no d2L block staged on this provider-only handle (pass Qv = NULL)"; return PYIPM_E_BADARG; }
     const RowMap rm = make_rowmap(g, 0);
     const int64_t n = g.n, me = g.me, mi = g.mi;
     const int nchunk = 64;

@@ -112,6 +112,8 @@ def load_library(path: str | None = None):
         "pyipm_newton_set_exchange": (c_int, [ctxp, c_void_p, c_void_p, c_void_p]),
         "pyipm_newton_rccl_library": (c_int, [c_char_p]),
         "pyipm_newton_comm_unique_id": (c_int, [c_void_p]),
+        "pyipm_newton_workspace_bytes_provider": (c_size_t, [c_int64, c_int64, c_int64]),
+        "pyipm_newton_create_provider": (c_int, [POINTER(ctxp), c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
         "pyipm_newton_comm_init": (c_int, [ctxp, c_void_p]),
         "pyipm_newton_comm_ranks": (c_int, [ctxp]),
         "pyipm_newton_owned_rows": (c_int64, [ctxp, POINTER(c_int64)]),
@@ -171,7 +173,9 @@ class NewtonCore(object):
         dz = core.solve(flip=True)                 # substitution + sign flip        (:1720-1725)
     """
 
-    def __init__(self, n, me, mi, device=None, nb=256, world=1, rank=0):
+    def __init__(self, n, me, mi, device=None, nb=256, world=1, rank=0, provider_only=False):
+        """provider_only: block products, residual and kkt_matvec from the staged blocks, no factorisation (O(N) workspace;
+        ``pyipm_newton_create_provider``)."""
         import torch
         self.torch = torch
         self.lib = load_library()
@@ -181,15 +185,24 @@ class NewtonCore(object):
         self.n, self.me, self.mi = int(n), int(me), int(mi)
         self.N = self.n + 2 * self.mi + self.me
         self.nb, self.world, self.rank = int(nb), int(world), int(rank)
-        need = self.lib.pyipm_newton_workspace_bytes(self.n, self.me, self.mi, self.nb, self.world, self.rank)
+        self.provider_only = bool(provider_only)
+        if self.provider_only and (self.world != 1 or self.rank != 0):
+            raise NewtonError("provider-only handles are single-rank")
+        need = self.lib.pyipm_newton_workspace_bytes_provider(self.n, self.me, self.mi) if self.provider_only else \
+            self.lib.pyipm_newton_workspace_bytes(self.n, self.me, self.mi, self.nb, self.world, self.rank)
         if need == 0:
             raise NewtonError("invalid geometry n=%d me=%d mi=%d nb=%d world=%d rank=%d" % (n, me, mi, nb, world, rank))
         with torch.cuda.device(self.device):
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
             h = c_void_p()
-            rc = self.lib.pyipm_newton_create(ctypes.byref(h), self.n, self.me, self.mi, self.nb, self.device.index,
-                                              self.world, self.rank, c_void_p(self.workspace.data_ptr()), need,
-                                              c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+            if self.provider_only:
+                rc = self.lib.pyipm_newton_create_provider(ctypes.byref(h), self.n, self.me, self.mi, self.device.index,
+                                                           c_void_p(self.workspace.data_ptr()), need,
+                                                           c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+            else:
+                rc = self.lib.pyipm_newton_create(ctypes.byref(h), self.n, self.me, self.mi, self.nb, self.device.index,
+                                                  self.world, self.rank, c_void_p(self.workspace.data_ptr()), need,
+                                                  c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc:
             raise NewtonError("pyipm_newton_create failed: %s" % ERRORS.get(rc, rc))
         self.h = h
@@ -261,7 +274,7 @@ class NewtonCore(object):
         """d2L (n,n) row-major (upper triangle read), Je (n,me), Ji (n,mi)."""
         self._use_current_stream()
         n, me, mi = self.n, self.me, self.mi
-        d2L = self._dev(d2L, (n, n))
+        d2L = self._dev(d2L, (n, n)) if (d2L is not None or not self.provider_only) else None
         Je = self._dev(Je, (n, me)) if me else None
         Ji = self._dev(Ji, (n, mi)) if mi else None
         self._keep.update(d2L=d2L, Je=Je, Ji=Ji)

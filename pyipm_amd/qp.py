@@ -84,10 +84,13 @@ class QPDeviceIPM(object):
             from .lbfgs import LbfgsCore
             if not 1 <= self.lbfgs <= 31:
                 raise ValueError("1 <= lbfgs <= 31")
-            self.backend = self.core = None
-            # x @ J through stored transposes: a row-vector times a row-major matrix is rocBLAS' slow GEMV flavour
-            self.JeT = self.Je.t().contiguous() if self.Je is not None else None
-            self.JiT = self.Ji.t().contiguous() if self.Ji is not None else None
+            self.backend = None
+            # the provider's products (df, ce, ci, the J lambda terms) through the library as in the exact-Hessian mode: a
+            # provider-only handle -- staged blocks, no KKT storage (pyipm_newton_create_provider); a factored Q stages no
+            # d2L block and keeps its own diag + low-rank product
+            from .newton import NewtonCore
+            self.core = NewtonCore(n, me, mi, device=dev.index, provider_only=True)
+            self.core.stage_blocks(self.Q, self.Je, self.Ji)
             self.lb = LbfgsCore(n, me, mi, self.lbfgs + 1, device=dev.index, nb=nb)     # storage reaches lbfgs+1 pairs
             self.lb.stage_jacobian(self.Je, self.Ji)                                    # linear constraints: once
         else:
@@ -107,11 +110,11 @@ class QPDeviceIPM(object):
         key = (id(v), v._version)
         if self._pcache[0] == key:
             return self._pcache[1]
-        if self.core is not None:
+        if self.Q is not None:
             out = self.core.block_products(v)
-        else:                                               # L-BFGS mode: no Newton core; Q may be factored
-            q = (self.Q @ v) if self.Q is not None else (self.Qd * v + self.QF @ (self.QF.t() @ v))
-            out = (q, self.JeT @ v if self.neq else None, self.JiT @ v if self.nineq else None)
+        else:                                               # L-BFGS mode with a factored Q: its own product, J' v from the library
+            _, e, i = self.core.block_products(v, want=(False, True, True))
+            out = (self.Qd * v + self.QF @ (self.QF.t() @ v), e, i)
         self._pcache = (key, out)
         self._pkeep = v                                     # keeps id(v) unique while cached
         return out
@@ -134,14 +137,7 @@ class QPDeviceIPM(object):
     def _jlam(self, lda):
         """Je lda_e + Ji lda_i (n)."""
         me, mi = self.neq, self.nineq
-        if self.core is not None:
-            return self.core.block_products_t(lda[:me] if me else None, lda[me:] if mi else None)
-        out = self.torch.zeros(self.nvar, dtype=self.torch.float64, device=self.device)
-        if me:
-            out = out + self.Je @ lda[:me]
-        if mi:
-            out = out + self.Ji @ lda[me:]
-        return out
+        return self.core.block_products_t(lda[:me] if me else None, lda[me:] if mi else None)
 
     def _con(self, x, s):
         parts = []

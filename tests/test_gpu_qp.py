@@ -201,3 +201,41 @@ def test_device_loop_retraces_the_reference_solve(name):
         assert abs(mu - float(d["it_mu_host"][it])) <= 1e-9 * max(1.0, float(d["it_mu_host"][it]))
     np.testing.assert_allclose(x.cpu().numpy(), d["x"], rtol=0, atol=1e-6 * max(1.0, np.abs(d["x"]).max()))
     assert abs(fval - float(d["fval"])) <= 1e-7 * max(1.0, abs(float(d["fval"])))
+
+
+def test_provider_only_handle():
+    """pyipm_newton_create_provider (round 3): block products, residual and kkt_matvec from staged blocks with O(N) workspace --
+    what QPDeviceIPM(lbfgs=m) forms df, ce, ci and the J lambda terms with (pyipm.py:855-954) -- and a clear error from
+    every entry that needs the KKT storage."""
+    import torch
+    from pyipm_amd.newton import NewtonCore, NewtonError
+    rng = np.random.default_rng(5)
+    n, me, mi = 700, 150, 260
+    qp = make_qp(n, me, mi, 4)
+    full = NewtonCore(n, me, mi, device=0)
+    prov = NewtonCore(n, me, mi, device=0, provider_only=True)
+    assert prov.workspace.numel() < full.workspace.numel() // 20
+    for c in (full, prov):
+        c.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+        c.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    v = torch.from_numpy(rng.standard_normal(n)).cuda()
+    for a, b in zip(full.block_products(v), prov.block_products(v)):
+        assert torch.equal(a, b)
+    le, li = rng.standard_normal(me), rng.standard_normal(mi)
+    assert torch.equal(full.block_products_t(le, li), prov.block_products_t(le, li))
+    assert torch.equal(full.residual(), prov.residual())
+    w = torch.from_numpy(rng.standard_normal(full.N)).cuda()
+    assert torch.equal(full.matvec(w), prov.matvec(w))
+    with pytest.raises(NewtonError, match="provider-only"):
+        prov.assemble(0.0, 0.0)
+    with pytest.raises(NewtonError):
+        prov.factor()
+    # a factored Hessian model: no d2L block at all
+    p2 = NewtonCore(n, me, mi, device=0, provider_only=True)
+    p2.stage_blocks(None, qp["Je"], qp["Ji"])
+    q, e, i = p2.block_products(v, want=(False, True, True))
+    assert q is None and torch.equal(e, full.block_products(v)[1]) and torch.equal(i, full.block_products(v)[2])
+    with pytest.raises(NewtonError, match="no d2L"):
+        p2.block_products(v)
+    for c in (full, prov, p2):
+        c.close()
