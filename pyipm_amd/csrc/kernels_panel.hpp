@@ -138,6 +138,8 @@ __global__ __launch_bounds__(256, 2) void k_tile_step(
         return;
     }
     const int tp = t - 1, it = t + b;                                // the stage applied; this block's row tile
+#define PYIPM_TS_STAMP(k_) if (dbg && b == 0 && tid == 0) dbg[200 + (k_)] = clock64();     /* diagnostics: tools/tile_clock.py */
+    PYIPM_TS_STAMP(0)
     if (y > it - t) return;                                          // fewer column tiles than y-blocks
     const int64_t i = c0 + (int64_t)it * TB + wave * 16 + l15;        // this lane's (global) row
     if (nref > 0 && Tflag[tp] == 0.0) nref = 0;
@@ -146,8 +148,10 @@ __global__ __launch_bounds__(256, 2) void k_tile_step(
     #pragma unroll
     for (int ks = 0; ks < 16; ++ks) sb[ks] = -W[i + (int64_t)(tp * TB + ks * 4 + l4) * ldw];    // S from its saved negative: the
     __syncthreads();                                     // y-blocks of a row tile all need it, and block y = 0 overwrites A with L
+    PYIPM_TS_STAMP(1)
     double4_t acc[4];
     strip_scale(X, Dinv + tp * TT, Tsv + tp * TT, nref, sb, tid, l15, l4, acc);
+    if (dbg && b == 0) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][3])); PYIPM_TS_STAMP(2) }
     if (y == 0) {
         double gmax = 0.0;
         #pragma unroll
@@ -160,8 +164,40 @@ __global__ __launch_bounds__(256, 2) void k_tile_step(
         gmax = wave_max(gmax);
         if (lane == 0) atomicMax(&st->growth_bits, (unsigned long long)__double_as_longlong(gmax));
     }
-    if (b == 0) __syncthreads();                                     // every wave is done with X: the tile goes where it was
-    for (int v = t + y; v <= it; v += ny) {
+    PYIPM_TS_STAMP(3)
+    if (b == 0) {
+        // The critical block: its one column tile is the diagonal tile t, and the Wn operand of that update is -S of ITS OWN
+        // 64 rows -- already in the registers of its four waves (sb, B-operand map).  It goes through shared memory into the
+        // A-operand map instead of being read back from the W buffer in two dependent batches of global loads (two memory
+        // round trips on the chain: 9400 of the prologue's 18500 cycles -> 7000 of 16100, tools/tile_clock.py).  Same values
+        // (W holds -S exactly), same products in the same order: the same bits.
+        double4_t c2[4];
+        #pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) c2[tt][r] = A[i + (lc0 + t * TB + tt * 16 + l4 + 4 * r) * ld];
+        __syncthreads();                                             // every wave is done with X (inv(T))
+        #pragma unroll
+        for (int ks = 0; ks < 16; ++ks) X[ks * 4 + l4][wave * 16 + l15] = -sb[ks];      // Wn[c][k] = -S[c][k], stored [k][c]
+        __syncthreads();
+        #pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            const double lop = acc[ks >> 2][ks & 3];
+            #pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                c2[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[ks * 4 + l4][16 * tt + l15], lop, c2[tt], 0, 0, 0);
+        }
+        __syncthreads();                                             // Wn read: the tile goes where it was
+        #pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = tt * 16 + l4 + 4 * r;
+                A[i + (lc0 + t * TB + c) * ld] = c2[tt][r];
+                sm.stage[wave * 16 + l15][c] = c2[tt][r];
+            }
+    }
+    for (int v = t + y; v <= it && b != 0; v += ny) {
         double4_t c2[4];
         #pragma unroll
         for (int tt = 0; tt < 4; ++tt)
@@ -178,6 +214,8 @@ __global__ __launch_bounds__(256, 2) void k_tile_step(
                 else if (v == t) W[i + (int64_t)(t * TB + c) * ldw] = -c2[tt][r];
             }
     }
+    PYIPM_TS_STAMP(4)
+#undef PYIPM_TS_STAMP
     if (b == 0)
         tile_invert_dev(sm, A, ld, c0 + (int64_t)t * TB, lc0 + (int64_t)t * TB, Dinv + t * TT, Tsv + t * TT, Tflag + t, refine_cond,
                         st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg, /*from_stage=*/true, blocked != 0);

@@ -28,3 +28,8 @@ if b[6]:
             t = [x - b[6] for x in b[8 + 32 * kb + 8 * w: 16 + 32 * kb + 8 * w]]
             print("  block %d wave %d: loads issued @%d, loaded @%d, elimination done @%d (+%d), U @%d, MFMA phase done @%d (+%d), past barrier @%d, committed @%d"
                   % (kb, w, t[4], t[0], t[1], t[1] - t[0], t[5], t[2], t[2] - t[1], t[6], t[3]))
+
+if b[200]:
+    t = [x - b[200] for x in b[200:205]]
+    print("k_tile_step block 0 (last launch): operands staged @%d, scaling product done @%d, L stored @%d, diagonal tile updated + staged @%d cycles; inversion starts @%d (clock of its own stamp: %d after entry)"
+          % (t[1], t[2], t[3], t[4], b[6] - b[200], b[6] - b[200]))
