@@ -177,7 +177,7 @@ def main():
     ap.add_argument("--nvar", "--n", dest="n", type=int, default=16384)
     ap.add_argument("--neq", "--me", dest="me", type=int, default=4096)
     ap.add_argument("--nineq", "--mi", dest="mi", type=int, default=6144)
-    ap.add_argument("--nb", type=int, default=0, help="panel width (default 256 on one GPU, 512 across GPUs: half the sync points)")
+    ap.add_argument("--nb", type=int, default=0, help="panel width (default 256 on one GPU, 1024 across GPUs: a quarter of the messages and sync points; the owner factors a wide panel with the single-rank group chain)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--refine", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -233,7 +233,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
     if args.nb == 0:
-        args.nb = 256 if world == 1 else 512
+        args.nb = 256 if world == 1 else 1024
     n, me, mi = args.n, args.me, args.mi
     N = n + 2 * mi + me
     qp = make_qp_device(n, me, mi, args.seed, device)

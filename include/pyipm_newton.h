@@ -331,7 +331,11 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *   updated panel by panel beside the chain; default 0 since the head is split), "bulk_bn" 128|256 (bulk update tiles of
  *   128 x 128 or 128 x 256), "reserve_cus" / "persist_rows" (chain-bound phase -- at most persist_rows rows left, default
  *   12288: the bulk update runs as a persistent launch that leaves reserve_cus CUs, default 16,
- *   to the panel chain; 0 = ordinary launches) -- all of these choose between implementations that accumulate the same
+ *   to the panel chain; 0 = ordinary launches), "wide_sub" (per-panel / multi-GPU schedule: a panel wider than this many
+ *   columns, default 256, is factored by its owner as a block of sub-panels this wide -- one tile chain over the panel's
+ *   diagonal block, the rows below it sub-panel by sub-panel with MFMA in-panel updates -- and swept sub-panel by
+ *   sub-panel: at nb = 512 / 1024 the launches, and the bits, of the single-rank schedule at nb = 256; 0 = all stages
+ *   of a panel in one launch) -- all of these choose between implementations that accumulate the same
  *   products in the same order: the results are bit-identical (tests/test_gpu_symmetric.py);
  *   "tile_blocked" 0|1 (default 1; batched handles 0): the 64 x 64 tile inversion 16 pivots at a time (in-register LDL' of the
  *   micro-block + fp64 MFMA block sweeps, Bunch-Kaufman verified afterwards, fallback to the single sweeps: DESIGN.md

@@ -132,6 +132,8 @@ struct Ctx {
     bool per_panel_mode = false;          // the per-panel phases (pyipm_newton_factor_begin ...) drive this factorisation
     int64_t head32_rows_dist = 16384;     // per-panel (multi-GPU) schedule: single-panel launches (the owner's head update of the
                                           // next panel, always on the critical path there) while at most this many rows remain
+    int wide_sub = 256;                   // per-panel schedule: a panel wider than this is factored as a block of sub-panels this wide
+                                          // (factor_wide_panel: the single-rank group chain inside one panel); 0 = all stages in one launch
     int64_t pending32_rows = 24576;       // ... and a panel's pending in-group update too while at most this many rows remain
                                           // (128x128 tiles keep one CU busy for 27 us per 256 columns of K, on the chain)
     int64_t head_split_rows = 0;          // the head in two launches (head_split) while at most this many rows remain, whatever kernel

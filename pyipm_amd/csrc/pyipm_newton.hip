@@ -216,7 +216,7 @@ int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, uns
         if (k == 1) throw std::bad_alloc();
         throw std::runtime_error("injected fault");
     }
-    std::vector<int64_t> key = {u.row_begin, u.Npad, u.first_lp, u.nrt, u.nct, u.a0, u.a1, u.b0, u.b1, u.nb, u.rt_min0, u.rt_step, bn, u.head_ct};
+    std::vector<int64_t> key = {u.row_begin, u.Npad, u.first_lp, u.nrt, u.nct, u.a0, u.a1, u.b0, u.b1, u.nb, u.rt_min0, u.rt_step, bn, u.head_ct, u.sub0};
     auto it = ctx->tile_lists.find(key);
     if (it != ctx->tile_lists.end()) {
         *dev = it->second.dev; *count = it->second.count; if (head_count) *head_count = it->second.head_count; return 0;
@@ -287,17 +287,18 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
                      int64_t row_begin, int64_t first_lp, int64_t n_lp, bool bulk = true,
                      int64_t ldw = 0, int64_t row_end = 0, int64_t col_end = 0, int64_t src_c0 = -1,
                      int ksplit = 1, int64_t ks_cstride = 0, int waves = 0,        // waves: 0 = the handle's bulk_waves
-                     int head_ct = 0, unsigned* head_counter = nullptr, unsigned* head_count = nullptr, bool list_only = false) {
-    const Geo& g = ctx->g;
+                     int head_ct = 0, unsigned* head_counter = nullptr, unsigned* head_count = nullptr, bool list_only = false,
+                     int sub0 = 0, int nct_sub = 0) {  // nct_sub > 0: only column tiles [sub0, sub0 + nct_sub) of local panel first_lp
+    const Geo& g = ctx->g;                             // (128 wide; the sub-panels of a wide panel, factor_block)
     if (ldw <= 0) ldw = g.Npad;
     if (row_end <= 0) row_end = g.Npad;
     if (col_end <= 0) col_end = g.Npad;
     const int64_t m = row_end - row_begin;
     if (m <= 0 || n_lp <= 0) return 0;
     UpdGeo u;
-    u.row_begin = row_begin; u.Npad = col_end; u.first_lp = first_lp; u.sub0 = 0;
+    u.row_begin = row_begin; u.Npad = col_end; u.first_lp = first_lp; u.sub0 = sub0;
     u.nb = g.nb; u.world = g.world; u.rank = g.rank;
-    u.nrt = (int)(m / BM); u.nct = (int)(n_lp * (g.nb / 128));
+    u.nrt = (int)(m / BM); u.nct = nct_sub > 0 ? nct_sub : (int)(n_lp * (g.nb / 128));
     u.dbg = ctx->dbg_buf;
     u.prio = bulk ? 0 : ctx->side_prio;
     u.rt_min0 = 0; u.rt_step = 0; u.tiles = nullptr; u.ks_cstride = 0; u.persist = 0;
@@ -306,7 +307,7 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     else { u.a0 = 0; u.a1 = g.Npad; u.b0 = 0; u.b1 = 0; }
     const int use_waves = waves ? waves : ctx->bulk_waves;
     if (ctx->xcd_swizzle && bulk && ctx->bulk_bn == 256 && use_waves == 8 && waves == 0 && ksplit == 1 && g.nb % 256 == 0 &&
-        K >= ctx->bulk_bn_min_k && head_ct == 0) {
+        K >= ctx->bulk_bn_min_k && head_ct == 0 && nct_sub == 0) {
         // 128 x 256 tiles (the K = 1024 bulk launches of the single-rank schedule, the K = nb launches of the per-panel one)
         u.nct = (int)(n_lp * (g.nb / 256));
         upd_fill_affine<256>(u);
@@ -368,6 +369,8 @@ void panel_hole(const Ctx* ctx, int64_t p, int64_t* h0, int64_t* h1) {
     if (b > a) { *h0 = a; *h1 = b; }
 }
 
+int factor_wide_panel(Ctx* ctx, int64_t p, hipStream_t stream);
+
 // Factor panel p on `stream`.  apply_pending: first apply the earlier panels of p's group to p's columns
 // (grouped single-rank driver; their bulk update is deferred to the end of the group).
 int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = false) {
@@ -418,6 +421,9 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
         panel_hole(ctx, p, &hole0, &hole1);             // per-panel mode (any number of ranks)
         if (hole1 > hole0) active_ranges(ctx, c0, c0 + nbw, &ha0, &ha1, &hb0, &hb1);
     }
+    if (ctx->tile_step && ctx->inpanel32 && ctx->per_panel_mode && ctx->wide_sub >= 128 && ctx->wide_sub % 128 == 0 &&
+        nbw > ctx->wide_sub && nt <= 32 && c0 + nbw < g.Npad)
+        return factor_wide_panel(ctx, p, stream);
     if (ctx->tile_step && ctx->inpanel32 && nt <= 16) {
         // stepped schedule: launch t inverts tile t (after eliminating tile t - 1 from the rows of the diagonal block), one
         // more launch runs all stages for the rows below the diagonal block
@@ -495,42 +501,60 @@ int ensure_rest_stream(Ctx* ctx) {
     return 0;
 }
 
-// One group of panels of the single-rank schedule, chained tile to tile (kernels_panel.hpp).  The diagonal block of the
-// WHOLE group (n0 * nb columns) runs as one sequence of k_tile_step launches on `chain`: a tile waits for nothing but the
-// tile before it, and what the per-panel schedule did between two panels of a group (the pending update of the next
-// panel's columns, the scaling of all rows below) no longer sits between two tile inversions.  The rows below the
-// diagonal block follow on ctx->rest, panel by panel: all stages of the panel (k_panel_rest), then the panel's
-// contribution to the later panels of the group (right-looking: the pending update, one source panel at a time --
-// the same products in the same order).  on_done(q, stream): panel q is complete once `stream` reaches this point.
-int factor_group(Ctx* ctx, int64_t p0, int64_t n0, hipStream_t chain, const std::function<int(int64_t, hipStream_t)>& on_done) {
+// One block of adjacent sub-panels owned by this rank, chained tile to tile (kernels_panel.hpp): a GROUP of panels of the
+// single-rank schedule (factor_group) or ONE wide panel of the per-panel schedule cut into sub-panels (factor_wide_panel).
+// The diagonal block of the WHOLE block runs as one sequence of k_tile_step launches on `chain`: a tile waits for nothing
+// but the tile before it, and what a per-panel schedule does between two panels (the pending update of the next panel's
+// columns, the scaling of all rows below) no longer sits between two tile inversions.  The rows below the diagonal block
+// follow on ctx->rest, sub-panel by sub-panel: all stages of the sub-panel (k_panel_rest), then its contribution to the
+// later sub-panels of the block (right-looking: the pending update, one source at a time -- the same products in the same
+// order).  on_done(id, stream): sub-panel `id` is complete once `stream` reaches this point.
+struct SubPanel { int64_t c0, lc0; int nt; double* W; int64_t id; };
+struct BlockDesc {
+    std::vector<SubPanel> sp;              // adjacent in global AND local columns; W adjacent too (sp[k].W = sp[0].W + (c0_k - c0_0) * Npad)
+    bool wide = false;                     // sub-panels of local panel `lp` (column tiles addressed inside it) instead of whole panels
+    int64_t lp = 0;                        // wide: the local panel index; else: sp[k].id is the (local = global) panel index
+    int64_t hole0 = 0, hole1 = 0;          // rows of exact zeros the rows kernels skip (KKT structure)
+};
+int factor_block(Ctx* ctx, const BlockDesc& bd, hipStream_t chain, const std::function<int(int64_t, hipStream_t)>& on_done) {
     const Geo& g = ctx->g;
-    std::vector<int> toff((size_t)n0 + 1, 0);           // first tile of each panel inside the group (the matrix's last panel may be narrower)
-    for (int64_t k = 0; k < n0; ++k) toff[(size_t)k + 1] = toff[(size_t)k] + (int)(g.panel_w(p0 + k) / TB);
+    const int64_t n0 = (int64_t)bd.sp.size();
+    std::vector<int> toff((size_t)n0 + 1, 0);           // first tile of each sub-panel inside the block (the matrix's last panel may be narrower)
+    for (int64_t k = 0; k < n0; ++k) toff[(size_t)k + 1] = toff[(size_t)k] + bd.sp[(size_t)k].nt;
     const int nT = toff[(size_t)n0];
-    const int64_t gc0 = g.panel_c0(p0), glc0 = g.local_c0(p0), gend = gc0 + (int64_t)nT * TB;
+    const int64_t gc0 = bd.sp[0].c0, glc0 = bd.sp[0].lc0, gend = gc0 + (int64_t)nT * TB;
     const int64_t TT = (int64_t)TB * TB;
     { int r0 = ensure_rest_stream(ctx); if (r0) return r0; }
     if (!ctx->ev_join) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     while ((int64_t)ctx->ev_band.size() < n0) { hipEvent_t e; PYIPM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_band.push_back(e); }
-    double* Wg = wbuf(ctx, p0);
+    double* Wg = bd.sp[0].W;
     double* Dv = ctx->Dinv + (gc0 / TB) * TT;
     double* Ts = ctx->Tsv + (gc0 / TB) * TT;
+    // update of the block's own columns, rows from `row_begin`: target sub-panels [k1, k1 + cnt)
+    auto upd = [&](hipStream_t st, const double* Lop, const double* Wop, int K, int64_t row_begin, int64_t k1, int64_t cnt,
+                   int64_t src_c0) -> int {
+        if (!bd.wide)
+            return launch_update128(ctx, st, Lop, g.Npad, Wop, K, row_begin, bd.sp[(size_t)k1].id, cnt, /*bulk=*/false, 0, 0, 0, src_c0);
+        const int s0 = (int)((bd.sp[(size_t)k1].c0 - g.panel_c0(bd.lp * g.world + g.rank)) / 128);
+        const int nc = (int)((int64_t)(toff[(size_t)(k1 + cnt)] - toff[(size_t)k1]) * TB / 128);
+        return launch_update128(ctx, st, Lop, g.Npad, Wop, K, row_begin, bd.lp, 1, /*bulk=*/false, 0, 0, 0, src_c0,
+                                1, 0, 0, 0, nullptr, nullptr, false, s0, nc);
+    };
     for (int j = 0, kp = 1; j < nT; ++j) {
         int ny = (nT - j + 4) / 5; if (ny < 1) ny = 1; if (ny > 4) ny = 4;     // <= ~5 column tiles per block
         hipLaunchKernelGGL(k_tile_step, dim3((unsigned)(nT - j), (unsigned)ny), dim3(256), 0, chain, ctx->A, g.Npad, gc0, glc0, j,
                            Wg, g.Npad, Dv, Ts, ctx->Tflag + gc0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats, g.N,
                            ctx->pivtol_rel, ctx->anorm, g.n + g.mi, ctx->dbg_buf, ctx->tile_blocked);
         PYIPM_KCHECK();
-        // panel q's columns are final inside the diagonal block once the first tile of panel q + 1 has applied its last stage
+        // sub-panel q's columns are final inside the diagonal block once the first tile of sub-panel q + 1 has applied its last stage
         if (kp < n0 && j == toff[(size_t)kp]) { PYIPM_HIP(hipEventRecord(ctx->ev_band[(size_t)(kp - 1)], chain)); ++kp; }
     }
-    const size_t gi = (size_t)ctx->grp_of[(size_t)p0];
-    const bool grp_in_x = !ctx->grp_x.empty() && ctx->grp_x[gi];
     for (int64_t k = 0; k < n0; ++k) {
-        const int64_t q = p0 + k, c0 = g.panel_c0(q), lc0 = g.local_c0(q);
-        const int nt = (int)(g.panel_w(q) / TB);
-        // the last panel's rows are what the next group waits for: they stay on the chain's stream (a dependency across
-        // streams costs 10-30 us when the waiting side is idle), behind the other panels' work on ctx->rest
+        const SubPanel& q = bd.sp[(size_t)k];
+        const int64_t c0 = q.c0, lc0 = q.lc0;
+        const int nt = q.nt;
+        // the last sub-panel's rows are what the next block waits for: they stay on the chain's stream (a dependency across
+        // streams costs 10-30 us when the waiting side is idle), behind the other sub-panels' work on ctx->rest
         hipStream_t rs = ctx->rest;
         if (k + 1 == n0) {
             PYIPM_HIP(hipEventRecord(ctx->ev_join, ctx->rest));
@@ -539,47 +563,80 @@ int factor_group(Ctx* ctx, int64_t p0, int64_t n0, hipStream_t chain, const std:
         } else {
             PYIPM_HIP(hipStreamWaitEvent(ctx->rest, ctx->ev_band[(size_t)k], 0));
         }
-        // Where the bulk update is the bound (many rows below), the in-group updates of the rows below the diagonal block
-        // are applied LEFT-looking -- all earlier panels of the group at once (K up to 768), right before the panel's own
-        // stages -- instead of panel by panel: half the read-modify-write passes over those rows and longer K per launch.
-        // In the tail the panel-by-panel form keeps only the last panel's stages behind the chain.  Same bits either way.
+        // Where the bulk update is the bound (many rows below), the in-block updates of the rows below the diagonal block
+        // are applied LEFT-looking -- all earlier sub-panels at once (K up to 768), right before the sub-panel's own
+        // stages -- instead of one by one: half the read-modify-write passes over those rows and longer K per launch.
+        // In the tail the one-by-one form keeps only the last sub-panel's stages behind the chain.  Same bits either way.
         const bool left = ctx->pending_left_rows >= 0 && g.Npad - gend > ctx->pending_left_rows;
         if (g.Npad > gend && left && k > 0) {
             const int K = toff[(size_t)k] * TB;
-            int rc = launch_update128(ctx, rs, ctx->A + glc0 * g.Npad, g.Npad, Wg, K, gend, q, 1, /*bulk=*/false, 0, 0, 0, gc0);
+            int rc = upd(rs, ctx->A + glc0 * g.Npad, Wg, K, gend, k, 1, gc0);
             if (rc) return rc;
         }
         if (g.Npad > gend) {
-            int64_t hole0 = 0, hole1 = 0;
-            if (ctx->skip_zeros && g.mi > 0 && grp_in_x) {
-                hole0 = (g.n + BM - 1) / BM * BM; hole1 = (g.n + g.mi) / BM * BM;
-                if (hole1 < hole0) hole1 = hole0;
-            }
             hipLaunchKernelGGL(k_panel_rest, dim3((unsigned)((g.Npad - gend) / TB)), dim3(256), 0, rs, ctx->A, g.Npad, c0, lc0, nt,
-                               gend, wbuf(ctx, q), g.Npad, ctx->Dinv + (c0 / TB) * TT, ctx->Tsv + (c0 / TB) * TT, ctx->Tflag + c0 / TB,
-                               ctx->block_refine, hole0, hole1, &ctx->dstats->growth_bits);
+                               gend, q.W, g.Npad, ctx->Dinv + (c0 / TB) * TT, ctx->Tsv + (c0 / TB) * TT, ctx->Tflag + c0 / TB,
+                               ctx->block_refine, bd.hole0, bd.hole1, &ctx->dstats->growth_bits);
             PYIPM_KCHECK();
             if (k + 1 < n0 && !left) {
-                // this panel's contribution to the later panels of the group, rows below the diagonal block
-                const int K = (int)g.panel_w(q);
-                const int64_t tc0 = g.panel_c0(q + 1), ncols = (int64_t)(nT - toff[(size_t)k + 1]) * TB;
+                // this sub-panel's contribution to the later ones of the block, rows below the diagonal block
+                const int K = nt * TB;
+                const SubPanel& nx = bd.sp[(size_t)k + 1];
+                const int64_t tc0 = nx.c0, ncols = (int64_t)(nT - toff[(size_t)k + 1]) * TB;
                 if (g.Npad - tc0 <= ctx->pending32_rows) {
                     int64_t pa0, pa1, pb0, pb1;
                     active_ranges(ctx, c0, c0 + K, &pa0, &pa1, &pb0, &pb1);
                     hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - gend) / 32), (unsigned)(ncols / TB)), dim3(256), 0,
-                                       rs, ctx->A, g.Npad, g.local_c0(q + 1), ctx->A + lc0 * g.Npad, g.Npad, wbuf(ctx, q), g.Npad,
+                                       rs, ctx->A, g.Npad, nx.lc0, ctx->A + lc0 * g.Npad, g.Npad, q.W, g.Npad,
                                        tc0, K, gend, g.Npad, pa0, pa1, pb0, pb1, ctx->side_prio);
                     PYIPM_KCHECK();
                 } else {
-                    int rc = launch_update128(ctx, rs, ctx->A + lc0 * g.Npad, g.Npad, wbuf(ctx, q), K, gend, q + 1, n0 - 1 - k,
-                                              /*bulk=*/false, 0, 0, 0, c0);
+                    int rc = upd(rs, ctx->A + lc0 * g.Npad, q.W, K, gend, k + 1, n0 - 1 - k, c0);
                     if (rc) return rc;
                 }
             }
         }
-        int rc = on_done(q, rs); if (rc) return rc;
+        int rc = on_done(q.id, rs); if (rc) return rc;
     }
     return 0;
+}
+
+// A group of panels of the single-rank schedule: panels [p0, p0 + n0).
+int factor_group(Ctx* ctx, int64_t p0, int64_t n0, hipStream_t chain, const std::function<int(int64_t, hipStream_t)>& on_done) {
+    const Geo& g = ctx->g;
+    BlockDesc bd;
+    for (int64_t k = 0; k < n0; ++k) {
+        const int64_t q = p0 + k;
+        bd.sp.push_back(SubPanel{g.panel_c0(q), g.local_c0(q), (int)(g.panel_w(q) / TB), wbuf(ctx, q), q});
+    }
+    const size_t gi = (size_t)ctx->grp_of[(size_t)p0];
+    const bool grp_in_x = !ctx->grp_x.empty() && ctx->grp_x[gi];
+    if (ctx->skip_zeros && g.mi > 0 && grp_in_x) {
+        bd.hole0 = (g.n + BM - 1) / BM * BM; bd.hole1 = (g.n + g.mi) / BM * BM;
+        if (bd.hole1 < bd.hole0) bd.hole1 = bd.hole0;
+    }
+    return factor_block(ctx, bd, chain, on_done);
+}
+
+// Per-panel schedule, a panel wider than `wide_sub` columns (nb = 512 / 1024): the owner factors it like the single-rank
+// schedule factors a group -- one tile chain over the panel's diagonal block, the rows below it sub-panel by sub-panel on
+// ctx->rest with the in-panel updates as MFMA launches of K up to nb - wide_sub (k_panel_rest with all nt stages in one
+// launch is right-looking 64 columns at a time through L2: 120 tile passes per strip at nt = 16).  The same products in the
+// same order: the same bits.  What the other ranks see does not change (one message, one rank-nb update per panel), only
+// that the message is 4 x larger and 4 x rarer than at nb = 256 and the owner's chain is the single-rank one.
+int factor_wide_panel(Ctx* ctx, int64_t p, hipStream_t stream) {
+    const Geo& g = ctx->g;
+    const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
+    const int nt = (int)(g.panel_w(p) / TB), snt = ctx->wide_sub / TB;
+    BlockDesc bd;
+    bd.wide = true; bd.lp = p / g.world;
+    double* W = wbuf(ctx, p);
+    for (int t = 0; t < nt; t += snt) {
+        const int w = nt - t < snt ? nt - t : snt;
+        bd.sp.push_back(SubPanel{c0 + (int64_t)t * TB, lc0 + (int64_t)t * TB, w, W + (int64_t)t * TB * g.Npad, p});
+    }
+    panel_hole(ctx, p, &bd.hole0, &bd.hole1);
+    return factor_block(ctx, bd, stream, [](int64_t, hipStream_t) { return 0; });
 }
 
 // One bulk k_update<128> launch: panels [p0, p0+np) (contiguous, same rank) applied with K = their total
@@ -734,11 +791,17 @@ int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
 
 // nrhs right-hand sides at stride vstride (doubles) share every launch (last grid dimension); the single-vector
 // callers use the defaults.
+// A panel wider than wide_sub columns is swept in sub-panels of that width (the in-panel kernels are one workgroup with nt - 1
+// dependent steps: at nb = 1024 the sweeps took 5.9 ms instead of 2.1): the launches of the same matrix at nb = wide_sub.
 int fwd_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr, int nrhs = 1, int64_t vstride = 0) {
     if (!stream) stream = ctx->stream;
     const Geo& g = ctx->g;
-    const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
-    const int nbw = (int)g.panel_w(p);
+    const int64_t pc0 = g.panel_c0(p), plc0 = g.local_c0(p);
+    const int pw = (int)g.panel_w(p);
+    const int sw = (ctx->wide_sub >= TB && ctx->wide_sub % TB == 0 && pw > ctx->wide_sub) ? ctx->wide_sub : pw;
+    for (int off = 0; off < pw; off += sw) {
+    const int64_t c0 = pc0 + off, lc0 = plc0 + off;
+    const int nbw = pw - off < sw ? pw - off : sw;
     hipLaunchKernelGGL(k_fwd_diag, dim3(1, nrhs), dim3(nbw), nbw * sizeof(double), stream, ctx->A, g.Npad, lc0, c0, nbw, v, vstride);
     PYIPM_KCHECK();
     const int64_t below = g.Npad - (c0 + nbw);
@@ -748,6 +811,7 @@ int fwd_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr, int 
         hipLaunchKernelGGL(k_fwd_gemv, dim3(grid1(below).x, nrhs), dim3(256), nbw * sizeof(double), stream, ctx->A, g.Npad, lc0, c0,
                            nbw, c0 + nbw, g.Npad, v, vstride, a0, a1, b0, b1);
         PYIPM_KCHECK();
+    }
     }
     return 0;
 }
@@ -767,8 +831,12 @@ int diag_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr, int
 int bwd_panel(Ctx* ctx, int64_t p, double* v, int nrhs = 1, int64_t vstride = 0, double* part = nullptr, int64_t pstride = 0) {
     const Geo& g = ctx->g;
     if (!part) part = ctx->partial;
-    const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
-    const int nbw = (int)g.panel_w(p);
+    const int64_t pc0 = g.panel_c0(p), plc0 = g.local_c0(p);
+    const int pw = (int)g.panel_w(p);
+    const int sw = (ctx->wide_sub >= TB && ctx->wide_sub % TB == 0 && pw > ctx->wide_sub) ? ctx->wide_sub : pw;
+    for (int off = ((pw - 1) / sw) * sw; off >= 0; off -= sw) {        // sub-panels of a wide panel, last first (see fwd_panel)
+    const int64_t c0 = pc0 + off, lc0 = plc0 + off;
+    const int nbw = pw - off < sw ? pw - off : sw;
     const int64_t below = g.Npad - (c0 + nbw);
     int nchunk = 0;
     if (below > 0) {
@@ -786,6 +854,7 @@ int bwd_panel(Ctx* ctx, int64_t p, double* v, int nrhs = 1, int64_t vstride = 0,
         hipLaunchKernelGGL(k_bwd_diag, dim3(1, nrhs), dim3(nbw), nbw * sizeof(double), ctx->stream, ctx->A, g.Npad, lc0, c0, nbw,
                            g.nb, part, nchunk, v, vstride, pstride);
     PYIPM_KCHECK();
+    }
     return 0;
 }
 
@@ -2128,6 +2197,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "head_waves")) { ctx->head_waves = ((int)value == 8) ? 8 : 4; return PYIPM_OK; }
     if (!strcmp(name, "head_serial")) { ctx->head_serial = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
+    if (!strcmp(name, "wide_sub")) { ctx->wide_sub = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "early_head")) { ctx->early_head = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows_dist")) { ctx->head32_rows_dist = (int64_t)value; return PYIPM_OK; }

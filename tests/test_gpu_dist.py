@@ -82,7 +82,10 @@ def _factor_bytes(n, me, mi, nb):
 
 @pytest.mark.parametrize("mode", ["native", "native-sharded", "python-lockstep", "python-lookahead"])
 @pytest.mark.parametrize("world,shape,nb", [(2, (300, 100, 150, 7), 128), (2, (900, 200, 300, 8), 256),
-                                            (3, (700, 150, 260, 9), 128), (2, (1400, 0, 400, 10), 128)])
+                                            (3, (700, 150, 260, 9), 128), (2, (1400, 0, 400, 10), 128),
+                                            # panels wider than 256 columns: the owner factors them as a block of 256-column
+                                            # sub-panels (factor_wide_panel), the sweeps run sub-panel by sub-panel
+                                            (2, (1300, 300, 450, 11), 512), (3, (2000, 400, 600, 12), 1024)])
 def test_ranks_sharing_one_gpu(world, shape, nb, mode):
     import torch.multiprocessing as mp
     n, me, mi, seed = shape
@@ -125,6 +128,37 @@ def test_native_and_python_drivers_agree_bitwise():
         mp.spawn(_worker, args=(world, _free_port(), shape, nb, mode, out), nprocs=world, join=True)
         res[mode] = out[0][0]
     assert np.array_equal(res["native"], res["python-lookahead"])
+
+
+@pytest.mark.parametrize("shape", [(4096, 1024, 1536, 3), (3000, 700, 1100, 4), (2048, 0, 0, 5)])
+def test_wide_panels_match_the_group_schedule_bitwise(shape):
+    """Per-panel schedule at nb = 512 / 1024 (what several GPUs run): the owner's wide panel is factored as a block of
+    256-column sub-panels and swept sub-panel by sub-panel -- the launches of the single-rank group schedule at nb = 256 on
+    the same entries in the same order, so the direction has the same bits; with all stages of a wide panel in one launch
+    (wide_sub = 0, the round-2 form) it agrees to rounding."""
+    import torch
+    from pyipm_amd.newton import NewtonCore
+    from pyipm_amd.dist import DistNewton
+    n, me, mi, seed = shape
+    qp = make_qp(n, me, mi, seed)
+
+    def run(nb, wide_sub, per_panel):
+        core = NewtonCore(n, me, mi, device=0, nb=nb)
+        core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+        core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+        core.set_option("wide_sub", wide_sub)
+        dz, st = (core.step_dist(0.0, 0.0) if per_panel else core.step(0.0, 0.0))
+        dz = dz.clone()
+        core.close()
+        return dz, st
+
+    ref, st0 = run(256, 256, False)
+    for nb in (512, 1024):
+        wide, st1 = run(nb, 256, True)
+        one, st2 = run(nb, 0, True)
+        assert st0["n_neg"] == st1["n_neg"] == st2["n_neg"] == me + mi
+        assert torch.equal(wide, ref)
+        assert float((one - ref).norm() / ref.norm()) <= 1e-12
 
 
 def test_dist_driver_world1_matches_fused_step():
