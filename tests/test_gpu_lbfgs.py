@@ -37,7 +37,19 @@ def test_direction_matches_reference_fixture(path):
         # then the solution of a system of condition ~1e13: compare through the system itself.
         assert st["regularised"] == 1 and st["n_factor"] == 2
         assert np.all(np.isfinite(dz))
-        assert _rel(dz, d["dz_raw"]) <= 5e-2
+        # The value, component by component.  Only the DIFFERENCE of the two duplicated multipliers is ill-determined:
+        # (r_0 - r_last) / (2 reg) ~ 3e11, a quotient by the pivot reg + O(eps |G|), which the reference's LU and this
+        # factorisation round differently (measured 1e-4 apart).  Their sum and every other entry of the direction are
+        # well-determined and carry only the contamination eps x 3e11 ~ 3e-5 of that component.
+        ref = d["dz_raw"]
+        i0, i1 = n + mi, n + mi + me - 1
+        assert abs(ref[i0]) > 1e11 and abs(ref[i0] + ref[i1]) < 10.0                  # (the fixture is what this test thinks it is)
+        assert abs(dz[i0] - ref[i0]) <= 1e-3 * abs(ref[i0]) and abs(dz[i1] - ref[i1]) <= 1e-3 * abs(ref[i1])
+        assert abs((dz[i0] + dz[i1]) - (ref[i0] + ref[i1])) <= 1e-3
+        rest = np.ones(len(ref), dtype=bool)
+        rest[[i0, i1]] = False
+        assert _rel(dz[rest], ref[rest]) <= 1e-4
+        assert _rel(dz, ref) <= 1e-3
     else:
         assert st["regularised"] == 0 and st["n_neg"] == 0 and st["n_zero"] == 0
         assert _rel(dz, d["dz_raw"]) <= 1e-9
