@@ -132,6 +132,11 @@ struct Ctx {
     bool per_panel_mode = false;          // the per-panel phases (pyipm_newton_factor_begin ...) drive this factorisation
     int64_t head32_rows_dist = 16384;     // per-panel (multi-GPU) schedule: single-panel launches (the owner's head update of the
                                           // next panel, always on the critical path there) while at most this many rows remain
+    int sweep_persist = 1;                // single rank, one right-hand side: the backward sweep as ONE device-driven launch (k_bwd_sweep)
+    int64_t sweep_buf_n = 0;              // ... (allocated for this many rows)
+    double* sweep_buf = nullptr;          // ... the near sums as the column owners hand them to workgroup 0 (Npad doubles, NaN = not there yet)
+    unsigned* sweep_sync = nullptr;       // ... its flags and counters (3 npanels + 1 words, zeroed before every sweep)
+    bool sweep_used = false;              // ... a sweep ran since the error word was last read (solve_info / factor_end look at it)
     int wide_sub = 256;                   // per-panel schedule: a panel wider than this is factored as a block of sub-panels this wide
                                           // (factor_wide_panel: the single-rank group chain inside one panel); 0 = all stages in one launch
     int64_t pending32_rows = 24576;       // ... and a panel's pending in-group update too while at most this many rows remain

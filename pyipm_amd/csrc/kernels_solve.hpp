@@ -255,6 +255,235 @@ __global__ __launch_bounds__(1024) void k_bwd_diag4(const double* __restrict__ A
 //      kernel takes the same ~10 us -- it is the dependent launch, not the three recursion steps, that costs -- and the
 //      128 extra inversions per step load the GPU during the factorisation.  Kept: 16-byte loads in k_bwd_dot, 9.6 -> 8.9 us.)
 
+// ---------------------------------------------------------------------------------------------
+// The whole backward sweep in ONE launch (round 3).  Per panel the launches above are k_bwd_dot (HBM-bound, 7.6 us on
+// average at N = 32768) and k_bwd_diag4 (one workgroup, 8.6 us of dependent latencies): 127 x 16 us = 2.06 ms for 4.3 GB,
+// 26 % of what HBM delivers, and 24 x 10 us of config 2's 2.9 ms.  Here the sweep is RIGHT-looking and device-driven:
+//   * workgroup 0 walks the panels from the last to the first; for panel s it waits until the contributions of all later
+//     panels have reached y_s, resolves the panel's own diagonal block (the three steps of k_bwd_diag4), stores x_s and
+//     raises flag[s];
+//   * every other wave owns fixed groups of 8 columns (group g -> wave g mod #waves) and, as soon as flag[t] is up, subtracts
+//     L[rows of panel t, its columns]' x_t from its entries of y -- 2 KB per column, read coalesced (lane = 4 rows), reduced
+//     across the wave by a butterfly that folds 8 columns in 10 shuffles.  The columns of panel t - 1 (the only ones
+//     workgroup 0 waits for immediately) come first and are counted apart (near[t]); everything else of step t is needed
+//     two panels later (a progress word per workgroup).  L is static: the loads of a step are issued BEFORE its flag is polled.
+// A flag hand-off between workgroups costs 0.6 us when nothing is fenced (tools/ubench/pingpong.hip; 2.7 us with
+// __threadfence on both sides: buffer_wbl2 / buffer_inv), so every value that crosses workgroups inside this kernel (x, y,
+// flags, counters) is read and written with relaxed agent-scope atomics -- they bypass the non-coherent cache levels -- and
+// ordered by s_waitcnt alone.  Ownership is static and every sum has a fixed order: deterministic.  Every poll carries a
+// timeout (a workgroup that is not resident would otherwise hang the GPU): on expiry *err is set, the sweep ends and
+// the vector is poisoned with NaN.
+struct SweepGeo {
+    int64_t Npad, ld, n, mi, me;
+    int nb, npanels, skip;              // skip: structural zeros of the KKT factor (active_ranges on the host)
+};
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// can L[rows [r0, r1), columns of the panel [cA, cB)] be non-zero?  (active_ranges, pyipm_newton.hip)
+__device__ __forceinline__ bool sweep_active(const SweepGeo& sg, int64_t cA, int64_t cB, int64_t r0, int64_t r1) {
+    if (!sg.skip || sg.mi == 0) return true;
+    const int64_t s0 = sg.n, s1 = sg.n + sg.mi, i0 = sg.n + sg.mi + sg.me;
+    if (cB <= s0) return (r0 < s0) || (r1 > s1);
+    if (cA >= s0 && cB <= s1) return r1 > i0 + (cA - s0) && r0 < i0 + (cB - s0);
+    return true;
+}
+// poll *p until it reaches `want`; false on timeout or when another workgroup gave up
+__device__ __forceinline__ bool sweep_wait(const unsigned* p, unsigned want, unsigned* err, unsigned long long timeout) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+        if ((unsigned long long)wall_clock64() - t0 > timeout) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_bwd_sweep(const double* __restrict__ A, SweepGeo sg, double* v, unsigned* sync,
+                                                    unsigned* err, unsigned long long timeout,
+                                                    double* nearbuf)                    // Npad doubles, filled with NaN before the launch
+{
+    __shared__ double Ls[3][TB][TB + 1];
+    __shared__ double x[4 * TB], ps[4][4 * TB];
+    __shared__ int ok_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = sg.npanels, nb = sg.nb;
+    unsigned* flag = sync; unsigned* nearc = sync + P; unsigned* prog = sync + 2 * P;     // prog[b]: steps workgroup b has completed
+    const int gpp = nb / 8;                                    // groups of 8 columns per panel
+    if (blockIdx.x == 0) {
+        const int k = tid & 255, q = tid >> 8;
+        if (tid == 0) ok_s = 1;
+        __syncthreads();
+        for (int s = P - 1; s >= 0; --s) {
+            const int64_t c0 = (int64_t)s * nb;
+            int64_t w64 = sg.Npad - c0; if (w64 > nb) w64 = nb;
+            const int nbw = (int)w64, nt = nbw / TB;
+            // tiles (u, t), t < u <= 3, of the panel's diagonal block: requested up front, coalesced (see k_bwd_diag4)
+            double lt[6][4];
+            {
+                int idx = 0;
+                #pragma unroll
+                for (int u = 1; u <= 3; ++u)
+                    #pragma unroll
+                    for (int t = 0; t < u; ++t, ++idx)
+                        #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int e = tid + 1024 * r;
+                            lt[idx][r] = (u < nt) ? A[(c0 + (int64_t)u * TB + (e & 63)) + (c0 + t * TB + (e >> 6)) * sg.ld] : 0.0;
+                        }
+            }
+            if (tid < nbw) {
+                // y_s with every contribution but the one of panel s + 1, which arrives as values, not as a count: a column's
+                // entry of nearbuf turns from NaN into its sum (one round trip instead of counter + load; should the sum BE
+                // NaN -- a broken factor -- the count near[s + 1] says so)
+                const double yv = ld_agent(v + c0 + tid);
+                double nv = 0.0;
+                if (s + 1 < P) {
+                    const unsigned long long t0 = wall_clock64();
+                    for (;;) {
+                        nv = ld_agent(nearbuf + c0 + tid);
+                        if (nv == nv) break;
+                        if (__hip_atomic_load(nearc + s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)gpp) { nv = ld_agent(nearbuf + c0 + tid); break; }
+                        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok_s = 0; break; }
+                        if ((unsigned long long)wall_clock64() - t0 > timeout) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok_s = 0; break; }
+                    }
+                }
+                x[tid] = yv - nv;
+            }
+            __syncthreads();
+            if (!ok_s) break;
+            #pragma unroll
+            for (int u = 3; u >= 1; --u) {
+                if (u < nt) {
+                    const int base = u * (u - 1) / 2;
+                    #pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        if (t < u) {
+                            #pragma unroll
+                            for (int r = 0; r < 4; ++r) { const int e = tid + 1024 * r; Ls[t][e & 63][e >> 6] = lt[base + t][r]; }
+                        }
+                    __syncthreads();
+                    double acc = 0.0;
+                    if (k < u * TB) {
+                        const int t = k >> 6, j = k & 63;
+                        #pragma unroll
+                        for (int i = 0; i < 16; ++i) acc = fma(Ls[t][16 * q + i][j], x[u * TB + 16 * q + i], acc);
+                    }
+                    ps[q][k] = acc;
+                    __syncthreads();
+                    if (tid < u * TB) x[tid] -= (ps[0][tid] + ps[1][tid]) + (ps[2][tid] + ps[3][tid]);
+                }
+            }
+            __syncthreads();
+            if (tid < nbw) st_agent(v + c0 + tid, x[tid]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flag + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // for the NEXT panel (s - 1): every column owner has finished step s + 1 -- thread b polls workgroup b's progress
+            // word (one counter per step took 4080 atomics on one address: 27 us a step).  Normally long done, and polled
+            // here, while the owners of panel s - 1's columns work on what this panel just published.
+            if (s + 1 < P && s >= 1 && tid >= 1 && tid < (int)gridDim.x && !sweep_wait(prog + tid, (unsigned)(P - (s + 1)), err, timeout)) ok_s = 0;
+            __syncthreads();
+            if (!ok_s) break;
+        }
+        __syncthreads();
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+            for (int64_t i = tid; i < sg.Npad; i += 1024) st_agent(v + i, __builtin_nan(""));
+        return;
+    }
+    // ---- column owners ----
+    __shared__ unsigned wprog[16];                             // steps completed by each wave of this workgroup
+    if (tid < 16) wprog[tid] = 0u;
+    __syncthreads();
+    auto publish = [&](unsigned steps_done) {                   // (wave-uniform) this wave has completed that many steps
+        if (lane == 0) {
+            __hip_atomic_store(&wprog[wave], steps_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            unsigned m = steps_done;
+            #pragma unroll
+            for (int w = 0; w < 16; ++w) { const unsigned o = __hip_atomic_load(&wprog[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); m = o < m ? o : m; }
+            __hip_atomic_fetch_max(prog + blockIdx.x, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    const int nwv = ((int)gridDim.x - 1) * 16;
+    const int gw = ((int)blockIdx.x - 1) * 16 + wave;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    for (int t = P - 1; t >= 1; --t) {
+        const int64_t r0 = (int64_t)t * nb;
+        int64_t w64 = sg.Npad - r0; if (w64 > nb) w64 = nb;
+        const int nbw = (int)w64;
+        const int glim = t * gpp;                              // groups [0, glim) lie left of panel t
+        if (gw >= glim) break;                                 // nothing left for this wave, now or later
+        // my groups left of panel t, the nearest (highest) first: g = gw + k nwv
+        int kmax = (glim - 1 - gw) / nwv;
+        const bool in_rows = 4 * lane < nbw;
+        bool have_x = false;
+        double xr[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int kk = kmax; kk >= 0; --kk) {
+            const int g = gw + kk * nwv;
+            const int64_t j0 = (int64_t)g * 8;
+            const int64_t cp = (j0 / nb) * nb;                 // panel of these columns
+            const bool nearg = g >= glim - gpp;
+            const bool act = sweep_active(sg, cp, cp + nb, r0, r0 + nbw);
+            d2_t la[8][2];
+            if (act) {
+                #pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (in_rows) {
+                        const double* src = A + (r0 + 4 * lane) + (j0 + c) * sg.ld;
+                        la[c][0] = *reinterpret_cast<const d2_t*>(src);
+                        la[c][1] = *reinterpret_cast<const d2_t*>(src + 2);
+                    } else { la[c][0] = d2_t{0.0, 0.0}; la[c][1] = d2_t{0.0, 0.0}; }
+                }
+            }
+            if (!have_x) {
+                // x_t: one word polled per wave, then PLAIN loads -- the first wave of an XCD brings the 2 KB into its L2 for
+                // the other 500 (no copy of these lines can be stale: nobody reads them before the flag, and polling the
+                // values themselves from 4080 waves costs more memory traffic than it saves in round trips)
+                if (!sweep_wait(flag + t, 1u, err, timeout)) { publish((unsigned)P); return; }
+                asm volatile("" ::: "memory");
+                if (in_rows) {
+                    const d2_t x01 = *reinterpret_cast<const d2_t*>(v + r0 + 4 * lane), x23 = *reinterpret_cast<const d2_t*>(v + r0 + 4 * lane + 2);
+                    xr[0] = x01.x; xr[1] = x01.y; xr[2] = x23.x; xr[3] = x23.y;
+                }
+                have_x = true;
+            }
+            if (act) {
+                double a[8];
+                #pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    a[c] = fma(la[c][1].y, xr[3], fma(la[c][1].x, xr[2], fma(la[c][0].y, xr[1], la[c][0].x * xr[0])));
+                // fold 8 columns x 64 lanes: after the xor-32 / 16 / 8 steps a lane holds ONE column's partial sum
+                double b4[4], b2[2];
+                const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0;
+                #pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const double send = h5 ? a[i] : a[i + 4], keep = h5 ? a[i + 4] : a[i];
+                    b4[i] = keep + __shfl_xor(send, 32, 64);
+                }
+                #pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const double send = h4 ? b4[i] : b4[i + 2], keep = h4 ? b4[i + 2] : b4[i];
+                    b2[i] = keep + __shfl_xor(send, 16, 64);
+                }
+                double r;
+                { const double send = h3 ? b2[0] : b2[1], keep = h3 ? b2[1] : b2[0]; r = keep + __shfl_xor(send, 8, 64); }
+                r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64);
+                if ((lane & 7) == 0) {
+                    const int c = (h5 ? 4 : 0) + (h4 ? 2 : 0) + (h3 ? 1 : 0);
+                    if (nearg) st_agent(nearbuf + j0 + c, r);          // workgroup 0 subtracts it (and is polling for it)
+                    else { double* yp = v + j0 + c; st_agent(yp, ld_agent(yp) - r); }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (nearg && lane < 8) {
+                st_agent(nearbuf + j0 + lane, 0.0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            if (nearg && lane == 0) __hip_atomic_fetch_add(nearc + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        publish((unsigned)(P - t));
+    }
+    publish((unsigned)P);
+}
+
 // v[i] = b[i] on the rows of the panels this rank owns, 0 elsewhere: the ranks' vectors sum to b (distributed sweeps)
 __global__ __launch_bounds__(256) void k_mask_owned(double* __restrict__ v, const double* __restrict__ b, Geo g)
 {

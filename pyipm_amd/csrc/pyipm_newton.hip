@@ -751,8 +751,16 @@ int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
     PYIPM_HIP(hipMemcpyAsync(&z, ctx->dstats, sizeof(z), hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->head_counters)
         PYIPM_HIP(hipMemcpyAsync(&wait_err, ctx->head_counters + ctx->n_head_counters, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    int sweep_err = 0;
+    if (ctx->sweep_used && ctx->sweep_sync)
+        PYIPM_HIP(hipMemcpyAsync(&sweep_err, ctx->sweep_sync + 3 * 4096, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PYIPM_HIP(hipStreamSynchronize(ctx->stream));
     if (wait_err) { ctx->err = "fused head: the next group's chain gave up waiting for the bulk update's head tiles"; return PYIPM_E_HIP; }
+    if (sweep_err) {
+        PYIPM_HIP(hipMemsetAsync(ctx->sweep_sync + 3 * 4096, 0, sizeof(unsigned), ctx->stream));
+        ctx->err = "backward sweep (k_bwd_sweep): a poll timed out in an earlier solve; its result was NaN"; return PYIPM_E_HIP;
+    }
+    ctx->sweep_used = false;
     if (ctx->profile) {
         // time during which SOME update launch ran: the launches of the main stream are serial, a lookahead head on the
         // side stream may overlap the bulk update that follows it -- union of the intervals, not their sum
@@ -865,6 +873,34 @@ int solve_plain(Ctx* ctx, double* v, bool forward_done, int nrhs = 1, int64_t vs
     if (!forward_done) {
         for (int64_t p = 0; p < g.npanels; ++p) { int rc = fwd_panel(ctx, p, v, nullptr, nrhs, vstride); if (rc) return rc; }
         for (int64_t p = 0; p < g.npanels; ++p) { int rc = diag_panel(ctx, p, v, nullptr, nrhs, vstride); if (rc) return rc; }
+    }
+    if (ctx->sweep_persist && nrhs == 1 && g.world == 1 && g.nb <= 4 * TB && g.nb % TB == 0 && g.npanels >= 2 &&
+        g.npanels <= 4096 && g.Npad % 8 == 0) {
+        // the whole backward sweep in one launch (k_bwd_sweep): workgroup 0 on the diagonal blocks, every other wave on its columns
+        if (ctx->sweep_buf_n < g.Npad) {
+            if (ctx->sweep_buf) { PYIPM_HIP(hipStreamSynchronize(ctx->stream)); PYIPM_HIP(hipFree(ctx->sweep_buf)); ctx->sweep_buf = nullptr; }
+            PYIPM_HIP(hipMalloc((void**)&ctx->sweep_buf, (size_t)g.Npad * sizeof(double)));
+            ctx->sweep_buf_n = g.Npad;
+        }
+        if (!ctx->sweep_sync) {
+            PYIPM_HIP(hipMalloc((void**)&ctx->sweep_sync, (3 * 4096 + 1) * sizeof(unsigned)));
+            PYIPM_HIP(hipMemsetAsync(ctx->sweep_sync + 3 * 4096, 0, sizeof(unsigned), ctx->stream));      // the error word: sticky
+        }
+        const int P = (int)g.npanels;
+        PYIPM_HIP(hipMemsetAsync(ctx->sweep_sync, 0, (size_t)(2 * P + 1024) * sizeof(unsigned), ctx->stream));
+        PYIPM_HIP(hipMemsetAsync(ctx->sweep_buf, 0xFF, (size_t)g.Npad * sizeof(double), ctx->stream));      // NaN: "not there yet"
+        SweepGeo sg;
+        sg.Npad = g.Npad; sg.ld = g.Npad; sg.n = g.n; sg.mi = g.mi; sg.me = g.me; sg.nb = g.nb; sg.npanels = P;
+        sg.skip = (ctx->skip_zeros && g.mi > 0) ? 1 : 0;
+        const int64_t groups = g.Npad / 8;
+        int64_t blocks = 1 + (groups + 15) / 16;
+        if (blocks > ctx->num_cus) blocks = ctx->num_cus;
+        if (blocks < 2) blocks = 2;
+        hipLaunchKernelGGL(k_bwd_sweep, dim3((unsigned)blocks), dim3(1024), 0, ctx->stream, ctx->A, sg, v, ctx->sweep_sync,
+                           ctx->sweep_sync + 3 * 4096, (unsigned long long)2.0e8, ctx->sweep_buf);                       // polls give up after 2 s (100 MHz clock)
+        PYIPM_KCHECK();
+        ctx->sweep_used = true;
+        return 0;
     }
     for (int64_t p = g.npanels - 1; p >= 0; --p) { int rc = bwd_panel(ctx, p, v, nrhs, vstride, part, pstride); if (rc) return rc; }
     return 0;
@@ -1594,6 +1630,8 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     if (ctx->Jx) hipFree(ctx->Jx);
     if (ctx->cond_pos) hipFree(ctx->cond_pos);
     if (ctx->head_counters) hipFree(ctx->head_counters);
+    if (ctx->sweep_sync) hipFree(ctx->sweep_sync);
+    if (ctx->sweep_buf) hipFree(ctx->sweep_buf);
     if (ctx->own_ws && ctx->ws) hipFree(ctx->ws);
     delete ctx;
     return PYIPM_OK;
@@ -2198,6 +2236,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "head_serial")) { ctx->head_serial = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "wide_sub")) { ctx->wide_sub = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "sweep_persist")) { ctx->sweep_persist = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "early_head")) { ctx->early_head = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows_dist")) { ctx->head32_rows_dist = (int64_t)value; return PYIPM_OK; }

@@ -147,6 +147,7 @@ def test_wide_panels_match_the_group_schedule_bitwise(shape):
         core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
         core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
         core.set_option("wide_sub", wide_sub)
+        core.set_option("sweep_persist", 0)          # (the per-panel sweeps on both sides: the one-launch backward sweep sums in another order)
         dz, st = (core.step_dist(0.0, 0.0) if per_panel else core.step(0.0, 0.0))
         dz = dz.clone()
         core.close()

@@ -183,6 +183,7 @@ def test_backward_sweep_kernels_agree():
     out = []
     for d4 in (0, 1):
         core = NewtonCore(n, me, mi, device=0)
+        core.set_option("sweep_persist", 0)              # (the per-panel launches: the one-launch sweep has its own test below)
         core.set_option("bwd_diag4", d4)
         core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
         core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
@@ -193,6 +194,77 @@ def test_backward_sweep_kernels_agree():
         core.close()
     assert float((out[0][0] - out[1][0]).norm() / out[0][0].norm()) <= 1e-13
     assert out[0][1] <= 1e-12 and out[1][1] <= 1e-12
+
+
+@pytest.mark.parametrize("shape,nb", [((1500, 300, 500, 11), 256), ((1000, 300, 900, 2), 256), ((2048, 0, 2048, 3), 256),
+                                      ((3000, 1000, 0, 7), 128), ((700, 0, 0, 5), 128), ((900, 100, 650, 6), 128),
+                                      ((3072, 768, 1152, 0), 256), ((130, 20, 30, 8), 256)])
+def test_one_launch_backward_sweep_matches_the_per_panel_launches(shape, nb):
+    """k_bwd_sweep (the whole backward substitution as one device-driven launch: workgroup 0 on the diagonal blocks, every
+    other wave on its columns, flags and values handed over through agent-scope atomics) against the per-panel launches:
+    equal to rounding, the same bits every time it runs (fixed ownership, fixed summation order), and it solves the system.
+    Shapes: ragged last panels, no constraints, panels inside the slack block, a matrix of one panel (falls back)."""
+    import torch
+    from pyipm_amd.newton import NewtonCore
+    from pyipm_amd.problems import make_qp
+    n, me, mi, seed = shape
+    qp = make_qp(n, me, mi, seed)
+    core = NewtonCore(n, me, mi, device=0, nb=nb)
+    core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    core.set_option("sweep_persist", 0)
+    ref, st0 = core.step(0.0, 0.0)
+    ref = ref.clone()
+    core.set_option("sweep_persist", 1)
+    runs = []
+    for _ in range(5):
+        dz, st = core.step(0.0, 0.0)
+        runs.append(dz.clone())
+        assert st == st0
+    assert all(torch.equal(runs[0], r) for r in runs[1:])
+    assert float((runs[0] - ref).norm() / ref.norm()) <= 1e-13
+    g = core.residual()
+    raw = core.solve(flip=False)
+    assert float((core.matvec(raw) - g).norm() / g.norm()) <= 1e-12
+    # refinement runs the sweep several times per solve; a right-hand side of its own
+    rhs = torch.randn(core.N, dtype=torch.float64, device="cuda")
+    x1 = core.solve(rhs, flip=False, refine=1)
+    core.set_option("sweep_persist", 0)
+    x0 = core.solve(rhs, flip=False, refine=1)
+    assert float((x1 - x0).norm() / x0.norm()) <= 1e-12
+    core.close()
+
+
+def test_one_launch_backward_sweep_with_nan_does_not_wait():
+    """The workgroups of k_bwd_sweep recognise a value that has arrived by its not being NaN; a right-hand side that IS NaN
+    must come back as NaN at once (the counts say the values are there), not after the 2 s poll timeout, and must not
+    leave the handle in an error state."""
+    import time
+    import torch
+    from pyipm_amd.newton import NewtonCore
+    from pyipm_amd.problems import make_qp
+    n, me, mi = 1500, 300, 500
+    qp = make_qp(n, me, mi, 11)
+    core = NewtonCore(n, me, mi, device=0)
+    core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    dz, st = core.step(0.0, 0.0)
+    good = dz.clone()
+    rhs = torch.full((core.N,), float("nan"), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x = core.solve(rhs, flip=False)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 1.0
+    assert bool(torch.isnan(x).all())
+    rhs2 = torch.randn(core.N, dtype=torch.float64, device="cuda")
+    rhs2[core.N // 2] = float("nan")                      # one NaN in the middle: everything it reaches is NaN, nothing hangs
+    x = core.solve(rhs2, flip=False)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(x).any())
+    dz2, st2 = core.step(0.0, 0.0)                       # factor_end would report a timed-out poll of an earlier sweep
+    assert torch.equal(dz2, good) and st2 == st
+    core.close()
 
 
 def test_random_schedule_options_give_the_same_bits():

@@ -18,6 +18,7 @@ for (n, me, mi) in ((4096, 1024, 1536), (3000, 700, 1100), (2048, 0, 0)):
         core = NewtonCore(n, me, mi, device=0, nb=nb)
         core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"]); core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
         core.set_option("wide_sub", wide_sub)
+        core.set_option("sweep_persist", 0)          # (the per-panel sweeps on both sides: the one-launch backward sweep sums in another order)
         if use_dist:
             drv = DistNewton(core, native=True)
             dz, st = drv.step(0.0, 0.0, refine=0)
