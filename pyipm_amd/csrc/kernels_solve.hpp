@@ -270,7 +270,11 @@ __global__ __launch_bounds__(1024) void k_bwd_diag4(const double* __restrict__ A
 // A flag hand-off between workgroups costs 0.6 us when nothing is fenced (tools/ubench/pingpong.hip; 2.7 us with
 // __threadfence on both sides: buffer_wbl2 / buffer_inv), so every value that crosses workgroups inside this kernel (x, y,
 // flags, counters) is read and written with relaxed agent-scope atomics -- they bypass the non-coherent cache levels -- and
-// ordered by s_waitcnt alone.  Ownership is static and every sum has a fixed order: deterministic.  Every poll carries a
+// ordered by s_waitcnt alone.  Per panel workgroup 0 spends (tools/sweep_clock.py, N = 6144): 2.8 us in the recursion of the
+// diagonal block (LDS-bound: 32 ds_read per thread and step; from the registers with __shfl_xor folds it took 4.4 us -- 84
+// ds_bpermute), 0.5 us publishing x, and 3.7 us until the near sums are back (flag seen, x loaded, 8 columns folded, sum
+// stored, seen): 6.9 us a panel where two dependent launches took 10-16.  Polling the VALUES of x instead of the flag saved
+// nothing on 32 waves and cost bandwidth on 4080.  Ownership is static and every sum has a fixed order: deterministic.  Every poll carries a
 // timeout (a workgroup that is not resident would otherwise hang the GPU): on expiry *err is set, the sweep ends and
 // the vector is poisoned with NaN.
 struct SweepGeo {
@@ -300,7 +304,8 @@ __device__ __forceinline__ bool sweep_wait(const unsigned* p, unsigned want, uns
 
 __global__ __launch_bounds__(1024) void k_bwd_sweep(const double* __restrict__ A, SweepGeo sg, double* v, unsigned* sync,
                                                     unsigned* err, unsigned long long timeout,
-                                                    double* nearbuf)                    // Npad doubles, filled with NaN before the launch
+                                                    double* nearbuf,                    // Npad doubles, filled with NaN before the launch
+                                                    unsigned long long* dbg)            // diagnostics (NULL normally): workgroup 0's phases, tools/sweep_clock.py
 {
     __shared__ double Ls[3][TB][TB + 1];
     __shared__ double x[4 * TB], ps[4][4 * TB];
@@ -331,6 +336,7 @@ __global__ __launch_bounds__(1024) void k_bwd_sweep(const double* __restrict__ A
                             lt[idx][r] = (u < nt) ? A[(c0 + (int64_t)u * TB + (e & 63)) + (c0 + t * TB + (e >> 6)) * sg.ld] : 0.0;
                         }
             }
+            if (dbg && tid == 0) dbg[4 * s + 0] = wall_clock64();
             if (tid < nbw) {
                 // y_s with every contribution but the one of panel s + 1, which arrives as values, not as a count: a column's
                 // entry of nearbuf turns from NaN into its sum (one round trip instead of counter + load; should the sum BE
@@ -351,6 +357,7 @@ __global__ __launch_bounds__(1024) void k_bwd_sweep(const double* __restrict__ A
             }
             __syncthreads();
             if (!ok_s) break;
+            if (dbg && tid == 0) dbg[4 * s + 1] = wall_clock64();
             #pragma unroll
             for (int u = 3; u >= 1; --u) {
                 if (u < nt) {
@@ -374,9 +381,11 @@ __global__ __launch_bounds__(1024) void k_bwd_sweep(const double* __restrict__ A
                 }
             }
             __syncthreads();
+            if (dbg && tid == 0) dbg[4 * s + 2] = wall_clock64();
             if (tid < nbw) st_agent(v + c0 + tid, x[tid]);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if (dbg && tid == 0) dbg[4 * s + 3] = wall_clock64();
             if (tid == 0) __hip_atomic_store(flag + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // for the NEXT panel (s - 1): every column owner has finished step s + 1 -- thread b polls workgroup b's progress
             // word (one counter per step took 4080 atomics on one address: 27 us a step).  Normally long done, and polled

@@ -897,7 +897,7 @@ int solve_plain(Ctx* ctx, double* v, bool forward_done, int nrhs = 1, int64_t vs
         if (blocks > ctx->num_cus) blocks = ctx->num_cus;
         if (blocks < 2) blocks = 2;
         hipLaunchKernelGGL(k_bwd_sweep, dim3((unsigned)blocks), dim3(1024), 0, ctx->stream, ctx->A, sg, v, ctx->sweep_sync,
-                           ctx->sweep_sync + 3 * 4096, (unsigned long long)2.0e8, ctx->sweep_buf);                       // polls give up after 2 s (100 MHz clock)
+                           ctx->sweep_sync + 3 * 4096, (unsigned long long)2.0e8, ctx->sweep_buf, ctx->dbg_buf);                       // polls give up after 2 s (100 MHz clock)
         PYIPM_KCHECK();
         ctx->sweep_used = true;
         return 0;
