@@ -7,12 +7,15 @@ $B --nvar 2048 --neq 0 --nineq 2048 --steps 20 --warmup 3 > gpurun_out/cfg2_full
 $B --nvar 2048 --neq 0 --nineq 2048 --steps 20 --warmup 3 --opt condensed=1 > gpurun_out/cfg2_cond.json 2> gpurun_out/cfg2_cond.err
 $B --nvar 16384 --neq 8192 --nineq 8192 --steps 3 --warmup 1 > gpurun_out/cfg3_full.json 2> gpurun_out/cfg3_full.err
 $B --nvar 16384 --neq 8192 --nineq 8192 --steps 3 --warmup 1 --opt condensed=1 > gpurun_out/cfg3_cond.json 2> gpurun_out/cfg3_cond.err
-$B --steps 3 --warmup 1 --force-dist > gpurun_out/metric_forcedist.json 2> gpurun_out/metric_forcedist.err
+$B --steps 3 --warmup 1 --force-dist --nb 1024 > gpurun_out/metric_forcedist.json 2> gpurun_out/metric_forcedist.err
+$B --steps 3 --warmup 1 --force-dist --nb 512 > gpurun_out/metric_forcedist_nb512.json 2> /dev/null
+$B --steps 3 --warmup 1 --force-dist --nb 256 > gpurun_out/metric_forcedist_nb256.json 2> /dev/null
+$B --steps 3 --warmup 1 --opt condensed=1 > gpurun_out/metric_condensed.json 2> /dev/null
 $B --nvar 65536 --neq 0 --nineq 32768 --steps 1 --warmup 1 > gpurun_out/cfg4_1gpu.json 2> gpurun_out/cfg4_1gpu.err
 $B --nvar 65536 --neq 0 --nineq 32768 --steps 1 --warmup 1 --opt condensed=1 > gpurun_out/cfg4_1gpu_cond.json 2> gpurun_out/cfg4_1gpu_cond.err
 python - <<'PY'
 import json, glob
-for f in sorted(glob.glob("gpurun_out/cfg*.json") + glob.glob("gpurun_out/metric_forcedist.json")):
+for f in sorted(glob.glob("gpurun_out/cfg*.json") + glob.glob("gpurun_out/metric_*.json")):
     try:
         d = json.load(open(f))
         print(f, "N=%d" % d["config"]["kkt_dim"], "%.4f steps/s" % d["value"], "%.2f ms" % d["ms_per_step"],

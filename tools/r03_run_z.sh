@@ -20,7 +20,7 @@ bash tools/pmc_update.sh $O/pmc > $O/pmc_update.log 2>&1
 python tools/pmc_summary.py $O/pmc $O/pmc_update.json 2 > $O/pmc_summary.txt 2>&1; head -12 $O/pmc_summary.txt
 bash tools/pmc_hbm.sh $O/pmc_hbm > $O/pmc_hbm.log 2>&1; tail -4 $O/pmc_hbm.log
 # the other BASELINE configurations: bench line, kernel stats, one counter pass each (FETCH / WRITE / MFMA busy)
-bash tools/measure_configs.sh > $O/configs.txt 2>&1; tail -9 $O/configs.txt; mkdir -p $O/cfg; cp gpurun_out/cfg*.json gpurun_out/metric_forcedist.json $O/cfg/ 2>/dev/null
+bash tools/measure_configs.sh > $O/configs.txt 2>&1; tail -9 $O/configs.txt; mkdir -p $O/cfg; cp gpurun_out/cfg*.json gpurun_out/metric_*.json $O/cfg/ 2>/dev/null
 cfgpmc() {   # name, bench args...
   name=$1; shift
   pass() { p=$1; ctrs=$2; shift 2
@@ -43,6 +43,9 @@ timeout 300 python tools/tile_clock.py 1 > $O/tile_clock_blocked.txt 2>&1; timeo
 timeout 300 python tools/tile_blocked_check.py > $O/tile_blocked_check.txt 2>&1
 ( timeout 300 python tools/contention_probe.py; timeout 300 python tools/contention_probe.py bulk_bn=256 ) > $O/contention_probe.txt 2>&1
 ( timeout 300 tools/ubench/contention 128 16384; timeout 300 tools/ubench/contention 256 16384 ) > $O/contention_ubench.txt 2>&1
+( timeout 300 python tools/sweep_clock.py; timeout 300 python tools/sweep_clock.py 16384 4096 6144 ) > $O/sweep_clock.txt 2>&1
+timeout 600 python tools/sweep_check.py > $O/sweep_check.txt 2>&1
+timeout 120 tools/ubench/pingpong > $O/pingpong.txt 2>&1
 timeout 600 python tools/qp_solve.py > $O/qp_solve_full.json 2> $O/qp_solve_full.err
 timeout 600 python tools/qp_solve.py --condensed > $O/qp_solve_condensed.json 2> $O/qp_solve_condensed.err
 timeout 600 python tools/bench_batched.py > $O/bench_batched.txt 2>&1
