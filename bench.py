@@ -57,14 +57,15 @@ def make_qp_device(n, me, mi, seed, device):
             "ci": G @ x - h, "s": s, "lam": torch.cat([lam_e, lam_i]), "mu": 0.2}
 
 
-def cpu_baseline(target_N=32768, eig_shape=(3072, 768, 1152), lu_shape=(6144, 1536, 2304), reps=3):
+def cpu_baseline(target_N=32768, eig_shape=(4096, 1024, 1536), lu_shape=(6144, 1536, 2304), reps=3):
     """The oracle (reference CPU path restated: NumPy assembly + scipy eigvalsh(H, I) + scipy LU solve + flip =
     pyipm.py:1717-1725) timed on this box's host cores on a bounded sample, MEDIAN OF `reps` RUNS of each leg:
       * BLAS thread count: swept (a dense LU at N = 6144 per candidate), the fastest is used for everything below --
         all cores is NOT the fastest on a 2-socket box (OpenBLAS oversubscribes: round 1's figure suffered from that);
-      * the whole step WITH the reference's eigvalsh inertia test at N = 6144, and the step without it at N = 12288: the
-        eigendecomposition is ~60 % of the reference's step at these sizes and too slow to run larger three times inside
-        a benchmark that has to finish in minutes (rounds 1-2 measured N = 8192 / 16384, once each);
+      * the reference's eigvalsh inertia test (one call of reghess) at N = 8192 and the rest of the step (assembly, LU
+        solve, flip) at N = 12288: the eigendecomposition is most of the reference's step and too slow to run larger
+        three times inside a benchmark that has to finish in minutes (N = 6144 would be faster still, but eigvalsh
+        grows faster than N^3 up to 8192 -- 3.4 s -> 14 s -- and the extrapolation would flatter the CPU by 1.7x);
       * N^3 extrapolation of each part from the size it was measured at to the metric's KKT dimension.
     A reported baseline, not the optimisation target.  If the first run of a leg takes more than 45 s the leg is not
     repeated (and `sample` says so)."""
@@ -103,40 +104,47 @@ def cpu_baseline(target_N=32768, eig_shape=(3072, 768, 1152), lu_shape=(6144, 15
     del Mx
     best = min(sweep, key=sweep.get) if limits is not None else ncpu
 
-    def timed(shape, regularise):
-        n_, me_, mi_ = shape
-        qp = make_qp(n_, me_, mi_, seed=0)
-        args = (qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], qp["mu"], n_, me_, mi_)
+    def median_of(fn):
         ts = []
         for _ in range(reps):
-            t0 = time.perf_counter(); orc.newton_step(*args, regularise=regularise); ts.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
             if ts[0] > 45.0:
                 break
         return float(np.median(ts)), ts
 
+    def problem(shape):
+        n_, me_, mi_ = shape
+        qp = make_qp(n_, me_, mi_, seed=0)
+        return qp, (qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], qp["mu"], n_, me_, mi_)
+
     with lim(limits=best):
         Ne = eig_shape[0] + 2 * eig_shape[2] + eig_shape[1]
         Nl = lu_shape[0] + 2 * lu_shape[2] + lu_shape[1]
-        t_e_full, r_full = timed(eig_shape, True)      # assembly + eigvalsh + LU at N = 6144
-        t_e_noeig, r_noeig = timed(eig_shape, False)   # the same without the eigvalsh
-        t_l_noeig, r_lu = timed(lu_shape, False)       # assembly + LU at N = 12288
-    t_eig = max(t_e_full - t_e_noeig, 0.0)
+        qe, _ = problem(eig_shape)
+        He = orc.kkt_matrix(qe["d2L"], qe["Je"], qe["Ji"], qe["s"], qe["lam"], *eig_shape)
+        t_eig, r_eig = median_of(lambda: orc.eigvalsh_ref(He))         # the inertia test of reghess, one call (pyipm.py:1379)
+        del He, qe
+        _, al = problem(lu_shape)
+        t_l_noeig, r_lu = median_of(lambda: orc.newton_step(*al, regularise=False))      # assembly + LU + flip
+        del al
     t_step = t_eig * (target_N / Ne) ** 3 + t_l_noeig * (target_N / Nl) ** 3
     t_step_noeig = t_l_noeig * (target_N / Nl) ** 3
-    nrep = min(len(r_full), len(r_lu))
+    nrep = min(len(r_eig), len(r_lu))
     return {"value": 1.0 / t_step, "unit": "steps/s", "cores": int(best), "kind": "port",
             "sample": ("oracle/newton_oracle.py = pyipm.py:1717-1725 on the host (NumPy assembly + scipy.linalg.eigvalsh(H, I) "
                        "+ scipy.linalg.solve(assume_a='gen') + flip), %d BLAS threads (fastest of a sweep over %s on a dense LU "
-                       "at N=6144: %s s) of %d host cores (%s; %s). %s: the full step at N=%d (n=%d,me=%d,mi=%d) "
-                       "%.2f s, of which eigvalsh %.2f s; the step without eigvalsh at N=%d (n=%d,me=%d,mi=%d) %.2f s. value = "
-                       "1 / (eigvalsh part x%.0f + rest x%.0f), each part N^3-extrapolated from the N it was measured at "
-                       "to N=%d" % (best, sorted(sweep), ", ".join("%.2f" % sweep[t] for t in sorted(sweep)), ncpu, cpu_model,
-                                    blas, ("Median of %d runs each" % nrep) if nrep > 1 else "Measured once each (first run above 45 s)",
-                                    Ne, eig_shape[0], eig_shape[1], eig_shape[2], t_e_full, t_eig, Nl, lu_shape[0],
-                                    lu_shape[1], lu_shape[2], t_l_noeig, (target_N / Ne) ** 3, (target_N / Nl) ** 3, target_N)),
-            "reps": nrep, "runs_s": {"full_step_N%d" % Ne: r_full, "no_eigvalsh_N%d" % Ne: r_noeig, "no_eigvalsh_N%d" % Nl: r_lu},
+                       "at N=6144: %s s) of %d host cores (%s; %s). %s: eigvalsh(H, I) -- the inertia test of reghess, one call -- "
+                       "at N=%d (n=%d,me=%d,mi=%d) %.2f s; the rest of the step (assembly + LU + flip) at N=%d (n=%d,me=%d,mi=%d) "
+                       "%.2f s. value = 1 / (eigvalsh x%.0f + rest x%.0f), each part N^3-extrapolated from the N it was measured at "
+                       "to N=%d (on the MI355X box's EPYC 9575F host eigvalsh took 3.4 s at N=6144 and 14-15 s at N=8192: it grows "
+                       "faster than N^3 while its tridiagonalisation leaves the caches, so the extrapolation flatters the CPU)"
+                       % (best, sorted(sweep), ", ".join("%.2f" % sweep[t] for t in sorted(sweep)), ncpu, cpu_model,
+                          blas, ("Median of %d runs each" % nrep) if nrep > 1 else "Measured once each (first run above 45 s)",
+                          Ne, eig_shape[0], eig_shape[1], eig_shape[2], t_eig, Nl, lu_shape[0],
+                          lu_shape[1], lu_shape[2], t_l_noeig, (target_N / Ne) ** 3, (target_N / Nl) ** 3, target_N)),
+            "reps": nrep, "runs_s": {"eigvalsh_N%d" % Ne: r_eig, "no_eigvalsh_N%d" % Nl: r_lu},
             "measured_N": Ne, "measured_N_without_eigvalsh": Nl, "threads_sweep_s": {str(k): v for k, v in sweep.items()},
-            "measured_s_per_step": t_e_full, "measured_s_eigvalsh": t_eig, "measured_s_per_step_no_eigvalsh_at_N%d" % Nl: t_l_noeig,
+            "measured_s_eigvalsh": t_eig, "measured_s_per_step_no_eigvalsh_at_N%d" % Nl: t_l_noeig,
             "value_no_eigvalsh": 1.0 / t_step_noeig}
 
 
