@@ -221,252 +221,17 @@ __global__ __launch_bounds__(256, 2) void k_tile_step(
                         st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg, /*from_stage=*/true, blocked != 0);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Tile steps [t0, t1) of a diagonal block in ONE launch (round 3, option "chain_persist").  k_tile_step needs one launch per
-// tile because block 0 of launch t reads what the other blocks of launch t - 1 wrote; the launch boundary and the global
-// round trips behind it are ~5 of the 22.5 us a tile takes, and beside a bulk update EVERY launch waits for a free slot
-// (section 4, lessons r3: 130 us instead of 33).  Here the roles are fixed for the whole launch and the hand-overs are
-// device flags, as in k_bwd_sweep:
-//   * workgroup 0 (critical): for t = t0 .. t1-1: stage t-1 on the 64 rows of tile t (its own product inv(T[t-1]) or the
-//     previous launch's), the inversion of tile t, inv[t] raised.  Before stage t-1 it needs row tile t as its OWNER left it
-//     (stages <= t-2 applied, -S of column tile t-1 saved): prog[t] >= t.
-//   * workgroup b >= 1 owns row tile r = t0 + b for the whole launch and applies the stages tp = max(t0-1, 0) .. min(t1-2,
-//     r-2) to it, all column tiles tp+1 .. r of the stage in turn (stage r-1 is the critical workgroup's): it waits for
-//     inv[tp] and for the -S rows of the row tiles between tp and r (prog[v] >= tp + 1), and raises prog[r] = tp + 2.
-//     (t0 = 0: it first saves -S of column tile 0, prog[r] = 1.)
-// The same device functions on the same operands in the same order as k_tile_step: the same bits.  Data crosses workgroups
-// through plain stores / loads bracketed by release / acquire fences (buffer_wbl2 / buffer_inv, ~1 us each: the 64 x 64
-// operands are too many for per-value atomics); flags are relaxed agent-scope atomics; every poll has a timeout (*err).
-__device__ __forceinline__ bool chain_wait(const unsigned* p, unsigned want, unsigned* err, unsigned long long timeout) {
-    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
-    const unsigned long long t0 = wall_clock64();
-    for (;;) {
-        if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return true;
-        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-        if ((unsigned long long)wall_clock64() - t0 > timeout) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return false; }
-        __builtin_amdgcn_s_sleep(2);
-    }
-}
-
-// (The arguments travel as ONE struct that every phase of the loop re-reads from the kernel-argument segment through a
-// pointer the compiler cannot see through: kept live in SGPRs across tile_invert_dev -- which needs a hundred of its own --
-// they spilled into VGPRs, 97 SGPRs and with them 153 VGPRs into scratch.)
-// tile_invert_dev behind a real call: inlined into the loop of k_tile_chain its per-lane constants (offsets, operand masks:
-// ~100 registers that depend on the lane only) were hoisted out of the loop and kept alive across the iterations -- 154
-// VGPRs spilled.  The scratch travels as an LDS pointer so that its accesses stay ds_ instructions.
-typedef __attribute__((address_space(3))) TileScratch* TileScratchLds;
-__device__ __attribute__((noinline)) void tile_invert_from_stage(
-    TileScratchLds smp, const double* A, int64_t ld, int64_t grow0, int64_t lcol0, double* Tinv, double* Tsave, double* Tflag,
-    double refine_cond, DevStats* st, int64_t Nreal, double pivtol_rel, const unsigned long long* anorm_bits, int64_t neg_from,
-    unsigned long long* dbg, int blocked)
-{
-    tile_invert_dev(*(TileScratch*)smp, A, ld, grow0, lcol0, Tinv, Tsave, Tflag, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from,
-                    dbg, /*from_stage=*/true, blocked != 0);
-}
-
-struct ChainArgs {
-    double* A; int64_t ld, c0, lc0; int nT, t0, t1, nref, blocked;
-    double* W; int64_t ldw; double* Dinv; double* Tsv; double* Tflag;
-    double refine_cond, pivtol_rel; DevStats* st; int64_t Nreal, neg_from;
-    const unsigned long long* anorm_bits; unsigned long long* dbg;
-    unsigned* sync; unsigned* err; unsigned long long timeout;
-};
-typedef const __attribute__((address_space(4))) ChainArgs* ChainArgsPtr;
-#define PYIPM_CHAIN_ARGS(a_)                                                                     \
-    ChainArgsPtr a_ = (ChainArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();                       \
-    asm volatile("" : "+s"(a_));
-
-__global__ __launch_bounds__(256, 2) void k_tile_chain(ChainArgs args_by_value)
-{
-    __shared__ TileScratch sm;
-    __shared__ int ok_s;
-    static_assert(sizeof(TileScratch) >= sizeof(double) * TB * (TB + 2), "X must fit into the tile scratch");
-    double (&X)[TB][TB + 2] = *reinterpret_cast<double (*)[TB][TB + 2]>(&sm);
-    __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int64_t TT = (int64_t)TB * TB;
-    (void)args_by_value;
-    // release: every thread's stores have reached L2, one thread writes the L2 back and raises the flag
-#define PYIPM_CHAIN_PUBLISH(ptr_, val_)                                                                         \
-    { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();                                          \
-      if (tid == 0) { __threadfence(); __hip_atomic_store((ptr_), (unsigned)(val_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } }
-    if (tid == 0) ok_s = 1;
-    __syncthreads();
-    int t0, t1, nT;
-    { PYIPM_CHAIN_ARGS(a) t0 = a->t0; t1 = a->t1; nT = a->nT; }
-    const int tp_first = t0 > 0 ? t0 - 1 : 0;                          // the first stage this launch applies
-    if (b == 0) {
-        for (int t = t0; t < t1; ++t) {
-            {
-            PYIPM_CHAIN_ARGS(a)
-            double* __restrict__ A = a->A; const int64_t ld = a->ld, c0 = a->c0, lc0 = a->lc0, ldw = a->ldw;
-            if (t == 0) {
-                // the first tile comes from global memory (what tile_invert_dev does without from_stage; one call site below)
-                double tmp[TB * TB / 256];
-                #pragma unroll
-                for (int q = 0; q < TB * TB / 256; ++q) {
-                    const int e = tid + 256 * q, ii = e & 63, jj = e >> 6;
-                    tmp[q] = (ii >= jj) ? A[(c0 + ii) + (lc0 + jj) * ld] : 0.0;
-                }
-                #pragma unroll
-                for (int q = 0; q < TB * TB / 256; ++q) {
-                    const int e = tid + 256 * q, ii = e & 63, jj = e >> 6;
-                    if (ii >= jj) sm.stage[ii][jj] = tmp[q];
-                }
-            } else {
-                const int tp = t - 1;
-                unsigned* prog = a->sync + nT;
-                if (t - 2 >= tp_first) {
-                    // the owner of row tile t applied stages <= t-2 in this launch (prog[t] >= t)
-                    if (tid == 0 && !chain_wait(prog + t, (unsigned)t, a->err, a->timeout)) ok_s = 0;
-                    __syncthreads();
-                    if (!ok_s) return;
-                    __threadfence();                                        // acquire: what that workgroup wrote
-                } else if (t0 == 0 && t == 1) {
-                    if (tid == 0 && !chain_wait(prog + 1, 1u, a->err, a->timeout)) ok_s = 0;      // -S of column tile 0 of row tile 1
-                    __syncthreads();
-                    if (!ok_s) return;
-                    __threadfence();
-                }
-                const int64_t i = c0 + (int64_t)t * TB + wave * 16 + l15;
-                int nref = a->nref;
-                if (nref > 0 && a->Tflag[tp] == 0.0) nref = 0;
-                PYIPM_STAGE_TILE(X, 1.0, a->Dinv + tp * TT)
-                double sb[16];
-                #pragma unroll
-                for (int ks = 0; ks < 16; ++ks) sb[ks] = -a->W[i + (int64_t)(tp * TB + ks * 4 + l4) * ldw];
-                __syncthreads();
-                double4_t acc[4];
-                strip_scale(X, a->Dinv + tp * TT, a->Tsv + tp * TT, nref, sb, tid, l15, l4, acc);
-                {
-                    double gmax = 0.0;
-                    #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt)
-                        #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            A[i + (lc0 + tp * TB + tt * 16 + l4 + 4 * r) * ld] = acc[tt][r];
-                            gmax = fmax(gmax, fabs(acc[tt][r]));
-                        }
-                    gmax = wave_max(gmax);
-                    if (lane == 0) atomicMax(&a->st->growth_bits, (unsigned long long)__double_as_longlong(gmax));
-                }
-                double4_t c2[4];
-                #pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
-                    #pragma unroll
-                    for (int r = 0; r < 4; ++r) c2[tt][r] = A[i + (lc0 + t * TB + tt * 16 + l4 + 4 * r) * ld];
-                __syncthreads();                                             // every wave is done with X (inv(T))
-                #pragma unroll
-                for (int ks = 0; ks < 16; ++ks) X[ks * 4 + l4][wave * 16 + l15] = -sb[ks];      // Wn[c][k] = -S[c][k], stored [k][c]
-                __syncthreads();
-                #pragma unroll
-                for (int ks = 0; ks < 16; ++ks) {
-                    const double lop = acc[ks >> 2][ks & 3];
-                    #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt)
-                        c2[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(X[ks * 4 + l4][16 * tt + l15], lop, c2[tt], 0, 0, 0);
-                }
-                __syncthreads();                                             // Wn read: the tile goes where it was
-                #pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
-                    #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int c = tt * 16 + l4 + 4 * r;
-                        A[i + (lc0 + t * TB + c) * ld] = c2[tt][r];
-                        sm.stage[wave * 16 + l15][c] = c2[tt][r];
-                    }
-            }
-            }
-            {
-            PYIPM_CHAIN_ARGS(a)
-            tile_invert_from_stage((TileScratchLds)&sm, a->A, a->ld, a->c0 + (int64_t)t * TB, a->lc0 + (int64_t)t * TB, a->Dinv + t * TT,
-                                   a->Tsv + t * TT, a->Tflag + t, a->refine_cond, a->st, a->Nreal, a->pivtol_rel, a->anorm_bits, a->neg_from,
-                                   a->dbg, a->blocked);
-            }
-            {
-            PYIPM_CHAIN_ARGS(a)
-            PYIPM_CHAIN_PUBLISH(a->sync + t, 1)
-            }
-            __syncthreads();
-        }
-        return;
-    }
-    // ---- the owner of row tile r ----
-    const int r = t0 + b;
-    if (r >= nT) return;
-    PYIPM_CHAIN_ARGS(a)
-    double* __restrict__ A = a->A; double* __restrict__ W = a->W;
-    const int64_t ld = a->ld, c0 = a->c0, lc0 = a->lc0, ldw = a->ldw;
-    unsigned* inv = a->sync; unsigned* prog = a->sync + nT;
-    // was the save of -S of column tile `col` (by any row owner) made inside this launch?
-    auto in_launch = [&](int col) { return t0 == 0 || col >= t0; };
-    const int64_t i = c0 + (int64_t)r * TB + wave * 16 + l15;            // this lane's (global) row
-    if (t0 == 0) {
-        double tmp[TB * TB / 256];
-        const int64_t r0 = c0 + (int64_t)r * TB;
-        #pragma unroll
-        for (int q = 0; q < TB * TB / 256; ++q) { const int e = tid + 256 * q; tmp[q] = A[(r0 + (e & 63)) + (lc0 + (e >> 6)) * ld]; }
-        #pragma unroll
-        for (int q = 0; q < TB * TB / 256; ++q) { const int e = tid + 256 * q; W[(r0 + (e & 63)) + (int64_t)(e >> 6) * ldw] = -tmp[q]; }
-        PYIPM_CHAIN_PUBLISH(prog + r, 1)
-    }
-    int tp_last = t1 - 2; if (tp_last > r - 2) tp_last = r - 2;
-    for (int tp = tp_first; tp <= tp_last; ++tp) {
-        const int t = tp + 1;
-        // inv(T[tp]) (this launch's, if tp >= t0) and the -S rows of the row tiles between the stage and this one
-        {
-            bool ok = true;
-            if (tid == 0 && tp >= t0) ok = chain_wait(inv + tp, 1u, a->err, a->timeout);
-            if (in_launch(tp) && tid >= 1 && tid < r - tp && tid < 64) ok = chain_wait(prog + tp + tid, (unsigned)(tp + 1), a->err, a->timeout);   // v = tp + tid in [tp+1, r-1]
-            if (!ok) ok_s = 0;
-        }
-        __syncthreads();
-        if (!ok_s) return;
-        __threadfence();                                                     // acquire
-        int nref = a->nref;
-        if (nref > 0 && a->Tflag[tp] == 0.0) nref = 0;
-        PYIPM_STAGE_TILE(X, 1.0, a->Dinv + tp * TT)
-        double sb[16];
-        #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) sb[ks] = -W[i + (int64_t)(tp * TB + ks * 4 + l4) * ldw];
-        __syncthreads();
-        double4_t acc[4];
-        strip_scale(X, a->Dinv + tp * TT, a->Tsv + tp * TT, nref, sb, tid, l15, l4, acc);
-        {
-            double gmax = 0.0;
-            #pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-                #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    A[i + (lc0 + tp * TB + tt * 16 + l4 + 4 * rr) * ld] = acc[tt][rr];
-                    gmax = fmax(gmax, fabs(acc[tt][rr]));
-                }
-            gmax = wave_max(gmax);
-            if (lane == 0) atomicMax(&a->st->growth_bits, (unsigned long long)__double_as_longlong(gmax));
-        }
-        for (int v = t; v <= r; ++v) {
-            double4_t c2[4];
-            #pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-                #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) c2[tt][rr] = A[i + (lc0 + v * TB + tt * 16 + l4 + 4 * rr) * ld];
-            strip_update(c2, acc, W + (c0 + (int64_t)v * TB) + (int64_t)(tp * TB) * ldw, ldw, l15, l4);
-            #pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-                #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int c = tt * 16 + l4 + 4 * rr;
-                    A[i + (lc0 + v * TB + c) * ld] = c2[tt][rr];
-                    if (v == t) W[i + (int64_t)(t * TB + c) * ldw] = -c2[tt][rr];
-                }
-        }
-        PYIPM_CHAIN_PUBLISH(prog + r, tp + 2)
-        __syncthreads();
-    }
-#undef PYIPM_CHAIN_PUBLISH
-}
+// (Round 3 built the tile steps of a sub-panel as ONE launch -- k_tile_chain, in the history at commit 435e38f: a
+// critical workgroup inverting tile after tile, one static owner workgroup per row tile applying the stages, release /
+// acquire fences and flags in between, the same device functions in the same order: the SAME BITS as this schedule on
+// every shape tried.  It was slower, 27 us a tile against 22.5 and 3.6 against 2.8 ms at N = 6144, for three measured
+// reasons (tools/chain_clock.py at the time): every acquire is a buffer_inv that empties the XCD's L2 for all sixteen
+// workgroups on it (the stage in front of an inversion took 8.7 us instead of 6.7); inlined into a loop, the inversion's
+// ~100 lane-constant registers were hoisted and 154 VGPRs spilled, behind a real call it ran 16.5 instead of 12.5 us; and
+// a far row tile has up to fifteen column tiles to update per stage, alone in its workgroup, so every launch ended
+// 35-130 us after its last inversion.  What it would take: operands read with per-access coherent loads instead of
+// fences, the far rows split over several workgroups as k_tile_step's grid.y does, the inversion's constants recomputed
+// per call.  Removed)
 
 // The rows below the diagonal block, 64 per block: all nt stages of the strip in one launch, right-looking.  The column
 // tile a stage scales is the last one the stage before it updated and stays in registers in between; the other column

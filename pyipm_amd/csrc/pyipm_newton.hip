@@ -504,26 +504,10 @@ int ensure_rest_stream(Ctx* ctx) {
 // follow on ctx->rest, sub-panel by sub-panel: all stages of the sub-panel (k_panel_rest), then its contribution to the
 // later sub-panels of the block (right-looking: the pending update, one source at a time -- the same products in the same
 // order).  on_done(id, stream): sub-panel `id` is complete once `stream` reaches this point.
-// Tile steps [ta, tb) of a diagonal block of nT tiles on `chain`: one k_tile_step launch per tile, or (chain_persist) ONE
-// k_tile_chain launch with device flags between its workgroups -- the same bits.
+// Tile steps [ta, tb) of a diagonal block of nT tiles on `chain`: one k_tile_step launch per tile.
 int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, int nT, int ta, int tb, double* Wg, double* Dv, double* Ts) {
     const Geo& g = ctx->g;
     if (tb <= ta) return 0;
-    if (ctx->chain_persist && tb - ta >= 2 && nT <= 64 && ctx->chain_sync &&
-        ctx->chain_sync_off + 2 * (size_t)nT <= ctx->chain_sync_words) {
-        unsigned* sync = ctx->chain_sync + ctx->chain_sync_off;
-        ctx->chain_sync_off += 2 * (size_t)nT;
-        ChainArgs ca;
-        ca.A = ctx->A; ca.ld = g.Npad; ca.c0 = gc0; ca.lc0 = glc0; ca.nT = nT; ca.t0 = ta; ca.t1 = tb; ca.nref = ctx->block_refine;
-        ca.blocked = ctx->tile_blocked; ca.W = Wg; ca.ldw = g.Npad; ca.Dinv = Dv; ca.Tsv = Ts; ca.Tflag = ctx->Tflag + gc0 / TB;
-        ca.refine_cond = ctx->refine_cond; ca.pivtol_rel = ctx->pivtol_rel; ca.st = ctx->dstats; ca.Nreal = g.N; ca.neg_from = g.n + g.mi;
-        ca.anorm_bits = ctx->anorm; ca.dbg = ctx->dbg_buf; ca.sync = sync; ca.err = ctx->chain_sync + ctx->chain_sync_words;
-        ca.timeout = (unsigned long long)2.0e8;                          // polls give up after 2 s (100 MHz clock)
-        hipLaunchKernelGGL(k_tile_chain, dim3((unsigned)(nT - ta)), dim3(256), 0, chain, ca);
-        PYIPM_KCHECK();
-        ctx->chain_used = true;
-        return 0;
-    }
     for (int j = ta; j < tb; ++j) {
         int ny = (nT - j + 4) / 5; if (ny < 1) ny = 1; if (ny > 4) ny = 4;     // <= ~5 column tiles per block
         hipLaunchKernelGGL(k_tile_step, dim3((unsigned)(nT - j), (unsigned)ny), dim3(256), 0, chain, ctx->A, g.Npad, gc0, glc0, j,
@@ -766,15 +750,6 @@ int factor_begin(Ctx* ctx) {
     PYIPM_HIP(hipMemsetAsync(ctx->head_counters, 0, (ctx->n_head_counters + 1) * sizeof(unsigned), ctx->stream));
     PYIPM_HIP(hipStreamSynchronize(ctx->stream));   // &z is a stack temporary
     ctx->n_trailing = 0; ctx->trailing_flops = 0.0; ctx->trailing_area = 0.0;
-    if (ctx->chain_persist) {                       // k_tile_chain: a fresh (zeroed) slice of flags per launch + the sticky error word
-        if (!ctx->chain_sync) {
-            ctx->chain_sync_words = (size_t)1 << 18;
-            PYIPM_HIP(hipMalloc((void**)&ctx->chain_sync, (ctx->chain_sync_words + 1) * sizeof(unsigned)));
-            PYIPM_HIP(hipMemsetAsync(ctx->chain_sync + ctx->chain_sync_words, 0, sizeof(unsigned), ctx->stream));
-        }
-        PYIPM_HIP(hipMemsetAsync(ctx->chain_sync, 0, ctx->chain_sync_words * sizeof(unsigned), ctx->stream));
-        ctx->chain_sync_off = 0;
-    }
     return 0;
 }
 
@@ -784,19 +759,11 @@ int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
     PYIPM_HIP(hipMemcpyAsync(&z, ctx->dstats, sizeof(z), hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->head_counters)
         PYIPM_HIP(hipMemcpyAsync(&wait_err, ctx->head_counters + ctx->n_head_counters, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    int chain_err = 0;
-    if (ctx->chain_used && ctx->chain_sync)
-        PYIPM_HIP(hipMemcpyAsync(&chain_err, ctx->chain_sync + ctx->chain_sync_words, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     int sweep_err = 0;
     if (ctx->sweep_used && ctx->sweep_sync)
         PYIPM_HIP(hipMemcpyAsync(&sweep_err, ctx->sweep_sync + 3 * 4096, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PYIPM_HIP(hipStreamSynchronize(ctx->stream));
     if (wait_err) { ctx->err = "fused head: the next group's chain gave up waiting for the bulk update's head tiles"; return PYIPM_E_HIP; }
-    if (chain_err) {
-        PYIPM_HIP(hipMemsetAsync(ctx->chain_sync + ctx->chain_sync_words, 0, sizeof(unsigned), ctx->stream));
-        ctx->err = "tile chain (k_tile_chain): a poll between its workgroups timed out"; return PYIPM_E_HIP;
-    }
-    ctx->chain_used = false;
     if (sweep_err) {
         PYIPM_HIP(hipMemsetAsync(ctx->sweep_sync + 3 * 4096, 0, sizeof(unsigned), ctx->stream));
         ctx->err = "backward sweep (k_bwd_sweep): a poll timed out in an earlier solve; its result was NaN"; return PYIPM_E_HIP;
@@ -1672,7 +1639,6 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     if (ctx->cond_pos) hipFree(ctx->cond_pos);
     if (ctx->head_counters) hipFree(ctx->head_counters);
     if (ctx->sweep_sync) hipFree(ctx->sweep_sync);
-    if (ctx->chain_sync) hipFree(ctx->chain_sync);
     if (ctx->sweep_buf) hipFree(ctx->sweep_buf);
     if (ctx->own_ws && ctx->ws) hipFree(ctx->ws);
     delete ctx;
@@ -2279,7 +2245,6 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "wide_sub")) { ctx->wide_sub = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "sweep_persist")) { ctx->sweep_persist = (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "chain_persist")) { ctx->chain_persist = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "early_head")) { ctx->early_head = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows_dist")) { ctx->head32_rows_dist = (int64_t)value; return PYIPM_OK; }
