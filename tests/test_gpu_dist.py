@@ -337,14 +337,16 @@ def test_bench_self_launches_for_several_gpus():
     multi = torch.cuda.device_count() >= 2
     if not multi:
         env["PYIPM_BENCH_SHARE_GPU"] = "1"
+    # (no --nb: the multi-GPU default, 1024 -- five panels here, the last one 640 wide, each factored as a block of sub-panels)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--nvar", "1536", "--neq", "256", "--nineq", "640", "--nb", "256", "--no-cpu-baseline"]
+           "--nvar", "2560", "--neq", "384", "--nineq", "896", "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["backward_error"] <= 1e-12
+    assert d["n_gpus"] == 2 and d["backward_error"] <= 1e-12 and d["config"]["nb"] == 1024
+    assert d["inertia"]["n_neg"] == 384 + 896 and d["inertia"]["n_zero"] == 0
     assert d["rccl_ranks"] == (2 if multi else 0)
 
 
