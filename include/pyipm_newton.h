@@ -337,11 +337,13 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *   sub-panel: at nb = 512 / 1024 the launches, and the bits, of the single-rank schedule at nb = 256; 0 = all stages
  *   of a panel in one launch) -- all of these choose between implementations that accumulate the same
  *   products in the same order: the results are bit-identical (tests/test_gpu_symmetric.py);
- *   "sweep_persist" 0|1 (default 1; single rank, one right-hand side, nb <= 256): the backward substitution as ONE
+ *   "sweep_persist" 0|1 (default 1; single rank, one right-hand side, nb <= 256): each substitution sweep as ONE
  *   device-driven launch (k_bwd_sweep: workgroup 0 resolves the diagonal blocks, every other wave subtracts its columns'
- *   share as soon as a panel's x is published; flags and values cross workgroups through agent-scope atomics, every poll
+ *   share as soon as a panel's x is published; k_fwd_sweep, its mirror with 64-row chunks, for the forward pass of a solve
+ *   that is not fused under a factorisation; flags and values cross workgroups through agent-scope atomics, every poll
  *   has a 2 s timeout that poisons the result with NaN and is reported by the next factorisation) instead of two dependent
  *   launches per panel -- equal to rounding, not to the bit (another summation order), deterministic;
+ *   "sweep_max_blocks" (test hook: cap on their workgroups);
  *   "tile_blocked" 0|1 (default 1; batched handles 0): the 64 x 64 tile inversion 16 pivots at a time (in-register LDL' of the
  *   micro-block + fp64 MFMA block sweeps, Bunch-Kaufman verified afterwards, fallback to the single sweeps: DESIGN.md
  *   section 3) -- same pivots and inertia, a different order of rounding than the single sweeps (not bit-identical). */

@@ -132,6 +132,7 @@ struct Ctx {
     bool per_panel_mode = false;          // the per-panel phases (pyipm_newton_factor_begin ...) drive this factorisation
     int64_t head32_rows_dist = 16384;     // per-panel (multi-GPU) schedule: single-panel launches (the owner's head update of the
                                           // next panel, always on the critical path there) while at most this many rows remain
+    int sweep_max_blocks = 0;             // test hook: cap on the workgroups of the one-launch sweeps (0 = as many as the GPU holds)
     int sweep_persist = 1;                // single rank, one right-hand side: the backward sweep as ONE device-driven launch (k_bwd_sweep)
     int64_t sweep_buf_n = 0;              // ... (allocated for this many rows)
     double* sweep_buf = nullptr;          // ... the near sums as the column owners hand them to workgroup 0 (Npad doubles, NaN = not there yet)

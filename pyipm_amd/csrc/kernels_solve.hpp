@@ -493,6 +493,137 @@ __global__ __launch_bounds__(1024) void k_bwd_sweep(const double* __restrict__ A
     publish((unsigned)P);
 }
 
+// ---------------------------------------------------------------------------------------------
+// The forward sweep in one launch (the mirror of k_bwd_sweep; refined solves and right-hand sides of their own run it --
+// the forward pass of a plain step trails the factorisation panel by panel instead).  Workgroup 0 walks the panels first to
+// last: for panel s it waits until the four row chunks of the panel have every earlier panel's contribution (a progress word
+// per chunk), resolves the panel's diagonal block (y_u -= sum_{t<u} L[u,t] y_t, a lane per row: no transposition, the 16
+// waves' partial sums meet in shared memory) and raises flag[s].  Every other workgroup owns 64-row chunks of the vector for
+// the whole launch: wave q of its eight takes an eighth of the panel's columns (32 loads of 512 contiguous bytes per lane,
+// issued before the flag is polled), the eight partial sums are added in a fixed order and subtracted from the chunk.
+// 512 threads per workgroup, two per CU.  Same hand-over rules as k_bwd_sweep: relaxed agent-scope atomics for everything
+// that crosses workgroups inside the launch, s_waitcnt for order, a timeout on every poll.
+__global__ __launch_bounds__(512, 4) void k_fwd_sweep(const double* __restrict__ A, SweepGeo sg, double* v, unsigned* sync,
+                                                      unsigned* err, unsigned long long timeout)
+{
+    __shared__ double xs[4 * TB];
+    __shared__ double ps[8][TB];
+    __shared__ int ok_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int P = sg.npanels, nb = sg.nb;
+    unsigned* flag = sync; unsigned* prog = sync + P;           // prog[c]: steps applied to the 64-row chunk c
+    const int cpp = nb / TB;                                    // chunks per panel
+    const int nchunks = (int)(sg.Npad / TB);
+    if (tid == 0) ok_s = 1;
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int s = 0; s < P; ++s) {
+            const int64_t c0 = (int64_t)s * nb;
+            int64_t w64 = sg.Npad - c0; if (w64 > nb) w64 = nb;
+            const int nbw = (int)w64, nt = nbw / TB;
+            // tiles (u, t), t < u <= 3: element e = tid + 512 r is row e & 63 = lane, column e >> 6 = wave + 8 r
+            double lt[6][8];
+            {
+                int idx = 0;
+                #pragma unroll
+                for (int u = 1; u <= 3; ++u)
+                    #pragma unroll
+                    for (int t = 0; t < u; ++t, ++idx)
+                        #pragma unroll
+                        for (int r = 0; r < 8; ++r)
+                            lt[idx][r] = (u < nt) ? A[(c0 + (int64_t)u * TB + lane) + (c0 + t * TB + wave + 8 * r) * sg.ld] : 0.0;
+            }
+            if (s > 0 && tid < nt && !sweep_wait(prog + (int)(c0 / TB) + tid, (unsigned)s, err, timeout)) ok_s = 0;
+            __syncthreads();
+            if (!ok_s) break;
+            if (tid < nbw) xs[tid] = ld_agent(v + c0 + tid);
+            __syncthreads();
+            #pragma unroll
+            for (int u = 1; u <= 3; ++u) {
+                if (u < nt) {
+                    const int base = u * (u - 1) / 2;
+                    double acc = 0.0;
+                    #pragma unroll
+                    for (int t = 0; t < 3; ++t)
+                        if (t < u) {
+                            #pragma unroll
+                            for (int r = 0; r < 8; ++r) acc = fma(lt[base + t][r], xs[t * TB + wave + 8 * r], acc);
+                        }
+                    ps[wave][lane] = acc;
+                    __syncthreads();
+                    if (tid < TB) {
+                        double t8 = ((ps[0][tid] + ps[1][tid]) + (ps[2][tid] + ps[3][tid])) + ((ps[4][tid] + ps[5][tid]) + (ps[6][tid] + ps[7][tid]));
+                        xs[u * TB + tid] -= t8;
+                    }
+                    __syncthreads();
+                }
+            }
+            if (tid < nbw) st_agent(v + c0 + tid, xs[tid]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flag + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)
+            for (int64_t i = tid; i < sg.Npad; i += 512) st_agent(v + i, __builtin_nan(""));
+        return;
+    }
+    // ---- row owners: chunk c = cpp + (blockIdx - 1) + k (gridDim - 1) ----
+    const int nown = (int)gridDim.x - 1;
+    for (int s = 0; s + 1 < P; ++s) {
+        const int64_t c0 = (int64_t)s * nb;                     // (every panel but the last is nb wide)
+        const int cfirst = (s + 1) * cpp;                       // chunks below panel s
+        const int cbeg = cpp + ((int)blockIdx.x - 1);
+        // my first chunk below panel s
+        int c = cbeg;
+        if (c < cfirst) c += ((cfirst - c + nown - 1) / nown) * nown;
+        if (c >= nchunks) return;                               // nothing below this panel is mine, now or later
+        const int kc = nb / 8;                                  // columns per wave: 8, 16, 24 or 32
+        const int64_t jc0 = c0 + (int64_t)wave * kc;
+        bool have_y = false;
+        for (; c < nchunks; c += nown) {
+            const int64_t r0 = (int64_t)c * TB;
+            const bool act = sweep_active(sg, c0, c0 + nb, r0, r0 + TB);
+            double la[32];
+            if (act) {
+                #pragma unroll
+                for (int j = 0; j < 32; ++j) la[j] = (j < kc) ? A[(r0 + lane) + (jc0 + j) * sg.ld] : 0.0;
+            }
+            if (!have_y) {
+                // (all eight waves agree before anyone leaves: a wave returning alone would leave the others at the barrier)
+                if (!sweep_wait(flag + s, 1u, err, timeout)) ok_s = 0;
+                __syncthreads();
+                if (!ok_s) return;
+                asm volatile("" ::: "memory");
+                have_y = true;
+            }
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            if (act) {
+                // y_s: the wave's 32 entries, the same for every lane (scalar loads; first touch of these lines in the launch)
+                #pragma unroll
+                for (int j = 0; j < 32; j += 4) {
+                    const double y0 = (j < kc) ? v[jc0 + j] : 0.0, y1 = (j + 1 < kc) ? v[jc0 + j + 1] : 0.0;
+                    const double y2 = (j + 2 < kc) ? v[jc0 + j + 2] : 0.0, y3 = (j + 3 < kc) ? v[jc0 + j + 3] : 0.0;
+                    a0 = fma(la[j], y0, a0); a1 = fma(la[j + 1], y1, a1);
+                    a2 = fma(la[j + 2], y2, a2); a3 = fma(la[j + 3], y3, a3);
+                }
+            }
+            ps[wave][lane] = (a0 + a1) + (a2 + a3);
+            __syncthreads();
+            if (wave == 0) {
+                if (act) {
+                    const double t8 = ((ps[0][lane] + ps[1][lane]) + (ps[2][lane] + ps[3][lane])) + ((ps[4][lane] + ps[5][lane]) + (ps[6][lane] + ps[7][lane]));
+                    double* vp = v + r0 + lane;
+                    st_agent(vp, ld_agent(vp) - t8);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (lane == 0) __hip_atomic_store(prog + c, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // v[i] = b[i] on the rows of the panels this rank owns, 0 elsewhere: the ranks' vectors sum to b (distributed sweeps)
 __global__ __launch_bounds__(256) void k_mask_owned(double* __restrict__ v, const double* __restrict__ b, Geo g)
 {

@@ -878,13 +878,9 @@ int bwd_panel(Ctx* ctx, int64_t p, double* v, int nrhs = 1, int64_t vstride = 0,
 int solve_plain(Ctx* ctx, double* v, bool forward_done, int nrhs = 1, int64_t vstride = 0, double* part = nullptr,
                 int64_t pstride = 0) {
     const Geo& g = ctx->g;
-    if (!forward_done) {
-        for (int64_t p = 0; p < g.npanels; ++p) { int rc = fwd_panel(ctx, p, v, nullptr, nrhs, vstride); if (rc) return rc; }
-        for (int64_t p = 0; p < g.npanels; ++p) { int rc = diag_panel(ctx, p, v, nullptr, nrhs, vstride); if (rc) return rc; }
-    }
-    if (ctx->sweep_persist && nrhs == 1 && g.world == 1 && g.nb <= 4 * TB && g.nb % TB == 0 && g.npanels >= 2 &&
-        g.npanels <= 4096 && g.Npad % 8 == 0) {
-        // the whole backward sweep in one launch (k_bwd_sweep): workgroup 0 on the diagonal blocks, every other wave on its columns
+    const bool one_launch = ctx->sweep_persist && nrhs == 1 && g.world == 1 && g.nb <= 4 * TB && g.nb % TB == 0 && g.npanels >= 2 &&
+                            g.npanels <= 4096 && g.Npad % 8 == 0 && g.Npad / TB <= 8192;
+    if (one_launch) {
         if (ctx->sweep_buf_n < g.Npad) {
             if (ctx->sweep_buf) { PYIPM_HIP(hipStreamSynchronize(ctx->stream)); PYIPM_HIP(hipFree(ctx->sweep_buf)); ctx->sweep_buf = nullptr; }
             PYIPM_HIP(hipMalloc((void**)&ctx->sweep_buf, (size_t)g.Npad * sizeof(double)));
@@ -894,15 +890,39 @@ int solve_plain(Ctx* ctx, double* v, bool forward_done, int nrhs = 1, int64_t vs
             PYIPM_HIP(hipMalloc((void**)&ctx->sweep_sync, (3 * 4096 + 1) * sizeof(unsigned)));
             PYIPM_HIP(hipMemsetAsync(ctx->sweep_sync + 3 * 4096, 0, sizeof(unsigned), ctx->stream));      // the error word: sticky
         }
+    }
+    SweepGeo sg;
+    sg.Npad = g.Npad; sg.ld = g.Npad; sg.n = g.n; sg.mi = g.mi; sg.me = g.me; sg.nb = g.nb; sg.npanels = (int)g.npanels;
+    sg.skip = (ctx->skip_zeros && g.mi > 0) ? 1 : 0;
+    if (!forward_done && one_launch) {
+        // forward sweep in one launch (k_fwd_sweep: workgroup 0 on the diagonal blocks, the others on their 64-row chunks),
+        // then inv(T) y for all tiles at once
+        const int P = (int)g.npanels;
+        PYIPM_HIP(hipMemsetAsync(ctx->sweep_sync, 0, (size_t)(P + g.Npad / TB) * sizeof(unsigned), ctx->stream));
+        int64_t blocks = 1 + (g.Npad / TB - g.nb / TB);
+        if (blocks > 2 * (int64_t)ctx->num_cus) blocks = 2 * (int64_t)ctx->num_cus;
+        if (ctx->sweep_max_blocks > 0 && blocks > ctx->sweep_max_blocks) blocks = ctx->sweep_max_blocks;      // (test hook: several chunks per owner)
+        if (blocks < 2) blocks = 2;
+        hipLaunchKernelGGL(k_fwd_sweep, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, ctx->A, sg, v, ctx->sweep_sync,
+                           ctx->sweep_sync + 3 * 4096, (unsigned long long)2.0e8);
+        PYIPM_KCHECK();
+        hipLaunchKernelGGL(k_diag_apply, dim3((unsigned)(g.Npad / TB), 1), dim3(64), 0, ctx->stream, ctx->Dinv, ctx->Tsv, ctx->Tflag,
+                           ctx->block_refine, (int64_t)0, (int64_t)0, v, (int64_t)0);
+        PYIPM_KCHECK();
+        ctx->sweep_used = true;
+    } else if (!forward_done) {
+        for (int64_t p = 0; p < g.npanels; ++p) { int rc = fwd_panel(ctx, p, v, nullptr, nrhs, vstride); if (rc) return rc; }
+        for (int64_t p = 0; p < g.npanels; ++p) { int rc = diag_panel(ctx, p, v, nullptr, nrhs, vstride); if (rc) return rc; }
+    }
+    if (one_launch) {
+        // the whole backward sweep in one launch (k_bwd_sweep): workgroup 0 on the diagonal blocks, every other wave on its columns
         const int P = (int)g.npanels;
         PYIPM_HIP(hipMemsetAsync(ctx->sweep_sync, 0, (size_t)(2 * P + 1024) * sizeof(unsigned), ctx->stream));
         PYIPM_HIP(hipMemsetAsync(ctx->sweep_buf, 0xFF, (size_t)g.Npad * sizeof(double), ctx->stream));      // NaN: "not there yet"
-        SweepGeo sg;
-        sg.Npad = g.Npad; sg.ld = g.Npad; sg.n = g.n; sg.mi = g.mi; sg.me = g.me; sg.nb = g.nb; sg.npanels = P;
-        sg.skip = (ctx->skip_zeros && g.mi > 0) ? 1 : 0;
         const int64_t groups = g.Npad / 8;
         int64_t blocks = 1 + (groups + 15) / 16;
         if (blocks > ctx->num_cus) blocks = ctx->num_cus;
+        if (ctx->sweep_max_blocks > 0 && blocks > ctx->sweep_max_blocks) blocks = ctx->sweep_max_blocks;
         if (blocks < 2) blocks = 2;
         hipLaunchKernelGGL(k_bwd_sweep, dim3((unsigned)blocks), dim3(1024), 0, ctx->stream, ctx->A, sg, v, ctx->sweep_sync,
                            ctx->sweep_sync + 3 * 4096, (unsigned long long)2.0e8, ctx->sweep_buf, ctx->dbg_buf);                       // polls give up after 2 s (100 MHz clock)
@@ -2245,6 +2265,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "wide_sub")) { ctx->wide_sub = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "sweep_persist")) { ctx->sweep_persist = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "sweep_max_blocks")) { ctx->sweep_max_blocks = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "early_head")) { ctx->early_head = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows_dist")) { ctx->head32_rows_dist = (int64_t)value; return PYIPM_OK; }

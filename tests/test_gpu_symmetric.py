@@ -226,12 +226,22 @@ def test_one_launch_backward_sweep_matches_the_per_panel_launches(shape, nb):
     g = core.residual()
     raw = core.solve(flip=False)
     assert float((core.matvec(raw) - g).norm() / g.norm()) <= 1e-12
-    # refinement runs the sweep several times per solve; a right-hand side of its own
+    # a right-hand side of its own: the forward pass is not fused under a factorisation and runs as ONE launch too
+    # (k_fwd_sweep + one k_diag_apply over all tiles); refinement runs both sweeps several times per solve
     rhs = torch.randn(core.N, dtype=torch.float64, device="cuda")
     x1 = core.solve(rhs, flip=False, refine=1)
+    xa = core.solve(rhs, flip=False)
+    xb = core.solve(rhs, flip=False)
+    assert torch.equal(xa, xb)
+    core.set_option("sweep_max_blocks", 5)               # few workgroups: every owner has several chunks / column groups
+    xc = core.solve(rhs, flip=False)
+    core.set_option("sweep_max_blocks", 0)
     core.set_option("sweep_persist", 0)
     x0 = core.solve(rhs, flip=False, refine=1)
+    xd = core.solve(rhs, flip=False)
     assert float((x1 - x0).norm() / x0.norm()) <= 1e-12
+    assert float((xa - xd).norm() / xd.norm()) <= 1e-13 and float((xc - xd).norm() / xd.norm()) <= 1e-13
+    assert float((core.matvec(xa) - rhs).norm() / rhs.norm()) <= 1e-12
     core.close()
 
 
@@ -291,6 +301,10 @@ def test_random_schedule_options_give_the_same_bits():
         for trial in range(10):
             opts = {} if trial == 0 else {k: rnd.choice(v) for k, v in space.items() if rnd.random() < 0.6}
             core = NewtonCore(n, me, mi, device=0, nb=nb)
+            # (the substitution sweeps as per-panel launches throughout: the one-launch sweeps sum in another order, so with
+            # them fuse_forward -- forward pass under the factorisation, panel by panel, or after it, in one launch -- would
+            # show in the last bits; they have their own test above)
+            core.set_option("sweep_persist", 0)
             for k, v in opts.items():
                 core.set_option(k, v)
             core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])

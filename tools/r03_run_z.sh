@@ -45,6 +45,7 @@ timeout 300 python tools/tile_blocked_check.py > $O/tile_blocked_check.txt 2>&1
 ( timeout 300 tools/ubench/contention 128 16384; timeout 300 tools/ubench/contention 256 16384 ) > $O/contention_ubench.txt 2>&1
 ( timeout 300 python tools/sweep_clock.py; timeout 300 python tools/sweep_clock.py 16384 4096 6144 ) > $O/sweep_clock.txt 2>&1
 timeout 600 python tools/sweep_check.py > $O/sweep_check.txt 2>&1
+timeout 600 python tools/fwd_check.py big > $O/fwd_check.txt 2>&1
 timeout 120 tools/ubench/pingpong > $O/pingpong.txt 2>&1
 timeout 600 python tools/qp_solve.py > $O/qp_solve_full.json 2> $O/qp_solve_full.err
 timeout 600 python tools/qp_solve.py --condensed > $O/qp_solve_condensed.json 2> $O/qp_solve_condensed.err
