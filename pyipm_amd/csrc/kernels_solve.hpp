@@ -273,7 +273,9 @@ __global__ __launch_bounds__(1024) void k_bwd_diag4(const double* __restrict__ A
 // ordered by s_waitcnt alone.  Per panel workgroup 0 spends (tools/sweep_clock.py, N = 6144): 2.8 us in the recursion of the
 // diagonal block (LDS-bound: 32 ds_read per thread and step; from the registers with __shfl_xor folds it took 4.4 us -- 84
 // ds_bpermute), 0.5 us publishing x, and 3.7 us until the near sums are back (flag seen, x loaded, 8 columns folded, sum
-// stored, seen): 6.9 us a panel where two dependent launches took 10-16.  Polling the VALUES of x instead of the flag saved
+// stored, seen): 6.9 us a panel where two dependent launches took 10-16.  (Also tried: the recursion on the matrix pipe, the
+// tiles loaded as v_mfma_f64_16x16x4 A operands -- 16 columns x 32 bytes per instruction: the uncoalesced 192 KB took one
+// CU ~5 us to fetch and every poll queued behind them, 11.4 us a panel.)  Polling the VALUES of x instead of the flag saved
 // nothing on 32 waves and cost bandwidth on 4080.  Ownership is static and every sum has a fixed order: deterministic.  Every poll carries a
 // timeout (a workgroup that is not resident would otherwise hang the GPU): on expiry *err is set, the sweep ends and
 // the vector is poisoned with NaN.
