@@ -277,6 +277,35 @@ def test_one_launch_backward_sweep_with_nan_does_not_wait():
     core.close()
 
 
+def test_one_launch_sweeps_beside_another_streams_work():
+    """The workgroups of k_fwd_sweep / k_bwd_sweep wait for each other, so they need the GPU to get all of them resident
+    eventually: beside another stream that keeps every CU busy (large GEMMs here) the solve must still come back right --
+    late, not wrong, and without tripping the 2 s poll timeout."""
+    import torch
+    from pyipm_amd.newton import NewtonCore
+    from pyipm_amd.problems import make_qp
+    n, me, mi = 3000, 700, 1200
+    qp = make_qp(n, me, mi, 3)
+    core = NewtonCore(n, me, mi, device=0)
+    core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    core.step(0.0, 0.0)
+    rhs = torch.randn(core.N, dtype=torch.float64, device="cuda")
+    ref = core.solve(rhs, flip=False).clone()
+    a = torch.randn(8192, 8192, dtype=torch.float64, device="cuda")
+    other = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(other):
+        for _ in range(12):
+            a2 = a @ a                                   # ~14 ms each at fp64: every CU busy for the whole test
+    outs = [core.solve(rhs, flip=False).clone() for _ in range(6)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, ref) for o in outs)
+    dz, st = core.step(0.0, 0.0)                         # (factor_end would report a timed-out poll)
+    assert st["n_neg"] == me + mi
+    core.close()
+
+
 def test_random_schedule_options_give_the_same_bits():
     """The schedule of a factorisation -- which stream runs what, in how many launches, how much is looked ahead, what is
     skipped as structurally zero, whether zeros are left in place between assemblies -- must never show in the result.
