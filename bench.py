@@ -148,17 +148,20 @@ def cpu_baseline(target_N=32768, eig_shape=(4096, 1024, 1536), lu_shape=(6144, 1
             "value_no_eigvalsh": 1.0 / t_step_noeig}
 
 
-def pmc_traffic(N, nb):
+def pmc_traffic(N, nb, bn=256):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md; tools/pmc_update.sh,
     tools/pmc_summary.py).  Counters cannot be collected inside this process, so the figure is attached
     only for the configuration it was measured on; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r03_z_pmc_update.json")
+    name = "r03_z_pmc_update.json" if bn == 256 else "r03_z_pmc_update_bn128.json"
+    path = os.path.join(ROOT, "profiles", name)
     if N != 32768 or nb != 256 or os.environ.get("PYIPM_NEWTON_GROUP") not in (None, "4") or not os.path.exists(path):
         return None, None
     try:
         d = json.load(open(path))
-        return float(d["hbm_bytes_per_launch_corrected"]), "profiles/r03_z_pmc_update.json (separate --pmc passes of this command)"
+        if ("<%d," % bn) not in d.get("kernel", ""):
+            return None, None
+        return float(d["hbm_bytes_per_launch_corrected"]), "profiles/%s (separate --pmc passes of this command)" % name
     except Exception:
         return None, None
 
@@ -295,6 +298,7 @@ def main():
         one_step()
     trailing_ms = trailing_flops = panel_ms = solve_ms = assemble_ms = gram_ms = trailing_area = 0.0
     n_launch = 0
+    inst = {128: {"launches": 0, "ms": 0.0, "flops": 0.0, "area": 0.0}, 256: {"launches": 0, "ms": 0.0, "flops": 0.0, "area": 0.0}}
     dist_ms = {}
     fence()
     t0 = time.perf_counter()
@@ -305,6 +309,9 @@ def main():
         panel_ms += tm["panel_ms"]; solve_ms += tm["solve_ms"]; assemble_ms += tm["assemble_ms"]
         gram_ms += tm["gram_ms"]
         trailing_area += tm["trailing_area"]
+        for bn, v in core.trailing_instances().items():      # the bulk launches by kernel instance (128 x 128 / 128 x 256 tiles)
+            for k2 in v:
+                inst[bn][k2] += v[k2]
         if use_dist and not args.python_driver:
             for k, v in core.dist_timings().items():
                 dist_ms[k] = dist_ms.get(k, 0.0) + v
@@ -331,7 +338,24 @@ def main():
     rccl_ranks = core.comm_ranks() if use_dist else 0
     if rank == 0:
         K = args.steps
-        ach = (trailing_flops / 1e12) / (trailing_ms * 1e-3) if trailing_ms > 0 else 0.0
+        ach_all = (trailing_flops / 1e12) / (trailing_ms * 1e-3) if trailing_ms > 0 else 0.0
+        # the dominant kernel = the k_update instance that executed most of the bulk flops (128 x 256 tiles since round 3; the
+        # chain-bound phase and K < 512 launches keep 128 x 128): the roofline object is ITS launches only, so that a kernel
+        # trace's per-name average agrees; the other instance gets the same figures in `other_instance`
+        dom = 256 if inst[256]["flops"] >= inst[128]["flops"] else 128
+        oth = 128 if dom == 256 else 256
+        if inst[dom]["launches"] == 0:                       # (python driver / no profile: fall back to the sums)
+            inst[dom] = {"launches": n_launch, "ms": trailing_ms, "flops": trailing_flops, "area": trailing_area}
+
+        def inst_obj(bn):
+            v = inst[bn]
+            a_ = (v["flops"] / 1e12) / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0
+            return {"kernel": "k_update<%d,true,8> (fp64 MFMA trailing rank-K update, 128 x %d tiles)" % (bn, bn),
+                    "achieved": a_, "frac": a_ / FP64_MFMA_PEAK_TFLOPS, "launches": v["launches"],
+                    "avg_launch_ms": v["ms"] / max(v["launches"], 1), "flops_per_launch_avg": v["flops"] / max(v["launches"], 1),
+                    "algorithmic_bytes_per_launch": (16.0 * v["area"] / v["launches"]) if (v["launches"] and world == 1 and not condensed) else None}
+        dobj, oobj = inst_obj(dom), inst_obj(oth)
+        ach = dobj["achieved"]
         try:
             peak_meas = mfma_f64_peak(local_rank, 20000)
         except Exception:
@@ -347,19 +371,21 @@ def main():
                        "kkt_dim": N, "n": n, "me": me, "mi": mi, "nb": args.nb,
                        "parallelism": "1D block-cyclic column panels over %d GPU(s)" % world,
                        "pivoting": "Bunch-Kaufman restricted to 64x64 diagonal tiles (block pivots); static pivots + refinement where a tile cannot pivot on its own"},
-            "roofline": {"bound": "mfma", "kernel": "k_update<128> (fp64 MFMA trailing rank-nb update)",
+            "roofline": {"bound": "mfma", "kernel": dobj["kernel"],
                          "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(N, args.nb)[0],
-                         "traffic_unit": "bytes per launch (HBM side, PMC)", "traffic_source": pmc_traffic(N, args.nb)[1],
-                         "algorithmic_bytes_per_launch": None,
-                         "launches": n_launch, "avg_launch_ms": trailing_ms / max(n_launch, 1),
-                         "flops_per_launch_avg": trailing_flops / max(n_launch, 1),
+                         "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(N, args.nb, dom)[0],
+                         "traffic_unit": "bytes per launch (HBM side, PMC)", "traffic_source": pmc_traffic(N, args.nb, dom)[1],
+                         "algorithmic_bytes_per_launch": dobj["algorithmic_bytes_per_launch"],
+                         "launches": dobj["launches"], "avg_launch_ms": dobj["avg_launch_ms"],
+                         "flops_per_launch_avg": dobj["flops_per_launch_avg"],
                          "peak_measured_mfma_only": peak_meas,
-                         "frac_of_measured_peak": (ach / peak_meas) if peak_meas else None},
+                         "frac_of_measured_peak": (ach / peak_meas) if peak_meas else None,
+                         "all_bulk_launches": {"achieved": ach_all, "launches": n_launch, "avg_launch_ms": trailing_ms / max(n_launch, 1)},
+                         "other_instance": dict(oobj, traffic=pmc_traffic(N, args.nb, oth)[0]) if oobj["launches"] else None},
             "phases_ms_per_step": {"assemble": assemble_ms / K, "panel(tile+scale+in-panel)": panel_ms / K,
                                    "trailing": trailing_ms / K, "solve": solve_ms / K},
             "phases_note": "trailing = sum of the bulk update launches' HIP-event durations on the main stream (what a kernel "
-                           "trace adds up for k_update<128,true,8>); panel = the rest of the factorisation: the tile chain where "
+                           "trace adds up for k_update<256,true,8> and k_update<128,true,8> together); panel = the rest of the factorisation: the tile chain where "
                            "no bulk launch runs, including the lookahead heads, which ride the chain's stream as "
                            "k_update<128,true,4> and are not part of the roofline figures",
             # the HBM-bound kernels, one roofline object each (bound, achieved, peak, frac): K1 = k_assemble on SURVEY 8d's
@@ -391,9 +417,8 @@ def main():
             "inertia": {"n_neg": st["n_neg"], "expected": me + mi, "n_zero": st["n_zero"], "n_2x2": st["n_2x2"],
                         "growth": st["growth"]},
         }
-        if world == 1 and n_launch and not condensed:
-            # C-tile read-modify-write: 16 B per matrix entry a launch updates (operand panels, read once, add < 10 %)
-            out["roofline"]["algorithmic_bytes_per_launch"] = 16.0 * trailing_area / n_launch
+        # (algorithmic bytes per launch: the C-tile read-modify-write, 16 B per matrix entry a launch updates; the operand
+        # panels, read once, add < 10 %)
         if dist_ms:
             # rank 0's view of the distributed schedule, per step: wall time of the factorisation, its own panel
             # factorisations (chain), packing, broadcasts as seen on the collective stream, rebuilding L from received

@@ -295,6 +295,12 @@ int pyipm_newton_kkt_storage(pyipm_newton_ctx* ctx, double** ptr, int64_t* ld, i
  * [5]=algorithmic flops of those launches, [6]=factor, [7]=Ji Sigma Ji' launch (condensed option) or, for the
  * full system, the number of matrix entries those launches update (their C-tile traffic is 16 B each). */
 int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
+
+/* The bulk trailing-update launches of the last factorisation by kernel instance (profile option on): out[0..3] = launches,
+ * summed HIP-event duration (ms), flops, matrix entries updated of the 128 x 128-tile launches (k_update<128,true,8>),
+ * out[4..7] = the same for the 128 x 256-tile launches (k_update<256,true,8>) -- what a kernel trace lists under the two
+ * names.  Measurement only; nothing in the reference. */
+int pyipm_newton_trailing_instances(pyipm_newton_ctx* h, double out[8]);
 /* Options (all default to the measured-best setting):
  *   "condensed" 0|1  handles with mi > 0 (several ranks since round 3: with the FULL blocks staged on every rank --
  *                    stage_blocks, not stage_blocks_owned -- assemble / factor_dist / solve_dist / step_dist work on it too,
@@ -328,8 +334,9 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  *   "pending32_rows", "head32_rows",
  *   "head32_rows_dist" (row counts up to which a panel's pending in-group update / the lookahead head / the per-panel
  *   head take that kernel; defaults 24576 / 6144 / 16384), "early_head" 0|1 (tail regime: the next group's columns are
- *   updated panel by panel beside the chain; default 0 since the head is split), "bulk_bn" 128|256 (bulk update tiles of
- *   128 x 128 or 128 x 256), "reserve_cus" / "persist_rows" (chain-bound phase -- at most persist_rows rows left, default
+ *   updated panel by panel beside the chain; default 0 since the head is split), "bulk_bn" 256|128 (bulk update tiles of
+ *   128 x 256, the default since round 3 for launches of K >= 512 outside the chain-bound phase, or 128 x 128 everywhere;
+ *   "bulk_bn_all" 1: 128 x 256 in the chain-bound phase too), "reserve_cus" / "persist_rows" (chain-bound phase -- at most persist_rows rows left, default
  *   12288: the bulk update runs as a persistent launch that leaves reserve_cus CUs, default 16,
  *   to the panel chain; 0 = ordinary launches), "wide_sub" (per-panel / multi-GPU schedule: a panel wider than this many
  *   columns, default 256, is factored by its owner as a block of sub-panels this wide -- one tile chain over the panel's

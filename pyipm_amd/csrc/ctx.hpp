@@ -132,6 +132,8 @@ struct Ctx {
     bool per_panel_mode = false;          // the per-panel phases (pyipm_newton_factor_begin ...) drive this factorisation
     int64_t head32_rows_dist = 16384;     // per-panel (multi-GPU) schedule: single-panel launches (the owner's head update of the
                                           // next panel, always on the critical path there) while at most this many rows remain
+    int bulk_bn_all = 0;                  // bulk_bn = 256 also in the chain-bound phase (m <= persist_rows), where the default keeps the
+                                          // persistent 128 x 128 launches that leave CUs to the panel chain
     int sweep_max_blocks = 0;             // test hook: cap on the workgroups of the one-launch sweeps (0 = as many as the GPU holds)
     int sweep_persist = 1;                // single rank, one right-hand side: the backward sweep as ONE device-driven launch (k_bwd_sweep)
     int64_t sweep_buf_n = 0;              // ... (allocated for this many rows)
@@ -151,9 +153,11 @@ struct Ctx {
     int reserve_cus = 16;                 // chain-bound phases: bulk updates run as persistent launches that leave this many CUs
     int64_t persist_rows = 12288;         // free for the panel chain -- while at most this many rows remain (on one rank the per-panel schedule with it
     int num_cus = 256;                    // everywhere took 140 instead of 120 ms); 0 = ordinary launches everywhere.  num_cus: of this device
-    int bulk_bn = 128;                    // column width of a bulk update tile: 128 (default), or 256 = 128 x 256 per block (8 waves x 64 x 64,
-                                          // one block per CU): 20 % less L2-miss traffic, the same step time, and a chain kernel waits twice
-                                          // as long for a slot beside it (tools/contention_probe.py) -- measured r03, kept as an option
+    int bulk_bn = 256;                    // column width of a bulk update tile: 256 = 128 x 256 per block (8 waves x 64 x 64, one block per
+                                          // CU): 22 % less L2-miss traffic than 128 x 128; the same step time on a fast box, 1.3 % less on
+                                          // the slow ones (boxes differ in memory speed, not in MFMA rate); a chain kernel waits twice as
+                                          // long for a slot beside it (tools/contention_probe.py), so the chain-bound phase keeps the
+                                          // persistent 128 x 128 launches (bulk_bn_all = 0).  128: 128 x 128 everywhere (rounds 1-2)
     int bulk_bn_min_k = 512;              // ... for launches with at least this K (shorter ones keep 128 x 128: twice the blocks)
     int xcd_swizzle = 1;
     int side_prio = 1;                    // raise wave priority in panel-chain update launches
@@ -215,6 +219,9 @@ struct Ctx {
     double t_trailing_union = 0; int64_t n_trailing_real = 0;   // time with some update launch running (launches may overlap); launches that did work
     double trailing_flops = 0, trailing_area = 0; int64_t n_trailing = 0;   // area: matrix entries updated, summed over launches
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_trailing;   // reused event pool
+    struct TrailTag { int bn; double flops, area; };
+    std::vector<TrailTag> trailing_tag;   // per bulk launch of the last factorisation: which k_update instance ran, its flops / entries
+    double inst_ms[2] = {0, 0}, inst_flops[2] = {0, 0}, inst_area[2] = {0, 0}; int64_t inst_n[2] = {0, 0};   // [0]: 128 x 128 tiles, [1]: 128 x 256
     hipEvent_t ev[8] = {};
     hipEvent_t ev_prov[4] = {}; bool prov_valid[2] = {false, false}; double prov_bytes[2] = {0.0, 0.0};   // provider products
     bool ev_assemble_valid = false, ev_solve_valid = false;

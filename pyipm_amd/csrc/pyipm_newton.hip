@@ -288,7 +288,8 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
                      int64_t ldw = 0, int64_t row_end = 0, int64_t col_end = 0, int64_t src_c0 = -1,
                      int ksplit = 1, int64_t ks_cstride = 0, int waves = 0,        // waves: 0 = the handle's bulk_waves
                      int head_ct = 0, unsigned* head_counter = nullptr, unsigned* head_count = nullptr, bool list_only = false,
-                     int sub0 = 0, int nct_sub = 0) {  // nct_sub > 0: only column tiles [sub0, sub0 + nct_sub) of local panel first_lp
+                     int sub0 = 0, int nct_sub = 0,    // nct_sub > 0: only column tiles [sub0, sub0 + nct_sub) of local panel first_lp
+                     int* used_bn = nullptr) {         // out: the tile width of the instance that ran (128 / 256)
     const Geo& g = ctx->g;                             // (128 wide; the sub-panels of a wide panel, factor_block)
     if (ldw <= 0) ldw = g.Npad;
     if (row_end <= 0) row_end = g.Npad;
@@ -307,7 +308,7 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     else { u.a0 = 0; u.a1 = g.Npad; u.b0 = 0; u.b1 = 0; }
     const int use_waves = waves ? waves : ctx->bulk_waves;
     if (ctx->xcd_swizzle && bulk && ctx->bulk_bn == 256 && use_waves == 8 && waves == 0 && ksplit == 1 && g.nb % 256 == 0 &&
-        K >= ctx->bulk_bn_min_k && head_ct == 0 && nct_sub == 0) {
+        K >= ctx->bulk_bn_min_k && head_ct == 0 && nct_sub == 0 && (ctx->bulk_bn_all || ctx->reserve_cus <= 0 || m > ctx->persist_rows)) {
         // 128 x 256 tiles (the K = 1024 bulk launches of the single-rank schedule, the K = nb launches of the per-panel one)
         u.nct = (int)(n_lp * (g.nb / 256));
         upd_fill_affine<256>(u);
@@ -318,6 +319,7 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
         if (ntiles == 0) return 0;
         hipLaunchKernelGGL((k_update<256, true, 8>), dim3(ntiles), dim3(512), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
         PYIPM_KCHECK();
+        if (used_bn) *used_bn = 256;
         return 0;
     }
     if (ctx->xcd_swizzle && bulk && upd_swizzle_ok<128>(u)) {
@@ -688,6 +690,7 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
         return launch_update128(ctx, stream, Lop, g.Npad, wbuf(ctx, p0), K, row_begin, first_lp, n_lp, true, 0, 0, 0,
                                 g.panel_c0(p0), 1, 0, 0, head_ct, head_counter, head_count, true);
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    int used_bn = 128;
     if (ctx->profile && !chain_side) {
         if ((size_t)ctx->n_trailing >= ctx->ev_trailing.size()) {
             hipEvent_t a, b;
@@ -707,7 +710,8 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
         PYIPM_KCHECK();
     } else {
         int rc = launch_update128(ctx, stream, Lop, g.Npad, wbuf(ctx, p0), K, row_begin, first_lp, n_lp, true, 0, 0, 0,
-                                  g.panel_c0(p0), 1, 0, chain_side ? ctx->head_waves : 0, head_ct, head_counter, head_count);
+                                  g.panel_c0(p0), 1, 0, chain_side ? ctx->head_waves : 0, head_ct, head_counter, head_count, false, 0, 0,
+                                  &used_bn);
         if (rc) return rc;
     }
     if (chain_side) return 0;
@@ -724,6 +728,8 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
     }
     ctx->trailing_flops += fl;
     ctx->trailing_area += fl / (2.0 * K);
+    if ((size_t)ctx->n_trailing >= ctx->trailing_tag.size()) ctx->trailing_tag.resize((size_t)ctx->n_trailing + 64);
+    ctx->trailing_tag[(size_t)ctx->n_trailing] = {used_bn, fl, fl / (2.0 * K)};
     ctx->n_trailing++;
     return 0;
 }
@@ -789,6 +795,15 @@ int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
             if (x.second <= hi) continue;
             uni += x.second - (x.first > hi ? x.first : hi);
             hi = x.second;
+        }
+        for (int k = 0; k < 2; ++k) { ctx->inst_ms[k] = 0.0; ctx->inst_flops[k] = 0.0; ctx->inst_area[k] = 0.0; ctx->inst_n[k] = 0; }
+        for (int64_t i = 0; i < ctx->n_trailing && (size_t)i < ctx->trailing_tag.size(); ++i) {
+            float d = 0.f;
+            PYIPM_HIP(hipEventElapsedTime(&d, ctx->ev_trailing[i].first, ctx->ev_trailing[i].second));
+            if (d <= 0.03f) continue;                            // (empty tile list: see above)
+            const int k = ctx->trailing_tag[(size_t)i].bn == 256 ? 1 : 0;
+            ctx->inst_ms[k] += d; ctx->inst_flops[k] += ctx->trailing_tag[(size_t)i].flops; ctx->inst_area[k] += ctx->trailing_tag[(size_t)i].area;
+            ctx->inst_n[k]++;
         }
         ctx->t_trailing = sum;                               // what a kernel trace adds up for the same launches
         ctx->t_trailing_union = uni;
@@ -2217,6 +2232,16 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* h, double out[8]) try {
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)
 
+int pyipm_newton_trailing_instances(pyipm_newton_ctx* h, double out[8]) try {
+    if (check_ctx(h) || !out) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    for (int k = 0; k < 2; ++k) {
+        out[4 * k + 0] = (double)ctx->inst_n[k]; out[4 * k + 1] = ctx->inst_ms[k];
+        out[4 * k + 2] = ctx->inst_flops[k]; out[4 * k + 3] = ctx->inst_area[k];
+    }
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
 int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value) try {
     if (check_ctx(h) || !name) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
@@ -2265,6 +2290,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "wide_sub")) { ctx->wide_sub = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "sweep_persist")) { ctx->sweep_persist = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "bulk_bn_all")) { ctx->bulk_bn_all = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "sweep_max_blocks")) { ctx->sweep_max_blocks = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "early_head")) { ctx->early_head = (int)value != 0; return PYIPM_OK; }

@@ -97,6 +97,7 @@ def load_library(path: str | None = None):
         "pyipm_newton_bwd_panel": (c_int, [ctxp, c_int64, c_void_p]),
         "pyipm_newton_kkt_storage": (c_int, [ctxp, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64)]),
         "pyipm_newton_last_timings": (c_int, [ctxp, POINTER(c_double)]),
+        "pyipm_newton_trailing_instances": (c_int, [ctxp, POINTER(c_double)]),
         "pyipm_newton_set_option": (c_int, [ctxp, c_char_p, c_double]),
         "pyipm_newton_workspace_bytes_batched": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
         "pyipm_newton_create_batched": (c_int, [POINTER(c_void_p), c_int64, c_int64, c_int64, c_int, c_int,
@@ -499,6 +500,13 @@ class NewtonCore(object):
                                              ctypes.byref(st), MEM_DEVICE)
         self._ck(rc, st.as_dict())
         return dz, st.as_dict()
+
+    def trailing_instances(self):
+        """Bulk update launches of the last factorisation by kernel instance: {128: {...}, 256: {...}} (profile option on)."""
+        t = (c_double * 8)()
+        self._ck(self.lib.pyipm_newton_trailing_instances(self.h, t))
+        return {bn: {"launches": int(t[4 * k]), "ms": t[4 * k + 1], "flops": t[4 * k + 2], "area": t[4 * k + 3]}
+                for k, bn in ((0, 128), (1, 256))}
 
     def dist_timings(self):
         t = (c_double * 8)()

@@ -17,7 +17,8 @@ kstats() {   # name, bench args...
 }
 kstats bench --steps 4 --warmup 1; head -12 $O/bench_kernel_stats.txt
 bash tools/pmc_update.sh $O/pmc > $O/pmc_update.log 2>&1
-python tools/pmc_summary.py $O/pmc $O/pmc_update.json 2 > $O/pmc_summary.txt 2>&1; head -12 $O/pmc_summary.txt
+python tools/pmc_summary.py $O/pmc $O/pmc_update.json 2 'k_update<256, true, 8>' > $O/pmc_summary.txt 2>&1; head -12 $O/pmc_summary.txt
+python tools/pmc_summary.py $O/pmc $O/pmc_update_bn128.json 2 'k_update<128, true, 8>' > $O/pmc_summary_bn128.txt 2>&1
 bash tools/pmc_hbm.sh $O/pmc_hbm > $O/pmc_hbm.log 2>&1; tail -4 $O/pmc_hbm.log
 # the other BASELINE configurations: bench line, kernel stats, one counter pass each (FETCH / WRITE / MFMA busy)
 bash tools/measure_configs.sh > $O/configs.txt 2>&1; tail -9 $O/configs.txt; mkdir -p $O/cfg; cp gpurun_out/cfg*.json gpurun_out/metric_*.json $O/cfg/ 2>/dev/null
@@ -41,7 +42,7 @@ cfgpmc cfg4 --nvar 65536 --neq 0 --nineq 32768 --steps 1 --warmup 0
 timeout 300 python tools/tile_clock.py 1 > $O/tile_clock_blocked.txt 2>&1; timeout 300 python tools/tile_clock.py 0 | head -1 > $O/tile_clock_sweeps.txt 2>&1
 ( timeout 300 python tools/bench_tile.py 1; timeout 300 python tools/bench_tile.py 0 ) > $O/bench_tile.txt 2>&1
 timeout 300 python tools/tile_blocked_check.py > $O/tile_blocked_check.txt 2>&1
-( timeout 300 python tools/contention_probe.py; timeout 300 python tools/contention_probe.py bulk_bn=256 ) > $O/contention_probe.txt 2>&1
+( timeout 300 python tools/contention_probe.py; timeout 300 python tools/contention_probe.py bulk_bn=128 ) > $O/contention_probe.txt 2>&1
 ( timeout 300 tools/ubench/contention 128 16384; timeout 300 tools/ubench/contention 256 16384 ) > $O/contention_ubench.txt 2>&1
 ( timeout 300 python tools/sweep_clock.py; timeout 300 python tools/sweep_clock.py 16384 4096 6144 ) > $O/sweep_clock.txt 2>&1
 timeout 600 python tools/sweep_check.py > $O/sweep_check.txt 2>&1
@@ -52,7 +53,7 @@ timeout 600 python tools/qp_solve.py > $O/qp_solve_full.json 2> $O/qp_solve_full
 timeout 600 python tools/qp_solve.py --condensed > $O/qp_solve_condensed.json 2> $O/qp_solve_condensed.err
 timeout 600 python tools/bench_batched.py > $O/bench_batched.txt 2>&1
 timeout 900 python tools/bench_lbfgs.py > $O/bench_lbfgs.txt 2>&1
-timeout 600 python bench.py --no-cpu-baseline --steps 4 --warmup 2 --opt bulk_bn=256 > $O/bench_bulk_bn256.json 2> /dev/null
+timeout 600 python bench.py --no-cpu-baseline --steps 4 --warmup 2 --opt bulk_bn=128 > $O/bench_bulk_bn128.json 2> /dev/null
 timeout 600 python bench.py --no-cpu-baseline --steps 4 --warmup 2 --opt tile_blocked=0 > $O/bench_tile_sweeps.json 2> /dev/null
 rm -rf $O/pmc/*/*.db $O/pmc_hbm/*/*.db 2>/dev/null
 du -sh $O
