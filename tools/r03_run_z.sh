@@ -48,7 +48,7 @@ timeout 300 python tools/tile_blocked_check.py > $O/tile_blocked_check.txt 2>&1
 timeout 600 python tools/sweep_check.py > $O/sweep_check.txt 2>&1
 timeout 600 python tools/fwd_check.py big > $O/fwd_check.txt 2>&1
 timeout 120 tools/ubench/pingpong > $O/pingpong.txt 2>&1
-timeout 300 tools/ubench/rounds 40 64 > $O/rounds.txt 2>&1
+( timeout 300 tools/ubench/rounds 40 64; timeout 300 tools/ubench/rounds 58 66 256; timeout 300 tools/ubench/rounds 126 128 256; timeout 300 tools/ubench/rounds 126 128 128 ) > $O/rounds.txt 2>&1
 timeout 600 python tools/qp_solve.py > $O/qp_solve_full.json 2> $O/qp_solve_full.err
 timeout 600 python tools/qp_solve.py --condensed > $O/qp_solve_condensed.json 2> $O/qp_solve_condensed.err
 timeout 600 python tools/bench_batched.py > $O/bench_batched.txt 2>&1
