@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM-side traffic (PMC) of the HBM-bound kernels K1 (k_assemble) and K5 (k_fwd_gemv, k_bwd_dot): two passes
+# HBM-side traffic (PMC) of the HBM-bound kernels K1 (k_assemble) and K5 (k_fwd_gemv, k_bwd_sweep; k_bwd_dot / k_fwd_sweep where they run): two passes
 # (FETCH_SIZE costs 3 of the 4 TCC slots, WRITE_SIZE 2).  Usage: tools/pmc_hbm.sh <outdir>
 set -u
 OUT=${1:-gpurun_out/pmc_hbm}
@@ -8,7 +8,7 @@ mkdir -p $ROOT/$OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 1 --warmup 1 --no-cpu-baseline"
 run() { name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --kernel-include-regex "k_assemble|k_fwd_gemv|k_bwd_dot" --output-format csv -d $ROOT/$OUT/$name -o $name -- python $ROOT/bench.py $ARGS > $ROOT/$OUT/$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --kernel-include-regex "k_assemble|k_fwd_gemv|k_bwd_dot|k_bwd_sweep|k_fwd_sweep" --output-format csv -d $ROOT/$OUT/$name -o $name -- python $ROOT/bench.py $ARGS > $ROOT/$OUT/$name.log 2>&1
 }
 run tcc1 FETCH_SIZE
 run tcc2 WRITE_SIZE
@@ -26,7 +26,7 @@ for name in ("tcc1", "tcc2"):
             calls[k] += 1
 N, n, me, mi, steps = 32768, 16384, 4096, 6144, 2
 alg = {"k_assemble": 4.0 * N * N + 8.0 * (n * n / 2.0 + n * me + n * mi),          # per step
-       "k_fwd_gemv": 4.0 * N * N, "k_bwd_dot": 4.0 * N * N}
+       "k_fwd_gemv": 4.0 * N * N, "k_bwd_dot": 4.0 * N * N, "k_bwd_sweep": 4.0 * N * N, "k_fwd_sweep": 4.0 * N * N}
 out = {}
 for k in tot:
     fetch = 2.0 * 1024.0 * tot[k]["FETCH_SIZE"]          # KB, doubled on gfx950 (MI355X_MICROARCH.md)
