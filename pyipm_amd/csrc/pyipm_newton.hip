@@ -935,10 +935,11 @@ int solve_plain(Ctx* ctx, double* v, bool forward_done, int nrhs = 1, int64_t vs
         PYIPM_HIP(hipMemsetAsync(ctx->sweep_sync, 0, (size_t)(2 * P + 1024) * sizeof(unsigned), ctx->stream));
         PYIPM_HIP(hipMemsetAsync(ctx->sweep_buf, 0xFF, (size_t)g.Npad * sizeof(double), ctx->stream));      // NaN: "not there yet"
         const int64_t groups = g.Npad / 8;
-        int64_t blocks = 1 + (groups + 15) / 16;
+        const int64_t nearb = (g.nb / 8 + 15) / 16;                  // workgroups that only do the next panel's columns
+        int64_t blocks = 1 + nearb + (groups + 15) / 16;
         if (blocks > ctx->num_cus) blocks = ctx->num_cus;
         if (ctx->sweep_max_blocks > 0 && blocks > ctx->sweep_max_blocks) blocks = ctx->sweep_max_blocks;
-        if (blocks < 2) blocks = 2;
+        if (blocks < 2 + nearb) blocks = 2 + nearb;
         hipLaunchKernelGGL(k_bwd_sweep, dim3((unsigned)blocks), dim3(1024), 0, ctx->stream, ctx->A, sg, v, ctx->sweep_sync,
                            ctx->sweep_sync + 3 * 4096, (unsigned long long)2.0e8, ctx->sweep_buf, ctx->dbg_buf);                       // polls give up after 2 s (100 MHz clock)
         PYIPM_KCHECK();
