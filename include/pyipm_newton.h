@@ -349,7 +349,10 @@ int pyipm_newton_trailing_instances(pyipm_newton_ctx* h, double out[8]);
  *   share as soon as a panel's x is published; k_fwd_sweep, its mirror with 64-row chunks, for the forward pass of a solve
  *   that is not fused under a factorisation; flags and values cross workgroups through agent-scope atomics, every poll
  *   has a 2 s timeout that poisons the result with NaN and is reported by the next factorisation) instead of two dependent
- *   launches per panel -- equal to rounding, not to the bit (another summation order), deterministic;
+ *   launches per panel -- equal to rounding, not to the bit (another summation order), deterministic.  Their workgroups
+ *   wait for each other, so all of them (one per CU backward, two per CU forward) must become resident at some point: beside
+ *   other streams' kernels they are merely late (tests/test_gpu_symmetric.py), but under a CU mask, or beside a kernel that
+ *   holds CUs for seconds, use "sweep_persist" 0;
  *   "sweep_max_blocks" (test hook: cap on their workgroups);
  *   "tile_blocked" 0|1 (default 1; batched handles 0): the 64 x 64 tile inversion 16 pivots at a time (in-register LDL' of the
  *   micro-block + fp64 MFMA block sweeps, Bunch-Kaufman verified afterwards, fallback to the single sweeps: DESIGN.md
