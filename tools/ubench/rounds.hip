@@ -11,7 +11,8 @@ using namespace pyipm;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 int main(int argc, char** argv) {
     const int r0 = argc > 1 ? atoi(argv[1]) : 40, r1 = argc > 2 ? atoi(argv[2]) : 56;
-    const int bn = argc > 3 ? atoi(argv[3]) : 128;            // 128 x bn tiles; slots: 512 (two blocks per CU) or 256 (one)
+    const int bn = argc > 3 ? atoi(argv[3]) : 128;
+    const int alias = argc > 4 ? atoi(argv[4]) : 0;           // 1: every column of C is the same memory (ldc = 0): no HBM traffic for the C tiles            // 128 x bn tiles; slots: 512 (two blocks per CU) or 256 (one)
     const int64_t mmax = (int64_t)r1 * 128; const int K = 1024;
     double *C, *L, *W;
     CK(hipMalloc(&C, (size_t)mmax * mmax * 8)); CK(hipMalloc(&L, (size_t)mmax * K * 8)); CK(hipMalloc(&W, (size_t)mmax * K * 8));
@@ -45,8 +46,8 @@ int main(int argc, char** argv) {
         unsigned* dl; CK(hipMalloc(&dl, list.size() * 4)); CK(hipMemcpy(dl, list.data(), list.size() * 4, hipMemcpyHostToDevice));
         u.tiles = dl;
         auto launch = [&]() {
-            if (bn == 256) hipLaunchKernelGGL((k_update<256, true, 8>), dim3((unsigned)list.size()), dim3(512), 0, 0, C, m, L, m, W, m, K, u);
-            else hipLaunchKernelGGL((k_update<128, true, 8>), dim3((unsigned)list.size()), dim3(512), 0, 0, C, m, L, m, W, m, K, u); };
+            if (bn == 256) hipLaunchKernelGGL((k_update<256, true, 8>), dim3((unsigned)list.size()), dim3(512), 0, 0, C, alias ? 0 : m, L, m, W, m, K, u);
+            else hipLaunchKernelGGL((k_update<128, true, 8>), dim3((unsigned)list.size()), dim3(512), 0, 0, C, alias ? 0 : m, L, m, W, m, K, u); };
         launch(); launch(); CK(hipDeviceSynchronize());
         std::vector<float> ts;
         for (int rep = 0; rep < 7; ++rep) { float ms; CK(hipEventRecord(e0, 0)); launch(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms); }
