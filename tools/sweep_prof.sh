@@ -1,3 +1,4 @@
+#!/bin/bash
 # kernel durations of the solve phase with the one-launch backward sweep (rocprofv3 --kernel-trace)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
