@@ -336,7 +336,7 @@ int pyipm_newton_trailing_instances(pyipm_newton_ctx* h, double out[8]);
  *   head take that kernel; defaults 24576 / 6144 / 16384), "early_head" 0|1 (tail regime: the next group's columns are
  *   updated panel by panel beside the chain; default 0 since the head is split), "bulk_bn" 256|128 (bulk update tiles of
  *   128 x 256, the default since round 3 for launches of K >= 512 outside the chain-bound phase, or 128 x 128 everywhere;
- *   "bulk_bn_all" 1: 128 x 256 in the chain-bound phase too), "reserve_cus" / "persist_rows" (chain-bound phase -- at most persist_rows rows left, default
+ *   "bulk_bn_rows": only for launches over more rows than this, default 20480; "bulk_bn_all" 1: everywhere), "reserve_cus" / "persist_rows" (chain-bound phase -- at most persist_rows rows left, default
  *   12288: the bulk update runs as a persistent launch that leaves reserve_cus CUs, default 16,
  *   to the panel chain; 0 = ordinary launches), "wide_sub" (per-panel / multi-GPU schedule: a panel wider than this many
  *   columns, default 256, is factored by its owner as a block of sub-panels this wide -- one tile chain over the panel's

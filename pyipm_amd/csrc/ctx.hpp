@@ -132,6 +132,10 @@ struct Ctx {
     bool per_panel_mode = false;          // the per-panel phases (pyipm_newton_factor_begin ...) drive this factorisation
     int64_t head32_rows_dist = 16384;     // per-panel (multi-GPU) schedule: single-panel launches (the owner's head update of the
                                           // next panel, always on the critical path there) while at most this many rows remain
+    int64_t bulk_bn_rows = 20480;         // 128 x 256 tiles only for launches over more rows than this (and than persist_rows): below it the
+                                          // next group's chain is no longer hidden behind the bulk launch, and beside the wide tiles (one
+                                          // block per CU, every register) its kernels wait twice as long for a slot -- exposed panel 6.0
+                                          // instead of 5.3 ms with the threshold at persist_rows, the step 0.8 % slower
     int bulk_bn_all = 0;                  // bulk_bn = 256 also in the chain-bound phase (m <= persist_rows), where the default keeps the
                                           // persistent 128 x 128 launches that leave CUs to the panel chain
     int sweep_max_blocks = 0;             // test hook: cap on the workgroups of the one-launch sweeps (0 = as many as the GPU holds)

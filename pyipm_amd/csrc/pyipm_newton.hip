@@ -308,7 +308,7 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     else { u.a0 = 0; u.a1 = g.Npad; u.b0 = 0; u.b1 = 0; }
     const int use_waves = waves ? waves : ctx->bulk_waves;
     if (ctx->xcd_swizzle && bulk && ctx->bulk_bn == 256 && use_waves == 8 && waves == 0 && ksplit == 1 && g.nb % 256 == 0 &&
-        K >= ctx->bulk_bn_min_k && head_ct == 0 && nct_sub == 0 && (ctx->bulk_bn_all || ctx->reserve_cus <= 0 || m > ctx->persist_rows)) {
+        K >= ctx->bulk_bn_min_k && head_ct == 0 && nct_sub == 0 && (ctx->bulk_bn_all || ctx->reserve_cus <= 0 || m > (ctx->bulk_bn_rows > ctx->persist_rows ? ctx->bulk_bn_rows : ctx->persist_rows))) {
         // 128 x 256 tiles (the K = 1024 bulk launches of the single-rank schedule, the K = nb launches of the per-panel one)
         u.nct = (int)(n_lp * (g.nb / 256));
         upd_fill_affine<256>(u);
@@ -2292,6 +2292,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "wide_sub")) { ctx->wide_sub = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "sweep_persist")) { ctx->sweep_persist = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "bulk_bn_all")) { ctx->bulk_bn_all = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "bulk_bn_rows")) { ctx->bulk_bn_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "sweep_max_blocks")) { ctx->sweep_max_blocks = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "early_head")) { ctx->early_head = (int)value != 0; return PYIPM_OK; }
