@@ -24,7 +24,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, shape, nb, mode, out):
+def _worker(rank, world, port, shape, nb, mode, out, opts=None):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -36,6 +36,10 @@ def _worker(rank, world, port, shape, nb, mode, out):
         n, me, mi, seed = shape
         qp = make_qp(n, me, mi, seed)
         core = NewtonCore(n, me, mi, device=0, nb=nb, world=world, rank=rank)
+        for k, v in (opts or {}).items():
+            core.set_option(k, v)
+        if opts:
+            core.set_option("profile", 1)                # (per-instance launch counts below)
         if mode == "native-sharded":                     # a rank stages only the rows of the x-columns it owns
             rows = core.owned_rows()
             core.stage_blocks_owned(qp["d2L"][rows], qp["Je"][rows] if me else None, qp["Ji"][rows] if mi else None)
@@ -56,6 +60,9 @@ def _worker(rank, world, port, shape, nb, mode, out):
             extra["info"] = core.solve_info()
             extra["refined_diff"] = float((dz_ref - dz).norm() / dz.norm())
             extra["timings"] = core.dist_timings()
+            if opts:
+                core.step_dist(0.0, 0.0)
+                extra["instances"] = core.trailing_instances()
         torch.cuda.synchronize()
         out[rank] = (dz.cpu().numpy(), st, core.ncols_local, drv.bytes_broadcast, g, extra)
     finally:
@@ -115,6 +122,32 @@ def test_ranks_sharing_one_gpu(world, shape, nb, mode):
     else:
         # the Python driver counts the sweeps too: nb numbers summed per panel forward, nb broadcast backward
         assert out[0][3] == fact + 16 * Npad
+
+
+@pytest.mark.parametrize("world,shape,nb", [(2, (1300, 300, 450, 11), 512), (3, (4600, 800, 1300, 12), 1024)])
+def test_wide_bulk_tiles_across_ranks(world, shape, nb):
+    """The 128 x 256 bulk tiles (the default for launches over more than 20480 rows: sizes no test with several ranks on one
+    GPU reaches) forced on at a small size across ranks: block-cyclic column tiles of 256, the direction against the oracle
+    and bit for bit the one of the 128 x 128 tiles."""
+    import torch.multiprocessing as mp
+    n, me, mi, seed = shape
+    res = {}
+    for name, opts in (("wide", {"bulk_bn": 256, "bulk_bn_rows": 0, "persist_rows": 0, "reserve_cus": 0, "bulk_bn_min_k": 256}),
+                       ("narrow", {"bulk_bn": 128})):
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, _free_port(), shape, nb, "native", out, opts), nprocs=world, join=True)
+        res[name] = {r: out[r] for r in range(world)}
+    qp = make_qp(n, me, mi, seed)
+    ref, _, _, _ = orc.newton_step(qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"],
+                                   qp["mu"], n, me, mi, regularise=False)
+    for r in range(world):
+        dz, st = res["wide"][r][0], res["wide"][r][1]
+        assert np.linalg.norm(dz - ref) / np.linalg.norm(ref) <= 1e-10
+        assert st["n_neg"] == me + mi and st["n_zero"] == 0
+        assert np.array_equal(dz, res["narrow"][r][0])
+    assert sum(res["wide"][r][5]["instances"][256]["launches"] for r in range(world)) > 0       # (the wide instance did run)
+    assert sum(res["narrow"][r][5]["instances"][256]["launches"] for r in range(world)) == 0
 
 
 def test_native_and_python_drivers_agree_bitwise():
