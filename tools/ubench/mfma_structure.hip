@@ -93,6 +93,68 @@ __global__ __launch_bounds__(256, 2) void k5(double* out, int steps) {
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
     if (sum == 123.456) out[0] = sum;
 }
+// V7: V5 + the global loads of the production kernel (two 16-byte loads per operand and stage, issued a full stage ahead of the
+// LDS stores that consume them): what does the VMEM side of the staging cost the matrix pipe?
+__global__ __launch_bounds__(256, 2) void k7(double* out, const double* __restrict__ Lg, const double* __restrict__ Wg, long ld, int steps) {
+    __shared__ double Ls[2][16][144];
+    __shared__ double Ws[2][16][144];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4, wi = (wave & 1) * 64, wj = (wave >> 1) * 64;
+    double4_t acc[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) acc[i][j] = (double4_t){0, 0, 0, 0};
+    for (int e = tid; e < 2 * 16 * 144; e += 256) { (&Ls[0][0][0])[e] = 1.0 + e * 1e-9; (&Ws[0][0][0])[e] = 1.0 - e * 1e-9; }
+    __syncthreads();
+    const double* lsrc = Lg + (long)(blockIdx.x % 64) * 128 + (tid & 63) * 2 + (long)(tid >> 6) * ld;
+    const double* wsrc = Wg + (long)((blockIdx.x / 64) % 64) * 128 + (tid & 63) * 2 + (long)(tid >> 6) * ld;
+    double2_t lreg[4], wreg[4];
+    #pragma unroll
+    for (int ps = 0; ps < 4; ++ps) { lreg[ps] = *reinterpret_cast<const double2_t*>(lsrc + (long)(4 * ps) * ld); wreg[ps] = *reinterpret_cast<const double2_t*>(wsrc + (long)(4 * ps) * ld); }
+    int cur = 0;
+    double a0[4], b0[4], a1[4], b1[4];
+#define ILV7(n, m) { _Pragma("unroll") for (int q = 0; q < n; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(m, 1, 0); } }
+    FR(cur, 0, a0, b0)
+    for (int s = 0; s < steps; ++s) {
+        const long k2 = (long)((s + 1) & 63) * 16;
+        FR(cur, 4, a1, b1)
+        MM(a0, b0)
+        ILV7(8, 0x100)
+        FR(cur, 8, a0, b0)
+        MM(a1, b1)
+        ILV7(8, 0x100)
+        FR(cur, 12, a1, b1)
+        #pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            *reinterpret_cast<double2_t*>(&Ls[cur ^ 1][(tid >> 6) + 4 * ps][(tid & 63) * 2]) = lreg[ps];
+            *reinterpret_cast<double2_t*>(&Ws[cur ^ 1][(tid >> 6) + 4 * ps][(tid & 63) * 2]) = wreg[ps];
+        }
+        #pragma unroll
+        for (int ps = 0; ps < 4; ++ps) { lreg[ps] = *reinterpret_cast<const double2_t*>(lsrc + (k2 + 4 * ps) * ld); wreg[ps] = *reinterpret_cast<const double2_t*>(wsrc + (k2 + 4 * ps) * ld); }
+        MM(a0, b0)
+        ILV7(16, 0x0A0)
+        __syncthreads();
+        FR(cur ^ 1, 0, a0, b0)
+        MM(a1, b1)
+        ILV7(8, 0x100)
+        cur ^= 1;
+    }
+    double sum = 0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) sum += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (sum == 123.456) out[0] = sum;
+}
+double run7(int blocks, int steps) {
+    double* d; hipMalloc(&d, 64);
+    const long ld = 8192 + 0;
+    double *Lg, *Wg; hipMalloc(&Lg, ld * 1040 * 8); hipMalloc(&Wg, ld * 1040 * 8);
+    hipMemset(Lg, 0, ld * 1040 * 8); hipMemset(Wg, 0, ld * 1040 * 8);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k7, dim3(blocks), dim3(256), 0, 0, d, Lg, Wg, ld, 8);
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(k7, dim3(blocks), dim3(256), 0, 0, d, Lg, Wg, ld, steps);
+    hipEventRecord(e1, 0); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    hipFree(d); hipFree(Lg); hipFree(Wg);
+    return (double)blocks * 4 * steps * 64.0 * 2048.0 / (ms * 1e-3) / 1e12;
+}
 template <int V> double run5(int blocks, int steps) {
     double* d; hipMalloc(&d, 64);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -124,6 +186,8 @@ int main(int argc, char** argv) {
                run<2>(blocks, steps * 512 / blocks), run<3>(blocks, steps * 512 / blocks));
     }
     printf("V5 (prefetch + 1 DS per MFMA, barrier mid-stage): blocks=512 %.1f  blocks=4096 %.1f TF/s\n", run5<5>(512, 4096), run5<5>(4096, 512));
+    printf("V7 (V5 + global loads a stage ahead): blocks=512 %.1f  blocks=4096 steps 64 (one K=1024 tile each) %.1f  steps 512 %.1f TF/s\n", run7(512, 4096), run7(4096, 64), run7(4096, 512));
+    printf("V5 again: blocks=4096 steps 64 %.1f TF/s\n", run5<5>(4096, 64));
     // short blocks like the real kernel: 16 steps per block, many blocks
     for (int steps2 : {16, 32, 64}) {
         int blocks = 32768;
