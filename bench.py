@@ -363,6 +363,7 @@ def main():
         out = {
             "metric": "newton_steps_per_sec", "value": K / elapsed, "unit": "steps/s", "n_gpus": world,
             "rccl_ranks": rccl_ranks,
+            "panel_bcast": ("scatter+allgather" if (use_dist and core.comm_bcast_mode()) else ("ncclBroadcast" if rccl_ranks else None)),
             "steps": K, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "synthetic convex dense QP Newton step (residual+KKT assembly+block LDL^T+solve+flip), "

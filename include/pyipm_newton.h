@@ -244,6 +244,13 @@ int pyipm_newton_comm_init(pyipm_newton_ctx* ctx, const void* id128);
 /* Number of ranks of the handle's RCCL communicator as RCCL itself reports it (ncclCommCount); 0 = no communicator
  * (callback exchange or single rank), negative = error.  bench.py prints it so that a multi-GPU line proves RCCL saw N ranks. */
 int pyipm_newton_comm_ranks(pyipm_newton_ctx* ctx);
+/* How the panel messages of factor_dist travel over the handle's communicator: 1 = scatter + all-gather (the owner sends
+ * piece r to rank r, then an in-place all-gather: W - 1 links of the xGMI mesh at once instead of the one link's bandwidth of
+ * ncclBroadcast's ring), 0 = ncclBroadcast.  comm_init switches the first form on for three ranks or more after it has
+ * reproduced ncclBroadcast on that communicator (two roots, a count that does not divide by the number of ranks; all ranks
+ * agree); the environment variable PYIPM_DIST_SAG=0 or set_option("dist_sag", 0) keep ncclBroadcast.  Messages below 4 MiB
+ * and the nb-long exchanges of the sweeps always use ncclBroadcast. */
+int pyipm_newton_comm_bcast_mode(pyipm_newton_ctx* ctx);
 /* Row-sharded staging: a rank assembles only the KKT columns it owns, and column j (j < n) of the lower triangle is
  * row j of triu(d2L) | Je | Ji -- so it needs only those rows.  owned_rows returns their number and (rows != NULL)
  * their global indices in the order the arrays must hold them (= the rank's local column order).  After

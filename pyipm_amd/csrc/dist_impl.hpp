@@ -22,6 +22,12 @@ struct RcclApi {
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    // optional (the panel broadcast as scatter + all-gather; without them ncclBroadcast carries the panels too)
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 RcclApi g_rccl;
@@ -46,6 +52,11 @@ int rccl_load(std::string* err) {
     a.Broadcast = (decltype(a.Broadcast))dlsym(lib, "ncclBroadcast");
     a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
     a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+    a.AllGather = (decltype(a.AllGather))dlsym(lib, "ncclAllGather");
+    a.Send = (decltype(a.Send))dlsym(lib, "ncclSend");
+    a.Recv = (decltype(a.Recv))dlsym(lib, "ncclRecv");
+    a.GroupStart = (decltype(a.GroupStart))dlsym(lib, "ncclGroupStart");
+    a.GroupEnd = (decltype(a.GroupEnd))dlsym(lib, "ncclGroupEnd");
     if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.Broadcast || !a.AllReduce) {
         if (err) *err = "RCCL library lacks an entry point"; return PYIPM_E_COMM;
     }
@@ -71,6 +82,8 @@ struct DistState {
     double* vloc = nullptr;                            // Npad: this rank's share of the vector during the sweeps
     double* small = nullptr;                           // 16 doubles: statistics reduction
     int selfmsg = 0;                                   // world == 1: pack + broadcast anyway (measures the message path on one GPU)
+    int sag = 0;                                       // panel messages travel as scatter + all-gather (set by comm_init after its self-test)
+    size_t sag_min_bytes = (size_t)4 << 20;            // ... from this size on
     // profile (ms, last factor_dist / solve_dist): chain = owner's panel factorisations, pack, wait-for-message, unpack
     std::vector<hipEvent_t> pool; size_t used = 0;
     struct Span { int kind; hipEvent_t a, b; };
@@ -147,6 +160,18 @@ void dist_free(Ctx* ctx) {
 
 int dist_set_option(Ctx* ctx, const char* name, double value, bool* handled) {
     *handled = false;
+    if (!strcmp(name, "dist_sag")) {                    // -1: query is through dist_timings; 0 / 1: panel messages as scatter + all-gather
+        *handled = true;
+        DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
+        if ((int)value == 0) D->sag = 0;                // (switching it ON by hand is not offered: comm_init's self-test decides)
+        return PYIPM_OK;
+    }
+    if (!strcmp(name, "dist_sag_min_bytes")) {          // panel messages of at least this size take the scatter + all-gather form
+        *handled = true;
+        DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
+        D->sag_min_bytes = value > 0 ? (size_t)value : 0;
+        return PYIPM_OK;
+    }
     if (!strcmp(name, "dist_selfmsg")) {                // world == 1: pack + "broadcast" every panel anyway (measures the message path)
         *handled = true;
         DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
@@ -177,8 +202,43 @@ struct CsHop {
     }
 };
 
+// A panel message over the handle's communicator as SCATTER + ALL-GATHER: the owner sends piece r to rank r (W - 1 sends over
+// W - 1 links at once), then every rank hands its piece to all the others (all-gather, in place).  ncclBroadcast is a ring
+// or a tree: one link's bandwidth whatever the topology; over the point-to-point xGMI mesh of an 8-GPU node this form moves
+// a message in 2 / W of the time per link-bandwidth -- and the panel messages are 4.3 GB per step at N = 32768, the whole
+// lower triangle.  `buf` must hold W * ceil(count / W) doubles (the panel buffers are allocated with that slack).
+// Unmeasured on more than one GPU (the development box has one): comm_init checks it against ncclBroadcast on every
+// communicator before switching it on.
+int sag_bcast(Ctx* ctx, DistState* D, double* buf, size_t count, int root, hipStream_t cs) {
+    const int W = ctx->g.world, me = ctx->g.rank;
+    const size_t chunk = (count + (size_t)W - 1) / (size_t)W;
+    auto fail = [&](const char* what, ncclResult_t r) {
+        ctx->err = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; };
+    ncclResult_t r = g_rccl.GroupStart(); if (r != ncclSuccess) return fail("ncclGroupStart", r);
+    if (me == root) {
+        for (int q = 0; q < W; ++q) {
+            if (q == root) continue;
+            r = g_rccl.Send(buf + (size_t)q * chunk, chunk, ncclDouble, q, D->comm, cs);
+            if (r != ncclSuccess) { g_rccl.GroupEnd(); return fail("ncclSend", r); }
+        }
+    } else {
+        r = g_rccl.Recv(buf + (size_t)me * chunk, chunk, ncclDouble, root, D->comm, cs);
+        if (r != ncclSuccess) { g_rccl.GroupEnd(); return fail("ncclRecv", r); }
+    }
+    r = g_rccl.GroupEnd(); if (r != ncclSuccess) return fail("ncclGroupEnd", r);
+    r = g_rccl.AllGather(buf + (size_t)me * chunk, buf, chunk, ncclDouble, D->comm, cs);
+    if (r != ncclSuccess) return fail("ncclAllGather", r);
+    return 0;
+}
+
 int ex_bcast(Ctx* ctx, DistState* D, void* buf, size_t bytes, int root, hipStream_t st) {
     if (bytes == 0) return 0;
+    if (D->comm && D->sag && bytes >= D->sag_min_bytes && (buf == D->msg[0] || buf == D->msg[1])) {
+        CsHop h(ctx, D, st); if (h.rc) return h.done();
+        int rc = sag_bcast(ctx, D, static_cast<double*>(buf), bytes / sizeof(double), root, h.stream());
+        if (rc) return rc;
+        return h.done();
+    }
     if (D->comm) {
         CsHop h(ctx, D, st); if (h.rc) return h.done();
         ncclResult_t r = g_rccl.Broadcast(buf, buf, bytes / sizeof(double), ncclDouble, root, D->comm, h.stream());
@@ -294,7 +354,8 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
     if (need > D->msg_bytes) {
         for (int b = 0; b < 2; ++b) { if (D->msg[b]) DIST_HIP(hipFree(D->msg[b])); D->msg[b] = nullptr; }
         for (int b = 0; b < 2; ++b)
-            if (hipMalloc((void**)&D->msg[b], need) != hipSuccess) { ctx->err = "factor_dist: no memory for the panel messages"; return PYIPM_E_NOMEM; }
+            if (hipMalloc((void**)&D->msg[b], need + (size_t)g.world * sizeof(double)) != hipSuccess) {     // (slack: W equal pieces, sag_bcast)
+                ctx->err = "factor_dist: no memory for the panel messages"; return PYIPM_E_NOMEM; }
         D->msg_bytes = need;
     }
     std::vector<char> has_msg((size_t)np, 0), on_side((size_t)np, 0);
@@ -596,6 +657,40 @@ int pyipm_newton_comm_init(pyipm_newton_ctx* h, const void* id128) try {
     ncclUniqueId id; memcpy(&id, id128, sizeof(id));
     ncclResult_t r = g_rccl.CommInitRank(&D->comm, ctx->g.world, id, ctx->g.rank);
     if (r != ncclSuccess) { D->comm = nullptr; ctx->err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; }
+    // Panel messages as scatter + all-gather (sag_bcast): only with at least three ranks, every entry point present, and after
+    // the form has reproduced ncclBroadcast on THIS communicator -- from rank 0 and from the last rank, a count that does not
+    // divide by the number of ranks; the ranks agree on the outcome (a sum of failures), so either all use it or none.
+    D->sag = 0;
+    const char* env = getenv("PYIPM_DIST_SAG");
+    const bool want = !(env && env[0] == '0');
+    if (want && ctx->g.world >= 3 && g_rccl.AllGather && g_rccl.Send && g_rccl.Recv && g_rccl.GroupStart && g_rccl.GroupEnd) {
+        const int W = ctx->g.world;
+        const size_t count = 100003, cap = ((count + W - 1) / W) * W;
+        double *a = nullptr, *b = nullptr;
+        PYIPM_HIP(hipMalloc((void**)&a, 2 * cap * sizeof(double)));
+        b = a + cap;
+        std::vector<double> host(count), got(count), ref(count);
+        double bad = 0.0;
+        for (int root : {0, W - 1}) {
+            for (size_t i = 0; i < count; ++i) host[i] = (ctx->g.rank == root) ? 0.5 + (double)i * (1.0 + root) : -1.0;
+            PYIPM_HIP(hipMemcpy(a, host.data(), count * sizeof(double), hipMemcpyHostToDevice));
+            PYIPM_HIP(hipMemcpy(b, host.data(), count * sizeof(double), hipMemcpyHostToDevice));
+            if (sag_bcast(ctx, D, a, count, root, D->cs)) { bad = 1.0; ctx->err.clear(); }
+            ncclResult_t rb = g_rccl.Broadcast(b, b, count, ncclDouble, root, D->comm, D->cs);
+            if (rb != ncclSuccess) { hipFree(a); ctx->err = "ncclBroadcast failed in the communicator's self-test"; return PYIPM_E_COMM; }
+            PYIPM_HIP(hipStreamSynchronize(D->cs));
+            PYIPM_HIP(hipMemcpy(got.data(), a, count * sizeof(double), hipMemcpyDeviceToHost));
+            PYIPM_HIP(hipMemcpy(ref.data(), b, count * sizeof(double), hipMemcpyDeviceToHost));
+            if (memcmp(got.data(), ref.data(), count * sizeof(double)) != 0) bad = 1.0;
+        }
+        PYIPM_HIP(hipMemcpy(a, &bad, sizeof(double), hipMemcpyHostToDevice));
+        ncclResult_t ra = g_rccl.AllReduce(a, a, 1, ncclDouble, ncclSum, D->comm, D->cs);
+        if (ra != ncclSuccess) { hipFree(a); ctx->err = "ncclAllReduce failed in the communicator's self-test"; return PYIPM_E_COMM; }
+        PYIPM_HIP(hipStreamSynchronize(D->cs));
+        PYIPM_HIP(hipMemcpy(&bad, a, sizeof(double), hipMemcpyDeviceToHost));
+        PYIPM_HIP(hipFree(a));
+        D->sag = (bad == 0.0) ? 1 : 0;
+    }
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)
 
@@ -608,6 +703,12 @@ int pyipm_newton_comm_ranks(pyipm_newton_ctx* h) try {
     ncclResult_t r = g_rccl.CommCount(ctx->dist->comm, &n);
     if (r != ncclSuccess) { ctx->err = std::string("ncclCommCount: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; }
     return n;
+} PYIPM_CATCH_H(h)
+
+int pyipm_newton_comm_bcast_mode(pyipm_newton_ctx* h) try {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    return (ctx->dist && ctx->dist->comm && ctx->dist->sag) ? 1 : 0;
 } PYIPM_CATCH_H(h)
 
 int64_t pyipm_newton_owned_rows(pyipm_newton_ctx* h, int64_t* rows) try {

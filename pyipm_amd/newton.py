@@ -117,6 +117,7 @@ def load_library(path: str | None = None):
         "pyipm_newton_create_provider": (c_int, [POINTER(ctxp), c_int64, c_int64, c_int64, c_int, c_void_p, c_size_t, c_void_p]),
         "pyipm_newton_comm_init": (c_int, [ctxp, c_void_p]),
         "pyipm_newton_comm_ranks": (c_int, [ctxp]),
+        "pyipm_newton_comm_bcast_mode": (c_int, [ctxp]),
         "pyipm_newton_owned_rows": (c_int64, [ctxp, POINTER(c_int64)]),
         "pyipm_newton_stage_blocks_owned": (c_int, [ctxp, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int]),
         "pyipm_newton_residual_dist": (c_int, [ctxp, c_void_p, c_int]),
@@ -464,6 +465,10 @@ class NewtonCore(object):
         if r < 0:
             self._ck(r)
         return int(r)
+
+    def comm_bcast_mode(self):
+        """1: the panel messages travel as scatter + all-gather over the handle's communicator, 0: ncclBroadcast."""
+        return int(self.lib.pyipm_newton_comm_bcast_mode(self.h))
 
     def residual_dist(self):
         self._use_current_stream()

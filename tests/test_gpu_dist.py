@@ -317,12 +317,16 @@ def _rccl_world_worker(rank, world, port, shape, nb, out):
         core.stage_blocks_owned(qp["d2L"][rows], qp["Je"][rows] if me else None, qp["Ji"][rows] if mi else None)
         core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
         core.set_option("profile", 1)
+        core.set_option("dist_sag_min_bytes", 1024)      # every panel message in the scatter + all-gather form (three ranks or more)
         drv = DistNewton(core, native=True)
         dz, st = drv.step(0.0, 0.0)
         dz2, _ = drv.step(0.0, 0.0)
         tm = core.dist_timings()
+        mode = core.comm_bcast_mode()
+        core.set_option("dist_sag", 0)                    # ... and once more through ncclBroadcast: the same bits
+        dz3, _ = drv.step(0.0, 0.0)
         torch.cuda.synchronize()
-        out[rank] = (dz.cpu().numpy(), float((dz - dz2).norm()), st, core.comm_ranks(), tm)
+        out[rank] = (dz.cpu().numpy(), float((dz - dz2).norm()) + float((dz - dz3).norm()), st, core.comm_ranks(), tm, mode)
     finally:
         dist.destroy_process_group()
 
@@ -331,7 +335,8 @@ def _rccl_world_worker(rank, world, port, shape, nb, out):
 def test_rccl_world_matches_single_rank(world):
     """Runs wherever the box has at least `world` GPUs (skips on the one-GPU development box): handle-owned RCCL
     communicator over `world` real devices, direction equal to the one-rank direction to 1e-12, RCCL itself
-    counting `world` ranks, bytes on the wire as predicted."""
+    counting `world` ranks, bytes on the wire as predicted; with three ranks or more every panel message travels as
+    scatter + all-gather (forced on for these small panels) and once more through ncclBroadcast: the same bits."""
     import torch
     import torch.multiprocessing as mp
     if torch.cuda.device_count() < world:
@@ -350,8 +355,9 @@ def test_rccl_world_matches_single_rank(world):
     out = mgr.dict()
     mp.spawn(_rccl_world_worker, args=(world, _free_port(), shape, nb, out), nprocs=world, join=True)
     for r in range(world):
-        dz, rep, st, ranks, tm = out[r]
+        dz, rep, st, ranks, tm, mode = out[r]
         assert ranks == world
+        assert mode == (1 if world >= 3 else 0)              # scatter + all-gather passed comm_init's self-test (three ranks or more)
         assert np.linalg.norm(dz - dz0) <= 1e-12 * np.linalg.norm(dz0)
         assert rep == 0.0 and st["n_neg"] == me + mi and st["n_zero"] == 0
         assert tm["bytes"] == _factor_bytes(n, me, mi, nb)[0]      # every rank takes part in every broadcast
