@@ -155,7 +155,7 @@ def pmc_traffic(N, nb, bn=256):
     only for the configuration it was measured on; otherwise null."""
     name = "r03_z_pmc_update.json" if bn == 256 else "r03_z_pmc_update_bn128.json"
     path = os.path.join(ROOT, "profiles", name)
-    if N != 32768 or nb != 256 or os.environ.get("PYIPM_NEWTON_GROUP") not in (None, "4") or not os.path.exists(path):
+    if N != 32768 or nb != 256 or os.environ.get("PYIPM_NEWTON_GROUP") not in (None, "8") or not os.path.exists(path):
         return None, None
     try:
         d = json.load(open(path))

@@ -37,10 +37,13 @@ struct Geo {
 
 // Panels aggregated per bulk trailing update (K = group * nb).  Grouping needs the group's panels on
 // one rank, so it applies to single-rank handles; PYIPM_NEWTON_GROUP overrides (read at create time).
-inline int default_group(int world) {
+inline int default_group(int world, int nb = 256) {
     if (world > 1) return 1;
     const char* e = getenv("PYIPM_NEWTON_GROUP");
-    int g = e ? atoi(e) : 4;
+    // 8 panels of 256 since the end of round 3 (K = 2048 per bulk launch while more than tail_cols columns remain, then
+    // tail_group = 4): with the 128 x 256 bulk tiles -1.2 % at N = 32768, -2.7 % at N = 131072 (4 before: no difference with
+    // 128 x 128 tiles).  A group's diagonal block is one chain of at most 32 tile steps: 8 x nb / 64 <= 32.
+    int g = e ? atoi(e) : (nb <= 256 ? 8 : 4);
     if (g < 1) g = 1;
     if (g > 8) g = 8;
     return g;

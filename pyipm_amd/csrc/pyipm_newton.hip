@@ -39,7 +39,7 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base, bool provider_only = fa
     // (a provider-only handle -- pyipm_newton_create_provider: block products and residuals, no factorisation -- has no KKT
     //  storage, no W buffers, no tile inverses: N^2 x 8 bytes that an L-BFGS run never needs)
     const size_t oA = cv.take(provider_only ? 256 : (size_t)g.Npad * (size_t)(g.ncols_local > 0 ? g.ncols_local : 1) * D);
-    const size_t oW = cv.take(provider_only ? 256 : 3 * (size_t)default_group(g.world) * (size_t)g.Npad * g.nb * D);   // -W of a panel group, three rotating buffers (group g+1 is written while g is read)
+    const size_t oW = cv.take(provider_only ? 256 : 3 * (size_t)default_group(g.world, g.nb) * (size_t)g.Npad * g.nb * D);   // -W of a panel group, three rotating buffers (group g+1 is written while g is read)
     const size_t oL = cv.take(g.world > 1 ? (size_t)g.Npad * g.nb * D : 256);
     const size_t oD = cv.take(provider_only ? 256 : (size_t)(g.Npad / TB) * TB * TB * D);
     const size_t oT = cv.take(provider_only ? 256 : (size_t)(g.Npad / TB) * TB * TB * D);
@@ -1513,7 +1513,7 @@ static int create_impl(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t mi
     Ctx* ctx = new Ctx();
     ctx->g = make_geo(n, me, mi, nb, world, rank);
     ctx->gc = make_geo(n, me, 0, nb, 1, 0);          // re-derived by every condensed assemble
-    ctx->group = default_group(world);
+    ctx->group = default_group(world, nb);
     ctx->device = device;
     ctx->stream = (hipStream_t)stream;
     if (hipSetDevice(device) != hipSuccess) return create_fail(ctx, PYIPM_E_NODEVICE);
@@ -2266,7 +2266,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "condensed_refine")) { ctx->cond_min_refine = (int)value < 0 ? 0 : (int)value; return PYIPM_OK; }
     if (!strcmp(name, "lookahead")) { ctx->lookahead = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "group")) {           // may only shrink below the create-time value (workspace is sized for it)
-        int v = (int)value; if (v < 1 || v > default_group(ctx->g.world)) { ctx->err = "group out of range"; return PYIPM_E_BADARG; }
+        int v = (int)value; if (v < 1 || v > default_group(ctx->g.world, ctx->g.nb)) { ctx->err = "group out of range"; return PYIPM_E_BADARG; }
         ctx->group = v; return PYIPM_OK; }
     if (!strcmp(name, "bulk_waves")) { ctx->bulk_waves = (int)value == 8 ? 8 : 4; return PYIPM_OK; }
     if (!strcmp(name, "s_fast")) { ctx->s_fast = (int)value != 0; return PYIPM_OK; }
