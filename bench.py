@@ -345,7 +345,7 @@ def main():
         dom = 256 if inst[256]["flops"] >= inst[128]["flops"] else 128
         oth = 128 if dom == 256 else 256
         if inst[dom]["launches"] == 0:                       # (python driver / no profile: fall back to the sums)
-            inst[dom] = {"launches": n_launch, "ms": trailing_ms, "flops": trailing_flops, "area": trailing_area}
+            inst[dom] = {"launches": n_launch, "ms": trailing_ms, "flops": trailing_flops, "area": 16.0 * trailing_area}
 
         def inst_obj(bn):
             v = inst[bn]
@@ -353,7 +353,7 @@ def main():
             return {"kernel": "k_update<%d,true,8> (fp64 MFMA trailing rank-K update, 128 x %d tiles)" % (bn, bn),
                     "achieved": a_, "frac": a_ / FP64_MFMA_PEAK_TFLOPS, "launches": v["launches"],
                     "avg_launch_ms": v["ms"] / max(v["launches"], 1), "flops_per_launch_avg": v["flops"] / max(v["launches"], 1),
-                    "algorithmic_bytes_per_launch": (16.0 * v["area"] / v["launches"]) if (v["launches"] and world == 1 and not condensed) else None}
+                    "algorithmic_bytes_per_launch": (v["area"] / v["launches"]) if (v["launches"] and world == 1 and not condensed) else None}
         dobj, oobj = inst_obj(dom), inst_obj(oth)
         ach = dobj["achieved"]
         try:
@@ -418,8 +418,8 @@ def main():
             "inertia": {"n_neg": st["n_neg"], "expected": me + mi, "n_zero": st["n_zero"], "n_2x2": st["n_2x2"],
                         "growth": st["growth"]},
         }
-        # (algorithmic bytes per launch: the C-tile read-modify-write, 16 B per matrix entry a launch updates; the operand
-        # panels, read once, add < 10 %)
+        # (algorithmic bytes per launch: the C tiles read and written once, 16 B per matrix entry a launch updates, + the
+        # two operand panels read once -- 37 % on top at K = 2048)
         if dist_ms:
             # rank 0's view of the distributed schedule, per step: wall time of the factorisation, its own panel
             # factorisations (chain), packing, broadcasts as seen on the collective stream, rebuilding L from received

@@ -304,7 +304,8 @@ int pyipm_newton_kkt_storage(pyipm_newton_ctx* ctx, double** ptr, int64_t* ld, i
 int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
 
 /* The bulk trailing-update launches of the last factorisation by kernel instance (profile option on): out[0..3] = launches,
- * summed HIP-event duration (ms), flops, matrix entries updated of the 128 x 128-tile launches (k_update<128,true,8>),
+ * summed HIP-event duration (ms), flops, algorithmic bytes (C tiles read and written once + the two operand panels read
+ * once) of the 128 x 128-tile launches (k_update<128,true,8>),
  * out[4..7] = the same for the 128 x 256-tile launches (k_update<256,true,8>) -- what a kernel trace lists under the two
  * names.  Measurement only; nothing in the reference. */
 int pyipm_newton_trailing_instances(pyipm_newton_ctx* h, double out[8]);

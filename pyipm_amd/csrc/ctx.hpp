@@ -226,8 +226,8 @@ struct Ctx {
     double t_trailing_union = 0; int64_t n_trailing_real = 0;   // time with some update launch running (launches may overlap); launches that did work
     double trailing_flops = 0, trailing_area = 0; int64_t n_trailing = 0;   // area: matrix entries updated, summed over launches
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_trailing;   // reused event pool
-    struct TrailTag { int bn; double flops, area; };
-    std::vector<TrailTag> trailing_tag;   // per bulk launch of the last factorisation: which k_update instance ran, its flops / entries
+    struct TrailTag { int bn; double flops, area; };   // (area: the launch's algorithmic bytes -- C tiles once in, once out, operand panels once)
+    std::vector<TrailTag> trailing_tag;   // per bulk launch of the last factorisation: which k_update instance ran, its flops / bytes
     double inst_ms[2] = {0, 0}, inst_flops[2] = {0, 0}, inst_area[2] = {0, 0}; int64_t inst_n[2] = {0, 0};   // [0]: 128 x 128 tiles, [1]: 128 x 256
     hipEvent_t ev[8] = {};
     hipEvent_t ev_prov[4] = {}; bool prov_valid[2] = {false, false}; double prov_bytes[2] = {0.0, 0.0};   // provider products

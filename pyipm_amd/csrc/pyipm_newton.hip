@@ -729,7 +729,9 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
     ctx->trailing_flops += fl;
     ctx->trailing_area += fl / (2.0 * K);
     if ((size_t)ctx->n_trailing >= ctx->trailing_tag.size()) ctx->trailing_tag.resize((size_t)ctx->n_trailing + 64);
-    ctx->trailing_tag[(size_t)ctx->n_trailing] = {used_bn, fl, fl / (2.0 * K)};
+    // algorithmic bytes of the launch: the C tiles read and written once (16 B per updated entry) + the two operand panels
+    // read once (K columns over the rows below the first updated column)
+    ctx->trailing_tag[(size_t)ctx->n_trailing] = {used_bn, fl, 16.0 * (fl / (2.0 * K)) + 16.0 * (double)K * (double)(g.Npad - row_begin)};
     ctx->n_trailing++;
     return 0;
 }

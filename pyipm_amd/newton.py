@@ -510,7 +510,7 @@ class NewtonCore(object):
         """Bulk update launches of the last factorisation by kernel instance: {128: {...}, 256: {...}} (profile option on)."""
         t = (c_double * 8)()
         self._ck(self.lib.pyipm_newton_trailing_instances(self.h, t))
-        return {bn: {"launches": int(t[4 * k]), "ms": t[4 * k + 1], "flops": t[4 * k + 2], "area": t[4 * k + 3]}
+        return {bn: {"launches": int(t[4 * k]), "ms": t[4 * k + 1], "flops": t[4 * k + 2], "area": t[4 * k + 3]}   # ("area": algorithmic bytes)
                 for k, bn in ((0, 128), (1, 256))}
 
     def dist_timings(self):
