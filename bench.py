@@ -166,6 +166,46 @@ def pmc_traffic(N, nb, bn=256):
         return None, None
 
 
+class Watchdog(object):
+    """A multi-GPU run can stall where no Python code runs (RCCL bootstrap, the communicator's scatter + all-gather
+    self-test, a collective a peer never joined).  The driver would then see no JSON at all.  Every phase that can stall
+    is bracketed by watch(name, seconds); a daemon thread -- ctypes and torch release the GIL while they block -- prints ONE
+    JSON line with an `error` field (rank 0; the other ranks only exit) and ends the process with status 3 when a phase
+    overruns.  VERDICT r3 item 2(c)."""
+
+    def __init__(self, json_fd, rank, base):
+        import threading
+        self.json_fd, self.rank, self.base = json_fd, rank, dict(base)
+        self.phase, self.deadline, self.lock = None, None, threading.Lock()
+        self.done = False
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def watch(self, phase, seconds):
+        with self.lock:
+            self.phase, self.deadline = phase, (time.monotonic() + seconds) if seconds else None
+
+    def clear(self):
+        self.watch(None, None)
+
+    def _run(self):
+        while not self.done:
+            time.sleep(1.0)
+            with self.lock:
+                phase, dl = self.phase, self.deadline
+            if dl is not None and time.monotonic() > dl:
+                if self.rank == 0:
+                    out = dict(self.base)
+                    out.update({"value": None, "error": "watchdog: phase '%s' did not finish in time (stalled collective / "
+                                                         "communicator bring-up?)" % phase, "stalled_phase": phase})
+                    try:
+                        os.write(self.json_fd, (json.dumps(out) + "\n").encode())
+                    except Exception:
+                        pass
+                print("[bench] watchdog: phase '%s' overran on rank %d -- giving up" % (phase, self.rank), file=sys.stderr, flush=True)
+                os._exit(3)
+
+
 def self_launch(nproc):
     """Re-run this command line under torch.distributed.run with one rank per GPU on 127.0.0.1 (free port)."""
     import socket
@@ -201,6 +241,10 @@ def main():
     ap.add_argument("--python-driver", action="store_true", help="distributed runs: the Python loop over the per-panel phases instead of the library's driver")
     ap.add_argument("--selfmsg", action="store_true", help="with --force-dist on one GPU: pack and 'send' every panel anyway (message path cost)")
     ap.add_argument("--opt", action="append", default=[], help="core option name=value (e.g. xcd_swizzle=0, lookahead=0)")
+    ap.add_argument("--config4", choices=("auto", "on", "off"), default="auto",
+                    help="after the timed region also time BASELINE.json's config 4 (n=65536, mi=32768 -> N=131072; 1 warm-up + 2 "
+                         "steps) on the same GPUs and attach it as `config4`: the >= 5x-at-8-GPUs target is stated on THAT size, so "
+                         "every 1-GPU and N-GPU line carries its leg of it.  auto = only with the default headline workload")
     ap.add_argument("--extras", action="store_true",
                     help="after the timed region also run and report (a) the all-dense factorisation (skip_zeros=0) with a "
                          "bitwise check of the direction and (b) one L-BFGS search direction (SURVEY 8f rank 4).  Off by "
@@ -238,6 +282,10 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
+    wd = Watchdog(json_fd, rank, {"metric": "newton_steps_per_sec", "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+                                  "warmup": args.warmup, "higher_is_better": True, "scaling": "strong", "dtype": "f64",
+                                  "data": "synthetic"})
+    wd.watch("process-group initialisation", 600)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -250,56 +298,59 @@ def main():
         args.nb = 256 if world == 1 else 1024
     n, me, mi = args.n, args.me, args.mi
     N = n + 2 * mi + me
-    qp = make_qp_device(n, me, mi, args.seed, device)
-    core = NewtonCore(n, me, mi, device=local_rank, nb=args.nb, world=world, rank=rank)
     want_condensed = any(kv.split("=")[0] == "condensed" and float(kv.split("=")[1]) != 0 for kv in args.opt) and mi > 0
-    if world > 1 and want_condensed:
-        # the condensed option across ranks takes the full blocks on every rank (a column of Ji Sigma Ji' needs every row of Ji)
-        core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
-    elif world > 1:
-        # row-sharded staging: a rank assembles only the KKT columns it owns, i.e. it needs only those rows of
-        # d2L / Je / Ji (every rank generated the same matrices from the same seed; the full copies are dropped)
-        rows = torch.from_numpy(core.owned_rows()).to(device)
-        core.stage_blocks_owned(qp["d2L"].index_select(0, rows), qp["Je"].index_select(0, rows) if me else None,
-                                qp["Ji"].index_select(0, rows) if mi else None)
-        qp["d2L"] = qp["Je"] = qp["Ji"] = None
-        torch.cuda.empty_cache()
-    else:
-        core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
-    core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
-    core.set_option("profile", 1)
-    condensed = False
-    for kv in args.opt:
-        k, v = kv.split("=")
-        core.set_option(k, float(v))
-        if k == "condensed":
-            condensed = float(v) != 0 and mi > 0
+    condensed = want_condensed
 
-    if use_dist:
-        # the library's own per-panel driver (pyipm_newton_step_dist); exchange = a handle-owned RCCL communicator
-        from pyipm_amd.dist import DistNewton
-        drv = DistNewton(core, native=not args.python_driver)
-        drv.force_lookahead = args.force_lookahead
-        if args.selfmsg and world == 1:
-            core.set_option("dist_selfmsg", 1)
+    def build(n, me, mi, seed):
+        """Problem + handle + the step callable for one workload (the headline one, then config 4)."""
+        qp = make_qp_device(n, me, mi, seed, device)
+        core = NewtonCore(n, me, mi, device=local_rank, nb=args.nb, world=world, rank=rank)
+        if world > 1 and want_condensed:
+            # the condensed option across ranks takes the full blocks on every rank (a column of Ji Sigma Ji' needs every row of Ji)
+            core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+        elif world > 1:
+            # row-sharded staging: a rank assembles only the KKT columns it owns, i.e. it needs only those rows of
+            # d2L / Je / Ji (every rank generated the same matrices from the same seed; the full copies are dropped)
+            rows = torch.from_numpy(core.owned_rows()).to(device)
+            core.stage_blocks_owned(qp["d2L"].index_select(0, rows), qp["Je"].index_select(0, rows) if me else None,
+                                    qp["Ji"].index_select(0, rows) if mi else None)
+            qp["d2L"] = qp["Je"] = qp["Ji"] = None
+            torch.cuda.empty_cache()
+        else:
+            core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+        core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+        core.set_option("profile", 1)
+        for kv in args.opt:
+            k, v = kv.split("=")
+            core.set_option(k, float(v))
+        if use_dist:
+            # the library's own per-panel driver (pyipm_newton_step_dist); exchange = a handle-owned RCCL communicator
+            from pyipm_amd.dist import DistNewton
+            wd.watch("communicator bring-up (ncclCommInitRank + scatter/all-gather self-test)", 600)
+            drv = DistNewton(core, native=not args.python_driver)
+            drv.force_lookahead = args.force_lookahead
+            if args.selfmsg and world == 1:
+                core.set_option("dist_selfmsg", 1)
+            return qp, core, (lambda: drv.step(0.0, 0.0, refine=args.refine))
+        return qp, core, (lambda: core.step(0.0, 0.0, refine=args.refine))
 
-        def one_step():
-            return drv.step(0.0, 0.0, refine=args.refine)
-    else:
-        def one_step():
-            return core.step(0.0, 0.0, refine=args.refine)
+    wd.watch("problem generation + staging", 900)
+    qp, core, one_step = build(n, me, mi, args.seed)
 
     def fence():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
+    wd.watch("warm-up steps", 300 + 120 * args.warmup)
     for _ in range(args.warmup):
         one_step()
     trailing_ms = trailing_flops = panel_ms = solve_ms = assemble_ms = gram_ms = trailing_area = 0.0
     n_launch = 0
     inst = {128: {"launches": 0, "ms": 0.0, "flops": 0.0, "area": 0.0}, 256: {"launches": 0, "ms": 0.0, "flops": 0.0, "area": 0.0}}
     dist_ms = {}
+    inst_bytes = {128: {"c_tiles": 0.0, "c_tiles_and_panels": 0.0}, 256: {"c_tiles": 0.0, "c_tiles_and_panels": 0.0}}
+    wd.watch("timed steps", 300 + 120 * args.steps)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -312,11 +363,15 @@ def main():
         for bn, v in core.trailing_instances().items():      # the bulk launches by kernel instance (128 x 128 / 128 x 256 tiles)
             for k2 in v:
                 inst[bn][k2] += v[k2]
+        for bn, v in core.trailing_bytes().items():
+            for k2 in v:
+                inst_bytes[bn][k2] += v[k2]
         if use_dist and not args.python_driver:
             for k, v in core.dist_timings().items():
                 dist_ms[k] = dist_ms.get(k, 0.0) + v
     fence()
     elapsed = time.perf_counter() - t0
+    wd.watch("backward-error check / reductions after the timed region", 600)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -350,10 +405,19 @@ def main():
         def inst_obj(bn):
             v = inst[bn]
             a_ = (v["flops"] / 1e12) / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0
+            ok = bool(v["launches"] and world == 1 and not condensed)
+            traffic = pmc_traffic(N, args.nb, bn)[0]
             return {"kernel": "k_update<%d,true,8> (fp64 MFMA trailing rank-K update, 128 x %d tiles)" % (bn, bn),
                     "achieved": a_, "frac": a_ / FP64_MFMA_PEAK_TFLOPS, "launches": v["launches"],
                     "avg_launch_ms": v["ms"] / max(v["launches"], 1), "flops_per_launch_avg": v["flops"] / max(v["launches"], 1),
-                    "algorithmic_bytes_per_launch": (v["area"] / v["launches"]) if (v["launches"] and world == 1 and not condensed) else None}
+                    # both definitions, so that rounds stay comparable: round 2 counted the C tiles only,
+                    # since round 3 the two operand panels (read once) count as well
+                    "algorithmic_bytes_per_launch": (v["area"] / v["launches"]) if ok else None,
+                    "algorithmic_bytes_per_launch_c_tiles_only": (inst_bytes[bn]["c_tiles"] / v["launches"]) if ok else None,
+                    "algorithmic_bytes_per_launch_c_tiles_and_panels": (inst_bytes[bn]["c_tiles_and_panels"] / v["launches"]) if ok else None,
+                    # the invariant across definitions: HBM-side bytes (PMC) per thousand flops of the launch
+                    "bytes_per_kflop": (traffic / (v["flops"] / v["launches"]) * 1e3) if (traffic and v["launches"] and v["flops"]) else None,
+                    "algorithmic_bytes_per_kflop": (v["area"] / v["flops"] * 1e3) if (ok and v["flops"]) else None}
         dobj, oobj = inst_obj(dom), inst_obj(oth)
         ach = dobj["achieved"]
         try:
@@ -377,6 +441,12 @@ def main():
                          "frac": ach / FP64_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(N, args.nb, dom)[0],
                          "traffic_unit": "bytes per launch (HBM side, PMC)", "traffic_source": pmc_traffic(N, args.nb, dom)[1],
                          "algorithmic_bytes_per_launch": dobj["algorithmic_bytes_per_launch"],
+                         "algorithmic_bytes_per_launch_c_tiles_only": dobj["algorithmic_bytes_per_launch_c_tiles_only"],
+                         "algorithmic_bytes_per_launch_c_tiles_and_panels": dobj["algorithmic_bytes_per_launch_c_tiles_and_panels"],
+                         "algorithmic_bytes_note": "c_tiles_only = 16 B per updated entry (round 2's definition); c_tiles_and_panels "
+                                                   "adds the two operand panels read once (the definition of `algorithmic_bytes_per_launch` "
+                                                   "since round 3); bytes_per_kflop = traffic / flops of a launch is the same under both",
+                         "bytes_per_kflop": dobj["bytes_per_kflop"], "algorithmic_bytes_per_kflop": dobj["algorithmic_bytes_per_kflop"],
                          "launches": dobj["launches"], "avg_launch_ms": dobj["avg_launch_ms"],
                          "flops_per_launch_avg": dobj["flops_per_launch_avg"],
                          "peak_measured_mfma_only": peak_meas,
@@ -463,13 +533,87 @@ def main():
             out["lbfgs_direction"] = lbfgs_block(device)
         out["backward_error"] = berr
         out["backward_error_note"] = "|Hc dz - g|/|g| of the last timed step, Hc from the staged blocks (pyipm_newton_kkt_matvec)"
+
+    # ---- config 4 (N = 131072) on the same GPUs, outside the timed region of `value`: every rank takes part ------------
+    default_workload = (n, me, mi) == (16384, 4096, 6144) and not args.opt and not args.force_dist and not args.python_driver
+    if args.config4 == "on" or (args.config4 == "auto" and default_workload):
+        core.close()
+        one_step = None                                      # (the closure holds the handle and its workspace)
+        del core, qp, dz, raw, g_res
+        torch.cuda.empty_cache()
+        c4 = config4_leg(build, fence, wd, world, rank, device, use_dist, share_gpu)
+        if rank == 0:
+            out["config4"] = c4
+    if rank == 0:
+        wd.watch("cpu baseline", 1800)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(target_N=N)
+        wd.clear()
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    wd.watch("process-group teardown", 300)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    wd.done = True
+
+
+def config4_leg(build, fence, wd, world, rank, device, use_dist, share_gpu, n=65536, me=0, mi=32768, steps=2, warmup=1):
+    """BASELINE.json configs[3] (n=65536, mi=32768 -> KKT dim 131072, 137 GB of KKT storage over the ranks): the size the
+    north star's ">= 5x the 1-GPU steps/s at 8 GPUs" is stated on.  1 warm-up + 2 timed steps with the same fences as the
+    headline (barrier + synchronize, max over ranks), backward error from the blocks, inertia.  Returned on every rank
+    (rank 0 attaches it); {"skipped": why} when the GPUs cannot hold it."""
+    import torch
+    import torch.distributed as dist
+    N = n + 2 * mi + me
+    free, total = torch.cuda.mem_get_info(device)
+    # peak per rank: the generator's transient (M, M M', Q: 3 n^2) or the resident set (its share of the KKT storage and the
+    # panel buffers, its rows of Q / Ji -- all of them on one rank)
+    need = 8.0 * max(3.0 * n * n + 2.0 * n * mi, 1.08 * N * N / world + (n * n + n * mi) / world + n * mi) + 8e9
+    ok = torch.tensor([1.0 if free >= need else 0.0], dtype=torch.float64, device="cpu" if share_gpu else device)
+    if use_dist:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) < 0.5:
+        return {"skipped": "needs %.0f GB of free HBM per GPU, %.0f available" % (need / 1e9, free / 1e9), "kkt_dim": N}
+    wd.watch("config 4: problem generation + staging", 1200)
+    qp, core, one_step = build(n, me, mi, 0)
+    wd.watch("config 4: steps", 600 + 300 * (steps + warmup))
+    for _ in range(warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    fl = ms = 0.0
+    for _ in range(steps):
+        dz, st = one_step()
+        tm = core.timings()
+        fl += tm["trailing_flops"]; ms += tm["trailing_ms"]
+    fence()
+    el = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([el], dtype=torch.float64, device="cpu" if share_gpu else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    raw = dz.clone()
+    raw[n + mi:] *= -1.0
+    if world > 1:
+        g_res = core.residual_dist()
+        berr = float((core.matvec_dist(raw) - g_res).norm() / g_res.norm())
+    else:
+        g_res = core.residual()
+        berr = float((core.matvec(raw) - g_res).norm() / g_res.norm())
+    out = {"workload": "BASELINE.json configs[3]: synthetic convex dense QP Newton step, n=%d me=%d mi=%d -> KKT dim N=%d, seed 0, nb=%d"
+                       % (n, me, mi, N, core.nb if hasattr(core, "nb") else 0),
+           "kkt_dim": N, "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * el / steps,
+           "value": steps / el, "unit": "steps/s",
+           "bulk_update_tflops_rank0": (fl / 1e12) / (ms * 1e-3) if ms > 0 else None,
+           "step_flops_dense_equivalent": N ** 3 / 3.0 + 2.0 * N ** 2,
+           "trailing_flops_executed_per_step_rank0": fl / steps,
+           "backward_error": berr, "inertia": {"n_neg": st["n_neg"], "expected": me + mi, "n_zero": st["n_zero"]},
+           "note": "the 1-GPU line's config4.value is the denominator of the north star's >= 5x target, the 8-GPU line's its numerator"}
+    core.close()
+    del core, qp
+    torch.cuda.empty_cache()
+    return out
 
 
 def lbfgs_block(device, n=131072, me=512, mi=1536, m=8, reps=3):

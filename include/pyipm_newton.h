@@ -192,6 +192,34 @@ int pyipm_newton_create_provider(pyipm_newton_ctx** ctx, int64_t n, int64_t me, 
  * converges to the same value from below (to Xtol = eps).  With mi == 0 both are 1. */
 int pyipm_newton_step_lengths(pyipm_newton_ctx* ctx, double tau, double* alpha_s, double* alpha_l);
 
+/* SURVEY.md section 8(f) rank 1, second half — the merit-function pieces of the line search as device reductions over the
+ * STAGED point (stage_vectors: df, ce, ci, s, lda) and a direction dz (device pointer, N doubles, reference order with the
+ * multiplier block already sign-flipped; NULL = the direction of the last solve()/step(), kept on the device).  Replaces
+ * the host passes of phi / dphi (pyipm.py:670-721, used by search :1438-1565), the merit-parameter update (:1727-1735),
+ * the KKT report (:958-991) and the barrier update (:1804-1814).  One small D2H per call; sums are taken over a fixed
+ * partition in a fixed order (bit-reproducible, independent of the launch).
+ * merit_info: out[16] =
+ *   [0] ||ce||_1   [1] ||ci - s||_1   [2] df . dx   [3] sum ds_i / (s_i + eps)   [4] sum log s_i
+ *   [5] |dL/dx|_2  [6] |s * (lda_i - mu/(s + eps))|_2   [7] |ce|_2   [8] |ci - s|_2      (5, 6: from g = -grad, i.e. after residual(); else NaN)
+ *   [9] sum s_i lda_i   [10] min s_i lda_i   [11] |dx|_2   [12] |ds|_2   [13..15] 0
+ *   so that  phi = f + nu ([0] + [1]) - mu [4],  dphi = [2] - nu ([0] + [1]) - mu [3],  nu threshold = ([2] - mu [3]) / ((1 - rho)([0] + [1])).
+ *   Entries that need a direction are NaN when there is none. */
+int pyipm_newton_merit_info(pyipm_newton_ctx* ctx, const double* dz, double* out16);
+/* out[p] = a_p . b_p for count <= 8 pairs of DEVICE vectors (a, b, len: host arrays) -- e.g. f(x) = x'(Qx)/2 + c'x from the
+ * provider's product; fixed summation order; works on any handle. */
+int pyipm_newton_dots(pyipm_newton_ctx* ctx, int count, const double* const* a, const double* const* b, const int64_t* len,
+                      double* out);
+/* QP family (the staged blocks are the constant Q, A', G' of min x'Qx/2 + c'x, Ax = b, Gx - h >= 0): the merit function
+ * ALONG THE RAY as a difference,  out[k] = phi(x + a_k dx, s + a_k ds) - phi(x, s)  for K <= 1024 candidates a_k at once
+ * (host arrays alphas / out) -- one launch evaluates every backtracking candidate alpha * tau^k of a search
+ * (pyipm.py:1534-1548 shrinks alpha by tau = 0.995 per trial).  f is quadratic and the constraints affine, so with
+ * g1 = df . dx, g2 = dx' Q dx, dce = Je' dx, dci = Ji' dx (formed once per direction from the staged blocks and kept):
+ *   a g1 + a^2 g2 / 2 + nu sum(|ce + a dce| - |ce|) + nu sum(|ci - s + a (dci - ds)| - |ci - s|) - mu sum log1p(a ds / s),
+ * every term a difference formed element by element (error relative to the CHANGE of phi).  quad: NULL = g2 from the staged
+ * d2L block, else *quad is taken for g2 (handles whose Q is not a staged dense block). */
+int pyipm_newton_merit_ray(pyipm_newton_ctx* ctx, const double* dz, double nu, double mu, const double* quad,
+                           const double* alphas, int K, double* out);
+
 /* ---- per-panel phases (multi-GPU host orchestration; single-rank factor() loops these) --- */
 
 /* Factor panel p on its owner: left-looking in-panel updates, tile inversions, scaling. */
@@ -248,8 +276,10 @@ int pyipm_newton_comm_ranks(pyipm_newton_ctx* ctx);
  * piece r to rank r, then an in-place all-gather: W - 1 links of the xGMI mesh at once instead of the one link's bandwidth of
  * ncclBroadcast's ring), 0 = ncclBroadcast.  comm_init switches the first form on for three ranks or more after it has
  * reproduced ncclBroadcast on that communicator (two roots, a count that does not divide by the number of ranks; all ranks
- * agree); the environment variable PYIPM_DIST_SAG=0 or set_option("dist_sag", 0) keep ncclBroadcast.  Messages below 4 MiB
- * and the nb-long exchanges of the sweeps always use ncclBroadcast. */
+ * agree -- first on whether every rank wants the form at all, so PYIPM_DIST_SAG=0 on ONE rank switches it off for all); the
+ * environment variable PYIPM_DIST_SAG=0 or set_option("dist_sag", 0) keep ncclBroadcast.  set_option("dist_sag", 0) is
+ * COLLECTIVE: call it on every rank or on none (a subset would mix the two forms inside one exchange).  Messages below
+ * 4 MiB and the nb-long exchanges of the sweeps always use ncclBroadcast. */
 int pyipm_newton_comm_bcast_mode(pyipm_newton_ctx* ctx);
 /* Row-sharded staging: a rank assembles only the KKT columns it owns, and column j (j < n) of the lower triangle is
  * row j of triu(d2L) | Je | Ji -- so it needs only those rows.  owned_rows returns their number and (rows != NULL)
@@ -309,6 +339,9 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* ctx, double out[8]);
  * out[4..7] = the same for the 128 x 256-tile launches (k_update<256,true,8>) -- what a kernel trace lists under the two
  * names.  Measurement only; nothing in the reference. */
 int pyipm_newton_trailing_instances(pyipm_newton_ctx* h, double out[8]);
+/* The same launches' algorithmic bytes in both definitions: out[k] = C tiles only (16 B per updated entry), out[2 + k] = C tiles +
+ * the two operand panels read once; k = 0: 128 x 128 tiles, k = 1: 128 x 256. */
+int pyipm_newton_trailing_bytes(pyipm_newton_ctx* ctx, double out[4]);
 /* Options (all default to the measured-best setting):
  *   "condensed" 0|1  handles with mi > 0 (several ranks since round 3: with the FULL blocks staged on every rank --
  *                    stage_blocks, not stage_blocks_owned -- assemble / factor_dist / solve_dist / step_dist work on it too,

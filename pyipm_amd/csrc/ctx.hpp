@@ -142,6 +142,7 @@ struct Ctx {
     int bulk_bn_all = 0;                  // bulk_bn = 256 also in the chain-bound phase (m <= persist_rows), where the default keeps the
                                           // persistent 128 x 128 launches that leave CUs to the panel chain
     int sweep_max_blocks = 0;             // test hook: cap on the workgroups of the one-launch sweeps (0 = as many as the GPU holds)
+    int occ_fwd_sweep = 0, occ_bwd_sweep = 0;   // resident workgroups per CU of the one-launch sweeps (occupancy query, cached)
     int sweep_persist = 1;                // single rank, one right-hand side: the backward sweep as ONE device-driven launch (k_bwd_sweep)
     int64_t sweep_buf_n = 0;              // ... (allocated for this many rows)
     double* sweep_buf = nullptr;          // ... the near sums as the column owners hand them to workgroup 0 (Npad doubles, NaN = not there yet)
@@ -208,6 +209,9 @@ struct Ctx {
     double delta = 0.0, delta_c = 0.0;
     bool have_blocks = false, have_vectors = false, have_rhs = false, assembled = false, factored = false;
     bool have_direction = false;          // v2 holds the last sign-flipped direction (for step_lengths)
+    // merit-function pieces (kernels_merit.hpp): scratch, the products of the current direction with the blocks (Q dx | Je' dx | Ji' dx)
+    double* merit_buf = nullptr; double* ray_buf = nullptr; size_t ray_buf_n = 0;
+    const double* ray_for = nullptr; bool ray_valid = false, ray_quad_given = false;
     // last solve (pyipm_newton_solve_info): refinement steps taken, |b - Hc x|/|b| before the first and after the last
     // one (-1 = not measured: a fixed-count solve), 1 = the adaptive loop met its target
     int info_steps = 0, info_converged = 0;
@@ -226,9 +230,9 @@ struct Ctx {
     double t_trailing_union = 0; int64_t n_trailing_real = 0;   // time with some update launch running (launches may overlap); launches that did work
     double trailing_flops = 0, trailing_area = 0; int64_t n_trailing = 0;   // area: matrix entries updated, summed over launches
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_trailing;   // reused event pool
-    struct TrailTag { int bn; double flops, area; };   // (area: the launch's algorithmic bytes -- C tiles once in, once out, operand panels once)
+    struct TrailTag { int bn; double flops, area, cbytes; };   // (area: the launch's algorithmic bytes -- C tiles once in, once out, operand panels once)
     std::vector<TrailTag> trailing_tag;   // per bulk launch of the last factorisation: which k_update instance ran, its flops / bytes
-    double inst_ms[2] = {0, 0}, inst_flops[2] = {0, 0}, inst_area[2] = {0, 0}; int64_t inst_n[2] = {0, 0};   // [0]: 128 x 128 tiles, [1]: 128 x 256
+    double inst_ms[2] = {0, 0}, inst_flops[2] = {0, 0}, inst_area[2] = {0, 0}, inst_cbytes[2] = {0, 0}; int64_t inst_n[2] = {0, 0};   // [0]: 128 x 128 tiles, [1]: 128 x 256
     hipEvent_t ev[8] = {};
     hipEvent_t ev_prov[4] = {}; bool prov_valid[2] = {false, false}; double prov_bytes[2] = {0.0, 0.0};   // provider products
     bool ev_assemble_valid = false, ev_solve_valid = false;

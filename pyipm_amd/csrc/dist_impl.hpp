@@ -212,23 +212,29 @@ struct CsHop {
 int sag_bcast(Ctx* ctx, DistState* D, double* buf, size_t count, int root, hipStream_t cs) {
     const int W = ctx->g.world, me = ctx->g.rank;
     const size_t chunk = (count + (size_t)W - 1) / (size_t)W;
+    // A rank whose scatter stage fails locally still takes part in the all-gather (on whatever its piece holds): its peers
+    // are already inside that collective and would otherwise never return.  The failure is reported afterwards.
+    int rc = 0;
     auto fail = [&](const char* what, ncclResult_t r) {
-        ctx->err = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; };
-    ncclResult_t r = g_rccl.GroupStart(); if (r != ncclSuccess) return fail("ncclGroupStart", r);
-    if (me == root) {
-        for (int q = 0; q < W; ++q) {
-            if (q == root) continue;
-            r = g_rccl.Send(buf + (size_t)q * chunk, chunk, ncclDouble, q, D->comm, cs);
-            if (r != ncclSuccess) { g_rccl.GroupEnd(); return fail("ncclSend", r); }
+        if (!rc) { ctx->err = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); rc = PYIPM_E_COMM; } };
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r != ncclSuccess) fail("ncclGroupStart", r);
+    else {
+        if (me == root) {
+            for (int q = 0; q < W; ++q) {
+                if (q == root) continue;
+                r = g_rccl.Send(buf + (size_t)q * chunk, chunk, ncclDouble, q, D->comm, cs);
+                if (r != ncclSuccess) { fail("ncclSend", r); break; }
+            }
+        } else {
+            r = g_rccl.Recv(buf + (size_t)me * chunk, chunk, ncclDouble, root, D->comm, cs);
+            if (r != ncclSuccess) fail("ncclRecv", r);
         }
-    } else {
-        r = g_rccl.Recv(buf + (size_t)me * chunk, chunk, ncclDouble, root, D->comm, cs);
-        if (r != ncclSuccess) { g_rccl.GroupEnd(); return fail("ncclRecv", r); }
+        r = g_rccl.GroupEnd(); if (r != ncclSuccess) fail("ncclGroupEnd", r);
     }
-    r = g_rccl.GroupEnd(); if (r != ncclSuccess) return fail("ncclGroupEnd", r);
     r = g_rccl.AllGather(buf + (size_t)me * chunk, buf, chunk, ncclDouble, D->comm, cs);
-    if (r != ncclSuccess) return fail("ncclAllGather", r);
-    return 0;
+    if (r != ncclSuccess) fail("ncclAllGather", r);
+    return rc;
 }
 
 int ex_bcast(Ctx* ctx, DistState* D, void* buf, size_t bytes, int root, hipStream_t st) {
@@ -662,34 +668,43 @@ int pyipm_newton_comm_init(pyipm_newton_ctx* h, const void* id128) try {
     // divide by the number of ranks; the ranks agree on the outcome (a sum of failures), so either all use it or none.
     D->sag = 0;
     const char* env = getenv("PYIPM_DIST_SAG");
-    const bool want = !(env && env[0] == '0');
-    if (want && ctx->g.world >= 3 && g_rccl.AllGather && g_rccl.Send && g_rccl.Recv && g_rccl.GroupStart && g_rccl.GroupEnd) {
-        const int W = ctx->g.world;
-        const size_t count = 100003, cap = ((count + W - 1) / W) * W;
-        double *a = nullptr, *b = nullptr;
-        PYIPM_HIP(hipMalloc((void**)&a, 2 * cap * sizeof(double)));
-        b = a + cap;
+    const int W = ctx->g.world;
+    // The environment is read per rank and so is the presence of the entry points: the ranks first AGREE on whether the
+    // form is wanted at all (a minimum over the ranks) -- a rank entering the self-test alone would wait for ever.
+    // Every rank takes part in every collective below whatever happens to it locally; device memory is released on all paths.
+    if (W < 2) return PYIPM_OK;
+    struct DevBuf { double* p = nullptr; ~DevBuf() { if (p) hipFree(p); } } scratch;
+    const size_t count = 100003, cap = ((count + (size_t)W - 1) / (size_t)W) * (size_t)W;
+    PYIPM_HIP(hipMalloc((void**)&scratch.p, (2 * cap + 8) * sizeof(double)));
+    double *a = scratch.p, *b = a + cap, *flag = a + 2 * cap;
+    auto agree = [&](double mine, ncclRedOp_t op, double* out) -> int {
+        PYIPM_HIP(hipMemcpy(flag, &mine, sizeof(double), hipMemcpyHostToDevice));
+        ncclResult_t ra = g_rccl.AllReduce(flag, flag, 1, ncclDouble, op, D->comm, D->cs);
+        if (ra != ncclSuccess) { ctx->err = "ncclAllReduce failed in the communicator's self-test"; return PYIPM_E_COMM; }
+        PYIPM_HIP(hipStreamSynchronize(D->cs));
+        PYIPM_HIP(hipMemcpy(out, flag, sizeof(double), hipMemcpyDeviceToHost));
+        return 0;
+    };
+    const bool mine = !(env && env[0] == '0') && W >= 3 && g_rccl.AllGather && g_rccl.Send && g_rccl.Recv && g_rccl.GroupStart && g_rccl.GroupEnd;
+    double all_want = 0.0;
+    rc = agree(mine ? 1.0 : 0.0, ncclMin, &all_want); if (rc) return rc;
+    if (all_want > 0.5) {
         std::vector<double> host(count), got(count), ref(count);
         double bad = 0.0;
         for (int root : {0, W - 1}) {
             for (size_t i = 0; i < count; ++i) host[i] = (ctx->g.rank == root) ? 0.5 + (double)i * (1.0 + root) : -1.0;
-            PYIPM_HIP(hipMemcpy(a, host.data(), count * sizeof(double), hipMemcpyHostToDevice));
-            PYIPM_HIP(hipMemcpy(b, host.data(), count * sizeof(double), hipMemcpyHostToDevice));
-            if (sag_bcast(ctx, D, a, count, root, D->cs)) { bad = 1.0; ctx->err.clear(); }
-            ncclResult_t rb = g_rccl.Broadcast(b, b, count, ncclDouble, root, D->comm, D->cs);
-            if (rb != ncclSuccess) { hipFree(a); ctx->err = "ncclBroadcast failed in the communicator's self-test"; return PYIPM_E_COMM; }
-            PYIPM_HIP(hipStreamSynchronize(D->cs));
-            PYIPM_HIP(hipMemcpy(got.data(), a, count * sizeof(double), hipMemcpyDeviceToHost));
-            PYIPM_HIP(hipMemcpy(ref.data(), b, count * sizeof(double), hipMemcpyDeviceToHost));
-            if (memcmp(got.data(), ref.data(), count * sizeof(double)) != 0) bad = 1.0;
+            bool local_ok = hipMemcpy(a, host.data(), count * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+                            hipMemcpy(b, host.data(), count * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+            if (sag_bcast(ctx, D, a, count, root, D->cs)) { local_ok = false; ctx->err.clear(); }
+            if (g_rccl.Broadcast(b, b, count, ncclDouble, root, D->comm, D->cs) != ncclSuccess) local_ok = false;
+            if (hipStreamSynchronize(D->cs) != hipSuccess) local_ok = false;
+            if (local_ok) local_ok = hipMemcpy(got.data(), a, count * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
+                                     hipMemcpy(ref.data(), b, count * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+            if (!local_ok || memcmp(got.data(), ref.data(), count * sizeof(double)) != 0) bad = 1.0;
         }
-        PYIPM_HIP(hipMemcpy(a, &bad, sizeof(double), hipMemcpyHostToDevice));
-        ncclResult_t ra = g_rccl.AllReduce(a, a, 1, ncclDouble, ncclSum, D->comm, D->cs);
-        if (ra != ncclSuccess) { hipFree(a); ctx->err = "ncclAllReduce failed in the communicator's self-test"; return PYIPM_E_COMM; }
-        PYIPM_HIP(hipStreamSynchronize(D->cs));
-        PYIPM_HIP(hipMemcpy(&bad, a, sizeof(double), hipMemcpyDeviceToHost));
-        PYIPM_HIP(hipFree(a));
-        D->sag = (bad == 0.0) ? 1 : 0;
+        double total = 1.0;
+        rc = agree(bad, ncclSum, &total); if (rc) return rc;
+        D->sag = (total == 0.0) ? 1 : 0;
     }
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)

@@ -9,6 +9,7 @@
 #include "kernels_panel.hpp"
 #include "kernels_solve.hpp"
 #include "kernels_batched.hpp"
+#include "kernels_merit.hpp"
 
 using namespace pyipm;
 
@@ -307,8 +308,10 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     if (src_c0 >= 0) active_ranges(ctx, src_c0, src_c0 + K, &u.a0, &u.a1, &u.b0, &u.b1);
     else { u.a0 = 0; u.a1 = g.Npad; u.b0 = 0; u.b1 = 0; }
     const int use_waves = waves ? waves : ctx->bulk_waves;
+    // (col_end % 256: Npad is a multiple of 128 only -- a 256-wide tile at the last 128 columns would read and rewrite 128
+    // columns past the storage, i.e. the first W slot, and W rows past Npad; such shapes keep 128 x 128 tiles)
     if (ctx->xcd_swizzle && bulk && ctx->bulk_bn == 256 && use_waves == 8 && waves == 0 && ksplit == 1 && g.nb % 256 == 0 &&
-        K >= ctx->bulk_bn_min_k && head_ct == 0 && nct_sub == 0 && (ctx->bulk_bn_all || ctx->reserve_cus <= 0 || m > (ctx->bulk_bn_rows > ctx->persist_rows ? ctx->bulk_bn_rows : ctx->persist_rows))) {
+        col_end % 256 == 0 && K >= ctx->bulk_bn_min_k && head_ct == 0 && nct_sub == 0 && (ctx->bulk_bn_all || ctx->reserve_cus <= 0 || m > (ctx->bulk_bn_rows > ctx->persist_rows ? ctx->bulk_bn_rows : ctx->persist_rows))) {
         // 128 x 256 tiles (the K = 1024 bulk launches of the single-rank schedule, the K = nb launches of the per-panel one)
         u.nct = (int)(n_lp * (g.nb / 256));
         upd_fill_affine<256>(u);
@@ -731,7 +734,8 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
     if ((size_t)ctx->n_trailing >= ctx->trailing_tag.size()) ctx->trailing_tag.resize((size_t)ctx->n_trailing + 64);
     // algorithmic bytes of the launch: the C tiles read and written once (16 B per updated entry) + the two operand panels
     // read once (K columns over the rows below the first updated column)
-    ctx->trailing_tag[(size_t)ctx->n_trailing] = {used_bn, fl, 16.0 * (fl / (2.0 * K)) + 16.0 * (double)K * (double)(g.Npad - row_begin)};
+    ctx->trailing_tag[(size_t)ctx->n_trailing] = {used_bn, fl, 16.0 * (fl / (2.0 * K)) + 16.0 * (double)K * (double)(g.Npad - row_begin),
+                                                  16.0 * (fl / (2.0 * K))};
     ctx->n_trailing++;
     return 0;
 }
@@ -798,13 +802,14 @@ int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
             uni += x.second - (x.first > hi ? x.first : hi);
             hi = x.second;
         }
-        for (int k = 0; k < 2; ++k) { ctx->inst_ms[k] = 0.0; ctx->inst_flops[k] = 0.0; ctx->inst_area[k] = 0.0; ctx->inst_n[k] = 0; }
+        for (int k = 0; k < 2; ++k) { ctx->inst_ms[k] = 0.0; ctx->inst_flops[k] = 0.0; ctx->inst_area[k] = 0.0; ctx->inst_cbytes[k] = 0.0; ctx->inst_n[k] = 0; }
         for (int64_t i = 0; i < ctx->n_trailing && (size_t)i < ctx->trailing_tag.size(); ++i) {
             float d = 0.f;
             PYIPM_HIP(hipEventElapsedTime(&d, ctx->ev_trailing[i].first, ctx->ev_trailing[i].second));
             if (d <= 0.03f) continue;                            // (empty tile list: see above)
             const int k = ctx->trailing_tag[(size_t)i].bn == 256 ? 1 : 0;
             ctx->inst_ms[k] += d; ctx->inst_flops[k] += ctx->trailing_tag[(size_t)i].flops; ctx->inst_area[k] += ctx->trailing_tag[(size_t)i].area;
+            ctx->inst_cbytes[k] += ctx->trailing_tag[(size_t)i].cbytes;
             ctx->inst_n[k]++;
         }
         ctx->t_trailing = sum;                               // what a kernel trace adds up for the same launches
@@ -917,7 +922,14 @@ int solve_plain(Ctx* ctx, double* v, bool forward_done, int nrhs = 1, int64_t vs
         const int P = (int)g.npanels;
         PYIPM_HIP(hipMemsetAsync(ctx->sweep_sync, 0, (size_t)(P + g.Npad / TB) * sizeof(unsigned), ctx->stream));
         int64_t blocks = 1 + (g.Npad / TB - g.nb / TB);
-        if (blocks > 2 * (int64_t)ctx->num_cus) blocks = 2 * (int64_t)ctx->num_cus;
+        // every workgroup of a sweep must be resident (they wait for each other): the grid comes from an occupancy query of
+        // THIS build of the kernel, not from an assumption about its registers / shared memory
+        if (ctx->occ_fwd_sweep <= 0) {
+            int occ = 0;
+            PYIPM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fwd_sweep, 512, 0));
+            ctx->occ_fwd_sweep = occ < 1 ? 1 : (occ > 2 ? 2 : occ);
+        }
+        if (blocks > (int64_t)ctx->occ_fwd_sweep * ctx->num_cus) blocks = (int64_t)ctx->occ_fwd_sweep * ctx->num_cus;
         if (ctx->sweep_max_blocks > 0 && blocks > ctx->sweep_max_blocks) blocks = ctx->sweep_max_blocks;      // (test hook: several chunks per owner)
         if (blocks < 2) blocks = 2;
         hipLaunchKernelGGL(k_fwd_sweep, dim3((unsigned)blocks), dim3(512), 0, ctx->stream, ctx->A, sg, v, ctx->sweep_sync,
@@ -939,6 +951,12 @@ int solve_plain(Ctx* ctx, double* v, bool forward_done, int nrhs = 1, int64_t vs
         const int64_t groups = g.Npad / 8;
         const int64_t nearb = (g.nb / 8 + 15) / 16;                  // workgroups that only do the next panel's columns
         int64_t blocks = 1 + nearb + (groups + 15) / 16;
+        if (ctx->occ_bwd_sweep <= 0) {
+            int occ = 0;
+            PYIPM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bwd_sweep, 1024, 0));
+            if (occ < 1) { ctx->err = "k_bwd_sweep does not fit a compute unit"; return PYIPM_E_HIP; }
+            ctx->occ_bwd_sweep = 1;                                  // (one workgroup per CU by design, whatever would fit)
+        }
         if (blocks > ctx->num_cus) blocks = ctx->num_cus;
         if (ctx->sweep_max_blocks > 0 && blocks > ctx->sweep_max_blocks) blocks = ctx->sweep_max_blocks;
         if (blocks < 2 + nearb) blocks = 2 + nearb;
@@ -1678,6 +1696,8 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     if (ctx->head_counters) hipFree(ctx->head_counters);
     if (ctx->sweep_sync) hipFree(ctx->sweep_sync);
     if (ctx->sweep_buf) hipFree(ctx->sweep_buf);
+    if (ctx->merit_buf) hipFree(ctx->merit_buf);
+    if (ctx->ray_buf) hipFree(ctx->ray_buf);
     if (ctx->own_ws && ctx->ws) hipFree(ctx->ws);
     delete ctx;
     return PYIPM_OK;
@@ -1714,6 +1734,7 @@ int pyipm_newton_stage_blocks(pyipm_newton_ctx* h, const double* d2L, int64_t ld
     rc = stage_block(ctx, Je, g.me ? g.n : 0, g.me, ld_Je, memkind, &ctx->stg_Je, &ctx->stg_Je_sz, &ctx->Je, &ctx->ld_Je); if (rc) return rc;
     rc = stage_block(ctx, Ji, g.mi ? g.n : 0, g.mi, ld_Ji, memkind, &ctx->stg_Ji, &ctx->stg_Ji_sz, &ctx->Ji, &ctx->ld_Ji); if (rc) return rc;
     ctx->have_blocks = true;
+    ctx->ray_valid = false;
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)
 
@@ -1731,6 +1752,8 @@ int pyipm_newton_stage_vectors(pyipm_newton_ctx* h, const double* df, const doub
     rc = put_vec(ctx, ctx->lda, lda, B * (g.me + g.mi), memkind); if (rc) return rc;
     ctx->mu = mu; ctx->eps = eps;
     ctx->have_vectors = true;
+    ctx->have_rhs = false;                        // (g = -grad belongs to the vectors staged before)
+    ctx->ray_valid = false;
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)
 
@@ -1845,6 +1868,7 @@ static int solve_finish(Ctx* ctx, double* dz, int flip, int refine, int memkind,
     rc = copy_out(ctx, dz, ctx->v2, g.N, memkind); if (rc) return rc;
     ctx->ev_solve_valid = true;
     ctx->have_direction = (flip != 0) || (g.me + g.mi == 0);     // v2 = dz with the reference's sign convention
+    ctx->ray_valid = false;                                      // (merit_ray: the products of the OLD direction)
     return PYIPM_OK;
 }
 
@@ -1898,6 +1922,7 @@ int pyipm_newton_rcond(pyipm_newton_ctx* h, int it_inv, int it_pow, double out[4
     if (it_inv < 1) it_inv = 3;
     if (it_pow < 1) it_pow = 6;
     ctx->forward_pending = false; ctx->have_direction = false;       // v0..v2 / vc are about to be reused
+    ctx->ray_valid = false;
     double ss[2], lmax = 0.0, linv = 0.0;
     auto norm_of = [&](const double* v, double* nrm) -> int {
         hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, ctx->stream, ctx->partial, v, v, g.N);
@@ -1946,11 +1971,17 @@ int pyipm_newton_anorm(pyipm_newton_ctx* h, double** dev_ptr) try {
 // The reference evaluates df = Q x + c, ce = A x - b, ci = G x - h and the Jacobian-transpose products of the KKT report
 // through compiled Aesara functions on the host (pyipm.py:855-954).  For a QP the blocks are constant and already staged,
 // so these are passes over the staged d2L (its UPPER triangle, as everywhere), Je and Ji.
+static int block_products_dev(Ctx* ctx, const double* v, double* Qv, double* JeTv, double* JiTv);
 int pyipm_newton_block_products(pyipm_newton_ctx* h, const double* v, double* Qv, double* JeTv, double* JiTv) try {
     if (check_ctx(h) || !v) return PYIPM_E_BADARG;
-    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    Ctx* ctx = C(h);
     if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
+    return block_products_dev(ctx, v, Qv, JeTv, JiTv);
+} PYIPM_CATCH_H(h)
+
+static int block_products_dev(Ctx* ctx, const double* v, double* Qv, double* JeTv, double* JiTv) {
+    const Geo& g = ctx->g;
     if (g.world != 1 || ctx->sharded) { ctx->err = "block_products: single-rank handles with fully staged blocks"; return PYIPM_E_BADARG; }
     if (!ctx->have_blocks) { ctx->err = "block_products: stage blocks first"; return PYIPM_E_BADARG; }
     if (Qv && !ctx->d2L) { ctx->err = "block_products: no d2L block staged on this provider-only handle (pass Qv = NULL)"; return PYIPM_E_BADARG; }
@@ -1989,7 +2020,7 @@ int pyipm_newton_block_products(pyipm_newton_ctx* h, const double* v, double* Qv
     if (ctx->profile) { PYIPM_HIP(hipEventRecord(ctx->ev_prov[1], ctx->stream)); ctx->prov_valid[0] = true; }
     ctx->prov_bytes[0] = bytes;
     return PYIPM_OK;
-} PYIPM_CATCH_H(h)
+}
 
 // out (n) = Je le + Ji li  (either may be NULL): the Jacobian terms of dL/dx (pyipm.py:655-668)
 int pyipm_newton_block_products_t(pyipm_newton_ctx* h, const double* le, const double* li, double* out) try {
@@ -2059,6 +2090,113 @@ int pyipm_newton_step_lengths(pyipm_newton_ctx* h, double tau, double* alpha_s, 
     PYIPM_HIP(hipMemcpyAsync(out, ctx->partial, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     PYIPM_HIP(hipStreamSynchronize(ctx->stream));
     *alpha_s = out[0]; *alpha_l = out[1];
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+// ---- merit-function pieces of the line search (kernels_merit.hpp) -----------------------------
+static int merit_scratch(Ctx* ctx) {
+    if (ctx->merit_buf) return 0;
+    // [partials | info out (MERIT_NQ) | gq (2) | dots (8) | alphas (MERIT_MAXK) | ray out (MERIT_MAXK)]
+    PYIPM_HIP(hipMalloc((void**)&ctx->merit_buf, (size_t)(MERIT_NB * MERIT_NQ + MERIT_NQ + 2 + 8 + 2 * 1024) * sizeof(double)));
+    return 0;
+}
+static const double* merit_direction(Ctx* ctx, const double* dz, const char* who) {
+    if (dz) return dz;
+    if (!ctx->have_direction) { ctx->err = std::string(who) + ": no direction (solve with flip first, or pass dz)"; return nullptr; }
+    return ctx->v2;
+}
+
+// out[16] for the STAGED point (stage_vectors) and the direction dz (device, reference order, multipliers flipped; NULL = the
+// last solve's; a handle without one: the direction entries come back as NaN):
+//   [0] ||ce||_1  [1] ||ci - s||_1  [2] df.dx  [3] sum ds/(s+eps)  [4] sum log s
+//   [5..8] the KKT report |dL/dx|, |s (lda_i - mu/(s+eps))|, |ce|, |ci - s| (2-norms; from g = -grad: NaN before residual())
+//   [9] sum s lda_i  [10] min s lda_i  [11] |dx|_2  [12] |ds|_2
+int pyipm_newton_merit_info(pyipm_newton_ctx* h, const double* dz, double* out) try {
+    if (check_ctx(h) || !out) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    if (g.world != 1) { ctx->err = "merit_info: single-rank handles"; return PYIPM_E_BADARG; }
+    if (!ctx->have_vectors) { ctx->err = "merit_info: stage vectors first"; return PYIPM_E_BADARG; }
+    int rc = merit_scratch(ctx); if (rc) return rc;
+    const double* d = dz ? dz : (ctx->have_direction ? ctx->v2 : nullptr);
+    const double* gres = ctx->have_rhs ? ctx->rhs : nullptr;
+    double* part = ctx->merit_buf; double* res = part + MERIT_NB * MERIT_NQ;
+    hipLaunchKernelGGL(k_merit_info, dim3(MERIT_NB), dim3(256), 0, ctx->stream, part, g, ctx->df, ctx->ce, ctx->ci, ctx->s,
+                       ctx->lda, d, gres, ctx->eps);
+    PYIPM_KCHECK();
+    hipLaunchKernelGGL(k_merit_info_final, dim3(1), dim3(64), 0, ctx->stream, res, part, MERIT_NB);
+    PYIPM_KCHECK();
+    double q[MERIT_NQ];
+    PYIPM_HIP(hipMemcpyAsync(q, res, sizeof(q), hipMemcpyDeviceToHost, ctx->stream));
+    PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+    const double nan = __builtin_nan("");
+    for (int k = 0; k < MERIT_NQ; ++k) out[k] = q[k];
+    for (int k = 5; k <= 8; ++k) out[k] = sqrt(q[k]);
+    out[11] = sqrt(q[11]); out[12] = sqrt(q[12]);
+    if (!d) { out[2] = out[3] = out[11] = out[12] = nan; }
+    if (!gres) { out[5] = out[6] = nan; }
+    if (g.mi == 0) out[10] = nan;
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+// out[p] = a_p . b_p, count <= 8 pairs of device vectors (host array of device pointers); fixed summation order.
+int pyipm_newton_dots(pyipm_newton_ctx* h, int count, const double* const* a, const double* const* b, const int64_t* len,
+                      double* out) try {
+    if (check_ctx(h) || !a || !b || !len || !out || count < 1 || count > 8) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    int rc = merit_scratch(ctx); if (rc) return rc;
+    DotPairs dp; memset(&dp, 0, sizeof(dp));
+    for (int p = 0; p < count; ++p) { dp.a[p] = a[p]; dp.b[p] = b[p]; dp.len[p] = len[p]; if ((!a[p] || !b[p]) && len[p] > 0) return PYIPM_E_BADARG; }
+    double* dev = ctx->merit_buf + MERIT_NB * MERIT_NQ + MERIT_NQ + 2;
+    hipLaunchKernelGGL(k_dots, dim3((unsigned)count), dim3(1024), 0, ctx->stream, dev, dp);
+    PYIPM_KCHECK();
+    PYIPM_HIP(hipMemcpyAsync(out, dev, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+// QP family (the staged blocks are the constant Q, A', G'): phi(x + a dx, s + a ds) - phi(x, s) for K candidates a at once
+// (k_merit_ray).  The products Q dx, Je' dx, Ji' dx and the two dot products are formed once per direction and kept until the
+// next solve / stage_vectors.  quad: NULL = dx' d2L dx from the staged block, else *quad (a caller whose Q is not staged).
+int pyipm_newton_merit_ray(pyipm_newton_ctx* h, const double* dz, double nu, double mu, const double* quad,
+                           const double* alphas, int K, double* out) try {
+    if (check_ctx(h) || !alphas || !out || K < 1 || K > 1024) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    if (g.world != 1 || ctx->sharded) { ctx->err = "merit_ray: single-rank handles with fully staged blocks"; return PYIPM_E_BADARG; }
+    if (!ctx->have_vectors || !ctx->have_blocks) { ctx->err = "merit_ray: stage blocks and vectors first"; return PYIPM_E_BADARG; }
+    const double* d = merit_direction(ctx, dz, "merit_ray"); if (!d) return PYIPM_E_BADARG;
+    if (!quad && !ctx->d2L) { ctx->err = "merit_ray: no d2L block staged (pass quad = dx' Q dx)"; return PYIPM_E_BADARG; }
+    int rc = merit_scratch(ctx); if (rc) return rc;
+    const size_t need = (size_t)(g.n + g.me + g.mi + 8);
+    if (ctx->ray_buf_n < need) {
+        if (ctx->ray_buf) { PYIPM_HIP(hipStreamSynchronize(ctx->stream)); PYIPM_HIP(hipFree(ctx->ray_buf)); ctx->ray_buf = nullptr; ctx->ray_buf_n = 0; }
+        PYIPM_HIP(hipMalloc((void**)&ctx->ray_buf, need * sizeof(double)));
+        ctx->ray_buf_n = need; ctx->ray_for = nullptr;
+    }
+    double* qd = ctx->ray_buf; double* dce = qd + g.n; double* dci = dce + g.me;
+    double* gq = ctx->merit_buf + MERIT_NB * MERIT_NQ + MERIT_NQ;
+    double* dal = gq + 2 + 8; double* dout = dal + 1024;
+    if (ctx->ray_for != d || !ctx->ray_valid) {
+        rc = block_products_dev(ctx, d, quad ? nullptr : qd, g.me ? dce : nullptr, g.mi ? dci : nullptr); if (rc) return rc;
+        DotPairs dp; memset(&dp, 0, sizeof(dp));
+        dp.a[0] = ctx->df; dp.b[0] = d; dp.len[0] = g.n;
+        dp.a[1] = d; dp.b[1] = qd; dp.len[1] = quad ? 0 : g.n;
+        hipLaunchKernelGGL(k_dots, dim3(2), dim3(1024), 0, ctx->stream, gq, dp);
+        PYIPM_KCHECK();
+        ctx->ray_for = d; ctx->ray_valid = true; ctx->ray_quad_given = quad != nullptr;
+    }
+    if (quad) PYIPM_HIP(hipMemcpyAsync(gq + 1, quad, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    else if (ctx->ray_quad_given) { ctx->ray_valid = false; ctx->err = "merit_ray: quad given for this direction before, missing now"; return PYIPM_E_BADARG; }
+    PYIPM_HIP(hipMemcpyAsync(dal, alphas, (size_t)K * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_merit_ray, dim3((unsigned)K), dim3(256), 0, ctx->stream, dout, dal, g, gq, ctx->ce, dce, ctx->ci, dci,
+                       ctx->s, d + g.n, nu, mu);
+    PYIPM_KCHECK();
+    PYIPM_HIP(hipMemcpyAsync(out, dout, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PYIPM_HIP(hipStreamSynchronize(ctx->stream));
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)
 
@@ -2242,6 +2380,16 @@ int pyipm_newton_trailing_instances(pyipm_newton_ctx* h, double out[8]) try {
         out[4 * k + 0] = (double)ctx->inst_n[k]; out[4 * k + 1] = ctx->inst_ms[k];
         out[4 * k + 2] = ctx->inst_flops[k]; out[4 * k + 3] = ctx->inst_area[k];
     }
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+// The bulk launches' algorithmic bytes in both definitions (rounds must stay comparable):
+// out[k] = C tiles only (16 B per updated entry: read once, written once), out[2 + k] = C tiles + the two operand panels read once
+// (what trailing_instances reports); k = 0: 128 x 128 tiles, k = 1: 128 x 256.  Sums over the launches of the last factorisation.
+int pyipm_newton_trailing_bytes(pyipm_newton_ctx* h, double out[4]) try {
+    if (check_ctx(h) || !out) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    for (int k = 0; k < 2; ++k) { out[k] = ctx->inst_cbytes[k]; out[2 + k] = ctx->inst_area[k]; }
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)
 

@@ -46,6 +46,10 @@ class HipNewtonBackend(object):
     * Without static pivots the "rcond <= eps" trigger is "d_min/d_max <= eps" on the block pivots."""
 
     berr_tol = 1e-11                       # backward error a refined direction must meet to count as converged
+    berr_fallback = float(np.sqrt(np.finfo(float).eps))   # ... and the bar of the LAST resort: when no shift within the budget
+                                           # yields a converged direction, the best one seen is returned if it meets this (the
+                                           # reference returns its LU direction whatever its accuracy, pyipm.py:1720-1721) and
+                                           # counted in n_inexact; only beyond it the backend gives up (ADVICE r3)
 
     def __init__(self, n, me, mi, device=None, nb=256, refine=0, max_shift_tries=60, device_step=False,
                  condensed=False):
@@ -66,6 +70,8 @@ class HipNewtonBackend(object):
         self.n_factor = 0
         self.n_static = 0                   # directions recovered from a statically pivoted factor
         self.n_unconverged = 0              # refined solves that missed berr_tol and were sent to the shift branch
+        self.n_inertia_retries = 0          # shifted factorisations whose inertia was still wrong (delta *= 10, pyipm.py:1399-1403)
+        self.n_inexact = 0                  # directions returned on berr_fallback after the shift budget was spent
         self.last_solve_info = None
 
     def shape(self):
@@ -97,17 +103,35 @@ class HipNewtonBackend(object):
         Block pivots of moderate spread cannot hide an eigenvalue ratio at the eps level; otherwise, and whenever
         static pivots were placed, the ratio is ESTIMATED from the factor and the blocks (``core.rcond``: inverse /
         power iterations).  With static pivots the factor is that of a perturbed matrix, whose smallest eigenvalue
-        sits at the perturbation level exactly when the unperturbed matrix is singular."""
+        sits at the perturbation level exactly when the unperturbed matrix is singular.
+
+        The estimate costs three substitution sweeps and six passes over the blocks (15 ms at N = 32768, a seventh of a
+        Newton step) and late in an interior-point run the pivot spread stays below ``suspect_spread`` at EVERY iterate
+        (Sigma = lda_i / s spans twenty decades by itself).  Consecutive iterates differ by one damped Newton step, so an
+        estimate is reused while it left a wide margin (``rcond >= reuse_margin * eps``) and the pivot spread has not
+        dropped by more than ``reuse_drop`` since it was taken; never with static pivots, never after a shift."""
         self.last_rcond = None
         if st["nonfinite"]:
             return True
         spread = st["d_min"] / st["d_max"] if st["d_max"] > 0 else 1.0
         if st["n_zero"] == 0 and spread > self.suspect_spread:
+            self._rcond_seen = None
+            return False
+        seen = self._rcond_seen
+        if (st["n_zero"] == 0 and seen is not None and seen[0] >= self.reuse_margin * eps and
+                spread >= self.reuse_drop * seen[1] and self.n_calls - seen[2] <= self.reuse_calls):
+            self.n_rcond_reused += 1
             return False
         est = self.last_rcond = self.core.rcond()
+        self.n_rcond += 1
+        self._rcond_seen = (est["rcond"], spread, self.n_calls) if st["n_zero"] == 0 else None
         if st["n_zero"] > 0 and est["w_min"] <= 100.0 * est["static_pivot"]:
             return True
         return est["rcond"] <= eps
+
+    reuse_margin, reuse_drop, reuse_calls = 1.0e3, 1.0e-2, 4   # see _singular; reuse_calls = 0 estimates at every suspect iterate
+    _rcond_seen = None
+    n_rcond = n_rcond_reused = 0
 
     @staticmethod
     def _at_risk(st):
@@ -126,13 +150,18 @@ class HipNewtonBackend(object):
         return core.solve(flip=True, refine=self.refine), True
 
     def direction(self, d2L, Je, Ji, df, ce, ci, s, lda, mu, delta, mu_host, eta, beta, reg_coef, delta0, eps,
-                  as_tensor=False):
-        """as_tensor: inputs may be device tensors (staged without copies) and dz stays on the device."""
+                  as_tensor=False, staged=False, g=None):
+        """as_tensor: inputs may be device tensors (staged without copies) and dz stays on the device.
+        staged: the caller has already staged the blocks (constant for a QP: once per solve) and this point's vectors and
+        formed g = -grad in the handle (``core.residual()``, passed as ``g``) -- nothing is staged again here."""
         core, need = self.core, self.me + self.mi
         self.n_calls += 1
-        core.stage_blocks(d2L, Je, Ji)
-        core.stage_vectors(df, ce, ci, s, lda, mu=mu, eps=eps)
-        g = core.residual()
+        if not staged:
+            core.stage_blocks(d2L, Je, Ji)
+            core.stage_vectors(df, ce, ci, s, lda, mu=mu, eps=eps)
+            g = core.residual()
+        elif g is None and self.condensed_on:
+            g = core.residual()
         if self.condensed_on:
             # Condensed system first (2x fewer flops at the benchmark shape).  The block pivots are explicit
             # 64x64 inverses, so a dense ill-conditioned tile (Sigma spanning > ~1e8 late in a run) costs
@@ -166,6 +195,18 @@ class HipNewtonBackend(object):
         st = self._factor()
         singular = self._singular(st, eps)
         dz = None
+        best = None                        # (backward error, dz, delta, stats) of the best unconverged direction so far
+
+        def remember(dz_, delta_, st_):
+            nonlocal best
+            info = self.last_solve_info
+            be = info["backward_error"] if info else -1.0
+            # the LEAST shifted direction that meets berr_fallback is kept (the reference does not shift such a system at
+            # all); below that bar, the most accurate one
+            if dz_ is not None and be >= 0.0 and np.isfinite(be) and \
+                    (best is None or (best[0] > self.berr_fallback and be < best[0])):
+                best = (be, dz_.clone() if hasattr(dz_, "clone") else dz_, float(delta_), st_)
+
         if not singular and st["n_neg"] == need:
             dz, converged = self._solve(st)
             if not converged:
@@ -173,10 +214,12 @@ class HipNewtonBackend(object):
                 # berr_tol solves a nearby system, not this one: what the reference's LU would flag as rcond <= eps.
                 # Take the branch reghess takes then (pyipm.py:1379-1403) instead of returning the direction silently.
                 self.n_unconverged += 1
+                remember(dz, 0.0, st)
                 dz, singular = None, True
             elif st["n_zero"] > 0:
                 self.n_static += 1         # reference: LU over the whole matrix, no shift (pyipm.py:1381 not taken)
         if dz is None:
+            self._rcond_seen = None         # (a shifted system is another matrix: its estimate is not carried over)
             delta_c = reg_coef * eta * (mu_host ** beta) if (singular and self.me) else 0.0
             delta = delta0 if delta == 0.0 else max(delta / 2.0, delta0)
             tries = 0
@@ -186,22 +229,31 @@ class HipNewtonBackend(object):
                 if st["n_neg"] == need and not st["nonfinite"]:
                     break
                 tries += 1
+                self.n_inertia_retries += 1
                 if tries > self.max_shift_tries:
                     raise RuntimeError("inertia not corrected after %d diagonal shifts" % tries)
                 delta *= 10.0
             dz, converged = self._solve(st)
             while not converged:
                 # still no direction that satisfies the blocks: the shift has not made the factor trustworthy yet.
-                # Larger shift (the reference's delta *= 10 loop, :1399-1403), then give up loudly.
+                # Larger shift (the reference's delta *= 10 loop, :1399-1403); when the budget is spent, the best direction
+                # seen if it is at least berr_fallback-accurate (shifted or not), else give up loudly.
                 self.n_unconverged += 1
+                remember(dz, delta, st)
                 tries += 1
                 if tries > self.max_shift_tries:
+                    if best is not None and best[0] <= self.berr_fallback:
+                        self.n_inexact += 1
+                        dz, delta, st = best[1], best[2], best[3]
+                        break
                     raise RuntimeError("refined solve did not reach backward error %.1e after %d diagonal shifts (last: %s)"
                                        % (self.berr_tol, tries, self.last_solve_info))
                 delta *= 10.0
                 core.assemble(delta, delta_c)
                 st = self._factor()
                 if st["n_neg"] != need or st["nonfinite"]:
+                    self.n_inertia_retries += 1
+                    self.n_unconverged -= 1          # (an inertia retry, not an unconverged solve: counted on its own)
                     continue
                 dz, converged = self._solve(st)
         if not as_tensor:

@@ -84,6 +84,10 @@ def load_library(path: str | None = None):
         "pyipm_newton_kkt_matvec": (c_int, [ctxp, c_void_p, c_void_p, c_int]),
         "pyipm_newton_step": (c_int, [ctxp, c_double, c_double, c_int, c_void_p, POINTER(FactorStats), c_int]),
         "pyipm_newton_step_lengths": (c_int, [ctxp, c_double, POINTER(c_double), POINTER(c_double)]),
+        "pyipm_newton_merit_info": (c_int, [ctxp, c_void_p, POINTER(c_double)]),
+        "pyipm_newton_dots": (c_int, [ctxp, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), POINTER(c_double)]),
+        "pyipm_newton_merit_ray": (c_int, [ctxp, c_void_p, c_double, c_double, POINTER(c_double), POINTER(c_double), c_int,
+                                           POINTER(c_double)]),
         "pyipm_newton_factor_panel": (c_int, [ctxp, c_int64]),
         "pyipm_newton_panel_msg_bytes": (c_size_t, [ctxp, c_int64]),
         "pyipm_newton_panel_pack": (c_int, [ctxp, c_int64, c_void_p]),
@@ -98,6 +102,7 @@ def load_library(path: str | None = None):
         "pyipm_newton_kkt_storage": (c_int, [ctxp, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64)]),
         "pyipm_newton_last_timings": (c_int, [ctxp, POINTER(c_double)]),
         "pyipm_newton_trailing_instances": (c_int, [ctxp, POINTER(c_double)]),
+        "pyipm_newton_trailing_bytes": (c_int, [ctxp, POINTER(c_double)]),
         "pyipm_newton_set_option": (c_int, [ctxp, c_char_p, c_double]),
         "pyipm_newton_workspace_bytes_batched": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
         "pyipm_newton_create_batched": (c_int, [POINTER(c_void_p), c_int64, c_int64, c_int64, c_int, c_int,
@@ -366,6 +371,40 @@ class NewtonCore(object):
         self._ck(self.lib.pyipm_newton_step_lengths(self.h, float(tau), ctypes.byref(a_s), ctypes.byref(a_l)))
         return a_s.value, a_l.value
 
+    MERIT_KEYS = ("ce_l1", "cis_l1", "df_dx", "ds_over_s", "sum_log_s", "kkt_x", "kkt_s", "kkt_ce", "kkt_ci", "comp_sum",
+                  "comp_min", "dx_norm", "ds_norm")
+
+    def merit_info(self, dz=None):
+        """Merit-function pieces for the staged point and the direction ``dz`` (device tensor; None = the last solve's):
+        ``pyipm_newton_merit_info`` -- see include/pyipm_newton.h.  One launch pair, one D2H of 16 doubles."""
+        self._use_current_stream()
+        out = (c_double * 16)()
+        self._ck(self.lib.pyipm_newton_merit_info(self.h, self._ptr(dz) if dz is not None else None, out))
+        return dict(zip(self.MERIT_KEYS, out[:13]))
+
+    def dots(self, pairs):
+        """[a . b for (a, b) in pairs] for up to 8 pairs of device vectors: one launch, one D2H."""
+        self._use_current_stream()
+        k = len(pairs)
+        A = (c_void_p * k)(*[self._ptr(a) for a, _ in pairs])
+        B = (c_void_p * k)(*[self._ptr(b) for _, b in pairs])
+        L = (c_int64 * k)(*[int(a.numel()) for a, _ in pairs])
+        out = (c_double * k)()
+        self._ck(self.lib.pyipm_newton_dots(self.h, k, A, B, L, out))
+        return list(out)
+
+    def merit_ray(self, alphas, nu, mu, dz=None, quad=None):
+        """phi(x + a dx, s + a ds) - phi(x, s) for every a in ``alphas`` (QP family; ``pyipm_newton_merit_ray``): one launch
+        for all candidates, one D2H of len(alphas) doubles."""
+        self._use_current_stream()
+        k = len(alphas)
+        al = (c_double * k)(*[float(a) for a in alphas])
+        out = (c_double * k)()
+        q = ctypes.byref(c_double(float(quad))) if quad is not None else None
+        self._ck(self.lib.pyipm_newton_merit_ray(self.h, self._ptr(dz) if dz is not None else None, float(nu), float(mu), q,
+                                                 al, k, out))
+        return list(out)
+
     # -- per-panel phases (used by pyipm_amd.dist) ----------------------------------------------
     def factor_begin(self):
         self._ck(self.lib.pyipm_newton_factor_begin(self.h))
@@ -512,6 +551,13 @@ class NewtonCore(object):
         self._ck(self.lib.pyipm_newton_trailing_instances(self.h, t))
         return {bn: {"launches": int(t[4 * k]), "ms": t[4 * k + 1], "flops": t[4 * k + 2], "area": t[4 * k + 3]}   # ("area": algorithmic bytes)
                 for k, bn in ((0, 128), (1, 256))}
+
+    def trailing_bytes(self):
+        """Algorithmic bytes of the last factorisation's bulk launches in both definitions, by instance:
+        {bn: {"c_tiles": .., "c_tiles_and_panels": ..}}."""
+        t = (c_double * 4)()
+        self._ck(self.lib.pyipm_newton_trailing_bytes(self.h, t))
+        return {bn: {"c_tiles": t[k], "c_tiles_and_panels": t[2 + k]} for k, bn in ((0, 128), (1, 256))}
 
     def dist_timings(self):
         t = (c_double * 8)()

@@ -99,10 +99,11 @@ class QPDeviceIPM(object):
             self.core = self.backend.core
             self.core.stage_blocks(self.Q, self.Je, self.Ji)       # constant blocks: device pointers, staged once
         self._pcache = (None, None)
+        self._staged_key, self._staged_keep, self._info, self._g = None, None, None, None
         self.trace = None                   # set to [] to record (x, s, lda, mu) at every Newton step
         self.signal = 0
         self.iter_count = 0
-        self.timings = {"newton_s": 0.0, "search_s": 0.0, "n_phi": 0}
+        self.timings = {"newton_s": 0.0, "search_s": 0.0, "n_phi": 0, "n_ray": 0, "newton_each_s": []}
 
     # ------------------------------------------------------------------ provider (pyipm.py:855-954 on the device)
     def _products(self, v):
@@ -123,7 +124,7 @@ class QPDeviceIPM(object):
         return self._products(x)[0]
 
     def f(self, x):
-        return float(0.5 * self.torch.dot(x, self.Qx(x)) + self.torch.dot(self.c, x))
+        return float(self.f_dev(x))
 
     def df(self, x):
         return self.Qx(x) + self.c
@@ -156,61 +157,62 @@ class QPDeviceIPM(object):
         return (gx, (lda[me:] - self.mu_host / (s + self.eps)) if mi else None,
                 self.ce(x) if me else None, (self.ci(x) - s) if mi else None)
 
+    # -- the point (x, s, lda) as the library sees it: staged vectors + residual, done once per point -----------------
+    def _stage_point(self, x, s, lda):
+        """df, ce, ci (the provider's products, one library call), s, lda staged into the handle and g = -grad formed there
+        (pyipm_newton_residual) -- ONCE per point and barrier parameter: the KKT report, the merit pieces and the Newton
+        step of the next iteration all read this staging (no re-staging inside the loop)."""
+        key = (id(x), x._version, id(s), s._version, id(lda), lda._version, float(self.mu_host))
+        if self._staged_key == key:
+            return
+        me, mi = self.neq, self.nineq
+        self.core.stage_vectors(self.df(x), self.ce(x) if me else None, self.ci(x) if mi else None, s if mi else None,
+                                lda if (me or mi) else None, mu=self.mu_host, eps=self.eps)
+        self._g = self.core.residual()                      # device vector, stays on the device
+        self._staged_key, self._staged_keep = key, (x, s, lda)
+        self._info = None
+
+    def _point_info(self, x, s, lda):
+        """pyipm_newton_merit_info for the staged point without a direction (KKT norms, ||c||_1, sum log s, s'lda, min)."""
+        self._stage_point(x, s, lda)
+        if self._info is None:
+            self._info = self.core.merit_info()
+        return self._info
+
     def KKT(self, x, s, lda):
-        """Norms of the four first-order blocks, slack block scaled by s (pyipm.py:958-991): ONE host sync."""
-        torch = self.torch
-        g = self.grad(x, s, lda)
-        z = torch.zeros((), dtype=torch.float64, device=self.device)
-        n2 = torch.stack([g[0].norm(), (g[1] * s).norm() if g[1] is not None else z,
-                          g[2].norm() if g[2] is not None else z, g[3].norm() if g[3] is not None else z])
-        return tuple(n2.tolist())
+        """Norms of the four first-order blocks, slack block scaled by s (pyipm.py:958-991): device reductions of the
+        library (k_merit_info), one D2H."""
+        q = self._point_info(x, s, lda)
+        return (q["kkt_x"], q["kkt_s"] if self.nineq else 0.0, q["kkt_ce"] if self.neq else 0.0,
+                q["kkt_ci"] if self.nineq else 0.0)
 
-    def phi(self, x, s):
-        """Merit function (pyipm.py:670-721) reduced on the device; one scalar crosses PCIe."""
-        torch = self.torch
-        v = 0.5 * torch.dot(x, self.Qx(x)) + torch.dot(self.c, x)
-        if self.neq:
-            v = v + self.nu_host * self.ce(x).abs().sum()
-        if self.nineq:
-            v = v + self.nu_host * (self.ci(x) - s).abs().sum() - self.mu_host * torch.log(s).sum()
+    def f_dev(self, x):
+        """f(x) = x'Qx/2 + c'x from the cached product (pyipm_newton_dots: one launch, one D2H)."""
+        d = self.core.dots([(x, self.Qx(x)), (self.c, x)])
+        return 0.5 * d[0] + d[1]
+
+    def phi(self, x, s, lda=None):
+        """Merit function (pyipm.py:670-721) at an ARBITRARY point: its vectors are staged (the staged point changes --
+        search() restages its own before it goes on) and reduced by the library."""
+        me, mi = self.neq, self.nineq
+        self.core.stage_vectors(self.df(x), self.ce(x) if me else None, self.ci(x) if mi else None, s if mi else None,
+                                self._staged_keep[2] if (me or mi) else None, mu=self.mu_host, eps=self.eps)
+        self._staged_key = None
+        q = self.core.merit_info()
         self.timings["n_phi"] += 1
-        return float(v)
+        self._last_con_l1 = (q["ce_l1"] if me else 0.0) + (q["cis_l1"] if mi else 0.0)
+        v = self.f_dev(x)
+        if me or mi:
+            v = v + self.nu_host * self._last_con_l1
+        if mi:
+            v = v - self.mu_host * q["sum_log_s"]
+        return v
 
-    def _ray(self, x0, s0, dx, ds):
-        """alpha -> phi(x0 + alpha dx, s0 + alpha ds) - phi(x0, s0) in closed form (see the module docstring).
-        The DIFFERENCE is formed term by term (|c + a dc| - |c| element-wise, log1p(a ds/s)), so its error is relative
-        to the change of the merit function, not to its size: the Armijo test stays meaningful for the tiny steps of
-        the last iterations, where evaluating phi twice and subtracting has cancelled everything."""
-        torch = self.torch
-        q0 = self.Qx(x0)
-        ce0 = self.ce(x0) if self.neq else None
-        if self.nineq:
-            r0 = self.ci(x0) - s0
-        g1 = torch.dot(q0 + self.c, dx)
-        qd, dce, dci = self._products(dx)                  # Q dx, A dx, G dx: one call
-        g2 = torch.dot(dx, qd)
-        if self.nineq:
-            dr = dci - ds
-            rs = ds / s0
-
-        def delta(a):
-            v = a * g1 + (0.5 * a * a) * g2
-            if self.neq:
-                v = v + self.nu_host * ((ce0 + a * dce).abs() - ce0.abs()).sum()
-            if self.nineq:
-                v = v + self.nu_host * ((r0 + a * dr).abs() - r0.abs()).sum() - self.mu_host * torch.log1p(a * rs).sum()
-            self.timings["n_phi"] += 1
-            return float(v)
-        return delta
-
-    def dphi(self, x, s, dz):
-        torch, n = self.torch, self.nvar
-        v = torch.dot(self.df(x), dz[:n])
-        if self.neq:
-            v = v - self.nu_host * self.ce(x).abs().sum()
-        if self.nineq:
-            v = v - self.nu_host * (self.ci(x) - s).abs().sum() - torch.dot(self.mu_host / (s + self.eps), dz[n:])
-        return float(v)
+    def _quad(self, dx):
+        """dx'Q dx when Q is not a staged dense block (L-BFGS mode with a factored Q); None lets the library form it."""
+        if self.Q is not None:
+            return None
+        return self.core.dots([(dx, self.Qd * dx + self.QF @ (self.QF.t() @ dx))])[0]
 
     def step(self, x, dx):
         """Largest alpha in [0,1] with x + alpha dx >= (1 - tau) x: closed form of the golden-section
@@ -236,8 +238,13 @@ class QPDeviceIPM(object):
             return -(top @ torch.linalg.solve(At @ top, c_new))
         return -(torch.linalg.pinv(At) @ c_new)
 
-    def search(self, x0, s0, lda0, dz, alpha_smax, alpha_lmax):
-        """Backtracking Armijo search with the optional second-order correction (pyipm.py:1438-1565)."""
+    RAY_BATCH = 64                       # backtracking candidates alpha tau^k evaluated per launch of k_merit_ray
+
+    def search(self, x0, s0, lda0, dz, alpha_smax, alpha_lmax, info=None):
+        """Backtracking Armijo search with the optional second-order correction (pyipm.py:1438-1565).  The merit function
+        and its slope come from the library's device reductions over the staged point (pyipm_newton_merit_info), the trial
+        values from ONE launch per batch of candidates alpha tau^k (pyipm_newton_merit_ray): phi(x0 + a dx, s0 + a ds) -
+        phi(x0, s0) in closed form, as a difference (see kernels_merit.hpp)."""
         torch = self.torch
         n, me, mi = self.nvar, self.neq, self.nineq
         dx = dz[:n]
@@ -245,21 +252,47 @@ class QPDeviceIPM(object):
         dl = dz[n + mi:]
         if not (me or mi):
             alpha_lmax = 0.0
-        delta = self._ray(x0, s0, dx, ds)                  # phi(x0 + a dx, s0 + a ds) - phi(x0, s0)
-        phi0 = self.phi(x0, s0)
-        dphi0 = self.dphi(x0, s0, dz[:n + mi])
+        self._stage_point(x0, s0, lda0)
+        q = info if info is not None else self.core.merit_info(dz=dz)
+        con_l1 = (q["ce_l1"] if me else 0.0) + (q["cis_l1"] if mi else 0.0)
+        phi0 = self.f_dev(x0)
+        if me or mi:
+            phi0 = phi0 + self.nu_host * con_l1
+        if mi:
+            phi0 = phi0 - self.mu_host * q["sum_log_s"]
+        dphi0 = q["df_dx"]
+        if me or mi:
+            dphi0 = dphi0 - self.nu_host * con_l1
+        if mi:
+            dphi0 = dphi0 - self.mu_host * q["ds_over_s"]
+        self.timings["n_phi"] += 1
         armijo = lambda a: phi0 + a * self.eta * dphi0     # noqa: E731
-        # rounded to the merit function's own precision, as the reference's two evaluations are: a change below
-        # ulp(phi0) compares equal and is accepted, which is how its last tiny steps pass (pyipm.py:1454-1459)
-        trial = lambda a: (phi0 + delta(a)) - armijo(a)    # noqa: E731   > 0: rejected
-        corrected, alpha_corr, dz_p = False, 1.0, None
+        quad = self._quad(dx)
 
-        if trial(alpha_smax) > 0.0:
+        def trials(alphas):
+            """> 0: rejected.  Rounded to the merit function's own precision, as the reference's two evaluations are: a
+            change below ulp(phi0) compares equal and is accepted, which is how its last tiny steps pass (pyipm.py:1454-1459)."""
+            self._stage_point(x0, s0, lda0)                # (the correction below may have staged another point)
+            d = self.core.merit_ray(alphas, self.nu_host, self.mu_host, dz=dz, quad=quad)
+            self.timings["n_phi"] += len(alphas)
+            self.timings["n_ray"] = self.timings.get("n_ray", 0) + 1
+            return [(phi0 + dk) - armijo(ak) for ak, dk in zip(alphas, d)]
+
+        corrected, alpha_corr, dz_p = False, 1.0, None
+        # the first batch already holds the backtracking candidates behind alpha_smax: one launch for most searches
+        # (the reference multiplies step by step, alpha *= tau: the same sequence of roundings)
+        cand, cand_l = [alpha_smax], [alpha_lmax]
+        for k in range(1, self.RAY_BATCH):
+            cand.append(cand[-1] * self.tau)
+            cand_l.append(cand_l[-1] * self.tau)
+        tr = trials(cand)
+        if tr[0] > 0.0:
             if me or mi:
-                c_old = self._con(x0, s0)
-                c_new = self._con(x0 + alpha_smax * dx, s0 + alpha_smax * ds if mi else s0)
-                if float(c_new.abs().sum()) > float(c_old.abs().sum()):
-                    dz_p = self._restoration(x0, c_new)
+                c_old_l1 = con_l1
+                xt, st = x0 + alpha_smax * dx, (s0 + alpha_smax * ds if mi else s0)
+                self.phi(xt, st)
+                if self._last_con_l1 > c_old_l1:
+                    dz_p = self._restoration(x0, self._con(xt, st))
                     if mi:
                         xs = x0 + alpha_smax * dx + dz_p[:n]
                         ss = s0 + alpha_smax * ds + dz_p[n:]
@@ -274,19 +307,28 @@ class QPDeviceIPM(object):
                     if corrected and self.verbosity > 2:
                         print('Second-order feasibility correction accepted')
             if not corrected:
-                alpha_smax *= self.tau
-                alpha_lmax *= self.tau
-                ndx = float(dx.norm())
-                nds = float(ds.norm()) if mi else 0.0
-                while trial(alpha_smax) > 0.0:
+                ndx = q["dx_norm"]
+                nds = q["ds_norm"] if mi else 0.0
+                k = 1                                        # cand[k] = alpha_smax tau^k is the candidate on trial
+                while True:
+                    if k >= len(cand):                       # next batch, continuing the same sequence of roundings
+                        a0, l0 = cand[-1], cand_l[-1]
+                        cand, cand_l = [], []
+                        for _ in range(self.RAY_BATCH):
+                            a0 *= self.tau; l0 *= self.tau
+                            cand.append(a0); cand_l.append(l0)
+                        tr = trials(cand)
+                        k = 0
+                    alpha_smax, alpha_lmax = cand[k], cand_l[k]
+                    if not tr[k] > 0.0:
+                        break
                     size = np.sqrt((alpha_smax * ndx) ** 2 + (alpha_lmax * nds) ** 2) if mi else alpha_smax * ndx
                     if size < self.eps:
                         if self.verbosity > 2:
                             print('Search direction is unreliable to machine precision.')
                         self.signal = -2
                         return x0, s0, lda0
-                    alpha_smax *= self.tau
-                    alpha_lmax *= self.tau
+                    k += 1
         if corrected:
             x = x0 + alpha_corr * (alpha_smax * dx + dz_p[:n])
             s = s0 + alpha_corr * (alpha_smax * ds + dz_p[n:]) if mi else s0.clone()
@@ -298,20 +340,21 @@ class QPDeviceIPM(object):
 
     # ------------------------------------------------------------------ the Newton step (hot path)
     def newton_direction(self, x, s, lda):
-        """pyipm.py:1717-1725 on the device: the blocks are resident, the vectors are device GEMVs."""
-        me, mi = self.neq, self.nineq
+        """pyipm.py:1717-1725 on the device: the blocks are resident (staged once), the vectors and g = -grad of this point
+        are already staged (_stage_point: the KKT report of the previous iteration did it)."""
         if self.trace is not None:
             self.trace.append((x.cpu().numpy(), s.cpu().numpy(), lda.cpu().numpy(), float(self.mu_host)))
+        self._stage_point(x, s, lda)
         dz, self.delta, self.last_stats = self.backend.direction(
-            self.Q, self.Je, self.Ji, self.df(x), self.ce(x) if me else None, self.ci(x) if mi else None,
-            s if mi else None, lda if (me or mi) else None, self.mu_host, self.delta, self.mu_host, self.eta,
-            self.beta, self.reg_coef, self.delta0, self.eps, as_tensor=True)
+            None, None, None, None, None, None, None, None, self.mu_host, self.delta, self.mu_host, self.eta,
+            self.beta, self.reg_coef, self.delta0, self.eps, as_tensor=True, staged=True, g=self._g)
         return dz
 
     # ------------------------------------------------------------------ L-BFGS mode (storage on the device)
     def _gvec(self, x, s, lda):
-        """-grad as ONE device vector (pyipm.py:1637, 1705-1706)."""
-        return -self.torch.cat([b for b in self.grad(x, s, lda) if b is not None])
+        """-grad as ONE device vector (pyipm.py:1637, 1705-1706): the library's residual of the staged point."""
+        self._stage_point(x, s, lda)
+        return self._g[:self.nvar + 2 * self.nineq + self.neq].clone()
 
     def _lbfgs_init(self):
         t, n, dev = self.torch, self.nvar, self.device
@@ -431,24 +474,25 @@ class QPDeviceIPM(object):
                         a_s, a_l = self.backend.step_lengths(self.tau)
                 torch.cuda.synchronize(self.device)
                 t1 = time.perf_counter()
+                self._stage_point(x, s, lda)                      # (L-BFGS mode: g of the current point was staged last)
+                q = self.core.merit_info(dz=dz)                   # ||c||_1, df.dx, sum ds/(s+eps), sum log s, |dx|, |ds|: one D2H
                 if me or mi:                                      # merit parameter (pyipm.py:1727-1735)
-                    bcg = self.df(x)
-                    if mi:
-                        bcg = torch.cat([bcg, -self.mu_host / (s + self.eps)])
-                    den = (1 - self.rho) * float(self._con(x, s).abs().sum())
-                    num = float(torch.dot(bcg, dz[:n + mi]))
+                    con_l1 = (q["ce_l1"] if me else 0.0) + (q["cis_l1"] if mi else 0.0)
+                    den = (1 - self.rho) * con_l1
+                    num = q["df_dx"] - (self.mu_host * q["ds_over_s"] if mi else 0.0)
                     with np.errstate(divide='ignore', invalid='ignore'):
                         nu_thres = np.float64(num) / np.float64(den)
                     if self.nu_host < nu_thres:
                         self.nu_host = float(nu_thres)
                 if mi:
-                    x, s, lda = self.search(x, s, lda, dz, float(a_s), float(a_l))
+                    x, s, lda = self.search(x, s, lda, dz, float(a_s), float(a_l), info=q)
                 else:
-                    x, s, lda = self.search(x, s, lda, dz, 1.0, 1.0)
+                    x, s, lda = self.search(x, s, lda, dz, 1.0, 1.0, info=q)
                 iter_count += 1
                 kkt = self.KKT(x, s, lda)
                 t2 = time.perf_counter()
                 self.timings["newton_s"] += t1 - t0
+                self.timings["newton_each_s"].append(t1 - t0)
                 self.timings["search_s"] += t2 - t1
                 if self.Ftol is not None and not mi and self.signal != -2:
                     f_new = self.f(x)
@@ -476,8 +520,8 @@ class QPDeviceIPM(object):
                     print('MAXIMUM OUTER ITERATIONS EXCEEDED' if mi else 'MAXIMUM ITERATIONS EXCEEDED')
                 break
             if mi:                                                # barrier update (pyipm.py:1804-1814)
-                sl = s * lda[me:]
-                comp, mn = torch.stack([sl.sum(), sl.min()]).tolist()
+                q = self._point_info(x, s, lda)                   # s'lda_i and min s lda_i of the staged point (k_merit_info)
+                comp, mn = q["comp_sum"], q["comp_min"]
                 xi = mi * mn / (comp + self.eps)
                 mu_new = 0.1 * min(0.05 * (1.0 - xi) / (xi + self.eps), 2.0) ** 3 * comp / mi
                 self.mu_host = max(float(mu_new), 0.0)

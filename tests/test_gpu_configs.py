@@ -69,3 +69,59 @@ def test_config4_kkt_131072_on_one_gpu():
     """BASELINE.json configs[3]: n=65536, mi=32768 -> N=131072 (137 GB) on ONE MI355X -- the 1-GPU leg of the
     >= 5x-at-8-GPUs target; the 8-GPU leg needs the 8-GPU node (bench.py --gpus 8)."""
     _run(65536, 0, 32768)
+
+
+def test_oracle_lu_where_the_headline_runs():
+    """ONE direct comparison with the oracle's LU (pyipm.py:1720-1721 = scipy.linalg.solve(assume_a='gen'))
+    in the regime the headline number is measured in.  n=13312, me=3328, mi=4992 -> N=26624 with DEFAULT options: the
+    first group has 8 panels (K = 2048 bulk launch over 24576 rows) and the bulk launches over more than 20480 rows run on
+    k_update<256,true,8> at their natural sizes -- asserted through trailing_instances().  The largest size whose LU the
+    GPU box's host finishes in about a minute (16 BLAS threads: 5.3 s at N = 12288).
+      * K1: the device storage equals triu(H) of the oracle bit for bit on a sample of rows from every block;
+      * K2: g to 1e-13; dz against the oracle's LU direction <= 1e-10 relative; inertia (n + mi, me + mi, 0)."""
+    import torch
+    from bench import make_qp_device
+    from oracle import newton_oracle as orc
+    from pyipm_amd.newton import NewtonCore
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:                                             # pragma: no cover
+        threadpool_limits = None
+    n, me, mi = 13312, 3328, 4992
+    N = n + 2 * mi + me
+    dev = torch.device("cuda", 0)
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < 40e9:
+        pytest.skip("needs 40 GB of free HBM")
+    qp = make_qp_device(n, me, mi, 5, dev)
+    torch.cuda.empty_cache()
+    core = NewtonCore(n, me, mi, device=0)                        # default nb, groups, tile widths, thresholds
+    core.set_option("profile", 1)
+    core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    g_dev = core.residual().cpu().numpy()
+    core.assemble(0.0, 0.0)
+    store = core.kkt_storage()                                    # (ncols, Npad) row-major: row j = column j of the lower triangle = row j of triu(H)
+    rows = sorted(set([0, 1, 127, 128, 2047, 2048, n - 1, n, n + 1, n + mi - 1, n + mi, n + mi + me - 1, n + mi + me, N - 2, N - 1] +
+                      list(np.random.default_rng(3).integers(0, N, 80))))
+    sample = {int(r): store[int(r), :N].cpu().numpy().copy() for r in rows}
+    dz, st = core.step(0.0, 0.0)
+    inst = core.trailing_instances()
+    dz = dz.cpu().numpy()
+    assert inst[256]["launches"] >= 3 and inst[256]["flops"] > 0.5 * (inst[128]["flops"] + inst[256]["flops"]), inst
+    assert st["nonfinite"] == 0 and st["n_zero"] == 0 and (st["n_neg"], st["n_pos"]) == (me + mi, n + mi)
+    host = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in qp.items()}
+    core.close()
+    del qp, store
+    torch.cuda.empty_cache()
+    import contextlib
+    with (threadpool_limits(limits=16) if threadpool_limits else contextlib.nullcontext()):   # (all 256 cores: 6x slower)
+        ref, _, H, g = orc.newton_step(host["d2L"], host["Je"], host["Ji"], host["df"], host["ce"], host["ci"], host["s"],
+                                       host["lam"], host["mu"], n, me, mi, regularise=False)
+    np.testing.assert_allclose(g_dev[:N], g, rtol=0, atol=1e-13 * np.abs(g).max())
+    for r, got in sample.items():
+        want = H[r].copy(); want[:r] = 0.0                        # triu(H): the storage holds the lower triangle's column r
+        got = got.copy(); got[:r] = 0.0                           # (entries left of the diagonal belong to other columns' rows)
+        assert np.array_equal(got, want), r
+    err = np.linalg.norm(dz - ref) / np.linalg.norm(ref)
+    assert err <= 1e-10, err

@@ -204,10 +204,20 @@ def test_unconverged_refinement_takes_the_shift_branch():
 
     be2 = HipNewtonBackend(n, me, mi, device=0, max_shift_tries=3)
     be2.berr_tol = 0.0                                             # nothing converges
+    be2.berr_fallback = 0.0                                        # ... and nothing is good enough for the last resort
     be2._at_risk = lambda st: True
     with pytest.raises(RuntimeError, match="refined solve did not reach"):
         _direction(be2, d, b)
     assert be2.n_unconverged >= 3
+
+    # with the budget spent, the best direction seen is returned when it is sqrt(eps)-accurate against its own
+    # blocks (the reference returns its LU direction whatever its accuracy) -- counted, never silent
+    be3 = HipNewtonBackend(n, me, mi, device=0, max_shift_tries=3)
+    be3.berr_tol = 0.0
+    be3._at_risk = lambda st: True
+    dz3, delta3, st3 = _direction(be3, d, b)
+    assert be3.n_inexact == 1 and be3.n_unconverged >= 3 and be3.n_inertia_retries == 0
+    assert delta3 == 0.0 and relerr(dz3, d["dz"]) <= 1e-10         # the unshifted direction had the smallest backward error
 
 
 # ---- static pivots where they hurt -- a whole LP solve of the reference, late iterates included ------

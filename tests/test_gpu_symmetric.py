@@ -347,3 +347,34 @@ def test_random_schedule_options_give_the_same_bits():
                     assert float((core.matvec(raw) - gres).norm() / gres.norm()) <= 1e-12, (shape, nb)
                 assert torch.equal(dz, ref), (shape, nb, opts, rep)
             core.close()
+
+
+@pytest.mark.parametrize("shape", [(1900, 300, 500, 5), (2300, 0, 0, 6), (1000, 300, 900, 2)])
+def test_wide_bulk_tiles_stop_at_the_storage_edge(shape):
+    """Npad is a multiple of 128 only, a 128 x 256 bulk tile at the last 128 columns of such a matrix
+    would read and rewrite 128 columns PAST the storage -- the first W slot, which the group after next reuses while the
+    launch runs.  Shapes with Npad % 256 == 128, wide tiles forced everywhere (no reserved CUs, no row threshold), groups
+    of one and two panels so that every W slot is reused several times; the dense (me = mi = 0) shape has no structural
+    zeros that could hide a clobbered W.  Bit for bit the 128 x 128 schedule, three steps in a row, and nothing outside the
+    lower triangle's storage changes (the W buffer is compared through the next factorisation's bits)."""
+    import torch
+    from pyipm_amd.newton import NewtonCore
+    from pyipm_amd.problems import make_qp
+    n, me, mi, seed = shape
+    qp = make_qp(n, me, mi, seed)
+    outs = {}
+    for bn in (128, 256):
+        for grp in (1, 2):
+            core = NewtonCore(n, me, mi, device=0, nb=256)
+            assert core.Npad % 256 == 128
+            for k, v in (("bulk_bn", bn), ("reserve_cus", 0), ("bulk_bn_rows", 0), ("bulk_bn_min_k", 256), ("group", grp),
+                         ("tail_group", grp), ("sweep_persist", 0)):
+                core.set_option(k, v)
+            core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+            core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+            steps = [core.step(0.0, 0.0)[0].clone() for _ in range(3)]
+            assert all(torch.equal(s, steps[0]) for s in steps), (shape, bn, grp)
+            outs[(bn, grp)] = steps[0]
+            core.close()
+    for grp in (1, 2):
+        assert torch.equal(outs[(128, grp)], outs[(256, grp)]), (shape, grp)

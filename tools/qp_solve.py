@@ -40,6 +40,13 @@ def main():
            "condensed_fallbacks": ipm.backend.n_condensed_fallback, "condensed_still_on": ipm.backend.condensed_on,
            "condensed_fallback_reason": ipm.backend.condensed_fallback_reason, "solve_seconds": dt, "newton_seconds": ipm.timings["newton_s"],
            "search_seconds": ipm.timings["search_s"], "merit_evaluations": ipm.timings["n_phi"],
+           "merit_ray_launches": ipm.timings.get("n_ray", 0),
+           "newton_seconds_per_factorisation": ipm.timings["newton_s"] / max(ipm.backend.n_factor, 1),
+           "newton_seconds_each": ipm.timings["newton_each_s"],
+           "rcond_estimates": ipm.backend.n_rcond, "rcond_estimates_reused": ipm.backend.n_rcond_reused,
+           "merit_note": "phi / dphi / nu threshold / KKT norms / barrier sums are device reductions of the library "
+                         "(pyipm_newton_merit_info, _dots); every backtracking candidate of a search comes from one "
+                         "pyipm_newton_merit_ray launch per batch of 64",
            "kkt_norms": list(kkt), "fval": f}
     # the provider's products in isolation (pyipm_newton_block_products / _t): HIP-event time and HBM rate
     core = ipm.core
