@@ -146,7 +146,11 @@ int pyipm_newton_solve(pyipm_newton_ctx* ctx, const double* rhs, double* dz, int
 int pyipm_newton_solve_info(pyipm_newton_ctx* ctx, double out[4]);
 /* Restates the quantity reghess tests (pyipm.py:1379-1381: rcond = min|w| / max|w| over the eigenvalues w of Hc, "singular"
  * when rcond <= eps) without the eigendecomposition: it_pow power iterations on Hc applied from the blocks give max|w|,
- * it_inv inverse iterations through the factor (one substitution sweep each) give min|w| (0 = defaults 6 / 3).
+ * it_inv inverse iterations through the factor (one substitution sweep each) give min|w| (0 = defaults 6 / 3; negative =
+ * ADAPTIVE, for the threshold test only: either iteration stops once two successive estimates agree to 10 %, and the
+ * inverse iteration also as soon as even a pessimistic correction of its running estimate -- x 64 sqrt(N): a random start
+ * vector's component along the extreme eigenvector -- leaves rcond a factor 100 above eps; the estimate returned is then
+ * the running one, an over-estimate of rcond that decides "not singular" correctly).
  * out[0] = min|w| estimate (of the FACTORED matrix: with static pivots that is the perturbed one, whose smallest
  * eigenvalue sits at the perturbation level out[3] exactly when Hc itself is singular), out[1] = max|w| estimate,
  * out[2] = their ratio, out[3] = magnitude of a static pivot (sqrt(eps) max|Hc|).  Call between factor() and solve();

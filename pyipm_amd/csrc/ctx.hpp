@@ -216,6 +216,7 @@ struct Ctx {
     // one (-1 = not measured: a fixed-count solve), 1 = the adaptive loop met its target
     int info_steps = 0, info_converged = 0;
     double info_berr0 = -1.0, info_berr = -1.0;
+    int rcond_its[2] = {0, 0};            // power / inverse iterations the last pyipm_newton_rcond took (solve_info reports them)
     double refine_target = 1.0e-14;       // adaptive refinement stops at this backward error ...
     int refine_max = 8;                   // ... or after this many steps, or when a step gains less than 4x
     // options

@@ -113,6 +113,16 @@ __global__ __launch_bounds__(1024) void k_dots(double* __restrict__ out, DotPair
     }
 }
 
+// |c + a d| - |c| without the cancellation: while c + a d keeps the sign of c the change IS sign(c) a d (one rounding,
+// relative to the change -- for the a ~ 1e-12 of the last backtracking steps the subtraction of two numbers of size |c| would
+// leave eps |c|, many times the change itself); across a sign change the two magnitudes are comparable and subtract safely.
+__device__ __forceinline__ double abs_change(double c, double d, double a) {
+    const double t = a * d, cn = fma(a, d, c);
+    if (c > 0.0 && cn >= 0.0) return t;
+    if (c < 0.0 && cn <= 0.0) return -t;
+    return fabs(cn) - fabs(c);
+}
+
 // The merit function of a QP along the ray, as a DIFFERENCE (pyipm.py:670-721 evaluated at x + a dx, s + a ds minus at x, s;
 // f quadratic, constraints affine, so everything is a closed form in a):
 //   out[k] = a g1 + a^2/2 g2 + nu sum(|ce + a dce| - |ce|) + nu sum(|r + a dr| - |r|) - mu sum log1p(a ds / s)
@@ -129,10 +139,10 @@ __global__ __launch_bounds__(256) void k_merit_ray(
     const double a = alphas[blockIdx.x];
     const int64_t me = geo.me, mi = geo.mi;
     double se = 0.0, si = 0.0, sl = 0.0;
-    for (int64_t i = threadIdx.x; i < me; i += 256) { const double c = ce[i]; se += fabs(fma(a, dce[i], c)) - fabs(c); }
+    for (int64_t i = threadIdx.x; i < me; i += 256) se += abs_change(ce[i], dce[i], a);
     for (int64_t i = threadIdx.x; i < mi; i += 256) {
         const double s0 = s[i], d = ds[i], r = ci[i] - s0, dr = dci[i] - d;
-        si += fabs(fma(a, dr, r)) - fabs(r);
+        si += abs_change(r, dr, a);
         sl += log1p(a * (d / s0));
     }
     se = merit_block_sum(se, red);

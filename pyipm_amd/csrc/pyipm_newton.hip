@@ -290,7 +290,8 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
                      int ksplit = 1, int64_t ks_cstride = 0, int waves = 0,        // waves: 0 = the handle's bulk_waves
                      int head_ct = 0, unsigned* head_counter = nullptr, unsigned* head_count = nullptr, bool list_only = false,
                      int sub0 = 0, int nct_sub = 0,    // nct_sub > 0: only column tiles [sub0, sub0 + nct_sub) of local panel first_lp
-                     int* used_bn = nullptr) {         // out: the tile width of the instance that ran (128 / 256)
+                     int* used_bn = nullptr,           // out: the tile width of the instance that ran (128 / 256)
+                     int prio = -1) {                  // >= 0: wave priority flag of the launch whatever `bulk` says
     const Geo& g = ctx->g;                             // (128 wide; the sub-panels of a wide panel, factor_block)
     if (ldw <= 0) ldw = g.Npad;
     if (row_end <= 0) row_end = g.Npad;
@@ -302,7 +303,7 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     u.nb = g.nb; u.world = g.world; u.rank = g.rank;
     u.nrt = (int)(m / BM); u.nct = nct_sub > 0 ? nct_sub : (int)(n_lp * (g.nb / 128));
     u.dbg = ctx->dbg_buf;
-    u.prio = bulk ? 0 : ctx->side_prio;
+    u.prio = prio >= 0 ? prio : (bulk ? 0 : ctx->side_prio);
     u.rt_min0 = 0; u.rt_step = 0; u.tiles = nullptr; u.ks_cstride = 0; u.persist = 0;
     u.head_ct = head_ct; u.head_counter = head_counter;
     if (src_c0 >= 0) active_ranges(ctx, src_c0, src_c0 + K, &u.a0, &u.a1, &u.b0, &u.b1);
@@ -365,12 +366,24 @@ bool panel_in_s(const Ctx* ctx, int64_t p) {
 // Per-panel mode: rows [h0, h1) of a panel that lies inside the x block are whole 128-row tiles of slack rows --
 // exact zeros that no update launch with these source columns ever reads (active_ranges).  The owner's chain
 // kernels skip them and the panel message leaves them out.  Empty range when nothing can be skipped.
+// Rows of exact zeros (whole slack rows of x-block columns) that the chain kernels neither compute nor WRITE into W.  Whole
+// HOLEG-row blocks only, HOLEG = the widest column tile of an update launch: a 128 x 256 tile whose columns straddled the edge of
+// a 128-aligned hole read W rows nobody had written -- stale memory, silently wrong factors whenever n or n + mi is an odd
+// multiple of 128 and the workspace is not fresh (found by tests/test_gpu_configs.py::test_oracle_lu_where_the_headline_runs,
+// round 4; the benchmark shapes are 256-aligned and were never affected).
+constexpr int64_t HOLEG = 256;
+inline void slack_hole(const Geo& g, int64_t* h0, int64_t* h1) {
+    *h0 = (g.n + HOLEG - 1) / HOLEG * HOLEG; *h1 = (g.n + g.mi) / HOLEG * HOLEG;
+    if (*h1 < *h0) *h1 = *h0;
+}
+
 void panel_hole(const Ctx* ctx, int64_t p, int64_t* h0, int64_t* h1) {
     const Geo& g = ctx->g;
     *h0 = 0; *h1 = 0;
     if (!ctx->skip_zeros || g.mi == 0 || !ctx->grp_of.empty() || ctx->cond_active) return;
     if (g.panel_c0(p) + g.panel_w(p) > g.n) return;
-    const int64_t a = (g.n + BM - 1) / BM * BM, b = (g.n + g.mi) / BM * BM;
+    int64_t a, b;
+    slack_hole(g, &a, &b);
     if (b > a) { *h0 = a; *h1 = b; }
 }
 
@@ -421,8 +434,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
     const bool grp_in_x = (size_t)p < ctx->grp_of.size() && !ctx->grp_x.empty() && ctx->grp_x[(size_t)ctx->grp_of[p]];
     if (ctx->skip_zeros && g.world == 1 && g.mi > 0 && grp_in_x) {
         active_ranges(ctx, c0, c0 + nbw, &ha0, &ha1, &hb0, &hb1);
-        hole0 = (g.n + BM - 1) / BM * BM; hole1 = (g.n + g.mi) / BM * BM;
-        if (hole1 < hole0) hole1 = hole0;
+        slack_hole(g, &hole0, &hole1);
     } else {
         panel_hole(ctx, p, &hole0, &hole1);             // per-panel mode (any number of ranks)
         if (hole1 > hole0) active_ranges(ctx, c0, c0 + nbw, &ha0, &ha1, &hb0, &hb1);
@@ -625,8 +637,7 @@ int factor_group(Ctx* ctx, int64_t p0, int64_t n0, hipStream_t chain, const std:
     const size_t gi = (size_t)ctx->grp_of[(size_t)p0];
     const bool grp_in_x = !ctx->grp_x.empty() && ctx->grp_x[gi];
     if (ctx->skip_zeros && g.mi > 0 && grp_in_x) {
-        bd.hole0 = (g.n + BM - 1) / BM * BM; bd.hole1 = (g.n + g.mi) / BM * BM;
-        if (bd.hole1 < bd.hole0) bd.hole1 = bd.hole0;
+        slack_hole(g, &bd.hole0, &bd.hole1);
     }
     return factor_block(ctx, bd, chain, on_done);
 }
@@ -655,7 +666,8 @@ int factor_wide_panel(Ctx* ctx, int64_t p, hipStream_t stream) {
 // One bulk k_update<128> launch: panels [p0, p0+np) (contiguous, same rank) applied with K = their total
 // width to local panels [first_lp, first_lp+n_lp); timed with HIP events on the handle's stream.
 int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_lp, hipStream_t stream = nullptr,
-                 int head_ct = 0, unsigned* head_counter = nullptr, unsigned* head_count = nullptr, bool list_only = false) {
+                 int head_ct = 0, unsigned* head_counter = nullptr, unsigned* head_count = nullptr, bool list_only = false,
+                 bool as_bulk = false) {             // as_bulk: a bulk launch although it runs on another stream
     const Geo& g = ctx->g;
     if (!stream) stream = ctx->stream;
     if (n_lp <= 0) return 0;
@@ -688,7 +700,7 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
     // A launch on another stream than the handle's is a lookahead head riding the chain's stream: it overlaps the bulk launch
     // on the main stream, so its duration says nothing about the kernel's rate -- it is not part of the "trailing" figures
     // (time, flops, launches), and it uses the 4-wave instance of the kernel so that a kernel trace keeps the two apart.
-    const bool chain_side = stream != ctx->stream && !ctx->per_panel_mode;
+    const bool chain_side = stream != ctx->stream && !ctx->per_panel_mode && !as_bulk;
     if (list_only)                                      // fused head: only build / look up the tile list (how many head tiles?)
         return launch_update128(ctx, stream, Lop, g.Npad, wbuf(ctx, p0), K, row_begin, first_lp, n_lp, true, 0, 0, 0,
                                 g.panel_c0(p0), 1, 0, 0, head_ct, head_counter, head_count, true);
@@ -1919,11 +1931,26 @@ int pyipm_newton_rcond(pyipm_newton_ctx* h, int it_inv, int it_pow, double out[4
     PYIPM_HIP(hipSetDevice(ctx->device));
     if (g.world != 1) { ctx->err = "rcond(): single-rank entry point"; return PYIPM_E_BADARG; }
     if (!ctx->factored) { ctx->err = "rcond: factor first"; return PYIPM_E_BADARG; }
+    // it_inv / it_pow >= 1: that many iterations of each; 0 = the defaults of rounds 2-3 (3 and 6).  < 0 = ADAPTIVE (round 4): an estimate for a
+    // THRESHOLD test does not need the converged value.  Power iteration stops when two successive estimates agree to 10 %
+    // (at most 6); inverse iteration stops when converged likewise (at most 3) -- or as soon as even a pessimistic correction
+    // of the running estimate cannot reach the threshold: from a random start one step already finds 1 / |w|_min to within
+    // the start vector's component along that eigenvector (~1/sqrt(N)), so min|w| >= 1 / (64 sqrt(N) est_1) is safe; if
+    // that is still far above eps max|w| (x 100), the matrix is not singular to working precision and the other two
+    // substitution sweeps (2.6 ms each at N = 32768) change nothing.  Late in an interior-point run this estimate is taken at
+    // every iterate (Sigma spreads the pivots by itself): 18 -> ~7 ms.
+    const bool adaptive_inv = it_inv < 0, adaptive_pow = it_pow < 0;
     if (it_inv < 1) it_inv = 3;
     if (it_pow < 1) it_pow = 6;
-    ctx->forward_pending = false; ctx->have_direction = false;       // v0..v2 / vc are about to be reused
-    ctx->ray_valid = false;
+    // work vectors: v3 (the adaptive refinement's spare iterate) and vc (free outside a condensed solve), so that v0 / v1 -- a
+    // right-hand side already forward-substituted under the factorisation -- and v2, the last direction, survive: the solve
+    // that follows starts at the backward sweep (1.3 ms at N = 32768, at every suspect iterate).  With the condensed system
+    // the substitution itself goes through vc: v0 / v1 as before, the pending forward pass is redone.
+    double* wa = ctx->cond_active ? ctx->v0 : ctx->v3;
+    double* wb = ctx->cond_active ? ctx->v1 : ctx->vc;
+    if (ctx->cond_active) { ctx->forward_pending = false; ctx->have_direction = false; ctx->ray_valid = false; }
     double ss[2], lmax = 0.0, linv = 0.0;
+    int used_pow = 0, used_inv = 0;
     auto norm_of = [&](const double* v, double* nrm) -> int {
         hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, ctx->stream, ctx->partial, v, v, g.N);
         PYIPM_KCHECK();
@@ -1933,26 +1960,35 @@ int pyipm_newton_rcond(pyipm_newton_ctx* h, int it_inv, int it_pow, double out[4
         return 0;
     };
     for (int phase = 0; phase < 2; ++phase) {
-        hipLaunchKernelGGL(k_hash_vector, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v1, g.N, g.Npad, (unsigned long long)(17 + phase));
+        hipLaunchKernelGGL(k_hash_vector, grid1(g.Npad), dim3(256), 0, ctx->stream, wb, g.N, g.Npad, (unsigned long long)(17 + phase));
         PYIPM_KCHECK();
-        double nrm = 0.0, est = 0.0;
-        int rc = norm_of(ctx->v1, &nrm); if (rc) return rc;
+        double nrm = 0.0, est = 0.0, prev_est = 0.0;
+        int rc = norm_of(wb, &nrm); if (rc) return rc;
         const int its = phase == 0 ? it_pow : it_inv;
         for (int it = 0; it < its; ++it) {
             if (!(nrm > 0.0) || !(nrm <= 1.0e300)) break;
             if (phase == 0) {
-                hipLaunchKernelGGL(k_scale_copy, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v0, ctx->v1, 1.0 / nrm, g.Npad); PYIPM_KCHECK();
-                rc = kkt_matvec_dev(ctx, ctx->v0, ctx->v1); if (rc) return rc;          // v1 = Hc (v / |v|)
+                hipLaunchKernelGGL(k_scale_copy, grid1(g.Npad), dim3(256), 0, ctx->stream, wa, wb, 1.0 / nrm, g.Npad); PYIPM_KCHECK();
+                rc = kkt_matvec_dev(ctx, wa, wb); if (rc) return rc;          // v1 = Hc (v / |v|)
             } else {
-                hipLaunchKernelGGL(k_scale_copy, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v0, ctx->v1, 1.0 / nrm, g.Npad); PYIPM_KCHECK();
-                rc = solve_inplace(ctx, ctx->v0); if (rc) return rc;                     // v0 = inv(factored) (v / |v|)
-                PYIPM_HIP(hipMemcpyAsync(ctx->v1, ctx->v0, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                hipLaunchKernelGGL(k_scale_copy, grid1(g.Npad), dim3(256), 0, ctx->stream, wa, wb, 1.0 / nrm, g.Npad); PYIPM_KCHECK();
+                rc = solve_inplace(ctx, wa); if (rc) return rc;                     // v0 = inv(factored) (v / |v|)
+                PYIPM_HIP(hipMemcpyAsync(wb, wa, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
             }
-            rc = norm_of(ctx->v1, &nrm); if (rc) return rc;
-            est = nrm;
+            rc = norm_of(wb, &nrm); if (rc) return rc;
+            prev_est = est; est = nrm;
+            (phase == 0 ? used_pow : used_inv) = it + 1;
+            if (phase == 0 && adaptive_pow && it >= 1 && est <= 1.1 * prev_est) break;
+            if (phase == 1 && adaptive_inv) {
+                if (it >= 1 && est <= 1.1 * prev_est) break;
+                // 1 / (pessimistic min|w|) = 64 sqrt(N) est; not singular by a factor 100:  that < 1 / (100 eps max|w|)
+                const double pess = 64.0 * sqrt((double)g.N) * est;
+                if (lmax > 0.0 && pess * (100.0 * 2.220446049250313e-16 * lmax) < 1.0) break;
+            }
         }
         if (phase == 0) lmax = est; else linv = est;
     }
+    ctx->rcond_its[0] = used_pow; ctx->rcond_its[1] = used_inv;
     const double lmin = linv > 0.0 ? 1.0 / linv : 0.0;
     out[0] = lmin; out[1] = lmax; out[2] = (lmax > 0.0) ? lmin / lmax : 0.0;
     double an = 0.0;

@@ -108,7 +108,8 @@ def test_oracle_lu_where_the_headline_runs():
     dz, st = core.step(0.0, 0.0)
     inst = core.trailing_instances()
     dz = dz.cpu().numpy()
-    assert inst[256]["launches"] >= 3 and inst[256]["flops"] > 0.5 * (inst[128]["flops"] + inst[256]["flops"]), inst
+    # (one K = 2048 launch over 24576 rows + three K = 1024 launches: 49 % of the bulk flops at this size, 78 % at N = 32768)
+    assert inst[256]["launches"] >= 4 and inst[256]["flops"] > 0.4 * (inst[128]["flops"] + inst[256]["flops"]), inst
     assert st["nonfinite"] == 0 and st["n_zero"] == 0 and (st["n_neg"], st["n_pos"]) == (me + mi, n + mi)
     host = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in qp.items()}
     core.close()

@@ -71,7 +71,8 @@ def _worker(rank, world, port, shape, nb, mode, out, opts=None):
 
 def _factor_bytes(n, me, mi, nb):
     """One message per panel that has rows below it, EXCEPT panels inside the slack block (every rank derives their
-    contribution from s / lambda locally); a panel inside the x block leaves the whole 128-row tiles of slack rows home."""
+    contribution from s / lambda locally); a panel inside the x block leaves the whole 256-row blocks of slack rows home (256:
+    the widest column tile of an update launch -- a 128 x 256 tile must never meet a W row nobody wrote, round 4)."""
     N = n + 2 * mi + me
     Npad = ((N + 127) // 128) * 128
     fact = 0
@@ -81,7 +82,7 @@ def _factor_bytes(n, me, mi, nb):
         m = Npad - (c0 + w)
         in_s = c0 >= n and c0 + w <= n + mi
         if c0 + w <= n and mi:
-            m -= max(0, (n + mi) // 128 * 128 - (n + 127) // 128 * 128)
+            m -= max(0, (n + mi) // 256 * 256 - (n + 255) // 256 * 256)
         if m > 0 and not in_s:
             fact += 8 * (m * w + 2 * (w // 64) * 4096 + w // 64)
     return fact, Npad
@@ -124,7 +125,9 @@ def test_ranks_sharing_one_gpu(world, shape, nb, mode):
         assert out[0][3] == fact + 16 * Npad
 
 
-@pytest.mark.parametrize("world,shape,nb", [(2, (1300, 300, 450, 11), 512), (3, (4600, 800, 1300, 12), 1024)])
+# (Npad a multiple of 256: 2560 and 8192 -- with an odd multiple of 128 the wide tiles are not used at all; n and
+#  n + mi odd multiples of 128 in the second shape: a wide tile straddles both edges of the slack rows)
+@pytest.mark.parametrize("world,shape,nb", [(2, (1300, 300, 450, 11), 512), (3, (4480, 920, 1344, 12), 1024)])
 def test_wide_bulk_tiles_across_ranks(world, shape, nb):
     """The 128 x 256 bulk tiles (the default for launches over more than 20480 rows: sizes no test with several ranks on one
     GPU reaches) forced on at a small size across ranks: block-cyclic column tiles of 256, the direction against the oracle

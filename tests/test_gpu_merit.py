@@ -81,28 +81,42 @@ def test_merit_info_on_every_iterate_of_the_reference_traces(k):
     core.close()
 
 
-def _qp_numpy_ray(qp, x, s, dz, nu, mu, alphas):
-    """phi(x + a dx, s + a ds) - phi(x, s) from the problem data in extended precision (the yardstick)."""
+def _qp_numpy_ray(qp, df, ce, ci, s, dz, nu, mu, alphas):
+    """phi(x + a dx, s + a ds) - phi(x, s) in extended precision (the yardstick) from exactly what the device was given: the
+    staged df, ce, ci, s (float64), its own direction, the blocks.  |c + a dc| - |c| is taken as sign(c) a dc wherever the
+    sign does not change: evaluating the two magnitudes and subtracting would limit the yardstick itself to eps_longdouble |c|
+    -- more than the whole change for the a ~ 1e-12 of a search's last candidates.
+    Returns the values and, per candidate, the sum of the MAGNITUDES that enter it -- of the outer terms and of the inner
+    products behind them (df . dx, dx'Q dx, A dx, G dx cancel internally: their rounding is relative to sum |a_i b_i|)."""
     n, me, mi = qp["n"], qp["me"], qp["mi"]
     L = np.longdouble
-    Q, c = qp["Q"].astype(L), qp["c"].astype(L)
+    Q = qp["Q"].astype(L)
     dx, ds = dz[:n].astype(L), dz[n:n + mi].astype(L)
-    x, s = x.astype(L), s.astype(L)
+    df, s = df.astype(L), (s.astype(L) if mi else None)
+
+    def abs_change(c0, dc, a):
+        c1 = c0 + a * dc
+        same = ((c0 > 0) & (c1 >= 0)) | ((c0 < 0) & (c1 <= 0))
+        return np.where(same, np.sign(c0) * a * dc, np.abs(c1) - np.abs(c0))
+
+    g1, g2 = df @ dx, dx @ (Q @ dx)
+    m1, m2 = np.abs(df * dx).sum(), np.abs(dx) @ (np.abs(Q) @ np.abs(dx))
+    if me:
+        A = qp["A"].astype(L)
+        ce0, dce, mce = ce.astype(L), A @ dx, (np.abs(A) @ np.abs(dx)).sum()
+    if mi:
+        G = qp["G"].astype(L)
+        r0, dr, mr = ci.astype(L) - s, G @ dx - ds, (np.abs(G) @ np.abs(dx)).sum() + np.abs(ds).sum()
     out, scale = [], []
     for a in alphas:
         a = L(a)
-        v = a * ((Q @ x + c) @ dx) + a * a / 2 * (dx @ (Q @ dx))
-        sc = abs(a * ((Q @ x + c) @ dx)) + abs(a * a / 2 * (dx @ (Q @ dx)))
+        v = a * g1 + a * a / 2 * g2
+        sc = a * m1 + a * a / 2 * m2
         if me:
-            c0 = qp["A"].astype(L) @ x - qp["b"].astype(L)
-            c1 = qp["A"].astype(L) @ (x + a * dx) - qp["b"].astype(L)
-            v += nu * (np.abs(c1) - np.abs(c0)).sum(); sc += nu * np.abs(np.abs(c1) - np.abs(c0)).sum()
+            v += nu * abs_change(ce0, dce, a).sum(); sc += nu * a * mce
         if mi:
-            r0 = qp["G"].astype(L) @ x - qp["h"].astype(L) - s
-            r1 = qp["G"].astype(L) @ (x + a * dx) - qp["h"].astype(L) - (s + a * ds)
-            v += nu * (np.abs(r1) - np.abs(r0)).sum(); sc += nu * np.abs(np.abs(r1) - np.abs(r0)).sum()
             lg = np.log1p(a * ds / s)
-            v -= mu * lg.sum(); sc += mu * np.abs(lg).sum()
+            v += nu * abs_change(r0, dr, a).sum() - mu * lg.sum(); sc += nu * a * mr + mu * np.abs(lg).sum()
         out.append(float(v)); scale.append(float(sc))
     return np.array(out), np.array(scale)
 
@@ -112,7 +126,8 @@ def test_merit_ray_on_every_iterate_of_the_reference_qp_solves(name):
     """tests/golden/qptrace_*.npz (the UNMODIFIED reference solving QPs): at every iterate, the device ray -- ONE launch for
     the whole geometric sequence of backtracking candidates a0 tau^k -- against the closed form evaluated in extended
     precision from the problem data: <= 1e-13 of the summed magnitudes of the differences (the 'difference form': error
-    relative to the CHANGE of phi, which is what an Armijo test near convergence needs), and the same accept / reject
+    relative to the CHANGE of phi, which is what an Armijo test near convergence needs; the magnitudes include those of the
+    inner products behind every term, which cancel internally), and the same accept / reject
     decision of pyipm.py:1454-1459, 1534-1548 for every candidate as the host loop's two evaluations of phi give wherever
     that comparison is not inside the rounding of phi itself."""
     from pyipm_amd.ipm import IPM
@@ -143,8 +158,11 @@ def test_merit_ray_on_every_iterate_of_the_reference_qp_solves(name):
         alphas += [1e-3 * a0, 1e-6 * a0, 1e-9 * a0, 1e-12 * a0]
         got = np.array(core.merit_ray(alphas, nu, mu))
         dzh = dz.cpu().numpy()
-        want, scale = _qp_numpy_ray(qp, x, s, dzh, nu, mu, alphas)
+        want, scale = _qp_numpy_ray(qp, df, ce, ci, s, dzh, nu, mu, alphas)
         assert np.all(np.abs(got - want) <= 1e-13 * scale + 1e-300), (it, np.max(np.abs(got - want) / scale))
+        # ... and relative to the CHANGE itself for the small steps of a search's end (no cancellation left in any term)
+        tiny = np.abs(want) > 0
+        assert np.all(np.abs(got - want)[-4:] <= 1e-10 * np.abs(want)[-4:]) or not tiny[-4:].all()
         checked += len(alphas)
         # Armijo decisions: host loop = two evaluations of phi (pyipm.py:1454-1459)
         q = core.merit_info()

@@ -349,7 +349,7 @@ def test_random_schedule_options_give_the_same_bits():
             core.close()
 
 
-@pytest.mark.parametrize("shape", [(1900, 300, 500, 5), (2300, 0, 0, 6), (1000, 300, 900, 2)])
+@pytest.mark.parametrize("shape", [(1900, 300, 500, 5), (2400, 0, 0, 6), (1000, 300, 900, 2)])
 def test_wide_bulk_tiles_stop_at_the_storage_edge(shape):
     """Npad is a multiple of 128 only, a 128 x 256 bulk tile at the last 128 columns of such a matrix
     would read and rewrite 128 columns PAST the storage -- the first W slot, which the group after next reuses while the
@@ -378,3 +378,46 @@ def test_wide_bulk_tiles_stop_at_the_storage_edge(shape):
             core.close()
     for grp in (1, 2):
         assert torch.equal(outs[(128, grp)], outs[(256, grp)]), (shape, grp)
+
+
+def _poison(core):
+    """Every byte of the handle's workspace that the library has not initialised itself becomes a NaN pattern: a kernel that
+    reads memory nobody wrote (a fresh process hands out zero pages, which hides it) turns the direction into NaN."""
+    import torch
+    ws = core.workspace.view(torch.float64)
+    keep = ws.clone()
+    ws.fill_(float("nan"))
+    return keep
+
+
+@pytest.mark.parametrize("shape,nb", [((1408, 300, 768, 3), 256), ((1280, 256, 896, 4), 256), ((2176, 0, 1472, 5), 256), ((1500, 356, 700, 6), 256),
+                                      ((1408, 300, 768, 3), 128)])
+def test_no_kernel_reads_memory_nobody_wrote(shape, nb):
+    """Round 4: with the slack rows of x-block panels skipped in whole 128-row tiles, a 128 x 256 bulk tile whose columns
+    straddle the edge of that hole read W rows that no kernel had written -- stale memory (zero pages in a fresh process: every
+    test passed).  Shapes with n and / or n + mi an odd multiple of 128, wide tiles forced everywhere, the whole workspace
+    poisoned with NaN before anything is staged: the direction is finite, meets the blocks to 1e-12 and has the bits of the
+    128 x 128 schedule -- for several steps on one handle (the W slots rotate)."""
+    import torch
+    from pyipm_amd.newton import NewtonCore
+    from pyipm_amd.problems import make_qp
+    n, me, mi, seed = shape
+    qp = make_qp(n, me, mi, seed)
+    outs = {}
+    for bn in (256, 128):
+        core = NewtonCore(n, me, mi, device=0, nb=nb)
+        _poison(core)
+        for k, v in (("bulk_bn", bn), ("reserve_cus", 0), ("bulk_bn_rows", 0), ("bulk_bn_min_k", 256), ("group", 2), ("tail_group", 2),
+                     ("sweep_persist", 0)):
+            core.set_option(k, v)
+        core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+        core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+        steps = [core.step(0.0, 0.0)[0].clone() for _ in range(3)]
+        assert all(bool(torch.isfinite(s).all()) for s in steps), (shape, bn)
+        assert all(torch.equal(s, steps[0]) for s in steps), (shape, bn)
+        raw = steps[0].clone(); raw[n + mi:] *= -1.0
+        gres = core.residual()
+        assert float((core.matvec(raw) - gres).norm() / gres.norm()) <= 1e-12, (shape, bn)
+        outs[bn] = steps[0]
+        core.close()
+    assert torch.equal(outs[128], outs[256]), shape

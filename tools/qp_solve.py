@@ -44,6 +44,7 @@ def main():
            "newton_seconds_per_factorisation": ipm.timings["newton_s"] / max(ipm.backend.n_factor, 1),
            "newton_seconds_each": ipm.timings["newton_each_s"],
            "rcond_estimates": ipm.backend.n_rcond, "rcond_estimates_reused": ipm.backend.n_rcond_reused,
+           "rcond_log_call_rcond_spread": ipm.backend.rcond_log,
            "merit_note": "phi / dphi / nu threshold / KKT norms / barrier sums are device reductions of the library "
                          "(pyipm_newton_merit_info, _dots); every backtracking candidate of a search comes from one "
                          "pyipm_newton_merit_ray launch per batch of 64",
