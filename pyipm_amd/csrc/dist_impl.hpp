@@ -172,6 +172,7 @@ int dist_set_option(Ctx* ctx, const char* name, double value, bool* handled) {
         D->sag_min_bytes = value > 0 ? (size_t)value : 0;
         return PYIPM_OK;
     }
+    if (!strcmp(name, "dist_head_split")) { *handled = true; ctx->dist_head_split = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "dist_selfmsg")) {                // world == 1: pack + "broadcast" every panel anyway (measures the message path)
         *handled = true;
         DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
@@ -448,9 +449,46 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
         const int64_t nxt = p + 1;
         if (nxt < np) {
             if (g.owner(nxt) == g.rank) {
-                rc = update_range(ctx, p, nxt, 1, main); if (rc) return rc;               // head: bring panel p+1 up to date first
-                DIST_HIP(hipEventRecord(D->ev_head, main));
-                DIST_HIP(hipStreamWaitEvent(side, D->ev_head, 0));
+                // head: bring panel p+1 up to date first.  The owner's chain is every rank's critical path (across ranks the
+                // per-rank bulk work shrinks with the number of ranks, the chain does not), and the tile chain of a wide panel
+                // needs the head only INSIDE the panel's diagonal block: that part first (a 1024 x 1024 block at nb = 1024,
+                // 32-row blocks), the chain starts behind it; the rows below -- 97 % of the head's flops -- follow on ctx->rest,
+                // where the panel's rows kernels first read them (factor_block).  The same entries, the same products in the
+                // same order (round 4; the single-rank schedule's head_split).
+                const int64_t c0n = g.panel_c0(nxt), nbwn = g.panel_w(nxt);
+                const bool wide_next = ctx->dist_head_split && ctx->tile_step && ctx->inpanel32 && ctx->wide_sub >= 128 &&
+                                       ctx->wide_sub % 128 == 0 && nbwn > ctx->wide_sub && nbwn / TB <= 32 && c0n + nbwn < g.Npad &&
+                                       !panel_in_s(ctx, nxt) && !panel_in_s(ctx, p) && nbwn % 32 == 0;
+                if (wide_next) {
+                    const bool mine_p = g.owner(p) == g.rank;
+                    const double* Lop = mine_p ? ctx->A + g.local_c0(p) * g.Npad : ctx->Lbuf;
+                    const int K = (int)g.panel_w(p);
+                    int64_t pa0, pa1, pb0, pb1;
+                    active_ranges(ctx, g.panel_c0(p), g.panel_c0(p) + K, &pa0, &pa1, &pb0, &pb1);
+                    rc = ensure_rest_stream(ctx); if (rc) return rc;
+                    hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)(nbwn / 32), (unsigned)(nbwn / TB)), dim3(256), 0, main,
+                                       ctx->A, g.Npad, g.local_c0(nxt), Lop, g.Npad, wbuf(ctx, p), g.Npad, c0n, K, c0n, g.Npad,
+                                       pa0, pa1, pb0, pb1, ctx->side_prio);
+                    DIST_KCHECK();
+                    DIST_HIP(hipEventRecord(D->ev_head, main));
+                    DIST_HIP(hipStreamWaitEvent(side, D->ev_head, 0));
+                    DIST_HIP(hipStreamWaitEvent(ctx->rest, D->ev_head, 0));           // (the main stream's earlier updates of these columns)
+                    const int64_t rb = c0n + nbwn;
+                    if (g.Npad - rb <= ctx->head32_rows_dist) {
+                        hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - rb) / 32), (unsigned)(nbwn / TB)), dim3(256), 0,
+                                           ctx->rest, ctx->A, g.Npad, g.local_c0(nxt), Lop, g.Npad, wbuf(ctx, p), g.Npad, c0n, K, rb,
+                                           g.Npad, pa0, pa1, pb0, pb1, ctx->side_prio);
+                        DIST_KCHECK();
+                    } else {
+                        rc = launch_update128(ctx, ctx->rest, Lop, g.Npad, wbuf(ctx, p), K, rb, nxt / g.world, 1, /*bulk=*/true, 0, 0, 0,
+                                              g.panel_c0(p), 1, 0, ctx->head_waves);
+                        if (rc) return rc;
+                    }
+                } else {
+                    rc = update_range(ctx, p, nxt, 1, main); if (rc) return rc;
+                    DIST_HIP(hipEventRecord(D->ev_head, main));
+                    DIST_HIP(hipStreamWaitEvent(side, D->ev_head, 0));
+                }
                 on_side[(size_t)nxt] = 1;
                 rc = post(nxt, side); if (rc) return rc;
             } else {

@@ -170,7 +170,8 @@ def test_merit_ray_on_every_iterate_of_the_reference_qp_solves(name):
         phi0 = host.phi(x, s if mi else np.zeros(0))
         con = (q["ce_l1"] if me else 0.0) + (q["cis_l1"] if mi else 0.0)
         dphi0 = q["df_dx"] - nu * con - (mu * q["ds_over_s"] if mi else 0.0)
-        _close(dphi0, host.dphi(x, s if mi else np.zeros(0), dzh[:n + mi]), abs(q["df_dx"]) + nu * con + abs(mu * q["ds_over_s"]) if mi else abs(q["df_dx"]) + nu * con)
+        _close(dphi0, host.dphi(x, s if mi else np.zeros(0), dzh[:n + mi]),
+               np.abs(df * dzh[:n]).sum() + nu * con + (mu * np.abs(dzh[n:n + mi] / (s + EPS)).sum() if mi else 0.0))
         for a, dk, sc in zip(alphas, got, scale):
             arm = phi0 + a * eta * dphi0
             host_val = host.phi(x + a * dzh[:n], (s + a * dzh[n:n + mi]) if mi else np.zeros(0))
