@@ -89,7 +89,10 @@ struct Ctx {
     int s_fast = 1;                       // panels inside the slack block: closed-form elimination (k_s_panel)
     std::vector<char> grp_fast;           // per group: every panel of it takes that path (built by factor_all)
     std::vector<char> grp_x;              // per group: lies inside the x block (its chain kernels may skip the slack rows)
-    struct TileList { unsigned* dev = nullptr; unsigned count = 0; unsigned head_count = 0; };
+    struct TileList { unsigned* dev = nullptr; unsigned count = 0; unsigned head_count = 0;
+                      hipEvent_t ready = nullptr; hipStream_t on = nullptr; bool seen_done = false; };   // the async upload: its event, its stream
+    struct TlArena { unsigned* dev = nullptr; unsigned* host = nullptr; size_t cap = 0, used = 0; };    // device + pinned host memory of the lists
+    std::vector<TlArena> tl_arenas;
     std::map<std::vector<int64_t>, TileList> tile_lists;   // compact tile orders of the bulk launches (geometry repeats every step)
     int skip_zeros = 1;                   // trailing updates skip tiles that the KKT block structure makes exact zeros
     int group = 1;                        // panels per bulk trailing update
@@ -239,6 +242,7 @@ struct Ctx {
     hipEvent_t ev[8] = {};
     hipEvent_t ev_prov[4] = {}; bool prov_valid[2] = {false, false}; double prov_bytes[2] = {0.0, 0.0};   // provider products
     bool ev_assemble_valid = false, ev_solve_valid = false;
+    double setup_lists_ms = 0.0; int setup_lists_n = 0;     // host time spent building tile lists (one-time per geometry; PYIPM_SETUP_TRACE)
     int debug_fault = 0;                  // test hook: 1 / 2 = the next tile-list build throws std::bad_alloc / std::runtime_error
     std::string err;
 };

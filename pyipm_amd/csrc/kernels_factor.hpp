@@ -464,6 +464,13 @@ __global__ __launch_bounds__(256) void k_panel_scale(
     // (row = (lane>>4)+4r of tile t, col = lane&15) puts L[i][16t+4r+(lane>>4)] in accumulator [t][r], which
     // is exactly the B-operand layout of k-step 4t+r: the refinement GEMMs need no data movement.
     __shared__ double X[TB][TB + 2];        // holds sign*inv(T), then -sign*T, then sign*inv(T) again (one array: LDS decides
+    // gridDim.y > 1 (a receiver rebuilding L of a whole panel, pyipm_newton_panel_unpack): tile column blockIdx.y of the panel --
+    // the tile columns are independent there (L_t = W_t inv(T_t)), one launch instead of nb / 64 in a row (round 4)
+    if (gridDim.y > 1) {
+        const int64_t t = blockIdx.y;
+        col_out += t * TB; col_in += t * TB; col_w += t * TB;
+        Tinv += t * (int64_t)(TB * TB); Tsave += t * (int64_t)(TB * TB); Tflag += t;
+    }
     {                                       // how many of these short blocks fit into the slot a retiring update block frees)
         const int64_t r0 = row_begin + (int64_t)blockIdx.x * TB;
         if (r0 >= hole0 && r0 + TB <= hole1) return;          // S rows identically zero here (KKT structure): L = 0 already

@@ -4,6 +4,7 @@
 #include "ctx.hpp"
 #include <algorithm>
 #include <functional>
+#include <chrono>
 #include "kernels_assemble.hpp"
 #include "kernels_factor.hpp"
 #include "kernels_panel.hpp"
@@ -210,8 +211,13 @@ double active_area(int64_t row_begin, int64_t Npad, int64_t j0, int64_t j1, int6
 // every block; tiles that are out of range, above the diagonal or structurally zero are dropped, the eight
 // per-XCD sequences (block b runs on XCD b % 8) are levelled by moving the tails of long ones to short ones,
 // and the result is interleaved back into launch order.  Cached per geometry: it repeats every step.
+// The list reaches the device WITHOUT a host synchronisation (round 4): built into pinned host memory, copied with
+// hipMemcpyAsync on the stream of its first consumer (a plain hipMemcpy is ordered against the legacy default stream -- with
+// torch's default stream as the handle's stream every list of a first factorisation waited for all the work enqueued so
+// far: 35 lists, 98 ms of host time, the GPU idle behind the host for 25 ms of the first step of every solve); a consumer on
+// another stream waits for the copy's event until it has been seen complete.  Device and host memory come from arenas.
 int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, unsigned* count, int bn = 128,
-              unsigned* head_count = nullptr) {
+              unsigned* head_count = nullptr, hipStream_t consumer = nullptr) {
     if (ctx->debug_fault) {                             // test hook (tests/test_gpu_host_abi.py): the containers below can throw
         const int k = ctx->debug_fault; ctx->debug_fault = 0;
         if (k == 1) throw std::bad_alloc();
@@ -220,13 +226,22 @@ int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, uns
     std::vector<int64_t> key = {u.row_begin, u.Npad, u.first_lp, u.nrt, u.nct, u.a0, u.a1, u.b0, u.b1, u.nb, u.rt_min0, u.rt_step, bn, u.head_ct, u.sub0};
     auto it = ctx->tile_lists.find(key);
     if (it != ctx->tile_lists.end()) {
-        *dev = it->second.dev; *count = it->second.count; if (head_count) *head_count = it->second.head_count; return 0;
+        Ctx::TileList& t = it->second;
+        if (t.ready && !t.seen_done) {
+            if (hipEventQuery(t.ready) == hipSuccess) t.seen_done = true;
+            else if (consumer != t.on) PYIPM_HIP(hipStreamWaitEvent(consumer, t.ready, 0));
+        }
+        *dev = t.dev; *count = t.count; if (head_count) *head_count = t.head_count; return 0;
     }
     if (ctx->tile_lists.size() >= 1024) {              // geometries that keep changing (condensed option: |A| varies): start over
         PYIPM_HIP(hipDeviceSynchronize());
-        for (auto& kv : ctx->tile_lists) if (kv.second.dev) hipFree(kv.second.dev);
+        for (auto& kv : ctx->tile_lists) if (kv.second.ready) hipEventDestroy(kv.second.ready);
         ctx->tile_lists.clear();
+        for (auto& a : ctx->tl_arenas) { a.used = 0; }
     }
+    const auto t_build0 = std::chrono::steady_clock::now();
+    struct BuildTimer { Ctx* c; std::chrono::steady_clock::time_point t0;
+                        ~BuildTimer() { c->setup_lists_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); c->setup_lists_n++; } } bt_{ctx, t_build0};
     const int64_t rounds = (nsup + 7) / 8, nblocks = rounds * 8 * SUPER * SUPER;
     const int nsr = (u.nrt + SUPER - 1) >> 3, nsc = (u.nct + SUPER - 1) >> 3;
     std::vector<unsigned> seq[8];
@@ -274,8 +289,27 @@ int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, uns
     Ctx::TileList tl;
     tl.count = (unsigned)list.size(); tl.head_count = nhead;
     if (tl.count) {
-        PYIPM_HIP(hipMalloc((void**)&tl.dev, list.size() * sizeof(unsigned)));
-        PYIPM_HIP(hipMemcpy(tl.dev, list.data(), list.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        // a slot in the arenas (device + pinned host, 1 Mi entries each; a list longer than that gets an arena of its own)
+        const size_t need = (list.size() + 63) / 64 * 64;
+        Ctx::TlArena* ar = nullptr;
+        for (auto& a : ctx->tl_arenas) if (a.cap - a.used >= need) { ar = &a; break; }
+        if (!ar) {
+            Ctx::TlArena a;
+            a.cap = need > ((size_t)1 << 20) ? need : ((size_t)1 << 20);
+            PYIPM_HIP(hipMalloc((void**)&a.dev, a.cap * sizeof(unsigned)));
+            if (hipHostMalloc((void**)&a.host, a.cap * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) {
+                hipFree(a.dev); ctx->err = "no pinned host memory for the tile lists"; return PYIPM_E_NOMEM; }
+            ctx->tl_arenas.push_back(a);
+            ar = &ctx->tl_arenas.back();
+        }
+        tl.dev = ar->dev + ar->used;
+        unsigned* hsrc = ar->host + ar->used;
+        ar->used += need;
+        memcpy(hsrc, list.data(), list.size() * sizeof(unsigned));
+        PYIPM_HIP(hipMemcpyAsync(tl.dev, hsrc, list.size() * sizeof(unsigned), hipMemcpyHostToDevice, consumer));
+        PYIPM_HIP(hipEventCreateWithFlags(&tl.ready, hipEventDisableTiming));
+        PYIPM_HIP(hipEventRecord(tl.ready, consumer));
+        tl.on = consumer;
     }
     ctx->tile_lists[key] = tl;
     *dev = tl.dev; *count = tl.count; if (head_count) *head_count = nhead;
@@ -319,7 +353,7 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
         const int64_t nsup = upd_super_count<256>(u);
         if (nsup <= 0) return 0;
         unsigned ntiles = 0;
-        int rc = tile_list(ctx, u, nsup, &u.tiles, &ntiles, 256); if (rc) return rc;
+        int rc = tile_list(ctx, u, nsup, &u.tiles, &ntiles, 256, nullptr, stream); if (rc) return rc;
         if (ntiles == 0) return 0;
         hipLaunchKernelGGL((k_update<256, true, 8>), dim3(ntiles), dim3(512), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
         PYIPM_KCHECK();
@@ -331,7 +365,7 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
         const int64_t nsup = upd_super_count<128>(u);
         if (nsup <= 0) return 0;
         unsigned ntiles = 0;
-        int rc = tile_list(ctx, u, nsup, &u.tiles, &ntiles, 128, head_count); if (rc) return rc;
+        int rc = tile_list(ctx, u, nsup, &u.tiles, &ntiles, 128, head_count, stream); if (rc) return rc;
         if (list_only || ntiles == 0) return 0;
         dim3 grid(ntiles, (unsigned)ksplit);             // K is the length of ONE split
         if (ksplit > 1) u.ks_cstride = ks_cstride;
@@ -1230,6 +1264,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     if (g.world != 1) { ctx->err = "factor(): single-rank entry point; use the per-panel phases when world > 1"; return PYIPM_E_BADARG; }
     if (!ctx->assembled) { ctx->err = "factor: assemble first"; return PYIPM_E_BADARG; }
     ctx->per_panel_mode = false;
+    const auto t_host0 = std::chrono::steady_clock::now();
     int rc = factor_begin(ctx); if (rc) return rc;
     if (!ctx->side) {
         // panel kernels are latency-critical and tiny: highest dispatch priority, so they take the first
@@ -1468,6 +1503,11 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     }
     PYIPM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
     ctx->assembled = false;                 // storage now holds the factor
+    if (getenv("PYIPM_SETUP_TRACE")) {
+        const double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+        fprintf(stderr, "[pyipm] factor_all: host enqueue %.2f ms (tile lists built so far: %d in %.2f ms)\n", host_ms,
+                ctx->setup_lists_n, ctx->setup_lists_ms);
+    }
     rc = factor_end(ctx, stats);
     float ms = 0.f;
     PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
@@ -1701,7 +1741,8 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     if (ctx->stg_d2L) hipFree(ctx->stg_d2L);
     if (ctx->stg_Je) hipFree(ctx->stg_Je);
     if (ctx->stg_Ji) hipFree(ctx->stg_Ji);
-    for (auto& kv : ctx->tile_lists) if (kv.second.dev) hipFree(kv.second.dev);
+    for (auto& kv : ctx->tile_lists) if (kv.second.ready) hipEventDestroy(kv.second.ready);
+    for (auto& a : ctx->tl_arenas) { if (a.dev) hipFree(a.dev); if (a.host) hipHostFree(a.host); }
     if (ctx->JT) hipFree(ctx->JT);
     if (ctx->Jx) hipFree(ctx->Jx);
     if (ctx->cond_pos) hipFree(ctx->cond_pos);
@@ -2350,12 +2391,19 @@ int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf)
             PYIPM_HIP(hipMemcpy2DAsync(wbuf(ctx, p) + h1, (size_t)g.Npad * sizeof(double), buf + seg0, (size_t)m * sizeof(double),
                                        (size_t)seg1 * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
         // rebuild the block column L = W * inv(T) tile by tile into Lbuf (rows of the hole: never read, skipped)
+        // (one launch for all tile columns -- they are independent on a receiver; sixteen launches in a row took 0.6 ms per
+        //  message at nb = 1024, on every receiver's path to its next head: tools/rank_replay.py)
         NextUpd nu_off; memset(&nu_off, 0, sizeof(nu_off));
-        for (int t = 0; t < nbw / TB; ++t) {
+        if (nbw / TB > 1) {
+            hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)((g.Npad - c1) / TB), (unsigned)(nbw / TB)), dim3(256), 0, ctx->stream,
+                               ctx->Lbuf, g.Npad, (int64_t)0, wbuf(ctx, p), g.Npad, (int64_t)0,
+                               (double*)nullptr, (int64_t)0, (int64_t)0, dinv, tsv, ctx->Tflag + c0 / TB, ctx->block_refine, c1, h0, h1,
+                               (unsigned long long*)nullptr, -1.0, nu_off);
+            PYIPM_KCHECK();
+        } else {
             hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)((g.Npad - c1) / TB)), dim3(256), 0, ctx->stream,
-                               ctx->Lbuf, g.Npad, (int64_t)t * TB, wbuf(ctx, p), g.Npad, (int64_t)t * TB,
-                               (double*)nullptr, (int64_t)0, (int64_t)0, dinv + (int64_t)t * TB * TB,
-                               tsv + (int64_t)t * TB * TB, ctx->Tflag + c0 / TB + t, ctx->block_refine, c1, h0, h1,
+                               ctx->Lbuf, g.Npad, (int64_t)0, wbuf(ctx, p), g.Npad, (int64_t)0,
+                               (double*)nullptr, (int64_t)0, (int64_t)0, dinv, tsv, ctx->Tflag + c0 / TB, ctx->block_refine, c1, h0, h1,
                                (unsigned long long*)nullptr, -1.0, nu_off);
             PYIPM_KCHECK();
         }
