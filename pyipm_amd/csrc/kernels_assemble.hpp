@@ -225,6 +225,121 @@ __global__ __launch_bounds__(256) void k_symv_row(
     if (lane == 0) y[j] = acc + delta * v[j];
 }
 
+// sym(triu(U)) v in ONE pass over the upper triangle (round 4).  The two kernels above / below read the
+// triangle once each -- row part and mirrored part -- i.e. 8 n^2 bytes for a product that needs 4 n^2.  Here a block takes a
+// group of 64-row strips (the rows of chunk blockIdx.y) times a segment of SYMV_SEG columns (blockIdx.x) and walks its 64 x 64
+// tiles through shared memory: each element is loaded once (512-byte rows, coalesced) and used twice --
+//   row sums   r[j] += U[j,k] v[k]   (k >= j): thread (row = tid/4, q = tid%4) adds its 16 columns of every tile IN ITS LANE
+//                                    and folds the four lanes once per strip -> part_row[segment][local row];
+//   col sums   c[k] += U[j,k] v[j]   (j <  k): thread (col = tid/4, q) adds its 16 rows, folds the four lanes and keeps the
+//                                    sum of its column over the strips of the chunk in shared memory -> part_col[chunk][k].
+// Deterministic: every partial has one writer and a fixed order; k_symv_finish adds the partials in a fixed order.
+constexpr int SYMV_SEG = 512;            // columns per block
+__global__ __launch_bounds__(256) void k_symv_tiles(
+    double* __restrict__ part_row, double* __restrict__ part_col, const double* __restrict__ U, int64_t ldh, int64_t n,
+    const double* __restrict__ v, int64_t rows_per_chunk, RowMap rm)
+{
+    __shared__ double T[64][65];
+    __shared__ double colacc[4][SYMV_SEG];                                // one copy per wave: summed in a fixed order at the end
+    __shared__ double vrow[64], vcol[64], rred[4][64];
+    const int tid = threadIdx.x;
+    const int lrow = tid >> 6, lcol = tid & 63;                           // loader: rows lrow, lrow + 4, ...; column lcol of the tile
+    // summing: lane = row (row sums) / lane = column (column sums), wave w takes the w-th quarter of the other index -- every
+    // shared-memory access of a wave then touches 64 consecutive words or 64 rows of stride 65: no bank conflicts
+    const int w = tid >> 6, l = tid & 63;
+    const int64_t k_seg0 = (int64_t)blockIdx.x * SYMV_SEG;
+    int64_t k_seg1 = k_seg0 + SYMV_SEG; if (k_seg1 > n) k_seg1 = n;
+    const int64_t jl0 = (int64_t)blockIdx.y * rows_per_chunk;             // local rows of this chunk (a multiple of 64)
+    int64_t jl1 = jl0 + rows_per_chunk; if (jl1 > rm.nloc) jl1 = rm.nloc;
+    if (jl0 >= jl1 || k_seg0 >= n) return;
+    for (int c = tid; c < 4 * SYMV_SEG; c += 256) (&colacc[0][0])[c] = 0.0;
+    bool any = false;
+    for (int64_t sl = jl0; sl < jl1; sl += 64) {                          // strips of 64 local rows: contiguous global rows j0 .. j0 + 63
+        const int64_t j0 = rm.glob(sl);
+        if (j0 >= k_seg1) continue;                                       // (block-uniform) the strip lies below the segment's columns
+        any = true;
+        const int rows = (int)((jl1 - sl) < 64 ? (jl1 - sl) : 64);
+        int64_t kt0 = (j0 / 64) * 64; if (kt0 < k_seg0) kt0 = k_seg0;
+        // every load is unconditional (clamped address, masked value): a branch around a load makes hipcc wait for each one in
+        // turn -- sixteen memory latencies per tile instead of one (first version: 2.0 ms for the product instead of 0.5)
+        const double* rowp[16];
+        #pragma unroll
+        for (int ps = 0; ps < 16; ++ps) {
+            const int rr = ps * 4 + lrow;
+            rowp[ps] = U + rm.brow(sl + (rr < rows ? rr : rows - 1)) * ldh;
+        }
+        double ureg[16], vreg;
+#define PYIPM_SYMV_LOAD(kt_)                                                                                   \
+        {                                                                                                      \
+            const int64_t kc_ = ((kt_) + lcol < n) ? (kt_) + lcol : n - 1;                                     \
+            _Pragma("unroll") for (int ps = 0; ps < 16; ++ps) ureg[ps] = rowp[ps][kc_];                        \
+            vreg = v[kc_];                                                                                     \
+        }
+        PYIPM_SYMV_LOAD(kt0)
+        const double vr_mine = v[j0 + (lcol < rows ? lcol : rows - 1)];
+        double racc = 0.0;
+        for (int64_t kt = kt0; kt < k_seg1; kt += 64) {
+            __syncthreads();                                              // the tile before has been consumed
+            {
+                const int64_t k = kt + lcol;
+                #pragma unroll
+                for (int ps = 0; ps < 16; ++ps) {
+                    const int rr = ps * 4 + lrow;
+                    T[rr][lcol] = (rr < rows && k < n && k >= j0 + rr) ? ureg[ps] : 0.0;
+                }
+                if (lrow == 0) { vcol[lcol] = (k < n) ? vreg : 0.0; if (kt == kt0) vrow[lcol] = (lcol < rows) ? vr_mine : 0.0; }
+            }
+            __syncthreads();
+            if (kt + 64 < k_seg1) PYIPM_SYMV_LOAD(kt + 64)                // the next tile's loads fly while this one is summed
+            {   // row sums: row l, columns 16 w .. 16 w + 15
+                double a = 0.0;
+                #pragma unroll
+                for (int c = 0; c < 16; ++c) a = fma(T[l][16 * w + c], vcol[16 * w + c], a);
+                racc += a;
+            }
+            {   // column sums, strictly above the diagonal only (j < k): column l, rows 16 w .. 16 w + 15
+                double a = 0.0;
+                const int64_t k = kt + l;
+                #pragma unroll
+                for (int c = 0; c < 16; ++c) { const int rr = 16 * w + c; a = fma((j0 + rr < k) ? T[rr][l] : 0.0, vrow[rr], a); }
+                if (k < k_seg1) colacc[w][(int)(k - k_seg0)] += a;        // (one owner thread per (wave, column) for the whole block)
+            }
+        }
+#undef PYIPM_SYMV_LOAD
+        rred[w][l] = racc;
+        __syncthreads();
+        if (w == 0 && l < rows) part_row[(int64_t)blockIdx.x * rm.nloc + (sl + l)] = (rred[0][l] + rred[1][l]) + (rred[2][l] + rred[3][l]);
+    }
+    // rows of this chunk whose strips lie wholly below the segment were skipped: their row partial for this segment is zero
+    for (int64_t sl = jl0; sl < jl1; sl += 64) {
+        if (rm.glob(sl) < k_seg1) continue;
+        if (tid < 64 && sl + tid < jl1) part_row[(int64_t)blockIdx.x * rm.nloc + (sl + tid)] = 0.0;
+    }
+    __syncthreads();
+    for (int c = tid; c < SYMV_SEG && k_seg0 + c < n; c += 256)
+        part_col[(int64_t)blockIdx.y * n + k_seg0 + c] = any ? (colacc[0][c] + colacc[1][c]) + (colacc[2][c] + colacc[3][c]) : 0.0;
+}
+
+// y[a] = (a is a row this rank works on ? sum_seg part_row[seg][local row] + delta v[a] : 0) + sum_chunk part_col[chunk][a]
+__global__ __launch_bounds__(256) void k_symv_finish(
+    double* __restrict__ y, const double* __restrict__ part_row, const double* __restrict__ part_col, int64_t n,
+    const double* __restrict__ v, double delta, int nseg, int nchunk, RowMap rm)
+{
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= n) return;
+    double acc = 0.0;
+    int64_t jl = -1;
+    if (rm.world == 1) jl = a;
+    else { const int64_t p = a / rm.nb; if (p % rm.world == rm.rank) jl = (p / rm.world) * (int64_t)rm.nb + a % rm.nb; }
+    if (jl >= 0 && jl < rm.nloc) {
+        for (int sg = 0; sg < nseg; ++sg) acc += part_row[(int64_t)sg * rm.nloc + jl];
+        acc += delta * v[a];
+    }
+    double cacc = 0.0;
+    for (int c = 0; c < nchunk; ++c) cacc += part_col[(int64_t)c * n + a];
+    y[a] = acc + cacc;
+}
+
 // Column-walk partial products, deterministic two-pass:
 //   part[chunk][a] = sum_{j in chunk, j < jmax(a)} M[j*ldm + a] * x[j]
 // strict_upper != 0 restricts to j < a (the mirrored half of triu(d2L)).

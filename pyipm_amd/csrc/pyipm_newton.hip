@@ -56,6 +56,10 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base, bool provider_only = fa
     const size_t cd_chunks = 64;                       // column-dot partials for the mat-vec
     size_t maxcol = (size_t)(g.n > g.me ? g.n : g.me); if ((size_t)g.mi > maxcol) maxcol = g.mi;
     if (cd_chunks * maxcol > npart) npart = cd_chunks * maxcol;
+    {   // one-pass symmetric product (k_symv_tiles): 64 chunks of column partials + one row partial per column segment
+        const size_t nseg = ((size_t)g.n + SYMV_SEG - 1) / SYMV_SEG;
+        if ((cd_chunks + nseg) * (size_t)g.n > npart) npart = (cd_chunks + nseg) * (size_t)g.n;
+    }
     const size_t op = cv.take(npart * D);
     const size_t odf = cv.take((size_t)(g.n + 1) * D);
     const size_t oce = cv.take((size_t)(g.me + 1) * D);
@@ -1069,6 +1073,27 @@ int solve_inplace(Ctx* ctx, double* v, bool forward_done = false) {
 // y = Hc v from the staged blocks (Npad vectors on the device).  With several ranks every rank adds the terms of the
 // KKT columns it owns (row j of triu(d2L) | Je | Ji is column j of the lower triangle), rank 0 the element-wise s /
 // multiplier part; the caller sums y over the ranks (dist_impl.hpp).
+
+// y[0:n) = sym(triu(d2L)) v + delta v for the rows / columns this rank works on: one pass over the upper triangle
+// (k_symv_tiles + k_symv_finish; ctx->partial holds the partials)
+int symv_dev(Ctx* ctx, const double* v, double* y, double delta, const RowMap& rm) {
+    const Geo& g = ctx->g;
+    const int64_t n = g.n;
+    const int nchunk = 64;
+    int64_t rpc = ((rm.nloc + nchunk - 1) / nchunk + 63) / 64 * 64; if (rpc < 64) rpc = 64;
+    const int nch = (int)((rm.nloc + rpc - 1) / rpc);
+    const int nseg = (int)((n + SYMV_SEG - 1) / SYMV_SEG);
+    double* part_col = ctx->partial;
+    double* part_row = ctx->partial + (size_t)nchunk * (size_t)n;
+    if (nch > 0) {
+        hipLaunchKernelGGL(k_symv_tiles, dim3((unsigned)nseg, (unsigned)nch), dim3(256), 0, ctx->stream, part_row, part_col,
+                           ctx->d2L, ctx->ld_d2L, n, v, rpc, rm);
+        PYIPM_KCHECK();
+    }
+    hipLaunchKernelGGL(k_symv_finish, grid1(n), dim3(256), 0, ctx->stream, y, part_row, part_col, n, v, delta, nseg, nch, rm);
+    PYIPM_KCHECK();
+    return 0;
+}
 int kkt_matvec_dev(Ctx* ctx, const double* v, double* y) {
     const Geo& g = ctx->g;
     const int64_t n = g.n, me = g.me, mi = g.mi;
@@ -1079,21 +1104,14 @@ int kkt_matvec_dev(Ctx* ctx, const double* v, double* y) {
     const int nchunk = 64;
     const int64_t rpc = (nl + nchunk - 1) / nchunk > 0 ? (nl + nchunk - 1) / nchunk : 1;
     if (nl > 0) {
-        // x block: row part of triu(d2L) + delta
-        hipLaunchKernelGGL(k_symv_row, grid1(nl, 4), dim3(256), 0, ctx->stream, y, ctx->d2L, ctx->ld_d2L, n, v, ctx->delta, rm);
-        PYIPM_KCHECK();
+        // x block: sym(triu(d2L)) v + delta v, one pass over the upper triangle (row sums and mirrored column sums together)
+        { int r2 = symv_dev(ctx, v, y, ctx->delta, rm); if (r2) return r2; }
         // + Je v_e + Ji v_i
         if (me + mi > 0) {
             hipLaunchKernelGGL(k_rowdot2, grid1(nl, 4), dim3(256), 0, ctx->stream, y, (const double*)nullptr, nl,
                                ctx->Je, ctx->ld_Je, v + n + mi, me, ctx->Ji, ctx->ld_Ji, v + n + mi + me, mi, 1, 0, rm);
             PYIPM_KCHECK();
         }
-        // + mirrored strict upper part of d2L (column walk, deterministic two-pass)
-        hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((n + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
-                           ctx->partial, ctx->d2L, ctx->ld_d2L, nl, n, v, rpc, 1, rm);
-        PYIPM_KCHECK();
-        hipLaunchKernelGGL(k_coldot_reduce, grid1(n), dim3(256), 0, ctx->stream, y, ctx->partial, n, nchunk, 1);
-        PYIPM_KCHECK();
     }
     // s, lambda_e, lambda_i, pad: element-wise parts (one rank)
     if (g.Npad > n && g.rank == 0) {                   // (nothing beyond the x block when me = mi = 0 and n is a multiple of 128)
@@ -2068,15 +2086,9 @@ static int block_products_dev(Ctx* ctx, const double* v, double* Qv, double* JeT
     const int64_t rpc = (n + nchunk - 1) / nchunk;
     if (ctx->profile) PYIPM_HIP(hipEventRecord(ctx->ev_prov[0], ctx->stream));
     double bytes = 0.0;
-    if (Qv) {            // sym(triu(d2L)) v: row part + mirrored strict upper part, each one pass over the upper triangle
-        hipLaunchKernelGGL(k_symv_row, grid1(n, 4), dim3(256), 0, ctx->stream, Qv, ctx->d2L, ctx->ld_d2L, n, v, 0.0, rm);
-        PYIPM_KCHECK();
-        hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((n + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
-                           ctx->partial, ctx->d2L, ctx->ld_d2L, n, n, v, rpc, 1, rm);
-        PYIPM_KCHECK();
-        hipLaunchKernelGGL(k_coldot_reduce, grid1(n), dim3(256), 0, ctx->stream, Qv, ctx->partial, n, nchunk, 1);
-        PYIPM_KCHECK();
-        bytes += 8.0 * (double)n * (double)n;
+    if (Qv) {            // sym(triu(d2L)) v: ONE pass over the upper triangle (round 4: was a row pass + a mirrored pass)
+        int r2 = symv_dev(ctx, v, Qv, 0.0, rm); if (r2) return r2;
+        bytes += 4.0 * (double)n * (double)n;
     }
     if (JeTv && me > 0) {
         hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((me + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
