@@ -153,7 +153,14 @@ def pmc_traffic(N, nb, bn=256):
     FETCH_SIZE / WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md; tools/pmc_update.sh,
     tools/pmc_summary.py).  Counters cannot be collected inside this process, so the figure is attached
     only for the configuration it was measured on; otherwise null."""
-    name = "r03_z_pmc_update.json" if bn == 256 else "r03_z_pmc_update_bn128.json"
+    name = None
+    for rnd in ("r04", "r03"):                           # the latest committed counter passes of this command
+        cand = "%s_z_pmc_update.json" % rnd if bn == 256 else "%s_z_pmc_update_bn128.json" % rnd
+        if os.path.exists(os.path.join(ROOT, "profiles", cand)):
+            name = cand
+            break
+    if name is None:
+        return None, None
     path = os.path.join(ROOT, "profiles", name)
     if N != 32768 or nb != 256 or os.environ.get("PYIPM_NEWTON_GROUP") not in (None, "8") or not os.path.exists(path):
         return None, None

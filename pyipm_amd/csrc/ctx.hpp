@@ -161,6 +161,7 @@ struct Ctx {
                                           // the rows below the diagonal block then take (head32_rows decides that)
     int fused_head = 0;                   // (measured r03: 106.55 vs 106.2 ms -- no gain, off) bulk-bound phase: the lookahead head is the first tiles of the bulk launch itself (they bump a
                                           // device counter the next chain waits for) instead of a second MFMA kernel beside it
+    int64_t fused_head_rows = 0;          // ... only while more rows than this remain below the next group's first column
     unsigned* head_counters = nullptr;    // one per group (device), zeroed by factor_begin; [n] = error flag of k_wait_counter
     size_t n_head_counters = 0;
     int reserve_cus = 16;                 // chain-bound phases: bulk updates run as persistent launches that leave this many CUs

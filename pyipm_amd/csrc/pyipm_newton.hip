@@ -350,15 +350,17 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     // (col_end % 256: Npad is a multiple of 128 only -- a 256-wide tile at the last 128 columns would read and rewrite 128
     // columns past the storage, i.e. the first W slot, and W rows past Npad; such shapes keep 128 x 128 tiles)
     if (ctx->xcd_swizzle && bulk && ctx->bulk_bn == 256 && use_waves == 8 && waves == 0 && ksplit == 1 && g.nb % 256 == 0 &&
-        col_end % 256 == 0 && K >= ctx->bulk_bn_min_k && head_ct == 0 && nct_sub == 0 && (ctx->bulk_bn_all || ctx->reserve_cus <= 0 || m > (ctx->bulk_bn_rows > ctx->persist_rows ? ctx->bulk_bn_rows : ctx->persist_rows))) {
+        col_end % 256 == 0 && K >= ctx->bulk_bn_min_k && head_ct % 2 == 0 && nct_sub == 0 && (ctx->bulk_bn_all || ctx->reserve_cus <= 0 || m > (ctx->bulk_bn_rows > ctx->persist_rows ? ctx->bulk_bn_rows : ctx->persist_rows))) {
         // 128 x 256 tiles (the K = 1024 bulk launches of the single-rank schedule, the K = nb launches of the per-panel one)
         u.nct = (int)(n_lp * (g.nb / 256));
+        u.head_ct = head_ct / 2;                        // (fused head: the callers count 128-column tiles)
         upd_fill_affine<256>(u);
         const int64_t nsup = upd_super_count<256>(u);
         if (nsup <= 0) return 0;
         unsigned ntiles = 0;
-        int rc = tile_list(ctx, u, nsup, &u.tiles, &ntiles, 256, nullptr, stream); if (rc) return rc;
-        if (ntiles == 0) return 0;
+        int rc = tile_list(ctx, u, nsup, &u.tiles, &ntiles, 256, head_count, stream); if (rc) return rc;
+        if (used_bn) *used_bn = 256;
+        if (list_only || ntiles == 0) return 0;
         hipLaunchKernelGGL((k_update<256, true, 8>), dim3(ntiles), dim3(512), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, u);
         PYIPM_KCHECK();
         if (used_bn) *used_bn = 256;
@@ -1444,8 +1446,9 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             {
                 bool any_early = false;
                 for (int64_t q = p0; q < p0 + n0; ++q) any_early = any_early || early[(size_t)q];
-                fused = ctx->fused_head && ctx->xcd_swizzle && ctx->bulk_waves == 8 && ctx->bulk_bn == 128 && !fast_src && !nxt_fast &&
+                fused = ctx->fused_head && ctx->xcd_swizzle && ctx->bulk_waves == 8 && !fast_src && !nxt_fast &&
                         cs == ctx->side && !any_early && g.world == 1 && g.Npad - g.panel_c0(p1) > ctx->persist_rows &&
+                        g.Npad - g.panel_c0(p1) > ctx->fused_head_rows &&
                         (size_t)grp < ctx->n_head_counters;
             }
             if (fused) {
@@ -2495,6 +2498,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
     if (!strcmp(name, "head_split_rows")) { ctx->head_split_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "fused_head")) { ctx->fused_head = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "fused_head_rows")) { ctx->fused_head_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "reserve_cus")) { ctx->reserve_cus = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "persist_rows")) { ctx->persist_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "bulk_bn")) { ctx->bulk_bn = (int)value == 256 ? 256 : 128; return PYIPM_OK; }
