@@ -9,6 +9,7 @@ simply split by rank.  Same algorithm and tile-inversion code as the single-syst
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import c_void_p
 
 import numpy as np
@@ -42,6 +43,8 @@ class BatchedNewton(object):
             raise NewtonError("batched handles need n + 2 mi + me <= 1024 (got %d)" % self.N)
         with torch.cuda.device(self.device):
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            if os.environ.get("PYIPM_POISON_WORKSPACE"):     # test hook (tests/conftest.py): every byte the library does not write
+                self.workspace.fill_(255)                    # itself reads back as NaN -- zero pages of a fresh process hide such reads
             h = c_void_p()
             rc = self.lib.pyipm_newton_create_batched(ctypes.byref(h), self.n, self.me, self.mi, batch, self.device.index,
                                                       c_void_p(self.workspace.data_ptr()), need,

@@ -248,6 +248,7 @@ int pyipm_lbfgs_create(pyipm_lbfgs_ctx** out, int64_t n, int64_t me, int64_t mi,
         if (lb->gcx) pyipm_newton_destroy(reinterpret_cast<pyipm_newton_ctx*>(lb->gcx));
         delete lb; return PYIPM_E_NOMEM;
     }
+    if (getenv("PYIPM_POISON_WORKSPACE")) hipMemset(lb->ws, 0xFF, lb->ws_bytes);   // test hook (tests/conftest.py): NaN wherever nothing is written first
     lb_carve(lb, n, me, mi, max_pairs, lb->p_pad, lb->n_pad, lb->ws);
     bool ok = true;
     if (lb->p > 0) ok = hipMemsetAsync(lb->JT, 0, (size_t)lb->p_pad * (size_t)lb->n_pad * sizeof(double), lb->stream) == hipSuccess;

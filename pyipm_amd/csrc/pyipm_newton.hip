@@ -1618,6 +1618,7 @@ static int create_impl(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t mi
         ctx->ws = (char*)workspace; ctx->own_ws = false;
     } else {
         if (hipMalloc((void**)&ctx->ws, need) != hipSuccess) return create_fail(ctx, PYIPM_E_NOMEM);
+        if (getenv("PYIPM_POISON_WORKSPACE")) hipMemset(ctx->ws, 0xFF, need);      // test hook: NaN wherever nothing is written before it is read
         ctx->own_ws = true;
     }
     ctx->ws_bytes = need;
@@ -1661,6 +1662,7 @@ int pyipm_newton_create_batched(pyipm_newton_ctx** out, int64_t n, int64_t me, i
         ctx->ws = (char*)workspace; ctx->own_ws = false;
     } else {
         if (hipMalloc((void**)&ctx->ws, need) != hipSuccess) return create_fail(ctx, PYIPM_E_NOMEM);
+        if (getenv("PYIPM_POISON_WORKSPACE")) hipMemset(ctx->ws, 0xFF, need);      // test hook: NaN wherever nothing is written before it is read
         ctx->own_ws = true;
     }
     ctx->ws_bytes = need;

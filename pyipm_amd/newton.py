@@ -201,6 +201,8 @@ class NewtonCore(object):
             raise NewtonError("invalid geometry n=%d me=%d mi=%d nb=%d world=%d rank=%d" % (n, me, mi, nb, world, rank))
         with torch.cuda.device(self.device):
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+            if os.environ.get("PYIPM_POISON_WORKSPACE"):     # test hook (tests/conftest.py): every byte the library does not write
+                self.workspace.fill_(255)                    # itself reads back as NaN -- zero pages of a fresh process hide such reads
             h = c_void_p()
             if self.provider_only:
                 rc = self.lib.pyipm_newton_create_provider(ctypes.byref(h), self.n, self.me, self.mi, self.device.index,

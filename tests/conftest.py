@@ -9,6 +9,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# Every handle the GPU suite creates gets its workspace filled with NaN before the library initialises it (newton.py, batched.py,
+# the library-owned allocations): a kernel that reads memory nobody wrote shows up instead of hiding behind the zero pages of a
+# fresh process (round 4: a 128 x 256 update tile did exactly that).  Worker processes inherit it.
+os.environ.setdefault("PYIPM_POISON_WORKSPACE", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -74,3 +74,31 @@ def test_product_never_imports_oracle():
                         "``/root/reference", "").replace("/root/reference/pyipm.py:", ""):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_bench_watchdog_prints_an_error_line_instead_of_hanging(tmp_path):
+    """bench.py's watchdog: a phase that overruns -- a stalled collective, a communicator that never comes
+    up -- ends the run with ONE JSON line carrying an `error` field on the descriptor bench.py prints its result to, and
+    exit status 3; a phase that finishes in time leaves nothing behind."""
+    import json
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "wd = bench.Watchdog(1, 0, {'metric': 'newton_steps_per_sec', 'n_gpus': 8})\n"
+        "wd.watch('quick phase', 30); time.sleep(0.2); wd.clear()\n"
+        "wd.watch('communicator bring-up', 1.5)\n"
+        "time.sleep(30)\n"
+        "print('not reached')\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 3
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "not reached" not in p.stdout
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["stalled_phase"] == "communicator bring-up" and "watchdog" in d["error"]
+    assert d["metric"] == "newton_steps_per_sec" and d["n_gpus"] == 8
+    # other ranks exit silently
+    p2 = subprocess.run([sys.executable, "-c", code.replace("Watchdog(1, 0,", "Watchdog(1, 3,")], capture_output=True, text=True, timeout=60)
+    assert p2.returncode == 3 and not [l for l in p2.stdout.splitlines() if l.startswith("{")]
