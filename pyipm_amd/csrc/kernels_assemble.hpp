@@ -82,10 +82,11 @@ __global__ __launch_bounds__(256) void k_assemble(
     const double* __restrict__ Ji, int64_t ldji,
     const double* __restrict__ s, const double* __restrict__ lda,
     double eps, double delta, double delta_c, unsigned long long* __restrict__ anorm_bits, int nt_store, int sharded,
-    int zeros_in_place)      // the storage still holds the zeros of an earlier assembly wherever nothing can ever fill in
+    int zeros_in_place,      // the storage still holds the zeros of an earlier assembly wherever nothing can ever fill in
+    int64_t lc_off)          // first local column of this launch (the assembly may come as two launches, see assemble_dev)
 {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;          // even row; rows i, i+1
-    const int64_t lc_base = (int64_t)blockIdx.y * 16;
+    const int64_t lc_base = lc_off + (int64_t)blockIdx.y * 16;
     if (i >= g.Npad) return;                          // (wave-uniform: Npad is a multiple of 128)
     const bool vec_h = ((ldh & 1) == 0) && ((reinterpret_cast<uintptr_t>(d2L) & 15) == 0);
     // the 16 columns of a block lie in ONE panel (nb is a multiple of 128): one division per block, not one per entry

@@ -22,7 +22,7 @@ struct BatchPtrs {
     double *rhs, *sol; int64_t sV;         // [B][Npad]
     const double *d2L, *Je, *Ji; int64_t sH, sJe, sJi, ldh, ldje, ldji;      // caller blocks, batch strides in doubles
     const double *df, *ce, *ci, *s, *lda;  // staged vectors [B][n], [B][me], [B][mi], [B][mi], [B][me+mi]
-    unsigned long long* anorm;             // [B] bits of max |assembled entry| (scale of a static pivot)
+    unsigned long long* anorm;             // [2 B]: per problem, bits of max |assembled entry| (scale of a static pivot) and the "assembly pending" word (always 0 here)
 };
 
 // K1 for the batch: grid (Npad/512, Npad/16, B)
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_b_assemble(BatchPtrs bp, Geo g, double 
             A[(i + 1) + j * g.Npad] = v1;
         }
     }
-    anorm_publish(bp.anorm + b, amax);
+    anorm_publish(bp.anorm + 2 * b, amax);
 }
 
 // K2 for the batch: g = -grad (pyipm.py:655-668, 1717).  grid B, 256 threads (one wave per row of the x part).
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double re
         __syncthreads();
         // (2) the block pivot
         tile_invert_dev(sm, A, ld, j0, j0, Tinv + (int64_t)t * TB * TB, Tsave + (int64_t)t * TB * TB, Tflag + t,
-                        refine_cond, st, g.N, pivtol_rel, bp.anorm + bi, g.n + g.mi, nullptr, false, blocked != 0);
+                        refine_cond, st, g.N, pivtol_rel, bp.anorm + 2 * bi, g.n + g.mi, nullptr, false, blocked != 0);
         __syncthreads();
         // (3) rows below: keep -S' in the upper blocks, overwrite S with L = S X (refined when the tile is flagged)
         if (t + 1 < nt) {

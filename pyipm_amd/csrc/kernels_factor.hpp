@@ -72,9 +72,25 @@ __device__ __forceinline__ double readlane_f64(double x, int l) {
 }
 
 // Magnitude of a static pivot: sqrt(eps) x the largest assembled entry (sqrt(eps) when that is unknown).
+// anorm_bits[1] != 0 says the assembly that accumulates anorm_bits[0] is still running on another stream (round 4: the first
+// group's chain starts while the columns to its right are still being assembled): whoever needs the scale waits for it -- a
+// rare path (a pivot that cancelled), bounded by a timeout of 1 s (100 MHz clock) after which the partial maximum is taken.
 __device__ __forceinline__ double static_pivot(const unsigned long long* __restrict__ anorm_bits) {
-    const double an = anorm_bits ? __longlong_as_double((long long)*anorm_bits) : 0.0;
+    if (!anorm_bits) return 1.4901161193847656e-08;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(anorm_bits + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull) {
+        __builtin_amdgcn_s_sleep(16);
+        if (wall_clock64() - t0 > 100000000ull) break;
+    }
+    const double an = __longlong_as_double((long long)__hip_atomic_load(anorm_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     return 1.4901161193847656e-08 * ((an > 0.0 && an <= 1.0e300) ? an : 1.0);
+}
+
+__global__ __launch_bounds__(64) void k_init_stats(DevStats* __restrict__ st) {
+    if (threadIdx.x == 0) {
+        st->n_neg = 0; st->n_zero = 0; st->n_2x2 = 0; st->n_pos = 0; st->nonfinite = 0;
+        st->d_min = 1.0e308; st->d_max = 0.0; st->growth_bits = 0ull;
+    }
 }
 
 // Shared-memory scratch of one tile inversion (a 256-thread workgroup).
@@ -159,7 +175,7 @@ __device__ __forceinline__ void tile_invert_dev(
     // as the unperturbed matrix whenever that one is non-singular, and an excellent preconditioner -- the host
     // recovers the unperturbed solution by refinement against the KKT blocks (HipNewtonBackend.direction), or
     // regularises as reghess does when that does not converge (pyipm.py:1379-1403).
-    const double pert = static_pivot(anorm_bits);
+    auto pert_f = [&]() { return static_pivot(anorm_bits); };      // read only where a pivot is rejected (it may have to wait, see static_pivot)
     const double ptol = pivtol_rel * cmax0;             // this lane's rejection threshold, should it become the pivot
     const int neg_lim = (int)((neg_from - grow0) < 0 ? 0 : ((neg_from - grow0) > TB ? TB : (neg_from - grow0)));   // pivots >= this: expected negative
     const int nreal = (int)((Nreal - grow0) < 0 ? 0 : ((Nreal - grow0) > TB ? TB : (Nreal - grow0)));   // real rows in this tile
@@ -205,7 +221,7 @@ __device__ __forceinline__ void tile_invert_dev(
         /* rejected?  lane pv_ compares its own entry with its own threshold (one vector compare, no broadcasts) */ \
         if (__builtin_expect(__ballot(lane == (pv_) && fabs(cpi_) <= ptol) != 0ull, 0)) {                \
             const double pivtol = readlane_f64(ptol, (pv_));                                             \
-            const double t = pivtol > pert ? pivtol : pert;                                              \
+            const double pert = pert_f(); const double t = pivtol > pert ? pivtol : pert;                                              \
             d = ((pv_) < neg_lim) ? t : -t;                      /* static pivot, expected sign */       \
             zmask |= 1ull << (pv_);                                                                      \
         }                                                                                                \
@@ -331,7 +347,7 @@ __device__ __forceinline__ void tile_invert_dev(
             neg += 1;
             if (fabs(e1) <= pivtol) zero++; else { dmin = fmin(dmin, fabs(e1)); dmax = fmax(dmax, fabs(e1)); }
             if (fabs(e2) <= pivtol) zero++; else { dmin = fmin(dmin, fabs(e2)); dmax = fmax(dmax, fabs(e2)); }
-            if (!(fabs(det) > 0.0)) det = -pert * pert;
+            if (!(fabs(det) > 0.0)) { const double pert = pert_f(); det = -pert * pert; }
             const double ia = cc / det, ib = -b / det, ic = a / det;   // inverse of [[a,b],[b,cc]]
             const double vp = rp[lane], vq = rq[lane];
             const double lpi = vp * ia + vq * ib, lqi = vp * ib + vq * ic;

@@ -106,7 +106,7 @@ size_t carve_batched(Ctx* c, const Geo& g, int64_t B, char* base) {
     const size_t os = cv.take((size_t)B * (g.mi + 1) * D);
     const size_t ol = cv.take((size_t)B * (g.me + g.mi + 1) * D);
     const size_t ost = cv.take((size_t)B * sizeof(DevStats));
-    const size_t oan = cv.take((size_t)B * sizeof(unsigned long long));
+    const size_t oan = cv.take((size_t)B * 2 * sizeof(unsigned long long));
     if (base) {
         c->anorm = (unsigned long long*)(base + oan);
         c->A = (double*)(base + oA); c->Dinv = (double*)(base + oD); c->Tsv = (double*)(base + oT);
@@ -803,16 +803,19 @@ int trailing_update(Ctx* ctx, int64_t p) {
     return timed_update(ctx, p, 1, q / g.world, local_panels - q / g.world);
 }
 
-int factor_begin(Ctx* ctx) {
-    DevStats z; memset(&z, 0, sizeof(z)); z.d_min = 1.0e308; z.d_max = 0.0;
-    PYIPM_HIP(hipMemcpyAsync(ctx->dstats, &z, sizeof(z), hipMemcpyHostToDevice, ctx->stream));
+// Reset of the device-side statistics, on `st` (the stream the first tile kernels of this factorisation run on; default: the
+// handle's).  A kernel, not a copy from a stack temporary followed by a host synchronisation (rounds 1-3): the host must be
+// able to enqueue the first group's chain while the assembly is still running.
+int factor_begin(Ctx* ctx, hipStream_t st = nullptr) {
+    if (!st) st = ctx->stream;
     if (!ctx->head_counters) {                      // fused heads: one counter per group + the error flag of k_wait_counter
         PYIPM_HIP(hipMalloc((void**)&ctx->head_counters, (256 + 1) * sizeof(unsigned)));
         ctx->n_head_counters = 256;
     }
-    // (every stream of the handle is idle here: the factorisation before joined them and was waited for)
-    PYIPM_HIP(hipMemsetAsync(ctx->head_counters, 0, (ctx->n_head_counters + 1) * sizeof(unsigned), ctx->stream));
-    PYIPM_HIP(hipStreamSynchronize(ctx->stream));   // &z is a stack temporary
+    hipLaunchKernelGGL(k_init_stats, dim3(1), dim3(64), 0, st, ctx->dstats);
+    PYIPM_KCHECK();
+    // (every stream of the handle is idle of factorisation work here: the factorisation before joined them and was waited for)
+    PYIPM_HIP(hipMemsetAsync(ctx->head_counters, 0, (ctx->n_head_counters + 1) * sizeof(unsigned), st));
     ctx->n_trailing = 0; ctx->trailing_flops = 0.0; ctx->trailing_area = 0.0;
     return 0;
 }
@@ -1212,7 +1215,7 @@ int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
         dim3 grid((unsigned)((gc.Npad + 511) / 512), (unsigned)((gc.ncols_local + 15) / 16));
         PYIPM_HIP(hipMemsetAsync(ctx->anorm, 0, sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, gc.Npad, gc, ctx->d2L, ctx->ld_d2L,
-                           Jx, ldx, (const double*)nullptr, (int64_t)0, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, 0, 0);
+                           Jx, ldx, (const double*)nullptr, (int64_t)0, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, 0, 0, (int64_t)0);
         PYIPM_KCHECK();
         if (na > 0) {
             hipLaunchKernelGGL(k_cond_fix_diag, grid1(na), dim3(256), 0, ctx->stream, ctx->A, gc.Npad, g.n + g.me,
@@ -1240,6 +1243,15 @@ int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
     return 0;
 }
 
+// panels of the first group of the single-rank schedule (the rule of factor_all)
+int64_t first_group_panels(const Ctx* ctx) {
+    const Geo& g = ctx->g;
+    int64_t G = (ctx->tail_group > 0 && g.Npad <= ctx->tail_cols) ? ctx->tail_group : ctx->group;
+    if (G > ctx->group) G = ctx->group;
+    if (G > g.npanels) G = g.npanels;
+    return G;
+}
+
 int assemble_dev(Ctx* ctx, double delta, double delta_c) {
     const Geo& g = ctx->g;
     if (ctx->provider_only) { ctx->err = "a provider-only handle has no KKT storage: block products and residuals only"; return PYIPM_E_BADARG; }
@@ -1259,12 +1271,42 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
     }
     ctx->cond_active = false;
     PYIPM_HIP(hipMemsetAsync(ctx->anorm, 0, sizeof(unsigned long long), ctx->stream));
+    ctx->asm_split_cols = 0;
     if (g.ncols_local > 0) {
+        const int zip = (ctx->keep_zeros && !ctx->storage_exported && ctx->zeros_clean && g.world == 1 && g.mi > 0) ? 1 : 0;
+        // Round 4: the columns of the FIRST group first, the rest as a second launch.  The first group's chain has no bulk update
+        // to hide behind (3.2 ms exposed at N = 32768) and touches nothing but its own columns: factor_all starts it on the
+        // chain's stream as soon as the first launch is through, beside the second (1.3 ms of pure HBM traffic).  The scale of a
+        // static pivot is a maximum over the WHOLE matrix: the word behind it says "pending" until the second launch is through
+        // and the rare reader waits (static_pivot).  The same entries either way.
+        int64_t c1 = 0;
+        if (ctx->asm_split && g.world == 1 && ctx->lookahead && ctx->group_chain && ctx->inpanel32 && ctx->tile_step) {
+            const int64_t G0 = first_group_panels(ctx);
+            if (G0 < g.npanels) c1 = G0 * (int64_t)g.nb;
+        }
+        if (c1 > 0 && c1 < g.ncols_local) {
+            if (!ctx->ev_asm) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_asm, hipEventDisableTiming));
+            PYIPM_HIP(hipMemsetAsync(ctx->anorm + 1, 0x01, sizeof(unsigned long long), ctx->stream));      // pending
+            dim3 grid1a((unsigned)((g.Npad + 511) / 512), (unsigned)(c1 / 16));
+            hipLaunchKernelGGL(k_assemble, grid1a, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
+                               ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, ctx->sharded,
+                               zip, (int64_t)0);
+            PYIPM_KCHECK();
+            PYIPM_HIP(hipEventRecord(ctx->ev_asm, ctx->stream));
+            dim3 grid1b((unsigned)((g.Npad + 511) / 512), (unsigned)((g.ncols_local - c1 + 15) / 16));
+            hipLaunchKernelGGL(k_assemble, grid1b, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
+                               ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, ctx->sharded,
+                               zip, c1);
+            PYIPM_KCHECK();
+            PYIPM_HIP(hipMemsetAsync(ctx->anorm + 1, 0, sizeof(unsigned long long), ctx->stream));         // complete
+            ctx->asm_split_cols = c1;
+        } else {
         dim3 grid((unsigned)((g.Npad + 511) / 512), (unsigned)((g.ncols_local + 15) / 16));
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
                            ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, ctx->sharded,
-                           (ctx->keep_zeros && !ctx->storage_exported && ctx->zeros_clean && g.world == 1 && g.mi > 0) ? 1 : 0);
+                           zip, (int64_t)0);
         PYIPM_KCHECK();
+        }
     }
     // the zeros of this assembly survive a factorisation of finite numbers (every update that reaches them adds an exact zero);
     // whatever else may write into the storage clears the flag (zeros_dirty)
@@ -1285,7 +1327,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     if (!ctx->assembled) { ctx->err = "factor: assemble first"; return PYIPM_E_BADARG; }
     ctx->per_panel_mode = false;
     const auto t_host0 = std::chrono::steady_clock::now();
-    int rc = factor_begin(ctx); if (rc) return rc;
+    int rc = 0;
     if (!ctx->side) {
         // panel kernels are latency-critical and tiny: highest dispatch priority, so they take the first
         // CU slot a retiring bulk-update block frees instead of queueing behind the whole bulk grid
@@ -1367,7 +1409,27 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         }
         return 0;
     };
-    rc = run_group(0, ctx->stream, false); if (rc) return rc;
+    // (round 4) the assembly came as two launches and the second may still be running on the main stream: the first group, which
+    // touches only its own columns, runs on the chain's stream behind the first launch; the main stream joins it before the
+    // first bulk update, the first head is ordered behind the whole assembly through ev_main.
+    bool g0_side = false;
+    if (ctx->asm_split_cols > 0 && ngroups > 1 && gsize(0) * (int64_t)g.nb == ctx->asm_split_cols && chain_group(0) && ctx->ev_asm &&
+        ctx->head_on_side) {
+        if (!ctx->ev_main) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
+        PYIPM_HIP(hipEventRecord(ctx->ev_main, ctx->stream));                      // everything the main stream has done: the whole assembly
+        PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_asm, 0));
+        { int r0 = ensure_rest_stream(ctx); if (r0) return r0; }
+        PYIPM_HIP(hipStreamWaitEvent(ctx->rest, ctx->ev_asm, 0));
+        rc = factor_begin(ctx, ctx->side); if (rc) return rc;                      // statistics reset ahead of the first tile kernel
+        rc = run_group(0, ctx->side, false); if (rc) return rc;
+        PYIPM_HIP(hipEventRecord(ctx->ev_panel, ctx->side));
+        PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
+        g0_side = true;
+    } else {
+        rc = factor_begin(ctx); if (rc) return rc;
+        rc = run_group(0, ctx->stream, false); if (rc) return rc;
+    }
+    ctx->asm_split_cols = 0;
     std::vector<char> early((size_t)np, 0);       // panel's contribution to the NEXT group's columns already applied
     for (int64_t grp = 0; grp + 1 < ngroups; ++grp) {
         const int64_t p0 = ctx->grp_first[(size_t)grp], n0 = gsize(grp), p1 = p0 + n0, n1 = gsize(grp + 1);
@@ -1471,7 +1533,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
                     continue;
                 }
             }
-            if (grp > 0 && ctx->head_on_side && cs == ctx->side) {
+            if ((grp > 0 || g0_side) && ctx->head_on_side && cs == ctx->side) {
                 PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_main, 0));    // (recorded at the end of the iteration before)
                 hs = ctx->side;
             }
@@ -1623,7 +1685,7 @@ static int create_impl(pyipm_newton_ctx** out, int64_t n, int64_t me, int64_t mi
     }
     ctx->ws_bytes = need;
     carve_workspace(ctx, ctx->g, ctx->ws, provider_only);
-    if (hipMemset(ctx->anorm, 0, sizeof(unsigned long long)) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
+    if (hipMemset(ctx->anorm, 0, 2 * sizeof(unsigned long long)) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);      // [0] max |entry|, [1] "assembly pending"
     for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     for (int i = 0; i < 4; ++i) if (hipEventCreate(&ctx->ev_prov[i]) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     if (hipEventCreateWithFlags(&ctx->ev_fwd, hipEventDisableTiming) != hipSuccess ||
@@ -1670,7 +1732,7 @@ int pyipm_newton_create_batched(pyipm_newton_ctx** out, int64_t n, int64_t me, i
     ctx->batched = true;
     ctx->tile_blocked = 0;               // throughput-bound (two problems per CU, every CU busy): the blocked inversion's register and
                                           // LDS appetite costs more there than its shorter chain gains (512 x N=768: 4.42 vs 4.04 ms, r03)
-    if (hipMemset(ctx->anorm, 0, (size_t)batch * sizeof(unsigned long long)) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
+    if (hipMemset(ctx->anorm, 0, (size_t)batch * 2 * sizeof(unsigned long long)) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     *out = reinterpret_cast<pyipm_newton_ctx*>(ctx);
     return PYIPM_OK;
@@ -1705,7 +1767,7 @@ int pyipm_newton_step_batched(pyipm_newton_ctx* h, double delta, double delta_c,
     hipLaunchKernelGGL(k_b_residual, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->mu, ctx->eps);
     PYIPM_KCHECK();
     {
-        PYIPM_HIP(hipMemsetAsync(ctx->anorm, 0, (size_t)B * sizeof(unsigned long long), ctx->stream));
+        PYIPM_HIP(hipMemsetAsync(ctx->anorm, 0, (size_t)B * 2 * sizeof(unsigned long long), ctx->stream));
         dim3 grid((unsigned)((g.Npad + 511) / 512), (unsigned)((g.Npad + 15) / 16), (unsigned)B);
         hipLaunchKernelGGL(k_b_assemble, grid, dim3(256), 0, ctx->stream, bp, g, ctx->eps, delta, delta_c);
         PYIPM_KCHECK();
@@ -1758,6 +1820,7 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->ev_split) hipEventDestroy(ctx->ev_split);
     if (ctx->ev_main) hipEventDestroy(ctx->ev_main);
+    if (ctx->ev_asm) hipEventDestroy(ctx->ev_asm);
     for (auto e : ctx->ev_band) hipEventDestroy(e);
     for (auto e : ctx->ev_done) hipEventDestroy(e);
     for (auto e : ctx->ev_early) hipEventDestroy(e);
@@ -2500,6 +2563,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
     if (!strcmp(name, "head_split_rows")) { ctx->head_split_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "fused_head")) { ctx->fused_head = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "asm_split")) { ctx->asm_split = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "fused_head_rows")) { ctx->fused_head_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "reserve_cus")) { ctx->reserve_cus = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "persist_rows")) { ctx->persist_rows = (int64_t)value; return PYIPM_OK; }
