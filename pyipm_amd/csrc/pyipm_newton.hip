@@ -1411,7 +1411,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     };
     // (round 4) the assembly came as two launches and the second may still be running on the main stream: the first group, which
     // touches only its own columns, runs on the chain's stream behind the first launch; the main stream joins it before the
-    // first bulk update, the first head is ordered behind the whole assembly through ev_main.
+    // first head and the first bulk update.
     bool g0_side = false;
     if (ctx->asm_split_cols > 0 && ngroups > 1 && gsize(0) * (int64_t)g.nb == ctx->asm_split_cols && chain_group(0) && ctx->ev_asm &&
         ctx->head_on_side) {
@@ -1424,7 +1424,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         rc = run_group(0, ctx->side, false); if (rc) return rc;
         PYIPM_HIP(hipEventRecord(ctx->ev_panel, ctx->side));
         PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
-        g0_side = true;
+        g0_side = true; (void)g0_side;
     } else {
         rc = factor_begin(ctx); if (rc) return rc;
         rc = run_group(0, ctx->stream, false); if (rc) return rc;
@@ -1533,7 +1533,9 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
                     continue;
                 }
             }
-            if ((grp > 0 || g0_side) && ctx->head_on_side && cs == ctx->side) {
+            // (the FIRST head stays on the main stream also when group 0 ran on the chain's stream: nothing runs beside it either
+            //  way, and as a main-stream launch it takes the bulk instance and is part of the trailing figures, as in rounds 1-3)
+            if (grp > 0 && ctx->head_on_side && cs == ctx->side) {
                 PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_main, 0));    // (recorded at the end of the iteration before)
                 hs = ctx->side;
             }

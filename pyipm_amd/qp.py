@@ -37,7 +37,7 @@ class QPDeviceIPM(object):
     def __init__(self, Q, c, A=None, b=None, G=None, h=None, Je=None, Ji=None, x0=None, s0=None, lda0=None,
                  mu=0.2, nu=10.0, rho=0.1, tau=0.995, eta=1.0E-4, beta=0.4, miter=20, niter=10, Xtol=None,
                  Ktol=1.0E-4, Ftol=None, verbosity=1, device=None, nb=256, refine=0, condensed=False,
-                 lbfgs=False, lbfgs_zeta=None):
+                 lbfgs=False, lbfgs_zeta=None, warm=True):
         import torch
         from .ipm import HipNewtonBackend
         if not torch.cuda.is_available():
@@ -100,10 +100,38 @@ class QPDeviceIPM(object):
             self.core.stage_blocks(self.Q, self.Je, self.Ji)       # constant blocks: device pointers, staged once
         self._pcache = (None, None)
         self._staged_key, self._staged_keep, self._info, self._g = None, None, None, None
+        self.warm_seconds = 0.0
+        if warm and not self.lbfgs:
+            self._warm_up()
         self.trace = None                   # set to [] to record (x, s, lda, mu) at every Newton step
         self.signal = 0
         self.iter_count = 0
         self.timings = {"newton_s": 0.0, "search_s": 0.0, "n_phi": 0, "n_ray": 0, "newton_each_s": []}
+
+    def _warm_up(self):
+        """The counterpart of the reference's ``compile()`` (pyipm.py:410-956: seconds of Aesara compilation before the
+        first ``solve()``): everything the library builds once per problem shape -- streams, events, the tile lists of the
+        update launches, the buffers of the one-launch sweeps -- is built here by ONE Newton step on a harmless point (x = 0,
+        s = lda_i = 1, lda_e = 0: the KKT matrix of the staged blocks with Sigma = I), so that the first iteration of
+        ``solve()`` costs what the others do (it took 50 ms more at N = 32768).  ``warm=False`` skips it."""
+        import time
+        torch, n, me, mi = self.torch, self.nvar, self.neq, self.nineq
+        t0 = time.perf_counter()
+        z = lambda k: torch.zeros(k, dtype=torch.float64, device=self.device)            # noqa: E731
+        one = lambda k: torch.ones(k, dtype=torch.float64, device=self.device)           # noqa: E731
+        lda = torch.cat([z(me), one(mi)]) if (me or mi) else None
+        self.core.stage_vectors(self.c, z(me) if me else None, one(mi) if mi else None, one(mi) if mi else None, lda, mu=self.mu,
+                                eps=self.eps)
+        try:
+            self.core.step(0.0, 0.0)
+            if mi:
+                self.core.step_lengths(self.tau)
+            self.core.merit_info()
+        except Exception:                                    # a singular warm-up system is nobody's problem
+            pass
+        torch.cuda.synchronize(self.device)
+        self._staged_key = None
+        self.warm_seconds = time.perf_counter() - t0
 
     # ------------------------------------------------------------------ provider (pyipm.py:855-954 on the device)
     def _products(self, v):

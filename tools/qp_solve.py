@@ -40,7 +40,7 @@ def main():
            "condensed_fallbacks": ipm.backend.n_condensed_fallback, "condensed_still_on": ipm.backend.condensed_on,
            "condensed_fallback_reason": ipm.backend.condensed_fallback_reason, "solve_seconds": dt, "newton_seconds": ipm.timings["newton_s"],
            "search_seconds": ipm.timings["search_s"], "merit_evaluations": ipm.timings["n_phi"],
-           "merit_ray_launches": ipm.timings.get("n_ray", 0),
+           "merit_ray_launches": ipm.timings.get("n_ray", 0), "warm_up_seconds_in_constructor": ipm.warm_seconds,
            "newton_seconds_per_factorisation": ipm.timings["newton_s"] / max(ipm.backend.n_factor, 1),
            "newton_seconds_each": ipm.timings["newton_each_s"],
            "rcond_estimates": ipm.backend.n_rcond, "rcond_estimates_reused": ipm.backend.n_rcond_reused,
