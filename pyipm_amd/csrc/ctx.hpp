@@ -117,6 +117,7 @@ struct Ctx {
                                           // its own line in a kernel trace; 8: the bulk instance)
     int64_t pending_left_rows = 12288;    // group chain: left-looking in-group updates of the rows below the diagonal block while more
                                           // rows than this remain below it (-1: never)
+    int asm_tri = 1;                      // K1 launches only the patches on or below the diagonal (single rank, Npad a multiple of 512)
     int asm_split = 0;                    // K1 as two launches, the first group's columns first: that group's chain starts beside the second (round 4;
                                           // measured 0 ... -0.3 ms at N = 32768 -- the chain is stretched by the HBM-saturating second launch --: an option, off)
     int64_t asm_split_cols = 0;           // ... columns of the first launch of the last assembly (0: one launch); consumed by factor_all

@@ -83,22 +83,38 @@ __global__ __launch_bounds__(256) void k_assemble(
     const double* __restrict__ s, const double* __restrict__ lda,
     double eps, double delta, double delta_c, unsigned long long* __restrict__ anorm_bits, int nt_store, int sharded,
     int zeros_in_place,      // the storage still holds the zeros of an earlier assembly wherever nothing can ever fill in
-    int64_t lc_off)          // first local column of this launch (the assembly may come as two launches, see assemble_dev)
+    int64_t lc_off,          // first local column of this launch (the assembly may come as two launches, see assemble_dev)
+    int tri_nbx)             // > 0 (single rank, lc_off == 0): a 1-D grid over the patches on or below the diagonal only -- the 2-D
+                             // grid launches as many patches above it, 65000 workgroups at N = 32768 that start only to return
 {
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;          // even row; rows i, i+1
-    const int64_t lc_base = lc_off + (int64_t)blockIdx.y * 16;
+    int64_t bx = blockIdx.x, by = blockIdx.y;
+    if (tri_nbx > 0) {
+        // 32 column patches (512 columns) share their first row patch G = by / 32; group G holds 32 (nbx - G) patches, the
+        // groups before it P(G) = 32 (G nbx - G (G - 1) / 2).  Invert P with a square root and correct by one.
+        const int64_t L = blockIdx.x, nbx = tri_nbx;
+        const double b2 = (double)(2 * nbx + 1);
+        int64_t G = (int64_t)((b2 - sqrt(b2 * b2 - 8.0 * ((double)L / 32.0))) * 0.5);
+        if (G < 0) G = 0;
+        while (G > 0 && 32 * (G * nbx - G * (G - 1) / 2) > L) --G;
+        while (32 * ((G + 1) * nbx - (G + 1) * G / 2) <= L) ++G;
+        const int64_t rem = L - 32 * (G * nbx - G * (G - 1) / 2), per = nbx - G;
+        by = G * 32 + rem / per; bx = G + rem % per;
+    }
+    const int64_t i = (bx * 256 + threadIdx.x) * 2;          // even row; rows i, i+1
+    const int64_t lc_base = lc_off + by * 16;
+    if (lc_base >= g.ncols_local) return;
     if (i >= g.Npad) return;                          // (wave-uniform: Npad is a multiple of 128)
     const bool vec_h = ((ldh & 1) == 0) && ((reinterpret_cast<uintptr_t>(d2L) & 15) == 0);
     // the 16 columns of a block lie in ONE panel (nb is a multiple of 128): one division per block, not one per entry
     const int64_t lp = lc_base / g.nb;
     const int64_t j0 = (lp * g.world + g.rank) * (int64_t)g.nb + (lc_base - lp * g.nb);
-    if ((int64_t)blockIdx.x * 512 + 512 <= j0) return;     // the whole patch lies above the diagonal: nothing is stored there
+    if (bx * 512 + 512 <= j0) return;     // the whole patch lies above the diagonal: nothing is stored there
     if (zeros_in_place) {
         // Zeros for ever (pyipm.py:824-842 and the elimination order x, s, lambda_e, lambda_i): the (s, x) block; below the
         // diagonal of the (s, s) block; the (lambda_e, s) block; the (lambda_i, s) block off its diagonal of -1.  Nothing
         // fills them in -- every update that reaches them adds an exact zero -- so once written they need no second
         // store (34 % of the lower triangle at the benchmark shape).  Decided per 512 x 16 patch, block-uniform.
-        const int64_t r0 = (int64_t)blockIdx.x * 512, r1 = r0 + 512;           // rows [r0, r1), columns [j0, j0 + 16)
+        const int64_t r0 = bx * 512, r1 = r0 + 512;           // rows [r0, r1), columns [j0, j0 + 16)
         const int64_t o_s = g.n, o_e = g.n + g.mi, o_i = o_e + g.me;
         if (j0 + 16 <= o_s && r0 >= o_s && r1 <= o_e) return;                  // (s, x)
         if (j0 >= o_s && j0 + 16 <= o_e) {

@@ -1168,6 +1168,7 @@ int residual_dev(Ctx* ctx) {
 //   A (ld = gc.Npad) <- tril [[H + delta I, Jx], [Jx', D]]   by K1 on the condensed geometry, Jx = [Je | Ji_A],
 //                        D = diag(-delta_c I, -1/Sigma_A);
 //   += Ji_I Sigma_I Ji_I'   as ONE rank-mi launch of the MFMA update kernel (C += JT * WT').
+void asm_grid(const Ctx* ctx, const Geo& g, dim3* grid, int* tri);
 int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
     const Geo& g = ctx->g;
     const int64_t nx = (g.n + BM - 1) / BM * BM;                 // rows / columns of the x-x block the Gram launch touches
@@ -1212,10 +1213,11 @@ int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
         Jx = ctx->Jx; ldx = mx;
     }
     {
-        dim3 grid((unsigned)((gc.Npad + 511) / 512), (unsigned)((gc.ncols_local + 15) / 16));
+        dim3 grid; int tri = 0;
+        asm_grid(ctx, gc, &grid, &tri);
         PYIPM_HIP(hipMemsetAsync(ctx->anorm, 0, sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, gc.Npad, gc, ctx->d2L, ctx->ld_d2L,
-                           Jx, ldx, (const double*)nullptr, (int64_t)0, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, 0, 0, (int64_t)0);
+                           Jx, ldx, (const double*)nullptr, (int64_t)0, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, 0, 0, (int64_t)0, tri);
         PYIPM_KCHECK();
         if (na > 0) {
             hipLaunchKernelGGL(k_cond_fix_diag, grid1(na), dim3(256), 0, ctx->stream, ctx->A, gc.Npad, g.n + g.me,
@@ -1241,6 +1243,20 @@ int assemble_condensed(Ctx* ctx, double delta, double delta_c) {
     }
     if (ctx->profile) PYIPM_HIP(hipEventRecord(ctx->ev[7], ctx->stream));
     return 0;
+}
+
+// Grid of a whole-matrix k_assemble launch.  Single rank, Npad a multiple of 512: a 1-D grid over the 512 x 16 patches on or
+// below the diagonal only (round 4: the 2-D grid started as many workgroups above the diagonal that returned at once --
+// 65000 of them at N = 32768 cost 0.5 of K1's 1.5 ms; with them gone K1 moves its algorithmic bytes at 6.5 TB/s).
+void asm_grid(const Ctx* ctx, const Geo& g, dim3* grid, int* tri) {
+    *grid = dim3((unsigned)((g.Npad + 511) / 512), (unsigned)((g.ncols_local + 15) / 16));
+    *tri = 0;
+    if (ctx->asm_tri && g.world == 1 && g.Npad % 512 == 0) {
+        const int64_t nbx = g.Npad / 512, ngrp = (g.ncols_local / 16 + 31) / 32;          // column patches in groups of 32
+        int64_t tot = 0;
+        for (int64_t G = 0; G < ngrp; ++G) tot += 32 * (nbx - G);
+        if (ngrp <= nbx && tot < (int64_t)1 << 31) { *grid = dim3((unsigned)tot, 1); *tri = (int)nbx; }
+    }
 }
 
 // panels of the first group of the single-rank schedule (the rule of factor_all)
@@ -1290,21 +1306,22 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
             dim3 grid1a((unsigned)((g.Npad + 511) / 512), (unsigned)(c1 / 16));
             hipLaunchKernelGGL(k_assemble, grid1a, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
                                ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, ctx->sharded,
-                               zip, (int64_t)0);
+                               zip, (int64_t)0, 0);
             PYIPM_KCHECK();
             PYIPM_HIP(hipEventRecord(ctx->ev_asm, ctx->stream));
             dim3 grid1b((unsigned)((g.Npad + 511) / 512), (unsigned)((g.ncols_local - c1 + 15) / 16));
             hipLaunchKernelGGL(k_assemble, grid1b, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
                                ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, ctx->sharded,
-                               zip, c1);
+                               zip, c1, 0);
             PYIPM_KCHECK();
             PYIPM_HIP(hipMemsetAsync(ctx->anorm + 1, 0, sizeof(unsigned long long), ctx->stream));         // complete
             ctx->asm_split_cols = c1;
         } else {
-        dim3 grid((unsigned)((g.Npad + 511) / 512), (unsigned)((g.ncols_local + 15) / 16));
+        dim3 grid; int tri = 0;
+        asm_grid(ctx, g, &grid, &tri);
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
                            ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, ctx->sharded,
-                           zip, (int64_t)0);
+                           zip, (int64_t)0, tri);
         PYIPM_KCHECK();
         }
     }
@@ -1514,6 +1531,10 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
                         (size_t)grp < ctx->n_head_counters;
             }
             if (fused) {
+                // (the wait kernel below reads a counter that factor_begin reset on the main stream -- without a host
+                //  synchronisation since round 4: the chain's stream is ordered behind it)
+                PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
+                PYIPM_HIP(hipStreamWaitEvent(cs, ctx->ev_head, 0));
                 unsigned nhead = 0;
                 unsigned* ctr = ctx->head_counters + grp;
                 const int hct = (int)(n1 * (g.nb / 128));
@@ -2565,6 +2586,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
     if (!strcmp(name, "head_split_rows")) { ctx->head_split_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "fused_head")) { ctx->fused_head = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "asm_tri")) { ctx->asm_tri = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "asm_split")) { ctx->asm_split = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "fused_head_rows")) { ctx->fused_head_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "reserve_cus")) { ctx->reserve_cus = (int)value; return PYIPM_OK; }
