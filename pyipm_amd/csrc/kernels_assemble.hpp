@@ -243,98 +243,90 @@ __global__ __launch_bounds__(256) void k_symv_row(
 }
 
 // sym(triu(U)) v in ONE pass over the upper triangle (round 4).  The two kernels above / below read the
-// triangle once each -- row part and mirrored part -- i.e. 8 n^2 bytes for a product that needs 4 n^2.  Here a block takes a
-// group of 64-row strips (the rows of chunk blockIdx.y) times a segment of SYMV_SEG columns (blockIdx.x) and walks its 64 x 64
-// tiles through shared memory: each element is loaded once (512-byte rows, coalesced) and used twice --
-//   row sums   r[j] += U[j,k] v[k]   (k >= j): thread (row = tid/4, q = tid%4) adds its 16 columns of every tile IN ITS LANE
-//                                    and folds the four lanes once per strip -> part_row[segment][local row];
-//   col sums   c[k] += U[j,k] v[j]   (j <  k): thread (col = tid/4, q) adds its 16 rows, folds the four lanes and keeps the
-//                                    sum of its column over the strips of the chunk in shared memory -> part_col[chunk][k].
-// Deterministic: every partial has one writer and a fixed order; k_symv_finish adds the partials in a fixed order.
-constexpr int SYMV_SEG = 512;            // columns per block
+// triangle once each -- row part and mirrored part -- i.e. 8 n^2 bytes for a product that needs 4 n^2.  Here a block takes the
+// rows of chunk blockIdx.y times a segment of SYMV_SEG columns (blockIdx.x) and streams the rows 16 at a time, every thread
+// one COLUMN of a 256-column window (a row is read in 2 KB pieces, 16 row streams per block -- a first version that staged
+// 64 x 64 tiles through shared memory kept 64 streams of 512 B per block going and reached only 2.1 TB/s):
+//   column sums  c[k] += U[j,k] v[j]  (j < k): the 16 values a thread has just loaded ARE its column's -- summed in registers,
+//                one accumulator per window of the segment, kept over all rows of the chunk -> part_col[chunk][k];
+//   row sums     r[j] += U[j,k] v[k]  (k >= j): accumulated per thread over the windows of the segment, folded over the 256
+//                threads once per 16 rows (through shared memory) -> part_row[segment][local row].
+// Every load is unconditional (clamped address, masked value).  Deterministic: every partial has one writer and a fixed
+// order; k_symv_finish adds the partials in a fixed order.
+constexpr int SYMV_SEG = 1024;           // columns per block: SYMV_SEG / 256 column accumulators per thread
+constexpr int SYMV_CHUNKS = 128;         // row chunks (the column partials are [SYMV_CHUNKS][n])
 __global__ __launch_bounds__(256) void k_symv_tiles(
     double* __restrict__ part_row, double* __restrict__ part_col, const double* __restrict__ U, int64_t ldh, int64_t n,
     const double* __restrict__ v, int64_t rows_per_chunk, RowMap rm)
 {
-    __shared__ double T[64][65];
-    __shared__ double colacc[4][SYMV_SEG];                                // one copy per wave: summed in a fixed order at the end
-    __shared__ double vrow[64], vcol[64], rred[4][64];
+    constexpr int NW = SYMV_SEG / 256;
+    __shared__ double red[16][257];
     const int tid = threadIdx.x;
-    const int lrow = tid >> 6, lcol = tid & 63;                           // loader: rows lrow, lrow + 4, ...; column lcol of the tile
-    // summing: lane = row (row sums) / lane = column (column sums), wave w takes the w-th quarter of the other index -- every
-    // shared-memory access of a wave then touches 64 consecutive words or 64 rows of stride 65: no bank conflicts
-    const int w = tid >> 6, l = tid & 63;
     const int64_t k_seg0 = (int64_t)blockIdx.x * SYMV_SEG;
     int64_t k_seg1 = k_seg0 + SYMV_SEG; if (k_seg1 > n) k_seg1 = n;
     const int64_t jl0 = (int64_t)blockIdx.y * rows_per_chunk;             // local rows of this chunk (a multiple of 64)
     int64_t jl1 = jl0 + rows_per_chunk; if (jl1 > rm.nloc) jl1 = rm.nloc;
     if (jl0 >= jl1 || k_seg0 >= n) return;
-    for (int c = tid; c < 4 * SYMV_SEG; c += 256) (&colacc[0][0])[c] = 0.0;
-    bool any = false;
-    for (int64_t sl = jl0; sl < jl1; sl += 64) {                          // strips of 64 local rows: contiguous global rows j0 .. j0 + 63
-        const int64_t j0 = rm.glob(sl);
-        if (j0 >= k_seg1) continue;                                       // (block-uniform) the strip lies below the segment's columns
-        any = true;
-        const int rows = (int)((jl1 - sl) < 64 ? (jl1 - sl) : 64);
-        int64_t kt0 = (j0 / 64) * 64; if (kt0 < k_seg0) kt0 = k_seg0;
-        // every load is unconditional (clamped address, masked value): a branch around a load makes hipcc wait for each one in
-        // turn -- sixteen memory latencies per tile instead of one (first version: 2.0 ms for the product instead of 0.5)
-        const double* rowp[16];
+    double cacc[NW], vk[NW];
+    #pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int64_t k = k_seg0 + 256 * w + tid;
+        cacc[w] = 0.0; vk[w] = (k < n) ? v[k] : 0.0;
+    }
+    for (int64_t gl = jl0; gl < jl1; gl += 16) {                          // 16 local rows: contiguous global rows jg .. jg + 15
+        const int64_t jg = rm.glob(gl);
+        const int rows = (int)((jl1 - gl) < 16 ? (jl1 - gl) : 16);
+        if (jg >= k_seg1) {                                               // (block-uniform) wholly left of / below the segment's columns
+            if (tid < rows) part_row[(int64_t)blockIdx.x * rm.nloc + (gl + tid)] = 0.0;
+            continue;
+        }
+        const double* rowp[16]; double vr[16];
         #pragma unroll
-        for (int ps = 0; ps < 16; ++ps) {
-            const int rr = ps * 4 + lrow;
-            rowp[ps] = U + rm.brow(sl + (rr < rows ? rr : rows - 1)) * ldh;
+        for (int r = 0; r < 16; ++r) {
+            const int rc = r < rows ? r : rows - 1;
+            rowp[r] = U + rm.brow(gl + rc) * ldh;
+            vr[r] = (r < rows) ? v[jg + rc] : 0.0;
         }
-        double ureg[16], vreg;
-#define PYIPM_SYMV_LOAD(kt_)                                                                                   \
-        {                                                                                                      \
-            const int64_t kc_ = ((kt_) + lcol < n) ? (kt_) + lcol : n - 1;                                     \
-            _Pragma("unroll") for (int ps = 0; ps < 16; ++ps) ureg[ps] = rowp[ps][kc_];                        \
-            vreg = v[kc_];                                                                                     \
+        double racc[16];
+        #pragma unroll
+        for (int r = 0; r < 16; ++r) racc[r] = 0.0;
+        #pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int64_t kt = k_seg0 + 256 * w;
+            if (kt + 256 <= jg || kt >= k_seg1) continue;                 // (uniform) the window lies left of the diagonal / past the matrix
+            const int64_t k = kt + tid, kc = k < n ? k : n - 1;
+            double u[16];
+            #pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = rowp[r][kc];
+            double ca = 0.0;
+            #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t j = jg + r;
+                const double uu = (r < rows && k < n && k >= j) ? u[r] : 0.0;
+                racc[r] = fma(uu, vk[w], racc[r]);
+                ca = fma((k > j) ? uu : 0.0, vr[r], ca);
+            }
+            cacc[w] += ca;
         }
-        PYIPM_SYMV_LOAD(kt0)
-        const double vr_mine = v[j0 + (lcol < rows ? lcol : rows - 1)];
-        double racc = 0.0;
-        for (int64_t kt = kt0; kt < k_seg1; kt += 64) {
-            __syncthreads();                                              // the tile before has been consumed
-            {
-                const int64_t k = kt + lcol;
-                #pragma unroll
-                for (int ps = 0; ps < 16; ++ps) {
-                    const int rr = ps * 4 + lrow;
-                    T[rr][lcol] = (rr < rows && k < n && k >= j0 + rr) ? ureg[ps] : 0.0;
-                }
-                if (lrow == 0) { vcol[lcol] = (k < n) ? vreg : 0.0; if (kt == kt0) vrow[lcol] = (lcol < rows) ? vr_mine : 0.0; }
-            }
-            __syncthreads();
-            if (kt + 64 < k_seg1) PYIPM_SYMV_LOAD(kt + 64)                // the next tile's loads fly while this one is summed
-            {   // row sums: row l, columns 16 w .. 16 w + 15
-                double a = 0.0;
-                #pragma unroll
-                for (int c = 0; c < 16; ++c) a = fma(T[l][16 * w + c], vcol[16 * w + c], a);
-                racc += a;
-            }
-            {   // column sums, strictly above the diagonal only (j < k): column l, rows 16 w .. 16 w + 15
-                double a = 0.0;
-                const int64_t k = kt + l;
-                #pragma unroll
-                for (int c = 0; c < 16; ++c) { const int rr = 16 * w + c; a = fma((j0 + rr < k) ? T[rr][l] : 0.0, vrow[rr], a); }
-                if (k < k_seg1) colacc[w][(int)(k - k_seg0)] += a;        // (one owner thread per (wave, column) for the whole block)
-            }
-        }
-#undef PYIPM_SYMV_LOAD
-        rred[w][l] = racc;
+        // fold the 16 row sums over the 256 threads: [row][thread] through shared memory, 16 threads per row
+        __syncthreads();                                                  // (the group before has been read)
+        #pragma unroll
+        for (int r = 0; r < 16; ++r) red[r][tid] = racc[r];
         __syncthreads();
-        if (w == 0 && l < rows) part_row[(int64_t)blockIdx.x * rm.nloc + (sl + l)] = (rred[0][l] + rred[1][l]) + (rred[2][l] + rred[3][l]);
+        {
+            const int r = tid >> 4, q = tid & 15;
+            double a = 0.0;
+            #pragma unroll
+            for (int c = 0; c < 16; ++c) a += red[r][c * 16 + q];
+            a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 8, 64);
+            if (q == 0 && r < rows) part_row[(int64_t)blockIdx.x * rm.nloc + (gl + r)] = a;
+        }
     }
-    // rows of this chunk whose strips lie wholly below the segment were skipped: their row partial for this segment is zero
-    for (int64_t sl = jl0; sl < jl1; sl += 64) {
-        if (rm.glob(sl) < k_seg1) continue;
-        if (tid < 64 && sl + tid < jl1) part_row[(int64_t)blockIdx.x * rm.nloc + (sl + tid)] = 0.0;
+    #pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const int64_t k = k_seg0 + 256 * w + tid;
+        if (k < k_seg1) part_col[(int64_t)blockIdx.y * n + k] = cacc[w];
     }
-    __syncthreads();
-    for (int c = tid; c < SYMV_SEG && k_seg0 + c < n; c += 256)
-        part_col[(int64_t)blockIdx.y * n + k_seg0 + c] = any ? (colacc[0][c] + colacc[1][c]) + (colacc[2][c] + colacc[3][c]) : 0.0;
 }
 
 // y[a] = (a is a row this rank works on ? sum_seg part_row[seg][local row] + delta v[a] : 0) + sum_chunk part_col[chunk][a]

@@ -58,7 +58,7 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base, bool provider_only = fa
     if (cd_chunks * maxcol > npart) npart = cd_chunks * maxcol;
     {   // one-pass symmetric product (k_symv_tiles): 64 chunks of column partials + one row partial per column segment
         const size_t nseg = ((size_t)g.n + SYMV_SEG - 1) / SYMV_SEG;
-        if ((cd_chunks + nseg) * (size_t)g.n > npart) npart = (cd_chunks + nseg) * (size_t)g.n;
+        if (((size_t)SYMV_CHUNKS + nseg) * (size_t)g.n > npart) npart = ((size_t)SYMV_CHUNKS + nseg) * (size_t)g.n;
     }
     const size_t op = cv.take(npart * D);
     const size_t odf = cv.take((size_t)(g.n + 1) * D);
@@ -1084,7 +1084,7 @@ int solve_inplace(Ctx* ctx, double* v, bool forward_done = false) {
 int symv_dev(Ctx* ctx, const double* v, double* y, double delta, const RowMap& rm) {
     const Geo& g = ctx->g;
     const int64_t n = g.n;
-    const int nchunk = 64;
+    const int nchunk = SYMV_CHUNKS;
     int64_t rpc = ((rm.nloc + nchunk - 1) / nchunk + 63) / 64 * 64; if (rpc < 64) rpc = 64;
     const int nch = (int)((rm.nloc + rpc - 1) / rpc);
     const int nseg = (int)((n + SYMV_SEG - 1) / SYMV_SEG);
