@@ -396,6 +396,32 @@ def main():
         g_res = core.residual()
         berr = float((core.matvec(raw) - g_res).norm() / g_res.norm())
 
+    # The shader clock the bulk update actually runs at (round 4): one more step with the update kernel's per-block stamps on
+    # (diagnostics buffer: 100 MHz wall clock and shader cycle counter around each block's main loop).  78.6 TFLOP/s is 256 CUs x
+    # 128 flop/clk at 2.4 GHz; under this load the part clocks lower, and cycles / time says by how much.
+    clock = None
+    if world == 1 and not use_dist and not condensed:
+        try:
+            nrec = (core.Npad // 128) ** 2 + 4096
+            tl = torch.zeros(nrec * 8, dtype=torch.int64, device=device)
+            core.set_option("debug_timeline_ptr", float(tl.data_ptr()))
+            one_step(); torch.cuda.synchronize()
+            core.set_option("debug_timeline_ptr", 0.0)
+            rec = tl.cpu().numpy().reshape(-1, 8)
+            rec = rec[rec[:, 0] != 0]
+            loop_us = (rec[:, 2] - rec[:, 1]) * 0.01
+            cyc = rec[:, 4] >> 16
+            ok = loop_us > 20.0
+            mhz = cyc[ok] / loop_us[ok]
+            if mhz.size:
+                p10, p50, p90 = (float(v) for v in np.percentile(mhz, [10, 50, 90]))
+                clock = {"shader_mhz_in_update_main_loop": {"p10": p10, "median": p50, "p90": p90, "blocks": int(mhz.size)},
+                         "fp64_mfma_peak_at_that_clock_tflops": 256 * 128 * p50 * 1e6 / 1e12,
+                         "method": "one extra step after the timed region with the update kernel's per-block stamps on: "
+                                   "clock64() ticks over s_memrealtime (100 MHz) time of each block's main loop"}
+        except Exception as e:          # diagnostics only
+            clock = {"error": str(e)}
+
     # ranks of the handle-owned RCCL communicator as RCCL itself counts them (0 on one GPU: no exchange exists)
     rccl_ranks = core.comm_ranks() if use_dist else 0
     if rank == 0:
@@ -458,6 +484,9 @@ def main():
                          "flops_per_launch_avg": dobj["flops_per_launch_avg"],
                          "peak_measured_mfma_only": peak_meas,
                          "frac_of_measured_peak": (ach / peak_meas) if peak_meas else None,
+                         "clock": clock,
+                         "frac_of_peak_at_measured_clock": (ach / clock["fp64_mfma_peak_at_that_clock_tflops"])
+                                                           if (clock and "fp64_mfma_peak_at_that_clock_tflops" in clock) else None,
                          "all_bulk_launches": {"achieved": ach_all, "launches": n_launch, "avg_launch_ms": trailing_ms / max(n_launch, 1)},
                          "other_instance": dict(oobj, traffic=pmc_traffic(N, args.nb, oth)[0]) if oobj["launches"] else None},
             "phases_ms_per_step": {"assemble": assemble_ms / K, "panel(tile+scale+in-panel)": panel_ms / K,

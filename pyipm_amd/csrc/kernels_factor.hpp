@@ -869,7 +869,7 @@ __global__ __launch_bounds__(NW * 64, (BN >= 256 ? 2 : NW / 2)) void k_update(
     }
     const int wi = (wave & 1) * 64, wj = (wave >> 1) * (BN / (NW / 2));
     const int l15 = lane & 15, l4 = lane >> 4;
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, cy1 = 0, cy2 = 0;
     if (u.dbg) ts0 = wall_clock64();
 
     double4_t acc[TJ][TI];
@@ -934,7 +934,7 @@ __global__ __launch_bounds__(NW * 64, (BN >= 256 ? 2 : NW / 2)) void k_update(
     PYIPM_STORE_LDS(0)
     { const int k1 = (BKU < K) ? BKU : 0; PYIPM_LOAD_REGS(k1) }
     __syncthreads();
-    if (u.dbg) { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[TJ - 1][TI - 1][3])); ts1 = wall_clock64(); }
+    if (u.dbg) { asm volatile("" :: "v"(acc[0][0][0]), "v"(acc[TJ - 1][TI - 1][3])); ts1 = wall_clock64(); cy1 = clock64(); }
     int cur = 0;
     double a0[TJ], b0[TI], a1[TJ], b1[TI];
     PYIPM_FRAGS(cur, 0, a0, b0)
@@ -959,7 +959,7 @@ __global__ __launch_bounds__(NW * 64, (BN >= 256 ? 2 : NW / 2)) void k_update(
         cur ^= 1;
     }
 #undef PYIPM_ILV
-    if (u.dbg) ts2 = wall_clock64();
+    if (u.dbg) { ts2 = wall_clock64(); cy2 = clock64(); }
 #undef PYIPM_STORE_LDS
 #undef PYIPM_FRAGS
 #undef PYIPM_MFMAS
@@ -985,7 +985,8 @@ __global__ __launch_bounds__(NW * 64, (BN >= 256 ? 2 : NW / 2)) void k_update(
         const unsigned long long ts3 = wall_clock64();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // diagnostics: when have this wave's stores drained?
         d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3; 
-        d[4] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);          // HW_ID low 16 bits... (size field = 15+1)
+        d[4] = (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) & 0xffffu)          // HW_ID low 16 bits (size field = 15+1)
+               | ((cy2 - cy1) << 16);                                          // ... and the shader cycles of the main loop (clock64; ts* tick at 100 MHz)
         d[5] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);          // XCC_ID
         d[6] = wall_clock64() - ts3; d[7] = ct;
     }

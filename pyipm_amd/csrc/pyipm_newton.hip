@@ -2101,6 +2101,7 @@ int pyipm_newton_rcond(pyipm_newton_ctx* h, int it_inv, int it_pow, double out[4
     if (ctx->cond_active) { ctx->forward_pending = false; ctx->have_direction = false; ctx->ray_valid = false; }
     double ss[2], lmax = 0.0, linv = 0.0;
     int used_pow = 0, used_inv = 0;
+    const bool trace = getenv("PYIPM_RCOND_TRACE") != nullptr;
     auto norm_of = [&](const double* v, double* nrm) -> int {
         hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, ctx->stream, ctx->partial, v, v, g.N);
         PYIPM_KCHECK();
@@ -2128,6 +2129,7 @@ int pyipm_newton_rcond(pyipm_newton_ctx* h, int it_inv, int it_pow, double out[4
             rc = norm_of(wb, &nrm); if (rc) return rc;
             prev_est = est; est = nrm;
             (phase == 0 ? used_pow : used_inv) = it + 1;
+            if (trace) fprintf(stderr, "[pyipm rcond] %s iteration %d: %.6e\n", phase == 0 ? "power" : "inverse", it + 1, est);
             if (phase == 0 && adaptive_pow && it >= 1 && est <= 1.1 * prev_est) break;
             if (phase == 1 && adaptive_inv) {
                 if (it >= 1 && est <= 1.1 * prev_est) break;

@@ -27,7 +27,10 @@ pro, loop, epi = T[:, 1] - T[:, 0], T[:, 2] - T[:, 1], T[:, 3] - T[:, 2]
 print("blocks timed:", len(d), " kernel span %.1f us" % (T[:, 3].max()))
 for name, x in (("prologue(C+stage0 load)", pro), ("main loop", loop), ("epilogue(stores issued)", epi), ("total", T[:, 3] - T[:, 0])):
     print("%-26s mean %7.2f  p10 %7.2f  p50 %7.2f  p90 %7.2f us" % (name, x.mean(), *np.percentile(x, [10, 50, 90])))
-hw = d[:, 4]; xcc = d[:, 5]
+hw = d[:, 4] & 0xffff; xcc = d[:, 5]
+cyc = d[:, 4] >> 16
+mhz = cyc / np.maximum(loop, 1e-9)
+print("shader clock over the main loop (clock64 ticks / wall time): mean %.0f MHz  p10 %.0f  p50 %.0f  p90 %.0f" % (mhz.mean(), *np.percentile(mhz, [10, 50, 90])))
 wave_id = hw & 0xF; simd = (hw >> 4) & 3; cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
 drain = d[:, 6] * 0.01
 print("store drain (vmcnt(0) after last store issue): mean %.2f p50 %.2f p90 %.2f us" % (drain.mean(), *np.percentile(drain, [50, 90])))
