@@ -254,10 +254,14 @@ __global__ __launch_bounds__(256) void k_symv_row(
 // Every load is unconditional (clamped address, masked value).  Deterministic: every partial has one writer and a fixed
 // order; k_symv_finish adds the partials in a fixed order.
 constexpr int SYMV_SEG = 1024;           // columns per block: SYMV_SEG / 256 column accumulators per thread
-constexpr int SYMV_CHUNKS = 128;         // row chunks (the column partials are [SYMV_CHUNKS][n])
-__global__ __launch_bounds__(256) void k_symv_tiles(
+constexpr int SYMV_CHUNKS = 128;         // row chunks (the column partials are [SYMV_CHUNKS][ncols])
+// TRI: the upper triangle of a square matrix (row sums over k >= j, column sums over j < k), vcol = vrow = v.
+// !TRI (round 4): a rectangular block M (rows = the x rows this rank works on, ncols columns) -- BOTH products of a Jacobian
+// block from one pass:  part_row -> M vcol (Je v_e: into the x rows),  part_col -> M' vrow (Je' v_x: the multiplier rows).
+template <bool TRI>
+__device__ __forceinline__ void rowcol_tiles(
     double* __restrict__ part_row, double* __restrict__ part_col, const double* __restrict__ U, int64_t ldh, int64_t n,
-    const double* __restrict__ v, int64_t rows_per_chunk, RowMap rm)
+    const double* __restrict__ vcol, const double* __restrict__ vrow, int64_t rows_per_chunk, const RowMap& rm)
 {
     constexpr int NW = SYMV_SEG / 256;
     __shared__ double red[16][257];
@@ -271,12 +275,12 @@ __global__ __launch_bounds__(256) void k_symv_tiles(
     #pragma unroll
     for (int w = 0; w < NW; ++w) {
         const int64_t k = k_seg0 + 256 * w + tid;
-        cacc[w] = 0.0; vk[w] = (k < n) ? v[k] : 0.0;
+        cacc[w] = 0.0; vk[w] = (k < n) ? vcol[k] : 0.0;
     }
     for (int64_t gl = jl0; gl < jl1; gl += 16) {                          // 16 local rows: contiguous global rows jg .. jg + 15
         const int64_t jg = rm.glob(gl);
         const int rows = (int)((jl1 - gl) < 16 ? (jl1 - gl) : 16);
-        if (jg >= k_seg1) {                                               // (block-uniform) wholly left of / below the segment's columns
+        if (TRI && jg >= k_seg1) {                                        // (block-uniform) wholly left of / below the segment's columns
             if (tid < rows) part_row[(int64_t)blockIdx.x * rm.nloc + (gl + tid)] = 0.0;
             continue;
         }
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(256) void k_symv_tiles(
         for (int r = 0; r < 16; ++r) {
             const int rc = r < rows ? r : rows - 1;
             rowp[r] = U + rm.brow(gl + rc) * ldh;
-            vr[r] = (r < rows) ? v[jg + rc] : 0.0;
+            vr[r] = (r < rows) ? vrow[jg + rc] : 0.0;
         }
         double racc[16];
         #pragma unroll
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(256) void k_symv_tiles(
         #pragma unroll
         for (int w = 0; w < NW; ++w) {
             const int64_t kt = k_seg0 + 256 * w;
-            if (kt + 256 <= jg || kt >= k_seg1) continue;                 // (uniform) the window lies left of the diagonal / past the matrix
+            if ((TRI && kt + 256 <= jg) || kt >= k_seg1) continue;        // (uniform) the window lies left of the diagonal / past the matrix
             const int64_t k = kt + tid, kc = k < n ? k : n - 1;
             double u[16];
             #pragma unroll
@@ -302,9 +306,9 @@ __global__ __launch_bounds__(256) void k_symv_tiles(
             #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t j = jg + r;
-                const double uu = (r < rows && k < n && k >= j) ? u[r] : 0.0;
+                const double uu = (r < rows && k < n && (!TRI || k >= j)) ? u[r] : 0.0;
                 racc[r] = fma(uu, vk[w], racc[r]);
-                ca = fma((k > j) ? uu : 0.0, vr[r], ca);
+                ca = fma((!TRI || k > j) ? uu : 0.0, vr[r], ca);
             }
             cacc[w] += ca;
         }
@@ -327,6 +331,29 @@ __global__ __launch_bounds__(256) void k_symv_tiles(
         const int64_t k = k_seg0 + 256 * w + tid;
         if (k < k_seg1) part_col[(int64_t)blockIdx.y * n + k] = cacc[w];
     }
+}
+__global__ __launch_bounds__(256) void k_symv_tiles(
+    double* __restrict__ part_row, double* __restrict__ part_col, const double* __restrict__ U, int64_t ldh, int64_t n,
+    const double* __restrict__ v, int64_t rows_per_chunk, RowMap rm)
+{
+    rowcol_tiles<true>(part_row, part_col, U, ldh, n, v, v, rows_per_chunk, rm);
+}
+// One Jacobian block (rows = the x rows of this rank, ncols = me or mi): part_row[seg][local row] = partial of M vcol,
+// part_col[chunk][k] = partial of M' vrow (vrow indexed by GLOBAL row).  k_jac_finish_rows adds the row partials into y.
+__global__ __launch_bounds__(256) void k_jac_tiles(
+    double* __restrict__ part_row, double* __restrict__ part_col, const double* __restrict__ M, int64_t ldm, int64_t ncols,
+    const double* __restrict__ vcol, const double* __restrict__ vrow, int64_t rows_per_chunk, RowMap rm)
+{
+    rowcol_tiles<false>(part_row, part_col, M, ldm, ncols, vcol, vrow, rows_per_chunk, rm);
+}
+// y[glob(jl)] += sum_seg part_row[seg][jl]  (fixed order)
+__global__ __launch_bounds__(256) void k_jac_finish_rows(double* __restrict__ y, const double* __restrict__ part_row, int nseg, RowMap rm)
+{
+    const int64_t jl = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (jl >= rm.nloc) return;
+    double acc = 0.0;
+    for (int sgi = 0; sgi < nseg; ++sgi) acc += part_row[(int64_t)sgi * rm.nloc + jl];
+    y[rm.glob(jl)] += acc;
 }
 
 // y[a] = (a is a row this rank works on ? sum_seg part_row[seg][local row] + delta v[a] : 0) + sum_chunk part_col[chunk][a]

@@ -59,6 +59,9 @@ size_t carve_workspace(Ctx* c, const Geo& g, char* base, bool provider_only = fa
     {   // one-pass symmetric product (k_symv_tiles): 64 chunks of column partials + one row partial per column segment
         const size_t nseg = ((size_t)g.n + SYMV_SEG - 1) / SYMV_SEG;
         if (((size_t)SYMV_CHUNKS + nseg) * (size_t)g.n > npart) npart = ((size_t)SYMV_CHUNKS + nseg) * (size_t)g.n;
+        // ... and the same for a Jacobian block (k_jac_tiles: [SYMV_CHUNKS][m] column partials + [segments of m][n] row partials)
+        const size_t mm = (size_t)(g.me > g.mi ? g.me : g.mi), jseg = (mm + SYMV_SEG - 1) / SYMV_SEG;
+        if ((size_t)SYMV_CHUNKS * mm + jseg * (size_t)g.n > npart) npart = (size_t)SYMV_CHUNKS * mm + jseg * (size_t)g.n;
     }
     const size_t op = cv.take(npart * D);
     const size_t odf = cv.take((size_t)(g.n + 1) * D);
@@ -1106,17 +1109,9 @@ int kkt_matvec_dev(Ctx* ctx, const double* v, double* y) {
     const RowMap rm = make_rowmap(g, ctx->sharded);
     const int64_t nl = rm.nloc;
     if (g.world > 1) { hipLaunchKernelGGL(k_fill, grid1(g.Npad), dim3(256), 0, ctx->stream, y, 0.0, g.Npad); PYIPM_KCHECK(); }
-    const int nchunk = 64;
-    const int64_t rpc = (nl + nchunk - 1) / nchunk > 0 ? (nl + nchunk - 1) / nchunk : 1;
     if (nl > 0) {
         // x block: sym(triu(d2L)) v + delta v, one pass over the upper triangle (row sums and mirrored column sums together)
         { int r2 = symv_dev(ctx, v, y, ctx->delta, rm); if (r2) return r2; }
-        // + Je v_e + Ji v_i
-        if (me + mi > 0) {
-            hipLaunchKernelGGL(k_rowdot2, grid1(nl, 4), dim3(256), 0, ctx->stream, y, (const double*)nullptr, nl,
-                               ctx->Je, ctx->ld_Je, v + n + mi, me, ctx->Ji, ctx->ld_Ji, v + n + mi + me, mi, 1, 0, rm);
-            PYIPM_KCHECK();
-        }
     }
     // s, lambda_e, lambda_i, pad: element-wise parts (one rank)
     if (g.Npad > n && g.rank == 0) {                   // (nothing beyond the x block when me = mi = 0 and n is a multiple of 128)
@@ -1124,20 +1119,29 @@ int kkt_matvec_dev(Ctx* ctx, const double* v, double* y) {
                            ctx->eps, ctx->delta_c);
         PYIPM_KCHECK();
     }
-    // + Je' v_x , Ji' v_x
-    if (me > 0 && nl > 0) {
-        hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((me + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
-                           ctx->partial, ctx->Je, ctx->ld_Je, nl, me, v, rpc, 0, rm);
-        PYIPM_KCHECK();
-        hipLaunchKernelGGL(k_coldot_reduce, grid1(me), dim3(256), 0, ctx->stream, y + n + mi, ctx->partial, me, nchunk, 1);
-        PYIPM_KCHECK();
-    }
-    if (mi > 0 && nl > 0) {
-        hipLaunchKernelGGL(k_coldot_partial, dim3((unsigned)((mi + 255) / 256), nchunk), dim3(256), 0, ctx->stream,
-                           ctx->partial, ctx->Ji, ctx->ld_Ji, nl, mi, v, rpc, 0, rm);
-        PYIPM_KCHECK();
-        hipLaunchKernelGGL(k_coldot_reduce, grid1(mi), dim3(256), 0, ctx->stream, y + n + mi + me, ctx->partial, mi, nchunk, 1);
-        PYIPM_KCHECK();
+    // + Je v_e, Ji v_i into the x rows and + Je' v_x, Ji' v_x into the multiplier rows: each Jacobian block is passed over ONCE
+    // (round 4: k_jac_tiles -- row sums and column sums from the same loads, as for the triangle of d2L; was k_rowdot2 + k_coldot_*,
+    // two passes)
+    if (nl > 0) {
+        int64_t rpc = ((nl + SYMV_CHUNKS - 1) / SYMV_CHUNKS + 63) / 64 * 64; if (rpc < 64) rpc = 64;
+        const int nch = (int)((nl + rpc - 1) / rpc);
+        for (int blk = 0; blk < 2; ++blk) {
+            const int64_t m = blk == 0 ? me : mi;
+            if (m <= 0) continue;
+            const double* M = blk == 0 ? ctx->Je : ctx->Ji;
+            const int64_t ldm = blk == 0 ? ctx->ld_Je : ctx->ld_Ji;
+            const int64_t off = n + mi + (blk == 0 ? 0 : me);                 // the multiplier rows of this block
+            const int nseg = (int)((m + SYMV_SEG - 1) / SYMV_SEG);
+            double* part_col = ctx->partial;
+            double* part_row = ctx->partial + (size_t)SYMV_CHUNKS * (size_t)m;
+            hipLaunchKernelGGL(k_jac_tiles, dim3((unsigned)nseg, (unsigned)nch), dim3(256), 0, ctx->stream, part_row, part_col,
+                               M, ldm, m, v + off, v, rpc, rm);
+            PYIPM_KCHECK();
+            hipLaunchKernelGGL(k_jac_finish_rows, grid1(nl), dim3(256), 0, ctx->stream, y, part_row, nseg, rm);
+            PYIPM_KCHECK();
+            hipLaunchKernelGGL(k_coldot_reduce, grid1(m), dim3(256), 0, ctx->stream, y + off, part_col, m, nch, 1);
+            PYIPM_KCHECK();
+        }
     }
     return 0;
 }
