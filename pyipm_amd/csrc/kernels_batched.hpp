@@ -95,7 +95,22 @@ __device__ __forceinline__ bool rows_active(const Geo& g, int64_t slo, int64_t s
     return true;
 }
 
+// The tile inversion behind a real call: inlined into the loop over the tile columns, its ~100 lane-constant registers were
+// hoisted over the whole kernel (256 + 256 registers and 102 of them spilled).  Round 4, 512 problems, whole step: 4.34 -> 3.97 ms
+// with the call, 3.85 with two row tiles per pass instead of four.  Two workgroups per CU (launch bounds 256, 2: the inversion
+// alone needs 242 registers) were slower in every variant tried (4.2 - 5.2 ms), and so was requesting the next step's operands
+// before the products of the current one (3.98: the extra live registers spill inside the loops).  A problem is a chain of
+// dependent round trips to memory (load L and W tiles, synchronise, 64 - 128 MFMAs, store): 1.3 ms alone on the GPU, 1.9 ms
+// with 255 others.
+__device__ __noinline__ void b_tile_invert(TileScratch& sm, const double* A, int64_t ld, int64_t j0, double* Tinv, double* Tsave,
+                                           double* Tflag, double refine_cond, DevStats* st, int64_t Nreal, double pivtol_rel,
+                                           const unsigned long long* anorm_bits, int64_t neg_from, bool blocked)
+{
+    tile_invert_dev(sm, A, ld, j0, j0, Tinv, Tsave, Tflag, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from, nullptr, false, blocked);
+}
+
 // Factor one problem per workgroup.  grid B, 256 threads.
+constexpr int B_RT = 2;                   // row tiles per left-looking pass (their accumulators: 32 registers each per lane)
 __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double refine_cond, int nref, double pivtol_rel, int blocked)
 {
     __shared__ TileScratch sm;
@@ -117,15 +132,14 @@ __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double re
     for (int t = 0; t < nt; ++t) {
         const int64_t j0 = (int64_t)t * TB;
         // (1) left-looking: block column t, row tiles r >= t, gets the contributions of tile columns u < t.
-        // Four row tiles per pass (a wave owns 16 rows of each): the staged W operand is reused 4x -- the batch
-        // as a whole is HBM-bound here (512 problems x 4.7 MB do not fit any cache).
+        // B_RT row tiles per pass (a wave owns 16 rows of each): the staged W operand is reused B_RT times.
         if (t > 0) {
-            for (int r0 = t; r0 < nt; r0 += 4) {
-                const int nq = (nt - r0) < 4 ? (nt - r0) : 4;
+            for (int r0 = t; r0 < nt; r0 += B_RT) {
+                const int nq = (nt - r0) < B_RT ? (nt - r0) : B_RT;
                 const int64_t ib = (int64_t)r0 * TB + wave * 16 + l15;          // row of tile r0; tile r0+q: + 64 q
-                double4_t acc[4][4];
+                double4_t acc[B_RT][4];
                 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < B_RT; ++q)
                     if (q < nq) {
                         #pragma unroll
                         for (int cb = 0; cb < 4; ++cb)
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double re
                     }
                     __syncthreads();
                     #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+                    for (int q = 0; q < B_RT; ++q)
                         if (q < nq) {
                             double bn[16];
                             if (q + 1 < nq) {
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double re
                         }
                 }
                 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < B_RT; ++q)
                     if (q < nq) {
                         #pragma unroll
                         for (int cb = 0; cb < 4; ++cb)
@@ -189,8 +203,8 @@ __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double re
         }
         __syncthreads();
         // (2) the block pivot
-        tile_invert_dev(sm, A, ld, j0, j0, Tinv + (int64_t)t * TB * TB, Tsave + (int64_t)t * TB * TB, Tflag + t,
-                        refine_cond, st, g.N, pivtol_rel, bp.anorm + 2 * bi, g.n + g.mi, nullptr, false, blocked != 0);
+        b_tile_invert(sm, A, ld, j0, Tinv + (int64_t)t * TB * TB, Tsave + (int64_t)t * TB * TB, Tflag + t,
+                      refine_cond, st, g.N, pivtol_rel, bp.anorm + 2 * bi, g.n + g.mi, blocked != 0);
         __syncthreads();
         // (3) rows below: keep -S' in the upper blocks, overwrite S with L = S X (refined when the tile is flagged)
         if (t + 1 < nt) {

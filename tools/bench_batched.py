@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pyipm_amd.batched import BatchedNewton
 
-B, n, me, mi = 512, 256, 0, 256
+B, n, me, mi = (int(sys.argv[1]) if len(sys.argv) > 1 else 512), 256, 0, 256
 gen = torch.Generator(device="cuda").manual_seed(0)
 M = torch.randn(B, n, n, dtype=torch.float64, device="cuda", generator=gen)
 Q = M @ M.transpose(1, 2) / n + torch.eye(n, dtype=torch.float64, device="cuda")
