@@ -238,7 +238,7 @@ def main():
     ap.add_argument("--nvar", "--n", dest="n", type=int, default=16384)
     ap.add_argument("--neq", "--me", dest="me", type=int, default=4096)
     ap.add_argument("--nineq", "--mi", dest="mi", type=int, default=6144)
-    ap.add_argument("--nb", type=int, default=0, help="panel width (default 256 on one GPU, 1024 across GPUs: a quarter of the messages and sync points; the owner factors a wide panel with the single-rank group chain)")
+    ap.add_argument("--nb", type=int, default=0, help="panel width (default 256 on one GPU; across GPUs 256 below KKT dimension 65536, where the owners' chain is the step, and 1024 from there on, where the bulk update is: tools/rank_replay.py, DESIGN.md section 6)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--refine", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -301,8 +301,15 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
-    if args.nb == 0:
-        args.nb = 256 if world == 1 else 1024
+    # across GPUs the panel width trades the owners' chain (proportional to nb) against the efficiency of the bulk update
+    # (rank-nb) and the number of messages: the rank replay on one GPU (profiles/r04_z_replay_*.json, r04_z_replay_nb.txt) puts
+    # N = 32768 at 47 / 55 / 55 ms for nb = 256 / 512 / 1024 on 8 ranks (90 / 106 / 114 on 2) and N = 131072 at 0.71 s for
+    # nb = 1024 against 0.81 s for 512.  Chosen per workload (the config-4 leg has its own).
+    nb_user = args.nb
+
+    def pick_nb(kkt_dim):
+        return nb_user if nb_user else (256 if (world == 1 or kkt_dim < 65536) else 1024)
+    args.nb = pick_nb(args.n + 2 * args.mi + args.me)
     n, me, mi = args.n, args.me, args.mi
     N = n + 2 * mi + me
     want_condensed = any(kv.split("=")[0] == "condensed" and float(kv.split("=")[1]) != 0 for kv in args.opt) and mi > 0
@@ -311,7 +318,7 @@ def main():
     def build(n, me, mi, seed):
         """Problem + handle + the step callable for one workload (the headline one, then config 4)."""
         qp = make_qp_device(n, me, mi, seed, device)
-        core = NewtonCore(n, me, mi, device=local_rank, nb=args.nb, world=world, rank=rank)
+        core = NewtonCore(n, me, mi, device=local_rank, nb=pick_nb(n + 2 * mi + me), world=world, rank=rank)
         if world > 1 and want_condensed:
             # the condensed option across ranks takes the full blocks on every rank (a column of Ji Sigma Ji' needs every row of Ji)
             core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])

@@ -379,9 +379,10 @@ def test_bench_self_launches_for_several_gpus():
     multi = torch.cuda.device_count() >= 2
     if not multi:
         env["PYIPM_BENCH_SHARE_GPU"] = "1"
-    # (no --nb: the multi-GPU default, 1024 -- five panels here, the last one 640 wide, each factored as a block of sub-panels)
+    # (nb = 1024, the multi-GPU default from KKT dimension 65536 on -- five panels here, the last one 640 wide, each factored as a
+    # block of sub-panels; below that size bench.py takes nb = 256: tools/rank_replay.py)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--nvar", "2560", "--neq", "384", "--nineq", "896", "--no-cpu-baseline"]
+           "--nvar", "2560", "--neq", "384", "--nineq", "896", "--nb", "1024", "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
