@@ -36,5 +36,6 @@ timeout 300 python tools/bench_provider.py > $O/bench_provider.json 2> /dev/null
 timeout 600 python tools/bench_batched.py > $O/bench_batched.txt 2>&1
 timeout 900 python tools/bench_lbfgs.py > $O/bench_lbfgs.txt 2>&1
 ( timeout 300 python tools/bench_tile.py 1 ) > $O/bench_tile.txt 2>&1
+( timeout 300 python tools/update_cycles.py; echo; echo '--- one wide launch (K = 1024) repeated in isolation:'; timeout 300 python tools/timeline_update.py 1024 | head -8 ) > $O/update_cycles.txt 2>&1 < /dev/null
 rm -rf $O/pmc/*/*.db $O/pmc_hbm/*/*.db 2>/dev/null
 du -sh $O
