@@ -308,7 +308,7 @@ def main():
     nb_user = args.nb
 
     def pick_nb(kkt_dim):
-        return nb_user if nb_user else (256 if (world == 1 or kkt_dim < 65536) else 1024)
+        return nb_user if nb_user else default_panel_width(world, kkt_dim)
     args.nb = pick_nb(args.n + 2 * args.mi + args.me)
     n, me, mi = args.n, args.me, args.mi
     N = n + 2 * mi + me
@@ -599,6 +599,12 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     wd.done = True
+
+
+def default_panel_width(world, kkt_dim):
+    """Panel width when --nb is not given: 256 on one GPU; across GPUs 256 while the owners' chain is the step (KKT dimension
+    below 65536) and 1024 where the bulk update is (tools/rank_replay.py, profiles/r04_z_replay_nb.txt)."""
+    return 256 if (world == 1 or kkt_dim < 65536) else 1024
 
 
 def config4_leg(build, fence, wd, world, rank, device, use_dist, share_gpu, n=65536, me=0, mi=32768, steps=2, warmup=1):

@@ -102,3 +102,14 @@ def test_bench_watchdog_prints_an_error_line_instead_of_hanging(tmp_path):
     # other ranks exit silently
     p2 = subprocess.run([sys.executable, "-c", code.replace("Watchdog(1, 0,", "Watchdog(1, 3,")], capture_output=True, text=True, timeout=60)
     assert p2.returncode == 3 and not [l for l in p2.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_default_panel_width():
+    """bench.py's panel width when --nb is not given: 256 on one GPU; across GPUs 256 while the owners' chain is the step
+    and 1024 where the bulk update is (rank replays at three widths, profiles/r04_z_replay_nb.txt)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.default_panel_width(1, 32768) == 256 and bench.default_panel_width(1, 131072) == 256
+    assert bench.default_panel_width(8, 32768) == 256 and bench.default_panel_width(2, 40960) == 256
+    assert bench.default_panel_width(8, 131072) == 1024 and bench.default_panel_width(2, 65536) == 1024
