@@ -252,6 +252,9 @@ def main():
                     help="after the timed region also time BASELINE.json's config 4 (n=65536, mi=32768 -> N=131072; 1 warm-up + 2 "
                          "steps) on the same GPUs and attach it as `config4`: the >= 5x-at-8-GPUs target is stated on THAT size, so "
                          "every 1-GPU and N-GPU line carries its leg of it.  auto = only with the default headline workload")
+    ap.add_argument("--no-clock", action="store_true",
+                    help="skip the extra step that measures the shader clock of the update kernel (counter-collection runs: the "
+                         "traced process then holds exactly warmup + steps steps)")
     ap.add_argument("--extras", action="store_true",
                     help="after the timed region also run and report (a) the all-dense factorisation (skip_zeros=0) with a "
                          "bitwise check of the direction and (b) one L-BFGS search direction (SURVEY 8f rank 4).  Off by "
@@ -407,7 +410,7 @@ def main():
     # (diagnostics buffer: 100 MHz wall clock and shader cycle counter around each block's main loop).  78.6 TFLOP/s is 256 CUs x
     # 128 flop/clk at 2.4 GHz; under this load the part clocks lower, and cycles / time says by how much.
     clock = None
-    if world == 1 and not use_dist and not condensed:
+    if world == 1 and not use_dist and not condensed and not args.no_clock:
         try:
             nrec = (core.Npad // 128) ** 2 + 4096
             tl = torch.zeros(nrec * 8, dtype=torch.int64, device=device)

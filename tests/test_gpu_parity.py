@@ -76,6 +76,38 @@ def test_qp_golden_step(shape):
     np.testing.assert_allclose(core.matvec(raw).cpu().numpy(), H @ raw, rtol=0, atol=1e-12 * np.abs(H @ raw).max())
 
 
+@pytest.mark.parametrize("n,me,mi", [(1, 0, 0), (5, 3, 0), (3, 0, 7), (200, 100, 300), (300, 0, 1500), (1100, 700, 200),
+                                     (2049, 1025, 1030), (257, 255, 1023), (1024, 0, 1025)])
+def test_block_matvec_and_provider_products_on_ragged_shapes(n, me, mi):
+    """`Hc v` from the staged blocks (every block passed over once since round 4: k_symv_tiles for the triangle of d2L, k_jac_tiles
+    for a Jacobian block's two products) and the provider products against the oracle's assembled matrix: constraint counts below
+    one 256-column window, above one 1024-column segment, larger than n, empty blocks; shifts delta / delta_c included."""
+    import torch
+    qp = make_qp(n, me, mi, 7 + n % 5)
+    core = _core(n, me, mi)
+    core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+    core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    rng = np.random.default_rng(n + 3 * me + 5 * mi)
+    N = core.N
+    for delta, delta_c in ((0.0, 0.0), (0.37, 1.0e-3)):
+        core.assemble(delta, delta_c)
+        H = orc.kkt_matrix(qp["d2L"], qp["Je"], qp["Ji"], qp["s"], qp["lam"], n, me, mi)
+        H = H + np.diag(np.r_[np.full(n, delta), np.zeros(mi), np.full(me, -delta_c), np.zeros(mi)])
+        v = rng.standard_normal(N)
+        y = core.matvec(torch.from_numpy(v).cuda()).cpu().numpy()
+        ref = H @ v
+        np.testing.assert_allclose(y, ref, rtol=0, atol=1e-13 * (np.abs(H) @ np.abs(v)).max())
+    x = rng.standard_normal(n)
+    Qx, Ax, Gx = core.block_products(torch.from_numpy(x).cuda())
+    Qs = np.triu(qp["d2L"]) + np.triu(qp["d2L"], 1).T
+    np.testing.assert_allclose(Qx.cpu().numpy(), Qs @ x, rtol=0, atol=1e-13 * (np.abs(Qs) @ np.abs(x)).max())
+    if me:
+        np.testing.assert_allclose(Ax.cpu().numpy(), qp["Je"].T @ x, rtol=0, atol=1e-13 * (np.abs(qp["Je"]).T @ np.abs(x)).max())
+    if mi:
+        np.testing.assert_allclose(Gx.cpu().numpy(), qp["Ji"].T @ x, rtol=0, atol=1e-13 * (np.abs(qp["Ji"]).T @ np.abs(x)).max())
+    core.close()
+
+
 @pytest.mark.parametrize("k", range(1, 11))
 def test_reference_traces(k):
     """Every Newton system the unmodified reference met while solving problems 1-10 (seed-42 x0):

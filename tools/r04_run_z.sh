@@ -11,7 +11,7 @@ timeout 900 python bench.py --no-cpu-baseline --config4 off --steps 5 --warmup 2
 # kernel trace + stats of the headline workload (the default command without its config-4 leg and CPU leg)
 kstats() {   # name, bench args...
   name=$1; shift
-  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $R/$O/prof_$name -o $name -- python $R/bench.py --no-cpu-baseline --config4 off "$@" > $R/$O/${name}_under_rocprof.json 2> $R/$O/${name}_rocprof.err )
+  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $R/$O/prof_$name -o $name -- python $R/bench.py --no-cpu-baseline --config4 off --no-clock "$@" > $R/$O/${name}_under_rocprof.json 2> $R/$O/${name}_rocprof.err )
   python tools/rocpd_stats.py $(find $O/prof_$name -name "*.db" | head -1) $O/${name}_kernel_stats.txt > /dev/null 2>&1
   rm -rf $O/prof_$name
 }
