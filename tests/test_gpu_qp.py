@@ -21,7 +21,24 @@ def _dev_ipm(qp, **kw):
                        G=qp["G"] if qp["mi"] else None, h=qp["h"] if qp["mi"] else None, verbosity=-1, **kw)
 
 
-@pytest.mark.parametrize("shape", [(40, 10, 20, 1), (64, 0, 48, 2), (96, 32, 0, 3), (200, 60, 120, 4), (300, 0, 0, 5)])
+def _fuzz_shapes():
+    """PYIPM_QP_FUZZ=count[,seed]: more seeded random shapes for the device loop / host loop comparison, by hand."""
+    import os
+    spec = os.environ.get("PYIPM_QP_FUZZ", "")
+    if not spec:
+        return []
+    count, seed = (spec.split(",") + ["77"])[:2]
+    rng = np.random.default_rng(int(seed))
+    out = []
+    for i in range(int(count)):
+        n = int(rng.integers(2, 160))
+        me = 0 if rng.random() < 0.3 else int(rng.integers(1, max(2, n // 2)))
+        mi = 0 if rng.random() < 0.3 else int(rng.integers(1, 220))
+        out.append((n, me, mi, 500 + i))
+    return out
+
+
+@pytest.mark.parametrize("shape", [(40, 10, 20, 1), (64, 0, 48, 2), (96, 32, 0, 3), (200, 60, 120, 4), (300, 0, 0, 5)] + _fuzz_shapes())
 @pytest.mark.parametrize("condensed", [False, True])
 def test_device_loop_tracks_host_loop(shape, condensed):
     n, me, mi, seed = shape
@@ -33,8 +50,13 @@ def test_device_loop_tracks_host_loop(shape, condensed):
     xd, sd, ld, fd, kkt = dev.solve()
     assert dev.signal == host.signal == 1
     # same algorithm, same Newton core; the provider GEMVs round differently (NumPy vs device), which can
-    # move a stopping test sitting right at its threshold by one iteration
-    assert abs(dev.iter_count - host.iter_count) <= 1
+    # move a stopping test sitting right at its threshold by one iteration.  The device loop may also finish EARLIER: it forms
+    # phi(x + a dx) - phi(x) without cancellation (pyipm_newton_merit_ray), the host (like the reference, pyipm.py:1534-1548)
+    # subtracts two merit values of size |phi| -- once the decrease falls below eps |phi| its Armijo test rejects full steps on
+    # rounding noise and the last decades of the KKT norm take one iteration each (seed 521, n = 60, me = 13, mi = 11: identical
+    # iterates up to |KKT| = 1.4e-6, then 7 against 9 iterations to 1e-8, x equal to 4e-11)
+    assert dev.iter_count <= host.iter_count + 1
+    assert dev.iter_count >= host.iter_count - 1 or shape[3] >= 500      # (the hand-picked shapes stay within one iteration)
     np.testing.assert_allclose(xd.cpu().numpy(), xh, rtol=1e-7, atol=1e-9)
     if mi:
         np.testing.assert_allclose(sd.cpu().numpy(), sh, rtol=1e-6, atol=1e-9)
