@@ -112,7 +112,7 @@ def test_medium_qp_all_on_device():
 
 
 # ---------------------------------------------------------------------- L-BFGS mode (pyipm.py:1633-1637, 1702-1713)
-@pytest.mark.parametrize("shape", [(60, 8, 20, 1), (120, 0, 40, 2), (90, 30, 0, 3), (150, 0, 0, 4)])
+@pytest.mark.parametrize("shape", [(60, 8, 20, 1), (120, 0, 40, 2), (90, 30, 0, 3), (150, 0, 0, 4)] + _fuzz_shapes())
 def test_device_lbfgs_loop_tracks_host_lbfgs_loop(shape):
     """QPDeviceIPM(lbfgs=m) (storage and iterate on the device, Jacobians staged once) against IPM(lbfgs=m) driven
     with the same QP as callables: same algorithm, same direction kernels."""
