@@ -157,6 +157,32 @@ def test_ipm_solves_an_lp_with_128_variables():
     assert np.all(G @ x - h >= -1e-6)
 
 
+def _lp_fuzz():
+    """PYIPM_LP_FUZZ=count[,seed]: more seeded random LPs, by hand."""
+    spec = os.environ.get("PYIPM_LP_FUZZ", "")
+    out = [(7, 0, 11), (65, 9, 12), (130, 77, 13)]
+    if spec:
+        count, seed = (spec.split(",") + ["5"])[:2]
+        rng = np.random.default_rng(int(seed))
+        out += [(int(rng.integers(2, 220)), int(rng.integers(0, 90)), 1000 + i) for i in range(int(count))]
+    return out
+
+
+@pytest.mark.parametrize("n,extra,seed", _lp_fuzz())
+def test_ipm_solves_random_lps(n, extra, seed):
+    """LPs of other sizes (one tile, several tiles, tile boundaries; with and without cuts) against scipy's LP solver: every
+    Newton system of such a solve has a zero x-x block, i.e. lives on static pivots / 2x2 pivots and refinement."""
+    from scipy.optimize import linprog
+    from pyipm_amd.ipm import IPM
+    prob, c, G, h = _lp(n, extra, seed)
+    p = IPM(x0=np.zeros(n), verbosity=-1, Ktol=1e-7, **prob)
+    x, s, lda, fval, kkt = p.solve()
+    ref = linprog(c, A_ub=-G, b_ub=-h, bounds=[(None, None)] * n, method="highs")
+    assert ref.status == 0
+    assert abs(fval - ref.fun) <= 1e-5 * max(1.0, abs(ref.fun)), (fval, ref.fun, p.signal)
+    assert np.all(G @ x - h >= -1e-6)
+
+
 def test_batched_handle_static_pivots_stay_finite():
     """The batched kernel shares the tile inversion: LP-shaped members no longer poison their batch."""
     from pyipm_amd.batched import BatchedNewton
