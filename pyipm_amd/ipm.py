@@ -229,12 +229,24 @@ class HipNewtonBackend(object):
                     raise RuntimeError("inertia not corrected after %d diagonal shifts" % tries)
                 delta *= 10.0
             dz, converged = self._solve(st)
+            stalled, prev_be = 0, None
             while not converged:
                 # still no direction that satisfies the blocks: the shift has not made the factor trustworthy yet.
                 # Larger shift (the reference's delta *= 10 loop, :1399-1403); when the budget is spent, the best direction
                 # seen if it is at least berr_fallback-accurate (shifted or not), else give up loudly.
                 self.n_unconverged += 1
                 remember(dz, delta, st)
+                # ... or as soon as larger shifts have stopped helping: two tries in a row whose backward error did not fall
+                # tenfold with the tenfold shift, and a direction at berr_fallback in hand.  (Exactly dependent equality
+                # constraints: no shift of the x block cures the multiplier block; waiting for delta ~ 1 to dominate the
+                # system cost nine factorisations per iterate and returned a gradient-like step -- round 4.)
+                be = self.last_solve_info["backward_error"] if self.last_solve_info else -1.0
+                stalled = stalled + 1 if (prev_be is not None and be >= 0.0 and be >= 0.1 * prev_be) else 0
+                prev_be = be if be >= 0.0 else prev_be
+                if stalled >= 2 and best is not None and best[0] <= self.berr_fallback:
+                    self.n_inexact += 1
+                    dz, delta, st = best[1], best[2], best[3]
+                    break
                 tries += 1
                 if tries > self.max_shift_tries:
                     if best is not None and best[0] <= self.berr_fallback:
