@@ -28,6 +28,43 @@ def test_batched_small_vs_oracle():
     bn.close()
 
 
+def _batched_shapes():
+    """Block boundaries on and off the 64-tile grid, empty blocks, one tile, the 1024-row limit of a batched problem;
+    PYIPM_BATCHED_FUZZ=count[,seed] adds seeded random shapes by hand."""
+    import os
+    out = [(1, 0, 0), (5, 2, 0), (3, 0, 9), (64, 0, 64), (65, 63, 1), (130, 40, 100), (200, 0, 400), (500, 20, 250), (1020, 0, 2)]
+    spec = os.environ.get("PYIPM_BATCHED_FUZZ", "")
+    if spec:
+        count, seed = (spec.split(",") + ["3"])[:2]
+        rng = np.random.default_rng(int(seed))
+        while len(out) < 9 + int(count):
+            n = int(rng.integers(1, 500))
+            me = 0 if rng.random() < 0.3 else int(rng.integers(1, n + 1))
+            mi = 0 if rng.random() < 0.3 else int(rng.integers(1, 300))
+            if n + me + 2 * mi <= 1024:
+                out.append((n, me, mi))
+    return out
+
+
+@pytest.mark.parametrize("n,me,mi", _batched_shapes())
+def test_batched_ragged_shapes_vs_oracle(n, me, mi):
+    from pyipm_amd.batched import BatchedNewton
+    B = 5
+    qps = [make_qp(n, me, mi, seed=700 + 13 * b + n) for b in range(B)]
+    bn = BatchedNewton(n, me, mi, workers=2)
+    opt = lambda key, on: _stack(qps, key) if on else None          # noqa: E731
+    dz, stats = bn.step_all(_stack(qps, "d2L"), opt("Je", me), opt("Ji", mi), _stack(qps, "df"), opt("ce", me), opt("ci", mi),
+                            opt("s", mi), opt("lam", me + mi), mu=0.2)
+    dz = dz.cpu().numpy()
+    for b, q in enumerate(qps):
+        ref, _, Hc, _ = orc.newton_step(q["d2L"], q["Je"], q["Ji"], q["df"], q["ce"], q["ci"], q["s"], q["lam"],
+                                        q["mu"], n, me, mi, regularise=False)
+        tol = max(1e-10, 20 * np.linalg.cond(Hc) * np.finfo(float).eps)
+        assert np.linalg.norm(dz[b] - ref) / np.linalg.norm(ref) <= tol
+        assert stats[b]["n_neg"] == me + mi and stats[b]["n_zero"] == 0
+    bn.close()
+
+
 def test_config5_512_problems():
     """512 independent n=256 QPs with 256 inequalities each (KKT dim 768); every 32nd one against the oracle,
     all of them through inertia + linear-system residual computed with torch fp64."""
