@@ -97,6 +97,36 @@ def test_condensed_vs_oracle_and_full(shape, nb):
     assert relerr(dz.cpu().numpy(), dzf.cpu().numpy()) <= TOL_DZ
 
 
+def _ragged_condensed(count, seed):
+    rng = np.random.default_rng(seed)
+    edge = [1, 2, 3, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383]
+    out = []
+    for i in range(count):
+        pick = lambda top: int(rng.choice(edge)) if rng.random() < 0.5 else int(rng.integers(1, top))   # noqa: E731
+        n = pick(420)
+        me = 0 if rng.random() < 0.3 else min(pick(200), n)
+        mi = pick(300)                                    # (the option does nothing without inequalities)
+        out.append((n, me, mi, 4000 + i, int(rng.choice([128, 256]))))
+    return out
+
+
+# PYIPM_RAGGED_COUNT / PYIPM_RAGGED_SEED: a longer sweep by hand
+@pytest.mark.parametrize("n,me,mi,seed,nb", _ragged_condensed(int(os.environ.get("PYIPM_RAGGED_COUNT", "24")),
+                                                              int(os.environ.get("PYIPM_RAGGED_SEED", "2025"))))
+def test_condensed_ragged_shapes_vs_oracle(n, me, mi, seed, nb):
+    """The condensed option on seeded ragged shapes (block boundaries on and off the 16-column K grid of the Gram launch, the 64 / 128
+    tile grids and the panels; n + me below one tile; more inequalities than variables) against the oracle's LU of the FULL system."""
+    qp = make_qp(n, me, mi, seed)
+    ref, _, Hc, g = orc.newton_step(qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"],
+                                    qp["mu"], n, me, mi, regularise=False)
+    core = _core(n, me, mi, nb=nb)
+    _stage(core, qp)
+    dz, st = core.step(0.0, 0.0)
+    assert st["n_neg"] == me + mi and st["n_zero"] == 0 and st["n_pos"] == core.N - me - mi
+    assert relerr(dz.cpu().numpy(), ref) <= max(TOL_DZ, 20 * np.linalg.cond(Hc) * np.finfo(float).eps)
+    core.close()
+
+
 def test_condensed_call_orders_and_toggle():
     """residual/assemble/factor/solve in the reference's order (fused forward), factor-before-residual,
     explicit right-hand sides, and switching the option off again on the same handle."""
