@@ -125,6 +125,45 @@ def test_ranks_sharing_one_gpu(world, shape, nb, mode):
         assert out[0][3] == fact + 16 * Npad
 
 
+def _ragged_dist_cases():
+    """Ranks, panel widths and block boundaries that do not line up (a last panel narrower than nb, ranks without a panel in some
+    block, empty blocks); PYIPM_DIST_FUZZ=count[,seed] adds seeded random cases by hand."""
+    out = [(2, (129, 0, 65, 21), 128), (3, (515, 129, 0, 22), 256), (4, (200, 70, 333, 23), 128), (4, (1100, 1, 127, 24), 512)]
+    spec = os.environ.get("PYIPM_DIST_FUZZ", "")
+    if spec:
+        count, seed = (spec.split(",") + ["4"])[:2]
+        rng = np.random.default_rng(int(seed))
+        for i in range(int(count)):
+            n = int(rng.integers(2, 1500))
+            me = 0 if rng.random() < 0.3 else int(rng.integers(1, min(n, 500) + 1))
+            mi = 0 if rng.random() < 0.3 else int(rng.integers(1, 700))
+            out.append((int(rng.integers(2, 5)), (n, me, mi, 5000 + i), int(rng.choice([128, 256, 512, 1024]))))
+    return out
+
+
+@pytest.mark.parametrize("world,shape,nb", _ragged_dist_cases())
+def test_ranks_sharing_one_gpu_ragged(world, shape, nb):
+    import torch.multiprocessing as mp
+    n, me, mi, seed = shape
+    N = n + 2 * mi + me
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), shape, nb, "native-sharded", out), nprocs=world, join=True)
+    qp = make_qp(n, me, mi, seed)
+    ref, _, Hc, gref = orc.newton_step(qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"],
+                                       qp["mu"], n, me, mi, regularise=False)
+    tol = max(1e-10, 20 * np.linalg.cond(Hc) * np.finfo(float).eps)
+    for r in range(world):
+        dz, st, ncl, _, g, extra = out[r]
+        np.testing.assert_allclose(g, gref, rtol=0, atol=1e-13 * np.abs(gref).max())
+        assert np.linalg.norm(dz - ref) / np.linalg.norm(ref) <= tol
+        assert st["n_neg"] == me + mi and st["n_zero"] == 0 and st["n_pos"] == N - me - mi
+        assert extra["berr"] <= 1e-12
+    for r in range(1, world):
+        assert np.array_equal(out[0][0], out[r][0])
+    assert out[0][5]["timings"]["bytes"] == _factor_bytes(n, me, mi, nb)[0]
+
+
 # (Npad a multiple of 256: 2560 and 8192 -- with an odd multiple of 128 the wide tiles are not used at all, ADVICE r3; n and
 #  n + mi odd multiples of 128 in the second shape: a wide tile straddles both edges of the slack rows)
 @pytest.mark.parametrize("world,shape,nb", [(2, (1300, 300, 450, 11), 512), (3, (4480, 920, 1344, 12), 1024)])
