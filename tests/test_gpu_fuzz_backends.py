@@ -116,3 +116,40 @@ def test_dependent_equalities_reach_the_point_of_the_reduced_problem(n, me, seed
     assert abs(float(fh) - float(fo)) <= 1e-6 * max(1.0, abs(float(fo)))
     np.testing.assert_allclose(xh, xo, rtol=0, atol=2e-3)
     assert np.abs(prob["ce"](xh)).max() <= 1e-6 and prob["ci"](xh).min() >= -1e-8
+
+
+def _psd_problem(n, me, seed):
+    """Convex QP over a box whose Hessian has rank n // 3 (and a block of exactly zero rows): the x-x block of every KKT system is
+    singular, the system as a whole is not -- tiles that cannot pivot on their own (static pivots, 2x2 pivots) on every solve."""
+    rng = np.random.default_rng(seed)
+    k = max(1, n // 3)
+    M = rng.standard_normal((n, k))
+    M[: n // 4] = 0.0
+    Q = M @ M.T / k
+    c = rng.standard_normal(n)
+    A = rng.standard_normal((me, n)) / np.sqrt(n)
+    G = np.vstack([np.eye(n), -np.eye(n)])
+    h = -np.ones(2 * n)
+    AT, GT = np.ascontiguousarray(A.T), np.ascontiguousarray(G.T)
+    Z = np.zeros((n, n))
+    prob = dict(f=lambda x: float(0.5 * x @ Q @ x + c @ x), df=lambda x: Q @ x + c, d2f=lambda x: Q,
+                ci=lambda x: G @ x - h, dci=lambda x: GT, d2ci=lambda x, lda: Z)
+    if me:
+        prob.update(ce=lambda x: A @ x, dce=lambda x: AT, d2ce=lambda x, lda: Z)
+    return prob
+
+
+@pytest.mark.parametrize("n,me,seed", [(n, me, s + 100) for n, me, s in _cases()])
+def test_hip_backend_tracks_the_oracle_backend_on_rank_deficient_hessians(n, me, seed):
+    from pyipm_amd.ipm import IPM
+    prob = _psd_problem(n, me, seed)
+    kw = dict(x0=np.zeros(n), verbosity=-1, Ktol=1e-6, niter=30, miter=30)
+    hip = IPM(**kw, **prob)
+    xh, sh, lh, fh, _ = hip.solve()
+    ora = IPM(backend=OracleBackend(n, me, 2 * n), **kw, **prob)
+    xo, so, lo, fo, _ = ora.solve()
+    assert hip.signal == ora.signal == 1
+    assert abs(hip.iter_count - ora.iter_count) <= 1
+    assert abs(float(fh) - float(fo)) <= 1e-6 * max(1.0, abs(float(fo)))
+    # (the minimiser need not be unique along the null space of Q inside the active face: compare what is determined)
+    assert np.abs(prob["ci"](xh)).min() >= -1e-8 and (me == 0 or np.abs(prob["ce"](xh)).max() <= 1e-6)
