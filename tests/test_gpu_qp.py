@@ -261,3 +261,47 @@ def test_provider_only_handle():
         p2.block_products(v)
     for c in (full, prov, p2):
         c.close()
+
+
+@pytest.mark.parametrize("n,m,kind", [(40, 90, "rand"), (90, 40, "rand"), (64, 64, "rand"), (300, 900, "box"), (50, 80, "dependent"),
+                                      (80, 50, "dependent"), (30, 70, "illcond")])
+def test_first_multiplier_estimate_equals_the_pseudo_inverse(n, m, kind):
+    """lda0 = pinv(J) df (pyipm.py:726-730) through the normal equations where J allows it, through the SVD elsewhere: the same
+    vector as torch.linalg.pinv in every case (rank-deficient and badly conditioned Jacobians take the SVD)."""
+    import torch
+    from pyipm_amd.qp import QPDeviceIPM
+    rng = np.random.default_rng(n * 1000 + m)
+    J = rng.standard_normal((n, m))
+    if kind == "box":
+        J = np.hstack([np.eye(n), -np.eye(n), rng.standard_normal((n, m - 2 * n)) / np.sqrt(n)])
+    elif kind == "dependent":
+        J[:, -1] = J[:, 0]
+        J[-1, :] = J[0, :]
+    elif kind == "illcond":
+        U, _, Vt = np.linalg.svd(J, full_matrices=False)
+        J = (U * np.logspace(0, -9, min(n, m))) @ Vt
+    g = rng.standard_normal(n)
+    Jd, gd = torch.from_numpy(J).cuda(), torch.from_numpy(g).cuda()
+    got = QPDeviceIPM._pinv_apply(Jd, gd).cpu().numpy()
+    ref = np.linalg.pinv(J) @ g
+    assert np.linalg.norm(got - ref) <= 1e-9 * max(np.linalg.norm(ref), 1e-300) * (1e3 if kind == "illcond" else 1.0)
+
+
+def test_device_loop_solves_an_lp():
+    """Q = 0: every Newton system of the device loop has a zero x-x block (static pivots + refinement), the first multiplier estimate
+    comes from the normal equations (a wide, well-conditioned Jacobian); optimum against scipy's LP solver."""
+    from scipy.optimize import linprog
+    from pyipm_amd.qp import QPDeviceIPM
+    rng = np.random.default_rng(8)
+    n, extra = 300, 120
+    R = rng.standard_normal((extra, n)) / np.sqrt(n)
+    G = np.vstack([np.eye(n), -np.eye(n), R])
+    h = np.concatenate([-np.ones(2 * n), -rng.uniform(0.5, 1.5, extra)])
+    c = rng.standard_normal(n)
+    p = QPDeviceIPM(np.zeros((n, n)), c, G=G, h=h, verbosity=-1, Ktol=1e-7)
+    x, s, lda, fval, kkt = p.solve()
+    ref = linprog(c, A_ub=-G, b_ub=-h, bounds=[(None, None)] * n, method="highs")
+    assert p.signal == 1 and ref.status == 0
+    assert abs(float(fval) - ref.fun) <= 1e-5 * max(1.0, abs(ref.fun))
+    assert (G @ x.cpu().numpy() - h).min() >= -1e-6
+    assert p.backend.n_static >= 1 and p.backend.n_factor == p.iter_count          # one factorisation per iterate
