@@ -261,10 +261,9 @@ class QPDeviceIPM(object):
             bottom = torch.cat([torch.zeros((mi, me), dtype=torch.float64, device=self.device),
                                 -torch.eye(mi, dtype=torch.float64, device=self.device)], dim=1)
             top = torch.cat([top, bottom], dim=0)
-        At = top.t()                                           # (me+mi) x (n+mi)
-        if At.numel() > (1 << 26):                             # large: minimum-norm solution through At At' (full row rank)
-            return -(top @ torch.linalg.solve(At @ top, c_new))
-        return -(torch.linalg.pinv(At) @ c_new)
+        At = top.t().contiguous()                              # (me+mi) x (n+mi)
+        # minimum-norm solution: the normal equations where At allows it, an SVD elsewhere (see _pinv_apply)
+        return -self._pinv_apply(At, c_new)
 
     RAY_BATCH = 64                       # backtracking candidates alpha tau^k evaluated per launch of k_merit_ray
 
