@@ -157,3 +157,23 @@ def test_host_loop_retraces_reference_qp_solve(name):
         assert np.isclose(c["delta"], d["it_delta_out"][it], rtol=1e-12, atol=0)
     np.testing.assert_allclose(x, d["x"], rtol=1e-8, atol=1e-10)
     assert np.isclose(float(fval), float(d["fval"]), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,m,kind", [(40, 90, "rand"), (90, 40, "rand"), (64, 64, "rand"), (120, 400, "box"), (50, 80, "dependent"),
+                                      (80, 50, "dependent"), (30, 70, "illcond"), (3, 1, "rand"), (1, 4, "rand")])
+def test_first_multiplier_estimate_equals_the_pseudo_inverse(n, m, kind):
+    """lda0 = pinv(J) df (pyipm.py:726-730): the normal equations where J allows it, numpy's pinv elsewhere -- the same vector."""
+    from pyipm_amd.ipm import pinv_apply
+    rng = np.random.default_rng(n * 1000 + m)
+    J = rng.standard_normal((n, m))
+    if kind == "box":
+        J = np.hstack([np.eye(n), -np.eye(n), rng.standard_normal((n, m - 2 * n)) / np.sqrt(n)])
+    elif kind == "dependent":
+        J[:, -1] = J[:, 0]
+        J[-1, :] = J[0, :]
+    elif kind == "illcond":
+        U, _, Vt = np.linalg.svd(J, full_matrices=False)
+        J = (U * np.logspace(0, -9, min(n, m))) @ Vt
+    g = rng.standard_normal(n)
+    ref = np.linalg.pinv(J) @ g
+    assert np.linalg.norm(pinv_apply(J, g) - ref) <= 1e-10 * max(np.linalg.norm(ref), 1e-300)
