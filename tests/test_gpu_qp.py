@@ -310,3 +310,27 @@ def test_device_loop_solves_an_lp():
     assert abs(float(fval) - ref.fun) <= 1e-5 * max(1.0, abs(ref.fun))
     assert (G @ x.cpu().numpy() - h).min() >= -1e-6
     assert p.backend.n_static >= 1 and p.backend.n_factor == p.iter_count          # one factorisation per iterate
+
+
+def test_infeasible_and_unbounded_problems_end_loudly():
+    """No minimiser exists: the loop must end with a failure signal (or the backend's RuntimeError once no shift gives a usable
+    direction) -- never with signal 1, never hanging.  The reference's counterparts: negative signals / LinAlgError."""
+    from pyipm_amd.qp import QPDeviceIPM
+    rng = np.random.default_rng(1)
+    n = 40
+    M = rng.standard_normal((n, n))
+    Q, c = M @ M.T / n + np.eye(n), rng.standard_normal(n)
+    box = dict(G=np.vstack([np.eye(n), -np.eye(n)]), h=-np.ones(2 * n))
+    A = rng.standard_normal((4, n))
+    A[3] = A[0]
+    cases = [dict(A=A, b=np.array([0.0, 0.0, 0.0, 1.0]), **box),                             # inconsistent equalities
+             dict(G=np.vstack([np.eye(n), -np.eye(n)]), h=np.ones(2 * n)),                   # x >= 1 and x <= -1
+             dict(Q=np.zeros((n, n)), G=np.eye(n)[:1], h=np.array([-1.0]))]                  # LP unbounded below
+    for kw in cases:
+        Qm = kw.pop("Q", Q)
+        try:
+            p = QPDeviceIPM(Qm, c, verbosity=-1, niter=10, miter=10, **kw)
+            p.solve()
+            assert p.signal != 1
+        except RuntimeError as e:
+            assert "shift" in str(e) or "inertia" in str(e)
