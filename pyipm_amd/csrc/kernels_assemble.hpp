@@ -390,7 +390,16 @@ __global__ __launch_bounds__(256) void k_coldot_partial(
     double acc = 0.0;
     if (rm.world == 1) {
         if (strict_upper && j1 > a) j1 = a;
-        for (int64_t j = j0; j < j1; ++j) acc += M[j * ldm + a] * x[j];
+        // eight rows in flight per thread (one load per trip left the memory pipe waiting on the add); same order of additions
+        int64_t j = j0;
+        for (; j + 8 <= j1; j += 8) {
+            double m[8];
+            #pragma unroll
+            for (int q = 0; q < 8; ++q) m[q] = M[(j + q) * ldm + a];
+            #pragma unroll
+            for (int q = 0; q < 8; ++q) acc += m[q] * x[j + q];
+        }
+        for (; j < j1; ++j) acc += M[j * ldm + a] * x[j];
     } else {
         for (int64_t jl = j0; jl < j1; ++jl) {
             const int64_t j = rm.glob(jl);                                // (ascending in jl)
