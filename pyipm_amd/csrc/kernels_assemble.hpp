@@ -372,7 +372,15 @@ __global__ __launch_bounds__(256) void k_symv_finish(
         acc += delta * v[a];
     }
     double cacc = 0.0;
-    for (int c = 0; c < nchunk; ++c) cacc += part_col[(int64_t)c * n + a];
+    int c = 0;
+    for (; c + 8 <= nchunk; c += 8) {                       // eight partials in flight, added in chunk order
+        double t[8];
+        #pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = part_col[(int64_t)(c + q) * n + a];
+        #pragma unroll
+        for (int q = 0; q < 8; ++q) cacc += t[q];
+    }
+    for (; c < nchunk; ++c) cacc += part_col[(int64_t)c * n + a];
     y[a] = acc + cacc;
 }
 
@@ -416,7 +424,15 @@ __global__ __launch_bounds__(256) void k_coldot_reduce(
     const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (a >= ncol) return;
     double acc = 0.0;
-    for (int c = 0; c < nchunk; ++c) acc += part[(int64_t)c * ncol + a];
+    int c = 0;
+    for (; c + 8 <= nchunk; c += 8) {
+        double t[8];
+        #pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = part[(int64_t)(c + q) * ncol + a];
+        #pragma unroll
+        for (int q = 0; q < 8; ++q) acc += t[q];
+    }
+    for (; c < nchunk; ++c) acc += part[(int64_t)c * ncol + a];
     y[a] = accumulate ? y[a] + acc : acc;
 }
 
