@@ -193,8 +193,11 @@ int pyipm_newton_create_provider(pyipm_newton_ctx** ctx, int64_t n, int64_t me, 
  * 1737-1742): the largest alpha in [0,1] with v + alpha*dv >= (1-tau)*v, for v = s (dv = ds) and
  * v = lda_i (dv = dlda_i), from the staged s / lda and the direction of the last solve()/step() kept on
  * the device.  Closed form min(1, min_{dv_i<0} -tau*v_i/dv_i); the reference's golden-section search
- * converges to the same value from below (to Xtol = eps).  With mi == 0 both are 1. */
-int pyipm_newton_step_lengths(pyipm_newton_ctx* ctx, double tau, double* alpha_s, double* alpha_l);
+ * converges to the same value from below (to Xtol = eps).  With mi == 0 both are 1.
+ * dz: NULL = the direction of the last solve()/step(); else a DEVICE pointer to N doubles in the reference's order with the
+ * multiplier block already sign-flipped (as merit_info / merit_ray take it) -- a host loop that steps along another direction
+ * than the handle's last solve (an earlier, less shifted one kept by its regularisation loop) passes that one. */
+int pyipm_newton_step_lengths(pyipm_newton_ctx* ctx, double tau, const double* dz, double* alpha_s, double* alpha_l);
 
 /* SURVEY.md section 8(f) rank 1, second half — the merit-function pieces of the line search as device reductions over the
  * STAGED point (stage_vectors: df, ce, ci, s, lda) and a direction dz (device pointer, N doubles, reference order with the
@@ -317,9 +320,19 @@ int pyipm_newton_create_batched(pyipm_newton_ctx** ctx, int64_t n, int64_t me, i
 int pyipm_newton_stage_blocks_batched(pyipm_newton_ctx* ctx, const double* d2L, int64_t ld_d2L, int64_t stride_d2L,
                                       const double* Je, int64_t ld_Je, int64_t stride_Je,
                                       const double* Ji, int64_t ld_Ji, int64_t stride_Ji);
-/* residual + assemble + factor + solve + flip for every problem; dz is [batch][N], stats (may be NULL) [batch]. */
+/* residual + assemble + factor + solve + flip for every problem; dz is [batch][N], stats (may be NULL) [batch].
+ * set_option("condensed", 1) (round 5): per problem the (s_k, lambda_i_k) pairs with Sigma_k <= "condensed_sigma_max" are
+ * eliminated analytically (pyipm.py:824-842's block structure), the rest stay as rows -1/Sigma_k: n + me + |A| columns are
+ * factored instead of n + 2 mi + me (BASELINE config 5: 256 instead of 768).  Same inputs, same outputs: the full
+ * [dx|ds|dle|dli] and the inertia of the FULL matrix.  pyipm_newton_last_timings on a batched handle: out[0] residual +
+ * assembly, [6] factorisation, [3] substitutions, [1] the whole step (ms). */
 int pyipm_newton_step_batched(pyipm_newton_ctx* ctx, double delta, double delta_c, double* dz,
                               pyipm_factor_stats* stats, int memkind);
+/* out[b] = |g - Hc raw_b| / |g| for every problem of the last step_batched: Hc applied from the staged blocks with that
+ * step's shifts (never from the factor), raw = dz ([batch][N], DEVICE) with the multiplier flip undone.  The guard of the
+ * condensed form (the host falls back to the full system when a problem misses its bar) and the batched counterpart of the
+ * kkt_matvec check of a single system.  out: batch doubles, host or device per memkind. */
+int pyipm_newton_backward_error_batched(pyipm_newton_ctx* ctx, const double* dz, double* out, int memkind);
 
 /* ---- introspection for tests / bench ------------------------------------------------------ */
 

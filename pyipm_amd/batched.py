@@ -18,11 +18,22 @@ from .newton import ERRORS, MEM_DEVICE, FactorStats, NewtonError, load_library
 
 
 class BatchedNewton(object):
-    def __init__(self, n, me, mi, batch=None, device=None, workers=None, nb=None, refine=0):
-        """``workers`` / ``nb`` are accepted and ignored (an earlier version drove one handle per host thread)."""
+    condensed_tol = 1e-9                   # backward-error bar (against the FULL blocks) a condensed direction must meet
+
+    def __init__(self, n, me, mi, batch=None, device=None, workers=None, nb=None, refine=0, condensed=False, guard=True):
+        """``workers`` / ``nb`` are accepted and ignored (an earlier version drove one handle per host thread).
+        ``condensed``: factor the condensed system of every problem (n + me + |active rows| columns instead of n + 2 mi + me:
+        the (s, lambda_i) pairs eliminated analytically, SURVEY 8f rank 2 for the batched handle) -- same directions, inertia
+        of the full matrix.  With ``guard`` every condensed step is checked on the device (inertia, static pivots, backward
+        error against the full blocks: ``pyipm_newton_backward_error_batched``) and the batch is redone with the full form
+        when a problem misses ``condensed_tol`` (counted in ``n_condensed_fallback``)."""
         import torch
         if refine:
             raise NotImplementedError("iterative refinement is not part of the batched path")
+        self.condensed, self.guard = bool(condensed and mi), bool(guard)
+        self.n_condensed_fallback, self.last_backward_errors = 0, None
+        if self.condensed:
+            self._opts = {"condensed": 1.0}
         self.torch = torch
         self.lib = load_library()
         if not torch.cuda.is_available():
@@ -105,7 +116,41 @@ class BatchedNewton(object):
         out = torch.empty((B, self.N), dtype=torch.float64, device=self.device)
         st = (FactorStats * B)()
         self._ck(self.lib.pyipm_newton_step_batched(self.h, float(delta), float(delta_c), ptr(out), st, MEM_DEVICE))
-        return out, [x.as_dict() for x in st]
+        stats = [x.as_dict() for x in st]
+        if self._opts_get("condensed") and self.guard and mi:
+            # the condensed form's guard (as HipNewtonBackend's for a single system): right inertia, no static pivot, and a
+            # direction that satisfies the FULL blocks; otherwise the batch is redone with the full 4-block system
+            be = self.backward_errors(out)
+            self.last_backward_errors = be
+            bad = (be > self.condensed_tol) | ~torch.isfinite(be)
+            ok = not bool(bad.any()) and all(x["n_neg"] == me + mi and x["n_zero"] == 0 and not x["nonfinite"] for x in stats)
+            if not ok:
+                self.n_condensed_fallback += 1
+                self._ck(self.lib.pyipm_newton_set_option(self.h, b"condensed", 0.0))
+                try:
+                    self._ck(self.lib.pyipm_newton_step_batched(self.h, float(delta), float(delta_c), ptr(out), st, MEM_DEVICE))
+                finally:
+                    self._ck(self.lib.pyipm_newton_set_option(self.h, b"condensed", 1.0))
+                stats = [x.as_dict() for x in st]
+        return out, stats
+
+    def _opts_get(self, name):
+        return getattr(self, "_opts", {}).get(name, 0.0)
+
+    def backward_errors(self, dz):
+        """|g - Hc raw| / |g| per problem for the directions ``dz`` (B, N) of the last step, Hc from the staged blocks (device
+        tensor of B doubles)."""
+        torch = self.torch
+        be = torch.empty(self.batch, dtype=torch.float64, device=self.device)
+        self._ck(self.lib.pyipm_newton_backward_error_batched(self.h, c_void_p(dz.data_ptr()), c_void_p(be.data_ptr()), MEM_DEVICE))
+        return be
+
+    def last_ms(self):
+        """HIP-event times of the last step (ms): residual + assembly, factorisation, substitutions, the whole step."""
+        from ctypes import c_double
+        t = (c_double * 8)()
+        self._ck(self.lib.pyipm_newton_last_timings(self.h, t))
+        return {"assemble_ms": t[0], "factor_ms": t[6], "solve_ms": t[3], "step_ms": t[1]}
 
     def close(self):
         if getattr(self, "h", None):

@@ -25,6 +25,19 @@ struct BatchPtrs {
     unsigned long long* anorm;             // [2 B]: per problem, bits of max |assembled entry| (scale of a static pivot) and the "assembly pending" word (always 0 here)
 };
 
+// The condensed form of a batched step (round 5; the big path's option, DESIGN section 7b, per problem): inequalities with
+// Sigma_k = lda_k / (s_k + eps) <= sigma_max are eliminated analytically (their Ji Sigma Ji' joins the x-x block), the rest
+// -- the constraints going active late in a run -- stay as rows with -1 / Sigma_k on the diagonal.  Per problem the system
+// has n + me + |A| rows in the order [x | lambda_e | lambda_A]; |A| differs from problem to problem, so every kernel reads it
+// from `cnt` and sizes its own loops (one workgroup per problem: nothing else has to agree).
+struct BatchCond {
+    int* pos;            // [B][mi]: index inside A, or -1
+    int* idx;            // [B][mi]: members of A
+    int* cnt;            // [B]: |A|
+    int64_t sP;          // stride of pos / idx (>= mi)
+    double sigma_max;
+};
+
 // K1 for the batch: grid (Npad/512, Npad/16, B)
 __global__ __launch_bounds__(256) void k_b_assemble(BatchPtrs bp, Geo g, double eps, double delta, double delta_c)
 {
@@ -84,6 +97,200 @@ __global__ __launch_bounds__(256) void k_b_residual(BatchPtrs bp, Geo g, double 
     }
 }
 
+// Condensed form, step 1 (grid B, 256 threads): the active set of problem b, its full right-hand side g = -grad (bp.rhs: the
+// expansion and the backward-error check read it) and the condensed one (bp.sol, solved in place):
+//   vc = [ g_x + Ji_I (Sigma_I g_i + g_s)_I ; g_e ; (g_i + g_s / Sigma)_A ; 0 ... ]
+__global__ __launch_bounds__(256) void k_bc_prep(BatchPtrs bp, Geo g, double mu, double eps, BatchCond bc)
+{
+    __shared__ int part[256];
+    __shared__ double tsh[512];                         // (mi <= 511: n + 2 mi + me <= 1024)
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n = g.n, me = g.me, mi = g.mi;
+    const double* lda = bp.lda + b * (me + mi);
+    const double* s = bp.s + b * mi;
+    int* pos = bc.pos + b * bc.sP;
+    int* idx = bc.idx + b * bc.sP;
+    double* out = bp.rhs + b * bp.sV;
+    double* vc = bp.sol + b * bp.sV;
+    // active set: an exclusive scan over 256 chunks
+    const int64_t per = (mi + 255) / 256, k0 = tid * per;
+    int64_t k1 = k0 + per; if (k1 > mi) k1 = mi;
+    int c = 0;
+    for (int64_t k = k0; k < k1; ++k) c += (lda[me + k] / (s[k] + eps) > bc.sigma_max) ? 1 : 0;
+    part[tid] = c;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int at = part[tid] - c;
+    for (int64_t k = k0; k < k1; ++k) {
+        if (lda[me + k] / (s[k] + eps) > bc.sigma_max) { pos[k] = at; idx[at] = (int)k; ++at; }
+        else pos[k] = -1;
+    }
+    const int na = part[255];
+    if (tid == 0) bc.cnt[b] = na;
+    __syncthreads();
+    for (int64_t k = tid; k < mi; k += 256) {
+        const double sg = lda[me + k] / (s[k] + eps);
+        const double gs = -(lda[me + k] - mu / (s[k] + eps)), gi = -(bp.ci[b * mi + k] - s[k]);
+        out[n + k] = gs; out[n + mi + me + k] = gi;
+        if (pos[k] < 0) tsh[k] = sg * gi + gs;
+        else { tsh[k] = 0.0; vc[n + me + pos[k]] = gi + gs * (s[k] + eps) / lda[me + k]; }
+    }
+    for (int64_t a = tid; a < me; a += 256) { const double v = -bp.ce[b * me + a]; out[n + mi + a] = v; vc[n + a] = v; }
+    for (int64_t i = g.N + tid; i < g.Npad; i += 256) out[i] = 0.0;
+    for (int64_t i = n + me + na + tid; i < g.Npad; i += 256) vc[i] = 0.0;
+    __syncthreads();
+    for (int64_t j = wave; j < n; j += 4) {
+        double acc = 0.0, acct = 0.0;
+        if (me) { const double* r = bp.Je + b * bp.sJe + j * bp.ldje; for (int64_t a = lane; a < me; a += 64) acc += r[a] * lda[a]; }
+        if (mi) {
+            const double* r = bp.Ji + b * bp.sJi + j * bp.ldji;
+            for (int64_t a = lane; a < mi; a += 64) { const double v = r[a]; acc += v * lda[me + a]; acct += v * tsh[a]; }
+        }
+        acc = wave_sum(acc); acct = wave_sum(acct);
+        if (lane == 0) { const double gx = -(bp.df[b * n + j] - acc); out[j] = gx; vc[j] = gx + acct; }
+    }
+}
+
+// Condensed form, step 2: the matrix  [[H + delta I + Ji_I Sigma_I Ji_I', Je, Ji_A], [Je', -delta_c I, 0], [Ji_A', 0, -1/Sigma_A]]
+// (lower triangle, identity pad up to the next multiple of 64) of problem blockIdx.y, one 64 x 64 tile per workgroup
+// (blockIdx.x enumerates the lower-triangular tile pairs of the LARGEST possible system; tiles beyond this problem's return).
+// The Gram part of an x-x tile is formed on the matrix pipe: both operand tiles of a 64-column chunk of Ji staged through
+// shared memory (coalesced along the rows of the row-major Ji), the Sigma scaling applied to one of them on the way.
+__global__ __launch_bounds__(256) void k_bc_assemble(BatchPtrs bp, Geo g, double eps, double delta, double delta_c, BatchCond bc)
+{
+    __shared__ double XA[TB][TB + 2];
+    __shared__ double XB[TB][TB + 2];
+    const int64_t b = blockIdx.y;
+    int rt = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+    while (rt * (rt + 1) / 2 > (int)blockIdx.x) --rt;
+    while ((rt + 1) * (rt + 2) / 2 <= (int)blockIdx.x) ++rt;
+    const int ct = (int)blockIdx.x - rt * (rt + 1) / 2;
+    const int64_t n = g.n, me = g.me, mi = g.mi, ld = g.Npad;
+    const int na = bc.cnt[b];
+    const int64_t nc = n + me + na;
+    if ((int64_t)rt * TB >= nc) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    double* A = bp.A + b * bp.sA;
+    const double* d2L = bp.d2L + b * bp.sH;
+    const double* Je = bp.Je ? bp.Je + b * bp.sJe : nullptr;
+    const double* Ji = bp.Ji ? bp.Ji + b * bp.sJi : nullptr;
+    const double* s = bp.s + b * mi;
+    const double* lda = bp.lda + b * (me + mi);
+    const int* pos = bc.pos + b * bc.sP;
+    const int* idx = bc.idx + b * bc.sP;
+    const int64_t i0 = (int64_t)rt * TB, j0 = (int64_t)ct * TB;
+    double4_t acc[4];
+    #pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    if (j0 < n && i0 < n && mi > 0) {
+        for (int64_t kc = 0; kc < mi; kc += TB) {
+            if (kc > 0) __syncthreads();
+            double va[TB * TB / 256], vb[TB * TB / 256];
+            #pragma unroll
+            for (int q = 0; q < TB * TB / 256; ++q) {
+                const int e = tid + 256 * q, r = e >> 6, k = e & 63;
+                const bool kin = kc + k < mi;
+                va[q] = (kin && j0 + r < n) ? Ji[(j0 + r) * bp.ldji + kc + k] : 0.0;
+                const double sg = (kin && pos[kc + k] < 0) ? lda[me + kc + k] / (s[kc + k] + eps) : 0.0;
+                vb[q] = (kin && i0 + r < n) ? sg * Ji[(i0 + r) * bp.ldji + kc + k] : 0.0;
+            }
+            #pragma unroll
+            for (int q = 0; q < TB * TB / 256; ++q) {
+                const int e = tid + 256 * q;
+                XA[e >> 6][e & 63] = va[q]; XB[e >> 6][e & 63] = vb[q];
+            }
+            __syncthreads();
+            #pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const double bop = XB[wave * 16 + l15][ks * 4 + l4];
+                #pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(XA[t * 16 + l15][ks * 4 + l4], bop, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    const int64_t i = i0 + wave * 16 + l15;
+    double amax = 0.0;
+    #pragma unroll
+    for (int t = 0; t < 4; ++t)
+        #pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t c = j0 + t * 16 + l4 + 4 * r;
+            if (i < c) continue;
+            double v = 0.0;
+            bool scale = true;
+            if (c < n) {
+                if (i < n)            v = d2L[c * bp.ldh + i] + (i == c ? delta : 0.0) + acc[t][r];
+                else if (i < n + me)  v = Je[c * bp.ldje + (i - n)];
+                else if (i < nc)      v = Ji[c * bp.ldji + idx[i - n - me]];
+            } else if (i == c) {
+                if (c < n + me)       v = -delta_c;
+                else if (c < nc)      { const int k = idx[c - n - me]; v = -(s[k] + eps) / lda[me + k]; scale = false; }
+                else                  v = 1.0;
+            }
+            A[i + c * ld] = v;
+            if (scale) amax = fmax(amax, fabs(v));      // (1 / Sigma stays out of the static-pivot scale, as Sigma does in the full form)
+        }
+    anorm_publish(bp.anorm + 2 * b, amax);
+}
+
+// Backward error of a batch of directions against the KKT blocks (never the factor): out[b] = |g - Hc raw| / |g| with raw the
+// direction with the multiplier flip undone, Hc the full 4-block matrix with the shifts of the last step.  grid B, 256
+// threads; g = -grad must be in bp.rhs (every batched step leaves it there).  The guard of the condensed form, and a check
+// any caller can afford: O(N^2) per problem.
+__global__ __launch_bounds__(256) void k_b_berr(BatchPtrs bp, Geo g, const double* __restrict__ dz, double eps, double delta,
+                                                double delta_c, double* __restrict__ out)
+{
+    __shared__ double red[2][4];
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n = g.n, me = g.me, mi = g.mi;
+    const double* d = dz + b * g.N;
+    const double* gr = bp.rhs + b * bp.sV;
+    const double* d2L = bp.d2L + b * bp.sH;
+    const double* s = bp.s + b * mi;
+    const double* lda = bp.lda + b * (me + mi);
+    const double* dx = d; const double* ds = d + n; const double* dle = d + n + mi; const double* dli = d + n + mi + me;   // (flipped)
+    double rr = 0.0, gg = 0.0;
+    for (int64_t j = wave; j < n; j += 4) {                  // x rows: sym(triu(d2L)) dx + delta dx + Je dle + Ji dli
+        double acc = 0.0;
+        for (int64_t i = lane; i < n; i += 64) acc += (i >= j ? d2L[j * bp.ldh + i] : d2L[i * bp.ldh + j]) * dx[i];
+        if (me) { const double* r = bp.Je + b * bp.sJe + j * bp.ldje; for (int64_t a = lane; a < me; a += 64) acc -= r[a] * dle[a]; }
+        if (mi) { const double* r = bp.Ji + b * bp.sJi + j * bp.ldji; for (int64_t a = lane; a < mi; a += 64) acc -= r[a] * dli[a]; }
+        acc = wave_sum(acc);
+        if (lane == 0) { const double r = gr[j] - (acc + delta * dx[j]); rr += r * r; gg += gr[j] * gr[j]; }
+    }
+    for (int64_t k = tid; k < mi; k += 256) {                // s rows and lambda_i rows
+        double u = 0.0;
+        const double* col = bp.Ji + b * bp.sJi + k;
+        for (int64_t j = 0; j < n; ++j) u += col[j * bp.ldji] * dx[j];
+        const double r1 = gr[n + k] - (lda[me + k] / (s[k] + eps) * ds[k] + dli[k]);
+        const double r2 = gr[n + mi + me + k] - (u - ds[k]);
+        rr += r1 * r1 + r2 * r2; gg += gr[n + k] * gr[n + k] + gr[n + mi + me + k] * gr[n + mi + me + k];
+    }
+    for (int64_t a = tid; a < me; a += 256) {                // lambda_e rows
+        double u = 0.0;
+        const double* col = bp.Je + b * bp.sJe + a;
+        for (int64_t j = 0; j < n; ++j) u += col[j * bp.ldje] * dx[j];
+        const double r = gr[n + mi + a] - (u + delta_c * dle[a]);
+        rr += r * r; gg += gr[n + mi + a] * gr[n + mi + a];
+    }
+    rr = wave_sum(rr); gg = wave_sum(gg);
+    if (lane == 0) { red[0][wave] = rr; red[1][wave] = gg; }
+    __syncthreads();
+    if (tid == 0) {
+        const double R = red[0][0] + red[0][1] + red[0][2] + red[0][3], G = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        out[b] = G > 0.0 ? sqrt(R / G) : sqrt(R);
+    }
+}
+
 // Can rows [lo, hi) hold a non-zero of the L / W operand whose source columns are [slo, shi)?  The block pattern
 // of pyipm.py:824-842 (same argument as active_ranges in pyipm_newton.hip): x-block sources never reach the
 // slack rows, slack-block sources only their own lambda_i rows.  Conservative at tile granularity.
@@ -111,11 +318,20 @@ __device__ __noinline__ void b_tile_invert(TileScratch& sm, const double* A, int
 
 // Factor one problem per workgroup.  grid B, 256 threads.
 constexpr int B_RT = 2;                   // row tiles per left-looking pass (their accumulators: 32 registers each per lane)
-__global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double refine_cond, int nref, double pivtol_rel, int blocked)
+__global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double refine_cond, int nref, double pivtol_rel, int blocked,
+                                                  const int* __restrict__ cond_cnt)      // != NULL: the condensed system of each problem
 {
     __shared__ TileScratch sm;
     __shared__ double X[TB][TB + 2];
     const int64_t bi = blockIdx.x, ld = g.Npad;
+    const Geo gfull = g;
+    int cond_na = 0;
+    if (cond_cnt) {
+        // condensed form: [x | lambda_e | lambda_A] of this problem, n + me + |A| rows padded to whole tiles inside the same
+        // storage (leading dimension unchanged); no slack block, so no structural zeros to skip
+        cond_na = cond_cnt[bi];
+        g.me = gfull.me + cond_na; g.mi = 0; g.N = gfull.n + g.me; g.Npad = (g.N + TB - 1) / TB * TB;
+    }
     double* A = bp.A + bi * bp.sA;
     double* Tinv = bp.Tinv + bi * bp.sT;
     double* Tsave = bp.Tsave + bi * bp.sT;
@@ -270,10 +486,17 @@ __global__ __launch_bounds__(256) void k_b_factor(BatchPtrs bp, Geo g, double re
     }
     gmax = wave_max(gmax);
     if (lane == 0) atomicMax(&st->growth_bits, (unsigned long long)__double_as_longlong(gmax));
+    // inertia of the FULL matrix: every eliminated (s_k, lambda_i_k) pair [[Sigma_k, -1], [-1, 0]] has one positive and one
+    // negative eigenvalue; an active row kept in the system already counted its negative one, its eliminated Sigma_k is the
+    // positive one (as the big path's factor_dispatch adds them)
+    if (cond_cnt && tid == 0) { st->n_neg += gfull.mi - cond_na; st->n_pos += gfull.mi; }
 }
 
 // Substitutions + sign flip for one problem per workgroup.  grid B, block Npad (<= 1024), LDS 2*Npad doubles.
-__global__ void k_b_solve(BatchPtrs bp, Geo g, int nref, int flip, double* __restrict__ dz)
+// cond != 0: the condensed system (k_bc_prep / k_bc_assemble): the right-hand side is the reduced one in bp.sol, the sweeps
+// run over this problem's n + me + |A| rows, and the full direction is recovered from the condensed solution:
+//   I: ds = Ji' dx - g_i , dli = Sigma ds - g_s ;   A: dli from the solve, ds = (dli + g_s) / Sigma.
+__global__ void k_b_solve(BatchPtrs bp, Geo g, int nref, int flip, double* __restrict__ dz, BatchCond bc, int cond, double eps)
 {
     extern __shared__ double lds[];
     double* y = lds;
@@ -281,12 +504,15 @@ __global__ void k_b_solve(BatchPtrs bp, Geo g, int nref, int flip, double* __res
     const int64_t bi = blockIdx.x, ld = g.Npad;
     const double* A = bp.A + bi * bp.sA;
     const int tid = threadIdx.x, lane = tid & 63, t = tid >> 6;
-    const int nt = (int)(g.Npad / TB);
-    const double y0 = bp.rhs[bi * bp.sV + tid];
+    const int na = cond ? bc.cnt[bi] : 0;
+    const int64_t nrows = cond ? (g.n + g.me + na + TB - 1) / TB * TB : g.Npad;      // rows that take part in the sweeps
+    const int nt = (int)(nrows / TB);
+    const bool act = tid < nrows;
+    const double y0 = (cond ? bp.sol : bp.rhs)[bi * bp.sV + tid];
     y[tid] = y0;
     for (int u = 0; u + 1 < nt; ++u) {                       // forward (unit block lower triangular)
         __syncthreads();
-        if (tid >= (u + 1) * TB) {
+        if (act && tid >= (u + 1) * TB) {
             const double* col = A + tid + ((int64_t)u * TB) * ld;
             double acc = 0.0;
             #pragma unroll 8
@@ -298,11 +524,13 @@ __global__ void k_b_solve(BatchPtrs bp, Geo g, int nref, int flip, double* __res
     // block diagonal: z = inv(T) y, refined against T for flagged tiles (uniform trip count for the barriers)
     const double* Xi = bp.Tinv + bi * bp.sT + (int64_t)t * TB * TB;
     const double* Tt = bp.Tsave + bi * bp.sT + (int64_t)t * TB * TB;
-    const bool flagged = bp.Tflag[bi * bp.sF + t] != 0.0;
+    const bool flagged = act && bp.Tflag[bi * bp.sF + t] != 0.0;
     const double yt = y[tid];
     double z = 0.0;
-    #pragma unroll 8
-    for (int j = 0; j < TB; ++j) z = fma(Xi[j * TB + lane], y[t * TB + j], z);
+    if (act) {
+        #pragma unroll 8
+        for (int j = 0; j < TB; ++j) z = fma(Xi[j * TB + lane], y[t * TB + j], z);
+    }
     for (int it = 0; it < nref; ++it) {
         w[tid] = z;
         __syncthreads();
@@ -333,7 +561,32 @@ __global__ void k_b_solve(BatchPtrs bp, Geo g, int nref, int flip, double* __res
         }
     }
     __syncthreads();
-    const double x = y[tid];
+    double x = y[tid];
+    if (cond) {
+        // expand: w <- [dx ; ds ; dle ; dli] from the condensed solution y and the full right-hand side (bp.rhs)
+        const int64_t n = g.n, me = g.me, mi = g.mi;
+        const double* gr = bp.rhs + bi * bp.sV;
+        const int* pos = bc.pos + bi * bc.sP;
+        w[tid] = 0.0;
+        __syncthreads();
+        if (tid < n) w[tid] = y[tid];
+        if (tid < me) w[n + mi + tid] = y[n + tid];
+        if (tid < mi) {
+            const int64_t k = tid;
+            const double* col = bp.Ji + bi * bp.sJi + k;
+            double u = 0.0;
+            #pragma unroll 4
+            for (int64_t j = 0; j < n; ++j) u = fma(col[j * bp.ldji], y[j], u);
+            const double bs = gr[n + k], b_i = gr[n + mi + me + k];
+            const double sg = bp.lda[bi * (me + mi) + me + k] / (bp.s[bi * mi + k] + eps);
+            double ds, dl;
+            if (pos[k] < 0) { ds = u - b_i; dl = sg * ds - bs; }
+            else            { dl = y[n + me + pos[k]]; ds = (dl + bs) / sg; }
+            w[n + k] = ds; w[n + mi + me + k] = dl;
+        }
+        __syncthreads();
+        x = w[tid];
+    }
     bp.sol[bi * bp.sV + tid] = x;
     if (tid < g.N) dz[bi * g.N + tid] = (flip && tid >= g.n + g.mi) ? -x : x;
 }

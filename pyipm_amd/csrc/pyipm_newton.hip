@@ -110,7 +110,13 @@ size_t carve_batched(Ctx* c, const Geo& g, int64_t B, char* base) {
     const size_t ol = cv.take((size_t)B * (g.me + g.mi + 1) * D);
     const size_t ost = cv.take((size_t)B * sizeof(DevStats));
     const size_t oan = cv.take((size_t)B * 2 * sizeof(unsigned long long));
+    // condensed form (set_option("condensed", 1)): per problem the active set -- position, members, count -- and the backward errors
+    const size_t ocp = cv.take((size_t)B * (size_t)(2 * g.mi + 2) * sizeof(int) + (size_t)B * sizeof(int));
+    const size_t obe = cv.take((size_t)B * sizeof(double));
     if (base) {
+        c->cond_pos = (int*)(base + ocp); c->cond_idx = c->cond_pos + (size_t)B * (size_t)(g.mi + 1);
+        c->cond_cnt = c->cond_idx + (size_t)B * (size_t)(g.mi + 1);
+        c->vt = (double*)(base + obe);
         c->anorm = (unsigned long long*)(base + oan);
         c->A = (double*)(base + oA); c->Dinv = (double*)(base + oD); c->Tsv = (double*)(base + oT);
         c->Tflag = (double*)(base + oTf); c->rhs = (double*)(base + orhs); c->v0 = (double*)(base + ov0);
@@ -136,6 +142,13 @@ BatchPtrs batch_ptrs(Ctx* ctx) {
     bp.df = ctx->df; bp.ce = ctx->ce; bp.ci = ctx->ci; bp.s = ctx->s; bp.lda = ctx->lda;
     bp.anorm = ctx->anorm;
     return bp;
+}
+
+BatchCond batch_cond(Ctx* ctx) {
+    BatchCond bc;
+    bc.pos = ctx->cond_pos; bc.idx = ctx->cond_idx; bc.cnt = ctx->cond_cnt; bc.sP = ctx->g.mi + 1;
+    bc.sigma_max = ctx->cond_sigma_max;
+    return bc;
 }
 
 int check_ctx(pyipm_newton_ctx* h) { return h ? 0 : PYIPM_E_BADARG; }
@@ -1790,22 +1803,40 @@ int pyipm_newton_step_batched(pyipm_newton_ctx* h, double delta, double delta_c,
     if (!dz) { ctx->err = "step_batched: null output"; return PYIPM_E_BADARG; }
     const int B = ctx->batch;
     BatchPtrs bp = batch_ptrs(ctx);
+    BatchCond bc = batch_cond(ctx);
+    const int cond = (ctx->condensed && g.mi > 0) ? 1 : 0;
+    ctx->delta = delta; ctx->delta_c = delta_c;
+    ctx->cond_active = cond != 0;
     PYIPM_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(k_b_residual, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->mu, ctx->eps);
-    PYIPM_KCHECK();
-    {
-        PYIPM_HIP(hipMemsetAsync(ctx->anorm, 0, (size_t)B * 2 * sizeof(unsigned long long), ctx->stream));
+    PYIPM_HIP(hipMemsetAsync(ctx->anorm, 0, (size_t)B * 2 * sizeof(unsigned long long), ctx->stream));
+    if (cond) {
+        // condensed form: per problem n + me + |A| columns instead of n + 2 mi + me (config 5: 256 instead of 768) -- the
+        // (s, lambda_i) pairs with Sigma <= condensed_sigma_max eliminated analytically (pyipm.py:824-842's block structure)
+        hipLaunchKernelGGL(k_bc_prep, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->mu, ctx->eps, bc);
+        PYIPM_KCHECK();
+        const int64_t ntmax = (g.n + g.me + g.mi + TB - 1) / TB;
+        hipLaunchKernelGGL(k_bc_assemble, dim3((unsigned)(ntmax * (ntmax + 1) / 2), (unsigned)B), dim3(256), 0, ctx->stream, bp, g,
+                           ctx->eps, delta, delta_c, bc);
+        PYIPM_KCHECK();
+    } else {
+        hipLaunchKernelGGL(k_b_residual, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->mu, ctx->eps);
+        PYIPM_KCHECK();
         dim3 grid((unsigned)((g.Npad + 511) / 512), (unsigned)((g.Npad + 15) / 16), (unsigned)B);
         hipLaunchKernelGGL(k_b_assemble, grid, dim3(256), 0, ctx->stream, bp, g, ctx->eps, delta, delta_c);
         PYIPM_KCHECK();
     }
-    hipLaunchKernelGGL(k_b_factor, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->refine_cond, ctx->block_refine, ctx->pivtol_rel, ctx->tile_blocked);
+    PYIPM_HIP(hipEventRecord(ctx->ev[2], ctx->stream));
+    hipLaunchKernelGGL(k_b_factor, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->refine_cond, ctx->block_refine, ctx->pivtol_rel, ctx->tile_blocked,
+                       cond ? (const int*)ctx->cond_cnt : (const int*)nullptr);
     PYIPM_KCHECK();
+    PYIPM_HIP(hipEventRecord(ctx->ev[3], ctx->stream));
     double* out_dev = (memkind == PYIPM_MEM_DEVICE) ? dz : ctx->v2;
     hipLaunchKernelGGL(k_b_solve, dim3(B), dim3((unsigned)g.Npad), 2 * g.Npad * sizeof(double), ctx->stream, bp, g,
-                       ctx->block_refine, (g.me + g.mi) > 0 ? 1 : 0, out_dev);
+                       ctx->block_refine, (g.me + g.mi) > 0 ? 1 : 0, out_dev, bc, cond, ctx->eps);
     PYIPM_KCHECK();
     PYIPM_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+    ctx->have_rhs = true;                 // g = -grad of every problem is in rhs (backward_error_batched reads it)
+    ctx->ev_assemble_valid = true;
     if (memkind == PYIPM_MEM_HOST)
         PYIPM_HIP(hipMemcpyAsync(dz, ctx->v2, (size_t)B * g.N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     int rc = PYIPM_OK;
@@ -1827,6 +1858,24 @@ int pyipm_newton_step_batched(pyipm_newton_ctx* h, double delta, double delta_c,
         PYIPM_HIP(hipStreamSynchronize(ctx->stream));
     }
     return rc;
+} PYIPM_CATCH_H(h)
+
+// out[b] = |g - Hc raw_b| / |g| of every problem of the last step_batched, Hc applied from the blocks (k_b_berr)
+int pyipm_newton_backward_error_batched(pyipm_newton_ctx* h, const double* dz, double* out, int memkind) try {
+    if (check_ctx(h) || !dz || !out) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h); const Geo& g = ctx->g;
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    if (!ctx->batched) { ctx->err = "backward_error_batched: not a batched handle"; return PYIPM_E_BADARG; }
+    if (!ctx->have_blocks || !ctx->have_vectors || !ctx->have_rhs) { ctx->err = "backward_error_batched: step_batched first"; return PYIPM_E_BADARG; }
+    BatchPtrs bp = batch_ptrs(ctx);
+    double* dev = (memkind == PYIPM_MEM_DEVICE) ? out : ctx->vt;
+    hipLaunchKernelGGL(k_b_berr, dim3(ctx->batch), dim3(256), 0, ctx->stream, bp, g, dz, ctx->eps, ctx->delta, ctx->delta_c, dev);
+    PYIPM_KCHECK();
+    if (memkind == PYIPM_MEM_HOST) {
+        PYIPM_HIP(hipMemcpyAsync(out, ctx->vt, (size_t)ctx->batch * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PYIPM_OK;
 } PYIPM_CATCH_H(h)
 
 int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
@@ -1858,7 +1907,7 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     for (auto& a : ctx->tl_arenas) { if (a.dev) hipFree(a.dev); if (a.host) hipHostFree(a.host); }
     if (ctx->JT) hipFree(ctx->JT);
     if (ctx->Jx) hipFree(ctx->Jx);
-    if (ctx->cond_pos) hipFree(ctx->cond_pos);
+    if (ctx->cond_pos && !ctx->batched) hipFree(ctx->cond_pos);      // (a batched handle's lives in its workspace)
     if (ctx->head_counters) hipFree(ctx->head_counters);
     if (ctx->sweep_sync) hipFree(ctx->sweep_sync);
     if (ctx->sweep_buf) hipFree(ctx->sweep_buf);
@@ -2259,16 +2308,16 @@ int pyipm_newton_step(pyipm_newton_ctx* h, double delta, double delta_c, int ref
     return solve_finish(ctx, dz, 1, refine, memkind, fuse && ctx->forward_fused);
 } PYIPM_CATCH_H(h)
 
-int pyipm_newton_step_lengths(pyipm_newton_ctx* h, double tau, double* alpha_s, double* alpha_l) try {
+int pyipm_newton_step_lengths(pyipm_newton_ctx* h, double tau, const double* dz_in, double* alpha_s, double* alpha_l) try {
     if (check_ctx(h) || !alpha_s || !alpha_l) return PYIPM_E_BADARG;
     Ctx* ctx = C(h); const Geo& g = ctx->g;
     if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     *alpha_s = 1.0; *alpha_l = 1.0;
     if (g.mi == 0) return PYIPM_OK;
-    if (!ctx->have_vectors || !ctx->have_direction) { ctx->err = "step_lengths: stage vectors and solve first"; return PYIPM_E_BADARG; }
+    if (!ctx->have_vectors || (!dz_in && !ctx->have_direction)) { ctx->err = "step_lengths: stage vectors and solve first (or pass dz)"; return PYIPM_E_BADARG; }
     // v2 holds the last direction in the reference's order with the multiplier block already sign-flipped
-    const double* dz = ctx->v2;
+    const double* dz = dz_in ? dz_in : ctx->v2;
     hipLaunchKernelGGL(k_step_lengths, dim3(1), dim3(256), 0, ctx->stream, ctx->partial, ctx->s, ctx->lda + g.me,
                        dz + g.n, dz + g.n + g.mi + g.me, g.mi, tau);
     PYIPM_KCHECK();
@@ -2558,6 +2607,16 @@ int pyipm_newton_last_timings(pyipm_newton_ctx* h, double out[8]) try {
     Ctx* ctx = C(h);
     PYIPM_HIP(hipSetDevice(ctx->device));
     PYIPM_HIP(hipStreamSynchronize(ctx->stream));          // timers are resolved lazily, never inside a step
+    if (ctx->batched) {                                    // step_batched: [0] residual + assembly, [6] factorisation, [3] substitutions, [1] whole step
+        for (int k = 0; k < 8; ++k) out[k] = 0.0;
+        if (ctx->ev_assemble_valid) {
+            float a = 0.f, f = 0.f, sv = 0.f, all = 0.f;
+            PYIPM_HIP(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[2])); PYIPM_HIP(hipEventElapsedTime(&f, ctx->ev[2], ctx->ev[3]));
+            PYIPM_HIP(hipEventElapsedTime(&sv, ctx->ev[3], ctx->ev[1])); PYIPM_HIP(hipEventElapsedTime(&all, ctx->ev[0], ctx->ev[1]));
+            out[0] = a; out[6] = f; out[3] = sv; out[1] = all;
+        }
+        return PYIPM_OK;
+    }
     if (ctx->ev_assemble_valid) { float ms = 0.f; PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->t_assemble = ms; }
     if (ctx->ev_solve_valid) { float ms = 0.f; PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->t_solve = ms; }
     out[0] = ctx->t_assemble; out[1] = ctx->t_panel; out[2] = ctx->t_trailing; out[3] = ctx->t_solve;

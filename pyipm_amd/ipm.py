@@ -49,7 +49,16 @@ def pinv_apply(J, g):
                     return J.T @ scipy.linalg.cho_solve(cf, r, check_finite=False)
                 return scipy.linalg.cho_solve(cf, J.T @ r, check_finite=False)
             lam = apply(g)
-            return lam + apply(g - J @ lam)
+            lam = lam + apply(g - J @ lam)
+            # the spread of an unpivoted Cholesky diagonal does not bound cond(J J'): accept the vector only if it satisfies
+            # the normal equations -- J lam = g for a wide J, J'(g - J lam) = 0 for a tall one -- to working precision
+            # (ADVICE r4); anything else takes the SVD, whose rcond cutoff is what the reference's pinv applies
+            r = g - J @ lam
+            if not wide:
+                r = J.T @ r
+            scale = np.linalg.norm(g) if wide else np.linalg.norm(J) * np.linalg.norm(g)      # (Frobenius: no SVD)
+            if np.isfinite(lam).all() and np.linalg.norm(r) <= 1.0e-11 * max(scale, np.finfo(float).tiny):
+                return lam
     except (np.linalg.LinAlgError, ValueError):
         pass
     return np.linalg.pinv(J) @ g
@@ -177,6 +186,7 @@ class HipNewtonBackend(object):
         formed g = -grad in the handle (``core.residual()``, passed as ``g``) -- nothing is staged again here."""
         core, need = self.core, self.me + self.mi
         self.n_calls += 1
+        self._dir_override = None          # set when the direction returned is NOT the handle's last solve (see step_lengths)
         if not staged:
             core.stage_blocks(d2L, Je, Ji)
             core.stage_vectors(df, ce, ci, s, lda, mu=mu, eps=eps)
@@ -255,28 +265,34 @@ class HipNewtonBackend(object):
                 delta *= 10.0
             dz, converged = self._solve(st)
             stalled, prev_be = 0, None
+            solved = True                  # the loop head looks at a solve that really happened (not at an inertia retry)
             while not converged:
                 # still no direction that satisfies the blocks: the shift has not made the factor trustworthy yet.
                 # Larger shift (the reference's delta *= 10 loop, :1399-1403); when the budget is spent, the best direction
                 # seen if it is at least berr_fallback-accurate (shifted or not), else give up loudly.
-                self.n_unconverged += 1
-                remember(dz, delta, st)
-                # ... or as soon as larger shifts have stopped helping: two tries in a row whose backward error did not fall
-                # tenfold with the tenfold shift, and a direction at berr_fallback in hand.  (Exactly dependent equality
-                # constraints: no shift of the x block cures the multiplier block; waiting for delta ~ 1 to dominate the
-                # system cost nine factorisations per iterate and returned a gradient-like step -- round 4.)
-                be = self.last_solve_info["backward_error"] if self.last_solve_info else -1.0
-                stalled = stalled + 1 if (prev_be is not None and be >= 0.0 and be >= 0.1 * prev_be) else 0
-                prev_be = be if be >= 0.0 else prev_be
-                if stalled >= 2 and best is not None and best[0] <= self.berr_fallback:
-                    self.n_inexact += 1
-                    dz, delta, st = best[1], best[2], best[3]
-                    break
+                if solved:
+                    self.n_unconverged += 1
+                    remember(dz, delta, st)
+                    # ... or as soon as larger shifts have stopped helping: two SOLVES in a row whose backward error did not
+                    # fall tenfold with the tenfold shift, and a direction at berr_fallback in hand.  (Exactly dependent
+                    # equality constraints: no shift of the x block cures the multiplier block; waiting for delta ~ 1 to
+                    # dominate the system cost nine factorisations per iterate and returned a gradient-like step -- round 4.)
+                    # A factorisation whose inertia was wrong produced no direction: it takes no part in this bookkeeping
+                    # (two inertia retries used to count as "larger shifts stopped helping").
+                    be = self.last_solve_info["backward_error"] if self.last_solve_info else -1.0
+                    stalled = stalled + 1 if (prev_be is not None and be >= 0.0 and be >= 0.1 * prev_be) else 0
+                    prev_be = be if be >= 0.0 else prev_be
+                    if stalled >= 2 and best is not None and best[0] <= self.berr_fallback:
+                        self.n_inexact += 1
+                        dz, delta, st = best[1], best[2], best[3]
+                        self._dir_override = dz
+                        break
                 tries += 1
                 if tries > self.max_shift_tries:
                     if best is not None and best[0] <= self.berr_fallback:
                         self.n_inexact += 1
                         dz, delta, st = best[1], best[2], best[3]
+                        self._dir_override = dz
                         break
                     raise RuntimeError("refined solve did not reach backward error %.1e after %d diagonal shifts (last: %s)"
                                        % (self.berr_tol, tries, self.last_solve_info))
@@ -284,19 +300,25 @@ class HipNewtonBackend(object):
                 core.assemble(delta, delta_c)
                 st = self._factor()
                 if st["n_neg"] != need or st["nonfinite"]:
-                    self.n_inertia_retries += 1
-                    self.n_unconverged -= 1          # (an inertia retry, not an unconverged solve: counted on its own)
+                    self.n_inertia_retries += 1      # (an inertia retry, not an unconverged solve: counted on its own)
+                    solved = False
                     continue
                 dz, converged = self._solve(st)
+                solved = True
         if not as_tensor:
             dz = dz.cpu().numpy()
         return dz, float(delta), st
 
+    _dir_override = None
+
     def step_lengths(self, tau):
-        """(alpha_smax, alpha_lmax) for the direction just returned, or None to let the host search."""
+        """(alpha_smax, alpha_lmax) for the direction just returned, or None to let the host search.  When direction() gave up
+        on shifting and returned an EARLIER, less shifted solve (n_inexact), the handle's last direction is another one: the
+        lengths are then taken for the direction actually returned (they used to come from the most shifted
+        solve, and s + a ds could leave the positive orthant)."""
         if not (self.device_step and self.mi):
             return None
-        return self.core.step_lengths(tau)
+        return self.core.step_lengths(tau, dz=self._dir_override)
 
 
 class HipLbfgsBackend(object):

@@ -83,7 +83,7 @@ def load_library(path: str | None = None):
         "pyipm_newton_rcond": (c_int, [ctxp, c_int, c_int, POINTER(c_double)]),
         "pyipm_newton_kkt_matvec": (c_int, [ctxp, c_void_p, c_void_p, c_int]),
         "pyipm_newton_step": (c_int, [ctxp, c_double, c_double, c_int, c_void_p, POINTER(FactorStats), c_int]),
-        "pyipm_newton_step_lengths": (c_int, [ctxp, c_double, POINTER(c_double), POINTER(c_double)]),
+        "pyipm_newton_step_lengths": (c_int, [ctxp, c_double, c_void_p, POINTER(c_double), POINTER(c_double)]),
         "pyipm_newton_merit_info": (c_int, [ctxp, c_void_p, POINTER(c_double)]),
         "pyipm_newton_dots": (c_int, [ctxp, c_int, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), POINTER(c_double)]),
         "pyipm_newton_merit_ray": (c_int, [ctxp, c_void_p, c_double, c_double, POINTER(c_double), POINTER(c_double), c_int,
@@ -110,6 +110,7 @@ def load_library(path: str | None = None):
         "pyipm_newton_stage_blocks_batched": (c_int, [ctxp, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64,
                                                       c_void_p, c_int64, c_int64]),
         "pyipm_newton_step_batched": (c_int, [ctxp, c_double, c_double, c_void_p, POINTER(FactorStats), c_int]),
+        "pyipm_newton_backward_error_batched": (c_int, [ctxp, c_void_p, c_void_p, c_int]),
         "pyipm_mfma_f64_peak": (c_int, [c_int, c_int, POINTER(c_double)]),
         "pyipm_newton_block_products": (c_int, [ctxp, c_void_p, c_void_p, c_void_p, c_void_p]),
         "pyipm_newton_block_products_t": (c_int, [ctxp, c_void_p, c_void_p, c_void_p]),
@@ -366,11 +367,13 @@ class NewtonCore(object):
         self._ck(rc, st.as_dict())
         return dz, st.as_dict()
 
-    def step_lengths(self, tau):
-        """Fraction-to-the-boundary step lengths (alpha_s, alpha_l) for the direction of the last solve."""
+    def step_lengths(self, tau, dz=None):
+        """Fraction-to-the-boundary step lengths (alpha_s, alpha_l) for the direction of the last solve, or for ``dz``
+        (device tensor, N doubles, multipliers sign-flipped) when the caller steps along another one."""
         self._use_current_stream()
         a_s, a_l = c_double(1.0), c_double(1.0)
-        self._ck(self.lib.pyipm_newton_step_lengths(self.h, float(tau), ctypes.byref(a_s), ctypes.byref(a_l)))
+        self._ck(self.lib.pyipm_newton_step_lengths(self.h, float(tau), self._ptr(dz) if dz is not None else None,
+                                                    ctypes.byref(a_s), ctypes.byref(a_l)))
         return a_s.value, a_l.value
 
     MERIT_KEYS = ("ce_l1", "cis_l1", "df_dx", "ds_over_s", "sum_log_s", "kkt_x", "kkt_s", "kkt_ce", "kkt_ci", "comp_sum",

@@ -223,8 +223,15 @@ class QPDeviceIPM(object):
         """Merit function (pyipm.py:670-721) at an ARBITRARY point: its vectors are staged (the staged point changes --
         search() restages its own before it goes on) and reduced by the library."""
         me, mi = self.neq, self.nineq
+        if not hasattr(self, "mu_host"):                     # (called before solve(): the initial barrier parameter)
+            self.mu_host, self.nu_host = (self.mu if mi else self.Ktol), self.nu
+        if lda is None:
+            # phi itself does not depend on lda; the staging does (comp_sum / kkt entries of merit_info): the multipliers of
+            # the point staged last when there is one, zeros before any point was staged (ADVICE r4)
+            lda = self._staged_keep[2] if self._staged_keep is not None else \
+                self.torch.zeros(me + mi, dtype=self.torch.float64, device=self.device)
         self.core.stage_vectors(self.df(x), self.ce(x) if me else None, self.ci(x) if mi else None, s if mi else None,
-                                self._staged_keep[2] if (me or mi) else None, mu=self.mu_host, eps=self.eps)
+                                lda if (me or mi) else None, mu=self.mu_host, eps=self.eps)
         self._staged_key = None
         q = self.core.merit_info()
         self.timings["n_phi"] += 1

@@ -136,3 +136,132 @@ def test_batched_indefinite_inertia_and_guards():
     with pytest.raises(NewtonError):
         BatchedNewton(600, 0, 300, batch=2)                      # N = 1200 > 1024: not a small system
     bn.close()
+
+
+# ---- condensed form of the batched handle (round 5) -----------------------------------------------------
+def _cond_shapes():
+    return [(3, 0, 9), (64, 0, 64), (65, 63, 1), (130, 40, 100), (200, 0, 400), (256, 0, 256), (500, 20, 250), (100, 30, 447)]
+
+
+@pytest.mark.parametrize("n,me,mi", _cond_shapes())
+def test_batched_condensed_vs_oracle_and_full_form(n, me, mi):
+    """set_option("condensed", 1) on a batched handle: n + me + |A| columns factored per problem, the full direction and the
+    inertia of the FULL matrix returned; against the oracle's LU, against the full form, and the device-side backward error
+    against a torch evaluation."""
+    import torch
+    from pyipm_amd.batched import BatchedNewton
+    B = 5
+    qps = [make_qp(n, me, mi, seed=900 + 7 * b + n) for b in range(B)]
+    opt = lambda key, on: _stack(qps, key) if on else None          # noqa: E731
+    args = (_stack(qps, "d2L"), opt("Je", me), opt("Ji", mi), _stack(qps, "df"), opt("ce", me), opt("ci", mi), opt("s", mi),
+            opt("lam", me + mi))
+    full = BatchedNewton(n, me, mi)
+    dz0, st0 = full.step_all(*args, mu=0.2)
+    cond = BatchedNewton(n, me, mi, condensed=True)
+    dz1, st1 = cond.step_all(*args, mu=0.2)
+    assert cond.n_condensed_fallback == 0
+    be = cond.last_backward_errors.cpu().numpy()
+    assert be.max() <= 1e-12
+    dz0, dz1 = dz0.cpu().numpy(), dz1.cpu().numpy()
+    N = n + 2 * mi + me
+    for b, q in enumerate(qps):
+        ref, _, Hc, g = orc.newton_step(q["d2L"], q["Je"], q["Ji"], q["df"], q["ce"], q["ci"], q["s"], q["lam"],
+                                        q["mu"], n, me, mi, regularise=False)
+        tol = max(1e-10, 20 * np.linalg.cond(Hc) * np.finfo(float).eps)
+        assert np.linalg.norm(dz1[b] - ref) / np.linalg.norm(ref) <= tol
+        assert np.linalg.norm(dz1[b] - dz0[b]) / np.linalg.norm(dz0[b]) <= tol
+        assert (st1[b]["n_neg"], st1[b]["n_pos"], st1[b]["n_zero"]) == (me + mi, N - me - mi, 0)
+        raw = dz1[b].copy(); raw[n + mi:] *= -1.0
+        assert abs(np.linalg.norm(Hc @ raw - g) / np.linalg.norm(g) - be[b]) <= 1e-13      # the device's own backward error
+    # the full form's directions through the same device check
+    assert float(full.backward_errors(torch.from_numpy(dz0).cuda()).max()) <= 1e-12
+    full.close(); cond.close()
+
+
+def test_config5_condensed_512_problems():
+    """BASELINE config 5 through the condensed form: 512 x (256, 0, 256) -> 256 columns factored per problem instead of 768;
+    every 32nd problem against the oracle, all of them through the backward error against the full blocks and the inertia
+    of the full matrix."""
+    import torch
+    from pyipm_amd.batched import BatchedNewton
+    n, me, mi, B = 256, 0, 256, 512
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    f64, dev = torch.float64, "cuda"
+    M = torch.randn(B, n, n, dtype=f64, device=dev, generator=gen)
+    Q = M @ M.transpose(1, 2) / n + torch.eye(n, dtype=f64, device=dev)
+    G = torch.randn(B, mi, n, dtype=f64, device=dev, generator=gen) / np.sqrt(n)
+    c = torch.randn(B, n, dtype=f64, device=dev, generator=gen)
+    s = torch.rand(B, mi, dtype=f64, device=dev, generator=gen) * 1.5 + 0.5
+    lam = torch.rand(B, mi, dtype=f64, device=dev, generator=gen) * 1.5 + 0.5
+    ci = s + 0.1 * torch.randn(B, mi, dtype=f64, device=dev, generator=gen)
+    Ji = G.transpose(1, 2).contiguous()
+    bn = BatchedNewton(n, me, mi, condensed=True)
+    dz, stats = bn.step_all(Q, None, Ji, c, None, ci, s, lam, mu=0.2)
+    assert bn.n_condensed_fallback == 0
+    assert all(st["n_neg"] == mi and st["n_pos"] == n + mi and st["n_zero"] == 0 for st in stats)
+    assert float(bn.last_backward_errors.max()) <= 1e-12
+    for b in range(0, B, 32):
+        ref, _, _, _ = orc.newton_step(Q[b].cpu().numpy(), None, Ji[b].cpu().numpy(), c[b].cpu().numpy(), None,
+                                       ci[b].cpu().numpy(), s[b].cpu().numpy(), lam[b].cpu().numpy(), 0.2, n, me, mi,
+                                       regularise=False)
+        assert np.linalg.norm(dz[b].cpu().numpy() - ref) / np.linalg.norm(ref) <= 1e-10
+    tm = bn.last_ms()
+    assert tm["step_ms"] > 0.0 and tm["factor_ms"] > 0.0
+    bn.close()
+
+
+@pytest.mark.parametrize("decades", [6, 12, 20])
+def test_batched_condensed_sigma_spread(decades):
+    """Late in an interior-point run Sigma = lda / s spans many decades: the pairs above condensed_sigma_max stay explicit rows
+    (another count in every problem of the batch), the direction still matches the oracle's LU of the FULL system."""
+    from pyipm_amd.batched import BatchedNewton
+    n, me, mi, B = 120, 20, 90, 6
+    rng = np.random.default_rng(decades)
+    qps = [make_qp(n, me, mi, seed=1200 + b) for b in range(B)]
+    for b, q in enumerate(qps):
+        k = rng.permutation(mi)[: 10 + 9 * b]                     # a different active set per problem
+        e = rng.uniform(-decades / 2.0, decades / 2.0, size=k.size)
+        q["s"][k] = 10.0 ** (-e / 2.0); q["lam"][me + k] = 10.0 ** (e / 2.0)
+    args = tuple(_stack(qps, key) for key in ("d2L", "Je", "Ji", "df", "ce", "ci", "s", "lam"))
+    bn = BatchedNewton(n, me, mi, condensed=True)
+    dz, st = bn.step_all(*args, mu=0.2)
+    dz = dz.cpu().numpy()
+    assert bn.n_condensed_fallback == 0
+    for b, q in enumerate(qps):
+        ref, _, Hc, _ = orc.newton_step(q["d2L"], q["Je"], q["Ji"], q["df"], q["ce"], q["ci"], q["s"], q["lam"],
+                                        q["mu"], n, me, mi, regularise=False)
+        tol = max(1e-10, 50 * np.linalg.cond(Hc) * np.finfo(float).eps)
+        assert np.linalg.norm(dz[b] - ref) / np.linalg.norm(ref) <= tol
+        assert st[b]["n_neg"] == me + mi and st[b]["n_zero"] == 0
+    bn.close()
+
+
+def test_batched_condensed_guard_falls_back():
+    """Non-convex members (indefinite d2L) in a condensed batch: whatever the condensed factor makes of them, what comes back
+    has the eigen-inertia of the full matrix and the oracle's direction -- through the condensed form when it passes the
+    device-side check, through the full form when it does not (n_condensed_fallback says which)."""
+    from pyipm_amd.batched import BatchedNewton
+    n, me, mi, B = 70, 10, 30, 8
+    rng = np.random.default_rng(11)
+    qps = [make_qp(n, me, mi, seed=1300 + b) for b in range(B)]
+    for b in range(0, B, 2):
+        M = rng.standard_normal((n, n))
+        qps[b]["d2L"] = (M + M.T) / 2
+    bn = BatchedNewton(n, me, mi, condensed=True)
+    dz, stats = bn.step_all(*[_stack(qps, k) for k in ("d2L", "Je", "Ji", "df", "ce", "ci", "s", "lam")], mu=0.2)
+    dz = dz.cpu().numpy()
+    for b, q in enumerate(qps):
+        H = orc.kkt_matrix(q["d2L"], q["Je"], q["Ji"], q["s"], q["lam"], n, me, mi)
+        assert stats[b]["n_neg"] == int((np.linalg.eigvalsh(H) < 0).sum())
+        ref, _, _, _ = orc.newton_step(q["d2L"], q["Je"], q["Ji"], q["df"], q["ce"], q["ci"], q["s"], q["lam"],
+                                       q["mu"], n, me, mi, regularise=False)
+        assert np.linalg.norm(dz[b] - ref) / np.linalg.norm(ref) <= 1e-8
+    # a bar nothing can meet: the guard must take the full form and still return the right directions
+    bn.condensed_tol = 0.0
+    before = bn.n_condensed_fallback
+    dz2, _ = bn.step_all(*[_stack(qps, k) for k in ("d2L", "Je", "Ji", "df", "ce", "ci", "s", "lam")], mu=0.2)
+    assert bn.n_condensed_fallback == before + 1
+    full = BatchedNewton(n, me, mi)
+    dz3, _ = full.step_all(*[_stack(qps, k) for k in ("d2L", "Je", "Ji", "df", "ce", "ci", "s", "lam")], mu=0.2)
+    assert np.array_equal(dz2.cpu().numpy(), dz3.cpu().numpy())
+    bn.close(); full.close()
