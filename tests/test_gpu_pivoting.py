@@ -245,6 +245,25 @@ def test_unconverged_refinement_takes_the_shift_branch():
     assert be3.n_inexact == 1 and be3.n_unconverged >= 3 and be3.n_inertia_retries == 0
     assert delta3 == 0.0 and relerr(dz3, d["dz"]) <= 1e-10         # the unshifted direction had the smallest backward error
 
+    # the direction returned above is NOT the handle's last solve (that one is the most shifted).  The fraction-to-
+    # the-boundary lengths of the device loop must belong to the direction actually returned.
+    be4 = HipNewtonBackend(n, me, mi, device=0, max_shift_tries=3, device_step=True)
+    be4.berr_tol = 0.0
+    be4._at_risk = lambda st: True
+    dz4, delta4, _ = _direction(be4, d, b)
+    assert be4.n_inexact == 1 and delta4 == 0.0 and be4._dir_override is not None
+    tau = 0.995
+
+    def closed_form(v, dv):
+        neg = dv < 0
+        return min(1.0, float((-tau * v[neg] / dv[neg]).min())) if neg.any() else 1.0
+
+    want = (closed_form(d["s"], dz4[n:n + mi]), closed_form(d["lda"][me:], dz4[n + mi + me:]))
+    got = be4.step_lengths(tau)
+    assert got == pytest.approx(want, rel=1e-14)
+    last = be4.core.step_lengths(tau)                              # ... the handle's own last solve: another direction
+    assert last != pytest.approx(want, rel=1e-6)
+
 
 # ---- static pivots where they hurt -- a whole LP solve of the reference, late iterates included ------
 def _lp_trace():
