@@ -269,6 +269,29 @@ int pyipm_newton_bwd_panel(pyipm_newton_ctx* ctx, int64_t p, double* v);
 typedef int (*pyipm_bcast_fn)(void* user, void* dev_buf, size_t bytes, int root, void* stream);
 typedef int (*pyipm_allreduce_fn)(void* user, double* dev_buf, size_t count, int op, void* stream);
 int pyipm_newton_set_exchange(pyipm_newton_ctx* ctx, pyipm_bcast_fn bcast, pyipm_allreduce_fn allreduce, void* user);
+/* The optional point-to-point half of variant 1 (round 5).  send / recv: `bytes` bytes at dev_buf to / from rank `peer`;
+ * allgather: every rank contributes bytes_per_rank bytes at send_buf, recv_buf receives the W pieces in rank order (send_buf
+ * may point into recv_buf at this rank's place: in place).  Same stream rule as above; `user` is set_exchange's.  With all
+ * three installed the library runs over the callbacks everything it runs over its own communicator: the scatter + all-gather
+ * form of the panel messages (after pyipm_newton_exchange_selftest has reproduced the plain broadcast with it) and the slice
+ * messages of the two-message protocol as point-to-point sends (without them a slice travels as a broadcast).  serialize != 0:
+ * the transport must not run two operations at once -- the library then issues every operation on its collective stream, one
+ * after the other, hopping from the stream that asked with a pair of events (what it does for RCCL). */
+typedef int (*pyipm_send_fn)(void* user, const void* dev_buf, size_t bytes, int peer, void* stream);
+typedef int (*pyipm_recv_fn)(void* user, void* dev_buf, size_t bytes, int peer, void* stream);
+typedef int (*pyipm_allgather_fn)(void* user, const void* send_buf, void* recv_buf, size_t bytes_per_rank, void* stream);
+int pyipm_newton_set_exchange_p2p(pyipm_newton_ctx* ctx, pyipm_send_fn send, pyipm_recv_fn recv, pyipm_allgather_fn allgather,
+                                  int serialize);
+/* COLLECTIVE (every rank or none): the self-test comm_init runs on a fresh communicator, on whichever exchange is installed.
+ * The ranks agree on whether every one of them wants and can run the scatter + all-gather form (three ranks or more, all
+ * primitives present, PYIPM_DIST_SAG != 0), reproduce the plain broadcast with it (two roots, a count that does not divide by
+ * the number of ranks), agree on the outcome, and switch the form on for all or for none (pyipm_newton_comm_bcast_mode). */
+int pyipm_newton_exchange_selftest(pyipm_newton_ctx* ctx);
+/* Wire accounting of the last factor_dist / step_dist on this rank: out[0] panel messages that travelled as a plain broadcast,
+ * [1] their bytes, [2] panel messages in the scatter + all-gather form, [3] their bytes, [4] point-to-point pieces sent or
+ * received, [5] all-gathers, [6] hops through the collective stream, [7] slice messages sent or received (two-message
+ * protocol), [8] their bytes, [9] slices that travelled as a broadcast, [10..11] 0. */
+int pyipm_newton_dist_wire(pyipm_newton_ctx* ctx, double out[12]);
 /* Exchange, variant 2 -- the handle owns an RCCL communicator over the `world` ranks it was created for.  Rank 0
  * obtains an id (128 bytes), it reaches the other ranks out of band (torch.distributed, MPI, a file), every rank calls
  * comm_init.  RCCL is dlopen'ed at that point (pyipm_newton_rccl_library names the library to bind: a process that has

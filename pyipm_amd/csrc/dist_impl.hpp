@@ -70,6 +70,10 @@ namespace pyipm {
 
 struct DistState {
     pyipm_bcast_fn bcast = nullptr; pyipm_allreduce_fn allreduce = nullptr; void* user = nullptr;
+    // the optional point-to-point half of a caller-supplied exchange (pyipm_newton_set_exchange_p2p): with all three the
+    // scatter + all-gather panel form, the slice messages of the two-message protocol and the self-test run over callbacks too
+    pyipm_send_fn send = nullptr; pyipm_recv_fn recv = nullptr; pyipm_allgather_fn allgather = nullptr;
+    int serialize = 0;                                 // callbacks: run every operation on the collective stream, one at a time (as for RCCL)
     ncclComm_t comm = nullptr;
     hipStream_t side = nullptr, cs = nullptr;          // owner's factor + pack stream (high priority); collectives
     hipStream_t fws = nullptr;                         // the forward substitution that trails the factorisation (step_dist)
@@ -90,6 +94,11 @@ struct DistState {
     std::vector<Span> spans;
     double t_chain = 0, t_pack = 0, t_bcast = 0, t_unpack = 0, t_factor = 0, t_solve = 0;
     size_t bytes_sent = 0; int64_t n_msgs = 0;
+    // wire accounting of the last factor_dist (pyipm_newton_dist_wire): [0] panel messages in the plain-broadcast form, [1] their
+    // bytes, [2] messages in the scatter + all-gather form, [3] their bytes, [4] point-to-point pieces this rank sent or received,
+    // [5] all-gathers, [6] hops through the collective stream, [7] slice messages (two-message protocol) this rank sent or
+    // received, [8] their bytes, [9] slice messages that travelled as a broadcast (no point-to-point transport)
+    double wire[12] = {};
 };
 
 }  // namespace pyipm
@@ -183,13 +192,27 @@ int dist_set_option(Ctx* ctx, const char* name, double value, bool* handled) {
 }
 
 // ---- exchange -----------------------------------------------------------------------------------------------------
-// With a communicator of its own the library keeps ALL its collectives on ONE stream (`cs`), in the order they are issued:
-// operations of one communicator on two streams may otherwise run concurrently, which RCCL does not promise to survive.  A
-// collective asked for on another stream hops over: that stream's work so far -> cs -> back.
+// ONE set of primitives over whichever transport the handle has: its own RCCL communicator (comm_init) or the caller's
+// callbacks (set_exchange [+ set_exchange_p2p]).  Everything above them -- the scatter + all-gather panel form, the slice
+// messages of the two-message protocol, the self-test that switches the panel form on -- is written once against these, so the
+// code the RCCL path runs on several GPUs is the code the callback path runs in the tests (round 5: until then sag_bcast, the
+// stream hop and the self-test had no execution of any kind on the one-GPU development pool).
+//
+// A transport that must not run two operations at the same time (one RCCL communicator; callbacks registered with
+// serialize != 0) gets ALL its operations on ONE stream (`cs`), in the order they are issued: an operation asked for on another
+// stream hops over -- that stream's work so far -> cs -> back.
+inline bool tr_serial(const DistState* D) { return D->comm != nullptr || D->serialize != 0; }
+inline bool tr_has_p2p(const DistState* D) {
+    if (D->comm) return g_rccl.AllGather && g_rccl.Send && g_rccl.Recv && g_rccl.GroupStart && g_rccl.GroupEnd;
+    return D->send && D->recv && D->allgather;
+}
+inline bool tr_present(const Ctx* ctx, const DistState* D) { return D->comm != nullptr || (D->bcast && D->allreduce) || ctx->g.world == 1; }
+
 struct CsHop {
     Ctx* ctx; DistState* D; hipStream_t st; bool hop; int rc = 0;
-    CsHop(Ctx* c, DistState* d, hipStream_t s) : ctx(c), D(d), st(s), hop(d->comm != nullptr && s != d->cs) {
+    CsHop(Ctx* c, DistState* d, hipStream_t s) : ctx(c), D(d), st(s), hop(tr_serial(d) && s != d->cs) {
         if (hop) {
+            D->wire[6] += 1.0;
             if (hipEventRecord(D->ev_hop[0], st) != hipSuccess || hipStreamWaitEvent(D->cs, D->ev_hop[0], 0) != hipSuccess) rc = PYIPM_E_HIP;
         }
     }
@@ -203,73 +226,164 @@ struct CsHop {
     }
 };
 
-// A panel message over the handle's communicator as SCATTER + ALL-GATHER: the owner sends piece r to rank r (W - 1 sends over
-// W - 1 links at once), then every rank hands its piece to all the others (all-gather, in place).  ncclBroadcast is a ring
-// or a tree: one link's bandwidth whatever the topology; over the point-to-point xGMI mesh of an 8-GPU node this form moves
-// a message in 2 / W of the time per link-bandwidth -- and the panel messages are 4.3 GB per step at N = 32768, the whole
-// lower triangle.  `buf` must hold W * ceil(count / W) doubles (the panel buffers are allocated with that slack).
-// Unmeasured on more than one GPU (the development box has one): comm_init checks it against ncclBroadcast on every
-// communicator before switching it on.
+inline int tr_fail(Ctx* ctx, const char* what, ncclResult_t r) {
+    ctx->err = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return PYIPM_E_COMM;
+}
+// the raw operations, on the stream given (the callers have hopped already where the transport asks for it)
+int tr_group_begin(Ctx* ctx, DistState* D) {
+    if (!D->comm) return 0;
+    ncclResult_t r = g_rccl.GroupStart(); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclGroupStart", r);
+}
+int tr_group_end(Ctx* ctx, DistState* D) {
+    if (!D->comm) return 0;
+    ncclResult_t r = g_rccl.GroupEnd(); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclGroupEnd", r);
+}
+int tr_send(Ctx* ctx, DistState* D, const double* buf, size_t count, int peer, hipStream_t st) {
+    D->wire[4] += 1.0;
+    if (D->comm) { ncclResult_t r = g_rccl.Send(buf, count, ncclDouble, peer, D->comm, st); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclSend", r); }
+    if (!D->send) { ctx->err = "no point-to-point send installed (pyipm_newton_set_exchange_p2p)"; return PYIPM_E_COMM; }
+    if (D->send(D->user, buf, count * sizeof(double), peer, (void*)st)) { ctx->err = "the send callback failed"; return PYIPM_E_COMM; }
+    return 0;
+}
+int tr_recv(Ctx* ctx, DistState* D, double* buf, size_t count, int peer, hipStream_t st) {
+    D->wire[4] += 1.0;
+    if (D->comm) { ncclResult_t r = g_rccl.Recv(buf, count, ncclDouble, peer, D->comm, st); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclRecv", r); }
+    if (!D->recv) { ctx->err = "no point-to-point receive installed (pyipm_newton_set_exchange_p2p)"; return PYIPM_E_COMM; }
+    if (D->recv(D->user, buf, count * sizeof(double), peer, (void*)st)) { ctx->err = "the receive callback failed"; return PYIPM_E_COMM; }
+    return 0;
+}
+int tr_allgather(Ctx* ctx, DistState* D, const double* sendbuf, double* recvbuf, size_t count_per_rank, hipStream_t st) {
+    D->wire[5] += 1.0;
+    if (D->comm) { ncclResult_t r = g_rccl.AllGather(sendbuf, recvbuf, count_per_rank, ncclDouble, D->comm, st); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclAllGather", r); }
+    if (!D->allgather) { ctx->err = "no all-gather installed (pyipm_newton_set_exchange_p2p)"; return PYIPM_E_COMM; }
+    if (D->allgather(D->user, sendbuf, recvbuf, count_per_rank * sizeof(double), (void*)st)) { ctx->err = "the all-gather callback failed"; return PYIPM_E_COMM; }
+    return 0;
+}
+int tr_bcast(Ctx* ctx, DistState* D, double* buf, size_t count, int root, hipStream_t st) {
+    if (D->comm) { ncclResult_t r = g_rccl.Broadcast(buf, buf, count, ncclDouble, root, D->comm, st); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclBroadcast", r); }
+    if (!D->bcast) { ctx->err = "no exchange installed: pyipm_newton_set_exchange or pyipm_newton_comm_init first"; return PYIPM_E_COMM; }
+    if (D->bcast(D->user, buf, count * sizeof(double), root, (void*)st)) { ctx->err = "the broadcast callback failed"; return PYIPM_E_COMM; }
+    return 0;
+}
+int tr_allreduce(Ctx* ctx, DistState* D, double* buf, size_t count, int op, hipStream_t st) {
+    if (D->comm) { ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclDouble, op ? ncclMax : ncclSum, D->comm, st); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclAllReduce", r); }
+    if (!D->allreduce) { ctx->err = "no exchange installed: pyipm_newton_set_exchange or pyipm_newton_comm_init first"; return PYIPM_E_COMM; }
+    if (D->allreduce(D->user, buf, count, op, (void*)st)) { ctx->err = "the all-reduce callback failed"; return PYIPM_E_COMM; }
+    return 0;
+}
+
+// A panel message as SCATTER + ALL-GATHER: the owner sends piece r to rank r (W - 1 sends over W - 1 links at once), then
+// every rank hands its piece to all the others (all-gather, in place).  A broadcast is a ring or a tree: one link's
+// bandwidth whatever the topology; over the point-to-point xGMI mesh of an 8-GPU node this form moves a message in 2 / W of the
+// time per link-bandwidth -- and the panel messages are 4.3 GB per step at N = 32768, the whole lower triangle.  `buf` must
+// hold W * ceil(count / W) doubles (the panel buffers are allocated with that slack).  Unmeasured on more than one GPU (the
+// development pool has one): the self-test checks it against the plain broadcast on every exchange before switching it on,
+// and the multi-rank tests on one GPU run it over callbacks (tests/test_gpu_dist.py).
 int sag_bcast(Ctx* ctx, DistState* D, double* buf, size_t count, int root, hipStream_t cs) {
     const int W = ctx->g.world, me = ctx->g.rank;
     const size_t chunk = (count + (size_t)W - 1) / (size_t)W;
     // A rank whose scatter stage fails locally still takes part in the all-gather (on whatever its piece holds): its peers
     // are already inside that collective and would otherwise never return.  The failure is reported afterwards.
-    int rc = 0;
-    auto fail = [&](const char* what, ncclResult_t r) {
-        if (!rc) { ctx->err = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); rc = PYIPM_E_COMM; } };
-    ncclResult_t r = g_rccl.GroupStart();
-    if (r != ncclSuccess) fail("ncclGroupStart", r);
+    int rc = 0; std::string first_err;
+    auto note = [&](int r) { if (r && !rc) { rc = r; first_err = ctx->err; } };
+    int r = tr_group_begin(ctx, D);
+    if (r) note(r);
     else {
         if (me == root) {
             for (int q = 0; q < W; ++q) {
                 if (q == root) continue;
-                r = g_rccl.Send(buf + (size_t)q * chunk, chunk, ncclDouble, q, D->comm, cs);
-                if (r != ncclSuccess) { fail("ncclSend", r); break; }
+                r = tr_send(ctx, D, buf + (size_t)q * chunk, chunk, q, cs);
+                if (r) { note(r); break; }
             }
         } else {
-            r = g_rccl.Recv(buf + (size_t)me * chunk, chunk, ncclDouble, root, D->comm, cs);
-            if (r != ncclSuccess) fail("ncclRecv", r);
+            note(tr_recv(ctx, D, buf + (size_t)me * chunk, chunk, root, cs));
         }
-        r = g_rccl.GroupEnd(); if (r != ncclSuccess) fail("ncclGroupEnd", r);
+        note(tr_group_end(ctx, D));
     }
-    r = g_rccl.AllGather(buf + (size_t)me * chunk, buf, chunk, ncclDouble, D->comm, cs);
-    if (r != ncclSuccess) fail("ncclAllGather", r);
+    note(tr_allgather(ctx, D, buf + (size_t)me * chunk, buf, chunk, cs));
+    if (rc) ctx->err = first_err;
     return rc;
 }
 
 int ex_bcast(Ctx* ctx, DistState* D, void* buf, size_t bytes, int root, hipStream_t st) {
     if (bytes == 0) return 0;
-    if (D->comm && D->sag && bytes >= D->sag_min_bytes && (buf == D->msg[0] || buf == D->msg[1])) {
+    if (ctx->g.world == 1 && !D->comm && !D->bcast) return 0;                          // one rank, nothing installed: nothing to do
+    const bool panel = buf == D->msg[0] || buf == D->msg[1];
+    if (D->sag && tr_has_p2p(D) && bytes >= D->sag_min_bytes && panel) {
+        D->wire[2] += 1.0; D->wire[3] += (double)bytes;
         CsHop h(ctx, D, st); if (h.rc) return h.done();
         int rc = sag_bcast(ctx, D, static_cast<double*>(buf), bytes / sizeof(double), root, h.stream());
         if (rc) return rc;
         return h.done();
     }
-    if (D->comm) {
-        CsHop h(ctx, D, st); if (h.rc) return h.done();
-        ncclResult_t r = g_rccl.Broadcast(buf, buf, bytes / sizeof(double), ncclDouble, root, D->comm, h.stream());
-        if (r != ncclSuccess) { ctx->err = std::string("ncclBroadcast: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; }
-        return h.done();
-    }
-    if (ctx->g.world == 1) return 0;
-    if (!D->bcast) { ctx->err = "no exchange installed: pyipm_newton_set_exchange or pyipm_newton_comm_init first"; return PYIPM_E_COMM; }
-    if (D->bcast(D->user, buf, bytes, root, (void*)st)) { ctx->err = "the broadcast callback failed"; return PYIPM_E_COMM; }
-    return 0;
+    if (panel) { D->wire[0] += 1.0; D->wire[1] += (double)bytes; }
+    CsHop h(ctx, D, st); if (h.rc) return h.done();
+    int rc = tr_bcast(ctx, D, static_cast<double*>(buf), bytes / sizeof(double), root, h.stream());
+    if (rc) return rc;
+    return h.done();
 }
 
 int ex_allreduce(Ctx* ctx, DistState* D, double* buf, size_t count, int op, hipStream_t st) {
     if (count == 0) return 0;
-    if (D->comm) {
-        CsHop h(ctx, D, st); if (h.rc) return h.done();
-        ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclDouble, op ? ncclMax : ncclSum, D->comm, h.stream());
-        if (r != ncclSuccess) { ctx->err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; }
-        return h.done();
+    if (ctx->g.world == 1 && !D->comm && !D->allreduce) return 0;
+    CsHop h(ctx, D, st); if (h.rc) return h.done();
+    int rc = tr_allreduce(ctx, D, buf, count, op, h.stream());
+    if (rc) return rc;
+    return h.done();
+}
+
+// The exchange's self-test (comm_init runs it on a fresh communicator; pyipm_newton_exchange_selftest on whatever is installed):
+// the scatter + all-gather form is switched on only with at least three ranks, every primitive present, and after it has
+// reproduced the plain broadcast on THIS exchange -- from rank 0 and from the last rank, a count that does not divide by the
+// number of ranks.  The environment (PYIPM_DIST_SAG=0) is read per rank and so is the presence of the primitives: the ranks
+// first AGREE on whether the form is wanted at all (a minimum over the ranks) -- a rank entering the test alone would wait for
+// ever -- and then on the outcome (a sum of failures), so either all use it or none.  Every rank takes part in
+// every collective below whatever happens to it locally: a local HIP failure is recorded, the collective is still issued (on
+// the always-present 16-double scratch of the handle), and the error is reported afterwards.
+int exchange_selftest(Ctx* ctx, DistState* D) {
+    D->sag = 0;
+    const int W = ctx->g.world;
+    if (W < 2) return PYIPM_OK;
+    const char* env = getenv("PYIPM_DIST_SAG");
+    struct DevBuf { double* p = nullptr; ~DevBuf() { if (p) hipFree(p); } } scratch;
+    const size_t count = 100003, cap = ((count + (size_t)W - 1) / (size_t)W) * (size_t)W;
+    int local_rc = 0; std::string local_err;
+    auto lfail = [&](const char* what, hipError_t e) { if (!local_rc) { local_rc = PYIPM_E_HIP; local_err = std::string(what) + ": " + hipGetErrorString(e); } };
+    {   hipError_t e = hipMalloc((void**)&scratch.p, 2 * cap * sizeof(double)); if (e != hipSuccess) { scratch.p = nullptr; lfail("hipMalloc (self-test scratch)", e); } }
+    double *a = scratch.p, *b = scratch.p ? scratch.p + cap : nullptr, *flag = D->small;
+    auto agree = [&](double mine, int op, double* out) -> int {          // op: 0 sum, 1 max (a minimum is a maximum of negatives)
+        hipError_t e = hipMemcpy(flag, &mine, sizeof(double), hipMemcpyHostToDevice); if (e != hipSuccess) lfail("hipMemcpy (self-test flag)", e);
+        int rc = tr_allreduce(ctx, D, flag, 1, op, D->cs);                 // ... still issued: the peers are inside it
+        e = hipStreamSynchronize(D->cs); if (e != hipSuccess) lfail("hipStreamSynchronize (self-test)", e);
+        *out = mine;
+        e = hipMemcpy(out, flag, sizeof(double), hipMemcpyDeviceToHost); if (e != hipSuccess) lfail("hipMemcpy (self-test flag back)", e);
+        return rc;
+    };
+    const bool mine = !(env && env[0] == '0') && W >= 3 && tr_has_p2p(D) && scratch.p != nullptr;
+    double neg_want = 0.0;
+    int rc = agree(mine ? -1.0 : 0.0, 1, &neg_want);                       // max of (-want) = -(min of want)
+    if (rc) return rc;
+    if (neg_want < -0.5) {
+        std::vector<double> host(count), got(count), ref(count);
+        double bad = 0.0;
+        for (int root : {0, W - 1}) {
+            for (size_t i = 0; i < count; ++i) host[i] = (ctx->g.rank == root) ? 0.5 + (double)i * (1.0 + root) : -1.0;
+            bool local_ok = hipMemcpy(a, host.data(), count * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+                            hipMemcpy(b, host.data(), count * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+            if (sag_bcast(ctx, D, a, count, root, D->cs)) { local_ok = false; ctx->err.clear(); }
+            if (tr_bcast(ctx, D, b, count, root, D->cs)) { local_ok = false; ctx->err.clear(); }
+            if (hipStreamSynchronize(D->cs) != hipSuccess) local_ok = false;
+            if (local_ok) local_ok = hipMemcpy(got.data(), a, count * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
+                                     hipMemcpy(ref.data(), b, count * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+            if (!local_ok || memcmp(got.data(), ref.data(), count * sizeof(double)) != 0) bad = 1.0;
+        }
+        double total = 1.0;
+        rc = agree(bad, 0, &total); if (rc) return rc;
+        D->sag = (total == 0.0) ? 1 : 0;
     }
-    if (ctx->g.world == 1) return 0;
-    if (!D->allreduce) { ctx->err = "no exchange installed: pyipm_newton_set_exchange or pyipm_newton_comm_init first"; return PYIPM_E_COMM; }
-    if (D->allreduce(D->user, buf, count, op, (void*)st)) { ctx->err = "the all-reduce callback failed"; return PYIPM_E_COMM; }
-    return 0;
+    if (local_rc) { ctx->err = local_err; return local_rc; }
+    return PYIPM_OK;
 }
 
 // run a piece of the per-panel machinery (which enqueues on ctx->stream) on another stream
@@ -350,6 +464,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
     ctx->zeros_clean = false;
     rc = factor_begin(ctx); if (rc) return rc;
     D->used = 0; D->spans.clear(); D->bytes_sent = 0; D->n_msgs = 0;
+    for (int k = 0; k < 12; ++k) D->wire[k] = 0.0;
     hipStream_t main = ctx->stream, side = D->side, cs = D->cs;
     DIST_HIP(hipEventRecord(ctx->ev[0], main));
     // every rank perturbs alike: the scale of a static pivot is the largest entry over ALL ranks' columns
@@ -680,6 +795,36 @@ int pyipm_newton_set_exchange(pyipm_newton_ctx* h, pyipm_bcast_fn bcast, pyipm_a
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)
 
+int pyipm_newton_set_exchange_p2p(pyipm_newton_ctx* h, pyipm_send_fn send, pyipm_recv_fn recv, pyipm_allgather_fn allgather,
+                                  int serialize) try {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
+    D->send = send; D->recv = recv; D->allgather = allgather; D->serialize = serialize != 0;
+    D->sag = 0;                                          // (whatever an earlier self-test decided belonged to another transport)
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
+int pyipm_newton_exchange_selftest(pyipm_newton_ctx* h) try {
+    if (check_ctx(h)) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    if (ctx->batched) return single_only(ctx);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
+    if (ctx->g.world > 1 && !D->comm && !(D->bcast && D->allreduce)) { ctx->err = "exchange_selftest: no exchange installed"; return PYIPM_E_COMM; }
+    return exchange_selftest(ctx, D);
+} PYIPM_CATCH_H(h)
+
+int pyipm_newton_dist_wire(pyipm_newton_ctx* h, double out[12]) try {
+    if (check_ctx(h) || !out) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
+    for (int k = 0; k < 12; ++k) out[k] = D->wire[k];
+    return PYIPM_OK;
+} PYIPM_CATCH_H(h)
+
 int pyipm_newton_comm_unique_id(void* id128) try {
     if (!id128) return PYIPM_E_BADARG;
     std::string err;
@@ -701,50 +846,7 @@ int pyipm_newton_comm_init(pyipm_newton_ctx* h, const void* id128) try {
     ncclUniqueId id; memcpy(&id, id128, sizeof(id));
     ncclResult_t r = g_rccl.CommInitRank(&D->comm, ctx->g.world, id, ctx->g.rank);
     if (r != ncclSuccess) { D->comm = nullptr; ctx->err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; }
-    // Panel messages as scatter + all-gather (sag_bcast): only with at least three ranks, every entry point present, and after
-    // the form has reproduced ncclBroadcast on THIS communicator -- from rank 0 and from the last rank, a count that does not
-    // divide by the number of ranks; the ranks agree on the outcome (a sum of failures), so either all use it or none.
-    D->sag = 0;
-    const char* env = getenv("PYIPM_DIST_SAG");
-    const int W = ctx->g.world;
-    // The environment is read per rank and so is the presence of the entry points: the ranks first AGREE on whether the
-    // form is wanted at all (a minimum over the ranks) -- a rank entering the self-test alone would wait for ever.
-    // Every rank takes part in every collective below whatever happens to it locally; device memory is released on all paths.
-    if (W < 2) return PYIPM_OK;
-    struct DevBuf { double* p = nullptr; ~DevBuf() { if (p) hipFree(p); } } scratch;
-    const size_t count = 100003, cap = ((count + (size_t)W - 1) / (size_t)W) * (size_t)W;
-    PYIPM_HIP(hipMalloc((void**)&scratch.p, (2 * cap + 8) * sizeof(double)));
-    double *a = scratch.p, *b = a + cap, *flag = a + 2 * cap;
-    auto agree = [&](double mine, ncclRedOp_t op, double* out) -> int {
-        PYIPM_HIP(hipMemcpy(flag, &mine, sizeof(double), hipMemcpyHostToDevice));
-        ncclResult_t ra = g_rccl.AllReduce(flag, flag, 1, ncclDouble, op, D->comm, D->cs);
-        if (ra != ncclSuccess) { ctx->err = "ncclAllReduce failed in the communicator's self-test"; return PYIPM_E_COMM; }
-        PYIPM_HIP(hipStreamSynchronize(D->cs));
-        PYIPM_HIP(hipMemcpy(out, flag, sizeof(double), hipMemcpyDeviceToHost));
-        return 0;
-    };
-    const bool mine = !(env && env[0] == '0') && W >= 3 && g_rccl.AllGather && g_rccl.Send && g_rccl.Recv && g_rccl.GroupStart && g_rccl.GroupEnd;
-    double all_want = 0.0;
-    rc = agree(mine ? 1.0 : 0.0, ncclMin, &all_want); if (rc) return rc;
-    if (all_want > 0.5) {
-        std::vector<double> host(count), got(count), ref(count);
-        double bad = 0.0;
-        for (int root : {0, W - 1}) {
-            for (size_t i = 0; i < count; ++i) host[i] = (ctx->g.rank == root) ? 0.5 + (double)i * (1.0 + root) : -1.0;
-            bool local_ok = hipMemcpy(a, host.data(), count * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
-                            hipMemcpy(b, host.data(), count * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
-            if (sag_bcast(ctx, D, a, count, root, D->cs)) { local_ok = false; ctx->err.clear(); }
-            if (g_rccl.Broadcast(b, b, count, ncclDouble, root, D->comm, D->cs) != ncclSuccess) local_ok = false;
-            if (hipStreamSynchronize(D->cs) != hipSuccess) local_ok = false;
-            if (local_ok) local_ok = hipMemcpy(got.data(), a, count * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess &&
-                                     hipMemcpy(ref.data(), b, count * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
-            if (!local_ok || memcmp(got.data(), ref.data(), count * sizeof(double)) != 0) bad = 1.0;
-        }
-        double total = 1.0;
-        rc = agree(bad, ncclSum, &total); if (rc) return rc;
-        D->sag = (total == 0.0) ? 1 : 0;
-    }
-    return PYIPM_OK;
+    return exchange_selftest(ctx, D);
 } PYIPM_CATCH_H(h)
 
 int pyipm_newton_comm_ranks(pyipm_newton_ctx* h) try {
@@ -761,7 +863,7 @@ int pyipm_newton_comm_ranks(pyipm_newton_ctx* h) try {
 int pyipm_newton_comm_bcast_mode(pyipm_newton_ctx* h) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
-    return (ctx->dist && ctx->dist->comm && ctx->dist->sag) ? 1 : 0;
+    return (ctx->dist && ctx->dist->sag && tr_has_p2p(ctx->dist)) ? 1 : 0;
 } PYIPM_CATCH_H(h)
 
 int64_t pyipm_newton_owned_rows(pyipm_newton_ctx* h, int64_t* rows) try {

@@ -34,7 +34,8 @@ struct BatchCond {
     int* pos;            // [B][mi]: index inside A, or -1
     int* idx;            // [B][mi]: members of A
     int* cnt;            // [B]: |A|
-    int64_t sP;          // stride of pos / idx (>= mi)
+    double* sig;         // [B][mi]: Sigma_k of the eliminated pairs, 0 for the members of A (the scaling of the Gram operand)
+    int64_t sP;          // stride of pos / idx / sig (>= mi)
     double sigma_max;
 };
 
@@ -138,22 +139,40 @@ __global__ __launch_bounds__(256) void k_bc_prep(BatchPtrs bp, Geo g, double mu,
         const double sg = lda[me + k] / (s[k] + eps);
         const double gs = -(lda[me + k] - mu / (s[k] + eps)), gi = -(bp.ci[b * mi + k] - s[k]);
         out[n + k] = gs; out[n + mi + me + k] = gi;
-        if (pos[k] < 0) tsh[k] = sg * gi + gs;
-        else { tsh[k] = 0.0; vc[n + me + pos[k]] = gi + gs * (s[k] + eps) / lda[me + k]; }
+        if (pos[k] < 0) { tsh[k] = sg * gi + gs; bc.sig[b * bc.sP + k] = sg; }
+        else { tsh[k] = 0.0; bc.sig[b * bc.sP + k] = 0.0; vc[n + me + pos[k]] = gi + gs * (s[k] + eps) / lda[me + k]; }
     }
     for (int64_t a = tid; a < me; a += 256) { const double v = -bp.ce[b * me + a]; out[n + mi + a] = v; vc[n + a] = v; }
     for (int64_t i = g.N + tid; i < g.Npad; i += 256) out[i] = 0.0;
     for (int64_t i = n + me + na + tid; i < g.Npad; i += 256) vc[i] = 0.0;
     __syncthreads();
-    for (int64_t j = wave; j < n; j += 4) {
-        double acc = 0.0, acct = 0.0;
-        if (me) { const double* r = bp.Je + b * bp.sJe + j * bp.ldje; for (int64_t a = lane; a < me; a += 64) acc += r[a] * lda[a]; }
-        if (mi) {
-            const double* r = bp.Ji + b * bp.sJi + j * bp.ldji;
-            for (int64_t a = lane; a < mi; a += 64) { const double v = r[a]; acc += v * lda[me + a]; acct += v * tsh[a]; }
+    // x rows: a wave takes FOUR rows per trip (their loads in flight together: one row at a time was one memory latency per row,
+    // 64 of them in a row per wave -- most of this kernel's time)
+    for (int64_t j0 = (int64_t)wave * 4; j0 < n; j0 += 16) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0}, acct[4] = {0.0, 0.0, 0.0, 0.0};
+        if (me) {
+            for (int64_t a = lane; a < me; a += 64) {
+                const double la = lda[a];
+                #pragma unroll
+                for (int q = 0; q < 4; ++q) if (j0 + q < n) acc[q] += bp.Je[b * bp.sJe + (j0 + q) * bp.ldje + a] * la;
+            }
         }
-        acc = wave_sum(acc); acct = wave_sum(acct);
-        if (lane == 0) { const double gx = -(bp.df[b * n + j] - acc); out[j] = gx; vc[j] = gx + acct; }
+        if (mi) {
+            for (int64_t a = lane; a < mi; a += 64) {
+                const double la = lda[me + a], ta = tsh[a];
+                #pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (j0 + q < n) { const double v = bp.Ji[b * bp.sJi + (j0 + q) * bp.ldji + a]; acc[q] += v * la; acct[q] += v * ta; }
+            }
+        }
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) { acc[q] = wave_sum(acc[q]); acct[q] = wave_sum(acct[q]); }
+        if (lane < 4 && j0 + lane < n) {
+            const int64_t j = j0 + lane;
+            const double a_ = lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3];
+            const double t_ = lane == 0 ? acct[0] : lane == 1 ? acct[1] : lane == 2 ? acct[2] : acct[3];
+            const double gx = -(bp.df[b * n + j] - a_); out[j] = gx; vc[j] = gx + t_;
+        }
     }
 }
 
@@ -183,30 +202,32 @@ __global__ __launch_bounds__(256) void k_bc_assemble(BatchPtrs bp, Geo g, double
     const double* Ji = bp.Ji ? bp.Ji + b * bp.sJi : nullptr;
     const double* s = bp.s + b * mi;
     const double* lda = bp.lda + b * (me + mi);
-    const int* pos = bc.pos + b * bc.sP;
     const int* idx = bc.idx + b * bc.sP;
     const int64_t i0 = (int64_t)rt * TB, j0 = (int64_t)ct * TB;
     double4_t acc[4];
     #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
     if (j0 < n && i0 < n && mi > 0) {
+        const double* sig = bc.sig + b * bc.sP;
+        const int kk = tid & 63, r0q = tid >> 6;             // this thread stages column kk of rows r0q + 4 q of both operand tiles
+        double va[TB * TB / 256], vb[TB * TB / 256];
+        auto fetch = [&](int64_t kc) {                        // (all 32 loads of a thread in flight together)
+            const bool kin = kc + kk < mi;
+            const double sg = kin ? sig[kc + kk] : 0.0;
+            #pragma unroll
+            for (int q = 0; q < TB * TB / 256; ++q) {
+                const int r = r0q + 4 * q;
+                va[q] = (kin && j0 + r < n) ? Ji[(j0 + r) * bp.ldji + kc + kk] : 0.0;
+                vb[q] = (kin && i0 + r < n) ? sg * Ji[(i0 + r) * bp.ldji + kc + kk] : 0.0;
+            }
+        };
+        fetch(0);
         for (int64_t kc = 0; kc < mi; kc += TB) {
             if (kc > 0) __syncthreads();
-            double va[TB * TB / 256], vb[TB * TB / 256];
             #pragma unroll
-            for (int q = 0; q < TB * TB / 256; ++q) {
-                const int e = tid + 256 * q, r = e >> 6, k = e & 63;
-                const bool kin = kc + k < mi;
-                va[q] = (kin && j0 + r < n) ? Ji[(j0 + r) * bp.ldji + kc + k] : 0.0;
-                const double sg = (kin && pos[kc + k] < 0) ? lda[me + kc + k] / (s[kc + k] + eps) : 0.0;
-                vb[q] = (kin && i0 + r < n) ? sg * Ji[(i0 + r) * bp.ldji + kc + k] : 0.0;
-            }
-            #pragma unroll
-            for (int q = 0; q < TB * TB / 256; ++q) {
-                const int e = tid + 256 * q;
-                XA[e >> 6][e & 63] = va[q]; XB[e >> 6][e & 63] = vb[q];
-            }
+            for (int q = 0; q < TB * TB / 256; ++q) { XA[r0q + 4 * q][kk] = va[q]; XB[r0q + 4 * q][kk] = vb[q]; }
             __syncthreads();
+            if (kc + TB < mi) fetch(kc + TB);                 // the next chunk's loads fly under this chunk's products
             #pragma unroll
             for (int ks = 0; ks < 16; ++ks) {
                 const double bop = XB[wave * 16 + l15][ks * 4 + l4];

@@ -113,7 +113,9 @@ size_t carve_batched(Ctx* c, const Geo& g, int64_t B, char* base) {
     // condensed form (set_option("condensed", 1)): per problem the active set -- position, members, count -- and the backward errors
     const size_t ocp = cv.take((size_t)B * (size_t)(2 * g.mi + 2) * sizeof(int) + (size_t)B * sizeof(int));
     const size_t obe = cv.take((size_t)B * sizeof(double));
+    const size_t osg = cv.take((size_t)B * (size_t)(g.mi + 1) * sizeof(double));
     if (base) {
+        c->WT = (double*)(base + osg);                  // (batched handle: Sigma of the eliminated pairs, the Gram operand's scaling)
         c->cond_pos = (int*)(base + ocp); c->cond_idx = c->cond_pos + (size_t)B * (size_t)(g.mi + 1);
         c->cond_cnt = c->cond_idx + (size_t)B * (size_t)(g.mi + 1);
         c->vt = (double*)(base + obe);
@@ -146,7 +148,7 @@ BatchPtrs batch_ptrs(Ctx* ctx) {
 
 BatchCond batch_cond(Ctx* ctx) {
     BatchCond bc;
-    bc.pos = ctx->cond_pos; bc.idx = ctx->cond_idx; bc.cnt = ctx->cond_cnt; bc.sP = ctx->g.mi + 1;
+    bc.pos = ctx->cond_pos; bc.idx = ctx->cond_idx; bc.cnt = ctx->cond_cnt; bc.sig = ctx->WT; bc.sP = ctx->g.mi + 1;
     bc.sigma_max = ctx->cond_sigma_max;
     return bc;
 }

@@ -117,6 +117,9 @@ def load_library(path: str | None = None):
         "pyipm_newton_provider_stats": (c_int, [ctxp, POINTER(c_double)]),
         # distributed driver (dist_impl.hpp)
         "pyipm_newton_set_exchange": (c_int, [ctxp, c_void_p, c_void_p, c_void_p]),
+        "pyipm_newton_set_exchange_p2p": (c_int, [ctxp, c_void_p, c_void_p, c_void_p, c_int]),
+        "pyipm_newton_exchange_selftest": (c_int, [ctxp]),
+        "pyipm_newton_dist_wire": (c_int, [ctxp, POINTER(c_double)]),
         "pyipm_newton_rccl_library": (c_int, [c_char_p]),
         "pyipm_newton_comm_unique_id": (c_int, [c_void_p]),
         "pyipm_newton_workspace_bytes_provider": (c_size_t, [c_int64, c_int64, c_int64]),
@@ -159,6 +162,9 @@ def mfma_f64_peak(device: int = 0, iters: int = 20000) -> float:
 
 BCAST_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p)
 ALLREDUCE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p)
+SEND_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p)
+RECV_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_int, c_void_p)
+ALLGATHER_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p)
 
 
 class _RawDeviceArray(object):
@@ -498,6 +504,25 @@ class NewtonCore(object):
         """ctypes callbacks (BCAST_FN / ALLREDUCE_FN); kept alive with the handle."""
         self._cbs = (bcast_cb, allreduce_cb)
         self._ck(self.lib.pyipm_newton_set_exchange(self.h, ctypes.cast(bcast_cb, c_void_p), ctypes.cast(allreduce_cb, c_void_p), None))
+
+    def set_exchange_p2p(self, send_cb, recv_cb, allgather_cb, serialize=False):
+        """ctypes callbacks (SEND_FN / RECV_FN / ALLGATHER_FN) for the point-to-point half of a callback exchange."""
+        self._cbs_p2p = (send_cb, recv_cb, allgather_cb)
+        self._ck(self.lib.pyipm_newton_set_exchange_p2p(self.h, ctypes.cast(send_cb, c_void_p), ctypes.cast(recv_cb, c_void_p),
+                                                        ctypes.cast(allgather_cb, c_void_p), int(bool(serialize))))
+
+    def exchange_selftest(self):
+        """COLLECTIVE: agree on and test the scatter + all-gather form of the panel messages on the installed exchange."""
+        self._ck(self.lib.pyipm_newton_exchange_selftest(self.h))
+        return self.comm_bcast_mode()
+
+    WIRE_KEYS = ("bcast_messages", "bcast_bytes", "sag_messages", "sag_bytes", "p2p_pieces", "allgathers", "stream_hops",
+                 "slice_messages", "slice_bytes", "slices_as_broadcast")
+
+    def dist_wire(self):
+        t = (c_double * 12)()
+        self._ck(self.lib.pyipm_newton_dist_wire(self.h, t))
+        return {k: int(t[i]) for i, k in enumerate(self.WIRE_KEYS)}
 
     def comm_init(self, id128):
         buf = (ctypes.c_char * 128).from_buffer_copy(bytes(id128))
