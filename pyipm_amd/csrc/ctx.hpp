@@ -158,6 +158,8 @@ struct Ctx {
     bool sweep_used = false;              // ... a sweep ran since the error word was last read (solve_info / factor_end look at it)
     int dist_head_split = 1;              // per-panel schedule: the owner's head in two launches -- the next panel's diagonal block (its chain waits for
                                           // that alone), then the rows below it on ctx->rest (round 4)
+    int dist_slices = 1;                  // distributed schedule: the two-message protocol (slices ahead of the panel message: the next owner's tile
+                                          // chain starts on an nb x nb message); 0 = one message per panel (rounds 1-4); collective
     int wide_sub = 256;                   // per-panel schedule: a panel wider than this is factored as a block of sub-panels this wide
                                           // (factor_wide_panel: the single-rank group chain inside one panel); 0 = all stages in one launch
     int64_t pending32_rows = 24576;       // ... and a panel's pending in-group update too while at most this many rows remain

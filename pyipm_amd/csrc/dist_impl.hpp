@@ -82,6 +82,11 @@ struct DistState {
     hipEvent_t ev_fact[2] = {}, ev_msg[2] = {}, ev_free[2] = {}, ev_head = nullptr, ev_join = nullptr;
     hipEvent_t ev_hop[2] = {};                         // a collective asked for on another stream is run on `cs` between these
     double* msg[2] = {nullptr, nullptr}; size_t msg_bytes = 0;
+    // two-message protocol: slice buffers [panel parity][slice 1 | 2] (a rank sends or receives a given slice, never both), the
+    // L rows rebuilt from a received slice, and their events: packed (owner's stream -> cs), received (cs -> owner-to-be's
+    // stream), free (the send has left / the slice is unpacked: the buffer may be written again)
+    double* sbuf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; double* EL[2] = {nullptr, nullptr}; size_t slice_bytes = 0;
+    hipEvent_t ev_spack[2][2] = {}, ev_srecv[2][2] = {}, ev_sfree[2][2] = {}, ev_pre = nullptr, ev_hr = nullptr;
     double* seg = nullptr;                             // nb doubles: the panel segment of the forward sum
     double* vloc = nullptr;                            // Npad: this rank's share of the vector during the sweeps
     double* small = nullptr;                           // 16 doubles: statistics reduction
@@ -157,6 +162,15 @@ void dist_free(Ctx* ctx) {
     }
     if (D->ev_head) hipEventDestroy(D->ev_head);
     if (D->ev_join) hipEventDestroy(D->ev_join);
+    for (int b = 0; b < 2; ++b) for (int j = 0; j < 2; ++j) {
+        if (D->sbuf[b][j]) hipFree(D->sbuf[b][j]);
+        if (D->ev_spack[b][j]) hipEventDestroy(D->ev_spack[b][j]);
+        if (D->ev_srecv[b][j]) hipEventDestroy(D->ev_srecv[b][j]);
+        if (D->ev_sfree[b][j]) hipEventDestroy(D->ev_sfree[b][j]);
+    }
+    for (int j = 0; j < 2; ++j) if (D->EL[j]) hipFree(D->EL[j]);
+    if (D->ev_pre) hipEventDestroy(D->ev_pre);
+    if (D->ev_hr) hipEventDestroy(D->ev_hr);
     for (int b = 0; b < 2; ++b) if (D->ev_hop[b]) hipEventDestroy(D->ev_hop[b]);
     for (auto e : D->pool) hipEventDestroy(e);
     if (D->seg) hipFree(D->seg);
@@ -182,6 +196,7 @@ int dist_set_option(Ctx* ctx, const char* name, double value, bool* handled) {
         return PYIPM_OK;
     }
     if (!strcmp(name, "dist_head_split")) { *handled = true; ctx->dist_head_split = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "dist_slices")) { *handled = true; ctx->dist_slices = (int)value != 0; return PYIPM_OK; }     // COLLECTIVE, like dist_sag
     if (!strcmp(name, "dist_selfmsg")) {                // world == 1: pack + "broadcast" every panel anyway (measures the message path)
         *handled = true;
         DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
@@ -469,19 +484,60 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
     DIST_HIP(hipEventRecord(ctx->ev[0], main));
     // every rank perturbs alike: the scale of a static pivot is the largest entry over ALL ranks' columns
     rc = ex_allreduce(ctx, D, reinterpret_cast<double*>(ctx->anorm), 1, 1, main); if (rc) return rc;
+    // the owner's stream starts behind everything the main stream has done to the matrix so far (the assembly, the reset of the
+    // statistics): with slices a panel's early phase waits for no other main-stream work
+    DIST_HIP(hipEventRecord(D->ev_head, main));
+    DIST_HIP(hipStreamWaitEvent(side, D->ev_head, 0));
     const int64_t np = g.npanels;
-    const bool wire = g.world > 1 || D->selfmsg;
+    const int W = g.world;
+    const bool wire = W > 1 || D->selfmsg;
     size_t need = 0;
     if (wire) for (int64_t p = 0; p < np; ++p) { const size_t b = dist_msg_bytes(ctx, p); if (b > need) need = b; }
     if (need > D->msg_bytes) {
         for (int b = 0; b < 2; ++b) { if (D->msg[b]) DIST_HIP(hipFree(D->msg[b])); D->msg[b] = nullptr; }
         for (int b = 0; b < 2; ++b)
-            if (hipMalloc((void**)&D->msg[b], need + (size_t)g.world * sizeof(double)) != hipSuccess) {     // (slack: W equal pieces, sag_bcast)
+            if (hipMalloc((void**)&D->msg[b], need + (size_t)W * sizeof(double)) != hipSuccess) {     // (slack: W equal pieces, sag_bcast)
                 ctx->err = "factor_dist: no memory for the panel messages"; return PYIPM_E_NOMEM; }
         D->msg_bytes = need;
     }
-    std::vector<char> has_msg((size_t)np, 0), on_side((size_t)np, 0);
     auto below = [&](int64_t p) { return g.Npad - (g.panel_c0(p) + g.panel_w(p)); };
+    auto own = [&](int64_t p) { return p >= 0 && p < np && g.owner(p) == g.rank; };
+    auto msg_of = [&](int64_t p) -> size_t { return (wire && p < np && below(p) > 0) ? dist_msg_bytes(ctx, p) : 0; };
+    // ---- the two-message protocol (round 5): slices ahead of the panel message --------------------------------------------
+    // sl(k): the rows of panel k that meet the diagonal block of panel k + 1 (slice 1, with the tile inverses) and the rows of
+    // panel k + 2 (slice 2) travel from owner(k) to owner(k + 1) point to point AHEAD of the panel message.  owner(k + 1) starts
+    // its tile chain on slice 1, runs the stages of its rows of panel k + 2 on slice 2 and hands ITS slice 1 on -- the chain of
+    // owners no longer waits for a panel message (hundreds of MB), its unpacking, or the rows work of the panel before: what
+    // it waits for is nb x nb.  The panel message itself is unchanged and follows for everybody's bulk update.  Decided from
+    // the geometry alone: every rank takes the same decision for every panel.
+    const bool slices_on = ctx->dist_slices && W > 1;
+    auto sl = [&](int64_t k) -> bool {
+        return slices_on && k >= 0 && k + 1 < np && msg_of(k) > 0 && g.owner(k + 1) != g.owner(k) && !panel_in_s(ctx, k) &&
+               panel_piecewise_ok(ctx, k + 1) && below(k + 1) >= 0;
+    };
+    const bool p2p = tr_has_p2p(D);
+    if (slices_on) {
+        size_t smax = 0;
+        for (int64_t p = 0; p < np; ++p) for (int j = 1; j <= 2; ++j) { const size_t e = slice_numel(g, p, j); if (e > smax) smax = e; }
+        if (smax * sizeof(double) > D->slice_bytes) {
+            for (int b = 0; b < 2; ++b) for (int j = 0; j < 2; ++j) { if (D->sbuf[b][j]) DIST_HIP(hipFree(D->sbuf[b][j])); D->sbuf[b][j] = nullptr; }
+            for (int j = 0; j < 2; ++j) { if (D->EL[j]) DIST_HIP(hipFree(D->EL[j])); D->EL[j] = nullptr; }
+            for (int b = 0; b < 2; ++b) for (int j = 0; j < 2; ++j)
+                if (hipMalloc((void**)&D->sbuf[b][j], smax * sizeof(double)) != hipSuccess) { ctx->err = "factor_dist: no memory for the slice messages"; return PYIPM_E_NOMEM; }
+            for (int j = 0; j < 2; ++j)
+                if (hipMalloc((void**)&D->EL[j], (size_t)g.nb * g.nb * sizeof(double)) != hipSuccess) { ctx->err = "factor_dist: no memory for the slice messages"; return PYIPM_E_NOMEM; }
+            D->slice_bytes = smax * sizeof(double);
+        }
+        if (!D->ev_spack[0][0])
+            for (int b = 0; b < 2; ++b) for (int j = 0; j < 2; ++j) {
+                DIST_HIP(hipEventCreateWithFlags(&D->ev_spack[b][j], hipEventDisableTiming));
+                DIST_HIP(hipEventCreateWithFlags(&D->ev_srecv[b][j], hipEventDisableTiming));
+                DIST_HIP(hipEventCreateWithFlags(&D->ev_sfree[b][j], hipEventDisableTiming));
+            }
+        if (!D->ev_pre) { DIST_HIP(hipEventCreateWithFlags(&D->ev_pre, hipEventDisableTiming)); DIST_HIP(hipEventCreateWithFlags(&D->ev_hr, hipEventDisableTiming)); }
+    }
+    bool sfree_rec[2][2] = {{false, false}, {false, false}};
+    bool pre_rec = false;
     D->fwd_done = false;
     if (fwd_b) {
         if (!D->fws) DIST_HIP(hipStreamCreateWithFlags(&D->fws, hipStreamNonBlocking));
@@ -496,126 +552,233 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
     auto fwd_step = [&](int64_t p) -> int {
         if (!fwd_b) return 0;
         const int64_t c0 = g.panel_c0(p); const int64_t nbw = g.panel_w(p);
-        const bool own = g.owner(p) == g.rank;
         double* v = D->vloc;
-        if (g.world > 1) {
+        if (W > 1) {
             DIST_HIP(hipMemcpyAsync(D->seg, v + c0, (size_t)nbw * sizeof(double), hipMemcpyDeviceToDevice, D->fws));
             int r = ex_allreduce(ctx, D, D->seg, (size_t)nbw, 0, D->fws); if (r) return r;
-            if (own) DIST_HIP(hipMemcpyAsync(v + c0, D->seg, (size_t)nbw * sizeof(double), hipMemcpyDeviceToDevice, D->fws));
+            if (own(p)) DIST_HIP(hipMemcpyAsync(v + c0, D->seg, (size_t)nbw * sizeof(double), hipMemcpyDeviceToDevice, D->fws));
         }
-        if (own) {
+        if (own(p)) {
             DIST_HIP(hipStreamWaitEvent(D->fws, ctx->ev_done[(size_t)p], 0));      // panel p factored
             int r = fwd_panel(ctx, p, v, D->fws); if (r) return r;
             r = diag_panel(ctx, p, v, D->fws); if (r) return r;
         }
         return 0;
     };
-
-    // factor (owner) + start the broadcast of panel p; fst = the stream the owner factors on
-    auto post = [&](int64_t p, hipStream_t fst) -> int {
-        const bool own = g.owner(p) == g.rank;
+    // ---- building blocks ------------------------------------------------------------------------------------------------
+    // owner: panel p is complete on `st` -> forward-sweep event, pack the panel message, "factored" event
+    auto finish_panel = [&](int64_t p, hipStream_t st) -> int {
         const int b = (int)(p & 1);
-        int r;
-        if (own) {
-            size_t sp; r = span_begin(ctx, D, 0, fst, &sp); if (r) return r;
-            r = factor_panel(ctx, p, fst, false); if (r) return r;
-            r = span_end(ctx, D, sp, fst); if (r) return r;
-            if (fwd_b) DIST_HIP(hipEventRecord(ctx->ev_done[(size_t)p], fst));
-        }
-        const size_t bytes = (wire && below(p) > 0) ? dist_msg_bytes(ctx, p) : 0;
-        has_msg[(size_t)p] = bytes > 0;
-        if (!bytes) { if (own) DIST_HIP(hipEventRecord(D->ev_fact[b], fst)); return 0; }
-        double* buf = D->msg[b];
-        if (own) {
-            DIST_HIP(hipStreamWaitEvent(fst, D->ev_free[b], 0));         // the previous message in this buffer has left / been unpacked
-            size_t sp; r = span_begin(ctx, D, 1, fst, &sp); if (r) return r;
-            { StreamScope sc(ctx, fst); r = pyipm_newton_panel_pack(reinterpret_cast<pyipm_newton_ctx*>(ctx), p, buf); }
+        if (fwd_b) DIST_HIP(hipEventRecord(ctx->ev_done[(size_t)p], st));
+        if (msg_of(p) > 0) {
+            DIST_HIP(hipStreamWaitEvent(st, D->ev_free[b], 0));          // the previous message in this buffer has left / been unpacked
+            size_t sp; int r = span_begin(ctx, D, 1, st, &sp); if (r) return r;
+            { StreamScope sc(ctx, st); r = pyipm_newton_panel_pack(reinterpret_cast<pyipm_newton_ctx*>(ctx), p, D->msg[b]); }
             if (r) return r;
-            r = span_end(ctx, D, sp, fst); if (r) return r;
-            DIST_HIP(hipEventRecord(D->ev_fact[b], fst));
-            DIST_HIP(hipStreamWaitEvent(cs, D->ev_fact[b], 0));
-        } else {
-            DIST_HIP(hipStreamWaitEvent(cs, D->ev_free[b], 0));
+            r = span_end(ctx, D, sp, st); if (r) return r;
         }
-        size_t sp; r = span_begin(ctx, D, 2, cs, &sp); if (r) return r;
-        r = ex_bcast(ctx, D, buf, bytes, g.owner(p), cs); if (r) return r;
+        DIST_HIP(hipEventRecord(D->ev_fact[b], st));
+        return 0;
+    };
+    // owner: pack slice j of panel p on `st` (its rows of panel p + j are final there)
+    auto pack_s = [&](int64_t p, int j, hipStream_t st) -> int {
+        if (slice_numel(g, p, j) == 0) return 0;
+        const int b = (int)(p & 1);
+        if (sfree_rec[b][j - 1]) DIST_HIP(hipStreamWaitEvent(st, D->ev_sfree[b][j - 1], 0));
+        int r = pack_slice(ctx, p, j, D->sbuf[b][j - 1], st); if (r) return r;
+        DIST_HIP(hipEventRecord(D->ev_spack[b][j - 1], st));
+        return 0;
+    };
+    // slice j of panel p on the wire: owner(p) -> owner(p + 1); without a point-to-point transport it travels as a broadcast
+    auto xchg_s = [&](int64_t p, int j) -> int {
+        const size_t cnt = slice_numel(g, p, j);
+        if (cnt == 0) return 0;
+        const int b = (int)(p & 1), src = g.owner(p), dst = g.owner(p + 1);
+        double* buf = D->sbuf[b][j - 1];
+        const bool sender = g.rank == src, receiver = g.rank == dst;
+        if (!p2p) {
+            if (sender) DIST_HIP(hipStreamWaitEvent(cs, D->ev_spack[b][j - 1], 0));
+            else if (sfree_rec[b][j - 1]) DIST_HIP(hipStreamWaitEvent(cs, D->ev_sfree[b][j - 1], 0));
+            int r = tr_bcast(ctx, D, buf, cnt, src, cs); if (r) return r;
+            D->wire[9] += 1.0;
+            if (!receiver) { DIST_HIP(hipEventRecord(D->ev_sfree[b][j - 1], cs)); sfree_rec[b][j - 1] = true; }
+        } else if (sender) {
+            DIST_HIP(hipStreamWaitEvent(cs, D->ev_spack[b][j - 1], 0));
+            int r = tr_send(ctx, D, buf, cnt, dst, cs); if (r) return r;
+            DIST_HIP(hipEventRecord(D->ev_sfree[b][j - 1], cs)); sfree_rec[b][j - 1] = true;
+        } else if (receiver) {
+            if (sfree_rec[b][j - 1]) DIST_HIP(hipStreamWaitEvent(cs, D->ev_sfree[b][j - 1], 0));
+            int r = tr_recv(ctx, D, buf, cnt, src, cs); if (r) return r;
+        } else return 0;
+        if (receiver) DIST_HIP(hipEventRecord(D->ev_srecv[b][j - 1], cs));
+        if (sender || receiver) { D->wire[7] += 1.0; D->wire[8] += (double)(cnt * sizeof(double)); }
+        return 0;
+    };
+    // head update of panel q's columns from panel p (p < q, q owned) over rows [r0, r1): Lop = where L of panel p lives for those
+    // rows (this rank's storage, the rebuilt panel, or a slice's L rows offset to global row numbers)
+    auto head_rows = [&](int64_t p, int64_t q, int64_t r0, int64_t r1, const double* Lop, int64_t ldl, hipStream_t st, bool small) -> int {
+        if (r1 > g.Npad) r1 = g.Npad;
+        if (r1 <= r0) return 0;
+        const int K = (int)g.panel_w(p);
+        const int64_t c0q = g.panel_c0(q), nbwq = g.panel_w(q);
+        if (panel_in_s(ctx, p)) return 0;                              // (a slack-block source: handled by update_range, whole columns)
+        if (small || g.Npad - (c0q + nbwq) <= ctx->head32_rows_dist) {
+            int64_t pa0, pa1, pb0, pb1;
+            active_ranges(ctx, g.panel_c0(p), g.panel_c0(p) + K, &pa0, &pa1, &pb0, &pb1);
+            hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((r1 - r0) / 32), (unsigned)(nbwq / TB)), dim3(256), 0, st,
+                               ctx->A, g.Npad, g.local_c0(q), Lop, ldl, wbuf(ctx, p), g.Npad, c0q, K, r0, g.Npad,
+                               pa0, pa1, pb0, pb1, ctx->side_prio);
+            DIST_KCHECK();
+            return 0;
+        }
+        return launch_update128(ctx, st, Lop, ldl, wbuf(ctx, p), K, r0, q / W, 1, /*bulk=*/true, 0, r1, 0, g.panel_c0(p), 1, 0, ctx->head_waves);
+    };
+    // the panel message of p: owner sends (its pack is behind ev_fact), everyone else joins
+    auto bcast_big = [&](int64_t p) -> int {
+        const size_t bytes = msg_of(p);
+        if (!bytes) return 0;
+        const int b = (int)(p & 1);
+        if (own(p)) DIST_HIP(hipStreamWaitEvent(cs, D->ev_fact[b], 0));
+        else DIST_HIP(hipStreamWaitEvent(cs, D->ev_free[b], 0));
+        size_t sp; int r = span_begin(ctx, D, 2, cs, &sp); if (r) return r;
+        r = ex_bcast(ctx, D, D->msg[b], bytes, g.owner(p), cs); if (r) return r;
         r = span_end(ctx, D, sp, cs); if (r) return r;
         DIST_HIP(hipEventRecord(D->ev_msg[b], cs));
-        if (own) DIST_HIP(hipEventRecord(D->ev_free[b], cs));           // an owner's buffer is free once the message has left
+        if (own(p)) DIST_HIP(hipEventRecord(D->ev_free[b], cs));        // an owner's buffer is free once the message has left
         D->bytes_sent += bytes; D->n_msgs++;
         return 0;
     };
+    // bulk update from panel p of the owned panels beyond `after`; with slices the panel this rank factors next goes first
+    // (its own launch, then an event: that panel's early phase waits for nothing else of the main stream)
+    auto bulk_from = [&](int64_t p, int64_t after) -> int {
+        int64_t nf = after + 1;
+        while (nf < np && !own(nf)) ++nf;
+        if (nf >= np) return 0;
+        if (slices_on) {
+            int r = update_range(ctx, p, nf, 1, main); if (r) return r;
+            DIST_HIP(hipEventRecord(D->ev_pre, main)); pre_rec = true;
+            return update_range(ctx, p, nf + 1, np, main);
+        }
+        return update_range(ctx, p, nf, np, main);
+    };
 
-    rc = post(0, main); if (rc) return rc;
+    // ---- panel 0: its owner factors it whole on the main stream ------------------------------------------------------------
+    std::vector<char> on_side((size_t)np, 0);
+    if (own(0)) {
+        size_t sp; rc = span_begin(ctx, D, 0, main, &sp); if (rc) return rc;
+        rc = factor_panel(ctx, 0, main, false); if (rc) return rc;
+        if (sl(0)) { rc = pack_s(0, 1, main); if (rc) return rc; rc = pack_s(0, 2, main); if (rc) return rc; }
+        rc = span_end(ctx, D, sp, main); if (rc) return rc;
+        rc = finish_panel(0, main); if (rc) return rc;
+    }
+    if (sl(0)) { rc = xchg_s(0, 1); if (rc) return rc; }
     int64_t fwd_next = 0;                                               // first panel whose forward step is not enqueued yet
-    for (int64_t p = 0; p < np; ++p) {
-        if (below(p) <= 0) break;
-        const int b = (int)(p & 1);
-        const bool own = g.owner(p) == g.rank;
-        if (own) {
-            if (on_side[(size_t)p]) DIST_HIP(hipStreamWaitEvent(main, D->ev_fact[b], 0));     // factored on the side stream
-        } else if (has_msg[(size_t)p]) {
+    for (int64_t k = 0; k < np; ++k) {
+        if (below(k) <= 0) break;
+        const int b = (int)(k & 1);
+        const int64_t nxt = k + 1;
+        const bool early = sl(k);                                       // panel k + 1 is factored in pieces, on slices of panel k
+        const int64_t c1n = nxt < np ? g.panel_c0(nxt) : g.Npad, c2n = nxt + 1 < np ? g.panel_c0(nxt + 1) : g.Npad,
+                      c3n = nxt + 2 < np ? g.panel_c0(nxt + 2) : g.Npad;
+        size_t sp_chain = (size_t)-1;
+        if (early) {
+            // (1) slice 2 of panel k, (2) the early phase of panel k + 1 on its owner, (3) slice 1 of panel k + 1, (4) the panel
+            // message of k -- in this order on every rank's collective stream
+            rc = xchg_s(k, 2); if (rc) return rc;
+            if (own(nxt)) {
+                const int64_t ldE1 = c2n - c1n;
+                if (pre_rec) DIST_HIP(hipStreamWaitEvent(side, D->ev_pre, 0));   // the main stream's updates of panel k + 1's columns
+                DIST_HIP(hipStreamWaitEvent(side, D->ev_srecv[b][0], 0));
+                rc = span_begin(ctx, D, 0, side, &sp_chain); if (rc) return rc;   // (chain path: work only, not the wait for a slice)
+                rc = unpack_slice(ctx, k, 1, D->sbuf[b][0], D->EL[0], side); if (rc) return rc;
+                DIST_HIP(hipEventRecord(D->ev_sfree[b][0], side)); sfree_rec[b][0] = true;
+                rc = head_rows(k, nxt, c1n, c2n, D->EL[0] - c1n, ldE1, side, true); if (rc) return rc;
+                rc = panel_chain(ctx, nxt, side); if (rc) return rc;
+                if (c3n > c2n) {
+                    rc = span_end(ctx, D, sp_chain, side); if (rc) return rc;
+                    DIST_HIP(hipStreamWaitEvent(side, D->ev_srecv[b][1], 0));
+                    rc = span_begin(ctx, D, 0, side, &sp_chain); if (rc) return rc;
+                    rc = unpack_slice(ctx, k, 2, D->sbuf[b][1], D->EL[1], side); if (rc) return rc;
+                    DIST_HIP(hipEventRecord(D->ev_sfree[b][1], side)); sfree_rec[b][1] = true;
+                    rc = head_rows(k, nxt, c2n, c3n, D->EL[1] - c2n, c3n - c2n, side, true); if (rc) return rc;
+                    rc = panel_rows(ctx, nxt, c2n, c3n, side); if (rc) return rc;
+                }
+                if (sl(nxt)) { rc = pack_s(nxt, 1, side); if (rc) return rc; }
+                rc = span_end(ctx, D, sp_chain, side); if (rc) return rc;
+                on_side[(size_t)nxt] = 1;
+            }
+            if (sl(nxt)) { rc = xchg_s(nxt, 1); if (rc) return rc; }
+        }
+        rc = bcast_big(k); if (rc) return rc;
+        // ---- main stream: panel k becomes available here ------------------------------------------------------------------
+        if (own(k)) {
+            if (on_side[(size_t)k]) DIST_HIP(hipStreamWaitEvent(main, D->ev_fact[b], 0));     // completed on the side stream
+        } else if (msg_of(k) > 0) {
             DIST_HIP(hipStreamWaitEvent(main, D->ev_msg[b], 0));
             size_t sp; rc = span_begin(ctx, D, 3, main, &sp); if (rc) return rc;
-            rc = pyipm_newton_panel_unpack(reinterpret_cast<pyipm_newton_ctx*>(ctx), p, D->msg[b]); if (rc) return rc;
+            const bool got_slices = early && own(nxt);
+            { StreamScope sc(ctx, main); rc = unpack_panel_from(ctx, k, D->msg[b], got_slices ? c3n : (int64_t)0, !got_slices, main); }
+            if (rc) return rc;
             rc = span_end(ctx, D, sp, main); if (rc) return rc;
             DIST_HIP(hipEventRecord(D->ev_free[b], main));
         }
-        const int64_t nxt = p + 1;
-        if (nxt < np) {
-            if (g.owner(nxt) == g.rank) {
-                // head: bring panel p+1 up to date first.  The owner's chain is every rank's critical path (across ranks the
-                // per-rank bulk work shrinks with the number of ranks, the chain does not), and the tile chain of a wide panel
-                // needs the head only INSIDE the panel's diagonal block: that part first (a 1024 x 1024 block at nb = 1024,
-                // 32-row blocks), the chain starts behind it; the rows below -- 97 % of the head's flops -- follow on ctx->rest,
-                // where the panel's rows kernels first read them (factor_block).  The same entries, the same products in the
-                // same order (round 4; the single-rank schedule's head_split).
-                const int64_t c0n = g.panel_c0(nxt), nbwn = g.panel_w(nxt);
+        if (nxt < np && own(nxt)) {
+            const bool mine_k = own(k);
+            const double* Lop = mine_k ? ctx->A + g.local_c0(k) * g.Npad : ctx->Lbuf;
+            if (early) {
+                // the rest of panel k + 1: the head from panel k on the rows beyond the slices (main stream: behind the unpack),
+                // then on the side stream its rows of panel k + 3 (slice 2 of panel k + 1 goes out in the next slot), the
+                // remaining rows, and the panel message
+                const int64_t c4n = nxt + 3 < np ? g.panel_c0(nxt + 3) : g.Npad;
+                rc = head_rows(k, nxt, c3n, g.Npad, Lop, g.Npad, main, false); if (rc) return rc;
+                DIST_HIP(hipEventRecord(D->ev_hr, main));
+                DIST_HIP(hipStreamWaitEvent(side, D->ev_hr, 0));
+                size_t sp_rest; rc = span_begin(ctx, D, 4, side, &sp_rest); if (rc) return rc;
+                rc = panel_rows(ctx, nxt, c3n, c4n, side); if (rc) return rc;
+                if (sl(nxt)) { rc = pack_s(nxt, 2, side); if (rc) return rc; }
+                rc = panel_rows(ctx, nxt, c4n, g.Npad, side); if (rc) return rc;
+                rc = span_end(ctx, D, sp_rest, side); if (rc) return rc;
+                rc = finish_panel(nxt, side); if (rc) return rc;
+            } else {
+                // classic: the whole head on the main stream, the whole panel on the side stream behind it
+                const int64_t nbwn = g.panel_w(nxt);
                 const bool wide_next = ctx->dist_head_split && ctx->tile_step && ctx->inpanel32 && ctx->wide_sub >= 128 &&
-                                       ctx->wide_sub % 128 == 0 && nbwn > ctx->wide_sub && nbwn / TB <= 32 && c0n + nbwn < g.Npad &&
-                                       !panel_in_s(ctx, nxt) && !panel_in_s(ctx, p) && nbwn % 32 == 0;
-                if (wide_next) {
-                    const bool mine_p = g.owner(p) == g.rank;
-                    const double* Lop = mine_p ? ctx->A + g.local_c0(p) * g.Npad : ctx->Lbuf;
-                    const int K = (int)g.panel_w(p);
-                    int64_t pa0, pa1, pb0, pb1;
-                    active_ranges(ctx, g.panel_c0(p), g.panel_c0(p) + K, &pa0, &pa1, &pb0, &pb1);
-                    rc = ensure_rest_stream(ctx); if (rc) return rc;
-                    hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)(nbwn / 32), (unsigned)(nbwn / TB)), dim3(256), 0, main,
-                                       ctx->A, g.Npad, g.local_c0(nxt), Lop, g.Npad, wbuf(ctx, p), g.Npad, c0n, K, c0n, g.Npad,
-                                       pa0, pa1, pb0, pb1, ctx->side_prio);
-                    DIST_KCHECK();
+                                       ctx->wide_sub % 128 == 0 && nbwn > ctx->wide_sub && nbwn / TB <= 32 && c1n + nbwn < g.Npad &&
+                                       !panel_in_s(ctx, nxt) && !panel_in_s(ctx, k) && nbwn % 32 == 0;
+                if (panel_in_s(ctx, k) || panel_in_s(ctx, nxt)) {
+                    rc = update_range(ctx, k, nxt, 1, main); if (rc) return rc;
                     DIST_HIP(hipEventRecord(D->ev_head, main));
                     DIST_HIP(hipStreamWaitEvent(side, D->ev_head, 0));
-                    DIST_HIP(hipStreamWaitEvent(ctx->rest, D->ev_head, 0));           // (the main stream's earlier updates of these columns)
-                    const int64_t rb = c0n + nbwn;
-                    if (g.Npad - rb <= ctx->head32_rows_dist) {
-                        hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - rb) / 32), (unsigned)(nbwn / TB)), dim3(256), 0,
-                                           ctx->rest, ctx->A, g.Npad, g.local_c0(nxt), Lop, g.Npad, wbuf(ctx, p), g.Npad, c0n, K, rb,
-                                           g.Npad, pa0, pa1, pb0, pb1, ctx->side_prio);
-                        DIST_KCHECK();
-                    } else {
-                        rc = launch_update128(ctx, ctx->rest, Lop, g.Npad, wbuf(ctx, p), K, rb, nxt / g.world, 1, /*bulk=*/true, 0, 0, 0,
-                                              g.panel_c0(p), 1, 0, ctx->head_waves);
-                        if (rc) return rc;
-                    }
+                } else if (wide_next) {
+                    // the tile chain of a wide panel needs the head only INSIDE the panel's diagonal block: that part first, the
+                    // chain starts behind it; the rows below -- 97 % of the head's flops -- follow on ctx->rest, where the panel's
+                    // rows kernels first read them (factor_block).  The same entries, the same products (round 4).
+                    rc = ensure_rest_stream(ctx); if (rc) return rc;
+                    rc = head_rows(k, nxt, c1n, c2n, Lop, g.Npad, main, true); if (rc) return rc;
+                    DIST_HIP(hipEventRecord(D->ev_head, main));
+                    DIST_HIP(hipStreamWaitEvent(side, D->ev_head, 0));
+                    DIST_HIP(hipStreamWaitEvent(ctx->rest, D->ev_head, 0));       // (the main stream's earlier updates of these columns)
+                    rc = head_rows(k, nxt, c2n, g.Npad, Lop, g.Npad, ctx->rest, false); if (rc) return rc;
                 } else {
-                    rc = update_range(ctx, p, nxt, 1, main); if (rc) return rc;
+                    rc = head_rows(k, nxt, c1n, g.Npad, Lop, g.Npad, main, false); if (rc) return rc;
                     DIST_HIP(hipEventRecord(D->ev_head, main));
                     DIST_HIP(hipStreamWaitEvent(side, D->ev_head, 0));
                 }
+                size_t sp; rc = span_begin(ctx, D, 0, side, &sp); if (rc) return rc;
+                rc = factor_panel(ctx, nxt, side, false); if (rc) return rc;
+                if (sl(nxt)) { rc = pack_s(nxt, 1, side); if (rc) return rc; rc = pack_s(nxt, 2, side); if (rc) return rc; }
+                rc = span_end(ctx, D, sp, side); if (rc) return rc;
+                rc = finish_panel(nxt, side); if (rc) return rc;
                 on_side[(size_t)nxt] = 1;
-                rc = post(nxt, side); if (rc) return rc;
-            } else {
-                rc = post(nxt, nullptr); if (rc) return rc;                               // joins the broadcast of p+1 ...
             }
-            rc = update_range(ctx, p, nxt + 1, np, main); if (rc) return rc;              // ... while everyone runs the bulk of update p
         }
+        if (!early && sl(nxt)) { rc = xchg_s(nxt, 1); if (rc) return rc; }       // (classic panel k + 1: its slice 1 follows the panel message of k)
+        rc = bulk_from(k, nxt); if (rc) return rc;                                // everyone's share of the bulk update of panel k
         // last in the iteration: the host submits the next panel's chain first (in the chain-bound tail the GPU is
         // waiting for exactly those launches; with the forward step submitted ahead of them the factorisation grew by as
         // much as the sweep shrank)
-        rc = fwd_step(p); if (rc) return rc;
-        fwd_next = p + 1;
+        rc = fwd_step(k); if (rc) return rc;
+        fwd_next = k + 1;
     }
     for (int64_t p = fwd_next; p < np; ++p) { rc = fwd_step(p); if (rc) return rc; }
     if (fwd_b) {
@@ -625,6 +788,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
     // join the helper streams (the last panel may have been factored on the side stream; messages in flight)
     DIST_HIP(hipEventRecord(D->ev_join, side)); DIST_HIP(hipStreamWaitEvent(main, D->ev_join, 0));
     DIST_HIP(hipEventRecord(D->ev_head, cs));   DIST_HIP(hipStreamWaitEvent(main, D->ev_head, 0));
+    if (ctx->rest) { DIST_HIP(hipEventRecord(D->ev_join, ctx->rest)); DIST_HIP(hipStreamWaitEvent(main, D->ev_join, 0)); }
     DIST_HIP(hipEventRecord(ctx->ev[1], main));
     ctx->assembled = false;
     pyipm_factor_stats loc;
@@ -634,15 +798,17 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
     {   float ms = 0.f; DIST_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); D->t_factor = ms; ctx->t_factor = ms; }
     if (ctx->profile) {
         D->t_chain = D->t_pack = D->t_bcast = D->t_unpack = 0.0;
+        double t_rest = 0.0;
         DIST_HIP(hipStreamSynchronize(cs)); DIST_HIP(hipStreamSynchronize(side));
         for (auto& s : D->spans) {
             float ms = 0.f; DIST_HIP(hipEventElapsedTime(&ms, s.a, s.b));
-            (s.kind == 0 ? D->t_chain : s.kind == 1 ? D->t_pack : s.kind == 2 ? D->t_bcast : D->t_unpack) += ms;
+            (s.kind == 0 ? D->t_chain : s.kind == 1 ? D->t_pack : s.kind == 2 ? D->t_bcast : s.kind == 3 ? D->t_unpack : t_rest) += ms;
         }
         ctx->t_panel = D->t_chain;
+        D->wire[10] = t_rest;           // ms of the owner's rows work BEHIND the chain path (two-message protocol)
     }
     // statistics over the ranks: counts add, extrema combine
-    if (g.world > 1) {
+    if (W > 1) {
         double h[8] = {(double)loc.n_neg, (double)loc.n_zero, (double)loc.n_2x2, (double)loc.n_pos, (double)loc.nonfinite,
                        loc.d_max, loc.growth, -loc.d_min};
         DIST_HIP(hipMemcpyAsync(D->small, h, sizeof(h), hipMemcpyHostToDevice, main));

@@ -177,23 +177,18 @@ __global__ __launch_bounds__(256) void k_bc_prep(BatchPtrs bp, Geo g, double mu,
 }
 
 // Condensed form, step 2: the matrix  [[H + delta I + Ji_I Sigma_I Ji_I', Je, Ji_A], [Je', -delta_c I, 0], [Ji_A', 0, -1/Sigma_A]]
-// (lower triangle, identity pad up to the next multiple of 64) of problem blockIdx.y, one 64 x 64 tile per workgroup
-// (blockIdx.x enumerates the lower-triangular tile pairs of the LARGEST possible system; tiles beyond this problem's return).
+// (lower triangle, identity pad up to the next multiple of 64) of problem blockIdx.y, 64 x 64 tiles.  Workgroups 0 .. T0 - 1
+// take one tile each of the first nt0 = ceil((n + me) / 64) tile rows (every problem has those: the x-x tiles with their Gram
+// part and the lambda_e rows); workgroup T0 walks over the tile rows that exist only where a problem keeps active inequality
+// rows (|A| > 0: late in a run) -- copies of Jacobian columns and a diagonal, no products -- and returns at once otherwise.
+// (A grid over the tile pairs of the LARGEST possible system started 13000 workgroups per launch only to return: 0.1 ms.)
 // The Gram part of an x-x tile is formed on the matrix pipe: both operand tiles of a 64-column chunk of Ji staged through
-// shared memory (coalesced along the rows of the row-major Ji), the Sigma scaling applied to one of them on the way.
-__global__ __launch_bounds__(256) void k_bc_assemble(BatchPtrs bp, Geo g, double eps, double delta, double delta_c, BatchCond bc)
+// shared memory (coalesced along the rows of the row-major Ji), the Sigma scaling applied to one of them on the way, the next
+// chunk's loads in flight under the products of the current one.
+__device__ __forceinline__ void bc_store_tile(const BatchPtrs& bp, const Geo& g, const BatchCond& bc, int64_t b, int rt, int ct,
+                                              const double4_t (&acc)[4], double eps, double delta, double delta_c, int na)
 {
-    __shared__ double XA[TB][TB + 2];
-    __shared__ double XB[TB][TB + 2];
-    const int64_t b = blockIdx.y;
-    int rt = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
-    while (rt * (rt + 1) / 2 > (int)blockIdx.x) --rt;
-    while ((rt + 1) * (rt + 2) / 2 <= (int)blockIdx.x) ++rt;
-    const int ct = (int)blockIdx.x - rt * (rt + 1) / 2;
-    const int64_t n = g.n, me = g.me, mi = g.mi, ld = g.Npad;
-    const int na = bc.cnt[b];
-    const int64_t nc = n + me + na;
-    if ((int64_t)rt * TB >= nc) return;
+    const int64_t n = g.n, me = g.me, mi = g.mi, ld = g.Npad, nc = n + me + na;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     double* A = bp.A + b * bp.sA;
@@ -203,47 +198,13 @@ __global__ __launch_bounds__(256) void k_bc_assemble(BatchPtrs bp, Geo g, double
     const double* s = bp.s + b * mi;
     const double* lda = bp.lda + b * (me + mi);
     const int* idx = bc.idx + b * bc.sP;
-    const int64_t i0 = (int64_t)rt * TB, j0 = (int64_t)ct * TB;
-    double4_t acc[4];
-    #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    if (j0 < n && i0 < n && mi > 0) {
-        const double* sig = bc.sig + b * bc.sP;
-        const int kk = tid & 63, r0q = tid >> 6;             // this thread stages column kk of rows r0q + 4 q of both operand tiles
-        double va[TB * TB / 256], vb[TB * TB / 256];
-        auto fetch = [&](int64_t kc) {                        // (all 32 loads of a thread in flight together)
-            const bool kin = kc + kk < mi;
-            const double sg = kin ? sig[kc + kk] : 0.0;
-            #pragma unroll
-            for (int q = 0; q < TB * TB / 256; ++q) {
-                const int r = r0q + 4 * q;
-                va[q] = (kin && j0 + r < n) ? Ji[(j0 + r) * bp.ldji + kc + kk] : 0.0;
-                vb[q] = (kin && i0 + r < n) ? sg * Ji[(i0 + r) * bp.ldji + kc + kk] : 0.0;
-            }
-        };
-        fetch(0);
-        for (int64_t kc = 0; kc < mi; kc += TB) {
-            if (kc > 0) __syncthreads();
-            #pragma unroll
-            for (int q = 0; q < TB * TB / 256; ++q) { XA[r0q + 4 * q][kk] = va[q]; XB[r0q + 4 * q][kk] = vb[q]; }
-            __syncthreads();
-            if (kc + TB < mi) fetch(kc + TB);                 // the next chunk's loads fly under this chunk's products
-            #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) {
-                const double bop = XB[wave * 16 + l15][ks * 4 + l4];
-                #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(XA[t * 16 + l15][ks * 4 + l4], bop, acc[t], 0, 0, 0);
-            }
-        }
-    }
-    const int64_t i = i0 + wave * 16 + l15;
+    const int64_t i = (int64_t)rt * TB + wave * 16 + l15;
     double amax = 0.0;
     #pragma unroll
     for (int t = 0; t < 4; ++t)
         #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int64_t c = j0 + t * 16 + l4 + 4 * r;
+            const int64_t c = (int64_t)ct * TB + t * 16 + l4 + 4 * r;
             if (i < c) continue;
             double v = 0.0;
             bool scale = true;
@@ -260,6 +221,87 @@ __global__ __launch_bounds__(256) void k_bc_assemble(BatchPtrs bp, Geo g, double
             if (scale) amax = fmax(amax, fabs(v));      // (1 / Sigma stays out of the static-pivot scale, as Sigma does in the full form)
         }
     anorm_publish(bp.anorm + 2 * b, amax);
+}
+
+__global__ __launch_bounds__(256) void k_bc_assemble(BatchPtrs bp, Geo g, double eps, double delta, double delta_c, BatchCond bc, int nt0)
+{
+    __shared__ double XA[TB][TB + 2];
+    __shared__ double XB[TB][TB + 2];
+    const int64_t b = blockIdx.y;
+    const int64_t n = g.n, me = g.me, mi = g.mi;
+    const int na = bc.cnt[b];
+    const int64_t nc = n + me + na;
+    const int T0 = nt0 * (nt0 + 1) / 2;
+    double4_t acc[4];
+    #pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    if ((int)blockIdx.x >= T0) {
+        const int ntc = (int)((nc + TB - 1) / TB);
+        for (int rt = nt0; rt < ntc; ++rt)
+            for (int ct = 0; ct <= rt; ++ct) bc_store_tile(bp, g, bc, b, rt, ct, acc, eps, delta, delta_c, na);
+        return;
+    }
+    int rt = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+    while (rt * (rt + 1) / 2 > (int)blockIdx.x) --rt;
+    while ((rt + 1) * (rt + 2) / 2 <= (int)blockIdx.x) ++rt;
+    const int ct = (int)blockIdx.x - rt * (rt + 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t i0 = (int64_t)rt * TB, j0 = (int64_t)ct * TB;
+    if (j0 < n && i0 < n && mi > 0) {
+        const double* Ji = bp.Ji + b * bp.sJi;
+        const double* sig = bc.sig + b * bc.sP;
+        const int kk = tid & 63, r0q = tid >> 6;             // this thread stages column kk of rows r0q + 4 q of both operand tiles
+        const double* pa = Ji + (j0 + r0q) * bp.ldji + kk;   // rows j0 + r0q + 4 q of the column-block operand
+        const double* pb = Ji + (i0 + r0q) * bp.ldji + kk;   // rows i0 + r0q + 4 q of the row-block operand (scaled)
+        const int64_t step = 4 * bp.ldji;
+        const bool full = j0 + TB <= n && i0 + TB <= n && (mi % TB) == 0;     // no masks anywhere (block-uniform)
+        double va[16], vb[16];
+        // chunk 0
+        if (full) {
+            const double sg = sig[kk];
+            #pragma unroll
+            for (int q = 0; q < 16; ++q) { va[q] = pa[q * step]; vb[q] = sg * pb[q * step]; }
+        } else {
+            const bool kin = kk < mi;
+            const double sg = kin ? sig[kk] : 0.0;
+            #pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                va[q] = (kin && j0 + r0q + 4 * q < n) ? pa[q * step] : 0.0;
+                vb[q] = (kin && i0 + r0q + 4 * q < n) ? sg * pb[q * step] : 0.0;
+            }
+        }
+        for (int64_t kc = 0; kc < mi; kc += TB) {
+            if (kc > 0) __syncthreads();
+            #pragma unroll
+            for (int q = 0; q < 16; ++q) { XA[r0q + 4 * q][kk] = va[q]; XB[r0q + 4 * q][kk] = vb[q]; }
+            __syncthreads();
+            const int64_t kn = kc + TB;
+            if (kn < mi) {                                    // the next chunk's loads fly under this chunk's products
+                if (full) {
+                    const double sg = sig[kn + kk];
+                    #pragma unroll
+                    for (int q = 0; q < 16; ++q) { va[q] = pa[kn + q * step]; vb[q] = sg * pb[kn + q * step]; }
+                } else {
+                    const bool kin = kn + kk < mi;
+                    const double sg = kin ? sig[kn + kk] : 0.0;
+                    #pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        va[q] = (kin && j0 + r0q + 4 * q < n) ? pa[kn + q * step] : 0.0;
+                        vb[q] = (kin && i0 + r0q + 4 * q < n) ? sg * pb[kn + q * step] : 0.0;
+                    }
+                }
+            }
+            #pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const double bop = XB[wave * 16 + l15][ks * 4 + l4];
+                #pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(XA[t * 16 + l15][ks * 4 + l4], bop, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    if ((int64_t)rt * TB < nc) bc_store_tile(bp, g, bc, b, rt, ct, acc, eps, delta, delta_c, na);
 }
 
 // Backward error of a batch of directions against the KKT blocks (never the factor): out[b] = |g - Hc raw| / |g| with raw the
@@ -280,13 +322,32 @@ __global__ __launch_bounds__(256) void k_b_berr(BatchPtrs bp, Geo g, const doubl
     const double* lda = bp.lda + b * (me + mi);
     const double* dx = d; const double* ds = d + n; const double* dle = d + n + mi; const double* dli = d + n + mi + me;   // (flipped)
     double rr = 0.0, gg = 0.0;
-    for (int64_t j = wave; j < n; j += 4) {                  // x rows: sym(triu(d2L)) dx + delta dx + Je dle + Ji dli
-        double acc = 0.0;
-        for (int64_t i = lane; i < n; i += 64) acc += (i >= j ? d2L[j * bp.ldh + i] : d2L[i * bp.ldh + j]) * dx[i];
-        if (me) { const double* r = bp.Je + b * bp.sJe + j * bp.ldje; for (int64_t a = lane; a < me; a += 64) acc -= r[a] * dle[a]; }
-        if (mi) { const double* r = bp.Ji + b * bp.sJi + j * bp.ldji; for (int64_t a = lane; a < mi; a += 64) acc -= r[a] * dli[a]; }
-        acc = wave_sum(acc);
-        if (lane == 0) { const double r = gr[j] - (acc + delta * dx[j]); rr += r * r; gg += gr[j] * gr[j]; }
+    for (int64_t j0 = (int64_t)wave * 4; j0 < n; j0 += 16) {    // x rows, four per trip: sym(triu(d2L)) dx + delta dx + Je dle + Ji dli
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int64_t i = lane; i < n; i += 64) {
+            const double xi = dx[i];
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t j = j0 + q;
+                if (j < n) acc[q] += (i >= j ? d2L[j * bp.ldh + i] : d2L[i * bp.ldh + j]) * xi;
+            }
+        }
+        for (int64_t a = lane; a < me; a += 64) {
+            const double v = dle[a];
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) if (j0 + q < n) acc[q] -= bp.Je[b * bp.sJe + (j0 + q) * bp.ldje + a] * v;
+        }
+        for (int64_t a = lane; a < mi; a += 64) {
+            const double v = dli[a];
+            #pragma unroll
+            for (int q = 0; q < 4; ++q) if (j0 + q < n) acc[q] -= bp.Ji[b * bp.sJi + (j0 + q) * bp.ldji + a] * v;
+        }
+        #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double a_ = wave_sum(acc[q]);
+            const int64_t j = j0 + q;
+            if (lane == 0 && j < n) { const double r = gr[j] - (a_ + delta * dx[j]); rr += r * r; gg += gr[j] * gr[j]; }
+        }
     }
     for (int64_t k = tid; k < mi; k += 256) {                // s rows and lambda_i rows
         double u = 0.0;

@@ -721,6 +721,168 @@ int factor_wide_panel(Ctx* ctx, int64_t p, hipStream_t stream) {
     return factor_block(ctx, bd, stream, [](int64_t, hipStream_t) { return 0; });
 }
 
+// ---- per-panel schedule, a panel in pieces (round 5: the two-message protocol of the distributed driver, dist_impl.hpp) ------
+// The owner of panel p + 1 starts that panel's tile chain as soon as the rows of panel p that meet ITS diagonal block have
+// arrived (a slice message, nb x nb); the rows below follow when their operands do.  A panel's rows below its diagonal block
+// do not interact, so factoring it in pieces -- the tile chain, then the stages of any row range -- runs the same kernels on
+// every entry in the same order as factor_panel does in one go: the same bits (tests/test_gpu_dist.py, tools/rank_replay.py).
+bool panel_piecewise_ok(const Ctx* ctx, int64_t p) {
+    const Geo& g = ctx->g;
+    if (!ctx->tile_step || !ctx->inpanel32 || panel_in_s(ctx, p)) return false;
+    const int nbw = (int)g.panel_w(p), nt = nbw / TB;
+    const bool wide = ctx->wide_sub >= 128 && ctx->wide_sub % 128 == 0 && nbw > ctx->wide_sub;
+    return wide ? (nt <= 32) : (nt <= 16);
+}
+// the tile steps of panel p's diagonal block (all that needs is the diagonal block up to date)
+int panel_chain(Ctx* ctx, int64_t p, hipStream_t stream) {
+    const Geo& g = ctx->g;
+    const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
+    const int nt = (int)(g.panel_w(p) / TB);
+    return launch_tile_steps(ctx, stream, c0, lc0, nt, 0, nt, wbuf(ctx, p), ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB),
+                             ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB));
+}
+// every stage of panel p for the rows [r0, r1) below its diagonal block (128-aligned), the chain complete on `stream` before
+int panel_rows(Ctx* ctx, int64_t p, int64_t r0, int64_t r1, hipStream_t stream) {
+    const Geo& g = ctx->g;
+    if (r1 > g.Npad) r1 = g.Npad;
+    if (r1 <= r0) return 0;
+    const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p), TT = (int64_t)TB * TB;
+    const int nbw = (int)g.panel_w(p), nt = nbw / TB;
+    double* W = wbuf(ctx, p);
+    int64_t hole0 = 0, hole1 = 0;
+    panel_hole(ctx, p, &hole0, &hole1);
+    const bool wide = ctx->wide_sub >= 128 && ctx->wide_sub % 128 == 0 && nbw > ctx->wide_sub;
+    if (!wide) {
+        hipLaunchKernelGGL(k_panel_rest, dim3((unsigned)((r1 - r0) / TB)), dim3(256), 0, stream, ctx->A, g.Npad, c0, lc0, nt, r0,
+                           W, g.Npad, ctx->Dinv + (c0 / TB) * TT, ctx->Tsv + (c0 / TB) * TT, ctx->Tflag + c0 / TB,
+                           ctx->block_refine, hole0, hole1, &ctx->dstats->growth_bits);
+        PYIPM_KCHECK();
+        return 0;
+    }
+    // a wide panel: sub-panel by sub-panel as factor_block does below a diagonal block (left-looking MFMA in-panel updates while
+    // many rows remain below the panel, right-looking one source at a time in the tail: decided by the PANEL, so every row range
+    // of it takes the same kernels)
+    const int snt = ctx->wide_sub / TB;
+    const int64_t gend = c0 + nbw, lp = p / g.world;
+    const bool left = ctx->pending_left_rows >= 0 && g.Npad - gend > ctx->pending_left_rows;
+    for (int t = 0; t < nt; t += snt) {
+        const int w = nt - t < snt ? nt - t : snt;
+        const int64_t sc0 = c0 + (int64_t)t * TB, slc0 = lc0 + (int64_t)t * TB;
+        double* sW = W + (int64_t)t * TB * g.Npad;
+        if (left && t > 0) {
+            int rc = launch_update128(ctx, stream, ctx->A + lc0 * g.Npad, g.Npad, W, t * TB, r0, lp, 1, /*bulk=*/false, 0, r1, 0, c0,
+                                      1, 0, 0, 0, nullptr, nullptr, false, (t * TB) / 128, (w * TB) / 128);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_panel_rest, dim3((unsigned)((r1 - r0) / TB)), dim3(256), 0, stream, ctx->A, g.Npad, sc0, slc0, w, r0,
+                           sW, g.Npad, ctx->Dinv + (sc0 / TB) * TT, ctx->Tsv + (sc0 / TB) * TT, ctx->Tflag + sc0 / TB,
+                           ctx->block_refine, hole0, hole1, &ctx->dstats->growth_bits);
+        PYIPM_KCHECK();
+        if (!left && t + w < nt) {
+            const int K = w * TB;
+            const int64_t tc0 = sc0 + K, ncols = (int64_t)(nt - t - w) * TB;
+            if (g.Npad - tc0 <= ctx->pending32_rows) {
+                int64_t pa0, pa1, pb0, pb1;
+                active_ranges(ctx, sc0, sc0 + K, &pa0, &pa1, &pb0, &pb1);
+                hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((r1 - r0) / 32), (unsigned)(ncols / TB)), dim3(256), 0, stream,
+                                   ctx->A, g.Npad, slc0 + K, ctx->A + slc0 * g.Npad, g.Npad, sW, g.Npad, tc0, K, r0, g.Npad,
+                                   pa0, pa1, pb0, pb1, ctx->side_prio);
+                PYIPM_KCHECK();
+            } else {
+                int rc = launch_update128(ctx, stream, ctx->A + slc0 * g.Npad, g.Npad, sW, K, r0, lp, 1, /*bulk=*/false, 0, r1, 0, sc0,
+                                          1, 0, 0, 0, nullptr, nullptr, false, ((t + w) * TB) / 128, (int)(ncols / 128));
+                if (rc) return rc;
+            }
+        }
+    }
+    return 0;
+}
+
+// Slice j (1 or 2) of panel p: the rows of panel p + j, i.e. W rows [c0(p + j), c0(p + j) + w(p + j)) of all the panel's columns
+// (leading dimension = the slice's rows); slice 1 also carries the panel's tile inverses, tiles and flags.
+int64_t slice_rows(const Geo& g, int64_t p, int j, int64_t* r0) {
+    if (p + j >= g.npanels) { *r0 = g.Npad; return 0; }
+    *r0 = g.panel_c0(p + j);
+    return g.panel_w(p + j);
+}
+size_t slice_numel(const Geo& g, int64_t p, int j) {
+    int64_t r0; const int64_t E = slice_rows(g, p, j, &r0), nbw = g.panel_w(p);
+    if (E <= 0) return 0;
+    return (size_t)(E * nbw + (j == 1 ? 2 * (nbw / TB) * TB * TB + nbw / TB : 0));
+}
+int pack_slice(Ctx* ctx, int64_t p, int j, double* buf, hipStream_t st) {
+    const Geo& g = ctx->g;
+    int64_t r0; const int64_t E = slice_rows(g, p, j, &r0), nbw = g.panel_w(p), c0 = g.panel_c0(p);
+    if (E <= 0) return 0;
+    PYIPM_HIP(hipMemcpy2DAsync(buf, (size_t)E * sizeof(double), wbuf(ctx, p) + r0, (size_t)g.Npad * sizeof(double),
+                               (size_t)E * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, st));
+    if (j == 1) {
+        const size_t tb = (size_t)(nbw / TB) * TB * TB;
+        PYIPM_HIP(hipMemcpyAsync(buf + E * nbw, ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB), tb * sizeof(double), hipMemcpyDeviceToDevice, st));
+        PYIPM_HIP(hipMemcpyAsync(buf + E * nbw + tb, ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB), tb * sizeof(double), hipMemcpyDeviceToDevice, st));
+        PYIPM_HIP(hipMemcpyAsync(buf + E * nbw + 2 * tb, ctx->Tflag + c0 / TB, (size_t)(nbw / TB) * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    return 0;
+}
+// receiver: the W rows go where the panel message would put them, L = W inv(T) of those rows into `EL` (E x nbw, leading dimension E)
+int unpack_slice(Ctx* ctx, int64_t p, int j, const double* buf, double* EL, hipStream_t st) {
+    const Geo& g = ctx->g;
+    int64_t r0; const int64_t E = slice_rows(g, p, j, &r0), nbw = g.panel_w(p), c0 = g.panel_c0(p);
+    if (E <= 0) return 0;
+    double* dinv = ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB);
+    double* tsv = ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB);
+    if (j == 1) {
+        const size_t tb = (size_t)(nbw / TB) * TB * TB;
+        PYIPM_HIP(hipMemcpyAsync(dinv, buf + E * nbw, tb * sizeof(double), hipMemcpyDeviceToDevice, st));
+        PYIPM_HIP(hipMemcpyAsync(tsv, buf + E * nbw + tb, tb * sizeof(double), hipMemcpyDeviceToDevice, st));
+        PYIPM_HIP(hipMemcpyAsync(ctx->Tflag + c0 / TB, buf + E * nbw + 2 * tb, (size_t)(nbw / TB) * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    PYIPM_HIP(hipMemcpy2DAsync(wbuf(ctx, p) + r0, (size_t)g.Npad * sizeof(double), buf, (size_t)E * sizeof(double),
+                               (size_t)E * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, st));
+    int64_t h0, h1;
+    panel_hole(ctx, p, &h0, &h1);
+    NextUpd nu_off; memset(&nu_off, 0, sizeof(nu_off));
+    hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(E / TB), (unsigned)(nbw / TB)), dim3(256), 0, st,
+                       EL - r0, E, (int64_t)0, wbuf(ctx, p), g.Npad, (int64_t)0, (double*)nullptr, (int64_t)0, (int64_t)0,
+                       dinv, tsv, ctx->Tflag + c0 / TB, ctx->block_refine, r0, h0, h1, (unsigned long long*)nullptr, -1.0, nu_off);
+    PYIPM_KCHECK();
+    return 0;
+}
+// The panel message of p on a receiver, rows from `row_from` on only (the rows before it came as slices), tiles optional.
+int unpack_panel_from(Ctx* ctx, int64_t p, const double* buf, int64_t row_from, bool with_tiles, hipStream_t st) {
+    const Geo& g = ctx->g;
+    int64_t h0, h1;
+    panel_hole(ctx, p, &h0, &h1);
+    const int64_t nbw = g.panel_w(p), c0 = g.panel_c0(p), c1 = c0 + nbw, m = g.Npad - c1 - (h1 - h0);
+    double* dinv = ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB);
+    double* tsv = ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB);
+    if (with_tiles) {
+        const size_t tbytes = (size_t)(nbw / TB) * TB * TB * sizeof(double);
+        PYIPM_HIP(hipMemcpyAsync(dinv, buf + m * nbw, tbytes, hipMemcpyDeviceToDevice, st));
+        PYIPM_HIP(hipMemcpyAsync(tsv, buf + m * nbw + (nbw / TB) * TB * TB, tbytes, hipMemcpyDeviceToDevice, st));
+        PYIPM_HIP(hipMemcpyAsync(ctx->Tflag + c0 / TB, buf + m * nbw + 2 * (nbw / TB) * TB * TB, (size_t)(nbw / TB) * sizeof(double),
+                                 hipMemcpyDeviceToDevice, st));
+    }
+    const int64_t rf = row_from > c1 ? row_from : c1;
+    if (m <= 0 || rf >= g.Npad) return 0;
+    // rows [c1, Npad) without the hole [h0, h1) sit in the message with leading dimension m; copy what lies at or beyond rf
+    const int64_t segs[2][2] = {{c1, (h1 > h0) ? h0 : g.Npad}, {(h1 > h0) ? h1 : g.Npad, g.Npad}};
+    for (int k = 0; k < 2; ++k) {
+        const int64_t a = segs[k][0] > rf ? segs[k][0] : rf, b = segs[k][1];
+        if (b <= a) continue;
+        const int64_t mrow = a - c1 - ((h1 > h0 && a >= h1) ? (h1 - h0) : 0);
+        PYIPM_HIP(hipMemcpy2DAsync(wbuf(ctx, p) + a, (size_t)g.Npad * sizeof(double), buf + mrow, (size_t)m * sizeof(double),
+                                   (size_t)(b - a) * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, st));
+    }
+    NextUpd nu_off; memset(&nu_off, 0, sizeof(nu_off));
+    hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)((g.Npad - rf) / TB), (unsigned)(nbw / TB)), dim3(256), 0, st,
+                       ctx->Lbuf, g.Npad, (int64_t)0, wbuf(ctx, p), g.Npad, (int64_t)0,
+                       (double*)nullptr, (int64_t)0, (int64_t)0, dinv, tsv, ctx->Tflag + c0 / TB, ctx->block_refine, rf, h0, h1,
+                       (unsigned long long*)nullptr, -1.0, nu_off);
+    PYIPM_KCHECK();
+    return 0;
+}
+
 // One bulk k_update<128> launch: panels [p0, p0+np) (contiguous, same rank) applied with K = their total
 // width to local panels [first_lp, first_lp+n_lp); timed with HIP events on the handle's stream.
 int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_lp, hipStream_t stream = nullptr,
@@ -1816,9 +1978,9 @@ int pyipm_newton_step_batched(pyipm_newton_ctx* h, double delta, double delta_c,
         // (s, lambda_i) pairs with Sigma <= condensed_sigma_max eliminated analytically (pyipm.py:824-842's block structure)
         hipLaunchKernelGGL(k_bc_prep, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->mu, ctx->eps, bc);
         PYIPM_KCHECK();
-        const int64_t ntmax = (g.n + g.me + g.mi + TB - 1) / TB;
-        hipLaunchKernelGGL(k_bc_assemble, dim3((unsigned)(ntmax * (ntmax + 1) / 2), (unsigned)B), dim3(256), 0, ctx->stream, bp, g,
-                           ctx->eps, delta, delta_c, bc);
+        const int nt0 = (int)((g.n + g.me + TB - 1) / TB);
+        hipLaunchKernelGGL(k_bc_assemble, dim3((unsigned)(nt0 * (nt0 + 1) / 2 + 1), (unsigned)B), dim3(256), 0, ctx->stream, bp, g,
+                           ctx->eps, delta, delta_c, bc, nt0);
         PYIPM_KCHECK();
     } else {
         hipLaunchKernelGGL(k_b_residual, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->mu, ctx->eps);

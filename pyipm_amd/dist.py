@@ -37,7 +37,11 @@ import numpy as np
 
 
 class DistNewton(object):
-    def __init__(self, core, group=None, stage_through_cpu=None, native=None):
+    def __init__(self, core, group=None, stage_through_cpu=None, native=None, p2p=True, serialize=False, selftest=True):
+        """p2p / serialize / selftest (callback exchange over gloo only): also install the point-to-point half of the exchange
+        (send / recv / all-gather callbacks: the slice messages then travel point to point and the scatter + all-gather panel
+        form becomes available), ask the library to issue every operation on its collective stream (what it does for RCCL), and
+        run the library's exchange self-test (collective) so that the panel form is decided as comm_init decides it."""
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -64,6 +68,7 @@ class DistNewton(object):
         self.overlap_owner = bool(getattr(core, "on_device", True)) and hasattr(core, "sync_stream")
         self._side = None
         self._cb_error = None
+        self._p2p, self._serialize, self._selftest = bool(p2p), bool(serialize), bool(selftest)
         if self.native and self.world > 1:
             self._bind_exchange(backend)
 
@@ -121,6 +126,50 @@ class DistNewton(object):
                 return 1
 
         core.set_exchange(BCAST_FN(bcast), ALLREDUCE_FN(allreduce))
+        if not self._p2p:
+            return
+        from .newton import ALLGATHER_FN, RECV_FN, SEND_FN
+
+        def grank(r):
+            return r if self.group is None else dist.get_global_rank(self.group, r)
+
+        def send(user, ptr, nbytes, peer, stream):
+            try:
+                torch.cuda.synchronize(core.device)
+                dist.send(view(ptr, nbytes // 8).cpu(), dst=grank(peer), group=self.group)
+                return 0
+            except Exception as e:
+                self._cb_error = e
+                return 1
+
+        def recv(user, ptr, nbytes, peer, stream):
+            try:
+                h = torch.empty(nbytes // 8, dtype=torch.float64)
+                dist.recv(h, src=grank(peer), group=self.group)
+                view(ptr, nbytes // 8).copy_(h)
+                torch.cuda.synchronize(core.device)
+                return 0
+            except Exception as e:
+                self._cb_error = e
+                return 1
+
+        def allgather(user, sptr, rptr, nbytes_per_rank, stream):
+            try:
+                n = nbytes_per_rank // 8
+                torch.cuda.synchronize(core.device)
+                h = view(sptr, n).cpu()                                   # (taken before anything is written: send may lie inside recv)
+                outs = [torch.empty_like(h) for _ in range(self.world)]
+                dist.all_gather(outs, h, group=self.group)
+                view(rptr, n * self.world).copy_(torch.cat(outs))
+                torch.cuda.synchronize(core.device)
+                return 0
+            except Exception as e:
+                self._cb_error = e
+                return 1
+
+        core.set_exchange_p2p(SEND_FN(send), RECV_FN(recv), ALLGATHER_FN(allgather), serialize=self._serialize)
+        if self._selftest:
+            self._native(core.exchange_selftest)
 
     # ------------------------------------------------------------------ helpers
     def owner(self, p):

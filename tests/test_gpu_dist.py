@@ -24,11 +24,13 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, shape, nb, mode, out, opts=None):
+def _worker(rank, world, port, shape, nb, mode, out, opts=None, drv_kw=None, env=None):
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    for k_, v_ in (env or {}).get(rank, {}).items():          # per-rank environment (PYIPM_DIST_SAG on ONE rank, ...)
+        os.environ[k_] = v_
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from pyipm_amd.newton import NewtonCore
@@ -46,7 +48,7 @@ def _worker(rank, world, port, shape, nb, mode, out, opts=None):
         else:
             core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
         core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
-        drv = DistNewton(core, native=mode.startswith("native"))
+        drv = DistNewton(core, native=mode.startswith("native"), **(drv_kw or {}))
         drv.lookahead = mode != "python-lockstep"
         g = drv.residual().cpu().numpy()
         dz, st = drv.step(0.0, 0.0)
@@ -60,6 +62,8 @@ def _worker(rank, world, port, shape, nb, mode, out, opts=None):
             extra["info"] = core.solve_info()
             extra["refined_diff"] = float((dz_ref - dz).norm() / dz.norm())
             extra["timings"] = core.dist_timings()
+            extra["wire"] = core.dist_wire()                # (of the last factorisation: the step above)
+            extra["bcast_mode"] = core.comm_bcast_mode()
             if opts:
                 core.step_dist(0.0, 0.0)
                 extra["instances"] = core.trailing_instances()
@@ -514,3 +518,94 @@ def test_condensed_across_ranks_needs_full_blocks():
             c2.assemble(0.0, 0.0)
     finally:
         c2.close()
+
+
+# ---- round 5: the exchange code that had never run and the two-message protocol (item 1a) ---------------
+def _run_world(world, shape, nb, opts=None, drv_kw=None, env=None, mode="native-sharded"):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), shape, nb, mode, out, opts, drv_kw, env), nprocs=world, join=True)
+    return {r: out[r] for r in range(world)}
+
+
+def _n_slices(n, me, mi, nb, world):
+    """Slices the geometry calls for (the library's sl(k) rule): panel k has a message, panel k + 1 exists, has another owner
+    and is not inside the slack block, panel k is not inside it either; slice 2 only when panel k + 2 exists."""
+    N = n + 2 * mi + me
+    Npad = ((N + 127) // 128) * 128
+    npan = (Npad + nb - 1) // nb
+    in_s = lambda p: mi > 0 and p * nb >= n and min((p + 1) * nb, Npad) <= n + mi          # noqa: E731
+    count = 0
+    for k in range(npan - 1):
+        w = min(nb, Npad - k * nb)
+        if Npad - (k * nb + w) <= 0 or in_s(k) or in_s(k + 1) or world < 2:
+            continue
+        count += 1 + (1 if k + 2 < npan else 0)
+    return count
+
+
+@pytest.mark.parametrize("world,shape,nb", [(2, (900, 200, 300, 8), 256), (3, (700, 150, 260, 9), 128), (4, (1500, 300, 500, 10), 256),
+                                            (3, (2000, 400, 600, 12), 1024)])
+def test_exchange_forms_give_the_same_bits(world, shape, nb):
+    """Every wire form of the distributed factorisation on 2 - 4 ranks sharing the GPU, exchange over gloo callbacks:
+      A  slices point to point + panel messages as scatter + all-gather (every size) + every operation serialised through the
+         collective stream (what the RCCL path does on several GPUs: sag_bcast's slicing with a count that does not divide by
+         the number of ranks, the stream hop, the self-test that switches the form on);
+      B  slices as broadcasts (an exchange without point-to-point callbacks), plain panel broadcasts;
+      C  one message per panel (dist_slices = 0), scatter + all-gather;
+      D  one message per panel, plain broadcast -- the protocol of rounds 1 - 4.
+    The same direction bit for bit from all four, on every rank; message and byte counts per form as predicted."""
+    n, me, mi, seed = shape
+    p2p = {"p2p": True, "serialize": True, "selftest": True}
+    nop2p = {"p2p": False}
+    runs = {"A": _run_world(world, shape, nb, {"dist_sag_min_bytes": 8}, p2p),
+            "B": _run_world(world, shape, nb, None, nop2p),
+            "C": _run_world(world, shape, nb, {"dist_slices": 0, "dist_sag_min_bytes": 8}, {"p2p": True, "serialize": False, "selftest": True}),
+            "D": _run_world(world, shape, nb, {"dist_slices": 0}, nop2p)}
+    qp = make_qp(n, me, mi, seed)
+    ref, _, _, _ = orc.newton_step(qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"],
+                                   qp["mu"], n, me, mi, regularise=False)
+    base = runs["D"][0][0]
+    assert np.linalg.norm(base - ref) / np.linalg.norm(ref) <= 1e-10
+    fact, _ = _factor_bytes(n, me, mi, nb)
+    nsl = _n_slices(n, me, mi, nb, world)
+    for name, res in runs.items():
+        for r in range(world):
+            dz, st, _, _, _, extra = res[r]
+            assert np.array_equal(dz, base), (name, r)
+            assert st["n_neg"] == me + mi and st["n_zero"] == 0
+            assert extra["timings"]["bytes"] == fact                         # the panel messages themselves never change
+            w = extra["wire"]
+            sag = name in ("A", "C") and world >= 3
+            assert extra["bcast_mode"] == (1 if sag else 0), (name, extra["bcast_mode"])
+            nmsg = extra["timings"]["messages"]
+            if sag:
+                assert (w["sag_messages"], w["sag_bytes"], w["bcast_messages"]) == (nmsg, fact, 0), (name, w)
+                assert w["allgathers"] == nmsg
+            else:
+                assert (w["bcast_messages"], w["bcast_bytes"], w["sag_messages"], w["allgathers"]) == (nmsg, fact, 0, 0), (name, w)
+            if name in ("C", "D"):
+                assert w["slice_messages"] == 0 and w["slices_as_broadcast"] == 0
+            if name == "A":
+                assert w["stream_hops"] > 0                                   # the sweeps' exchanges hop through the collective stream
+            if name in ("B", "C", "D") and not (name == "C"):
+                assert w["stream_hops"] == 0
+        if name == "A":
+            assert sum(res[r][5]["wire"]["slice_messages"] for r in range(world)) == 2 * nsl     # counted by sender and receiver
+            assert all(res[r][5]["wire"]["slices_as_broadcast"] == 0 for r in range(world))
+        if name == "B":
+            assert all(res[r][5]["wire"]["slices_as_broadcast"] == nsl for r in range(world))
+    assert nsl > 0
+
+
+def test_selftest_agreement_one_rank_opts_out():
+    """PYIPM_DIST_SAG=0 on ONE rank of three: the ranks agree on NOT using the scatter + all-gather form (a rank entering the
+    self-test alone would wait for ever), every panel message travels as a broadcast, the result does not change."""
+    shape, nb, world = (700, 150, 260, 9), 128, 3
+    res = _run_world(world, shape, nb, {"dist_sag_min_bytes": 8}, {"p2p": True, "serialize": True, "selftest": True},
+                     env={1: {"PYIPM_DIST_SAG": "0"}})
+    ref = _run_world(world, shape, nb, {"dist_slices": 0}, {"p2p": False})
+    for r in range(world):
+        assert res[r][5]["bcast_mode"] == 0 and res[r][5]["wire"]["sag_messages"] == 0
+        assert np.array_equal(res[r][0], ref[0][0])
