@@ -259,18 +259,49 @@ class QPDeviceIPM(object):
         return min(1.0, float((-self.tau * x[neg] / dx[neg]).min()))
 
     def _restoration(self, x0, c_new):
-        """Minimum-norm feasibility-restoration direction (pyipm.py:1466-1477, 1518-1529)."""
+        """Minimum-norm feasibility-restoration direction (pyipm.py:1466-1477, 1518-1529): -pinv(At) c for the constraint
+        Jacobian At = [[Je', 0], [Ji', -I]] over (x, s).  At At' = J'J + diag(0, I) is the Gram matrix of the library's
+        L-BFGS direction with zeta = 1 and Sigma = 1 (include/pyipm_lbfgs.h: G = J'J / zeta + diag(0, 1 / Sigma)), and with an
+        empty storage that direction is Zg = [inv(A)(g1 - B y); y], y = inv(G)(B'inv(A) g1 - g2): for g1 = 0, g2 = -c its (x, s)
+        part IS -At'(At At')^-1 c.  So the step comes from the library's own kernels (split-K MFMA Gram launch -- cached while
+        the Jacobians do not change --, block LDL', two passes over J); round 4 went through torch.linalg.cholesky_ex and a
+        rocBLAS product.  Guard: a factor with rejected / negative pivots, or a step that does not satisfy At z = -c, takes the
+        SVD as before (rank-deficient constraints)."""
         torch = self.torch
         n, me, mi = self.nvar, self.neq, self.nineq
+        f64, dev = torch.float64, self.device
+        try:
+            core = self._restoration_core()
+            g = torch.cat([torch.zeros(n + mi, dtype=f64, device=dev), -c_new])
+            s1 = torch.full((mi,), 1.0 - self.eps, dtype=f64, device=dev) if mi else None       # (s + eps == 1 exactly)
+            l1 = torch.cat([torch.zeros(me, dtype=f64, device=dev), torch.ones(mi, dtype=f64, device=dev)])
+            dz, st = core.direction(g, s1, l1, 1.0, None, None, None, None, None, reg=0.0, eps=self.eps, flip=False)
+            z = dz[:n + mi]
+            if st["n_neg"] == 0 and st["n_zero"] == 0 and not st["regularised"] and bool(torch.isfinite(z).all()):
+                _, je, ji = self.core.block_products(z[:n].contiguous(), want=(False, True, True))
+                parts = ([je] if me else []) + ([ji - z[n:]] if mi else [])
+                res = torch.cat(parts) + c_new                                               # At z + c
+                if float(res.norm()) <= 1.0e-9 * max(float(c_new.norm()), 1.0e-300):
+                    return z
+        except Exception:                                                                    # (no memory for the Gram matrix, ...)
+            pass
         cols = [m for m in (self.Je, self.Ji) if m is not None]
         top = torch.cat(cols, dim=1)
         if mi:
-            bottom = torch.cat([torch.zeros((mi, me), dtype=torch.float64, device=self.device),
-                                -torch.eye(mi, dtype=torch.float64, device=self.device)], dim=1)
+            bottom = torch.cat([torch.zeros((mi, me), dtype=f64, device=dev), -torch.eye(mi, dtype=f64, device=dev)], dim=1)
             top = torch.cat([top, bottom], dim=0)
-        At = top.t().contiguous()                              # (me+mi) x (n+mi)
-        # minimum-norm solution: the normal equations where At allows it, an SVD elsewhere (see _pinv_apply)
-        return -self._pinv_apply(At, c_new)
+        return -self._pinv_svd(top.t().contiguous(), c_new)
+
+    def _restoration_core(self):
+        """The L-BFGS direction handle the restoration step runs on: the limited-memory mode's own (Jacobians staged, J'J cached),
+        or one created on first use and kept for the solve."""
+        if self.lbfgs:
+            return self.lb
+        if getattr(self, "_rcore", None) is None:
+            from .lbfgs import LbfgsCore
+            self._rcore = LbfgsCore(self.nvar, self.neq, self.nineq, 1, device=self.device.index)
+            self._rcore.stage_jacobian(self.Je, self.Ji)
+        return self._rcore
 
     RAY_BATCH = 64                       # backtracking candidates alpha tau^k evaluated per launch of k_merit_ray
 
@@ -431,34 +462,80 @@ class QPDeviceIPM(object):
         return zeta, S, Y, SS, L, D, fail
 
     @staticmethod
-    def _pinv_apply(J, g):
-        """pinv(J) @ g, the reference's first multiplier estimate (pyipm.py:726-730), for J (n x m) on the device.  An SVD of a
-        4000 x 9500 Jacobian takes 11 s on the GPU (34 Newton iterations of that LP take 1.2 s): when J has full rank and is not
-        badly conditioned the same vector comes from the normal equations -- J'(J J')^-1 g for a wide J, (J'J)^-1 J'g for a
-        tall one -- by a Cholesky factorisation and one step of refinement; otherwise (Cholesky fails, or its diagonal spans
-        more than three decades, i.e. cond(J) above ~1e3) the SVD as before."""
+    def _pinv_svd(J, g):
+        """pinv(J) @ g through an SVD: the last resort for rank-deficient or badly conditioned Jacobians."""
         import torch
-        n, m = J.shape
-        wide = m >= n
-        G = J @ J.t() if wide else J.t() @ J
-        L, info = torch.linalg.cholesky_ex(G)
-        if int(info) == 0:
-            d = torch.diagonal(L)
-            if float(d.min()) > 1.0e-3 * float(d.max()):
-                def apply(r):                                   # pinv(J) r through the factor
-                    if wide:
-                        return J.t() @ torch.cholesky_solve(r.reshape(-1, 1), L).reshape(-1)
-                    return torch.cholesky_solve((J.t() @ r).reshape(-1, 1), L).reshape(-1)
-                lam = apply(g)
-                # one refinement step on the least-squares residual (wide: J lam = g exactly; tall: J'(g - J lam) = 0)
-                lam = lam + apply(g - J @ lam)
-                return lam
         if J.numel() <= (1 << 22):
-            # rank-deficient or badly conditioned, and small enough for the host: LAPACK's SVD (the device SVD loses the small
-            # singular values of such a matrix -- 1.28e-9 for 1.00e-9 on a 30 x 70 example -- and pinv is all about those)
-            import numpy as np
+            # small enough for the host: LAPACK's SVD (the device SVD loses the small singular values of such a matrix -- 1.28e-9
+            # for 1.00e-9 on a 30 x 70 example -- and pinv is all about those)
             return torch.from_numpy(np.linalg.pinv(J.cpu().numpy()) @ g.cpu().numpy()).to(J.device)
         return torch.linalg.pinv(J) @ g
+
+    @staticmethod
+    def _pinv_apply(J, g, matvec=None, rmatvec=None, info=None):
+        """pinv(J) @ g, the reference's first multiplier estimate (pyipm.py:726-730), for J (n x m) on the device.  When J has full
+        rank and is not badly conditioned the same vector comes from the normal equations -- (J'J)^-1 J'g for a tall J,
+        J'(J J')^-1 g for a wide one -- formed and solved by the LIBRARY'S OWN kernels (round 5; rounds 3-4: torch.linalg.cholesky_ex
+        and a rocBLAS product): the L-BFGS direction of include/pyipm_lbfgs.h with an empty storage, zeta = 1 and every constraint
+        an equality is  y = (J'J)^-1 (J'g1 - g2)  -- a split-K MFMA Gram launch, the block LDL' of the Newton core, two passes
+        over J -- and its x part (g1 - J y).  One refinement step on the least-squares residual follows.  Accepted only if the
+        factorisation found G positive definite with pivots spanning less than six decades AND the result satisfies the normal
+        equations to working precision (a pivot spread does not bound cond(J'J)); otherwise the SVD as before.
+        matvec(lam) = J lam / rmatvec(v) = J'v: the caller's own products (QPDeviceIPM: the library's block products); default:
+        torch's."""
+        import torch
+        from .lbfgs import LbfgsCore
+        n, m = J.shape
+        f64, dev = torch.float64, J.device
+        if matvec is None:
+            matvec = lambda v: J @ v                    # noqa: E731
+        if rmatvec is None:
+            rmatvec = lambda v: J.t() @ v               # noqa: E731
+        z = lambda k: torch.zeros(k, dtype=f64, device=dev)     # noqa: E731
+        wide = m >= n
+        core = None
+        try:
+            if wide:                                    # Gram over the other dimension: K = J' (m x n) plays the Jacobian
+                core = LbfgsCore(m, n, 0, 1, device=dev.index)
+                core.stage_jacobian(J.t().contiguous(), None)
+            else:
+                core = LbfgsCore(n, m, 0, 1, device=dev.index)
+                core.stage_jacobian(J.contiguous(), None)
+            stats = []
+
+            def apply(r):                               # pinv(J) r through the factor of the Gram matrix
+                if wide:                                # y = (J J')^-1 r from g1 = 0, g2 = -r; the x part is -K y = -J'y
+                    dz, st = core.direction(torch.cat([z(m), -r]), None, z(n), 1.0, None, None, None, None, None, reg=0.0)
+                    stats.append(st)
+                    return -dz[:m]
+                dz, st = core.direction(torch.cat([r, z(m)]), None, z(m), 1.0, None, None, None, None, None, reg=0.0)
+                stats.append(st)
+                return dz[n:].clone()
+
+            lam = apply(g)
+            st = stats[0]
+            ok = (st["n_neg"] == 0 and st["n_zero"] == 0 and not st["regularised"] and st["d_max"] > 0.0 and
+                  st["d_min"] > 1.0e-6 * st["d_max"] and bool(torch.isfinite(lam).all()))
+            if ok:
+                # one refinement step on the least-squares residual (wide: J lam = g exactly; tall: J'(g - J lam) = 0)
+                lam = lam + apply(g - matvec(lam))
+                r = g - matvec(lam)
+                if wide:
+                    ok = float(r.norm()) <= 1.0e-11 * max(float(g.norm()), 1.0e-300)
+                else:
+                    ok = float(rmatvec(r).norm()) <= 1.0e-11 * max(float(J.norm()) * float(g.norm()), 1.0e-300)
+                if ok and bool(torch.isfinite(lam).all()):
+                    if info is not None:
+                        info["path"] = "normal equations (library Gram + block LDL')"
+                    return lam
+        except Exception:                               # (no memory for the Gram matrix: the SVD path needs less)
+            pass
+        finally:
+            if core is not None:
+                core.close()
+        if info is not None:
+            info["path"] = "svd"
+        return QPDeviceIPM._pinv_svd(J, g)
 
     def _small(self, kkt, tol):
         return all(k <= tol for k in kkt)
@@ -478,9 +555,17 @@ class QPDeviceIPM(object):
         self.nu_host = self.nu
         if me or mi:
             if self.lda0 is None:
+                t_init = time.perf_counter()
                 J = torch.cat([m for m in (self.Je, self.Ji) if m is not None], dim=1)
-                lda = self._pinv_apply(J, self.df(x))
+                # (the residual checks of the estimate through the library's own block products, as everything else in the loop)
+                info = {}
+                lda = self._pinv_apply(J, self.df(x), matvec=self._jlam,
+                                       rmatvec=lambda v: torch.cat([t for t in self.core.block_products(v, want=(False, True, True))[1:]
+                                                                    if t is not None]), info=info)
                 del J
+                torch.cuda.synchronize(self.device)
+                self.timings["init_multipliers_s"] = time.perf_counter() - t_init
+                self.timings["init_multipliers_path"] = info.get("path")
                 if mi:
                     li = lda[me:]
                     li[li < 0.0] = self.Ktol

@@ -17,6 +17,8 @@ def main():
     ap.add_argument("--condensed", action="store_true")
     ap.add_argument("--ktol", type=float, default=1e-6)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--given-lda0", action="store_true", help="start from the generator's multipliers (rounds 3-4) instead of the "
+                                                              "reference's default first estimate pinv(J) df (pyipm.py:726-730)")
     args = ap.parse_args()
     import torch
     from bench import make_qp_device
@@ -26,7 +28,7 @@ def main():
     qp = make_qp_device(n, me, mi, args.seed, dev)
     # x = 0 in the generator: c = df, b = -ce, h = -ci
     ipm = QPDeviceIPM(qp["d2L"], qp["df"], Je=qp["Je"], b=-qp["ce"] if me else None, Ji=qp["Ji"],
-                      h=-qp["ci"] if mi else None, lda0=qp["lam"], s0=None, Ktol=args.ktol, niter=30, miter=20,
+                      h=-qp["ci"] if mi else None, lda0=qp["lam"] if args.given_lda0 else None, s0=None, Ktol=args.ktol, niter=30, miter=20,
                       verbosity=1, condensed=args.condensed)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -43,6 +45,8 @@ def main():
            "merit_ray_launches": ipm.timings.get("n_ray", 0), "warm_up_seconds_in_constructor": ipm.warm_seconds,
            "newton_seconds_per_factorisation": ipm.timings["newton_s"] / max(ipm.backend.n_factor, 1),
            "newton_seconds_each": ipm.timings["newton_each_s"],
+           "first_multiplier_estimate": ("given (generator's)" if args.given_lda0 else "pinv(J) df (pyipm.py:726-730), the default"),
+           "init_multipliers_seconds": ipm.timings.get("init_multipliers_s"), "init_multipliers_path": ipm.timings.get("init_multipliers_path"),
            "rcond_estimates": ipm.backend.n_rcond, "rcond_estimates_reused": ipm.backend.n_rcond_reused,
            "rcond_log_call_rcond_spread": ipm.backend.rcond_log,
            "merit_note": "phi / dphi / nu threshold / KKT norms / barrier sums are device reductions of the library "
