@@ -178,8 +178,11 @@ def test_wide_bulk_tiles_across_ranks(world, shape, nb):
     import torch.multiprocessing as mp
     n, me, mi, seed = shape
     res = {}
-    for name, opts in (("wide", {"bulk_bn": 256, "bulk_bn_rows": 0, "persist_rows": 0, "reserve_cus": 0, "bulk_bn_min_k": 256}),
-                       ("narrow", {"bulk_bn": 128})):
+    # (head32_rows_dist = 0: with the two-message protocol a rank's share of a bulk update comes as the panel it factors next, alone,
+    #  and the rest -- at these sizes every launch is ONE panel, which would otherwise take the 32-row kernel of a head)
+    for name, opts in (("wide", {"bulk_bn": 256, "bulk_bn_rows": 0, "persist_rows": 0, "reserve_cus": 0, "bulk_bn_min_k": 256,
+                                 "head32_rows_dist": 0}),
+                       ("narrow", {"bulk_bn": 128, "head32_rows_dist": 0})):
         mgr = mp.Manager()
         out = mgr.dict()
         mp.spawn(_worker, args=(world, _free_port(), shape, nb, "native", out, opts), nprocs=world, join=True)
