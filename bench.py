@@ -390,6 +390,7 @@ def main():
             core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
         core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
         core.set_option("profile", 1)
+        core.set_option("expert", 1)                         # (--opt may name an expert switch; the clock stamps are one)
         for kv in args.opt:
             k, v = kv.split("=")
             core.set_option(k, float(v))

@@ -382,62 +382,70 @@ int pyipm_newton_trailing_instances(pyipm_newton_ctx* h, double out[8]);
 /* The same launches' algorithmic bytes in both definitions: out[k] = C tiles only (16 B per updated entry), out[2 + k] = C tiles +
  * the two operand panels read once; k = 0: 128 x 128 tiles, k = 1: 128 x 256. */
 int pyipm_newton_trailing_bytes(pyipm_newton_ctx* ctx, double out[4]);
-/* Options (all default to the measured-best setting):
- *   "condensed" 0|1  handles with mi > 0 (several ranks since round 3: with the FULL blocks staged on every rank --
- *                    stage_blocks, not stage_blocks_owned -- assemble / factor_dist / solve_dist / step_dist work on it too,
- *                    same 1-D block-cyclic map on the smaller matrix): assemble/factor/solve work on the condensed system
- *                    [[d2L + delta I + Ji Sigma Ji', Je], [Je', -delta_c I]] of dimension n+me (s and lambda_i
- *                    eliminated analytically).  Same inputs, same outputs (full [dx|ds|dle|dli], inertia of the
- *                    full matrix); kkt_storage then exposes the condensed matrix.
- *   "condensed_sigma_max" (default 1e4): inequalities whose Sigma_k = lda_i/(s+eps) exceeds it are not folded
- *                    into the x-x block but kept as rows with -1/Sigma_k on the diagonal (dimension n+me+|A|);
- *                    "condensed_refine" (default 0): refinement steps every condensed solve gets at least.
- *   "block_refine" 0..3 (default 2), "refine_cond" (default 1e3): refinement steps of the block solves
- *                    L T = S / T z = y for diagonal tiles whose pivot spread exceeds refine_cond (the tile
- *                    inverses are explicit).
- *   "profile" 0|1, "lookahead" 0|1, "group" 1..create-time value, "tail_group" / "tail_cols" (group size once
- *   at most tail_cols columns remain; defaults 4 (= no shorter groups) / 24576), "fuse_forward" 0|1, "pivtol_rel",
- *   "xcd_swizzle", "side_prio", "bulk_waves" 4|8 (measurement switches);
- *   "refine_target" / "refine_max" (adaptive refinement of solve(refine < 0): stop at this backward error, default 1e-14,
- *   or after this many steps, default 8); "dist_selfmsg" 0|1 (world == 1 only: the distributed driver packs and sends
- *   every panel anyway, to measure the message path on one GPU);
- *   "group_chain" 0|1 (single rank: the panels of a group run as one tile-to-tile sequence of k_tile_step launches, the
- *   rows below the group's diagonal block follow on their own stream -- DESIGN.md section 3; "pending_left_rows": their
- *   in-group updates are applied left-looking while more rows than this remain, default 12288, -1 never), "tile_step" 0|1 (the same
- *   pair of kernels panel by panel: what the per-panel / multi-GPU driver uses), "head_on_side" 0|1 (the lookahead head on
- *   the stream of the chain it follows), "head_serial" 0|1 (the group's bulk update waits for that head), "head_split" 0|1
- *   (chain-bound regime: the head's rows below the target group's diagonal block run on the rows stream), "fast_on_main"
- *   0|1 (groups inside the slack block run on the main stream), "bwd_diag4" 0|1 (in-panel backward substitution on 1024
- *   threads through shared memory), "keep_zeros" 0|1 (K1 leaves in place the zeros of the (s,x), (s,s), (lambda_e,s),
- *   (lambda_i,s) blocks that nothing can fill in; single rank), "head_waves" 4|8,
- *   "inpanel32" 0|1 (updates on the panel chain through the fine-grained kernel), "fuse_scale_update" 0|1 (tile-by-tile
- *   schedule, group_chain = tile_step = 0: a tile's in-panel update rides the scaling launch of the tile before it),
- *   "pending32_rows", "head32_rows",
- *   "head32_rows_dist" (row counts up to which a panel's pending in-group update / the lookahead head / the per-panel
- *   head take that kernel; defaults 24576 / 6144 / 16384), "early_head" 0|1 (tail regime: the next group's columns are
- *   updated panel by panel beside the chain; default 0 since the head is split), "bulk_bn" 256|128 (bulk update tiles of
- *   128 x 256, the default since round 3 for launches of K >= 512 outside the chain-bound phase, or 128 x 128 everywhere;
- *   "bulk_bn_rows": only for launches over more rows than this, default 20480; "bulk_bn_all" 1: everywhere), "reserve_cus" / "persist_rows" (chain-bound phase -- at most persist_rows rows left, default
- *   12288: the bulk update runs as a persistent launch that leaves reserve_cus CUs, default 16,
- *   to the panel chain; 0 = ordinary launches), "wide_sub" (per-panel / multi-GPU schedule: a panel wider than this many
- *   columns, default 256, is factored by its owner as a block of sub-panels this wide -- one tile chain over the panel's
- *   diagonal block, the rows below it sub-panel by sub-panel with MFMA in-panel updates -- and swept sub-panel by
- *   sub-panel: at nb = 512 / 1024 the launches, and the bits, of the single-rank schedule at nb = 256; 0 = all stages
- *   of a panel in one launch) -- all of these choose between implementations that accumulate the same
- *   products in the same order: the results are bit-identical (tests/test_gpu_symmetric.py);
- *   "sweep_persist" 0|1 (default 1; single rank, one right-hand side, nb <= 256): each substitution sweep as ONE
- *   device-driven launch (k_bwd_sweep: workgroup 0 resolves the diagonal blocks, every other wave subtracts its columns'
- *   share as soon as a panel's x is published; k_fwd_sweep, its mirror with 64-row chunks, for the forward pass of a solve
- *   that is not fused under a factorisation; flags and values cross workgroups through agent-scope atomics, every poll
- *   has a 2 s timeout that poisons the result with NaN and is reported by the next factorisation) instead of two dependent
- *   launches per panel -- equal to rounding, not to the bit (another summation order), deterministic.  Their workgroups
- *   wait for each other, so all of them (one per CU backward, two per CU forward) must become resident at some point: beside
- *   other streams' kernels they are merely late (tests/test_gpu_symmetric.py), but under a CU mask, or beside a kernel that
- *   holds CUs for seconds, use "sweep_persist" 0;
- *   "sweep_max_blocks" (test hook: cap on their workgroups);
- *   "tile_blocked" 0|1 (default 1; batched handles 0): the 64 x 64 tile inversion 16 pivots at a time (in-register LDL' of the
- *   micro-block + fp64 MFMA block sweeps, Bunch-Kaufman verified afterwards, fallback to the single sweeps: DESIGN.md
- *   section 3) -- same pivots and inertia, a different order of rounding than the single sweeps (not bit-identical). */
+/* Options.  Every one defaults to the measured-best setting; the public ones (25 names) choose numerics, forms of the
+ * system and the few schedule parameters a deployment may have to adapt; everything else is an EXPERT switch (measurement
+ * knobs, test hooks and parked experiments whose measurements are in HISTORY.md) and is refused unless the process has
+ * PYIPM_EXPERT=1 in its environment or the handle was given set_option("expert", 1) -- so that nothing outside the tests
+ * and tools/ runs a path nobody else runs.  tests/test_gpu_symmetric.py checks both lists against the library and runs the
+ * bitwise-neutrality sweep over every schedule option in them.
+ *
+ * PUBLIC OPTIONS: expert, condensed, condensed_sigma_max, condensed_refine, block_refine, refine_cond, refine_target,
+ *   refine_max, pivtol_rel, tile_blocked, profile, skip_zeros, keep_zeros, fuse_forward, sweep_persist, lookahead, group,
+ *   bulk_bn, reserve_cus, persist_rows, wide_sub, dist_sag, dist_sag_min_bytes, dist_slices, dist_selfmsg
+ *
+ *   "expert" 0|1        unlock the expert switches on this handle.
+ *   "condensed" 0|1     handles with mi > 0: assemble / factor / solve work on the condensed system
+ *                       [[d2L + delta I + Ji Sigma Ji', Je], [Je', -delta_c I]] of dimension n + me (+ active rows): s and
+ *                       lambda_i eliminated analytically.  Same inputs, same outputs (full [dx|ds|dle|dli], inertia of the
+ *                       full matrix); kkt_storage then exposes the condensed matrix.  Several ranks: with the FULL blocks
+ *                       staged on every rank (stage_blocks, not stage_blocks_owned).  Batched handles: per problem.
+ *   "condensed_sigma_max" (1e4): inequalities whose Sigma_k = lda_i/(s+eps) exceeds it are not folded into the x-x block but
+ *                       kept as rows with -1/Sigma_k on the diagonal; "condensed_refine" (0): refinement steps against the
+ *                       full blocks every condensed solve gets at least.
+ *   "block_refine" 0..3 (2), "refine_cond" (1e3): refinement steps of the block solves L T = S / T z = y for diagonal tiles
+ *                       whose pivot spread exceeds refine_cond (the tile inverses are explicit).
+ *   "refine_target" (1e-14) / "refine_max" (8): adaptive refinement of solve(refine < 0): stop at this backward error or
+ *                       after this many steps.
+ *   "pivtol_rel" (1e-14): a pivot below this fraction of its tile column's magnitude has cancelled: static pivot.
+ *   "tile_blocked" 0|1  (1; batched handles: 0 with the full form, 1 with the condensed one): the 64 x 64 tile inversion 16
+ *                       pivots at a time (in-register LDL' of the micro-block + fp64 MFMA block sweeps, Bunch-Kaufman
+ *                       verified afterwards, fallback to the single sweeps) -- same pivots and inertia, another order of
+ *                       rounding than the single sweeps (not bit-identical).
+ *   "profile" 0|1       HIP-event timings (last_timings, trailing_instances, dist_timings, provider_stats).
+ *   "skip_zeros" 0|1    (1) products with blocks that pyipm.py:824-842 makes identically zero are not formed; bitwise-neutral.
+ *   "keep_zeros" 0|1    (1) K1 leaves in place the zeros nothing can fill in; single rank; bitwise-neutral.
+ *   "fuse_forward" 0|1  (1) the forward substitution of a pending residual trails the factorisation; bitwise-neutral
+ *                       against the per-panel sweeps.
+ *   "sweep_persist" 0|1 (1; single rank, one right-hand side, nb <= 256): each substitution sweep as ONE device-driven
+ *                       launch (k_fwd_sweep / k_bwd_sweep; flags and values cross workgroups through agent-scope atomics,
+ *                       every poll has a 2 s timeout that poisons the result with NaN and is reported by the next
+ *                       factorisation) -- equal to rounding, not to the bit (another summation order), deterministic.
+ *                       Their workgroups wait for each other, so all of them must become resident: under a CU mask, or
+ *                       beside a kernel that holds CUs for seconds, use 0.
+ *   "lookahead" 0|1     (1) one-group lookahead of the single-rank schedule; "group" 1..create-time value: panels per
+ *                       bulk trailing update (K = group * nb).  Bitwise-neutral.
+ *   "bulk_bn" 256|128   (256) column width of a bulk update tile; "reserve_cus" (16) / "persist_rows" (12288): in the
+ *                       chain-bound phase (at most persist_rows rows left) the bulk update runs as a persistent launch
+ *                       that leaves reserve_cus CUs to the panel chain; 0 = ordinary launches.  Bitwise-neutral.
+ *   "wide_sub" (256)    per-panel / multi-GPU schedule: a panel wider than this is factored by its owner as a block of
+ *                       sub-panels this wide (the launches, and the bits, of the single-rank schedule at nb = 256).
+ *   "dist_sag" 0        COLLECTIVE: keep the plain broadcast for the panel messages (see pyipm_newton_comm_bcast_mode);
+ *                       "dist_sag_min_bytes" (4 MiB): smaller messages always take the plain broadcast.
+ *   "dist_slices" 0|1   (1) COLLECTIVE: the two-message protocol of the distributed factorisation -- the rows of panel p
+ *                       that meet the diagonal block of panel p + 1 (and the rows of panel p + 2) go from owner(p) to
+ *                       owner(p + 1) point to point AHEAD of the panel message, so the next owner's tile chain starts on an
+ *                       nb x nb message; 0: one message per panel (rounds 1-4).  Bit-identical either way.
+ *   "dist_selfmsg" 0|1  world == 1 only: the distributed driver packs and "sends" every panel anyway (measures the
+ *                       message path on one GPU).
+ *
+ * EXPERT OPTIONS: tail_group, tail_cols, xcd_swizzle, side_prio, bulk_waves, group_chain, pending_left_rows, tile_step,
+ *   head_on_side, head_serial, head_split, head_split_rows, fast_on_main, rest_prio, s_fast, bwd_diag4, head_waves,
+ *   inpanel32, fuse_scale_update, pending32_rows, head32_rows, head32_rows_dist, early_head, bulk_bn_rows, bulk_bn_all,
+ *   bulk_bn_min_k, sweep_max_blocks, asm_tri, asm_split, fused_head, fused_head_rows, dist_head_split, debug_fault,
+ *   debug_timeline_ptr
+ *   (which stream runs what, in how many launches, which kernel instance takes which row counts -- all of them choose between
+ *   implementations that accumulate the same products in the same order: bit-identical results, tests/test_gpu_symmetric.py;
+ *   what each one is and what it measured: the comments in csrc/ctx.hpp and HISTORY.md.) */
 int pyipm_newton_set_option(pyipm_newton_ctx* ctx, const char* name, double value);
 
 /* fp64 MFMA peak micro-benchmark: register-resident v_mfma_f64_16x16x4_f64 only.

@@ -239,6 +239,7 @@ struct Ctx {
     int block_refine = 2;                 // refinement steps of L T = S in the panel scaling and of T z = y in the solves
     double refine_cond = 1.0e3;           // ... applied to tiles whose pivot spread dmax/dmin exceeds this
     int profile = 0;
+    int expert = 0;                       // set_option("expert", 1): the expert switches are accepted on this handle (else PYIPM_EXPERT=1)
     // timings of last calls (ms)
     double t_assemble = 0, t_panel = 0, t_trailing = 0, t_solve = 0, t_factor = 0;
     double t_trailing_union = 0; int64_t n_trailing_real = 0;   // time with some update launch running (launches may overlap); launches that did work

@@ -2812,6 +2812,24 @@ int pyipm_newton_trailing_bytes(pyipm_newton_ctx* h, double out[4]) try {
 int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value) try {
     if (check_ctx(h) || !name) return PYIPM_E_BADARG;
     Ctx* ctx = C(h);
+    if (!strcmp(name, "expert")) { ctx->expert = (int)value != 0; return PYIPM_OK; }
+    {   // expert switches (include/pyipm_newton.h): measurement knobs, test hooks, parked experiments
+        static const char* const kExpert[] = {
+            "tail_group", "tail_cols", "xcd_swizzle", "side_prio", "bulk_waves", "group_chain", "pending_left_rows", "tile_step",
+            "head_on_side", "head_serial", "head_split", "head_split_rows", "fast_on_main", "rest_prio", "s_fast", "bwd_diag4",
+            "head_waves", "inpanel32", "fuse_scale_update", "pending32_rows", "head32_rows", "head32_rows_dist", "early_head",
+            "bulk_bn_rows", "bulk_bn_all", "bulk_bn_min_k", "sweep_max_blocks", "asm_tri", "asm_split", "fused_head",
+            "fused_head_rows", "dist_head_split", "debug_fault", "debug_timeline_ptr"};
+        bool is_expert = false;
+        for (const char* e : kExpert) if (!strcmp(name, e)) { is_expert = true; break; }
+        if (is_expert && !ctx->expert) {
+            const char* env = getenv("PYIPM_EXPERT");
+            if (!(env && env[0] && env[0] != '0')) {
+                ctx->err = std::string("option ") + name + " is an expert switch: set PYIPM_EXPERT=1 or set_option(\"expert\", 1) first";
+                return PYIPM_E_BADARG;
+            }
+        }
+    }
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
     if (!strcmp(name, "head_split_rows")) { ctx->head_split_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "fused_head")) { ctx->fused_head = (int)value != 0; return PYIPM_OK; }

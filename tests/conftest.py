@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # the library-owned allocations): a kernel that reads memory nobody wrote shows up instead of hiding behind the zero pages of a
 # fresh process (round 4: a 128 x 256 update tile did exactly that).  Worker processes inherit it.
 os.environ.setdefault("PYIPM_POISON_WORKSPACE", "1")
+os.environ.setdefault("PYIPM_EXPERT", "1")          # the tests drive the expert switches too (include/pyipm_newton.h; test_gpu_symmetric.py checks the gate itself)
 
 
 def pytest_configure(config):

@@ -224,11 +224,13 @@ def test_wide_panels_match_the_group_schedule_bitwise(shape):
     n, me, mi, seed = shape
     qp = make_qp(n, me, mi, seed)
 
-    def run(nb, wide_sub, per_panel):
+    def run(nb, wide_sub, per_panel, **opts):
         core = NewtonCore(n, me, mi, device=0, nb=nb)
         core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
         core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
         core.set_option("wide_sub", wide_sub)
+        for k_, v_ in opts.items():
+            core.set_option(k_, v_)
         core.set_option("sweep_persist", 0)          # (the per-panel sweeps on both sides: the one-launch backward sweep sums in another order)
         dz, st = (core.step_dist(0.0, 0.0) if per_panel else core.step(0.0, 0.0))
         dz = dz.clone()
@@ -242,6 +244,11 @@ def test_wide_panels_match_the_group_schedule_bitwise(shape):
         assert st0["n_neg"] == st1["n_neg"] == st2["n_neg"] == me + mi
         assert torch.equal(wide, ref)
         assert float((one - ref).norm() / ref.norm()) <= 1e-12
+        # the per-panel schedule's own expert switches: the owner's head in one launch or two, the 32-row kernel for a
+        # single-panel head at every size or at none -- the same bits
+        for opts in ({"dist_head_split": 0}, {"head32_rows_dist": 0}, {"head32_rows_dist": 1 << 20, "dist_head_split": 0}):
+            alt, _ = run(nb, 256, True, **opts)
+            assert torch.equal(alt, ref), (nb, opts)
 
 
 def test_dist_driver_world1_matches_fused_step():

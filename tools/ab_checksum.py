@@ -3,6 +3,7 @@
 systems (convex QPs, the reference traces' indefinite / rank-deficient steps).  Run before and after a
 kernel change that is meant to keep the arithmetic identical and diff the output."""
 import glob, hashlib, os, sys
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyipm_amd.newton import NewtonCore

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Throughput of BASELINE.json configs[4]: 512 independent QPs (n=256, mi=256 -> N=768 each), full and condensed form."""
 import os, sys, time
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pyipm_amd.batched import BatchedNewton

@@ -2,6 +2,7 @@
 against torch on the symmetrised triangle.  usage: python tools/bench_provider.py [n me mi]"""
 import json
 import os
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Latency of the panel chain: factor a small system (dominated by k_tile_invert) and report us per tile."""
 import os, sys, time
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pyipm_amd.newton import NewtonCore

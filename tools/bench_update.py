@@ -2,6 +2,7 @@
 """Time ONE trailing update (k_update<128>) in isolation: panel 0 factored, then trailing_update(0) repeated.
 usage: python tools/bench_update.py [n me mi] [nb]   (PYIPM_NEWTON_LIB selects an ablation build)"""
 import os, sys
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pyipm_amd.newton import NewtonCore

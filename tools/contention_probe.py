@@ -4,6 +4,7 @@ system on one stream while another handle factors a small, chain-bound system (N
 stream.  Prints the chain's time per tile alone and beside the bulk kernel, and the bulk kernel's rate alone / beside.
 usage: contention_probe.py [opt=value ...]   (options go to both handles)"""
 import os, sys, time
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pyipm_amd.newton import NewtonCore

@@ -1,6 +1,7 @@
 """Which option makes the direction of a given shape differ?  Backward error from the blocks and the relative difference to the
 default for a list of option variants.  usage: python tools/dbg_shape.py n me mi [variant ...]  (variant: a=1,b=2)"""
 import os
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

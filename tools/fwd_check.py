@@ -2,6 +2,7 @@
 """k_fwd_sweep + k_bwd_sweep (sweep_persist=1) against the per-panel launches on solves with a right-hand side of their own
 (forward pass not fused under a factorisation): difference, repeatability, time per solve."""
 import os, sys, time
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pyipm_amd.newton import NewtonCore

@@ -1,6 +1,7 @@
 """Bitwise check of schedule options at a mid size where every phase of the schedule occurs: the direction with each option
 set against the default's.  usage: python tools/opt_bits.py name=value [name=value ...] (each argument one variant)"""
 import os
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

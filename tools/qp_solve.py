@@ -3,6 +3,7 @@ iterations, Newton-step share.  Usage: python tools/qp_solve.py [--nvar N --neq 
 import argparse
 import json
 import os
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 import sys
 import time
 

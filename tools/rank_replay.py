@@ -29,6 +29,7 @@ import argparse
 import ctypes
 import json
 import os
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 import sys
 import time
 

@@ -3,6 +3,7 @@
 launches: same direction to rounding on several shapes, repeated (a missed ordering between workgroups would show up as
 an occasional difference), and the exposed solve time of both.  Diagnostics; tests/test_gpu_symmetric.py holds the test."""
 import os, sys
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pyipm_amd.newton import NewtonCore

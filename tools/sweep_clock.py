@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Phases of workgroup 0 of the one-launch backward sweep (k_bwd_sweep), per panel, from its own timestamps."""
 import os, sys
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from pyipm_amd.newton import NewtonCore

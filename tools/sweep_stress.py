@@ -3,6 +3,7 @@
 for bit with the first one of its kind and to rounding with the per-panel launches; a missed ordering between workgroups
 would show as an occasional difference, a lost wake-up as a 2 s stall (reported through the error word / NaN)."""
 import os, sys, time
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pyipm_amd.newton import NewtonCore

@@ -3,6 +3,7 @@
 n <= 64, me = mi = 0 IS one diagonal tile, so step() = tile inversion + one product.  Prints, per tile family, the error
 of both paths against numpy.linalg.solve, the inertia against eigvalsh, and the shader cycles of the tile kernel."""
 import os, sys
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

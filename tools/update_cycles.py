@@ -3,6 +3,7 @@
 shader cycles per tile main loop against what its MFMAs need (a 128 x 256 tile at K: 8 waves x 4 K MFMAs of 64 cycles on 4 SIMDs
 = 512 K cycles per SIMD), and of the wall-clock gaps.  usage: python tools/update_cycles.py [opt=value ...]"""
 import os, sys
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from pyipm_amd.newton import NewtonCore

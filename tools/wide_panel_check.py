@@ -3,6 +3,7 @@
 the direction must be bit-identical to the all-stages-in-one-launch form (wide_sub=0) and to the single-rank group schedule
 at nb = 256.  Diagnostics; the test proper is tests/test_gpu_dist.py::test_wide_panels_match_bitwise."""
 import os, sys
+os.environ.setdefault("PYIPM_EXPERT", "1")     # tools use expert switches (include/pyipm_newton.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.distributed as dist
 from pyipm_amd.newton import NewtonCore
