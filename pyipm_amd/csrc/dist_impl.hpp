@@ -75,6 +75,9 @@ struct DistState {
     pyipm_send_fn send = nullptr; pyipm_recv_fn recv = nullptr; pyipm_allgather_fn allgather = nullptr;
     int serialize = 0;                                 // callbacks: run every operation on the collective stream, one at a time (as for RCCL)
     ncclComm_t comm = nullptr;
+    ncclComm_t comm2 = nullptr;                        // a second communicator over the same ranks for the slice messages (point to point):
+                                                       // they must not queue behind a panel broadcast in flight (one communicator = one stream)
+    hipStream_t cs2 = nullptr;                         // ... its stream (callbacks that need no serialising use it too)
     hipStream_t side = nullptr, cs = nullptr;          // owner's factor + pack stream (high priority); collectives
     hipStream_t fws = nullptr;                         // the forward substitution that trails the factorisation (step_dist)
     hipEvent_t ev_fw = nullptr;
@@ -130,6 +133,7 @@ int dist_state(Ctx* ctx, DistState** out) {
         DIST_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         DIST_HIP(hipStreamCreateWithPriority(&D->side, hipStreamNonBlocking, hi));
         DIST_HIP(hipStreamCreateWithPriority(&D->cs, hipStreamNonBlocking, hi));
+        DIST_HIP(hipStreamCreateWithPriority(&D->cs2, hipStreamNonBlocking, hi));
         for (int b = 0; b < 2; ++b) {
             DIST_HIP(hipEventCreateWithFlags(&D->ev_fact[b], hipEventDisableTiming));
             DIST_HIP(hipEventCreateWithFlags(&D->ev_msg[b], hipEventDisableTiming));
@@ -152,6 +156,7 @@ void dist_free(Ctx* ctx) {
     if (!D) return;
     if (D->side) { hipStreamSynchronize(D->side); hipStreamDestroy(D->side); }
     if (D->cs) { hipStreamSynchronize(D->cs); hipStreamDestroy(D->cs); }
+    if (D->cs2) { hipStreamSynchronize(D->cs2); hipStreamDestroy(D->cs2); }
     if (D->fws) { hipStreamSynchronize(D->fws); hipStreamDestroy(D->fws); }
     if (D->ev_fw) hipEventDestroy(D->ev_fw);
     for (int b = 0; b < 2; ++b) {
@@ -176,6 +181,7 @@ void dist_free(Ctx* ctx) {
     if (D->seg) hipFree(D->seg);
     if (D->vloc) hipFree(D->vloc);
     if (D->small) hipFree(D->small);
+    if (D->comm2 && g_rccl.CommDestroy) g_rccl.CommDestroy(D->comm2);
     if (D->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(D->comm);
     delete D;
     ctx->dist = nullptr;
@@ -254,16 +260,22 @@ int tr_group_end(Ctx* ctx, DistState* D) {
     if (!D->comm) return 0;
     ncclResult_t r = g_rccl.GroupEnd(); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclGroupEnd", r);
 }
-int tr_send(Ctx* ctx, DistState* D, const double* buf, size_t count, int peer, hipStream_t st) {
+// The stream the slice messages travel on: their own (second communicator / callbacks that need no serialising), else the
+// collective stream.
+inline hipStream_t tr_slice_stream(const DistState* D) {
+    if (D->comm) return D->comm2 ? D->cs2 : D->cs;
+    return D->serialize ? D->cs : D->cs2;
+}
+int tr_send(Ctx* ctx, DistState* D, const double* buf, size_t count, int peer, hipStream_t st, bool slice = false) {
     D->wire[4] += 1.0;
-    if (D->comm) { ncclResult_t r = g_rccl.Send(buf, count, ncclDouble, peer, D->comm, st); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclSend", r); }
+    if (D->comm) { ncclResult_t r = g_rccl.Send(buf, count, ncclDouble, peer, (slice && D->comm2) ? D->comm2 : D->comm, st); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclSend", r); }
     if (!D->send) { ctx->err = "no point-to-point send installed (pyipm_newton_set_exchange_p2p)"; return PYIPM_E_COMM; }
     if (D->send(D->user, buf, count * sizeof(double), peer, (void*)st)) { ctx->err = "the send callback failed"; return PYIPM_E_COMM; }
     return 0;
 }
-int tr_recv(Ctx* ctx, DistState* D, double* buf, size_t count, int peer, hipStream_t st) {
+int tr_recv(Ctx* ctx, DistState* D, double* buf, size_t count, int peer, hipStream_t st, bool slice = false) {
     D->wire[4] += 1.0;
-    if (D->comm) { ncclResult_t r = g_rccl.Recv(buf, count, ncclDouble, peer, D->comm, st); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclRecv", r); }
+    if (D->comm) { ncclResult_t r = g_rccl.Recv(buf, count, ncclDouble, peer, (slice && D->comm2) ? D->comm2 : D->comm, st); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclRecv", r); }
     if (!D->recv) { ctx->err = "no point-to-point receive installed (pyipm_newton_set_exchange_p2p)"; return PYIPM_E_COMM; }
     if (D->recv(D->user, buf, count * sizeof(double), peer, (void*)st)) { ctx->err = "the receive callback failed"; return PYIPM_E_COMM; }
     return 0;
@@ -516,6 +528,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
                panel_piecewise_ok(ctx, k + 1) && below(k + 1) >= 0;
     };
     const bool p2p = tr_has_p2p(D);
+    const hipStream_t ps = tr_slice_stream(D);          // where the point-to-point slices travel
     if (slices_on) {
         size_t smax = 0;
         for (int64_t p = 0; p < np; ++p) for (int j = 1; j <= 2; ++j) { const size_t e = slice_numel(g, p, j); if (e > smax) smax = e; }
@@ -603,14 +616,14 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
             D->wire[9] += 1.0;
             if (!receiver) { DIST_HIP(hipEventRecord(D->ev_sfree[b][j - 1], cs)); sfree_rec[b][j - 1] = true; }
         } else if (sender) {
-            DIST_HIP(hipStreamWaitEvent(cs, D->ev_spack[b][j - 1], 0));
-            int r = tr_send(ctx, D, buf, cnt, dst, cs); if (r) return r;
-            DIST_HIP(hipEventRecord(D->ev_sfree[b][j - 1], cs)); sfree_rec[b][j - 1] = true;
+            DIST_HIP(hipStreamWaitEvent(ps, D->ev_spack[b][j - 1], 0));
+            int r = tr_send(ctx, D, buf, cnt, dst, ps, true); if (r) return r;
+            DIST_HIP(hipEventRecord(D->ev_sfree[b][j - 1], ps)); sfree_rec[b][j - 1] = true;
         } else if (receiver) {
-            if (sfree_rec[b][j - 1]) DIST_HIP(hipStreamWaitEvent(cs, D->ev_sfree[b][j - 1], 0));
-            int r = tr_recv(ctx, D, buf, cnt, src, cs); if (r) return r;
+            if (sfree_rec[b][j - 1]) DIST_HIP(hipStreamWaitEvent(ps, D->ev_sfree[b][j - 1], 0));
+            int r = tr_recv(ctx, D, buf, cnt, src, ps, true); if (r) return r;
         } else return 0;
-        if (receiver) DIST_HIP(hipEventRecord(D->ev_srecv[b][j - 1], cs));
+        if (receiver) DIST_HIP(hipEventRecord(D->ev_srecv[b][j - 1], p2p ? ps : cs));
         if (sender || receiver) { D->wire[7] += 1.0; D->wire[8] += (double)(cnt * sizeof(double)); }
         return 0;
     };
@@ -654,7 +667,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
         int64_t nf = after + 1;
         while (nf < np && !own(nf)) ++nf;
         if (nf >= np) return 0;
-        if (slices_on) {
+        if (slices_on && nf == after + 1) {                 // (its early phase comes in the very next slot)
             int r = update_range(ctx, p, nf, 1, main); if (r) return r;
             DIST_HIP(hipEventRecord(D->ev_pre, main)); pre_rec = true;
             return update_range(ctx, p, nf + 1, np, main);
@@ -788,6 +801,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
     // join the helper streams (the last panel may have been factored on the side stream; messages in flight)
     DIST_HIP(hipEventRecord(D->ev_join, side)); DIST_HIP(hipStreamWaitEvent(main, D->ev_join, 0));
     DIST_HIP(hipEventRecord(D->ev_head, cs));   DIST_HIP(hipStreamWaitEvent(main, D->ev_head, 0));
+    DIST_HIP(hipEventRecord(D->ev_head, D->cs2)); DIST_HIP(hipStreamWaitEvent(main, D->ev_head, 0));
     if (ctx->rest) { DIST_HIP(hipEventRecord(D->ev_join, ctx->rest)); DIST_HIP(hipStreamWaitEvent(main, D->ev_join, 0)); }
     DIST_HIP(hipEventRecord(ctx->ev[1], main));
     ctx->assembled = false;
@@ -980,6 +994,25 @@ int pyipm_newton_exchange_selftest(pyipm_newton_ctx* h) try {
     PYIPM_HIP(hipSetDevice(ctx->device));
     DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
     if (ctx->g.world > 1 && !D->comm && !(D->bcast && D->allreduce)) { ctx->err = "exchange_selftest: no exchange installed"; return PYIPM_E_COMM; }
+    // A second communicator over the same ranks for the slice messages of the two-message protocol: on ONE communicator a
+    // slice would queue behind whatever panel broadcast is in flight on the collective stream (operations of a communicator
+    // run one at a time), which is exactly what it is sent ahead of.  Its id comes from rank 0 through the first one.  Without
+    // it (an RCCL without point-to-point calls, or a failure here) the slices share the collective stream: correct, slower.
+    if (D->comm2) { g_rccl.CommDestroy(D->comm2); D->comm2 = nullptr; }
+    if (ctx->g.world >= 2 && g_rccl.Send && g_rccl.Recv) {
+        ncclUniqueId id2; memset(&id2, 0, sizeof(id2));
+        bool ok = true;
+        if (ctx->g.rank == 0) ok = g_rccl.GetUniqueId(&id2) == ncclSuccess;
+        static_assert(sizeof(ncclUniqueId) <= 16 * sizeof(double), "the id travels through the 16-double scratch");
+        if (hipMemcpy(D->small, &id2, sizeof(id2), hipMemcpyHostToDevice) != hipSuccess) ok = false;
+        // (every rank issues the broadcast whatever happened locally: the peers are inside it)
+        if (g_rccl.Broadcast(D->small, D->small, 16, ncclDouble, 0, D->comm, D->cs) != ncclSuccess) ok = false;
+        if (hipStreamSynchronize(D->cs) != hipSuccess) ok = false;
+        if (hipMemcpy(&id2, D->small, sizeof(id2), hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+        bool zero = true;
+        for (size_t k = 0; k < sizeof(id2); ++k) zero = zero && reinterpret_cast<const char*>(&id2)[k] == 0;
+        if (ok && !zero && g_rccl.CommInitRank(&D->comm2, ctx->g.world, id2, ctx->g.rank) != ncclSuccess) D->comm2 = nullptr;
+    }
     return exchange_selftest(ctx, D);
 } PYIPM_CATCH_H(h)
 

@@ -255,7 +255,7 @@ def main():
                 cb = (BCAST_FN(bcast), ALLREDUCE_FN(allreduce))
                 core.set_exchange(*cb)
                 cb2 = (SEND_FN(send), RECV_FN(recv), ALLGATHER_FN(allgather))
-                core.set_exchange_p2p(*cb2, serialize=True)
+                core.set_exchange_p2p(*cb2, serialize=False)     # (slices on their own stream: the RCCL path's second communicator)
                 core.set_option("dist_slices", 1 if args.slices else 0)
                 walls, tms, dts, wrs = [], [], [], []
                 for it in range(args.steps + 1):
