@@ -443,8 +443,9 @@ int pyipm_newton_trailing_bytes(pyipm_newton_ctx* ctx, double out[4]);
  *   inpanel32, fuse_scale_update, pending32_rows, head32_rows, head32_rows_dist, early_head, bulk_bn_rows, bulk_bn_all,
  *   bulk_bn_min_k, sweep_max_blocks, asm_tri, asm_split, fused_head, fused_head_rows, dist_head_split, debug_fault,
  *   debug_timeline_ptr
- *   (which stream runs what, in how many launches, which kernel instance takes which row counts -- all of them choose between
- *   implementations that accumulate the same products in the same order: bit-identical results, tests/test_gpu_symmetric.py;
+ *   (which stream runs what, in how many launches, which kernel instance takes which row counts -- all of them but one choose
+ *   between implementations that accumulate the same products in the same order: bit-identical results,
+ *   tests/test_gpu_symmetric.py; the one: bwd_diag4 = 0 sums the in-panel backward substitution in another order, 1e-16;
  *   what each one is and what it measured: the comments in csrc/ctx.hpp and HISTORY.md.) */
 int pyipm_newton_set_option(pyipm_newton_ctx* ctx, const char* name, double value);
 

@@ -89,7 +89,7 @@ struct DistState {
     // L rows rebuilt from a received slice, and their events: packed (owner's stream -> cs), received (cs -> owner-to-be's
     // stream), free (the send has left / the slice is unpacked: the buffer may be written again)
     double* sbuf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; double* EL[2] = {nullptr, nullptr}; size_t slice_bytes = 0;
-    hipEvent_t ev_spack[2][2] = {}, ev_srecv[2][2] = {}, ev_sfree[2][2] = {}, ev_pre = nullptr, ev_hr = nullptr;
+    hipEvent_t ev_spack[2][2] = {}, ev_srecv[2][2] = {}, ev_sfree[2][2] = {}, ev_pre = nullptr, ev_hr = nullptr, ev_hr2 = nullptr;
     double* seg = nullptr;                             // nb doubles: the panel segment of the forward sum
     double* vloc = nullptr;                            // Npad: this rank's share of the vector during the sweeps
     double* small = nullptr;                           // 16 doubles: statistics reduction
@@ -176,6 +176,7 @@ void dist_free(Ctx* ctx) {
     for (int j = 0; j < 2; ++j) if (D->EL[j]) hipFree(D->EL[j]);
     if (D->ev_pre) hipEventDestroy(D->ev_pre);
     if (D->ev_hr) hipEventDestroy(D->ev_hr);
+    if (D->ev_hr2) hipEventDestroy(D->ev_hr2);
     for (int b = 0; b < 2; ++b) if (D->ev_hop[b]) hipEventDestroy(D->ev_hop[b]);
     for (auto e : D->pool) hipEventDestroy(e);
     if (D->seg) hipFree(D->seg);
@@ -547,7 +548,8 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
                 DIST_HIP(hipEventCreateWithFlags(&D->ev_srecv[b][j], hipEventDisableTiming));
                 DIST_HIP(hipEventCreateWithFlags(&D->ev_sfree[b][j], hipEventDisableTiming));
             }
-        if (!D->ev_pre) { DIST_HIP(hipEventCreateWithFlags(&D->ev_pre, hipEventDisableTiming)); DIST_HIP(hipEventCreateWithFlags(&D->ev_hr, hipEventDisableTiming)); }
+        if (!D->ev_pre) { DIST_HIP(hipEventCreateWithFlags(&D->ev_pre, hipEventDisableTiming)); DIST_HIP(hipEventCreateWithFlags(&D->ev_hr, hipEventDisableTiming));
+                          DIST_HIP(hipEventCreateWithFlags(&D->ev_hr2, hipEventDisableTiming)); }
     }
     bool sfree_rec[2][2] = {{false, false}, {false, false}};
     bool pre_rec = false;
@@ -703,21 +705,26 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
                 if (pre_rec) DIST_HIP(hipStreamWaitEvent(side, D->ev_pre, 0));   // the main stream's updates of panel k + 1's columns
                 DIST_HIP(hipStreamWaitEvent(side, D->ev_srecv[b][0], 0));
                 rc = span_begin(ctx, D, 0, side, &sp_chain); if (rc) return rc;   // (chain path: work only, not the wait for a slice)
-                rc = unpack_slice(ctx, k, 1, D->sbuf[b][0], D->EL[0], side); if (rc) return rc;
-                DIST_HIP(hipEventRecord(D->ev_sfree[b][0], side)); sfree_rec[b][0] = true;
+                const double* tiles_k = D->sbuf[b][0] + ldE1 * g.panel_w(k);      // slice 1 carries the panel's tile inverses, tiles, flags
+                rc = unpack_slice(ctx, k, 1, D->sbuf[b][0], tiles_k, D->EL[0], side); if (rc) return rc;
                 rc = head_rows(k, nxt, c1n, c2n, D->EL[0] - c1n, ldE1, side, true); if (rc) return rc;
                 rc = panel_chain(ctx, nxt, side); if (rc) return rc;
                 if (c3n > c2n) {
                     rc = span_end(ctx, D, sp_chain, side); if (rc) return rc;
                     DIST_HIP(hipStreamWaitEvent(side, D->ev_srecv[b][1], 0));
                     rc = span_begin(ctx, D, 0, side, &sp_chain); if (rc) return rc;
-                    rc = unpack_slice(ctx, k, 2, D->sbuf[b][1], D->EL[1], side); if (rc) return rc;
+                    rc = unpack_slice(ctx, k, 2, D->sbuf[b][1], tiles_k, D->EL[1], side); if (rc) return rc;
                     DIST_HIP(hipEventRecord(D->ev_sfree[b][1], side)); sfree_rec[b][1] = true;
                     rc = head_rows(k, nxt, c2n, c3n, D->EL[1] - c2n, c3n - c2n, side, true); if (rc) return rc;
                     rc = panel_rows(ctx, nxt, c2n, c3n, side); if (rc) return rc;
                 }
                 if (sl(nxt)) { rc = pack_s(nxt, 1, side); if (rc) return rc; }
                 rc = span_end(ctx, D, sp_chain, side); if (rc) return rc;
+                // behind the chain path: panel k's tiles into the handle's arrays (the rest of its unpacking reads them there);
+                // only then may the slice-1 buffer be written again
+                rc = unpack_slice_tiles(ctx, k, tiles_k, side); if (rc) return rc;
+                DIST_HIP(hipEventRecord(D->ev_sfree[b][0], side)); sfree_rec[b][0] = true;
+                DIST_HIP(hipEventRecord(D->ev_hr2, side));
                 on_side[(size_t)nxt] = 1;
             }
             if (sl(nxt)) { rc = xchg_s(nxt, 1); if (rc) return rc; }
@@ -730,6 +737,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
             DIST_HIP(hipStreamWaitEvent(main, D->ev_msg[b], 0));
             size_t sp; rc = span_begin(ctx, D, 3, main, &sp); if (rc) return rc;
             const bool got_slices = early && own(nxt);
+            if (got_slices) DIST_HIP(hipStreamWaitEvent(main, D->ev_hr2, 0));      // panel k's tiles are in the handle's arrays
             { StreamScope sc(ctx, main); rc = unpack_panel_from(ctx, k, D->msg[b], got_slices ? c3n : (int64_t)0, !got_slices, main); }
             if (rc) return rc;
             rc = span_end(ctx, D, sp, main); if (rc) return rc;

@@ -500,9 +500,9 @@ __global__ __launch_bounds__(256) void k_panel_scale(
     double b[16];
     #pragma unroll
     for (int ks = 0; ks < 16; ++ks) b[ks] = Win[i + (col_in + ks * 4 + l4) * ld_in];
-    if (Wcopy) {
+    if (Wcopy) {                                         // -S: the owner loaded S (sign = +1), a receiver -S itself (sign = -1; a product by +-1 is exact)
         #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) Wcopy[i + (col_w + ks * 4 + l4) * ld_w] = -b[ks];
+        for (int ks = 0; ks < 16; ++ks) Wcopy[i + (col_w + ks * 4 + l4) * ld_w] = -sign * b[ks];
     }
     __syncthreads();
     double4_t acc[4];
@@ -1078,6 +1078,25 @@ __global__ __launch_bounds__(256) void k_inpanel_update(
         #pragma unroll
         for (int r = 0; r < 4; ++r)
             C[(i0 + 16 * h + l15) + (ccol + wave * 16 + l4 + 4 * r) * ldc] = acc[h][r];
+}
+
+// A slice of the two-message protocol in ONE launch: E rows of the panel's W (all nbw columns, leading dimension E in the
+// message) and, with slice 1, the panel's tile inverses, tiles and flags behind them (four copies in a row sat on the owners'
+// chain path otherwise).
+__global__ __launch_bounds__(256) void k_slice_pack(double* __restrict__ buf, int64_t E, int64_t nbw, const double* __restrict__ W,
+                                                    int64_t ldw, const double* __restrict__ Dinv, const double* __restrict__ Tsv,
+                                                    const double* __restrict__ Tflag, int with_tiles)
+{
+    const int64_t rows = E * nbw, tb = (nbw / TB) * (int64_t)(TB * TB);
+    const int64_t total = rows + (with_tiles ? 2 * tb + nbw / TB : 0);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        double v;
+        if (e < rows) v = W[(e % E) + (e / E) * ldw];
+        else if (e < rows + tb) v = Dinv[e - rows];
+        else if (e < rows + 2 * tb) v = Tsv[e - rows - tb];
+        else v = Tflag[e - rows - 2 * tb];
+        buf[e] = v;
+    }
 }
 
 // Register-resident MFMA-only loop for the fp64 matrix peak measurement.  Inline asm keeps the

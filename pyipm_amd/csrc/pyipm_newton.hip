@@ -814,38 +814,42 @@ int pack_slice(Ctx* ctx, int64_t p, int j, double* buf, hipStream_t st) {
     const Geo& g = ctx->g;
     int64_t r0; const int64_t E = slice_rows(g, p, j, &r0), nbw = g.panel_w(p), c0 = g.panel_c0(p);
     if (E <= 0) return 0;
-    PYIPM_HIP(hipMemcpy2DAsync(buf, (size_t)E * sizeof(double), wbuf(ctx, p) + r0, (size_t)g.Npad * sizeof(double),
-                               (size_t)E * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, st));
-    if (j == 1) {
-        const size_t tb = (size_t)(nbw / TB) * TB * TB;
-        PYIPM_HIP(hipMemcpyAsync(buf + E * nbw, ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB), tb * sizeof(double), hipMemcpyDeviceToDevice, st));
-        PYIPM_HIP(hipMemcpyAsync(buf + E * nbw + tb, ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB), tb * sizeof(double), hipMemcpyDeviceToDevice, st));
-        PYIPM_HIP(hipMemcpyAsync(buf + E * nbw + 2 * tb, ctx->Tflag + c0 / TB, (size_t)(nbw / TB) * sizeof(double), hipMemcpyDeviceToDevice, st));
-    }
+    const int64_t total = (int64_t)slice_numel(g, p, j);
+    int64_t blocks = (total + 1023) / 1024; if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_slice_pack, dim3((unsigned)blocks), dim3(256), 0, st, buf, E, nbw, wbuf(ctx, p) + r0, g.Npad,
+                       ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB), ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB), ctx->Tflag + c0 / TB,
+                       j == 1 ? 1 : 0);
+    PYIPM_KCHECK();
     return 0;
 }
-// receiver: the W rows go where the panel message would put them, L = W inv(T) of those rows into `EL` (E x nbw, leading dimension E)
-int unpack_slice(Ctx* ctx, int64_t p, int j, const double* buf, double* EL, hipStream_t st) {
+// receiver: L = W inv(T) of the slice's rows into `EL` (E x nbw, leading dimension E), in ONE launch straight from the message:
+// the tile inverses are read where slice 1 carries them (`tiles` = the tail of the slice-1 buffer), and slice 1's W rows --
+// the columns of the panel this rank factors next: the W operand of every update of those columns -- are copied to where the
+// panel message would put them by the same launch.  (Slice 2's W rows are the column positions of a panel this rank does not
+// own: nobody here reads them.)
+int unpack_slice(Ctx* ctx, int64_t p, int j, const double* buf, const double* tiles, double* EL, hipStream_t st) {
     const Geo& g = ctx->g;
-    int64_t r0; const int64_t E = slice_rows(g, p, j, &r0), nbw = g.panel_w(p), c0 = g.panel_c0(p);
+    int64_t r0; const int64_t E = slice_rows(g, p, j, &r0), nbw = g.panel_w(p);
     if (E <= 0) return 0;
-    double* dinv = ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB);
-    double* tsv = ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB);
-    if (j == 1) {
-        const size_t tb = (size_t)(nbw / TB) * TB * TB;
-        PYIPM_HIP(hipMemcpyAsync(dinv, buf + E * nbw, tb * sizeof(double), hipMemcpyDeviceToDevice, st));
-        PYIPM_HIP(hipMemcpyAsync(tsv, buf + E * nbw + tb, tb * sizeof(double), hipMemcpyDeviceToDevice, st));
-        PYIPM_HIP(hipMemcpyAsync(ctx->Tflag + c0 / TB, buf + E * nbw + 2 * tb, (size_t)(nbw / TB) * sizeof(double), hipMemcpyDeviceToDevice, st));
-    }
-    PYIPM_HIP(hipMemcpy2DAsync(wbuf(ctx, p) + r0, (size_t)g.Npad * sizeof(double), buf, (size_t)E * sizeof(double),
-                               (size_t)E * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, st));
+    const int64_t tb = (nbw / TB) * (int64_t)(TB * TB);
     int64_t h0, h1;
     panel_hole(ctx, p, &h0, &h1);
     NextUpd nu_off; memset(&nu_off, 0, sizeof(nu_off));
     hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)(E / TB), (unsigned)(nbw / TB)), dim3(256), 0, st,
-                       EL - r0, E, (int64_t)0, wbuf(ctx, p), g.Npad, (int64_t)0, (double*)nullptr, (int64_t)0, (int64_t)0,
-                       dinv, tsv, ctx->Tflag + c0 / TB, ctx->block_refine, r0, h0, h1, (unsigned long long*)nullptr, -1.0, nu_off);
+                       EL - r0, E, (int64_t)0, buf - r0, E, (int64_t)0, j == 1 ? wbuf(ctx, p) : (double*)nullptr, g.Npad, (int64_t)0,
+                       tiles, tiles + tb, tiles + 2 * tb, ctx->block_refine, r0, h0, h1, (unsigned long long*)nullptr, -1.0, nu_off);
     PYIPM_KCHECK();
+    return 0;
+}
+// ... and the panel's tile inverses, tiles and flags from the slice-1 buffer into the handle's arrays (what the rest of the
+// panel's unpacking and nothing on the chain path reads)
+int unpack_slice_tiles(Ctx* ctx, int64_t p, const double* tiles, hipStream_t st) {
+    const Geo& g = ctx->g;
+    const int64_t nbw = g.panel_w(p), c0 = g.panel_c0(p);
+    const size_t tb = (size_t)(nbw / TB) * TB * TB;
+    PYIPM_HIP(hipMemcpyAsync(ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB), tiles, tb * sizeof(double), hipMemcpyDeviceToDevice, st));
+    PYIPM_HIP(hipMemcpyAsync(ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB), tiles + tb, tb * sizeof(double), hipMemcpyDeviceToDevice, st));
+    PYIPM_HIP(hipMemcpyAsync(ctx->Tflag + c0 / TB, tiles + 2 * tb, (size_t)(nbw / TB) * sizeof(double), hipMemcpyDeviceToDevice, st));
     return 0;
 }
 // The panel message of p on a receiver, rows from `row_from` on only (the rows before it came as slices), tiles optional.

