@@ -133,7 +133,8 @@ int dist_state(Ctx* ctx, DistState** out) {
         DIST_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         DIST_HIP(hipStreamCreateWithPriority(&D->side, hipStreamNonBlocking, hi));
         DIST_HIP(hipStreamCreateWithPriority(&D->cs, hipStreamNonBlocking, hi));
-        DIST_HIP(hipStreamCreateWithPriority(&D->cs2, hipStreamNonBlocking, hi));
+        if (!getenv("PYIPM_NO_CS2")) DIST_HIP(hipStreamCreateWithPriority(&D->cs2, hipStreamNonBlocking, hi));
+        else D->cs2 = D->cs;
         for (int b = 0; b < 2; ++b) {
             DIST_HIP(hipEventCreateWithFlags(&D->ev_fact[b], hipEventDisableTiming));
             DIST_HIP(hipEventCreateWithFlags(&D->ev_msg[b], hipEventDisableTiming));
@@ -156,7 +157,7 @@ void dist_free(Ctx* ctx) {
     if (!D) return;
     if (D->side) { hipStreamSynchronize(D->side); hipStreamDestroy(D->side); }
     if (D->cs) { hipStreamSynchronize(D->cs); hipStreamDestroy(D->cs); }
-    if (D->cs2) { hipStreamSynchronize(D->cs2); hipStreamDestroy(D->cs2); }
+    if (D->cs2 && D->cs2 != D->cs) { hipStreamSynchronize(D->cs2); hipStreamDestroy(D->cs2); }
     if (D->fws) { hipStreamSynchronize(D->fws); hipStreamDestroy(D->fws); }
     if (D->ev_fw) hipEventDestroy(D->ev_fw);
     for (int b = 0; b < 2; ++b) {
