@@ -76,8 +76,11 @@ struct DistState {
     int serialize = 0;                                 // callbacks: run every operation on the collective stream, one at a time (as for RCCL)
     ncclComm_t comm = nullptr;
     ncclComm_t comm2 = nullptr;                        // a second communicator over the same ranks for the slice messages (point to point):
-                                                       // they must not queue behind a panel broadcast in flight (one communicator = one stream)
-    hipStream_t cs2 = nullptr;                         // ... its stream (callbacks that need no serialising use it too)
+                                                       // they must not queue behind a panel broadcast in flight (one communicator = one stream).
+                                                       // Its stream is the OWNER'S stream `side` -- a slice is received exactly where it is
+                                                       // consumed and sent where it was produced.  (A stream of its own was measured: one more
+                                                       // stream in the process and every kernel of a rank got slower -- unpack 4.2 -> 16 ms, bulk
+                                                       // update 16 -> 22 ms per step at N = 32768 on 8 ranks: streams share hardware queues.)
     hipStream_t side = nullptr, cs = nullptr;          // owner's factor + pack stream (high priority); collectives
     hipStream_t fws = nullptr;                         // the forward substitution that trails the factorisation (step_dist)
     hipEvent_t ev_fw = nullptr;
@@ -133,8 +136,6 @@ int dist_state(Ctx* ctx, DistState** out) {
         DIST_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         DIST_HIP(hipStreamCreateWithPriority(&D->side, hipStreamNonBlocking, hi));
         DIST_HIP(hipStreamCreateWithPriority(&D->cs, hipStreamNonBlocking, hi));
-        if (!getenv("PYIPM_NO_CS2")) DIST_HIP(hipStreamCreateWithPriority(&D->cs2, hipStreamNonBlocking, hi));
-        else D->cs2 = D->cs;
         for (int b = 0; b < 2; ++b) {
             DIST_HIP(hipEventCreateWithFlags(&D->ev_fact[b], hipEventDisableTiming));
             DIST_HIP(hipEventCreateWithFlags(&D->ev_msg[b], hipEventDisableTiming));
@@ -157,7 +158,6 @@ void dist_free(Ctx* ctx) {
     if (!D) return;
     if (D->side) { hipStreamSynchronize(D->side); hipStreamDestroy(D->side); }
     if (D->cs) { hipStreamSynchronize(D->cs); hipStreamDestroy(D->cs); }
-    if (D->cs2 && D->cs2 != D->cs) { hipStreamSynchronize(D->cs2); hipStreamDestroy(D->cs2); }
     if (D->fws) { hipStreamSynchronize(D->fws); hipStreamDestroy(D->fws); }
     if (D->ev_fw) hipEventDestroy(D->ev_fw);
     for (int b = 0; b < 2; ++b) {
@@ -265,8 +265,8 @@ int tr_group_end(Ctx* ctx, DistState* D) {
 // The stream the slice messages travel on: their own (second communicator / callbacks that need no serialising), else the
 // collective stream.
 inline hipStream_t tr_slice_stream(const DistState* D) {
-    if (D->comm) return D->comm2 ? D->cs2 : D->cs;
-    return D->serialize ? D->cs : D->cs2;
+    if (D->comm) return D->comm2 ? D->side : D->cs;
+    return D->serialize ? D->cs : D->side;
 }
 int tr_send(Ctx* ctx, DistState* D, const double* buf, size_t count, int peer, hipStream_t st, bool slice = false) {
     D->wire[4] += 1.0;
@@ -606,12 +606,14 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
         return 0;
     };
     // slice j of panel p on the wire: owner(p) -> owner(p + 1); without a point-to-point transport it travels as a broadcast
-    auto xchg_s = [&](int64_t p, int j) -> int {
+    // role: 0 = whatever this rank's part is, 1 = only if it is the sender, 2 = only if it is the receiver
+    auto xchg_s = [&](int64_t p, int j, int role) -> int {
         const size_t cnt = slice_numel(g, p, j);
         if (cnt == 0) return 0;
         const int b = (int)(p & 1), src = g.owner(p), dst = g.owner(p + 1);
         double* buf = D->sbuf[b][j - 1];
-        const bool sender = g.rank == src, receiver = g.rank == dst;
+        const bool sender = g.rank == src && role != 2, receiver = g.rank == dst && role != 1;
+        if (p2p && !sender && !receiver) return 0;
         if (!p2p) {
             if (sender) DIST_HIP(hipStreamWaitEvent(cs, D->ev_spack[b][j - 1], 0));
             else if (sfree_rec[b][j - 1]) DIST_HIP(hipStreamWaitEvent(cs, D->ev_sfree[b][j - 1], 0));
@@ -678,6 +680,16 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
         return update_range(ctx, p, nf, np, main);
     };
 
+    // an early panel's rows beyond its slices + its panel message (see the slot loop)
+    int64_t rest_panel = -1, rest_from = 0;
+    auto flush_rest = [&]() -> int {
+        if (rest_panel < 0) return 0;
+        const int64_t q = rest_panel; rest_panel = -1;
+        size_t sp; int r = span_begin(ctx, D, 4, side, &sp); if (r) return r;
+        r = panel_rows(ctx, q, rest_from, g.Npad, side); if (r) return r;
+        r = span_end(ctx, D, sp, side); if (r) return r;
+        return finish_panel(q, side);
+    };
     // ---- panel 0: its owner factors it whole on the main stream ------------------------------------------------------------
     std::vector<char> on_side((size_t)np, 0);
     if (own(0)) {
@@ -687,7 +699,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
         rc = span_end(ctx, D, sp, main); if (rc) return rc;
         rc = finish_panel(0, main); if (rc) return rc;
     }
-    if (sl(0)) { rc = xchg_s(0, 1); if (rc) return rc; }
+    if (sl(0)) { rc = xchg_s(0, 1, 0); if (rc) return rc; }
     int64_t fwd_next = 0;                                               // first panel whose forward step is not enqueued yet
     for (int64_t k = 0; k < np; ++k) {
         if (below(k) <= 0) break;
@@ -700,7 +712,11 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
         if (early) {
             // (1) slice 2 of panel k, (2) the early phase of panel k + 1 on its owner, (3) slice 1 of panel k + 1, (4) the panel
             // message of k -- in this order on every rank's collective stream
-            rc = xchg_s(k, 2); if (rc) return rc;
+            // (slices on the owner's stream: the receiver posts its receive of slice 2 BEHIND its tile chain, below -- in front of
+            //  it the stream would sit waiting for a message the chain does not need)
+            const bool s2_late = p2p && ps == side;
+            rc = xchg_s(k, 2, s2_late ? 1 : 0); if (rc) return rc;
+            rc = flush_rest(); if (rc) return rc;
             if (own(nxt)) {
                 const int64_t ldE1 = c2n - c1n;
                 if (pre_rec) DIST_HIP(hipStreamWaitEvent(side, D->ev_pre, 0));   // the main stream's updates of panel k + 1's columns
@@ -712,6 +728,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
                 rc = panel_chain(ctx, nxt, side); if (rc) return rc;
                 if (c3n > c2n) {
                     rc = span_end(ctx, D, sp_chain, side); if (rc) return rc;
+                    if (s2_late) { rc = xchg_s(k, 2, 2); if (rc) return rc; }
                     DIST_HIP(hipStreamWaitEvent(side, D->ev_srecv[b][1], 0));
                     rc = span_begin(ctx, D, 0, side, &sp_chain); if (rc) return rc;
                     rc = unpack_slice(ctx, k, 2, D->sbuf[b][1], tiles_k, D->EL[1], side); if (rc) return rc;
@@ -728,8 +745,9 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
                 DIST_HIP(hipEventRecord(D->ev_hr2, side));
                 on_side[(size_t)nxt] = 1;
             }
-            if (sl(nxt)) { rc = xchg_s(nxt, 1); if (rc) return rc; }
+            if (sl(nxt)) { rc = xchg_s(nxt, 1, 0); if (rc) return rc; }
         }
+        rc = flush_rest(); if (rc) return rc;                           // (a slot without slices: nothing to send first)
         rc = bcast_big(k); if (rc) return rc;
         // ---- main stream: panel k becomes available here ------------------------------------------------------------------
         if (own(k)) {
@@ -758,9 +776,10 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
                 size_t sp_rest; rc = span_begin(ctx, D, 4, side, &sp_rest); if (rc) return rc;
                 rc = panel_rows(ctx, nxt, c3n, c4n, side); if (rc) return rc;
                 if (sl(nxt)) { rc = pack_s(nxt, 2, side); if (rc) return rc; }
-                rc = panel_rows(ctx, nxt, c4n, g.Npad, side); if (rc) return rc;
                 rc = span_end(ctx, D, sp_rest, side); if (rc) return rc;
-                rc = finish_panel(nxt, side); if (rc) return rc;
+                // the remaining rows and the panel message follow BEHIND the send of slice 2 on this stream: enqueued at the top
+                // of the next slot, right after that send (flush_rest)
+                rest_panel = nxt; rest_from = c4n;
             } else {
                 // classic: the whole head on the main stream, the whole panel on the side stream behind it
                 const int64_t nbwn = g.panel_w(nxt);
@@ -794,7 +813,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
                 on_side[(size_t)nxt] = 1;
             }
         }
-        if (!early && sl(nxt)) { rc = xchg_s(nxt, 1); if (rc) return rc; }       // (classic panel k + 1: its slice 1 follows the panel message of k)
+        if (!early && sl(nxt)) { rc = xchg_s(nxt, 1, 0); if (rc) return rc; }       // (classic panel k + 1: its slice 1 follows the panel message of k)
         rc = bulk_from(k, nxt); if (rc) return rc;                                // everyone's share of the bulk update of panel k
         // last in the iteration: the host submits the next panel's chain first (in the chain-bound tail the GPU is
         // waiting for exactly those launches; with the forward step submitted ahead of them the factorisation grew by as
@@ -802,6 +821,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
         rc = fwd_step(k); if (rc) return rc;
         fwd_next = k + 1;
     }
+    rc = flush_rest(); if (rc) return rc;
     for (int64_t p = fwd_next; p < np; ++p) { rc = fwd_step(p); if (rc) return rc; }
     if (fwd_b) {
         DIST_HIP(hipEventRecord(D->ev_fw, D->fws)); DIST_HIP(hipStreamWaitEvent(main, D->ev_fw, 0));
@@ -810,7 +830,6 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
     // join the helper streams (the last panel may have been factored on the side stream; messages in flight)
     DIST_HIP(hipEventRecord(D->ev_join, side)); DIST_HIP(hipStreamWaitEvent(main, D->ev_join, 0));
     DIST_HIP(hipEventRecord(D->ev_head, cs));   DIST_HIP(hipStreamWaitEvent(main, D->ev_head, 0));
-    DIST_HIP(hipEventRecord(D->ev_head, D->cs2)); DIST_HIP(hipStreamWaitEvent(main, D->ev_head, 0));
     if (ctx->rest) { DIST_HIP(hipEventRecord(D->ev_join, ctx->rest)); DIST_HIP(hipStreamWaitEvent(main, D->ev_join, 0)); }
     DIST_HIP(hipEventRecord(ctx->ev[1], main));
     ctx->assembled = false;
