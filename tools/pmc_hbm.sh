@@ -6,7 +6,7 @@ OUT=${1:-gpurun_out/pmc_hbm}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $ROOT/$OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 1 --no-cpu-baseline --config4 off --no-clock"
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline --config4 off --configs off --no-clock"
 run() { name=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --kernel-include-regex "k_assemble|k_fwd_gemv|k_bwd_dot|k_bwd_sweep|k_fwd_sweep|k_symv_tiles" --output-format csv -d $ROOT/$OUT/$name -o $name -- python $ROOT/bench.py $ARGS > $ROOT/$OUT/$name.log 2>&1
 }
