@@ -230,6 +230,9 @@ struct Ctx {
     int info_steps = 0, info_converged = 0;
     double info_berr0 = -1.0, info_berr = -1.0;
     int rcond_its[2] = {0, 0};            // power / inverse iterations the last pyipm_newton_rcond took (solve_info reports them)
+    double* rc_warm[2] = {nullptr, nullptr};   // warm start of the adaptive condition estimate: the vectors its power / inverse
+    int64_t rc_warm_n = 0;                // iterations ended with last time (the next estimate starts from them)
+    bool rc_warm_valid[2] = {false, false};
     double refine_target = 1.0e-14;       // adaptive refinement stops at this backward error ...
     int refine_max = 8;                   // ... or after this many steps, or when a step gains less than 4x
     // options

@@ -2080,6 +2080,7 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     if (ctx->sweep_sync) hipFree(ctx->sweep_sync);
     if (ctx->sweep_buf) hipFree(ctx->sweep_buf);
     if (ctx->merit_buf) hipFree(ctx->merit_buf);
+    if (ctx->rc_warm[0]) hipFree(ctx->rc_warm[0]);
     if (ctx->ray_buf) hipFree(ctx->ray_buf);
     if (ctx->own_ws && ctx->ws) hipFree(ctx->ws);
     delete ctx;
@@ -2118,6 +2119,7 @@ int pyipm_newton_stage_blocks(pyipm_newton_ctx* h, const double* d2L, int64_t ld
     rc = stage_block(ctx, Ji, g.mi ? g.n : 0, g.mi, ld_Ji, memkind, &ctx->stg_Ji, &ctx->stg_Ji_sz, &ctx->Ji, &ctx->ld_Ji); if (rc) return rc;
     ctx->have_blocks = true;
     ctx->ray_valid = false;
+    ctx->rc_warm_valid[0] = ctx->rc_warm_valid[1] = false;      // (another matrix: the condition estimate starts cold)
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)
 
@@ -2331,11 +2333,34 @@ int pyipm_newton_rcond(pyipm_newton_ctx* h, int it_inv, int it_pow, double out[4
         *nrm = sqrt(ss[0]);
         return 0;
     };
+    // Warm start (round 5, adaptive mode only): late in an interior-point run this estimate is taken at EVERY iterate, on a matrix
+    // that changes little from one iterate to the next -- and so do its extreme eigenvectors.  Starting each iteration from the
+    // vector the previous estimate ended with (instead of a hashed one) the first two estimates already agree: two substitution
+    // sweeps instead of three, two products instead of up to six (-5 ms per late iterate at N = 32768).  Any start vector with a
+    // component along the extreme eigenvector is valid; the stopping rules are unchanged; a hashed start is taken whenever the
+    // stored vector is missing, of another size, or not finite.  stage_blocks forgets it.
+    const bool warm_ok = (adaptive_inv || adaptive_pow) && !ctx->cond_active && getenv("PYIPM_RCOND_COLD") == nullptr;
+    if (warm_ok && ctx->rc_warm_n != g.Npad) {
+        if (ctx->rc_warm[0]) { PYIPM_HIP(hipStreamSynchronize(ctx->stream)); PYIPM_HIP(hipFree(ctx->rc_warm[0])); ctx->rc_warm[0] = nullptr; }
+        if (hipMalloc((void**)&ctx->rc_warm[0], 2 * (size_t)g.Npad * sizeof(double)) != hipSuccess) { ctx->rc_warm[0] = nullptr; ctx->rc_warm_n = 0; }
+        else { ctx->rc_warm[1] = ctx->rc_warm[0] + g.Npad; ctx->rc_warm_n = g.Npad; }
+        ctx->rc_warm_valid[0] = ctx->rc_warm_valid[1] = false;
+    }
     for (int phase = 0; phase < 2; ++phase) {
-        hipLaunchKernelGGL(k_hash_vector, grid1(g.Npad), dim3(256), 0, ctx->stream, wb, g.N, g.Npad, (unsigned long long)(17 + phase));
-        PYIPM_KCHECK();
+        const bool adaptive_phase = phase == 0 ? adaptive_pow : adaptive_inv;
+        const bool warm = warm_ok && adaptive_phase && ctx->rc_warm[0] && ctx->rc_warm_valid[phase];
+        if (warm) PYIPM_HIP(hipMemcpyAsync(wb, ctx->rc_warm[phase], g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        else {
+            hipLaunchKernelGGL(k_hash_vector, grid1(g.Npad), dim3(256), 0, ctx->stream, wb, g.N, g.Npad, (unsigned long long)(17 + phase));
+            PYIPM_KCHECK();
+        }
         double nrm = 0.0, est = 0.0, prev_est = 0.0;
         int rc = norm_of(wb, &nrm); if (rc) return rc;
+        if (warm && (!(nrm > 0.0) || !(nrm <= 1.0e300))) {              // (a stored vector that went bad: start over)
+            hipLaunchKernelGGL(k_hash_vector, grid1(g.Npad), dim3(256), 0, ctx->stream, wb, g.N, g.Npad, (unsigned long long)(17 + phase));
+            PYIPM_KCHECK();
+            rc = norm_of(wb, &nrm); if (rc) return rc;
+        }
         const int its = phase == 0 ? it_pow : it_inv;
         for (int it = 0; it < its; ++it) {
             if (!(nrm > 0.0) || !(nrm <= 1.0e300)) break;
@@ -2360,6 +2385,12 @@ int pyipm_newton_rcond(pyipm_newton_ctx* h, int it_inv, int it_pow, double out[4
             }
         }
         if (phase == 0) lmax = est; else linv = est;
+        if (warm_ok && adaptive_phase && ctx->rc_warm[0]) {
+            // keep the iterate (unnormalised: the next call normalises it) -- if it is finite
+            const bool good = nrm > 0.0 && nrm <= 1.0e300;
+            if (good) PYIPM_HIP(hipMemcpyAsync(ctx->rc_warm[phase], wb, g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            ctx->rc_warm_valid[phase] = good;
+        }
     }
     ctx->rcond_its[0] = used_pow; ctx->rcond_its[1] = used_inv;
     const double lmin = linv > 0.0 ? 1.0 / linv : 0.0;
