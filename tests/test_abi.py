@@ -113,3 +113,21 @@ def test_bench_default_panel_width():
     assert bench.default_panel_width(1, 32768) == 256 and bench.default_panel_width(1, 131072) == 256
     assert bench.default_panel_width(8, 32768) == 256 and bench.default_panel_width(2, 40960) == 256
     assert bench.default_panel_width(8, 131072) == 1024 and bench.default_panel_width(2, 65536) == 1024
+
+
+def test_option_lists_of_header_and_sources_agree():
+    """include/pyipm_newton.h documents 25 public options and names the expert ones: both lists against
+    the option names the sources actually compare with, and against the table that gates the expert ones -- without a GPU."""
+    hdr = open(os.path.join(ROOT, "include", "pyipm_newton.h")).read()
+    pub = re.search(r"PUBLIC OPTIONS:(.*?)\n \*\n", hdr, re.S).group(1)
+    exp = re.search(r"EXPERT OPTIONS:(.*?)\n \*   \(which stream", hdr, re.S).group(1)
+    names = lambda blk: [w for w in re.sub(r"[*\n]", " ", blk).replace(",", " ").split() if w]     # noqa: E731
+    pub, exp = names(pub), names(exp)
+    assert len(pub) <= 25 and len(set(pub)) == len(pub) and len(set(exp)) == len(exp) and not set(pub) & set(exp)
+    src = ""
+    for f in ("pyipm_newton.hip", "dist_impl.hpp"):
+        src += open(os.path.join(ROOT, "pyipm_amd", "csrc", f)).read()
+    accepted = set(re.findall(r'strcmp\(name, "([a-z_0-9]+)"\)', src))
+    assert accepted == set(pub) | set(exp), accepted ^ (set(pub) | set(exp))
+    table = re.search(r"kExpert\[\] = \{(.*?)\};", src, re.S).group(1)
+    assert set(re.findall(r'"([a-z_0-9]+)"', table)) == set(exp)

@@ -334,3 +334,35 @@ def test_infeasible_and_unbounded_problems_end_loudly():
             assert p.signal != 1
         except RuntimeError as e:
             assert "shift" in str(e) or "inertia" in str(e)
+
+
+def test_device_loop_with_dependent_equalities_and_inequalities():
+    """with exactly dependent equality constraints the backend may give up on shifting and return an EARLIER, less
+    shifted direction than the handle's last solve; the fraction-to-the-boundary lengths of the device loop must belong to the
+    direction returned (s and lda_i stay positive at every iterate, the merit never turns NaN), and the solve still ends at the
+    optimum of the consistent problem."""
+    from pyipm_amd.qp import QPDeviceIPM
+    rng = np.random.default_rng(21)
+    n, me, mi = 60, 6, 40
+    M = rng.standard_normal((n, n))
+    Q, c = M @ M.T / n + np.eye(n), rng.standard_normal(n)
+    A = rng.standard_normal((me, n))
+    A[4] = A[0] + A[1]                                           # exactly dependent rows ...
+    A[5] = 2.0 * A[2]
+    xf = 0.1 * rng.standard_normal(n)
+    b = A @ xf                                                   # ... of a consistent system
+    G = np.vstack([np.eye(n)[:mi // 2], -np.eye(n)[:mi // 2]])
+    h = -np.ones(mi)
+    p = QPDeviceIPM(Q, c, A=A, b=b, G=G, h=h, verbosity=-1, Ktol=1e-7, niter=20, miter=20)
+    p.trace = []
+    x, s, lda, fval, kkt = p.solve()
+    for xt, st, lt, _mu in p.trace:
+        assert np.isfinite(xt).all() and (st > 0).all() and (lt[me:] > 0).all()
+    x = x.cpu().numpy()
+    assert np.isfinite(float(fval)) and p.signal in (1, -1)
+    assert np.abs(A @ x - b).max() <= 1e-6 and (G @ x - h).min() >= -1e-6
+    # the optimum: against the same problem with the dependent rows removed (full row rank: the plain path)
+    q = QPDeviceIPM(Q, c, A=A[:4], b=b[:4], G=G, h=h, verbosity=-1, Ktol=1e-7, niter=20, miter=20)
+    x2 = q.solve()[0].cpu().numpy()
+    assert abs(float(fval) - float(q.fval)) <= 1e-5 * max(1.0, abs(float(q.fval)))
+    assert np.linalg.norm(x - x2) <= 1e-3 * max(1.0, np.linalg.norm(x2))
