@@ -239,6 +239,9 @@ struct Ctx {
     double pivtol_rel = 1e-14;
     int tile_blocked = 1;                 // tile inversion 16 pivots at a time while Bunch-Kaufman would accept them in natural order
                                           // (tile_blocked.hpp); 0: the single sweeps of rounds 1-2 only
+    int tile_waves = 8;                   // k_tile_step on 512 threads (round 5): the critical block = four chain waves + four helper waves
+                                          // (diagonal tile prefetched beside the scaling product; the blocked inversion's updates and commits
+                                          // beside the next elimination, tile_blocked8.hpp); 4: the 256-thread kernel of rounds 2-4.  Same bits.
     int block_refine = 2;                 // refinement steps of L T = S in the panel scaling and of T z = y in the solves
     double refine_cond = 1.0e3;           // ... applied to tiles whose pivot spread dmax/dmin exceeds this
     int profile = 0;

@@ -9,6 +9,7 @@
 #pragma once
 #include "ctx.hpp"
 #include "tile_blocked.hpp"
+#include "tile_blocked8.hpp"
 
 namespace pyipm {
 
@@ -112,6 +113,11 @@ static_assert(sizeof(BlockedScratch) + 4 * TB * sizeof(double) <= 16 * TB * size
 
 // The sweep inversion itself; called by k_tile_invert (one tile of the big factorisation) and by the
 // batched small-system kernel (every tile of one problem, one workgroup per problem).
+// W8 (k_tile_step8, 512 threads): waves 4..7 are HELPERS -- they save the tile for the refinement, form the column maxima
+// and run the updates / commits of the blocked sweep (tile_blocked8.hpp) beside the critical waves' eliminations, and
+// leave the kernel when the blocked sweep ends; ex = its exchange scratch.  Everything from the general loop on runs on
+// waves 0..3 as before.
+template <bool W8 = false>
 __device__ __forceinline__ void tile_invert_dev(
     TileScratch& sm,
     const double* __restrict__ A, int64_t ld, int64_t grow0, int64_t lcol0,
@@ -122,7 +128,8 @@ __device__ __forceinline__ void tile_invert_dev(
     int64_t neg_from,                          // global index from which pivots are expected negative (n + mi; pyipm.py:1381)
     unsigned long long* __restrict__ dbg,      // diagnostics only (NULL normally)
     bool from_stage = false,                   // the caller has put the tile into sm.stage[i][j] (i >= j at least): no global read
-    bool blocked = true)                       // try the blocked fast path first (tile_blocked.hpp); false: the sweeps of rounds 1-2 only
+    bool blocked = true,                       // try the blocked fast path first (tile_blocked.hpp); false: the sweeps of rounds 1-2 only
+    Blocked8Scratch* ex = nullptr)             // W8 only
 {
     double (&stage)[TB][TB + 1] = sm.stage;
     double (&colbuf)[2][2][TB] = sm.colbuf;
@@ -130,42 +137,66 @@ __device__ __forceinline__ void tile_invert_dev(
     unsigned long long dbg_c0 = 0, dbg_w0 = 0;
     if (dbg) { dbg_c0 = clock64(); dbg_w0 = wall_clock64(); }
 
+    constexpr int NT = W8 ? 512 : 256;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), cb = wave * 16;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3, cb = wave * 16;
+    const bool helper = W8 && tid >= 256;
 
     if (!from_stage) {
-        // coalesced read of the lower triangle: ALL 16 loads of a thread in flight before the first wait (the rolled loop
+        // coalesced read of the lower triangle: ALL loads of a thread in flight before the first wait (the rolled loop
         // waited out one memory latency per trip, on the critical path of the whole factorisation)
-        double tmp[TB * TB / 256];
+        double tmp[TB * TB / NT];
         #pragma unroll
-        for (int q = 0; q < TB * TB / 256; ++q) {
-            const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+        for (int q = 0; q < TB * TB / NT; ++q) {
+            const int e = tid + NT * q, i = e & 63, j = e >> 6;
             tmp[q] = (i >= j) ? A[(grow0 + i) + (lcol0 + j) * ld] : 0.0;
         }
         #pragma unroll
-        for (int q = 0; q < TB * TB / 256; ++q) {
-            const int e = tid + 256 * q, i = e & 63, j = e >> 6;
+        for (int q = 0; q < TB * TB / NT; ++q) {
+            const int e = tid + NT * q, i = e & 63, j = e >> 6;
             if (i >= j) stage[i][j] = tmp[q];
         }
     }
     __syncthreads();
     row16_t row;                           // native 16-wide vector: a wave-uniform dynamic index becomes ONE
     double amax = 0.0;                     // relative-addressed move (s_set_gpr_idx), not a 16-deep select chain
-    #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const int j = cb + c;
-        row[c] = (lane >= j) ? stage[lane][j] : stage[j][lane];
-        amax = fmax(amax, fabs(row[c]));
-        Tsave[j * TB + lane] = row[c];                 // kept for the refinement of the block solves
+    int kb_done8 = 0;
+    if (!W8 || helper || !blocked) {
+        #pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int j = cb + c;
+            row[c] = (lane >= j) ? stage[lane][j] : stage[j][lane];
+            if (!W8 || helper) {
+                amax = fmax(amax, fabs(row[c]));
+                Tsave[j * TB + lane] = row[c];             // kept for the refinement of the block solves
+            }
+        }
     }
     // per-row maximum of the loaded tile (== per-column, by symmetry): the reference scale of a pivot.
     // A pivot counts as rejected only when it has shrunk below pivtol_rel x its OWN column's original
     // magnitude (cancellation), so a badly scaled but perfectly regular tile (Sigma entries spanning
     // 1e-8..1e8 late in an interior-point run) is left alone.
-    sm.f.xmax[wave][lane] = amax;
-    amax = wave_max(amax);
-    if (lane == 0) sh_red[wave] = amax;
-    __syncthreads();
+    if (!W8 || helper) {
+        sm.f.xmax[wave][lane] = amax;
+        amax = wave_max(amax);
+        if (lane == 0) sh_red[wave] = amax;
+    }
+    if (W8) {
+        // the critical waves are already eliminating the first micro-block while the helpers do the above
+        if (helper) {
+            if (tid == 256) sm.f.bs.fail = 0;
+            if (blocked) tile_blocked8_sweep_help(stage, sm.f.bs, *ex);
+            else __syncthreads();
+            return;                                    // the helpers are done (a barrier counts the waves that are left)
+        }
+        if (blocked) {
+            if (dbg && tid == 0) dbg[4] = clock64() - dbg_c0;
+            kb_done8 = tile_blocked8_sweep_crit(stage, sm.f.bs, *ex, sm.dsave, sm.f.xmax, pivtol_rel, dbg);
+            if (dbg && tid == 0) { dbg[5] = clock64() - dbg_c0; dbg[6] = dbg_c0; dbg[7] += (unsigned long long)kb_done8; }
+        } else __syncthreads();
+    } else {
+        __syncthreads();
+    }
     const double cmax0 = fmax(fmax(sm.f.xmax[0][lane], sm.f.xmax[1][lane]), fmax(sm.f.xmax[2][lane], sm.f.xmax[3][lane]));
     const double scale = fmax(fmax(sh_red[0], sh_red[1]), fmax(sh_red[2], sh_red[3]));
     const double inv_scale = scale > 0.0 ? 1.0 / scale : 0.0;
@@ -181,8 +212,15 @@ __device__ __forceinline__ void tile_invert_dev(
     const int nreal = (int)((Nreal - grow0) < 0 ? 0 : ((Nreal - grow0) > TB ? TB : (Nreal - grow0)));   // real rows in this tile
 
     // ---- blocked fast path: 16 pivots at a time in natural order while Bunch-Kaufman would have accepted them ----
-    int kb_done = 0;
-    if (blocked) {
+    int kb_done = kb_done8;
+    if (W8 && blocked) {
+        #pragma unroll
+        for (int c = 0; c < 16; ++c) {                 // the working matrix as it stands, in the sweep layout
+            const int j = cb + c;
+            row[c] = (lane >= j) ? stage[lane][j] : stage[j][lane];
+        }
+    }
+    if (!W8 && blocked) {
         if (wave == 0) sm.f.bs.ptol[lane] = ptol;
         if (tid == 0) sm.f.bs.fail = 0;
         __syncthreads();

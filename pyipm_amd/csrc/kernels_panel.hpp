@@ -22,6 +22,12 @@ namespace pyipm {
 
 // L = S inv(T) for one 64-row strip (wave: 16 rows x 64 columns), nref refinement steps against T; the arithmetic of
 // k_panel_scale with sign = +1.  X holds inv(T) on entry (staged, synchronised) and on exit; sb = S in the B-operand map.
+// one refinement step of strip_scale (four barriers)
+__device__ __forceinline__ void strip_refine_step(double (&X)[TB][TB + 2], const double* __restrict__ Tinv,
+                                                  const double* __restrict__ Tsave, const double (&sb)[16],
+                                                  int tid, int l15, int l4, double4_t (&acc)[4]);
+
+template <bool REFINE = true>
 __device__ __forceinline__ void strip_scale(double (&X)[TB][TB + 2], const double* __restrict__ Tinv,
                                             const double* __restrict__ Tsave, int nref, const double (&sb)[16],
                                             int tid, int l15, int l4, double4_t (&acc)[4])
@@ -36,7 +42,15 @@ __device__ __forceinline__ void strip_scale(double (&X)[TB][TB + 2], const doubl
             acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sb[ks], acc[t], 0, 0, 0);
         }
     }
-    for (int it = 0; it < nref; ++it) {
+    if (REFINE)
+        for (int it = 0; it < nref; ++it) strip_refine_step(X, Tinv, Tsave, sb, tid, l15, l4, acc);
+}
+
+__device__ __forceinline__ void strip_refine_step(double (&X)[TB][TB + 2], const double* __restrict__ Tinv,
+                                                  const double* __restrict__ Tsave, const double (&sb)[16],
+                                                  int tid, int l15, int l4, double4_t (&acc)[4])
+{
+    {
         __syncthreads();
         PYIPM_STAGE_TILE(X, -1.0, Tsave)
         __syncthreads();
@@ -219,6 +233,180 @@ __global__ __launch_bounds__(256, 2) void k_tile_step(
     if (b == 0)
         tile_invert_dev(sm, A, ld, c0 + (int64_t)t * TB, lc0 + (int64_t)t * TB, Dinv + t * TT, Tsv + t * TT, Tflag + t, refine_cond,
                         st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg, /*from_stage=*/true, blocked != 0);
+}
+
+// k_tile_step on 512 threads (round 5).  Same arithmetic, same order per entry -- the same bits -- with the work of the
+// critical block split over eight waves:
+//   * block 0: waves 0..3 are the chain (scaling product, update of the diagonal tile, the eliminations of the blocked
+//     inversion); waves 4..7 fetch the diagonal tile while the scaling runs (the chain used to wait out a memory round trip
+//     for it after the scaling: requesting it earlier from the same waves spilled registers), save the tile for the
+//     refinement, form the column maxima and run the inversion's updates and commits beside the next elimination
+//     (tile_blocked8.hpp).  The -S' operand of the diagonal update sits in a buffer of its own, so no barrier separates
+//     the two products.
+//   * blocks 1..: two (row tile, y) units of k_tile_step per block, one per half (the same footprint per CU as two
+//     256-thread blocks).
+// grid = (1 + ceil((nt - t - 1) * ny / 2)); ny as for k_tile_step.
+struct TileScratch8 {
+    TileScratch ts;
+    double X[TB][TB + 2];        // inv(T[t-1]) (block 0; unit of half 0)
+    double Wn[TB][TB + 2];       // -S' of the critical rows, [k][c] (block 0); inv(T[t-1]) of the unit of half 1
+    Blocked8Scratch ex;
+};
+
+__global__ __launch_bounds__(512) void k_tile_step8(
+    double* __restrict__ A, int64_t ld, int64_t c0, int64_t lc0, int t, int nt, int ny,
+    double* __restrict__ W, int64_t ldw,
+    double* __restrict__ Dinv, double* __restrict__ Tsv, double* __restrict__ Tflag,
+    double refine_cond, int nref, DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel,
+    const unsigned long long* __restrict__ anorm_bits, int64_t neg_from, unsigned long long* __restrict__ dbg, int blocked)
+{
+    __shared__ TileScratch8 sm;
+    __builtin_amdgcn_s_setprio(3);
+    const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
+    const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int64_t TT = (int64_t)TB * TB;
+    if (blockIdx.x == 0) {
+        // ------------------------------------------------ the critical block ------------------------------------------------
+        if (t == 0) {
+            tile_invert_dev<true>(sm.ts, A, ld, c0, lc0, Dinv, Tsv, Tflag, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg,
+                                  false, blocked != 0, &sm.ex);
+            return;
+        }
+        const int tp = t - 1;
+#define PYIPM_TS_STAMP(k_) if (dbg && threadIdx.x == 0) dbg[200 + (k_)] = clock64();
+        PYIPM_TS_STAMP(0)
+        const int64_t i = c0 + (int64_t)t * TB + wave * 16 + l15;    // this lane's (global) row: the same map in both halves
+        if (nref > 0 && Tflag[tp] == 0.0) nref = 0;                  // (uniform over the block)
+        double4_t acc[4];
+        double sb[16];
+        if (half == 0) {
+            PYIPM_STAGE_TILE(sm.X, 1.0, Dinv + tp * TT)
+            #pragma unroll
+            for (int ks = 0; ks < 16; ++ks) sb[ks] = -W[i + (int64_t)(tp * TB + ks * 4 + l4) * ldw];
+            #pragma unroll
+            for (int ks = 0; ks < 16; ++ks) sm.Wn[ks * 4 + l4][wave * 16 + l15] = -sb[ks];      // Wn[c][k] = -S[c][k], stored [k][c]
+        } else {
+            double c2[16];                                           // the diagonal tile as it stands, in the C/D map of the update
+            #pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) c2[4 * tt + r] = A[i + (lc0 + t * TB + tt * 16 + l4 + 4 * r) * ld];
+            #pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) sm.ts.stage[wave * 16 + l15][tt * 16 + l4 + 4 * r] = c2[4 * tt + r];
+        }
+        __syncthreads();
+        PYIPM_TS_STAMP(1)
+        if (half == 0) {
+            strip_scale<false>(sm.X, Dinv + tp * TT, Tsv + tp * TT, 0, sb, tid, l15, l4, acc);
+        }
+        for (int it = 0; it < nref; ++it) {                          // refinement of the block solve: four barriers a step,
+            if (half == 0) strip_refine_step(sm.X, Dinv + tp * TT, Tsv + tp * TT, sb, tid, l15, l4, acc);   // the helpers keep count
+            else { __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); }
+        }
+        if (half == 0) {
+            if (dbg) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][3])); PYIPM_TS_STAMP(2) }
+            double4_t c2[4];
+            #pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) c2[tt][r] = sm.ts.stage[wave * 16 + l15][tt * 16 + l4 + 4 * r];
+            #pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const double lop = acc[ks >> 2][ks & 3];
+                #pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+                    c2[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(sm.Wn[ks * 4 + l4][16 * tt + l15], lop, c2[tt], 0, 0, 0);
+            }
+            double gmax = 0.0;                                       // L goes out while the matrix pipe works on the update
+            #pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    A[i + (lc0 + tp * TB + tt * 16 + l4 + 4 * r) * ld] = acc[tt][r];
+                    gmax = fmax(gmax, fabs(acc[tt][r]));
+                }
+            gmax = wave_max(gmax);
+            if (lane == 0) atomicMax(&st->growth_bits, (unsigned long long)__double_as_longlong(gmax));
+            PYIPM_TS_STAMP(3)
+            #pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = tt * 16 + l4 + 4 * r;
+                    A[i + (lc0 + t * TB + c) * ld] = c2[tt][r];
+                    sm.ts.stage[wave * 16 + l15][c] = c2[tt][r];
+                }
+        }
+        PYIPM_TS_STAMP(4)
+#undef PYIPM_TS_STAMP
+        tile_invert_dev<true>(sm.ts, A, ld, c0 + (int64_t)t * TB, lc0 + (int64_t)t * TB, Dinv + t * TT, Tsv + t * TT, Tflag + t, refine_cond,
+                              st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg, /*from_stage=*/true, blocked != 0, &sm.ex);
+        return;
+    }
+    // ------------------------------------------------ the other row tiles -----------------------------------------------
+    const int unit = 2 * ((int)blockIdx.x - 1) + half;
+    const int b = 1 + unit / ny, y = unit % ny;
+    const bool live = b < nt - t;                                    // (uniform per half)
+    if (t == 0) {
+        if (live && y == 0) {
+            double tmp[TB * TB / 256];
+            const int64_t r0 = c0 + (int64_t)b * TB;
+            #pragma unroll
+            for (int q = 0; q < TB * TB / 256; ++q) {
+                const int e = tid + 256 * q;
+                tmp[q] = A[(r0 + (e & 63)) + (lc0 + (e >> 6)) * ld];
+            }
+            #pragma unroll
+            for (int q = 0; q < TB * TB / 256; ++q) {
+                const int e = tid + 256 * q;
+                W[(r0 + (e & 63)) + (int64_t)(e >> 6) * ldw] = -tmp[q];
+            }
+        }
+        return;
+    }
+    const int tp = t - 1, it = t + b;
+    if (!live || y > it - t) return;                                 // (a half that leaves is not waited for)
+    double (&X)[TB][TB + 2] = half ? sm.Wn : sm.X;
+    const int64_t i = c0 + (int64_t)it * TB + wave * 16 + l15;
+    if (nref > 0 && Tflag[tp] == 0.0) nref = 0;
+    PYIPM_STAGE_TILE(X, 1.0, Dinv + tp * TT)
+    double sb[16];
+    #pragma unroll
+    for (int ks = 0; ks < 16; ++ks) sb[ks] = -W[i + (int64_t)(tp * TB + ks * 4 + l4) * ldw];
+    __syncthreads();
+    double4_t acc[4];
+    strip_scale(X, Dinv + tp * TT, Tsv + tp * TT, nref, sb, tid, l15, l4, acc);
+    if (y == 0) {
+        double gmax = 0.0;
+        #pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                A[i + (lc0 + tp * TB + tt * 16 + l4 + 4 * r) * ld] = acc[tt][r];
+                gmax = fmax(gmax, fabs(acc[tt][r]));
+            }
+        gmax = wave_max(gmax);
+        if (lane == 0) atomicMax(&st->growth_bits, (unsigned long long)__double_as_longlong(gmax));
+    }
+    for (int v = t + y; v <= it; v += ny) {
+        double4_t c2[4];
+        #pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) c2[tt][r] = A[i + (lc0 + v * TB + tt * 16 + l4 + 4 * r) * ld];
+        strip_update(c2, acc, W + (c0 + (int64_t)v * TB) + (int64_t)(tp * TB) * ldw, ldw, l15, l4);
+        #pragma unroll
+        for (int tt = 0; tt < 4; ++tt)
+            #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = tt * 16 + l4 + 4 * r;
+                A[i + (lc0 + v * TB + c) * ld] = c2[tt][r];
+                if (v == t) W[i + (int64_t)(t * TB + c) * ldw] = -c2[tt][r];
+            }
+    }
 }
 
 // (Round 3 built the tile steps of a sub-panel as ONE launch -- k_tile_chain, in the history at commit 435e38f: a

@@ -337,7 +337,9 @@ SCHEDULE_SPACE = {"lookahead": [0, 1], "group": [1, 2, 4, 8], "group_chain": [0,
                   # the rest of the header's schedule switches (round 5: the header and this sweep list the same names)
                   "tail_group": [2, 4], "tail_cols": [0, 24576, 1 << 20], "xcd_swizzle": [0, 1], "side_prio": [0, 1], "bulk_waves": [4, 8],
                   "rest_prio": [0, 1], "s_fast": [0, 1], "head_waves": [4, 8], "inpanel32": [0, 1],
-                  "fuse_scale_update": [0, 1], "asm_tri": [0, 1], "asm_split": [0, 1]}
+                  "fuse_scale_update": [0, 1], "asm_tri": [0, 1], "asm_split": [0, 1],
+                  # round 5: the tile steps' critical block on eight waves (chain + helpers)
+                  "tile_waves": [4, 8]}
 
 
 def test_option_lists_header_library_and_sweep_agree():

@@ -6,7 +6,7 @@ cp $S/bench_kernel_stats.txt ${P}_kernel_stats.txt; cp $S/pmc_update.json ${P}_p
 for c in 2 3 4; do cp $S/cfg${c}_kernel_stats.txt ${P}_cfg${c}_kernel_stats.txt; done
 for f in $S/cfg/*.json; do cp $f ${P}_$(basename $f); done
 for f in bench_batched.txt bench_tile.txt update_cycles.txt; do [ -f $S/$f ] && grep -v "amdgpu.ids" $S/$f > ${P}_$f; done
-for f in qp_solve_condensed qp_solve_full replay_N32768 replay_N131072 first_call bench_provider; do grep '^{' $S/$f.json | tail -1 > ${P}_$f.json; done
+for f in qp_solve_condensed qp_solve_full replay_N32768 replay_N131072 first_call bench_provider; do [ -f $S/$f.json ] && grep '^{' $S/$f.json | tail -1 > ${P}_$f.json; done
 cp $S/qp_kernel_stats.txt ${P}_qp_search_kernel_stats.txt
 grep '^{' $S/bench_lbfgs.txt | tail -1 > ${P}_lbfgs.json
 grep pyipm $S/first_call.err > ${P}_first_call_setup_trace.txt

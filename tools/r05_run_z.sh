@@ -29,11 +29,7 @@ timeout 600 python tools/qp_solve.py --condensed > $O/qp_solve_condensed.json 2>
 # the search phase of the device QP loop under a kernel trace: no at::native reduction left in it
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $R/$O/prof_qp -o qp -- python $R/tools/qp_solve.py --nvar 4096 --neq 1024 --nineq 1536 > $R/$O/qp_small_under_rocprof.json 2> $R/$O/qp_rocprof.err )
 python tools/rocpd_stats.py $(find $O/prof_qp -name "*.db" | head -1) $O/qp_kernel_stats.txt > /dev/null 2>&1; rm -rf $O/prof_qp
-timeout 1500 python tools/rank_replay.py --nb 256 > $O/replay_N32768.json 2> $O/replay_N32768.err; tail -6 $O/replay_N32768.err
-timeout 900 python tools/rank_replay.py --nb 256 --worlds 8 --models sag --slices 0 > $O/replay_N32768_one_message.json 2> /dev/null
-timeout 900 python tools/rank_replay.py --nb 256 --worlds 8 --models sag --serialize 1 > $O/replay_N32768_one_communicator.json 2> /dev/null
-timeout 1200 python tools/rank_replay.py --nb 1024 --worlds 8 --models sag > $O/replay_N32768_nb1024.json 2> /dev/null
-timeout 3000 python tools/rank_replay.py --nvar 65536 --neq 0 --nineq 32768 --host-record --steps 1 --worlds 4,8 --models sag > $O/replay_N131072.json 2> $O/replay_N131072.err; tail -6 $O/replay_N131072.err
+if [ -n "${WITH_REPLAY:-}" ]; then bash tools/r05_run_z_replay.sh; fi
 PYIPM_SETUP_TRACE=1 timeout 300 python tools/first_call.py > $O/first_call.json 2> $O/first_call.err
 timeout 300 python tools/bench_provider.py > $O/bench_provider.json 2> /dev/null
 timeout 600 python tools/bench_batched.py > $O/bench_batched.txt 2>&1
