@@ -243,9 +243,10 @@ __global__ __launch_bounds__(256, 2) void k_tile_step(
 //     refinement, form the column maxima and run the inversion's updates and commits beside the next elimination
 //     (tile_blocked8.hpp).  The -S' operand of the diagonal update sits in a buffer of its own, so no barrier separates
 //     the two products.
-//   * blocks 1..: two (row tile, y) units of k_tile_step per block, one per half (the same footprint per CU as two
-//     256-thread blocks).
-// grid = (1 + ceil((nt - t - 1) * ny / 2)); ny as for k_tile_step.
+//   * blocks 1..: upb = 2: two (row tile, y) units of k_tile_step per block, one per half (the footprint per CU of two
+//     256-thread blocks: what fits beside a bulk update); upb = 1: one unit per block, the other half leaves at once (an
+//     idle GPU: two units on one CU share its matrix pipes and the launch would end after its critical block).
+// grid = (1 + ceil((nt - t - 1) * ny / upb)); ny as for k_tile_step.
 struct TileScratch8 {
     TileScratch ts;
     double X[TB][TB + 2];        // inv(T[t-1]) (block 0; unit of half 0)
@@ -254,7 +255,7 @@ struct TileScratch8 {
 };
 
 __global__ __launch_bounds__(512) void k_tile_step8(
-    double* __restrict__ A, int64_t ld, int64_t c0, int64_t lc0, int t, int nt, int ny,
+    double* __restrict__ A, int64_t ld, int64_t c0, int64_t lc0, int t, int nt, int ny, int upb,
     double* __restrict__ W, int64_t ldw,
     double* __restrict__ Dinv, double* __restrict__ Tsv, double* __restrict__ Tflag,
     double refine_cond, int nref, DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel,
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(512) void k_tile_step8(
     const int64_t TT = (int64_t)TB * TB;
     if (blockIdx.x == 0) {
         // ------------------------------------------------ the critical block ------------------------------------------------
+        if (half) __builtin_amdgcn_s_setprio(1);                     // the chain's waves win the issue arbitration on their SIMDs
         if (t == 0) {
             tile_invert_dev<true>(sm.ts, A, ld, c0, lc0, Dinv, Tsv, Tflag, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from, dbg,
                                   false, blocked != 0, &sm.ex);
@@ -279,33 +281,44 @@ __global__ __launch_bounds__(512) void k_tile_step8(
         const int64_t i = c0 + (int64_t)t * TB + wave * 16 + l15;    // this lane's (global) row: the same map in both halves
         if (nref > 0 && Tflag[tp] == 0.0) nref = 0;                  // (uniform over the block)
         double4_t acc[4];
-        double sb[16];
+        double sb[16], c2h[16];
         if (half == 0) {
             PYIPM_STAGE_TILE(sm.X, 1.0, Dinv + tp * TT)
             #pragma unroll
             for (int ks = 0; ks < 16; ++ks) sb[ks] = -W[i + (int64_t)(tp * TB + ks * 4 + l4) * ldw];
-            #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) sm.Wn[ks * 4 + l4][wave * 16 + l15] = -sb[ks];      // Wn[c][k] = -S[c][k], stored [k][c]
         } else {
-            double c2[16];                                           // the diagonal tile as it stands, in the C/D map of the update
             #pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
+            for (int tt = 0; tt < 4; ++tt)                           // the diagonal tile as it stands, in the C/D map of the update
                 #pragma unroll
-                for (int r = 0; r < 4; ++r) c2[4 * tt + r] = A[i + (lc0 + t * TB + tt * 16 + l4 + 4 * r) * ld];
-            #pragma unroll
-            for (int tt = 0; tt < 4; ++tt)
-                #pragma unroll
-                for (int r = 0; r < 4; ++r) sm.ts.stage[wave * 16 + l15][tt * 16 + l4 + 4 * r] = c2[4 * tt + r];
+                for (int r = 0; r < 4; ++r) c2h[4 * tt + r] = A[i + (lc0 + t * TB + tt * 16 + l4 + 4 * r) * ld];
         }
-        __syncthreads();
+        __syncthreads();                                             // inv(T) is staged (nobody waits for the other loads here)
         PYIPM_TS_STAMP(1)
         if (half == 0) {
-            strip_scale<false>(sm.X, Dinv + tp * TT, Tsv + tp * TT, 0, sb, tid, l15, l4, acc);
+            // the scaling product; the -S' operand of the diagonal update goes to its buffer in the shadow of the MFMAs
+            #pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc[tt] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            #pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                #pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const double a = sm.X[tt * 16 + l15][ks * 4 + l4];
+                    acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sb[ks], acc[tt], 0, 0, 0);
+                }
+            }
+            #pragma unroll
+            for (int ks = 0; ks < 16; ++ks) sm.Wn[ks * 4 + l4][wave * 16 + l15] = -sb[ks];       // Wn[c][k] = -S[c][k], stored [k][c]
+        } else {
+            #pragma unroll
+            for (int tt = 0; tt < 4; ++tt)
+                #pragma unroll
+                for (int r = 0; r < 4; ++r) sm.ts.stage[wave * 16 + l15][tt * 16 + l4 + 4 * r] = c2h[4 * tt + r];
         }
         for (int it = 0; it < nref; ++it) {                          // refinement of the block solve: four barriers a step,
             if (half == 0) strip_refine_step(sm.X, Dinv + tp * TT, Tsv + tp * TT, sb, tid, l15, l4, acc);   // the helpers keep count
             else { __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); }
         }
+        __syncthreads();                                             // the diagonal tile and -S' are in shared memory
         if (half == 0) {
             if (dbg) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][3])); PYIPM_TS_STAMP(2) }
             double4_t c2[4];
@@ -347,9 +360,9 @@ __global__ __launch_bounds__(512) void k_tile_step8(
         return;
     }
     // ------------------------------------------------ the other row tiles -----------------------------------------------
-    const int unit = 2 * ((int)blockIdx.x - 1) + half;
+    const int unit = upb * ((int)blockIdx.x - 1) + half;
     const int b = 1 + unit / ny, y = unit % ny;
-    const bool live = b < nt - t;                                    // (uniform per half)
+    const bool live = b < nt - t && half < upb;                      // (uniform per half)
     if (t == 0) {
         if (live && y == 0) {
             double tmp[TB * TB / 256];

@@ -57,6 +57,19 @@ __device__ __forceinline__ bool tile_blocked8_crit(double (&stage)[TB][STRIDE], 
             for (int c = 0; c < 16; ++c) bs.Ds[c] = d[c];
         }
     }
+    // (what only needs the elimination -- M, M', the pivots and their reciprocals -- is formed in front of the barrier)
+    int bad = (int)!(lmax <= PYIPM_BK_INV_ALPHA);
+    double rsel[4], dsel[4], aM[4], aMT[4];
+    #pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = 4 * s + q;
+        const double v = bs.Ms[i15][c], w = bs.Ms[c][i15];
+        dsel[s] = bs.Ds[c];
+        aM[s] = fma(v, L.mlt[s], L.meq[s]);
+        aMT[s] = fma(w, L.mgt[s], L.meq[s]);
+    }
+    #pragma unroll
+    for (int s = 0; s < 4; ++s) rsel[s] = blocked_recip(dsel[s]);
     __syncthreads();                                   // B2: the helpers have committed the block before (KB == 0: column maxima are out)
     PYIPM_TB_STAMP(4)
     double bWt[4];                                     // the wave's own rows of W (B operand of U; A operand of the next micro-block's update)
@@ -73,26 +86,13 @@ __device__ __forceinline__ bool tile_blocked8_crit(double (&stage)[TB][STRIDE], 
         if (KB == 0) pt4[s] = pivtol_rel * fmax(fmax(xmax[0][c], xmax[1][c]), fmax(xmax[2][c], xmax[3][c]));
         else         pt4[s] = bs.ptol[c];
     }
-    int bad = (int)!(lmax <= PYIPM_BK_INV_ALPHA);
-    double rsel[4], dsel[4], aM[4], aMT[4];
-    #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int c = 4 * s + q;
-        const double v = bs.Ms[i15][c], w = bs.Ms[c][i15];
-        dsel[s] = bs.Ds[c];
-        aM[s] = fma(v, L.mlt[s], L.meq[s]);
-        aMT[s] = fma(w, L.mgt[s], L.meq[s]);
-    }
     double4_tb U = {0.0, 0.0, 0.0, 0.0}, U2 = {0.0, 0.0, 0.0, 0.0};
     U  = __builtin_amdgcn_mfma_f64_16x16x4f64(aM[0], bWt[0], U, 0, 0, 0);
     U2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aM[2], bWt[2], U2, 0, 0, 0);
     U  = __builtin_amdgcn_mfma_f64_16x16x4f64(aM[1], bWt[1], U, 0, 0, 0);
     U2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aM[3], bWt[3], U2, 0, 0, 0);
     #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        rsel[s] = blocked_recip(dsel[s]);
-        bad |= (int)!(fabs(dsel[s]) > pt4[s]) | (int)!(fabs(dsel[s]) <= 1.0e300);
-    }
+    for (int s = 0; s < 4; ++s) bad |= (int)!(fabs(dsel[s]) > pt4[s]) | (int)!(fabs(dsel[s]) <= 1.0e300);
     if (dbg) { asm volatile("" :: "v"(U[0])); PYIPM_TB_STAMP(5) }
     const bool isK = t == KB;
     double Lr[4];
@@ -118,11 +118,10 @@ __device__ __forceinline__ bool tile_blocked8_crit(double (&stage)[TB][STRIDE], 
     #pragma unroll
     for (int s = 0; s < 4; ++s) ex.Xbuf[t][s][lane] = X[s];
     if (KB < 3) {
-        // the next micro-block: C(KB+1, KB+1) -= X W' with the k-steps in the order of tile_blocked_block (every wave runs
-        // the four MFMAs -- one instruction stream --, the owner's result is the one that is published)
-        #pragma unroll
-        for (int s = 0; s < 4; ++s) Cd = __builtin_amdgcn_mfma_f64_16x16x4f64(bWt[s], -X[s], Cd, 0, 0, 0);
-        if (t == KB + 1) {
+        // the next micro-block: C(KB+1, KB+1) -= X W' with the k-steps in the order of tile_blocked_block
+        if (t == KB + 1) {                             // (wave-uniform)
+            #pragma unroll
+            for (int s = 0; s < 4; ++s) Cd = __builtin_amdgcn_mfma_f64_16x16x4f64(bWt[s], -X[s], Cd, 0, 0, 0);
             #pragma unroll
             for (int rr = 0; rr < 4; ++rr) ex.Pnext[i15][q + 4 * rr] = Cd[rr];
         }
@@ -148,61 +147,70 @@ __device__ __forceinline__ bool tile_blocked8_crit(double (&stage)[TB][STRIDE], 
     return true;
 }
 
-// helper wave (row tile t = wave - 4), block KB: the updates and the commit of tile_blocked_block
+// helper waves, block KB.  The six tiles (t, t'), t >= t', t and t' != KB, that the block updates are spread over the four
+// helper waves whatever their rows (every operand comes from shared memory: W rows of t' from column block K, X of row t
+// from Xbuf, the tile itself): r0 < r1 < r2 the three row tiles other than KB,
+//     helper 0: (r0, r0), (r2, r2)    helper 1: (r1, r0), (r2, r1)    helper 2: (r1, r1)    helper 3: (r2, r0)
+// Helper h also commits X of row tile h into column block K (the micro-block's own rows receive -inv(P) there, the rows
+// above the block their X' in the transposed position).  Tiles above the diagonal, which the four-wave path updates and
+// stores as junk, are not touched (nobody reads them).
+template <int KB, int I> struct Tile8Rows { static constexpr int value = I + (I >= KB ? 1 : 0); };     // r_I
+
+template <int KB, int T, int TP, int STRIDE>
+struct Tile8Update {
+    double bW[4];
+    double4_tb Cn;
+    static constexpr int k0 = 16 * KB, D8 = (int)sizeof(double), S8 = STRIDE * D8;
+    __device__ __forceinline__ void load(const char* sb, const BlockedLane& L) {       // between B2 and B1
+        #pragma unroll
+        for (int s = 0; s < 4; ++s)
+            bW[s] = TP > KB ? *reinterpret_cast<const double*>(sb + L.oRow + 16 * TP * S8 + (k0 + 4 * s) * D8)
+                            : *reinterpret_cast<const double*>(sb + L.oCol + (k0 + 4 * s) * S8 + 16 * TP * D8);
+        #pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Cn[rr] = *reinterpret_cast<const double*>(sb + L.oRow + 16 * T * S8 + (16 * TP + 4 * rr) * D8);
+    }
+    __device__ __forceinline__ void run(char* sb, const BlockedLane& L, const Blocked8Scratch& ex, int lane) {     // after B1
+        #pragma unroll
+        for (int s = 0; s < 4; ++s) Cn = __builtin_amdgcn_mfma_f64_16x16x4f64(bW[s], -ex.Xbuf[T][s][lane], Cn, 0, 0, 0);
+        #pragma unroll
+        for (int rr = 0; rr < 4; ++rr) *reinterpret_cast<double*>(sb + L.oRow + 16 * T * S8 + (16 * TP + 4 * rr) * D8) = Cn[rr];
+    }
+};
+
 template <int KB, int STRIDE>
 __device__ __forceinline__ bool tile_blocked8_help(double (&stage)[TB][STRIDE], BlockedScratch& bs, Blocked8Scratch& ex,
                                                    const BlockedLane& L)
 {
-#define PYIPM_TB_LD(off_) (*reinterpret_cast<const double*>(sb + (off_)))
-#define PYIPM_TB_ST(off_) (*reinterpret_cast<double*>(sb + (off_)))
     constexpr int k0 = 16 * KB;
     constexpr int D8 = (int)sizeof(double), S8 = STRIDE * D8;
+    constexpr int r0 = Tile8Rows<KB, 0>::value, r1 = Tile8Rows<KB, 1>::value, r2 = Tile8Rows<KB, 2>::value;
     const int tid = threadIdx.x, lane = tid & 63;
     const int t = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
     char* sb = reinterpret_cast<char*>(&stage[0][0]);
+    Tile8Update<KB, r0, r0, STRIDE> u00; Tile8Update<KB, r2, r2, STRIDE> u22;
+    Tile8Update<KB, r1, r0, STRIDE> u10; Tile8Update<KB, r2, r1, STRIDE> u21;
+    Tile8Update<KB, r1, r1, STRIDE> u11; Tile8Update<KB, r2, r0, STRIDE> u20;
     __syncthreads();                                   // B2: the working matrix holds the blocks before this one
-    double bW[4][4];
-    double4_tb Cn[4];
-    #pragma unroll
-    for (int tp = 0; tp < 4; ++tp) {
-        #pragma unroll
-        for (int s = 0; s < 4; ++s)
-            bW[tp][s] = tp > KB ? PYIPM_TB_LD(L.oRow + 16 * tp * S8 + (k0 + 4 * s) * D8)
-                                : PYIPM_TB_LD(L.oCol + (k0 + 4 * s) * S8 + 16 * tp * D8);
-        #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) Cn[tp][rr] = PYIPM_TB_LD(L.oRowT + (16 * tp + 4 * rr) * D8);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (column block K is overwritten with X by the other helpers after B1)
+    if (t == 0)      { u00.load(sb, L); u22.load(sb, L); }
+    else if (t == 1) { u10.load(sb, L); u21.load(sb, L); }
+    else if (t == 2) { u11.load(sb, L); }
+    else             { u20.load(sb, L); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (column block K is overwritten with X by the helpers after B1)
     __syncthreads();                                   // B1
     if (bs.fail) return false;
-    double X[4];
-    #pragma unroll
-    for (int s = 0; s < 4; ++s) X[s] = ex.Xbuf[t][s][lane];
-    #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const double xn = -X[s];
-        #pragma unroll
-        for (int tp = 0; tp < 4; ++tp)
-            if (tp != KB) Cn[tp] = __builtin_amdgcn_mfma_f64_16x16x4f64(bW[tp][s], xn, Cn[tp], 0, 0, 0);
-    }
+    if (t == 0)      { u00.run(sb, L, ex, lane); u22.run(sb, L, ex, lane); }
+    else if (t == 1) { u10.run(sb, L, ex, lane); u21.run(sb, L, ex, lane); }
+    else if (t == 2) { u11.run(sb, L, ex, lane); }
+    else             { u20.run(sb, L, ex, lane); }
     {
         const int xo = t >= KB ? L.oRowT + k0 * D8 : L.oColT + k0 * S8;
         #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-            if (t >= KB) PYIPM_TB_ST(xo + 4 * rr * D8) = X[rr];
-            else         PYIPM_TB_ST(xo + 4 * rr * S8) = X[rr];
+            const double x = ex.Xbuf[t][rr][lane];
+            if (t >= KB) *reinterpret_cast<double*>(sb + xo + 4 * rr * D8) = x;
+            else         *reinterpret_cast<double*>(sb + xo + 4 * rr * S8) = x;
         }
     }
-    if (t != KB) {
-        #pragma unroll
-        for (int tp = 0; tp < 4; ++tp) {
-            if (tp == KB) continue;
-            #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) PYIPM_TB_ST(L.oRowT + (16 * tp + 4 * rr) * D8) = Cn[tp][rr];
-        }
-    }
-#undef PYIPM_TB_LD
-#undef PYIPM_TB_ST
     return true;
 }
 
