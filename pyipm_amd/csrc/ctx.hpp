@@ -242,7 +242,7 @@ struct Ctx {
     int tile_waves = 8;                   // k_tile_step on 512 threads (round 5): the critical block = four chain waves + four helper waves
                                           // (diagonal tile prefetched beside the scaling product; the blocked inversion's updates and commits
                                           // beside the next elimination, tile_blocked8.hpp); 4: the 256-thread kernel of rounds 2-4.  Same bits.
-    int64_t tile8_rows = 12288;           // ... used for the first group, the per-panel schedule, and where at most this many rows are left
+    int64_t tile8_rows = 12288;           // ... used by the single-rank schedule for the first group and where at most this many rows are left
     int tile_ny3 = 0;                     // ... its row-tile units with at most 3 (instead of 5) column tiles each
     int tile_free_cus = 64;               // ... CUs assumed free beside a persistent bulk launch (units per block: 1 while the launch fits)
     int tile_upb = 0;                     // ... its other row tiles: (row tile, y) units per 512-thread block, 1 | 2; 0 = by the size of the launch

@@ -185,8 +185,16 @@ __device__ __forceinline__ void tile_invert_dev(
         // the critical waves are already eliminating the first micro-block while the helpers do the above
         if (helper) {
             if (tid == 256) sm.f.bs.fail = 0;
-            if (blocked) tile_blocked8_sweep_help(stage, sm.f.bs, *ex);
-            else __syncthreads();
+            if (blocked) {
+                if (tile_blocked8_sweep_help(stage, sm.f.bs, *ex)) {
+                    // all four blocks swept: the general loop has nothing to do, the inverse goes out on eight waves
+                    #pragma unroll
+                    for (int c = 8; c < 16; ++c) {
+                        const int j = cb + c;
+                        Tinv[j * TB + lane] = -((lane >= j) ? stage[lane][j] : stage[j][lane]);
+                    }
+                }
+            } else __syncthreads();
             return;                                    // the helpers are done (a barrier counts the waves that are left)
         }
         if (blocked) {
@@ -213,11 +221,12 @@ __device__ __forceinline__ void tile_invert_dev(
 
     // ---- blocked fast path: 16 pivots at a time in natural order while Bunch-Kaufman would have accepted them ----
     int kb_done = kb_done8;
+    const int c_out = (W8 && kb_done8 == 4) ? 8 : 16;  // (all four blocks swept: the helpers write the other columns of the inverse)
     if (W8 && blocked) {
         #pragma unroll
         for (int c = 0; c < 16; ++c) {                 // the working matrix as it stands, in the sweep layout
             const int j = cb + c;
-            row[c] = (lane >= j) ? stage[lane][j] : stage[j][lane];
+            if (c < c_out) row[c] = (lane >= j) ? stage[lane][j] : stage[j][lane];
         }
     }
     if (!W8 && blocked) {
@@ -415,7 +424,7 @@ __device__ __forceinline__ void tile_invert_dev(
 #undef PYIPM_PUBLISH
 #undef PYIPM_SWEEP1
     #pragma unroll
-    for (int c = 0; c < 16; ++c) Tinv[(cb + c) * TB + lane] = -row[c];
+    for (int c = 0; c < 16; ++c) if (c < c_out) Tinv[(cb + c) * TB + lane] = -row[c];
     if (dbg && tid == 0) { dbg[0] = clock64() - dbg_c0; dbg[1] = wall_clock64() - dbg_w0; dbg[2] += 1; }
     __syncthreads();                                     // dsave complete
     if (wave == 0) {                                     // statistics of the 1x1 pivots: lane p looks at pivot p

@@ -283,9 +283,13 @@ __global__ __launch_bounds__(512) void k_tile_step8(
         double4_t acc[4];
         double sb[16], c2h[16];
         if (half == 0) {
+            // S first, inv(T) behind it: waiting for the tile that goes to shared memory then covers both round trips
+            #pragma unroll
+            for (int ks = 0; ks < 16; ++ks) sb[ks] = W[i + (int64_t)(tp * TB + ks * 4 + l4) * ldw];
+            asm volatile("" ::: "memory");
             PYIPM_STAGE_TILE(sm.X, 1.0, Dinv + tp * TT)
             #pragma unroll
-            for (int ks = 0; ks < 16; ++ks) sb[ks] = -W[i + (int64_t)(tp * TB + ks * 4 + l4) * ldw];
+            for (int ks = 0; ks < 16; ++ks) sb[ks] = -sb[ks];
         } else {
             #pragma unroll
             for (int tt = 0; tt < 4; ++tt)                           // the diagonal tile as it stands, in the C/D map of the update

@@ -587,11 +587,13 @@ int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, in
         int ny = (nT - j + 4) / 5; if (ny < 1) ny = 1; if (ny > 4) ny = 4;     // <= ~5 column tiles per block
         // the critical block on eight waves (chain + helpers) where a whole CU is to be had: a 512-thread block owns the
         // registers of its CU, so beside an ordinary bulk launch it would wait for BOTH resident bulk blocks of a CU to retire
+        // (all launches: exposed panel 7.1 -> 10.9 ms at N = 32768; the per-panel schedule, whose ranks run their bulk updates
+        // beside every chain: owners' chain path 31.0 -> 32.1 ms in the replay -- it keeps the 256-thread kernel)
         const int64_t m_left = g.Npad - gc0;
-        if (ctx->tile_waves == 8 && (gc0 == 0 || ctx->per_panel_mode || m_left <= ctx->tile8_rows)) {
+        if (ctx->tile_waves == 8 && !ctx->per_panel_mode && (gc0 == 0 || m_left <= ctx->tile8_rows)) {
             if (ctx->tile_ny3) { ny = (nT - j + 2) / 3; if (ny < 1) ny = 1; if (ny > 6) ny = 6; }
             const int units = (nT - j - 1) * ny;
-            const int free_cus = (gc0 == 0 || ctx->per_panel_mode || ctx->reserve_cus <= 0) ? ctx->num_cus : ctx->tile_free_cus;
+            const int free_cus = (gc0 == 0 || ctx->reserve_cus <= 0) ? ctx->num_cus : ctx->tile_free_cus;
             const int upb = ctx->tile_upb > 0 ? ctx->tile_upb : (units + 1 <= free_cus ? 1 : 2);
             const unsigned nblk = 1u + (unsigned)((units + upb - 1) / upb);
             hipLaunchKernelGGL(k_tile_step8, dim3(nblk), dim3(512), 0, chain, ctx->A, g.Npad, gc0, glc0, j, nT, ny, upb,

@@ -256,17 +256,18 @@ __device__ __forceinline__ int tile_blocked8_sweep_crit(double (&stage)[TB][STRI
 }
 
 template <int STRIDE>
-__device__ __forceinline__ void tile_blocked8_sweep_help(double (&stage)[TB][STRIDE], BlockedScratch& bs, Blocked8Scratch& ex)
+__device__ __forceinline__ bool tile_blocked8_sweep_help(double (&stage)[TB][STRIDE], BlockedScratch& bs, Blocked8Scratch& ex)
 {
     const int lane = threadIdx.x & 63;
     const int t = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
     BlockedLane L;
     tile_blocked8_lane<STRIDE>(L, lane, t);
-    if (!tile_blocked8_help<0>(stage, bs, ex, L)) return;
-    if (!tile_blocked8_help<1>(stage, bs, ex, L)) return;
-    if (!tile_blocked8_help<2>(stage, bs, ex, L)) return;
-    if (!tile_blocked8_help<3>(stage, bs, ex, L)) return;
+    if (!tile_blocked8_help<0>(stage, bs, ex, L)) return false;
+    if (!tile_blocked8_help<1>(stage, bs, ex, L)) return false;
+    if (!tile_blocked8_help<2>(stage, bs, ex, L)) return false;
+    if (!tile_blocked8_help<3>(stage, bs, ex, L)) return false;
     __syncthreads();
+    return true;
 }
 
 }  // namespace pyipm
