@@ -590,10 +590,10 @@ int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, in
         // (all launches: exposed panel 7.1 -> 10.9 ms at N = 32768; the per-panel schedule, whose ranks run their bulk updates
         // beside every chain: owners' chain path 31.0 -> 32.1 ms in the replay -- it keeps the 256-thread kernel)
         const int64_t m_left = g.Npad - gc0;
-        if (ctx->tile_waves == 8 && !ctx->per_panel_mode && (gc0 == 0 || m_left <= ctx->tile8_rows)) {
+        if (ctx->tile_waves == 8 && (ctx->per_panel_mode ? ctx->tile8_dist != 0 : (gc0 == 0 || m_left <= ctx->tile8_rows))) {
             if (ctx->tile_ny3) { ny = (nT - j + 2) / 3; if (ny < 1) ny = 1; if (ny > 6) ny = 6; }
             const int units = (nT - j - 1) * ny;
-            const int free_cus = (gc0 == 0 || ctx->reserve_cus <= 0) ? ctx->num_cus : ctx->tile_free_cus;
+            const int free_cus = (gc0 == 0 || ctx->reserve_cus <= 0 || ctx->per_panel_mode) ? ctx->num_cus : ctx->tile_free_cus;
             const int upb = ctx->tile_upb > 0 ? ctx->tile_upb : (units + 1 <= free_cus ? 1 : 2);
             const unsigned nblk = 1u + (unsigned)((units + upb - 1) / upb);
             hipLaunchKernelGGL(k_tile_step8, dim3(nblk), dim3(512), 0, chain, ctx->A, g.Npad, gc0, glc0, j, nT, ny, upb,
@@ -2871,7 +2871,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
             "head_on_side", "head_serial", "head_split", "head_split_rows", "fast_on_main", "rest_prio", "s_fast", "bwd_diag4",
             "head_waves", "inpanel32", "fuse_scale_update", "pending32_rows", "head32_rows", "head32_rows_dist", "early_head",
             "bulk_bn_rows", "bulk_bn_all", "bulk_bn_min_k", "sweep_max_blocks", "asm_tri", "asm_split", "fused_head",
-            "fused_head_rows", "dist_head_split", "tile_waves", "tile_upb", "tile8_rows", "tile_ny3", "tile_free_cus", "debug_fault", "debug_timeline_ptr"};
+            "fused_head_rows", "dist_head_split", "tile_waves", "tile_upb", "tile8_rows", "tile_ny3", "tile_free_cus", "tile8_dist", "debug_fault", "debug_timeline_ptr"};
         bool is_expert = false;
         for (const char* e : kExpert) if (!strcmp(name, e)) { is_expert = true; break; }
         if (is_expert && !ctx->expert) {
@@ -2897,6 +2897,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "tile8_rows")) { ctx->tile8_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "tile_ny3")) { ctx->tile_ny3 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile_free_cus")) { ctx->tile_free_cus = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "tile8_dist")) { ctx->tile8_dist = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile_upb")) { ctx->tile_upb = (int)value < 0 ? 0 : ((int)value > 2 ? 2 : (int)value); return PYIPM_OK; }
     if (!strcmp(name, "profile")) { ctx->profile = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "debug_fault")) { ctx->debug_fault = (int)value; return PYIPM_OK; }

@@ -83,3 +83,57 @@ def test_tile_inversion_blocked_and_single_sweeps(name, H, blocks_expected):
         assert committed == blocks_expected, (name, committed, blocks_expected)
     if blocks_expected == 0:
         np.testing.assert_array_equal(dz1, dz0)             # nothing committed: the same sweeps from the same state
+
+
+def _graded_qp(n, me, mi, seed, decades):
+    """A convex QP whose x-x tiles have pivot spreads far beyond refine_cond (block solves with them are refined) and, with
+    `decades` large enough, micro-blocks the natural-order check rejects (the tile inversion hands over to the single sweeps
+    in the middle of a tile)."""
+    from pyipm_amd.problems import make_qp
+    qp = make_qp(n, me, mi, seed)
+    rng = np.random.default_rng(seed)
+    sc = np.logspace(0.0, decades, n)[rng.permutation(n)]
+    qp["d2L"] = qp["d2L"] * np.sqrt(sc)[:, None] * np.sqrt(sc)[None, :]
+    return qp
+
+
+@pytest.mark.parametrize("shape", [(700, 100, 200, 1, 5.0), (1100, 0, 300, 2, 9.0), (520, 130, 0, 3, 3.0), (2100, 300, 500, 4, 6.0)])
+def test_eight_wave_tile_step_gives_the_bits_of_the_four_wave_one(shape):
+    """k_tile_step8 (chain waves + helper waves, csrc/kernels_panel.hpp, tile_blocked8.hpp) against k_tile_step on systems
+    whose tiles exercise every branch the helpers have to keep in step with: refined block solves (flagged tiles: four
+    barriers per refinement step that the helper waves mirror), micro-blocks that fail the Bunch-Kaufman check after one to
+    three committed blocks (the helpers leave, the critical waves go on with the single sweeps), units paired two per
+    block or one per block.  Factor storage, statistics and direction are bit for bit the same; three steps in a row per
+    handle.  Replaces the LAPACK factorisation reached from pyipm.py:18-20, 1720-1721."""
+    import torch
+    from pyipm_amd.newton import NewtonCore
+    n, me, mi, seed, decades = shape
+    qp = _graded_qp(n, me, mi, seed, decades)
+    out = {}
+    for key, opts in (("w4", {"tile_waves": 4}),
+                      ("w8", {"tile_waves": 8, "tile8_rows": 1 << 20}),
+                      ("w8_upb1", {"tile_waves": 8, "tile8_rows": 1 << 20, "tile_upb": 1}),
+                      ("w8_upb2_ny3", {"tile_waves": 8, "tile8_rows": 1 << 20, "tile_upb": 2, "tile_ny3": 1}),
+                      ("w8_single_sweeps", {"tile_waves": 8, "tile8_rows": 1 << 20, "tile_blocked": 0}),
+                      ("w4_single_sweeps", {"tile_waves": 4, "tile_blocked": 0})):
+        core = NewtonCore(n, me, mi, device=0)
+        core.set_option("expert", 1)
+        core.set_option("sweep_persist", 0)
+        for k, v in opts.items():
+            core.set_option(k, v)
+        core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+        core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+        for rep in range(3):
+            dz, st = core.step(0.0, 0.0)
+            fac = core.kkt_storage().clone().view(torch.int64)      # (bit patterns: what no kernel writes is NaN-poisoned by the suite)
+            if key not in out:
+                out[key] = (dz.clone(), fac, st)
+            assert torch.equal(dz, out[key][0]) and torch.equal(fac, out[key][1]), (shape, key, rep)
+        core.close()
+    for a, b in (("w4", "w8"), ("w4", "w8_upb1"), ("w4", "w8_upb2_ny3"), ("w4_single_sweeps", "w8_single_sweeps")):
+        assert torch.equal(out[a][1], out[b][1]), (shape, a, b, "factor storage")
+        assert torch.equal(out[a][0], out[b][0]), (shape, a, b, "direction")
+        sa, sb = out[a][2], out[b][2]
+        assert {k: sa[k] for k in sa if not k.endswith("_ms")} == {k: sb[k] for k in sb if not k.endswith("_ms")}, (shape, a, b)
+    st = out["w4"][2]
+    assert st["n_neg"] == me + mi and st["nonfinite"] == 0, (shape, st)
