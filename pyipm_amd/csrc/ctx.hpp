@@ -245,6 +245,7 @@ struct Ctx {
     int64_t tile8_rows = 12288;           // ... used by the single-rank schedule for the first group and where at most this many rows are left
     int tile_ny3 = 0;                     // ... its row-tile units with at most 3 (instead of 5) column tiles each
     int tile_free_cus = 64;               // ... CUs assumed free beside a persistent bulk launch (units per block: 1 while the launch fits)
+    int bc_per_problem = 1;               // batched condensed form: the Gram part by one workgroup per problem where n = 64 .. 256 allows it
     int tile8_dist = 0;                   // ... also in the per-panel (multi-GPU) schedule
     int tile_upb = 0;                     // ... its other row tiles: (row tile, y) units per 512-thread block, 1 | 2; 0 = by the size of the launch
     int block_refine = 2;                 // refinement steps of L T = S in the panel scaling and of T z = y in the solves

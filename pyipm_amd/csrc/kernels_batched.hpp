@@ -185,11 +185,19 @@ __global__ __launch_bounds__(256) void k_bc_prep(BatchPtrs bp, Geo g, double mu,
 // The Gram part of an x-x tile is formed on the matrix pipe: both operand tiles of a 64-column chunk of Ji staged through
 // shared memory (coalesced along the rows of the row-major Ji), the Sigma scaling applied to one of them on the way, the next
 // chunk's loads in flight under the products of the current one.
+// (sw: which 16-row strip of the 64 x 64 tile this wave stores; acc: its Gram part, columns t * 16 + l4 + 4 r)
+__device__ __forceinline__ void bc_store_strip(const BatchPtrs& bp, const Geo& g, const BatchCond& bc, int64_t b, int rt, int ct, int sw,
+                                               const double4_t (&acc)[4], double eps, double delta, double delta_c, int na);
 __device__ __forceinline__ void bc_store_tile(const BatchPtrs& bp, const Geo& g, const BatchCond& bc, int64_t b, int rt, int ct,
                                               const double4_t (&acc)[4], double eps, double delta, double delta_c, int na)
 {
+    bc_store_strip(bp, g, bc, b, rt, ct, (int)(threadIdx.x >> 6), acc, eps, delta, delta_c, na);
+}
+__device__ __forceinline__ void bc_store_strip(const BatchPtrs& bp, const Geo& g, const BatchCond& bc, int64_t b, int rt, int ct, int wave,
+                                               const double4_t (&acc)[4], double eps, double delta, double delta_c, int na)
+{
     const int64_t n = g.n, me = g.me, mi = g.mi, ld = g.Npad, nc = n + me + na;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int l15 = lane & 15, l4 = lane >> 4;
     double* A = bp.A + b * bp.sA;
     const double* d2L = bp.d2L + b * bp.sH;
@@ -302,6 +310,121 @@ __global__ __launch_bounds__(256) void k_bc_assemble(BatchPtrs bp, Geo g, double
         }
     }
     if ((int64_t)rt * TB < nc) bc_store_tile(bp, g, bc, b, rt, ct, acc, eps, delta, delta_c, na);
+}
+
+// k_bc_assemble with ONE workgroup per problem (round 5) for n = 64 NX <= 256 and mi a multiple of 32 (BASELINE's batched
+// configuration: n = mi = 256).  The tile-per-workgroup form above fetches a 64-row chunk of Ji twice per tile -- ten tiles per
+// problem at n = 256: every entry of Ji crosses L2 -> CU ten times -- with two workgroups of four waves per CU: the matrix pipes
+// ran at a third of their rate.  Here a chunk of 32 inequality rows of ALL n columns is staged once, double buffered (the next
+// chunk's loads fly under this chunk's products), and every x-x tile is updated from it.  2 NX waves; wave w owns the 16-row
+// strips w and 4 NX - 1 - w of the lower block triangle -- tile rows RLO = w / 4 and NX - 1 - RLO: 4 (NX + 1) accumulator tiles
+// of 16 x 16 for every wave.  The Sigma scaling is applied to the row operand on its way out of shared memory (the same single
+// product sigma_k Ji[k][i] as above), k ascends in MFMA groups of 4 as above: the same bits as k_bc_assemble.
+template <int NX, int RLO>
+__device__ __forceinline__ void bc_gram_problem(double (&V)[2][64 * NX][34], double (&SG)[2][32], const BatchPtrs& bp, const Geo& g,
+                                                const BatchCond& bc, int64_t b, int na, double eps, double delta, double delta_c)
+{
+    constexpr int RHI = NX - 1 - RLO, NLO = 4 * (RLO + 1), NHI = 4 * (RHI + 1);
+    constexpr int NT = 128 * NX, NVAR = 64 * NX, KC = 32, VPP = NT / 32, NPASS = NVAR / VPP;
+    static_assert(RHI >= RLO, "the high strip's tile row is never above the low strip's");
+    const int64_t mi = g.mi;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const double* Ji = bp.Ji + b * bp.sJi;
+    const double* sig = bc.sig + b * bc.sP;
+    const int s_lo = wave, s_hi = 4 * NX - 1 - wave;
+    double4_t alo[NLO], ahi[NHI];
+    #pragma unroll
+    for (int t = 0; t < NLO; ++t) alo[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    #pragma unroll
+    for (int t = 0; t < NHI; ++t) ahi[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const int kk = tid & 31, v0 = tid >> 5;        // staging: 32 lanes along a column's rows, NT / 32 columns per pass
+    constexpr int HP = NPASS / 2 > 0 ? NPASS / 2 : 1;      // the next chunk arrives in two halves (half the staging registers)
+    double stg[HP], sgv = 0.0;
+    #pragma unroll
+    for (int h = 0; h < NPASS; h += HP) {
+        #pragma unroll
+        for (int q = 0; q < HP; ++q) stg[q] = Ji[(int64_t)(v0 + VPP * (h + q)) * bp.ldji + kk];
+        #pragma unroll
+        for (int q = 0; q < HP; ++q) V[0][v0 + VPP * (h + q)][kk] = stg[q];
+    }
+    if (tid < KC) SG[0][tid] = sig[tid];
+    __syncthreads();
+    int buf = 0;
+    auto products = [&](int ks0, int ks1) {
+        #pragma unroll 1
+        for (int ks = ks0; ks < ks1; ++ks) {
+            const double sg = SG[buf][ks * 4 + l4];
+            const double blo = sg * V[buf][16 * s_lo + l15][ks * 4 + l4];
+            const double bhi = sg * V[buf][16 * s_hi + l15][ks * 4 + l4];
+            #pragma unroll
+            for (int jj = 0; jj < NHI; ++jj) {
+                const double a = V[buf][16 * jj + l15][ks * 4 + l4];
+                ahi[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bhi, ahi[jj], 0, 0, 0);
+                if (jj < NLO) alo[jj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, blo, alo[jj], 0, 0, 0);
+            }
+        }
+    };
+    for (int64_t kc = 0; kc < mi; kc += KC) {
+        const int64_t kn = kc + KC;
+        const bool more = kn < mi;                         // (uniform)
+        if (more) {
+            #pragma unroll
+            for (int q = 0; q < HP; ++q) stg[q] = Ji[(int64_t)(v0 + VPP * q) * bp.ldji + kn + kk];
+            if (tid < KC) sgv = sig[kn + tid];
+        }
+        products(0, KC / 8);
+        if (more) {                                        // the other buffer is nobody's operand during this chunk
+            #pragma unroll
+            for (int q = 0; q < HP; ++q) V[buf ^ 1][v0 + VPP * q][kk] = stg[q];
+            if (tid < KC) SG[buf ^ 1][tid] = sgv;
+            if (NPASS > HP) {
+                #pragma unroll
+                for (int q = 0; q < HP; ++q) stg[q] = Ji[(int64_t)(v0 + VPP * (HP + q)) * bp.ldji + kn + kk];
+            }
+        }
+        products(KC / 8, KC / 4);
+        if (more && NPASS > HP) {
+            #pragma unroll
+            for (int q = 0; q < HP; ++q) V[buf ^ 1][v0 + VPP * (HP + q)][kk] = stg[q];
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    #pragma unroll
+    for (int J = 0; J <= RLO; ++J) {
+        const double4_t a4[4] = {alo[4 * J], alo[4 * J + 1], alo[4 * J + 2], alo[4 * J + 3]};
+        bc_store_strip(bp, g, bc, b, RLO, J, s_lo & 3, a4, eps, delta, delta_c, na);
+    }
+    #pragma unroll
+    for (int J = 0; J <= RHI; ++J) {
+        const double4_t a4[4] = {ahi[4 * J], ahi[4 * J + 1], ahi[4 * J + 2], ahi[4 * J + 3]};
+        bc_store_strip(bp, g, bc, b, RHI, J, s_hi & 3, a4, eps, delta, delta_c, na);
+    }
+}
+
+template <int NX>
+__global__ __launch_bounds__(128 * NX) void k_bc_assemble_p(BatchPtrs bp, Geo g, double eps, double delta, double delta_c, BatchCond bc)
+{
+    __shared__ double V[2][64 * NX][34];
+    __shared__ double SG[2][32];
+    const int64_t b = blockIdx.x;
+    const int na = bc.cnt[b];
+    const int64_t nc = g.n + g.me + na;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // (every wave runs the same number of barriers whatever its pair of strips)
+    if (NX >= 3 && wave >= 4) bc_gram_problem<NX, (NX >= 3 ? 1 : 0)>(V, SG, bp, g, bc, b, na, eps, delta, delta_c);
+    else                      bc_gram_problem<NX, 0>(V, SG, bp, g, bc, b, na, eps, delta, delta_c);
+    // the tile rows below the x block (lambda_e rows, active inequality rows): copies and a diagonal, strip by strip
+    const int ntc = (int)((nc + TB - 1) / TB);
+    double4_t zero[4];
+    #pragma unroll
+    for (int t = 0; t < 4; ++t) zero[t] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    int idx = 0;
+    for (int rt = NX; rt < ntc; ++rt)
+        for (int ct = 0; ct <= rt; ++ct)
+            for (int sw = 0; sw < 4; ++sw, ++idx)
+                if (idx % (2 * NX) == wave) bc_store_strip(bp, g, bc, b, rt, ct, sw, zero, eps, delta, delta_c, na);
 }
 
 // Backward error of a batch of directions against the KKT blocks (never the factor): out[b] = |g - Hc raw| / |g| with raw the

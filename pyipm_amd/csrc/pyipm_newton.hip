@@ -2000,8 +2000,15 @@ int pyipm_newton_step_batched(pyipm_newton_ctx* h, double delta, double delta_c,
         hipLaunchKernelGGL(k_bc_prep, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->mu, ctx->eps, bc);
         PYIPM_KCHECK();
         const int nt0 = (int)((g.n + g.me + TB - 1) / TB);
-        hipLaunchKernelGGL(k_bc_assemble, dim3((unsigned)(nt0 * (nt0 + 1) / 2 + 1), (unsigned)B), dim3(256), 0, ctx->stream, bp, g,
-                           ctx->eps, delta, delta_c, bc, nt0);
+        const int nx = (g.n % TB == 0 && g.n >= TB && g.n <= 4 * TB && g.mi % 32 == 0 && ctx->bc_per_problem) ? (int)(g.n / TB) : 0;
+        // one workgroup per problem while the Jacobian chunk of all n columns fits shared memory twice (n <= 256), else a tile each
+        if (nx == 4)      hipLaunchKernelGGL((k_bc_assemble_p<4>), dim3((unsigned)B), dim3(512), 0, ctx->stream, bp, g, ctx->eps, delta, delta_c, bc);
+        else if (nx == 3) hipLaunchKernelGGL((k_bc_assemble_p<3>), dim3((unsigned)B), dim3(384), 0, ctx->stream, bp, g, ctx->eps, delta, delta_c, bc);
+        else if (nx == 2) hipLaunchKernelGGL((k_bc_assemble_p<2>), dim3((unsigned)B), dim3(256), 0, ctx->stream, bp, g, ctx->eps, delta, delta_c, bc);
+        else if (nx == 1) hipLaunchKernelGGL((k_bc_assemble_p<1>), dim3((unsigned)B), dim3(128), 0, ctx->stream, bp, g, ctx->eps, delta, delta_c, bc);
+        else
+            hipLaunchKernelGGL(k_bc_assemble, dim3((unsigned)(nt0 * (nt0 + 1) / 2 + 1), (unsigned)B), dim3(256), 0, ctx->stream, bp, g,
+                               ctx->eps, delta, delta_c, bc, nt0);
         PYIPM_KCHECK();
     } else {
         hipLaunchKernelGGL(k_b_residual, dim3(B), dim3(256), 0, ctx->stream, bp, g, ctx->mu, ctx->eps);
@@ -2871,7 +2878,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
             "head_on_side", "head_serial", "head_split", "head_split_rows", "fast_on_main", "rest_prio", "s_fast", "bwd_diag4",
             "head_waves", "inpanel32", "fuse_scale_update", "pending32_rows", "head32_rows", "head32_rows_dist", "early_head",
             "bulk_bn_rows", "bulk_bn_all", "bulk_bn_min_k", "sweep_max_blocks", "asm_tri", "asm_split", "fused_head",
-            "fused_head_rows", "dist_head_split", "tile_waves", "tile_upb", "tile8_rows", "tile_ny3", "tile_free_cus", "tile8_dist", "debug_fault", "debug_timeline_ptr"};
+            "fused_head_rows", "dist_head_split", "tile_waves", "tile_upb", "tile8_rows", "tile_ny3", "tile_free_cus", "tile8_dist", "bc_per_problem", "debug_fault", "debug_timeline_ptr"};
         bool is_expert = false;
         for (const char* e : kExpert) if (!strcmp(name, e)) { is_expert = true; break; }
         if (is_expert && !ctx->expert) {
@@ -2897,6 +2904,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "tile8_rows")) { ctx->tile8_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "tile_ny3")) { ctx->tile_ny3 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile_free_cus")) { ctx->tile_free_cus = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "bc_per_problem")) { ctx->bc_per_problem = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile8_dist")) { ctx->tile8_dist = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile_upb")) { ctx->tile_upb = (int)value < 0 ? 0 : ((int)value > 2 ? 2 : (int)value); return PYIPM_OK; }
     if (!strcmp(name, "profile")) { ctx->profile = (int)value; return PYIPM_OK; }

@@ -265,3 +265,37 @@ def test_batched_condensed_guard_falls_back():
     dz3, _ = full.step_all(*[_stack(qps, k) for k in ("d2L", "Je", "Ji", "df", "ce", "ci", "s", "lam")], mu=0.2)
     assert np.array_equal(dz2.cpu().numpy(), dz3.cpu().numpy())
     bn.close(); full.close()
+
+
+@pytest.mark.parametrize("n,me,mi,spread", [(64, 0, 32, 0), (128, 10, 96, 0), (192, 0, 160, 0), (256, 0, 256, 0), (256, 20, 64, 0),
+                                            (128, 0, 128, 12), (256, 30, 224, 12)])
+def test_batched_condensed_gram_per_problem_gives_the_same_bits(n, me, mi, spread):
+    """k_bc_assemble_p (one workgroup per problem: the Jacobian chunk of all n columns staged once for every x-x tile) against
+    k_bc_assemble (a workgroup per tile) where the former applies -- n a multiple of 64 up to 256, mi a multiple of 32 --: the
+    condensed matrices, hence factors, statistics and directions, are bit for bit the same; with `spread` decades of Sigma some
+    inequalities stay explicit rows (the tile rows below the x block).  Block structure: pyipm.py:824-842."""
+    import torch
+    from pyipm_amd.batched import BatchedNewton
+    B = 12
+    qps = [make_qp(n, me, mi, seed=900 + b) for b in range(B)]
+    if spread:
+        rng = np.random.default_rng(n + mi)
+        for q in qps:
+            q["lam"] = q["lam"].copy()
+            q["lam"][me:] = q["s"] * 10.0 ** rng.uniform(-spread / 2, spread / 2, mi)
+    args = [_stack(qps, k) for k in ("d2L", "Je", "Ji", "df", "ce", "ci", "s", "lam")]
+    out = {}
+    for per_problem in (1, 0):
+        bn = BatchedNewton(n, me, mi, condensed=True, guard=False)
+        bn.set_option("expert", 1)
+        bn.set_option("bc_per_problem", per_problem)
+        dz, stats = bn.step_all(*args, mu=0.2)
+        out[per_problem] = (dz.clone(), [{k: v for k, v in st.items()} for st in stats])
+        bn.close()
+    assert torch.equal(out[1][0], out[0][0])
+    assert out[1][1] == out[0][1]
+    for b in (0, B - 1):
+        q = qps[b]
+        ref, _, _, _ = orc.newton_step(q["d2L"], q["Je"], q["Ji"], q["df"], q["ce"], q["ci"], q["s"],
+                                       args[7][b] if spread else q["lam"], 0.2, n, me, mi, regularise=False)
+        assert np.linalg.norm(out[1][0][b].cpu().numpy() - ref) / np.linalg.norm(ref) <= 1e-9

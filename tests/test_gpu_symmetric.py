@@ -325,7 +325,7 @@ NOT_SCHEDULE = {"expert", "condensed", "condensed_sigma_max", "condensed_refine"
                 # multi-rank / per-panel schedule: swept in tests/test_gpu_dist.py (exchange forms, wide panels, slices)
                 "wide_sub", "dist_sag", "dist_sag_min_bytes", "dist_slices", "dist_selfmsg", "dist_head_split", "head32_rows_dist",
                 # test hooks and diagnostics
-                "tile8_dist",
+                "tile8_dist", "bc_per_problem",       # (batched handles: swept in tests/test_gpu_batched.py)
                 "sweep_max_blocks", "debug_fault", "debug_timeline_ptr"}
 SCHEDULE_SPACE = {"lookahead": [0, 1], "group": [1, 2, 4, 8], "group_chain": [0, 1], "head_on_side": [0, 1], "fast_on_main": [0, 1], "early_head": [0, 1],
                   "pending_left_rows": [-1, 0, 12288], "fuse_forward": [0, 1], "keep_zeros": [0, 1], "skip_zeros": [0, 1],
