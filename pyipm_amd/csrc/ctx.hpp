@@ -110,7 +110,7 @@ struct Ctx {
                                           // below the group's diagonal block follow on their own stream; same bits
     hipStream_t rest = nullptr;           // ... that stream (high priority, created on first use)
     std::vector<hipEvent_t> ev_band;      // panel (by offset in its group): its tiles are inverted and applied inside the diagonal block
-    hipEvent_t ev_join = nullptr, ev_main = nullptr, ev_split = nullptr;
+    hipEvent_t ev_join = nullptr, ev_main = nullptr, ev_split = nullptr, ev_sfast = nullptr;
     int head_split = 1;                   // the lookahead head in two launches: the target group's diagonal block on the chain's stream,
                                           // the rows below it on ctx->rest (first read there)
     int head_waves = 4;                   // waves per block of a lookahead head launched on the chain's stream (4: k_update<128,true,4>,
@@ -246,6 +246,7 @@ struct Ctx {
     int tile_ny3 = 0;                     // ... its row-tile units with at most 3 (instead of 5) column tiles each
     int tile_free_cus = 64;               // ... CUs assumed free beside a persistent bulk launch (units per block: 1 while the launch fits)
     int bc_per_problem = 1;               // batched condensed form: the Gram part by one workgroup per problem where n = 64 .. 256 allows it
+    int s_early = 1;                      // the slack block's closed-form panels enqueued up front on the rows stream (factor_all)
     int tile8_dist = 0;                   // ... also in the per-panel (multi-GPU) schedule
     int tile_upb = 0;                     // ... its other row tiles: (row tile, y) units per 512-thread block, 1 | 2; 0 = by the size of the launch
     int block_refine = 2;                 // refinement steps of L T = S in the panel scaling and of T z = y in the solves

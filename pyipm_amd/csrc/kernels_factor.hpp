@@ -87,6 +87,20 @@ __device__ __forceinline__ double static_pivot(const unsigned long long* __restr
     return 1.4901161193847656e-08 * ((an > 0.0 && an <= 1.0e300) ? an : 1.0);
 }
 
+// One tile's (or one closed-form panel's) contribution to the statistics of a factorisation.  Atomics (round 5): the closed-form
+// panels of the slack block run beside the x block's tile chain; every quantity is order-independent (integer sums, minimum and
+// maximum of non-negative doubles through their bit patterns), so the statistics are the same whoever comes first.
+__device__ __forceinline__ void stats_add(DevStats* __restrict__ st, long long neg, long long zero, long long n2, long long pos,
+                                          long long bad, double dmin, double dmax) {
+    if (neg)  atomicAdd(reinterpret_cast<unsigned long long*>(&st->n_neg), (unsigned long long)neg);
+    if (zero) atomicAdd(reinterpret_cast<unsigned long long*>(&st->n_zero), (unsigned long long)zero);
+    if (n2)   atomicAdd(reinterpret_cast<unsigned long long*>(&st->n_2x2), (unsigned long long)n2);
+    if (pos)  atomicAdd(reinterpret_cast<unsigned long long*>(&st->n_pos), (unsigned long long)pos);
+    if (bad)  atomicAdd(reinterpret_cast<unsigned long long*>(&st->nonfinite), (unsigned long long)bad);
+    if (dmin >= 0.0) atomicMin(reinterpret_cast<unsigned long long*>(&st->d_min), (unsigned long long)__double_as_longlong(dmin));
+    if (dmax >= 0.0) atomicMax(reinterpret_cast<unsigned long long*>(&st->d_max), (unsigned long long)__double_as_longlong(dmax));
+}
+
 __global__ __launch_bounds__(64) void k_init_stats(DevStats* __restrict__ st) {
     if (threadIdx.x == 0) {
         st->n_neg = 0; st->n_zero = 0; st->n_2x2 = 0; st->n_pos = 0; st->nonfinite = 0;
@@ -441,10 +455,7 @@ __device__ __forceinline__ void tile_invert_dev(
         // beyond refine_cond (or with 2x2 pivots) pay for refined block solves.  A tile with a rejected pivot
         // is singular to working precision: its "inverse" belongs to a perturbed tile, nothing to refine against.
         *Tflag = (zero == 0 && (n2 > 0 || !(dmax <= refine_cond * dmin))) ? 1.0 : 0.0;
-        st->n_neg += neg; st->n_zero += zero; st->n_2x2 += n2; st->n_pos += nreal - neg;    // static pivots count by their sign
-        st->nonfinite += bad;
-        if (dmin < st->d_min) st->d_min = dmin;
-        if (dmax > st->d_max) st->d_max = dmax;
+        stats_add(st, neg, zero, n2, nreal - neg, bad, dmin, dmax);                          // static pivots count by their sign
     }
 }
 
@@ -726,9 +737,7 @@ __global__ __launch_bounds__(256) void k_s_panel(
         long long n = 0, z = 0, b = 0; double mn = 1.0e308, mx = 0.0, gm = 0.0;
         for (int w = 0; w < 4; ++w) { n += sh_cnt[w][0]; z += sh_cnt[w][1]; b += sh_cnt[w][2];
                                       mn = fmin(mn, sh_mm[w][0]); mx = fmax(mx, sh_mm[w][1]); gm = fmax(gm, sh_mm[w][2]); }
-        st->n_neg += n; st->n_zero += z; st->n_pos += (long long)nt * TB - n; st->nonfinite += b;   // static pivots are positive
-        if (mn < st->d_min) st->d_min = mn;
-        if (mx > st->d_max) st->d_max = mx;
+        stats_add(st, n, z, 0, (long long)nt * TB - n, b, mn, mx);                               // static pivots are positive
         atomicMax(&st->growth_bits, (unsigned long long)__double_as_longlong(gm));
     }
 }

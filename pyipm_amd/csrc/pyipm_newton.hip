@@ -1587,6 +1587,17 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     }
     const int64_t ngroups = (int64_t)ctx->grp_first.size() - 1;
     auto gsize = [&](int64_t grp) { return ctx->grp_first[(size_t)grp + 1] - ctx->grp_first[(size_t)grp]; };
+    // diagnostics (PYIPM_GROUP_TRACE=1): where each group's chain, head and bulk update begin and end on the device, without a
+    // tracer's per-call cost on the host (tools/group_trace.py)
+    static const bool group_trace = getenv("PYIPM_GROUP_TRACE") != nullptr;
+    std::vector<std::pair<std::string, hipEvent_t>> marks;
+    auto mark = [&](const char* what, int64_t grp, hipStream_t st) {
+        if (!group_trace) return;
+        hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return;
+        hipEventRecord(e, st);
+        char buf[64]; snprintf(buf, sizeof(buf), "%s g%lld", what, (long long)grp);
+        marks.push_back({buf, e});
+    };
     // Fused forward substitution: y_p only needs panel p factored, so the forward pass of the step's
     // right-hand side (already in v0) trails the factorisation on its own stream.
     ctx->forward_fused = false;
@@ -1596,9 +1607,10 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));          // v0 = rhs copy was enqueued on the main stream
         PYIPM_HIP(hipStreamWaitEvent(ctx->fwd, ctx->ev_head, 0));
     }
+    std::vector<char> s_done_early((size_t)np, 0);     // closed-form panels of the slack block already enqueued (s_early, below)
     auto after_panel = [&](int64_t q, hipStream_t used) -> int {
         if (!fuse_forward) return 0;
-        PYIPM_HIP(hipEventRecord(ctx->ev_done[q], used));
+        if (!s_done_early[(size_t)q]) PYIPM_HIP(hipEventRecord(ctx->ev_done[q], used));      // (else: recorded behind its kernel)
         PYIPM_HIP(hipStreamWaitEvent(ctx->fwd, ctx->ev_done[q], 0));
         int r2 = fwd_panel(ctx, q, ctx->fwd_vec, ctx->fwd); if (r2) return r2;
         return diag_panel(ctx, q, ctx->fwd_vec, ctx->fwd);
@@ -1623,9 +1635,36 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         };
         if (chain_group(grp)) return factor_group(ctx, pA, nA, S, done);
         for (int64_t q = pA; q < pA + nA; ++q) {
-            int r2 = factor_panel(ctx, q, S, true); if (r2) return r2;
-            r2 = done(q, S); if (r2) return r2;
+            if (!s_done_early[(size_t)q]) { int r2 = factor_panel(ctx, q, S, true); if (r2) return r2; }
+            int r2 = done(q, S); if (r2) return r2;
         }
+        return 0;
+    };
+    // s_early (round 5): the closed-form panels of the slack block depend on nothing but the assembly -- no x-block update
+    // reaches their columns -- and used to sit, one 7 us launch after the other, between the x block's last chain and the
+    // multiplier block's first (config 2: 0.15 of 2.7 ms, plus the last x group's bulk update queued behind them on the same
+    // stream).  They are enqueued up front on the rows stream; what READS them (k_s_schur on the update stream, the forward
+    // sweep) keeps its place and waits for one event.  Statistics are atomic sums / minima / maxima: the same numbers.
+    bool s_early = false;
+    auto enqueue_s_early = [&](hipStream_t after) -> int {
+        if (!(ctx->s_early && ctx->lookahead && g.world == 1 && ngroups > 1) || ctx->grp_fast.empty()) return 0;
+        bool any = false;
+        for (int64_t gi = 1; gi < ngroups; ++gi) any = any || ctx->grp_fast[(size_t)gi];
+        if (!any || (ctx->grp_fast[0])) return 0;
+        { int r0 = ensure_rest_stream(ctx); if (r0) return r0; }
+        if (!ctx->ev_sfast) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_sfast, hipEventDisableTiming));
+        PYIPM_HIP(hipEventRecord(ctx->ev_sfast, after));                  // the assembly and the reset of the statistics
+        PYIPM_HIP(hipStreamWaitEvent(ctx->rest, ctx->ev_sfast, 0));
+        for (int64_t gi = 1; gi < ngroups; ++gi) {
+            if (!ctx->grp_fast[(size_t)gi]) continue;
+            for (int64_t q = ctx->grp_first[(size_t)gi]; q < ctx->grp_first[(size_t)gi + 1]; ++q) {
+                int r2 = factor_panel(ctx, q, ctx->rest, true); if (r2) return r2;
+                if (fuse_forward) PYIPM_HIP(hipEventRecord(ctx->ev_done[q], ctx->rest));
+                s_done_early[(size_t)q] = 1;
+            }
+        }
+        PYIPM_HIP(hipEventRecord(ctx->ev_sfast, ctx->rest));              // every closed-form panel is done
+        s_early = true;
         return 0;
     };
     // (round 4) the assembly came as two launches and the second may still be running on the main stream: the first group, which
@@ -1646,7 +1685,10 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         g0_side = true; (void)g0_side;
     } else {
         rc = factor_begin(ctx); if (rc) return rc;
+        rc = enqueue_s_early(ctx->stream); if (rc) return rc;
+        mark("chain+rows begin", 0, ctx->stream);
         rc = run_group(0, ctx->stream, false); if (rc) return rc;
+        mark("chain+rows end", 0, ctx->stream);
     }
     ctx->asm_split_cols = 0;
     std::vector<char> early((size_t)np, 0);       // panel's contribution to the NEXT group's columns already applied
@@ -1766,7 +1808,12 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
                 int64_t q = p0;
                 while (q < p0 + n0 && early[(size_t)q]) ++q;                       // applied early (always a prefix of the group)
                 const bool split = ctx->head_split && chain_group(grp + 1) && cs != ctx->stream;
-                if (q < p0 + n0) { rc = head_from(q, p0 + n0 - q, p1, n1, hs, split); if (rc) return rc; }
+                mark("head begin", grp, hs);
+                // (a head INTO the slack block is structurally empty: no x column reaches an s column, and a slack column's only
+                //  update is a diagonal entry of the multiplier block -- no launch, 10-15 us of the chain's path each)
+                const bool empty_head = ctx->s_early && nxt_fast;
+                if (q < p0 + n0 && !empty_head) { rc = head_from(q, p0 + n0 - q, p1, n1, hs, split); if (rc) return rc; }
+                mark("head end (its first launch's stream)", grp, hs);
             }
             (void)hc0;
             if (hs == ctx->stream && cs == ctx->side) {
@@ -1782,9 +1829,17 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             // as soon as each is factored, on the main stream behind this group's bulk update
             const bool do_early = ctx->early_head && grp + 2 < ngroups && n1 >= 2 && !nxt_fast && !fast_src &&
                                   g.Npad - g.panel_c0(p1) <= ctx->tail_cols;
+            mark("chain+rows begin", grp + 1, cs);
+            if (s_early && nxt_fast) {                                   // its kernels ran up front: whoever follows on cs (and the
+                PYIPM_HIP(hipStreamWaitEvent(cs, ctx->ev_sfast, 0));      // update stream, for k_s_schur) is ordered behind them
+                if (cs != ctx->stream) PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_sfast, 0));
+            }
             rc = run_group(grp + 1, cs, do_early); if (rc) return rc;
+            mark("chain+rows end", grp + 1, cs);
             PYIPM_HIP(hipEventRecord(ctx->ev_panel, cs));
+            mark("bulk begin", grp, ctx->stream);
             rc = timed_update(ctx, p0, n0, p1 + n1, np - (p1 + n1)); if (rc) return rc;   // bulk (overlaps the side stream)
+            mark("bulk end", grp, ctx->stream);
             if (do_early) {
                 const int64_t p2 = p1 + n1, n2 = gsize(grp + 2);
                 for (int64_t q = p1; q + 1 < p1 + n1; ++q) {
@@ -1819,6 +1874,16 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     rc = factor_end(ctx, stats);
     float ms = 0.f;
     PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    if (group_trace) {
+        hipEventSynchronize(ctx->ev[1]);
+        for (auto& m : marks) {
+            float t = 0.f;
+            if (hipEventSynchronize(m.second) == hipSuccess && hipEventElapsedTime(&t, ctx->ev[0], m.second) == hipSuccess)
+                fprintf(stderr, "[pyipm group trace] %9.1f us  %s\n", 1e3 * t, m.first.c_str());
+            hipEventDestroy(m.second);
+        }
+        fprintf(stderr, "[pyipm group trace] %9.1f us  factorisation end\n", 1e3 * ms);
+    }
     ctx->t_factor = ms;
     ctx->t_panel = ctx->profile ? (ms - ctx->t_trailing_union) : 0.0;    // exposed panel time: no update launch running
     return rc;
@@ -2087,6 +2152,7 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     if (ctx->ev_fwd) hipEventDestroy(ctx->ev_fwd);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->ev_split) hipEventDestroy(ctx->ev_split);
+    if (ctx->ev_sfast) hipEventDestroy(ctx->ev_sfast);
     if (ctx->ev_main) hipEventDestroy(ctx->ev_main);
     if (ctx->ev_asm) hipEventDestroy(ctx->ev_asm);
     for (auto e : ctx->ev_band) hipEventDestroy(e);
@@ -2878,7 +2944,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
             "head_on_side", "head_serial", "head_split", "head_split_rows", "fast_on_main", "rest_prio", "s_fast", "bwd_diag4",
             "head_waves", "inpanel32", "fuse_scale_update", "pending32_rows", "head32_rows", "head32_rows_dist", "early_head",
             "bulk_bn_rows", "bulk_bn_all", "bulk_bn_min_k", "sweep_max_blocks", "asm_tri", "asm_split", "fused_head",
-            "fused_head_rows", "dist_head_split", "tile_waves", "tile_upb", "tile8_rows", "tile_ny3", "tile_free_cus", "tile8_dist", "bc_per_problem", "debug_fault", "debug_timeline_ptr"};
+            "fused_head_rows", "dist_head_split", "tile_waves", "tile_upb", "tile8_rows", "tile_ny3", "tile_free_cus", "tile8_dist", "bc_per_problem", "s_early", "debug_fault", "debug_timeline_ptr"};
         bool is_expert = false;
         for (const char* e : kExpert) if (!strcmp(name, e)) { is_expert = true; break; }
         if (is_expert && !ctx->expert) {
@@ -2905,6 +2971,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "tile_ny3")) { ctx->tile_ny3 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile_free_cus")) { ctx->tile_free_cus = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "bc_per_problem")) { ctx->bc_per_problem = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "s_early")) { ctx->s_early = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile8_dist")) { ctx->tile8_dist = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile_upb")) { ctx->tile_upb = (int)value < 0 ? 0 : ((int)value > 2 ? 2 : (int)value); return PYIPM_OK; }
     if (!strcmp(name, "profile")) { ctx->profile = (int)value; return PYIPM_OK; }

@@ -4,4 +4,7 @@ O=gpurun_out/r05n; mkdir -p $O
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 export PYIPM_EXPERT=1
-( timeout 1200 python tools/ab_opts.py 16384 4096 6144 4 "" "bulk_waves=4" "bulk_bn_rows=12288,wide_persist_rows=20480" "bulk_bn_rows=12288,wide_persist_rows=20480,reserve_cus=8" "bulk_bn_rows=16384,wide_persist_rows=20480" "bulk_bn_rows=0,persist_rows=0,wide_persist_rows=12288" ) > $O/ab_metric.txt 2>&1; tail -6 $O/ab_metric.txt
+timeout 1200 python -m pytest tests/test_gpu_symmetric.py -x -q -k "bits or option" > $O/pytest_bits.log 2>&1; tail -3 $O/pytest_bits.log
+timeout 2400 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_configs.py > $O/pytest_all.log 2>&1; tail -3 $O/pytest_all.log
+( timeout 300 python tools/ab_opts.py 2048 0 2048 30 "s_early=0" "" ) > $O/ab_cfg2.txt 2>&1; tail -2 $O/ab_cfg2.txt
+( timeout 300 python tools/ab_opts.py 4096 1024 1536 20 "s_early=0" "" ) > $O/ab_8k.txt 2>&1; tail -2 $O/ab_8k.txt
