@@ -1670,7 +1670,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     // (round 4) the assembly came as two launches and the second may still be running on the main stream: the first group, which
     // touches only its own columns, runs on the chain's stream behind the first launch; the main stream joins it before the
     // first head and the first bulk update.
-    bool g0_side = false;
+    bool g0_side = false, first_early = false;
     if (ctx->asm_split_cols > 0 && ngroups > 1 && gsize(0) * (int64_t)g.nb == ctx->asm_split_cols && chain_group(0) && ctx->ev_asm &&
         ctx->head_on_side) {
         if (!ctx->ev_main) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
@@ -1683,6 +1683,20 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         PYIPM_HIP(hipEventRecord(ctx->ev_panel, ctx->side));
         PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
         g0_side = true; (void)g0_side;
+    } else if (ctx->early_first && ctx->early_head && ctx->lookahead && ctx->head_on_side && ngroups > 2 && gsize(0) >= 2 &&
+               chain_group(0) && chain_group(1) && g.Npad - g.panel_c0(ctx->grp_first[1]) <= ctx->tail_cols) {
+        // Chain-bound from the first group on (small systems): the first group runs on the chain's stream and every panel of
+        // it but the last updates the second group's columns as soon as it is factored, on the main stream (the early heads of
+        // the tail regime, applied to the first group): the head that the second chain waits for is one panel's (K = nb), not
+        // the group's.  The same products in the same order.
+        rc = factor_begin(ctx); if (rc) return rc;
+        rc = enqueue_s_early(ctx->stream); if (rc) return rc;
+        PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));             // the assembly, the reset of the statistics
+        PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_head, 0));
+        mark("chain+rows begin", 0, ctx->side);
+        rc = run_group(0, ctx->side, true); if (rc) return rc;
+        mark("chain+rows end", 0, ctx->side);
+        first_early = true;
     } else {
         rc = factor_begin(ctx); if (rc) return rc;
         rc = enqueue_s_early(ctx->stream); if (rc) return rc;
@@ -1692,6 +1706,30 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     }
     ctx->asm_split_cols = 0;
     std::vector<char> early((size_t)np, 0);       // panel's contribution to the NEXT group's columns already applied
+    if (group_trace) fprintf(stderr, "[pyipm group trace] first group: %s, %lld groups\n", first_early ? "early heads" : (g0_side ? "asm split" : "plain"), (long long)ngroups);
+    if (first_early) {
+        const int64_t n0 = gsize(0), p1 = ctx->grp_first[1], n1 = gsize(1);
+        for (int64_t q = 0; q + 1 < n0; ++q) {
+            PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_early[(size_t)q], 0));
+            // (the second group's columns, K = one panel; same launch form as the early heads of the group loop)
+            const int64_t tc0 = g.panel_c0(p1);
+            if (ctx->inpanel32 && g.Npad - tc0 <= ctx->head32_rows) {
+                int K = (int)g.panel_w(q); int64_t cols = 0;
+                for (int64_t t = p1; t < p1 + n1; ++t) cols += g.panel_w(t);
+                int64_t pa0, pa1, pb0, pb1;
+                active_ranges(ctx, g.panel_c0(q), g.panel_c0(q) + K, &pa0, &pa1, &pb0, &pb1);
+                hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - tc0) / 32), (unsigned)(cols / TB)), dim3(256), 0,
+                                   ctx->stream, ctx->A, g.Npad, g.local_c0(p1), ctx->A + g.local_c0(q) * g.Npad, g.Npad,
+                                   wbuf(ctx, q), g.Npad, tc0, K, tc0, g.Npad, pa0, pa1, pb0, pb1, ctx->side_prio);
+                PYIPM_KCHECK();
+            } else {
+                rc = timed_update(ctx, q, 1, p1, n1, ctx->stream); if (rc) return rc;
+            }
+            early[(size_t)q] = 1;
+        }
+        PYIPM_HIP(hipEventRecord(ctx->ev_panel, ctx->side));
+        PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
+    }
     for (int64_t grp = 0; grp + 1 < ngroups; ++grp) {
         const int64_t p0 = ctx->grp_first[(size_t)grp], n0 = gsize(grp), p1 = p0 + n0, n1 = gsize(grp + 1);
         if (ctx->lookahead) {
@@ -1827,7 +1865,8 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             }
             // early heads: in the tail regime the panels of the NEXT group except its last one update the group after it
             // as soon as each is factored, on the main stream behind this group's bulk update
-            const bool do_early = ctx->early_head && grp + 2 < ngroups && n1 >= 2 && !nxt_fast && !fast_src &&
+            // (round 5: also behind a slack-block source group -- its "bulk update" is one k_s_schur launch, the main stream is free)
+            const bool do_early = ctx->early_head && grp + 2 < ngroups && n1 >= 2 && !nxt_fast && (!fast_src || ctx->early_first) &&
                                   g.Npad - g.panel_c0(p1) <= ctx->tail_cols;
             mark("chain+rows begin", grp + 1, cs);
             if (s_early && nxt_fast) {                                   // its kernels ran up front: whoever follows on cs (and the
@@ -2944,7 +2983,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
             "head_on_side", "head_serial", "head_split", "head_split_rows", "fast_on_main", "rest_prio", "s_fast", "bwd_diag4",
             "head_waves", "inpanel32", "fuse_scale_update", "pending32_rows", "head32_rows", "head32_rows_dist", "early_head",
             "bulk_bn_rows", "bulk_bn_all", "bulk_bn_min_k", "sweep_max_blocks", "asm_tri", "asm_split", "fused_head",
-            "fused_head_rows", "dist_head_split", "tile_waves", "tile_upb", "tile8_rows", "tile_ny3", "tile_free_cus", "tile8_dist", "bc_per_problem", "s_early", "debug_fault", "debug_timeline_ptr"};
+            "fused_head_rows", "dist_head_split", "tile_waves", "tile_upb", "tile8_rows", "tile_ny3", "tile_free_cus", "tile8_dist", "bc_per_problem", "s_early", "early_first", "debug_fault", "debug_timeline_ptr"};
         bool is_expert = false;
         for (const char* e : kExpert) if (!strcmp(name, e)) { is_expert = true; break; }
         if (is_expert && !ctx->expert) {
@@ -2971,6 +3010,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "tile_ny3")) { ctx->tile_ny3 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile_free_cus")) { ctx->tile_free_cus = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "bc_per_problem")) { ctx->bc_per_problem = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "early_first")) { ctx->early_first = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "s_early")) { ctx->s_early = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile8_dist")) { ctx->tile8_dist = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile_upb")) { ctx->tile_upb = (int)value < 0 ? 0 : ((int)value > 2 ? 2 : (int)value); return PYIPM_OK; }
