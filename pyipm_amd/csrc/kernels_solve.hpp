@@ -314,7 +314,7 @@ __global__ __launch_bounds__(1024) void k_bwd_sweep(const double* __restrict__ A
     __shared__ int ok_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = sg.npanels, nb = sg.nb;
-    unsigned* flag = sync; unsigned* nearc = sync + P; unsigned* prog = sync + 2 * P;     // prog[b]: steps workgroup b has completed
+    unsigned* flag = sync; unsigned* nearc = sync + P; unsigned* prog = sync + 2 * P;     // prog[w]: steps column-owner wave w has completed
     const int gpp = nb / 8;                                    // groups of 8 columns per panel
     if (blockIdx.x == 0) {
         const int k = tid & 255, q = tid >> 8;
@@ -389,10 +389,17 @@ __global__ __launch_bounds__(1024) void k_bwd_sweep(const double* __restrict__ A
             __syncthreads();
             if (dbg && tid == 0) dbg[4 * s + 3] = wall_clock64();
             if (tid == 0) __hip_atomic_store(flag + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // for the NEXT panel (s - 1): every column owner has finished step s + 1 -- thread b polls workgroup b's progress
-            // word (one counter per step took 4080 atomics on one address: 27 us a step).  Normally long done, and polled
-            // here, while the owners of panel s - 1's columns work on what this panel just published.
-            if (s + 1 < P && s >= 1 && tid >= 1 && tid < (int)gridDim.x && !sweep_wait(prog + tid, (unsigned)(P - (s + 1)), err, timeout)) ok_s = 0;
+            // for the NEXT panel (s - 1): the owners of ITS columns have finished step s + 1 -- thread j polls the progress word of
+            // the wave that owns group j of that panel (ownership is static: group g -> wave g mod #waves).  Until round 5 this
+            // waited for EVERY owner to finish the step (a progress word per workgroup): where the sweep is bandwidth-bound --
+            // the first half at N = 32768: 64 ... 32 MB of far columns per step against 6.5 us of chain -- the chain then ran at
+            // the pace of the slowest owner of columns it would not need for a hundred panels (3.1 us of this wait per panel
+            // against 1.5 at N = 6144); now those owners fall behind and catch up while the chain is the bound.
+            // (One counter per step took 4080 atomics on one address: 27 us a step.)
+            if (s + 1 < P && s >= 1 && tid < gpp) {
+                const int nwv_o = ((int)gridDim.x - 1 - (gpp + 15) / 16) * 16;
+                if (!sweep_wait(prog + ((s - 1) * gpp + tid) % nwv_o, (unsigned)(P - (s + 1)), err, timeout)) ok_s = 0;
+            }
             __syncthreads();
             if (!ok_s) break;
         }
@@ -402,17 +409,11 @@ __global__ __launch_bounds__(1024) void k_bwd_sweep(const double* __restrict__ A
         return;
     }
     // ---- column owners ----
-    __shared__ unsigned wprog[16];                             // steps completed by each wave of this workgroup
-    if (tid < 16) wprog[tid] = 0u;
-    __syncthreads();
+    const int nearb_ = (gpp + 15) / 16;
+    const bool specialist_ = (int)blockIdx.x <= nearb_;
+    const int gw_ = ((int)blockIdx.x - 1 - nearb_) * 16 + wave;
     auto publish = [&](unsigned steps_done) {                   // (wave-uniform) this wave has completed that many steps
-        if (lane == 0) {
-            __hip_atomic_store(&wprog[wave], steps_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            unsigned m = steps_done;
-            #pragma unroll
-            for (int w = 0; w < 16; ++w) { const unsigned o = __hip_atomic_load(&wprog[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); m = o < m ? o : m; }
-            __hip_atomic_fetch_max(prog + blockIdx.x, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (lane == 0 && !specialist_) __hip_atomic_store(prog + gw_, steps_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
     // The first `nearb` workgroups are NEAR specialists: wave j of theirs takes, at every step t, group j of the columns of
     // panel t - 1 -- the sums workgroup 0 is waiting for -- and nothing else, so it is already polling flag[t] when it goes

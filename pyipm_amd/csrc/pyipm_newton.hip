@@ -1202,7 +1202,7 @@ int solve_plain(Ctx* ctx, double* v, bool forward_done, int nrhs = 1, int64_t vs
     if (one_launch) {
         // the whole backward sweep in one launch (k_bwd_sweep): workgroup 0 on the diagonal blocks, every other wave on its columns
         const int P = (int)g.npanels;
-        PYIPM_HIP(hipMemsetAsync(ctx->sweep_sync, 0, (size_t)(2 * P + 1024) * sizeof(unsigned), ctx->stream));
+        PYIPM_HIP(hipMemsetAsync(ctx->sweep_sync, 0, (size_t)(2 * P + 4096) * sizeof(unsigned), ctx->stream));     // flags, near counts, a progress word per owner wave
         PYIPM_HIP(hipMemsetAsync(ctx->sweep_buf, 0xFF, (size_t)g.Npad * sizeof(double), ctx->stream));      // NaN: "not there yet"
         const int64_t groups = g.Npad / 8;
         const int64_t nearb = (g.nb / 8 + 15) / 16;                  // workgroups that only do the next panel's columns
