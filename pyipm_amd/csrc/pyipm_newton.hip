@@ -1567,6 +1567,13 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             int64_t G = (ctx->tail_group > 0 && remaining <= ctx->tail_cols) ? ctx->tail_group : ctx->group;
             if (G > ctx->group) G = ctx->group;
             if (p + G > np) G = np - p;
+            // (round 5) the panels inside the slack block as ONE group: their kernels run up front (s_early) and what is left of
+            // a slack group in the loop below is a head, a k_s_schur launch and four stream hops -- 56 us per group of four
+            // panels between the x block's last bulk update and the multiplier block's first chain (N = 32768: six groups)
+            if (ctx->s_early && ctx->s_fast && ctx->skip_zeros && g.mi > 0 && g.world == 1 && ctx->lookahead && p > 0 &&
+                g.panel_c0(p) >= g.n && g.panel_c0(p + G - 1) + g.panel_w(p + G - 1) <= g.n + g.mi) {
+                while (p + G < np && g.panel_c0(p + G) + g.panel_w(p + G) <= g.n + g.mi) ++G;
+            }
             ctx->grp_first.push_back(p);
             for (int64_t q = 0; q < G; ++q) { ctx->grp_of[(size_t)(p + q)] = gid; ctx->grp_off[(size_t)(p + q)] = (int)q; }
             p += G; ++gid;

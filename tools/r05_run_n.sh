@@ -4,4 +4,7 @@ O=gpurun_out/r05n; mkdir -p $O
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 export PYIPM_EXPERT=1
-( timeout 1200 python tools/ab_opts.py 16384 4096 6144 4 "" "reserve_cus=32" "reserve_cus=48" "reserve_cus=64" "reserve_cus=96" "reserve_cus=64,head_serial=2" "reserve_cus=48,persist_rows=10240" ) > $O/ab_metric.txt 2>&1; tail -7 $O/ab_metric.txt
+timeout 1200 python -m pytest tests/test_gpu_symmetric.py -x -q -k "bits or option" > $O/pytest_bits.log 2>&1; tail -3 $O/pytest_bits.log
+timeout 1800 python -m pytest tests/test_gpu_parity.py tests/test_gpu_pivoting.py tests/test_gpu_ipm.py tests/test_gpu_qp.py -x -q > $O/pytest_par.log 2>&1; tail -3 $O/pytest_par.log
+( timeout 300 python tools/ab_opts.py 2048 0 2048 30 "s_early=0" "" ) > $O/ab_cfg2.txt 2>&1; tail -2 $O/ab_cfg2.txt
+( timeout 900 python tools/ab_opts.py 16384 4096 6144 4 "s_early=0" "" ) > $O/ab_metric.txt 2>&1; tail -2 $O/ab_metric.txt
