@@ -442,7 +442,7 @@ int pyipm_newton_trailing_bytes(pyipm_newton_ctx* ctx, double out[4]);
  *   head_on_side, head_serial, head_split, head_split_rows, fast_on_main, rest_prio, s_fast, bwd_diag4, head_waves,
  *   inpanel32, fuse_scale_update, pending32_rows, head32_rows, head32_rows_dist, early_head, bulk_bn_rows, bulk_bn_all,
  *   bulk_bn_min_k, sweep_max_blocks, asm_tri, asm_split, fused_head, fused_head_rows, dist_head_split, tile_waves, tile_upb,
- *   tile8_rows, tile_ny3, tile_free_cus, tile8_dist, bc_per_problem, s_early, early_first,
+ *   tile8_rows, tile_ny3, tile_free_cus, tile8_dist, bc_per_problem, s_early, early_first, s_across,
  *   debug_fault, debug_timeline_ptr
  *   (which stream runs what, in how many launches, which kernel instance takes which row counts -- all of them but one choose
  *   between implementations that accumulate the same products in the same order: bit-identical results,

@@ -247,6 +247,7 @@ struct Ctx {
     int tile_free_cus = 64;               // ... CUs assumed free beside a persistent bulk launch (units per block: 1 while the launch fits)
     int bc_per_problem = 1;               // batched condensed form: the Gram part by one workgroup per problem where n = 64 .. 256 allows it
     int early_first = 1;                  // early heads also for the first group and behind a slack-block group (chain-bound systems)
+    int s_across = 1;                     // ... and the group after the slack block is the lookahead target of the group before it
     int s_early = 1;                      // the slack block's closed-form panels enqueued up front on the rows stream (factor_all)
     int tile8_dist = 0;                   // ... also in the per-panel (multi-GPU) schedule
     int tile_upb = 0;                     // ... its other row tiles: (row tile, y) units per 512-thread block, 1 | 2; 0 = by the size of the launch

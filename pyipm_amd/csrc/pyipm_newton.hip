@@ -1713,6 +1713,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     }
     ctx->asm_split_cols = 0;
     std::vector<char> early((size_t)np, 0);       // panel's contribution to the NEXT group's columns already applied
+    bool across_prev = false;
     if (group_trace) fprintf(stderr, "[pyipm group trace] first group: %s, %lld groups\n", first_early ? "early heads" : (g0_side ? "asm split" : "plain"), (long long)ngroups);
     if (first_early) {
         const int64_t n0 = gsize(0), p1 = ctx->grp_first[1], n1 = gsize(1);
@@ -1845,9 +1846,23 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             }
             // (the FIRST head stays on the main stream also when group 0 ran on the chain's stream: nothing runs beside it either
             //  way, and as a main-stream launch it takes the bulk instance and is part of the trailing figures, as in rounds 1-3)
-            if (grp > 0 && ctx->head_on_side && cs == ctx->side) {
-                PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_main, 0));    // (recorded at the end of the iteration before)
+            // (round 5) Lookahead ACROSS the slack block.  With its panels run up front the slack group between the last x group
+            // and the first multiplier group is no work at all -- but that multiplier group's columns used to get this group's
+            // contribution from its BULK update, and its chain started behind the whole launch and the slack group's hops
+            // (N = 32768: 1.6 + 0.3 ms with nothing else on the chain's path; config 2: 0.14 ms).  The group after the slack group
+            // is treated as the lookahead target: a head (split: its diagonal block on the chain's stream, the rows below on the
+            // rows stream) applies this group's contribution to its columns, the bulk update starts beyond them.  The same
+            // products in the same order per entry (x groups in order, then the slack block's diagonal update).
+            const bool across = s_early && ctx->s_across && nxt_fast && !fast_src && grp > 0 && grp + 2 < ngroups &&
+                                !ctx->grp_fast[(size_t)(grp + 2)] && chain_group(grp + 2) && ctx->head_on_side && ctx->head_split;
+            const int64_t pT = across ? ctx->grp_first[(size_t)(grp + 2)] : 0, nT = across ? gsize(grp + 2) : 0;
+            if (grp > 0 && ctx->head_on_side && (cs == ctx->side || across)) {
+                // (recorded at the end of the iteration before.  Behind an `across` iteration the source is the slack group: its
+                //  head is the diagonal update of the target's columns, ordered behind the x group's head on this stream, and the
+                //  x group's bulk update -- what the event would wait for -- no longer touches those columns)
+                if (!across_prev) PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_main, 0));
                 hs = ctx->side;
+                if (s_early && fast_src) PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_sfast, 0));   // (k_s_schur reads the slack columns)
             }
             {
                 int64_t q = p0;
@@ -1857,7 +1872,8 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
                 // (a head INTO the slack block is structurally empty: no x column reaches an s column, and a slack column's only
                 //  update is a diagonal entry of the multiplier block -- no launch, 10-15 us of the chain's path each)
                 const bool empty_head = ctx->s_early && nxt_fast;
-                if (q < p0 + n0 && !empty_head) { rc = head_from(q, p0 + n0 - q, p1, n1, hs, split); if (rc) return rc; }
+                if (across) { rc = head_from(p0, n0, pT, nT, hs, true); if (rc) return rc; }
+                else if (q < p0 + n0 && !empty_head) { rc = head_from(q, p0 + n0 - q, p1, n1, hs, split); if (rc) return rc; }
                 mark("head end (its first launch's stream)", grp, hs);
             }
             (void)hc0;
@@ -1884,6 +1900,9 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             mark("chain+rows end", grp + 1, cs);
             PYIPM_HIP(hipEventRecord(ctx->ev_panel, cs));
             mark("bulk begin", grp, ctx->stream);
+            across_prev = across;
+            if (across) { rc = timed_update(ctx, p0, n0, pT + nT, np - (pT + nT)); if (rc) return rc; }   // (the target's columns: the head above)
+            else
             rc = timed_update(ctx, p0, n0, p1 + n1, np - (p1 + n1)); if (rc) return rc;   // bulk (overlaps the side stream)
             mark("bulk end", grp, ctx->stream);
             if (do_early) {
@@ -2990,7 +3009,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
             "head_on_side", "head_serial", "head_split", "head_split_rows", "fast_on_main", "rest_prio", "s_fast", "bwd_diag4",
             "head_waves", "inpanel32", "fuse_scale_update", "pending32_rows", "head32_rows", "head32_rows_dist", "early_head",
             "bulk_bn_rows", "bulk_bn_all", "bulk_bn_min_k", "sweep_max_blocks", "asm_tri", "asm_split", "fused_head",
-            "fused_head_rows", "dist_head_split", "tile_waves", "tile_upb", "tile8_rows", "tile_ny3", "tile_free_cus", "tile8_dist", "bc_per_problem", "s_early", "early_first", "debug_fault", "debug_timeline_ptr"};
+            "fused_head_rows", "dist_head_split", "tile_waves", "tile_upb", "tile8_rows", "tile_ny3", "tile_free_cus", "tile8_dist", "bc_per_problem", "s_early", "early_first", "s_across", "debug_fault", "debug_timeline_ptr"};
         bool is_expert = false;
         for (const char* e : kExpert) if (!strcmp(name, e)) { is_expert = true; break; }
         if (is_expert && !ctx->expert) {
@@ -3018,6 +3037,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "tile_free_cus")) { ctx->tile_free_cus = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "bc_per_problem")) { ctx->bc_per_problem = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "early_first")) { ctx->early_first = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "s_across")) { ctx->s_across = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "s_early")) { ctx->s_early = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile8_dist")) { ctx->tile8_dist = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile_upb")) { ctx->tile_upb = (int)value < 0 ? 0 : ((int)value > 2 ? 2 : (int)value); return PYIPM_OK; }

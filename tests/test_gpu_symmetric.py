@@ -341,7 +341,7 @@ SCHEDULE_SPACE = {"lookahead": [0, 1], "group": [1, 2, 4, 8], "group_chain": [0,
                   "fuse_scale_update": [0, 1], "asm_tri": [0, 1], "asm_split": [0, 1],
                   # round 5: the tile steps' critical block on eight waves (chain + helpers)
                   "tile_waves": [4, 8], "tile_upb": [0, 1, 2], "tile8_rows": [0, 12288, 1 << 20],
-                  "tile_ny3": [0, 1], "tile_free_cus": [16, 256], "s_early": [0, 1], "early_first": [0, 1]}
+                  "tile_ny3": [0, 1], "tile_free_cus": [16, 256], "s_early": [0, 1], "early_first": [0, 1], "s_across": [0, 1]}
 
 
 def test_option_lists_header_library_and_sweep_agree():
