@@ -4,5 +4,4 @@ O=gpurun_out/r05n; mkdir -p $O
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 export PYIPM_EXPERT=1
-( timeout 1200 python tools/ab_opts.py 16384 4096 6144 4 "" "head_split_rows=12288" "head_split_rows=20480" "head_split_rows=12288,head_serial=2" "head_serial=2" ) > $O/ab_metric.txt 2>&1; tail -5 $O/ab_metric.txt
-( timeout 900 python tools/ab_opts.py 16384 8192 8192 2 "" "head_split_rows=12288" "head_split_rows=20480" ) > $O/ab_cfg3.txt 2>&1; tail -3 $O/ab_cfg3.txt
+( timeout 600 python tools/ab_opts.py 2048 0 2048 30 "" "tail_group=8" "tail_group=2" "tile_ny3=1" "early_head=1" "fuse_forward=0" "head_serial=1" "pending_left_rows=-1" ) > $O/ab_cfg2.txt 2>&1; tail -8 $O/ab_cfg2.txt
