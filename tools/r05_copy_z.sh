@@ -1,5 +1,5 @@
 #!/bin/bash
-# gpurun_out/r05z/* (tools/r04_run_z.sh) -> profiles/r05_z_*
+# gpurun_out/r05z/* (tools/r05_run_z.sh) -> profiles/r05_z_*
 S=gpurun_out/r05z P=profiles/r05_z
 cp $S/bench.json ${P}_bench.json; cp $S/bench_default.json ${P}_bench_default.json; cp $S/bench_under_rocprof.json ${P}_bench_under_rocprof.json
 cp $S/bench_kernel_stats.txt ${P}_kernel_stats.txt; cp $S/pmc_update.json ${P}_pmc_update.json; cp $S/pmc_update_bn128.json ${P}_pmc_update_bn128.json; cp $S/pmc_hbm/pmc_hbm.json ${P}_pmc_hbm_kernels.json

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5 evidence set: gpurun_out/r05z/ -> profiles/r04_z_*   (run on the GPU box: gpurun -- bash tools/r04_run_z.sh)
+# round 5 evidence set: gpurun_out/r05z/ -> profiles/r05_z_*   (on the GPU box: gpurun -- "WITH_REPLAY=1 bash tools/r05_run_z.sh"; then tools/r05_copy_z.sh here)
 set -u
 O=gpurun_out/r05z; mkdir -p $O
 R=${GRAFT_REPO_ROOT:-$(pwd)}
