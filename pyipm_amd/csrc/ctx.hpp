@@ -242,6 +242,14 @@ struct Ctx {
     int tile_waves = 8;                   // k_tile_step on 512 threads (round 5): the critical block = four chain waves + four helper waves
                                           // (diagonal tile prefetched beside the scaling product; the blocked inversion's updates and commits
                                           // beside the next elimination, tile_blocked8.hpp); 4: the 256-thread kernel of rounds 2-4.  Same bits.
+    int tile_chain = 0;                   // the tile steps of a diagonal block as ONE launch of persistent workgroups per piece (k_tile_chain,
+                                          // kernels_chain.hpp; round 6): 1 where the chain is exposed (first group, at most tile8_rows rows left,
+                                          // the per-panel / multi-GPU schedule), 2 everywhere, 0 one launch per tile.  Same bits.
+    int chain_cpy = 5;                    // ... column tiles per unit and stage a row tile is split for
+    static constexpr int CHAIN_SLOTS = 8, CHAIN_WORDS = 160;
+    unsigned* chain_sync = nullptr;       // ... progress words (CHAIN_SLOTS regions used round robin, epoch-stamped) + the sticky error word
+    unsigned chain_epoch = 0;
+    bool chain_used = false;              // ... a chain launch ran since the error word was last read (factor_end)
     int64_t tile8_rows = 12288;           // ... used by the single-rank schedule for the first group and where at most this many rows are left
     int tile_ny3 = 0;                     // ... its row-tile units with at most 3 (instead of 5) column tiles each
     int tile_free_cus = 64;               // ... CUs assumed free beside a persistent bulk launch (units per block: 1 while the launch fits)

@@ -33,6 +33,20 @@ extern "C" __device__ __attribute__((const)) double __ockl_wfred_max_f64(double)
 
 __device__ __forceinline__ double wave_max(double v) { return __ockl_wfred_max_f64(v); }
 
+// Loads / stores of data that crosses workgroups INSIDE one launch (k_tile_chain, kernels_chain.hpp): relaxed agent-scope
+// atomics (global_load / global_store ... sc1: past the CU's L1, written through the XCD's L2) instead of a fence per
+// hand-over -- the rule of the one-launch sweeps (kernels_solve.hpp).  COH = false: the plain access of every other kernel.
+template <bool COH>
+__device__ __forceinline__ double ldg_c(const double* p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH>
+__device__ __forceinline__ void stg_c(double* p, double v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 #define PYIPM_BK_ALPHA 0.6403882032022076   /* (1+sqrt(17))/8 */
 
 // Timing experiments on the pivot loop (tools/tile_variants.sh builds extra libraries with -DPYIPM_TILE_EXPERIMENT=bits;
@@ -131,7 +145,9 @@ static_assert(sizeof(BlockedScratch) + 4 * TB * sizeof(double) <= 16 * TB * size
 // and run the updates / commits of the blocked sweep (tile_blocked8.hpp) beside the critical waves' eliminations, and
 // leave the kernel when the blocked sweep ends; ex = its exchange scratch.  Everything from the general loop on runs on
 // waves 0..3 as before.
-template <bool W8 = false>
+// COH: the tile's outputs (inverse, saved tile, refinement flag) are read by other workgroups of the SAME launch: written
+// through (stg_c).  LOOPED: called from inside a persistent loop (tile_tid).
+template <bool W8 = false, bool COH = false, bool LOOPED = false>
 __device__ __forceinline__ void tile_invert_dev(
     TileScratch& sm,
     const double* __restrict__ A, int64_t ld, int64_t grow0, int64_t lcol0,
@@ -152,7 +168,7 @@ __device__ __forceinline__ void tile_invert_dev(
     if (dbg) { dbg_c0 = clock64(); dbg_w0 = wall_clock64(); }
 
     constexpr int NT = W8 ? 512 : 256;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = tile_tid<LOOPED>(), lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 3, cb = wave * 16;
     const bool helper = W8 && tid >= 256;
 
@@ -182,7 +198,7 @@ __device__ __forceinline__ void tile_invert_dev(
             row[c] = (lane >= j) ? stage[lane][j] : stage[j][lane];
             if (!W8 || helper) {
                 amax = fmax(amax, fabs(row[c]));
-                Tsave[j * TB + lane] = row[c];             // kept for the refinement of the block solves
+                stg_c<COH>(Tsave + j * TB + lane, row[c]); // kept for the refinement of the block solves
             }
         }
     }
@@ -248,7 +264,7 @@ __device__ __forceinline__ void tile_invert_dev(
         if (tid == 0) sm.f.bs.fail = 0;
         __syncthreads();
         if (dbg && tid == 0) dbg[4] = clock64() - dbg_c0;
-        kb_done = tile_blocked_sweep(stage, sm.f.bs, sm.dsave, dbg);
+        kb_done = tile_blocked_sweep<TB + 1, LOOPED>(stage, sm.f.bs, sm.dsave, dbg);
         if (dbg && tid == 0) { dbg[5] = clock64() - dbg_c0; dbg[6] = dbg_c0; dbg[7] += (unsigned long long)kb_done; }   // (micro-blocks committed, summed over tiles)
         #pragma unroll
         for (int c = 0; c < 16; ++c) {                 // the working matrix as it stands, back in the sweep layout
@@ -438,7 +454,7 @@ __device__ __forceinline__ void tile_invert_dev(
 #undef PYIPM_PUBLISH
 #undef PYIPM_SWEEP1
     #pragma unroll
-    for (int c = 0; c < 16; ++c) if (c < c_out) Tinv[(cb + c) * TB + lane] = -row[c];
+    for (int c = 0; c < 16; ++c) if (c < c_out) stg_c<COH>(Tinv + (cb + c) * TB + lane, -row[c]);
     if (dbg && tid == 0) { dbg[0] = clock64() - dbg_c0; dbg[1] = wall_clock64() - dbg_w0; dbg[2] += 1; }
     __syncthreads();                                     // dsave complete
     if (wave == 0) {                                     // statistics of the 1x1 pivots: lane p looks at pivot p
@@ -454,7 +470,7 @@ __device__ __forceinline__ void tile_invert_dev(
         // pivot spread of THIS tile ~ cond(T): the explicit inverse is accurate to cond*eps, so only tiles
         // beyond refine_cond (or with 2x2 pivots) pay for refined block solves.  A tile with a rejected pivot
         // is singular to working precision: its "inverse" belongs to a perturbed tile, nothing to refine against.
-        *Tflag = (zero == 0 && (n2 > 0 || !(dmax <= refine_cond * dmin))) ? 1.0 : 0.0;
+        stg_c<COH>(Tflag, (zero == 0 && (n2 > 0 || !(dmax <= refine_cond * dmin))) ? 1.0 : 0.0);
         stats_add(st, neg, zero, n2, nreal - neg, bad, dmin, dmax);                          // static pivots count by their sign
     }
 }
@@ -487,10 +503,11 @@ __global__ __launch_bounds__(256) void k_tile_invert(
 
 // 64x64 tile (global, row-major [k][c]) -> LDS array dst_[k][c], scaled: the 16 loads of a thread are issued together
 // (a rolled loop costs one memory latency per trip -- 16 of them were the whole run time of k_panel_scale).
-#define PYIPM_STAGE_TILE(dst_, scale_, src_)                                                          \
+#define PYIPM_STAGE_TILE(dst_, scale_, src_) PYIPM_STAGE_TILE_C(dst_, scale_, src_, false)
+#define PYIPM_STAGE_TILE_C(dst_, scale_, src_, coh_)                                                  \
     {                                                                                                 \
         double stg_[TB * TB / 256];                                                                   \
-        _Pragma("unroll") for (int q_ = 0; q_ < TB * TB / 256; ++q_) stg_[q_] = (src_)[tid + 256 * q_]; \
+        _Pragma("unroll") for (int q_ = 0; q_ < TB * TB / 256; ++q_) stg_[q_] = ldg_c<coh_>((src_) + tid + 256 * q_); \
         _Pragma("unroll") for (int q_ = 0; q_ < TB * TB / 256; ++q_) {                                \
             const int e_ = tid + 256 * q_;                                                            \
             (dst_)[e_ >> 6][e_ & 63] = (scale_) * stg_[q_];                                           \

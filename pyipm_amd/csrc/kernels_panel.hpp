@@ -23,11 +23,13 @@ namespace pyipm {
 // L = S inv(T) for one 64-row strip (wave: 16 rows x 64 columns), nref refinement steps against T; the arithmetic of
 // k_panel_scale with sign = +1.  X holds inv(T) on entry (staged, synchronised) and on exit; sb = S in the B-operand map.
 // one refinement step of strip_scale (four barriers)
+template <bool COH = false>
 __device__ __forceinline__ void strip_refine_step(double (&X)[TB][TB + 2], const double* __restrict__ Tinv,
                                                   const double* __restrict__ Tsave, const double (&sb)[16],
                                                   int tid, int l15, int l4, double4_t (&acc)[4]);
 
-template <bool REFINE = true>
+// (COH: inv(T) / T come from another workgroup of the same launch, k_tile_chain -- kernels_factor.hpp:ldg_c)
+template <bool REFINE = true, bool COH = false>
 __device__ __forceinline__ void strip_scale(double (&X)[TB][TB + 2], const double* __restrict__ Tinv,
                                             const double* __restrict__ Tsave, int nref, const double (&sb)[16],
                                             int tid, int l15, int l4, double4_t (&acc)[4])
@@ -43,16 +45,17 @@ __device__ __forceinline__ void strip_scale(double (&X)[TB][TB + 2], const doubl
         }
     }
     if (REFINE)
-        for (int it = 0; it < nref; ++it) strip_refine_step(X, Tinv, Tsave, sb, tid, l15, l4, acc);
+        for (int it = 0; it < nref; ++it) strip_refine_step<COH>(X, Tinv, Tsave, sb, tid, l15, l4, acc);
 }
 
+template <bool COH>
 __device__ __forceinline__ void strip_refine_step(double (&X)[TB][TB + 2], const double* __restrict__ Tinv,
                                                   const double* __restrict__ Tsave, const double (&sb)[16],
                                                   int tid, int l15, int l4, double4_t (&acc)[4])
 {
     {
         __syncthreads();
-        PYIPM_STAGE_TILE(X, -1.0, Tsave)
+        PYIPM_STAGE_TILE_C(X, -1.0, Tsave, COH)
         __syncthreads();
         double4_t res[4];                                            // R = S - L T
         #pragma unroll
@@ -69,7 +72,7 @@ __device__ __forceinline__ void strip_refine_step(double (&X)[TB][TB + 2], const
             }
         }
         __syncthreads();
-        PYIPM_STAGE_TILE(X, 1.0, Tinv)
+        PYIPM_STAGE_TILE_C(X, 1.0, Tinv, COH)
         __syncthreads();
         #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {                            // L += R inv(T)
@@ -85,7 +88,7 @@ __device__ __forceinline__ void strip_refine_step(double (&X)[TB][TB + 2], const
 
 // C[i][c] += sum_{k < 64} L[i][k] Wn[c][k] for the strip: L from the scaling accumulators (their C/D map is the B-operand
 // map), Wn[c][k] = wn[c + k * ldw] (the -S rows of the target column tile, 64 x 64).
-template <int KS = 8>                     // k-steps (of 4 columns) whose Wn operands are in flight together
+template <int KS = 8, bool COH = false>   // k-steps (of 4 columns) whose Wn operands are in flight together
 __device__ __forceinline__ void strip_update(double4_t (&c2)[4], const double4_t (&acc)[4], const double* __restrict__ wn,
                                              int64_t ldw, int l15, int l4)
 {
@@ -95,7 +98,7 @@ __device__ __forceinline__ void strip_update(double4_t (&c2)[4], const double4_t
         #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
             #pragma unroll
-            for (int t = 0; t < 4; ++t) wa[t][ks] = wn[(16 * t + l15) + (int64_t)(4 * (KS * h + ks) + l4) * ldw];
+            for (int t = 0; t < 4; ++t) wa[t][ks] = ldg_c<COH>(wn + (16 * t + l15) + (int64_t)(4 * (KS * h + ks) + l4) * ldw);
         #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const double lop = acc[(KS * h + ks) >> 2][(KS * h + ks) & 3];

@@ -8,6 +8,7 @@
 #include "kernels_assemble.hpp"
 #include "kernels_factor.hpp"
 #include "kernels_panel.hpp"
+#include "kernels_chain.hpp"
 #include "kernels_solve.hpp"
 #include "kernels_batched.hpp"
 #include "kernels_merit.hpp"
@@ -583,6 +584,34 @@ int ensure_rest_stream(Ctx* ctx) {
 int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, int nT, int ta, int tb, double* Wg, double* Dv, double* Ts) {
     const Geo& g = ctx->g;
     if (tb <= ta) return 0;
+    const bool exposed = ctx->per_panel_mode || gc0 == 0 || g.Npad - gc0 <= ctx->tile8_rows;   // (where the chain is what the step waits for)
+    if (ctx->tile_chain && tb - ta >= 2 && nT <= 32 && (ctx->tile_chain >= 2 || exposed)) {
+        // the steps [ta, tb) as ONE launch of persistent workgroups (kernels_chain.hpp): no launch boundary between two tiles
+        if (!ctx->chain_sync) {
+            PYIPM_HIP(hipMalloc((void**)&ctx->chain_sync, (size_t)(Ctx::CHAIN_SLOTS * Ctx::CHAIN_WORDS + 1) * sizeof(unsigned)));
+            PYIPM_HIP(hipMemset(ctx->chain_sync, 0, (size_t)(Ctx::CHAIN_SLOTS * Ctx::CHAIN_WORDS + 1) * sizeof(unsigned)));
+            ctx->chain_epoch = 0;
+        }
+        if (ctx->chain_epoch >= (1u << 24)) {            // the words' epochs must stay ordered: start over (every 16 M launches)
+            PYIPM_HIP(hipDeviceSynchronize());
+            PYIPM_HIP(hipMemset(ctx->chain_sync, 0, (size_t)(Ctx::CHAIN_SLOTS * Ctx::CHAIN_WORDS) * sizeof(unsigned)));
+            ctx->chain_epoch = 0;
+        }
+        ChainGeo cg;
+        cg.ta = ta; cg.tb = tb; cg.nT = nT; cg.cpy = ctx->chain_cpy > 0 ? ctx->chain_cpy : 5;
+        ctx->chain_epoch += 1;
+        cg.base = ctx->chain_epoch * 64u;
+        cg.sync = ctx->chain_sync + (size_t)(ctx->chain_epoch % Ctx::CHAIN_SLOTS) * Ctx::CHAIN_WORDS;
+        cg.err = ctx->chain_sync + (size_t)Ctx::CHAIN_SLOTS * Ctx::CHAIN_WORDS;
+        cg.timeout = (unsigned long long)2.0e8;          // 2 s (100 MHz clock)
+        const unsigned nblk = 1u + (unsigned)chain_units(ta, nT, cg.cpy);
+        hipLaunchKernelGGL(k_tile_chain, dim3(nblk), dim3(256), 0, chain, ctx->A, g.Npad, gc0, glc0, Wg, g.Npad, Dv, Ts,
+                           ctx->Tflag + gc0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats, g.N, ctx->pivtol_rel, ctx->anorm,
+                           g.n + g.mi, ctx->tile_blocked, cg);
+        PYIPM_KCHECK();
+        ctx->chain_used = true;
+        return 0;
+    }
     for (int j = ta; j < tb; ++j) {
         int ny = (nT - j + 4) / 5; if (ny < 1) ny = 1; if (ny > 4) ny = 4;     // <= ~5 column tiles per block
         // the critical block on eight waves (chain + helpers) where a whole CU is to be had: a 512-thread block owns the
@@ -1030,7 +1059,19 @@ int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
     int sweep_err = 0;
     if (ctx->sweep_used && ctx->sweep_sync)
         PYIPM_HIP(hipMemcpyAsync(&sweep_err, ctx->sweep_sync + 3 * 4096, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    int chain_err = 0;
+    unsigned* const chain_errw = ctx->chain_sync ? ctx->chain_sync + (size_t)Ctx::CHAIN_SLOTS * Ctx::CHAIN_WORDS : nullptr;
+    if (ctx->chain_used && chain_errw)
+        PYIPM_HIP(hipMemcpyAsync(&chain_err, chain_errw, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->chain_used = false;
+    if (chain_err) {
+        PYIPM_HIP(hipMemsetAsync(chain_errw, 0, sizeof(unsigned), ctx->stream));
+        ctx->zeros_clean = false;
+        ctx->err = "tile chain (k_tile_chain): a poll timed out -- a workgroup of the chain did not become resident; this factorisation is invalid "
+                   "(set_option(\"tile_chain\", 0) runs one launch per tile)";
+        return PYIPM_E_HIP;
+    }
     if (wait_err) { ctx->err = "fused head: the next group's chain gave up waiting for the bulk update's head tiles"; return PYIPM_E_HIP; }
     if (sweep_err) {
         PYIPM_HIP(hipMemsetAsync(ctx->sweep_sync + 3 * 4096, 0, sizeof(unsigned), ctx->stream));
@@ -1474,6 +1515,7 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
     const Geo& g = ctx->g;
     if (ctx->provider_only) { ctx->err = "a provider-only handle has no KKT storage: block products and residuals only"; return PYIPM_E_BADARG; }
     if (!ctx->have_blocks || !ctx->have_vectors) { ctx->err = "assemble: stage blocks and vectors first"; return PYIPM_E_BADARG; }
+    if (delta != ctx->delta || delta_c != ctx->delta_c) ctx->rc_warm_valid[0] = ctx->rc_warm_valid[1] = false;   // (a shifted matrix: the condition estimate starts cold)
     ctx->delta = delta; ctx->delta_c = delta_c;
     if (ctx->condensed && g.mi > 0 && g.world > 1 && ctx->sharded) {
         ctx->err = "condensed option across ranks needs the full blocks on every rank (stage_blocks, not stage_blocks_owned): "
@@ -2233,6 +2275,7 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     if (ctx->cond_pos && !ctx->batched) hipFree(ctx->cond_pos);      // (a batched handle's lives in its workspace)
     if (ctx->head_counters) hipFree(ctx->head_counters);
     if (ctx->sweep_sync) hipFree(ctx->sweep_sync);
+    if (ctx->chain_sync) hipFree(ctx->chain_sync);
     if (ctx->sweep_buf) hipFree(ctx->sweep_buf);
     if (ctx->merit_buf) hipFree(ctx->merit_buf);
     if (ctx->rc_warm[0]) hipFree(ctx->rc_warm[0]);
@@ -2504,17 +2547,23 @@ int pyipm_newton_rcond(pyipm_newton_ctx* h, int it_inv, int it_pow, double out[4
     for (int phase = 0; phase < 2; ++phase) {
         const bool adaptive_phase = phase == 0 ? adaptive_pow : adaptive_inv;
         const bool warm = warm_ok && adaptive_phase && ctx->rc_warm[0] && ctx->rc_warm_valid[phase];
-        if (warm) PYIPM_HIP(hipMemcpyAsync(wb, ctx->rc_warm[phase], g.Npad * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        else {
-            hipLaunchKernelGGL(k_hash_vector, grid1(g.Npad), dim3(256), 0, ctx->stream, wb, g.N, g.Npad, (unsigned long long)(17 + phase));
-            PYIPM_KCHECK();
-        }
+        // The start vector is hashed; a warm start ADDS the stored iterate to it, both normalised: the stored vector
+        // has been through inverse (power) iterations on every earlier call, so along a direction that has only just become
+        // (nearly) singular -- or a Sigma entry that has only just become dominant -- it holds rounding noise, and the stopping
+        // rules below (two estimates agree; the pessimistic bound from the start vector's ~1/sqrt(N) component along every
+        // eigenvector) would read the OLD extreme eigenvalue off it.  The hashed half keeps that component for every direction.
+        hipLaunchKernelGGL(k_hash_vector, grid1(g.Npad), dim3(256), 0, ctx->stream, wb, g.N, g.Npad, (unsigned long long)(17 + phase));
+        PYIPM_KCHECK();
         double nrm = 0.0, est = 0.0, prev_est = 0.0;
         int rc = norm_of(wb, &nrm); if (rc) return rc;
-        if (warm && (!(nrm > 0.0) || !(nrm <= 1.0e300))) {              // (a stored vector that went bad: start over)
-            hipLaunchKernelGGL(k_hash_vector, grid1(g.Npad), dim3(256), 0, ctx->stream, wb, g.N, g.Npad, (unsigned long long)(17 + phase));
-            PYIPM_KCHECK();
-            rc = norm_of(wb, &nrm); if (rc) return rc;
+        if (warm && nrm > 0.0) {
+            double wn = 0.0;
+            rc = norm_of(ctx->rc_warm[phase], &wn); if (rc) return rc;
+            if (wn > 0.0 && wn <= 1.0e300) {                             // (a stored vector that went bad is ignored)
+                hipLaunchKernelGGL(k_axpby, grid1(g.Npad), dim3(256), 0, ctx->stream, wb, wb, ctx->rc_warm[phase], 1.0 / nrm, 1.0 / wn, g.Npad);
+                PYIPM_KCHECK();
+                rc = norm_of(wb, &nrm); if (rc) return rc;
+            }
         }
         const int its = phase == 0 ? it_pow : it_inv;
         for (int it = 0; it < its; ++it) {
@@ -3009,7 +3058,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
             "head_on_side", "head_serial", "head_split", "head_split_rows", "fast_on_main", "rest_prio", "s_fast", "bwd_diag4",
             "head_waves", "inpanel32", "fuse_scale_update", "pending32_rows", "head32_rows", "head32_rows_dist", "early_head",
             "bulk_bn_rows", "bulk_bn_all", "bulk_bn_min_k", "sweep_max_blocks", "asm_tri", "asm_split", "fused_head",
-            "fused_head_rows", "dist_head_split", "tile_waves", "tile_upb", "tile8_rows", "tile_ny3", "tile_free_cus", "tile8_dist", "bc_per_problem", "s_early", "early_first", "s_across", "debug_fault", "debug_timeline_ptr"};
+            "fused_head_rows", "dist_head_split", "tile_waves", "tile_upb", "tile8_rows", "tile_ny3", "tile_free_cus", "tile8_dist", "chain_cpy", "bc_per_problem", "s_early", "early_first", "s_across", "debug_fault", "debug_timeline_ptr"};
         bool is_expert = false;
         for (const char* e : kExpert) if (!strcmp(name, e)) { is_expert = true; break; }
         if (is_expert && !ctx->expert) {
@@ -3032,6 +3081,8 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "bulk_bn_min_k")) { ctx->bulk_bn_min_k = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "tile_blocked")) { ctx->tile_blocked = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile_waves")) { ctx->tile_waves = (int)value == 8 ? 8 : 4; return PYIPM_OK; }
+    if (!strcmp(name, "tile_chain")) { int v = (int)value; ctx->tile_chain = v < 0 ? 0 : (v > 2 ? 2 : v); return PYIPM_OK; }
+    if (!strcmp(name, "chain_cpy")) { int v = (int)value; ctx->chain_cpy = v < 1 ? 1 : (v > 32 ? 32 : v); return PYIPM_OK; }
     if (!strcmp(name, "tile8_rows")) { ctx->tile8_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "tile_ny3")) { ctx->tile_ny3 = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile_free_cus")) { ctx->tile_free_cus = (int)value; return PYIPM_OK; }

@@ -40,6 +40,17 @@ struct BlockedScratch {
 
 #define PYIPM_BK_INV_ALPHA 1.5615528128088303   /* 8 / (1 + sqrt(17)) */
 
+// The thread index through an opaque move.  Inside the loop of a persistent kernel (k_tile_chain, kernels_chain.hpp) the
+// ~100 lane constants of a tile inversion would otherwise be hoisted out of the loop and spill (round 3's k_tile_chain: 154
+// spilled VGPRs); behind this nothing derived from the index is loop-invariant, so each tile recomputes them as each launch
+// of k_tile_step does.
+template <bool LOOPED>
+__device__ __forceinline__ int tile_tid() {
+    int t = (int)threadIdx.x;
+    if constexpr (LOOPED) asm volatile("" : "+v"(t));
+    return t;
+}
+
 // v_rcp_f64 and two Newton steps, exactly as microblock_asm.inc computes 1/d (and as pivot_recip in kernels_factor.hpp)
 __device__ __forceinline__ double blocked_recip(double d) {
     double r = __builtin_amdgcn_rcp(d);
@@ -59,7 +70,7 @@ struct BlockedLane {
 };
 
 // One block sweep, micro-block KB (compile time).  Returns false (uniform) when the block was NOT committed.
-template <int KB, int STRIDE>
+template <int KB, int STRIDE, bool LOOPED = false>
 __device__ __forceinline__ bool tile_blocked_block(double (&stage)[TB][STRIDE], BlockedScratch& bs, double* __restrict__ dsave,
                                                    const BlockedLane& L, unsigned long long* __restrict__ dbg)
 {
@@ -68,7 +79,7 @@ __device__ __forceinline__ bool tile_blocked_block(double (&stage)[TB][STRIDE], 
 #define PYIPM_TB_ST(off_) (*reinterpret_cast<double*>(sb + (off_)))
     constexpr int k0 = 16 * KB;
     constexpr int D8 = (int)sizeof(double), S8 = STRIDE * D8;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = tile_tid<LOOPED>(), lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i15 = lane & 15, q = lane >> 4;
     const int t = wave;                                // this wave's 16-row tile
@@ -212,12 +223,13 @@ __device__ __forceinline__ bool tile_blocked_block(double (&stage)[TB][STRIDE], 
 // stage: the working matrix, lower triangle valid (entries [i][j], i >= j).  256 threads; everyone has passed a barrier
 // after the last write to stage / bs.ptol / bs.fail = 0.  Returns the number of micro-blocks swept (0..4); on return
 // everyone has passed a barrier after the last write.  dsave[p] = pivot p as used.
-template <int STRIDE>
+template <int STRIDE, bool LOOPED = false>
 __device__ __forceinline__ int tile_blocked_sweep(double (&stage)[TB][STRIDE], BlockedScratch& bs, double* __restrict__ dsave,
                                                   unsigned long long* __restrict__ dbg = nullptr)    // diagnostics: dbg[8 + 32 kb + 8 wave + phase] = clock
 {
-    const int lane = threadIdx.x & 63, i15 = lane & 15, q = lane >> 4;
-    const int t = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid_ = tile_tid<LOOPED>();
+    const int lane = tid_ & 63, i15 = lane & 15, q = lane >> 4;
+    const int t = __builtin_amdgcn_readfirstlane(tid_ >> 6);
     constexpr int D8 = (int)sizeof(double), S8 = STRIDE * D8;
     BlockedLane L;
     #pragma unroll
@@ -229,10 +241,10 @@ __device__ __forceinline__ int tile_blocked_sweep(double (&stage)[TB][STRIDE], B
         const int c = 4 * s + q;
         L.mlt[s] = c < i15 ? 1.0 : 0.0;  L.mgt[s] = c > i15 ? 1.0 : 0.0;  L.meq[s] = c == i15 ? 1.0 : 0.0;
     }
-    if (!tile_blocked_block<0>(stage, bs, dsave, L, dbg)) return 0;
-    if (!tile_blocked_block<1>(stage, bs, dsave, L, dbg)) return 1;
-    if (!tile_blocked_block<2>(stage, bs, dsave, L, dbg)) return 2;
-    if (!tile_blocked_block<3>(stage, bs, dsave, L, dbg)) return 3;
+    if (!tile_blocked_block<0, STRIDE, LOOPED>(stage, bs, dsave, L, dbg)) return 0;
+    if (!tile_blocked_block<1, STRIDE, LOOPED>(stage, bs, dsave, L, dbg)) return 1;
+    if (!tile_blocked_block<2, STRIDE, LOOPED>(stage, bs, dsave, L, dbg)) return 2;
+    if (!tile_blocked_block<3, STRIDE, LOOPED>(stage, bs, dsave, L, dbg)) return 3;
     return 4;
 }
 

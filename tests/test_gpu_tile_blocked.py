@@ -137,3 +137,83 @@ def test_eight_wave_tile_step_gives_the_bits_of_the_four_wave_one(shape):
         assert {k: sa[k] for k in sa if not k.endswith("_ms")} == {k: sb[k] for k in sb if not k.endswith("_ms")}, (shape, a, b)
     st = out["w4"][2]
     assert st["n_neg"] == me + mi and st["nonfinite"] == 0, (shape, st)
+
+
+@pytest.mark.parametrize("shape", [(700, 100, 200, 1, 5.0), (1100, 0, 300, 2, 9.0), (520, 130, 0, 3, 3.0), (2100, 300, 500, 4, 6.0),
+                                   (2048, 0, 2048, 5, 0.0), (4100, 1000, 700, 6, 4.0)])
+def test_tile_chain_in_one_launch_gives_the_bits_of_the_launch_per_tile(shape):
+    """k_tile_chain (csrc/kernels_chain.hpp, round 6): the tile steps of a diagonal block as ONE launch of persistent
+    workgroups -- the chain workgroup and units that own row tiles, handing inv(T), W and the diagonal tiles over through
+    written-through stores and one progress word per workgroup -- against one launch per tile (k_tile_step, four and eight
+    waves).  Graded systems: refined block solves, micro-blocks that fail the Bunch-Kaufman check in the middle of a tile
+    (single sweeps, 2 x 2 pivots), several groups, ragged last panels; units per row tile 1 .. 4 (chain_cpy).  Factor storage,
+    statistics and direction are bit for bit the same; three steps in a row per handle (the words' epochs), in the single-rank
+    schedule and in the per-panel one (factor_panel: a chain of 4 tiles per panel).  Replaces the LAPACK factorisation
+    reached from pyipm.py:18-20, 1720-1721."""
+    import torch
+    from pyipm_amd.newton import NewtonCore
+    n, me, mi, seed, decades = shape
+    qp = _graded_qp(n, me, mi, seed, decades)
+    out = {}
+    for key, opts in (("steps4", {"tile_chain": 0, "tile_waves": 4}),
+                      ("steps8", {"tile_chain": 0, "tile_waves": 8}),
+                      ("chain", {"tile_chain": 2}),
+                      ("chain_exposed", {"tile_chain": 1}),
+                      ("chain_cpy2", {"tile_chain": 2, "chain_cpy": 2}),
+                      ("chain_cpy9", {"tile_chain": 2, "chain_cpy": 9}),
+                      ("chain_group2", {"tile_chain": 2, "group": 2, "tail_group": 2}),
+                      ("steps_single", {"tile_chain": 0, "tile_waves": 4, "tile_blocked": 0}),
+                      ("chain_single", {"tile_chain": 2, "tile_blocked": 0})):
+        core = NewtonCore(n, me, mi, device=0)
+        core.set_option("expert", 1)
+        core.set_option("sweep_persist", 0)
+        for k, v in opts.items():
+            core.set_option(k, v)
+        core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+        core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+        for rep in range(3):
+            dz, st = core.step(0.0, 0.0)
+            fac = core.kkt_storage().clone().view(torch.int64)
+            if key not in out:
+                out[key] = (dz.clone(), fac, st)
+            assert torch.equal(dz, out[key][0]) and torch.equal(fac, out[key][1]), (shape, key, rep)
+        core.close()
+    for a, b in (("steps4", "steps8"), ("steps4", "chain"), ("steps4", "chain_exposed"), ("steps4", "chain_cpy2"), ("steps4", "chain_cpy9"),
+                 ("steps4", "chain_group2"), ("steps_single", "chain_single")):
+        assert torch.equal(out[a][1], out[b][1]), (shape, a, b, "factor storage")
+        assert torch.equal(out[a][0], out[b][0]), (shape, a, b, "direction")
+        sa, sb = out[a][2], out[b][2]
+        assert {k: sa[k] for k in sa if not k.endswith("_ms")} == {k: sb[k] for k in sb if not k.endswith("_ms")}, (shape, a, b)
+    st = out["steps4"][2]
+    assert st["n_neg"] == me + mi and st["nonfinite"] == 0, (shape, st)
+
+
+def test_tile_chain_in_the_per_panel_schedule():
+    """The per-panel (multi-GPU) schedule on one rank: a chain of nb / 64 tiles per panel as one launch, nb = 256 and the wide
+    panels of nb = 1024 (factor_wide_panel), against the launch-per-tile form."""
+    import torch
+    from pyipm_amd.newton import NewtonCore
+    n, me, mi = 1500, 200, 400
+    qp = _graded_qp(n, me, mi, 11, 4.0)
+    for nb in (256, 1024):
+        out = {}
+        for key, opts in (("steps", {"tile_chain": 0}), ("chain", {"tile_chain": 1})):
+            core = NewtonCore(n, me, mi, device=0, nb=nb)
+            core.set_option("expert", 1)
+            core.set_option("sweep_persist", 0)
+            for k, v in opts.items():
+                core.set_option(k, v)
+            core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+            core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+            core.assemble(0.0, 0.0)
+            core.factor_begin()
+            for p in range(core.npanels):
+                core.factor_panel(p)
+                core.trailing_update(p)
+            st = core.factor_end()
+            fac = core.kkt_storage().clone().view(torch.int64)
+            out[key] = (fac, st)
+            core.close()
+        assert torch.equal(out["steps"][0], out["chain"][0]), nb
+        sa, sb = out["steps"][1], out["chain"][1]
+        assert {k: sa[k] for k in sa if not k.endswith("_ms")} == {k: sb[k] for k in sb if not k.endswith("_ms")}, nb
