@@ -382,16 +382,18 @@ int pyipm_newton_trailing_instances(pyipm_newton_ctx* h, double out[8]);
 /* The same launches' algorithmic bytes in both definitions: out[k] = C tiles only (16 B per updated entry), out[2 + k] = C tiles +
  * the two operand panels read once; k = 0: 128 x 128 tiles, k = 1: 128 x 256. */
 int pyipm_newton_trailing_bytes(pyipm_newton_ctx* ctx, double out[4]);
-/* Options.  Every one defaults to the measured-best setting; the public ones (25 names) choose numerics, forms of the
- * system and the few schedule parameters a deployment may have to adapt; everything else is an EXPERT switch (measurement
- * knobs, test hooks and parked experiments whose measurements are in HISTORY.md) and is refused unless the process has
- * PYIPM_EXPERT=1 in its environment or the handle was given set_option("expert", 1) -- so that nothing outside the tests
- * and tools/ runs a path nobody else runs.  tests/test_gpu_symmetric.py checks both lists against the library and runs the
- * bitwise-neutrality sweep over every schedule option in them.
+/* Options.  Every one defaults to the measured-best setting; the public ones (28 names) choose numerics, forms of the
+ * system and the few schedule parameters a deployment may have to adapt; the 12 EXPERT switches (test hooks, diagnostics
+ * and the reference forms the bit-identity tests compare against) are refused unless the process has PYIPM_EXPERT=1 in
+ * its environment or the handle was given set_option("expert", 1) -- so that nothing outside the tests and tools/ runs a
+ * path nobody else runs.  Round 6 removed the 35 switches whose measurements HISTORY.md records as lost or neutral (with
+ * the code paths behind the ones that lost): 40 names in all.  tests/test_gpu_symmetric.py checks both lists against the
+ * library and runs the bitwise-neutrality sweep over every schedule option in them.
  *
  * PUBLIC OPTIONS: expert, condensed, condensed_sigma_max, condensed_refine, block_refine, refine_cond, refine_target,
  *   refine_max, pivtol_rel, tile_blocked, profile, skip_zeros, keep_zeros, fuse_forward, sweep_persist, lookahead, group,
- *   bulk_bn, reserve_cus, persist_rows, wide_sub, dist_sag, dist_sag_min_bytes, dist_slices, dist_selfmsg
+ *   bulk_bn, reserve_cus, persist_rows, tile_chain, wide_sub, dist_sag, dist_sag_min_bytes, dist_slices, dist_comm2,
+ *   dist_timeout_s, dist_selfmsg
  *
  *   "expert" 0|1        unlock the expert switches on this handle.
  *   "condensed" 0|1     handles with mi > 0: assemble / factor / solve work on the condensed system
@@ -407,10 +409,10 @@ int pyipm_newton_trailing_bytes(pyipm_newton_ctx* ctx, double out[4]);
  *   "refine_target" (1e-14) / "refine_max" (8): adaptive refinement of solve(refine < 0): stop at this backward error or
  *                       after this many steps.
  *   "pivtol_rel" (1e-14): a pivot below this fraction of its tile column's magnitude has cancelled: static pivot.
- *   "tile_blocked" 0|1  (1; batched handles: 0 with the full form, 1 with the condensed one): the 64 x 64 tile inversion 16
- *                       pivots at a time (in-register LDL' of the micro-block + fp64 MFMA block sweeps, Bunch-Kaufman
- *                       verified afterwards, fallback to the single sweeps) -- same pivots and inertia, another order of
- *                       rounding than the single sweeps (not bit-identical).
+ *   "tile_blocked" 0|1  (1; batched handles: 0 with the full form, 1 with the condensed one, until set explicitly): the 64 x 64
+ *                       tile inversion 16 pivots at a time (in-register LDL' of the micro-block + fp64 MFMA block sweeps,
+ *                       Bunch-Kaufman verified afterwards, fallback to the single sweeps) -- same pivots and inertia, another
+ *                       order of rounding than the single sweeps (not bit-identical).
  *   "profile" 0|1       HIP-event timings (last_timings, trailing_instances, dist_timings, provider_stats).
  *   "skip_zeros" 0|1    (1) products with blocks that pyipm.py:824-842 makes identically zero are not formed; bitwise-neutral.
  *   "keep_zeros" 0|1    (1) K1 leaves in place the zeros nothing can fill in; single rank; bitwise-neutral.
@@ -427,28 +429,50 @@ int pyipm_newton_trailing_bytes(pyipm_newton_ctx* ctx, double out[4]);
  *   "bulk_bn" 256|128   (256) column width of a bulk update tile; "reserve_cus" (16) / "persist_rows" (12288): in the
  *                       chain-bound phase (at most persist_rows rows left) the bulk update runs as a persistent launch
  *                       that leaves reserve_cus CUs to the panel chain; 0 = ordinary launches.  Bitwise-neutral.
+ *   "tile_chain" 0|1|2  (1; round 6) the 64 x 64 tile steps of a diagonal block as ONE launch of persistent workgroups
+ *                       (k_tile_chain: the chain workgroup + units that own row tiles; hand-overs through written-through
+ *                       stores and progress words, every poll with a 2 s timeout that factor() reports as PYIPM_E_HIP)
+ *                       instead of one launch per tile: 1 where the chain is what the step waits for (first group, last
+ *                       12288 rows, the per-panel / multi-GPU schedule), 2 everywhere, 0 never.  Same condition on residency
+ *                       as sweep_persist.  Bit-identical to the launches.
  *   "wide_sub" (256)    per-panel / multi-GPU schedule: a panel wider than this is factored by its owner as a block of
  *                       sub-panels this wide (the launches, and the bits, of the single-rank schedule at nb = 256).
- *   "dist_sag" 0        COLLECTIVE: keep the plain broadcast for the panel messages (see pyipm_newton_comm_bcast_mode);
- *                       "dist_sag_min_bytes" (4 MiB): smaller messages always take the plain broadcast.
+ *   "dist_sag" 0|1      COLLECTIVE: 0 keeps the plain broadcast for the panel messages, 1 goes back to what the exchange
+ *                       self-test decided (see pyipm_newton_comm_bcast_mode); "dist_sag_min_bytes" (4 MiB): smaller messages
+ *                       always take the plain broadcast.
  *   "dist_slices" 0|1   (1) COLLECTIVE: the two-message protocol of the distributed factorisation -- the rows of panel p
  *                       that meet the diagonal block of panel p + 1 (and the rows of panel p + 2) go from owner(p) to
  *                       owner(p + 1) point to point AHEAD of the panel message, so the next owner's tile chain starts on an
  *                       nb x nb message; 0: one message per panel (rounds 1-4).  Bit-identical either way.
+ *   "dist_comm2" 0|1    (0) COLLECTIVE, RCCL transport: the slice messages on a SECOND communicator over the same ranks, on
+ *                       the owner's stream, so that they do not queue behind a panel broadcast in flight.  Setting it (before
+ *                       or after comm_init) creates the communicator -- every rank must make the call; the ranks agree before
+ *                       anyone enters ncclCommInitRank.  Off by default: two communicators in flight on one device have not
+ *                       run on more than one GPU yet; bench.py's ladder tries it last.  Bit-identical.
+ *   "dist_timeout_s"    (300) bound on the host's wait for the device at the end of a distributed factorisation; on expiry
+ *                       PYIPM_E_COMM names the panel whose message / update / chain did not complete and the handle refuses
+ *                       further distributed steps (destroy aborts its communicators).  <= 0: wait for ever.
  *   "dist_selfmsg" 0|1  world == 1 only: the distributed driver packs and "sends" every panel anyway (measures the
  *                       message path on one GPU).
  *
- * EXPERT OPTIONS: tail_group, tail_cols, xcd_swizzle, side_prio, bulk_waves, group_chain, pending_left_rows, tile_step,
- *   head_on_side, head_serial, head_split, head_split_rows, fast_on_main, rest_prio, s_fast, bwd_diag4, head_waves,
- *   inpanel32, fuse_scale_update, pending32_rows, head32_rows, head32_rows_dist, early_head, bulk_bn_rows, bulk_bn_all,
- *   bulk_bn_min_k, sweep_max_blocks, asm_tri, asm_split, fused_head, fused_head_rows, dist_head_split, tile_waves, tile_upb,
- *   tile8_rows, tile_ny3, tile_free_cus, tile8_dist, bc_per_problem, s_early, early_first, s_across,
- *   debug_fault, debug_timeline_ptr
- *   (which stream runs what, in how many launches, which kernel instance takes which row counts -- all of them but one choose
- *   between implementations that accumulate the same products in the same order: bit-identical results,
- *   tests/test_gpu_symmetric.py; the one: bwd_diag4 = 0 sums the in-panel backward substitution in another order, 1e-16;
- *   what each one is and what it measured: the comments in csrc/ctx.hpp and HISTORY.md.) */
+ * EXPERT OPTIONS: tail_group, group_chain, tile_step, tile_waves, bc_per_problem, chain_cpy, chain_whole, chain_lds_kb,
+ *   sweep_max_blocks, debug_fault, debug_timeline_ptr, debug_chain_ptr
+ *   (which stream runs what, in how many launches: tail_group = panels per group once at most 24576 columns remain (4);
+ *   group_chain 0 = a group's panels one after the other instead of one tile chain; tile_step 0 = the two-launches-per-tile
+ *   schedule of round 1; tile_waves 4|8|9 = the launch-per-tile kernel on four waves, on eight where a whole CU is to be had,
+ *   on eight everywhere; bc_per_problem 0 = the batched condensed form's Gram part by one workgroup per tile; chain_cpy / chain_whole /
+ *   chain_lds_kb = units per row tile, one launch per group or per sub-panel, and the shared-memory pad that gives a workgroup
+ *   of k_tile_chain its compute unit to itself; sweep_max_blocks, debug_* = test hooks and diagnostics buffers.  All of them
+ *   choose between implementations that accumulate the same products in the same order: bit-identical results,
+ *   tests/test_gpu_symmetric.py, tests/test_gpu_tile_blocked.py.) */
 int pyipm_newton_set_option(pyipm_newton_ctx* ctx, const char* name, double value);
+
+/* Version of this interface: bumped whenever an entry point changes its argument list (round 5 added `dz` to
+ * pyipm_newton_step_lengths in place: a caller built against the older header would have passed a host pointer where the
+ * device direction goes).  A binding checks pyipm_newton_abi_version() == PYIPM_NEWTON_ABI_VERSION of the header it was
+ * written against before any other call (pyipm_amd/newton.py does). */
+#define PYIPM_NEWTON_ABI_VERSION 6
+int pyipm_newton_abi_version(void);
 
 /* fp64 MFMA peak micro-benchmark: register-resident v_mfma_f64_16x16x4_f64 only.
  * Returns achieved TFLOP/s in *tflops. */

@@ -70,6 +70,19 @@ struct DevStats {          // lives in device memory; tile kernels of one rank r
     unsigned long long growth_bits;   // bit pattern of max |L| (monotone for non-negative doubles)
 };
 
+// One launch of k_tile_chain (kernels_chain.hpp)
+struct ChainGeo {
+    int ta, tb, nT;          // steps [ta, tb) of a diagonal block of nT tiles
+    int cpy;                 // column tiles per unit and stage a row tile is split for (5: k_tile_step's rule)
+    unsigned base;           // epoch of the progress words: word - base = progress of THIS launch (wrap-safe compare)
+    unsigned* sync;          // [0]: tiles inverted by the chain (base + t + 1 after tile t);  [1 + 4 r + y]: stages unit (r, y) completed
+    unsigned* err;           // sticky: a poll timed out
+    unsigned long long timeout;   // 100 MHz ticks
+    unsigned long long* dbg;      // diagnostics (NULL normally; tools/chain_clock.py): 100 MHz stamps, [8 t + k] of the chain's step t,
+                                  // [256 + 64 (4 r + y) + 2 tp + k] of unit (r, y)'s stage tp (CHAIN_DBG_WORDS per launch)
+};
+constexpr int CHAIN_DBG_WORDS = 256 + 64 * 4 * 32;
+
 struct Ctx {
     Geo g;
     int batch = 1;                        // problems of a batched small-system handle (kernels_batched.hpp)
@@ -81,7 +94,6 @@ struct Ctx {
     hipEvent_t ev_head = nullptr, ev_panel = nullptr, ev_fwd = nullptr;
     hipStream_t fwd = nullptr;            // fused forward-substitution stream
     std::vector<hipEvent_t> ev_done;      // panel q factored
-    std::vector<hipEvent_t> ev_early;     // panel (by offset in its group) factored: early head updates wait for it
     int fuse_forward = 1;
     bool forward_fused = false;
     bool forward_pending = false;         // factor() already forward-substituted the pending residual into v0
@@ -102,7 +114,6 @@ struct Ctx {
     std::vector<int64_t> grp_first;       // per group: first panel (+ one past the last group)
     int bulk_waves = 8;                   // waves per block of the BULK update tiles (8: 128 VGPRs each, 4 waves per SIMD;
                                           // 4: 241 VGPRs, 2 per SIMD: 1.5 % slower); the short side-stream launches keep 4
-    int inpanel32 = 1;                    // in-panel updates on 32-row blocks straight from global memory (k_inpanel_update)
     int fuse_su = 1;                      // ... fused into the previous tile's scaling launch (k_panel_scale + NextUpd): two
                                           // dependent launches per tile on the chain instead of three; same bits
     double* Wnext = nullptr;              // 64 x 64: -S of the next diagonal tile's rows (handed from the tile kernel to that launch)
@@ -111,33 +122,22 @@ struct Ctx {
     hipStream_t rest = nullptr;           // ... that stream (high priority, created on first use)
     std::vector<hipEvent_t> ev_band;      // panel (by offset in its group): its tiles are inverted and applied inside the diagonal block
     hipEvent_t ev_join = nullptr, ev_main = nullptr, ev_split = nullptr, ev_sfast = nullptr;
-    int head_split = 1;                   // the lookahead head in two launches: the target group's diagonal block on the chain's stream,
-                                          // the rows below it on ctx->rest (first read there)
     int head_waves = 4;                   // waves per block of a lookahead head launched on the chain's stream (4: k_update<128,true,4>,
                                           // its own line in a kernel trace; 8: the bulk instance)
     int64_t pending_left_rows = 12288;    // group chain: left-looking in-group updates of the rows below the diagonal block while more
                                           // rows than this remain below it (-1: never)
     int asm_tri = 1;                      // K1 launches only the patches on or below the diagonal (single rank, Npad a multiple of 512)
-    int asm_split = 0;                    // K1 as two launches, the first group's columns first: that group's chain starts beside the second (round 4;
-                                          // measured 0 ... -0.3 ms at N = 32768 -- the chain is stretched by the HBM-saturating second launch --: an option, off)
-    int64_t asm_split_cols = 0;           // ... columns of the first launch of the last assembly (0: one launch); consumed by factor_all
-    hipEvent_t ev_asm = nullptr;          // ... recorded behind the first launch
     int keep_zeros = 1;                   // K1 does not store again the zeros nothing can fill in (k_assemble, zeros_in_place)
     bool zeros_clean = false;             // ... which requires that the last writer of those places was a full assembly
     bool storage_exported = false;        // kkt_storage() handed the pointer out: a holder may write into those zeros at any time,
                                           // so every assembly is a full one until set_option("keep_zeros") is called again
     int rest_prio = 1;                    // ctx->rest is a high-priority stream (set before the first factorisation)
     int fast_on_main = 1;                 // groups inside the slack block (closed form) run on the main stream, not through the lookahead
-    int head_serial = 0;                  // ... and the bulk update of the group waits for it (instead of running beside it): 0 never,
-                                          // 1 always, 2 in the chain-bound phase only (at most persist_rows rows left); measured r03: 107.3 / 107.6 ms for 2 / 0 -- noise
     int head_on_side = 1;                 // the lookahead head runs on the stream of the chain it follows (no stream crossing between
                                           // a group's chain, the head and the next chain); ordered against the main stream by an event
     int bwd_diag4 = 1;                    // in-panel backward substitution on 1024 threads through shared memory (k_bwd_diag4)
     int tile_step = 1;                    // stepped panel schedule (kernels_panel.hpp): one launch per diagonal tile (the rows inside the
                                           // diagonal block), one for the rows below it; panels of at most 4 tiles; same bits
-    int early_head = 0;                   // tail regime: a group's panels except the last update the next group's columns as soon
-                                          // as each is factored (beside the chain), so only the last panel's K = nb is left between two chains.
-                                          // Off since the head became two launches (head_split): it then costs 1 % (108.2 vs 109.4 ms)
     int64_t head32_rows = 6144;           // ... and the lookahead HEAD update (next group's columns, on the critical path between two
                                           // groups' chains: one 128x128 tile at K = 512 takes 132 us however few tiles there are)
     bool per_panel_mode = false;          // the per-panel phases (pyipm_newton_factor_begin ...) drive this factorisation
@@ -147,8 +147,6 @@ struct Ctx {
                                           // next group's chain is no longer hidden behind the bulk launch, and beside the wide tiles (one
                                           // block per CU, every register) its kernels wait twice as long for a slot -- exposed panel 6.0
                                           // instead of 5.3 ms with the threshold at persist_rows, the step 0.8 % slower
-    int bulk_bn_all = 0;                  // bulk_bn = 256 also in the chain-bound phase (m <= persist_rows), where the default keeps the
-                                          // persistent 128 x 128 launches that leave CUs to the panel chain
     int sweep_max_blocks = 0;             // test hook: cap on the workgroups of the one-launch sweeps (0 = as many as the GPU holds)
     int occ_fwd_sweep = 0, occ_bwd_sweep = 0;   // resident workgroups per CU of the one-launch sweeps (occupancy query, cached)
     int sweep_persist = 1;                // single rank, one right-hand side: the backward sweep as ONE device-driven launch (k_bwd_sweep)
@@ -160,17 +158,12 @@ struct Ctx {
                                           // that alone), then the rows below it on ctx->rest (round 4)
     int dist_slices = 1;                  // distributed schedule: the two-message protocol (slices ahead of the panel message: the next owner's tile
                                           // chain starts on an nb x nb message); 0 = one message per panel (rounds 1-4); collective
+    double dist_timeout_s = 300.0;        // distributed step: bound on the host's wait for the device (dist_impl.hpp:bounded_wait); <= 0: none
+    int dist_comm2 = 0;                   // RCCL transport: the slice messages on a second communicator of their own (set before comm_init; dist_impl.hpp:comm2_setup)
     int wide_sub = 256;                   // per-panel schedule: a panel wider than this is factored as a block of sub-panels this wide
                                           // (factor_wide_panel: the single-rank group chain inside one panel); 0 = all stages in one launch
     int64_t pending32_rows = 24576;       // ... and a panel's pending in-group update too while at most this many rows remain
                                           // (128x128 tiles keep one CU busy for 27 us per 256 columns of K, on the chain)
-    int64_t head_split_rows = 0;          // the head in two launches (head_split) while at most this many rows remain, whatever kernel
-                                          // the rows below the diagonal block then take (head32_rows decides that)
-    int fused_head = 0;                   // (measured r03: 106.55 vs 106.2 ms -- no gain, off) bulk-bound phase: the lookahead head is the first tiles of the bulk launch itself (they bump a
-                                          // device counter the next chain waits for) instead of a second MFMA kernel beside it
-    int64_t fused_head_rows = 0;          // ... only while more rows than this remain below the next group's first column
-    unsigned* head_counters = nullptr;    // one per group (device), zeroed by factor_begin; [n] = error flag of k_wait_counter
-    size_t n_head_counters = 0;
     int reserve_cus = 16;                 // chain-bound phases: bulk updates run as persistent launches that leave this many CUs
     int64_t persist_rows = 12288;         // free for the panel chain -- while at most this many rows remain (on one rank the per-panel schedule with it
     int num_cus = 256;                    // everywhere took 140 instead of 120 ms); 0 = ordinary launches everywhere.  num_cus: of this device
@@ -237,25 +230,29 @@ struct Ctx {
     int refine_max = 8;                   // ... or after this many steps, or when a step gains less than 4x
     // options
     double pivtol_rel = 1e-14;
+    bool tile_blocked_user = false;       // set_option("tile_blocked") was called: a batched handle's set_option("condensed") leaves it alone
     int tile_blocked = 1;                 // tile inversion 16 pivots at a time while Bunch-Kaufman would accept them in natural order
                                           // (tile_blocked.hpp); 0: the single sweeps of rounds 1-2 only
     int tile_waves = 8;                   // k_tile_step on 512 threads (round 5): the critical block = four chain waves + four helper waves
                                           // (diagonal tile prefetched beside the scaling product; the blocked inversion's updates and commits
                                           // beside the next elimination, tile_blocked8.hpp); 4: the 256-thread kernel of rounds 2-4.  Same bits.
-    int tile_chain = 0;                   // the tile steps of a diagonal block as ONE launch of persistent workgroups per piece (k_tile_chain,
+    int tile_chain = 1;                   // the tile steps of a diagonal block as ONE launch of persistent workgroups per piece (k_tile_chain,
                                           // kernels_chain.hpp; round 6): 1 where the chain is exposed (first group, at most tile8_rows rows left,
                                           // the per-panel / multi-GPU schedule), 2 everywhere, 0 one launch per tile.  Same bits.
+    int chain_whole = 1;                  // ... a group's (wide panel's) whole diagonal block as ONE launch: the rows below wait for the chain's
+                                          // progress words on their own stream (k_chain_wait); 0: one launch per sub-panel piece, events between
+    int chain_lds_kb = 100;               // ... KB of untouched dynamic shared memory per workgroup (keeps other workgroups off its CU)
+    bool chain_lds_set = false;
     int chain_cpy = 5;                    // ... column tiles per unit and stage a row tile is split for
     static constexpr int CHAIN_SLOTS = 8, CHAIN_WORDS = 160;
     unsigned* chain_sync = nullptr;       // ... progress words (CHAIN_SLOTS regions used round robin, epoch-stamped) + the sticky error word
     unsigned chain_epoch = 0;
+    ChainGeo chain_last = {};             // ... the last chain launch (factor_block hands it to k_chain_wait)
+    unsigned long long* chain_dbg = nullptr; int chain_dbg_launch = 0;   // diagnostics only (option debug_chain_ptr)
     bool chain_used = false;              // ... a chain launch ran since the error word was last read (factor_end)
     int64_t tile8_rows = 12288;           // ... used by the single-rank schedule for the first group and where at most this many rows are left
-    int tile_ny3 = 0;                     // ... its row-tile units with at most 3 (instead of 5) column tiles each
     int tile_free_cus = 64;               // ... CUs assumed free beside a persistent bulk launch (units per block: 1 while the launch fits)
     int bc_per_problem = 1;               // batched condensed form: the Gram part by one workgroup per problem where n = 64 .. 256 allows it
-    int early_first = 1;                  // early heads also for the first group and behind a slack-block group (chain-bound systems)
-    int s_across = 1;                     // ... and the group after the slack block is the lookahead target of the group before it
     int s_early = 1;                      // the slack block's closed-form panels enqueued up front on the rows stream (factor_all)
     int tile8_dist = 0;                   // ... also in the per-panel (multi-GPU) schedule
     int tile_upb = 0;                     // ... its other row tiles: (row tile, y) units per 512-thread block, 1 | 2; 0 = by the size of the launch
@@ -275,7 +272,8 @@ struct Ctx {
     hipEvent_t ev_prov[4] = {}; bool prov_valid[2] = {false, false}; double prov_bytes[2] = {0.0, 0.0};   // provider products
     bool ev_assemble_valid = false, ev_solve_valid = false;
     double setup_lists_ms = 0.0; int setup_lists_n = 0;     // host time spent building tile lists (one-time per geometry; PYIPM_SETUP_TRACE)
-    int debug_fault = 0;                  // test hook: 1 / 2 = the next tile-list build throws std::bad_alloc / std::runtime_error
+    int debug_fault = 0;                  // test hook: 1 / 2 = the next tile-list build throws std::bad_alloc / std::runtime_error;
+                                          // 3 = the message of the middle panel of the next distributed factorisation stalls (dist_impl.hpp)
     std::string err;
 };
 

@@ -19,6 +19,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;           // optional: tears down a communicator whose collectives are stuck
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
@@ -48,6 +49,7 @@ int rccl_load(std::string* err) {
     a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
     a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+    a.CommAbort = (decltype(a.CommAbort))dlsym(lib, "ncclCommAbort");
     a.CommCount = (decltype(a.CommCount))dlsym(lib, "ncclCommCount");
     a.Broadcast = (decltype(a.Broadcast))dlsym(lib, "ncclBroadcast");
     a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
@@ -75,6 +77,7 @@ struct DistState {
     pyipm_send_fn send = nullptr; pyipm_recv_fn recv = nullptr; pyipm_allgather_fn allgather = nullptr;
     int serialize = 0;                                 // callbacks: run every operation on the collective stream, one at a time (as for RCCL)
     ncclComm_t comm = nullptr;
+    bool use_comm2 = false;                            // ... in use (option dist_comm2; the communicator may exist and rest)
     ncclComm_t comm2 = nullptr;                        // a second communicator over the same ranks for the slice messages (point to point):
                                                        // they must not queue behind a panel broadcast in flight (one communicator = one stream).
                                                        // Its stream is the OWNER'S stream `side` -- a slice is received exactly where it is
@@ -98,6 +101,7 @@ struct DistState {
     double* small = nullptr;                           // 16 doubles: statistics reduction
     int selfmsg = 0;                                   // world == 1: pack + broadcast anyway (measures the message path on one GPU)
     int sag = 0;                                       // panel messages travel as scatter + all-gather (set by comm_init after its self-test)
+    int sag_ok = 0;                                    // ... what the last self-test decided (set_option("dist_sag", 1) goes back to it)
     size_t sag_min_bytes = (size_t)4 << 20;            // ... from this size on
     // profile (ms, last factor_dist / solve_dist): chain = owner's panel factorisations, pack, wait-for-message, unpack
     std::vector<hipEvent_t> pool; size_t used = 0;
@@ -110,7 +114,22 @@ struct DistState {
     // [5] all-gathers, [6] hops through the collective stream, [7] slice messages (two-message protocol) this rank sent or
     // received, [8] their bytes, [9] slice messages that travelled as a broadcast (no point-to-point transport)
     double wire[12] = {};
+    // Progress of the last factor_dist as the DEVICE saw it (round 6): pinned host words a one-thread kernel writes behind each
+    // panel message (collective stream), each bulk update (main stream) and each owned panel (owner's stream).  A collective a
+    // peer never joined does not return an error -- its stream just stops; the host waits for the step with a bound
+    // (set_option("dist_timeout_s")) and reports WHICH panel's message / update / chain did not complete (PYIPM_E_COMM) instead
+    // of blocking for ever.
+    unsigned* prog_host = nullptr; unsigned* prog_dev = nullptr;     // [0] panel messages, [1] bulk updates, [2] owned panels (count so far: index + 1)
+    hipEvent_t ev_all = nullptr;
+    bool broken = false;                               // a step timed out: the streams hold work that may never finish; only destroy is safe
 };
+
+__global__ __launch_bounds__(64) void k_mark(unsigned* p, unsigned v) { if (threadIdx.x == 0) *p = v; }
+// test hook (debug_fault = 3): what a collective that never completes looks like to the stream behind it, for `ticks` of the 100 MHz clock
+__global__ __launch_bounds__(64) void k_stall(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
 
 }  // namespace pyipm
 
@@ -148,6 +167,10 @@ int dist_state(Ctx* ctx, DistState** out) {
         DIST_HIP(hipMalloc((void**)&D->seg, (size_t)g.nb * sizeof(double)));
         DIST_HIP(hipMalloc((void**)&D->vloc, (size_t)g.Npad * sizeof(double)));
         DIST_HIP(hipMalloc((void**)&D->small, 16 * sizeof(double)));
+        DIST_HIP(hipHostMalloc((void**)&D->prog_host, 4 * sizeof(unsigned), hipHostMallocMapped));
+        DIST_HIP(hipHostGetDevicePointer((void**)&D->prog_dev, D->prog_host, 0));
+        for (int k = 0; k < 4; ++k) D->prog_host[k] = 0u;
+        DIST_HIP(hipEventCreateWithFlags(&D->ev_all, hipEventDisableTiming));
     }
     *out = D;
     return 0;
@@ -156,6 +179,12 @@ int dist_state(Ctx* ctx, DistState** out) {
 void dist_free(Ctx* ctx) {
     DistState* D = ctx->dist;
     if (!D) return;
+    if (D->broken && g_rccl.CommAbort) {                                 // (stuck collectives: abort them, or the synchronisations below never return)
+        if (D->comm2) { g_rccl.CommAbort(D->comm2); D->comm2 = nullptr; }
+        if (D->comm) { g_rccl.CommAbort(D->comm); D->comm = nullptr; }
+    }
+    if (D->prog_host) hipHostFree(D->prog_host);
+    if (D->ev_all) hipEventDestroy(D->ev_all);
     if (D->side) { hipStreamSynchronize(D->side); hipStreamDestroy(D->side); }
     if (D->cs) { hipStreamSynchronize(D->cs); hipStreamDestroy(D->cs); }
     if (D->fws) { hipStreamSynchronize(D->fws); hipStreamDestroy(D->fws); }
@@ -189,22 +218,33 @@ void dist_free(Ctx* ctx) {
     ctx->dist = nullptr;
 }
 
+int comm2_setup(Ctx* ctx, DistState* D);
 int dist_set_option(Ctx* ctx, const char* name, double value, bool* handled) {
     *handled = false;
-    if (!strcmp(name, "dist_sag")) {                    // -1: query is through dist_timings; 0 / 1: panel messages as scatter + all-gather
-        *handled = true;
-        DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
-        if ((int)value == 0) D->sag = 0;                // (switching it ON by hand is not offered: comm_init's self-test decides)
-        return PYIPM_OK;
-    }
     if (!strcmp(name, "dist_sag_min_bytes")) {          // panel messages of at least this size take the scatter + all-gather form
         *handled = true;
         DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
         D->sag_min_bytes = value > 0 ? (size_t)value : 0;
         return PYIPM_OK;
     }
-    if (!strcmp(name, "dist_head_split")) { *handled = true; ctx->dist_head_split = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "dist_timeout_s")) { *handled = true; ctx->dist_timeout_s = value; return PYIPM_OK; }
     if (!strcmp(name, "dist_slices")) { *handled = true; ctx->dist_slices = (int)value != 0; return PYIPM_OK; }     // COLLECTIVE, like dist_sag
+    if (!strcmp(name, "dist_comm2")) {                  // COLLECTIVE: the slice messages on a second communicator (comm2_setup below)
+        *handled = true;
+        ctx->dist_comm2 = (int)value != 0;
+        if (ctx->dist) {
+            DistState* D = ctx->dist;
+            if (ctx->dist_comm2 && D->comm && !D->comm2) { int rc = comm2_setup(ctx, D); if (rc) return rc; }   // (after comm_init: created here, by all ranks)
+            D->use_comm2 = ctx->dist_comm2 && D->comm2 != nullptr;
+        }
+        return PYIPM_OK;
+    }
+    if (!strcmp(name, "dist_sag")) {                    // 0: plain broadcast for the panel messages; 1: back to what the self-test decided
+        *handled = true;
+        DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
+        D->sag = ((int)value != 0) ? D->sag_ok : 0;
+        return PYIPM_OK;
+    }
     if (!strcmp(name, "dist_selfmsg")) {                // world == 1: pack + "broadcast" every panel anyway (measures the message path)
         *handled = true;
         DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
@@ -265,19 +305,19 @@ int tr_group_end(Ctx* ctx, DistState* D) {
 // The stream the slice messages travel on: their own (second communicator / callbacks that need no serialising), else the
 // collective stream.
 inline hipStream_t tr_slice_stream(const DistState* D) {
-    if (D->comm) return D->comm2 ? D->side : D->cs;
+    if (D->comm) return (D->comm2 && D->use_comm2) ? D->side : D->cs;
     return D->serialize ? D->cs : D->side;
 }
 int tr_send(Ctx* ctx, DistState* D, const double* buf, size_t count, int peer, hipStream_t st, bool slice = false) {
     D->wire[4] += 1.0;
-    if (D->comm) { ncclResult_t r = g_rccl.Send(buf, count, ncclDouble, peer, (slice && D->comm2) ? D->comm2 : D->comm, st); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclSend", r); }
+    if (D->comm) { ncclResult_t r = g_rccl.Send(buf, count, ncclDouble, peer, (slice && D->comm2 && D->use_comm2) ? D->comm2 : D->comm, st); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclSend", r); }
     if (!D->send) { ctx->err = "no point-to-point send installed (pyipm_newton_set_exchange_p2p)"; return PYIPM_E_COMM; }
     if (D->send(D->user, buf, count * sizeof(double), peer, (void*)st)) { ctx->err = "the send callback failed"; return PYIPM_E_COMM; }
     return 0;
 }
 int tr_recv(Ctx* ctx, DistState* D, double* buf, size_t count, int peer, hipStream_t st, bool slice = false) {
     D->wire[4] += 1.0;
-    if (D->comm) { ncclResult_t r = g_rccl.Recv(buf, count, ncclDouble, peer, (slice && D->comm2) ? D->comm2 : D->comm, st); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclRecv", r); }
+    if (D->comm) { ncclResult_t r = g_rccl.Recv(buf, count, ncclDouble, peer, (slice && D->comm2 && D->use_comm2) ? D->comm2 : D->comm, st); return r == ncclSuccess ? 0 : tr_fail(ctx, "ncclRecv", r); }
     if (!D->recv) { ctx->err = "no point-to-point receive installed (pyipm_newton_set_exchange_p2p)"; return PYIPM_E_COMM; }
     if (D->recv(D->user, buf, count * sizeof(double), peer, (void*)st)) { ctx->err = "the receive callback failed"; return PYIPM_E_COMM; }
     return 0;
@@ -371,7 +411,7 @@ int ex_allreduce(Ctx* ctx, DistState* D, double* buf, size_t count, int op, hipS
 // every collective below whatever happens to it locally: a local HIP failure is recorded, the collective is still issued (on
 // the always-present 16-double scratch of the handle), and the error is reported afterwards.
 int exchange_selftest(Ctx* ctx, DistState* D) {
-    D->sag = 0;
+    D->sag = D->sag_ok = 0;
     const int W = ctx->g.world;
     if (W < 2) return PYIPM_OK;
     const char* env = getenv("PYIPM_DIST_SAG");
@@ -409,10 +449,38 @@ int exchange_selftest(Ctx* ctx, DistState* D) {
         }
         double total = 1.0;
         rc = agree(bad, 0, &total); if (rc) return rc;
-        D->sag = (total == 0.0) ? 1 : 0;
+        D->sag = D->sag_ok = (total == 0.0) ? 1 : 0;
     }
     if (local_rc) { ctx->err = local_err; return local_rc; }
     return PYIPM_OK;
+}
+
+// Wait for everything enqueued on `main` (the helper streams have been joined into it) -- at most dist_timeout_s seconds.  On
+// expiry: PYIPM_E_COMM naming the first panel whose message / bulk update / chain the device has not completed (the progress
+// words of DistState), the handle is marked broken (its streams may never drain: RCCL has no per-operation timeout; destroy
+// aborts the communicators where the library offers ncclCommAbort).
+int bounded_wait(Ctx* ctx, DistState* D, hipStream_t main, int64_t np) {
+    DIST_HIP(hipEventRecord(D->ev_all, main));
+    const double bound = ctx->dist_timeout_s > 0 ? ctx->dist_timeout_s : 1.0e30;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipEventQuery(D->ev_all);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) { ctx->err = std::string("hipEventQuery: ") + hipGetErrorString(q); return PYIPM_E_HIP; }
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (el > bound) {
+            const unsigned m = D->prog_host[0], u = D->prog_host[1], c = D->prog_host[2];
+            char buf[320];
+            snprintf(buf, sizeof(buf), "distributed step: no completion within %.1f s (dist_timeout_s) on rank %d of %d: the device has completed the "
+                     "panel messages before panel %u, the bulk updates before panel %u and this rank's panels before panel %u (of %lld) -- "
+                     "a collective a peer never joined?", bound, ctx->g.rank, ctx->g.world, m, u, c, (long long)np);
+            ctx->err = buf;
+            D->broken = true;
+            ctx->factored = false;
+            return PYIPM_E_COMM;
+        }
+        if (el > 0.2) { struct timespec ts = {0, 200000}; nanosleep(&ts, nullptr); }       // (a healthy step is over long before)
+    }
 }
 
 // run a piece of the per-panel machinery (which enqueues on ctx->stream) on another stream
@@ -555,6 +623,8 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
     bool sfree_rec[2][2] = {{false, false}, {false, false}};
     bool pre_rec = false;
     D->fwd_done = false;
+    if (D->broken) { ctx->err = "an earlier distributed step timed out: this handle's streams may hold collectives that never complete -- destroy it"; return PYIPM_E_COMM; }
+    for (int k = 0; k < 3; ++k) D->prog_host[k] = 0u;
     if (fwd_b) {
         if (!D->fws) DIST_HIP(hipStreamCreateWithFlags(&D->fws, hipStreamNonBlocking));
         if (!D->ev_fw) DIST_HIP(hipEventCreateWithFlags(&D->ev_fw, hipEventDisableTiming));
@@ -594,6 +664,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
             r = span_end(ctx, D, sp, st); if (r) return r;
         }
         DIST_HIP(hipEventRecord(D->ev_fact[b], st));
+        hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, st, D->prog_dev + 2, (unsigned)(p + 1)); DIST_KCHECK();
         return 0;
     };
     // owner: pack slice j of panel p on `st` (its rows of panel p + j are final there)
@@ -656,6 +727,12 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
         const size_t bytes = msg_of(p);
         if (!bytes) return 0;
         const int b = (int)(p & 1);
+        if (ctx->debug_fault == 3 && p == np / 2) {        // test hook: this panel's message "never completes" (for 3 x the step's time bound)
+            ctx->debug_fault = 0;
+            double tb = ctx->dist_timeout_s > 0 ? 3.0 * ctx->dist_timeout_s : 30.0; if (tb > 30.0) tb = 30.0;
+            hipLaunchKernelGGL(k_stall, dim3(1), dim3(64), 0, cs, (unsigned long long)(tb * 1.0e8));
+            DIST_KCHECK();
+        }
         if (own(p)) DIST_HIP(hipStreamWaitEvent(cs, D->ev_fact[b], 0));
         else DIST_HIP(hipStreamWaitEvent(cs, D->ev_free[b], 0));
         size_t sp; int r = span_begin(ctx, D, 2, cs, &sp); if (r) return r;
@@ -664,6 +741,8 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
         DIST_HIP(hipEventRecord(D->ev_msg[b], cs));
         if (own(p)) DIST_HIP(hipEventRecord(D->ev_free[b], cs));        // an owner's buffer is free once the message has left
         D->bytes_sent += bytes; D->n_msgs++;
+        hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, cs, D->prog_dev + 0, (unsigned)(p + 1));      // progress word (bounded_wait)
+        DIST_KCHECK();
         return 0;
     };
     // bulk update from panel p of the owned panels beyond `after`; with slices the panel this rank factors next goes first
@@ -783,7 +862,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
             } else {
                 // classic: the whole head on the main stream, the whole panel on the side stream behind it
                 const int64_t nbwn = g.panel_w(nxt);
-                const bool wide_next = ctx->dist_head_split && ctx->tile_step && ctx->inpanel32 && ctx->wide_sub >= 128 &&
+                const bool wide_next = ctx->dist_head_split && ctx->tile_step && ctx->wide_sub >= 128 &&
                                        ctx->wide_sub % 128 == 0 && nbwn > ctx->wide_sub && nbwn / TB <= 32 && c1n + nbwn < g.Npad &&
                                        !panel_in_s(ctx, nxt) && !panel_in_s(ctx, k) && nbwn % 32 == 0;
                 if (panel_in_s(ctx, k) || panel_in_s(ctx, nxt)) {
@@ -815,6 +894,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
         }
         if (!early && sl(nxt)) { rc = xchg_s(nxt, 1, 0); if (rc) return rc; }       // (classic panel k + 1: its slice 1 follows the panel message of k)
         rc = bulk_from(k, nxt); if (rc) return rc;                                // everyone's share of the bulk update of panel k
+        hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, main, D->prog_dev + 1, (unsigned)(k + 1)); DIST_KCHECK();
         // last in the iteration: the host submits the next panel's chain first (in the chain-bound tail the GPU is
         // waiting for exactly those launches; with the forward step submitted ahead of them the factorisation grew by as
         // much as the sweep shrank)
@@ -833,6 +913,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
     if (ctx->rest) { DIST_HIP(hipEventRecord(D->ev_join, ctx->rest)); DIST_HIP(hipStreamWaitEvent(main, D->ev_join, 0)); }
     DIST_HIP(hipEventRecord(ctx->ev[1], main));
     ctx->assembled = false;
+    rc = bounded_wait(ctx, D, main, np); if (rc) return rc;
     pyipm_factor_stats loc;
     rc = factor_end(ctx, &loc);
     const int rc_nonfinite = rc;
@@ -983,6 +1064,46 @@ int residual_dist(Ctx* ctx) {
     return ex_allreduce(ctx, D, ctx->rhs, (size_t)ctx->g.Npad, 0, ctx->stream);
 }
 
+// A second communicator over the same ranks for the slice messages of the two-message protocol (option dist_comm2, off by
+// default): on ONE communicator a slice queues behind whatever panel broadcast is in flight on the collective stream (the
+// operations of a communicator run one at a time), which is what it is sent ahead of -- the rank replay gives 35.4 ms with it
+// against 42.6 without at N = 32768 / 8 ranks.  But two communicators driven concurrently on one device, with an issue order
+// that depends on the rank's role, is the classic multi-communicator deadlock pattern of NCCL and has never run on more than
+// one GPU: opt-in, and bench.py's ladder steps down from it when a run stalls.  RCCL transport only (D->comm);
+// the ranks AGREE (an all-reduce on the first communicator) before anybody enters ncclCommInitRank -- a rank that failed
+// locally would otherwise leave its peers inside it -- and again on the outcome: all have the communicator or none.
+int comm2_setup(Ctx* ctx, DistState* D) {
+    if (D->comm2) { g_rccl.CommDestroy(D->comm2); D->comm2 = nullptr; }
+    if (!D->comm || !ctx->dist_comm2 || ctx->g.world < 2 || !g_rccl.Send || !g_rccl.Recv) return PYIPM_OK;
+    auto agree_sum = [&](double mine, double* out) -> int {       // (issued whatever happened locally: the peers are inside it)
+        bool lok = hipMemcpy(D->small, &mine, sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+        const int rc = tr_allreduce(ctx, D, D->small, 1, 0, D->cs);
+        lok = (hipStreamSynchronize(D->cs) == hipSuccess) && lok;
+        *out = 1.0;
+        if (hipMemcpy(out, D->small, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess || !lok) *out = 1.0e9;
+        return rc;
+    };
+    ncclUniqueId id2; memset(&id2, 0, sizeof(id2));
+    bool ok = true;
+    if (ctx->g.rank == 0) ok = g_rccl.GetUniqueId(&id2) == ncclSuccess;
+    static_assert(sizeof(ncclUniqueId) <= 16 * sizeof(double), "the id travels through the 16-double scratch");
+    if (hipMemcpy(D->small, &id2, sizeof(id2), hipMemcpyHostToDevice) != hipSuccess) ok = false;
+    if (g_rccl.Broadcast(D->small, D->small, 16, ncclDouble, 0, D->comm, D->cs) != ncclSuccess) ok = false;
+    if (hipStreamSynchronize(D->cs) != hipSuccess) ok = false;
+    if (hipMemcpy(&id2, D->small, sizeof(id2), hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+    bool zero = true;
+    for (size_t k = 0; k < sizeof(id2); ++k) zero = zero && reinterpret_cast<const char*>(&id2)[k] == 0;
+    double bad = 0.0;
+    int rc = agree_sum((ok && !zero) ? 0.0 : 1.0, &bad); if (rc) return rc;
+    if (bad != 0.0) return PYIPM_OK;                             // somebody cannot: nobody enters; the slices share the collective stream
+    const bool mine = g_rccl.CommInitRank(&D->comm2, ctx->g.world, id2, ctx->g.rank) == ncclSuccess;
+    if (!mine) D->comm2 = nullptr;
+    rc = agree_sum(mine ? 0.0 : 1.0, &bad); if (rc) return rc;
+    if (bad != 0.0 && D->comm2) { g_rccl.CommDestroy(D->comm2); D->comm2 = nullptr; }
+    D->use_comm2 = D->comm2 != nullptr;
+    return PYIPM_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1011,7 +1132,7 @@ int pyipm_newton_set_exchange_p2p(pyipm_newton_ctx* h, pyipm_send_fn send, pyipm
     PYIPM_HIP(hipSetDevice(ctx->device));
     DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
     D->send = send; D->recv = recv; D->allgather = allgather; D->serialize = serialize != 0;
-    D->sag = 0;                                          // (whatever an earlier self-test decided belonged to another transport)
+    D->sag = D->sag_ok = 0;                                          // (whatever an earlier self-test decided belonged to another transport)
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)
 
@@ -1022,25 +1143,7 @@ int pyipm_newton_exchange_selftest(pyipm_newton_ctx* h) try {
     PYIPM_HIP(hipSetDevice(ctx->device));
     DistState* D; int rc = dist_state(ctx, &D); if (rc) return rc;
     if (ctx->g.world > 1 && !D->comm && !(D->bcast && D->allreduce)) { ctx->err = "exchange_selftest: no exchange installed"; return PYIPM_E_COMM; }
-    // A second communicator over the same ranks for the slice messages of the two-message protocol: on ONE communicator a
-    // slice would queue behind whatever panel broadcast is in flight on the collective stream (operations of a communicator
-    // run one at a time), which is exactly what it is sent ahead of.  Its id comes from rank 0 through the first one.  Without
-    // it (an RCCL without point-to-point calls, or a failure here) the slices share the collective stream: correct, slower.
-    if (D->comm2) { g_rccl.CommDestroy(D->comm2); D->comm2 = nullptr; }
-    if (ctx->g.world >= 2 && g_rccl.Send && g_rccl.Recv) {
-        ncclUniqueId id2; memset(&id2, 0, sizeof(id2));
-        bool ok = true;
-        if (ctx->g.rank == 0) ok = g_rccl.GetUniqueId(&id2) == ncclSuccess;
-        static_assert(sizeof(ncclUniqueId) <= 16 * sizeof(double), "the id travels through the 16-double scratch");
-        if (hipMemcpy(D->small, &id2, sizeof(id2), hipMemcpyHostToDevice) != hipSuccess) ok = false;
-        // (every rank issues the broadcast whatever happened locally: the peers are inside it)
-        if (g_rccl.Broadcast(D->small, D->small, 16, ncclDouble, 0, D->comm, D->cs) != ncclSuccess) ok = false;
-        if (hipStreamSynchronize(D->cs) != hipSuccess) ok = false;
-        if (hipMemcpy(&id2, D->small, sizeof(id2), hipMemcpyDeviceToHost) != hipSuccess) ok = false;
-        bool zero = true;
-        for (size_t k = 0; k < sizeof(id2); ++k) zero = zero && reinterpret_cast<const char*>(&id2)[k] == 0;
-        if (ok && !zero && g_rccl.CommInitRank(&D->comm2, ctx->g.world, id2, ctx->g.rank) != ncclSuccess) D->comm2 = nullptr;
-    }
+    // (the second communicator of the slice messages is comm_init's business -- option dist_comm2; this entry only tests what is installed)
     return exchange_selftest(ctx, D);
 } PYIPM_CATCH_H(h)
 
@@ -1073,6 +1176,7 @@ int pyipm_newton_comm_init(pyipm_newton_ctx* h, const void* id128) try {
     ncclUniqueId id; memcpy(&id, id128, sizeof(id));
     ncclResult_t r = g_rccl.CommInitRank(&D->comm, ctx->g.world, id, ctx->g.rank);
     if (r != ncclSuccess) { D->comm = nullptr; ctx->err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"); return PYIPM_E_COMM; }
+    rc = comm2_setup(ctx, D); if (rc) return rc;
     return exchange_selftest(ctx, D);
 } PYIPM_CATCH_H(h)
 

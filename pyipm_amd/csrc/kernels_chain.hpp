@@ -30,14 +30,7 @@
 
 namespace pyipm {
 
-struct ChainGeo {
-    int ta, tb, nT;          // steps [ta, tb) of a diagonal block of nT tiles
-    int cpy;                 // column tiles per unit and stage a row tile is split for (5: k_tile_step's rule)
-    unsigned base;           // epoch of the progress words: word - base = progress of THIS launch (wrap-safe compare)
-    unsigned* sync;          // [0]: tiles inverted by the chain (base + t + 1 after tile t);  [1 + 4 r + y]: stages unit (r, y) completed
-    unsigned* err;           // sticky: a poll timed out
-    unsigned long long timeout;   // 100 MHz ticks
-};
+// (struct ChainGeo: ctx.hpp)
 
 // units of row tile r: ny = ceil(#column tiles of its first stage / cpy), 1 .. 4
 __host__ __device__ inline int chain_ny(int r, int ta, int cpy) {
@@ -73,14 +66,31 @@ __device__ __forceinline__ bool chain_wait(const unsigned* word, bool active, un
     }
 }
 
+// What the rows below a diagonal block wait for when its chain is ONE launch (ta = 0): the chain has inverted `crit_need`
+// tiles and every unit of the row tiles from `row0` on has completed `unit_need` stages.  One wave on the rows' stream in
+// place of an event between two launches of the chain; the kernels behind it start with the acquire of a kernel boundary
+// and read what the chain has written through.  *err is the chain's sticky error word.
+__global__ __launch_bounds__(64) void k_chain_wait(ChainGeo cg, int crit_need, int row0, int unit_need)
+{
+    const int lane = threadIdx.x;
+    bool ok = chain_wait(cg.sync, lane == 0, cg.base + (unsigned)crit_need, cg.err, cg.timeout, true);
+    for (int idx = lane; ok && idx < 4 * cg.nT; idx += 64) {
+        const int r = idx >> 2, y = idx & 3;
+        const bool act = r >= row0 && r >= 1 && r < cg.nT && y < chain_ny(r, 0, cg.cpy);
+        ok = chain_wait(cg.sync + 1 + idx, act, cg.base + (unsigned)unit_need, cg.err, cg.timeout, true);
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void k_tile_chain(
     double* A, int64_t ld, int64_t c0, int64_t lc0,                          // the diagonal block: first global / local column
     double* W, int64_t ldw,                                                  // its -S buffer: W[row + k * ldw], k < 64 nT
     double* Dinv, double* Tsv, double* Tflag,                                // of the block's first tile
     double refine_cond, int nref, DevStats* __restrict__ st, int64_t Nreal, double pivtol_rel,
-    const unsigned long long* __restrict__ anorm_bits, int64_t neg_from, int blocked, ChainGeo cg)
+    const unsigned long long* __restrict__ anorm_bits, int64_t neg_from, int blocked, ChainGeo cg,
+    unsigned long long* tdbg)                                                // the tile inversion's diagnostics (NULL normally; debug_timeline_ptr)
 {
     __shared__ TileScratch sm;
+    extern __shared__ char chain_pad[];               // (never touched: its SIZE keeps other workgroups off this one's compute unit, option chain_lds_kb)
     static_assert(sizeof(TileScratch) >= sizeof(double) * TB * (TB + 2), "X must fit into the tile scratch");
     double (&X)[TB][TB + 2] = *reinterpret_cast<double (*)[TB][TB + 2]>(&sm);
     __builtin_amdgcn_s_setprio(3);
@@ -96,9 +106,11 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
         for (int t = ta; t < tb; ++t) {
             const int tid = tile_tid<true>(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             const int l15 = lane & 15, l4 = lane >> 4;
+#define PYIPM_CH_STAMP(k_) if (cg.dbg && tid == 0) cg.dbg[8 * t + (k_)] = wall_clock64();
+            PYIPM_CH_STAMP(0)
             if (t == 0) {
                 tile_invert_dev<false, true, true>(sm, A, ld, c0, lc0, Dinv, Tsv, Tflag, refine_cond, st, Nreal, pivtol_rel, anorm_bits,
-                                                   neg_from, nullptr, false, blocked != 0);
+                                                   neg_from, tdbg, false, blocked != 0);
             } else {
                 const int tp = t - 1;
                 const int64_t i = c0 + (int64_t)t * TB + wave * 16 + l15;        // this lane's (global) row
@@ -109,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
                     if (need > 0) chain_wait(cg.sync + 1 + 4 * t + (lane & 3), lane < ny, cg.base + (unsigned)need, cg.err, cg.timeout, false);
                 }
                 asm volatile("" ::: "memory");
+                PYIPM_CH_STAMP(1)
                 int nr = nref;
                 if (nr > 0 && ldg_c<true>(Tflag + tp) == 0.0) nr = 0;
                 PYIPM_STAGE_TILE_C(X, 1.0, Dinv + tp * TT, true)
@@ -116,8 +129,10 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
                 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks) sb[ks] = -ldg_c<true>(W + i + (int64_t)(tp * TB + ks * 4 + l4) * ldw);
                 __syncthreads();
+                PYIPM_CH_STAMP(2)
                 double4_t acc[4];
                 strip_scale<true, true>(X, Dinv + tp * TT, Tsv + tp * TT, nr, sb, tid, l15, l4, acc);
+                if (cg.dbg) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][3])); PYIPM_CH_STAMP(3) }
                 {
                     double gmax = 0.0;
                     #pragma unroll
@@ -130,7 +145,9 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
                     gmax = wave_max(gmax);
                     if (lane == 0) atomicMax(&st->growth_bits, (unsigned long long)__double_as_longlong(gmax));
                 }
-                // the diagonal tile: Wn = -S of the chain's own 64 rows, from the registers through shared memory (k_tile_step)
+                // the diagonal tile: Wn = -S of the chain's own 64 rows, from the registers through shared memory (k_tile_step).
+                // (Requesting the tile ahead of the scaling product -- it comes from memory, written through by row t's units --
+                //  spilled 30 more registers and slowed the product by 1.1 us: 8.6 against 7.3 us for the steps before an inversion.)
                 double4_t c2[4];
                 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
@@ -156,14 +173,18 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
                         A[i + (lc0 + t * TB + c) * ld] = c2[tt][r];
                         sm.stage[wave * 16 + l15][c] = c2[tt][r];
                     }
+                PYIPM_CH_STAMP(4)
                 tile_invert_dev<false, true, true>(sm, A, ld, c0 + (int64_t)t * TB, lc0 + (int64_t)t * TB, Dinv + t * TT, Tsv + t * TT,
-                                                   Tflag + t, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from, nullptr,
+                                                   Tflag + t, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from, tdbg,
                                                    /*from_stage=*/true, blocked != 0);
             }
             // inv(T[t]), T[t] and its flag are out (every wave's stores drained) before the word says so
+            PYIPM_CH_STAMP(5)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) __hip_atomic_store(crit_w, cg.base + (unsigned)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            PYIPM_CH_STAMP(6)
+#undef PYIPM_CH_STAMP
         }
         return;
     }
@@ -228,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
             if (need > 0) chain_wait(cg.sync + 1 + 4 * v + yo, act && v >= rfirst, cg.base + (unsigned)need, cg.err, cg.timeout, true);
         }
         asm volatile("" ::: "memory");
+        if (cg.dbg && tid == 0) cg.dbg[256 + 64 * (4 * r + y) + 2 * tp] = wall_clock64();
         int nr = nref;
         if (nr > 0 && ldg_c<true>(Tflag + tp) == 0.0) nr = 0;
         PYIPM_STAGE_TILE_C(X, 1.0, Dinv + tp * TT, true)
@@ -292,6 +314,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
         __syncthreads();
         ++done;
         if (tid == 0) __hip_atomic_store(my_w, cg.base + (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cg.dbg && tid == 0) cg.dbg[256 + 64 * (4 * r + y) + 2 * tp + 1] = wall_clock64();
     }
 }
 

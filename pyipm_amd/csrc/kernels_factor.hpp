@@ -1079,21 +1079,6 @@ __global__ __launch_bounds__(NW * 64, (BN >= 256 ? 2 : NW / 2)) void k_update(
     }
 }
 
-// Fused head: the chain of the next group starts behind this one-wave kernel, which returns once `expected` head tiles of
-// the bulk launch on the other stream have been stored (or after `timeout` ticks of the 100 MHz clock: *err = 1 and the
-// factorisation reports it -- a hang would cost the whole GPU).
-__global__ __launch_bounds__(64) void k_wait_counter(const unsigned* __restrict__ ctr, unsigned expected, unsigned long long timeout,
-                                                     int* __restrict__ err)
-{
-    if (threadIdx.x != 0) return;
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < expected) {
-        __builtin_amdgcn_s_sleep(32);
-        if (wall_clock64() - t0 > timeout) { *err = 1; break; }
-    }
-    __threadfence();
-}
-
 // ---------------------------------------------------------------------------------------------
 // In-panel left-looking update of one 64-column block with the K = 64 t columns before it (K <= nb - 64):
 //   C[i][c] += sum_k L[i][k] * Wn[c][k]        (Wn = -W), rows i >= row_begin

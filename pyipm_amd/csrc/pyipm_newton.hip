@@ -241,7 +241,7 @@ double active_area(int64_t row_begin, int64_t Npad, int64_t j0, int64_t j1, int6
 // another stream waits for the copy's event until it has been seen complete.  Device and host memory come from arenas.
 int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, unsigned* count, int bn = 128,
               unsigned* head_count = nullptr, hipStream_t consumer = nullptr) {
-    if (ctx->debug_fault) {                             // test hook (tests/test_gpu_host_abi.py): the containers below can throw
+    if (ctx->debug_fault == 1 || ctx->debug_fault == 2) {   // test hook (tests/test_gpu_host_abi.py): the containers below can throw
         const int k = ctx->debug_fault; ctx->debug_fault = 0;
         if (k == 1) throw std::bad_alloc();
         throw std::runtime_error("injected fault");
@@ -369,7 +369,7 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
     // (col_end % 256: Npad is a multiple of 128 only -- a 256-wide tile at the last 128 columns would read and rewrite 128
     // columns past the storage, i.e. the first W slot, and W rows past Npad; such shapes keep 128 x 128 tiles)
     if (ctx->xcd_swizzle && bulk && ctx->bulk_bn == 256 && use_waves == 8 && waves == 0 && ksplit == 1 && g.nb % 256 == 0 &&
-        col_end % 256 == 0 && K >= ctx->bulk_bn_min_k && head_ct % 2 == 0 && nct_sub == 0 && (ctx->bulk_bn_all || ctx->reserve_cus <= 0 || m > (ctx->bulk_bn_rows > ctx->persist_rows ? ctx->bulk_bn_rows : ctx->persist_rows))) {
+        col_end % 256 == 0 && K >= ctx->bulk_bn_min_k && head_ct % 2 == 0 && nct_sub == 0 && (ctx->reserve_cus <= 0 || m > (ctx->bulk_bn_rows > ctx->persist_rows ? ctx->bulk_bn_rows : ctx->persist_rows))) {
         // 128 x 256 tiles (the K = 1024 bulk launches of the single-rank schedule, the K = nb launches of the per-panel one)
         u.nct = (int)(n_lp * (g.nb / 256));
         u.head_ct = head_ct / 2;                        // (fused head: the callers count 128-column tiles)
@@ -472,7 +472,7 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
     if (apply_pending && poff != 0) {
         const int64_t p0 = p - poff;
         const int K = (int)((p - p0) * g.nb);
-        if (ctx->inpanel32 && g.Npad - c0 <= ctx->pending32_rows) {
+        if (g.Npad - c0 <= ctx->pending32_rows) {
             int64_t pa0, pa1, pb0, pb1;
             active_ranges(ctx, g.panel_c0(p0), g.panel_c0(p0) + K, &pa0, &pa1, &pb0, &pb1);
             hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - c0) / 32), (unsigned)(nbw / TB)), dim3(256), 0, stream,
@@ -498,10 +498,10 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
         panel_hole(ctx, p, &hole0, &hole1);             // per-panel mode (any number of ranks)
         if (hole1 > hole0) active_ranges(ctx, c0, c0 + nbw, &ha0, &ha1, &hb0, &hb1);
     }
-    if (ctx->tile_step && ctx->inpanel32 && ctx->per_panel_mode && ctx->wide_sub >= 128 && ctx->wide_sub % 128 == 0 &&
+    if (ctx->tile_step && ctx->per_panel_mode && ctx->wide_sub >= 128 && ctx->wide_sub % 128 == 0 &&
         nbw > ctx->wide_sub && nt <= 32 && c0 + nbw < g.Npad)
         return factor_wide_panel(ctx, p, stream);
-    if (ctx->tile_step && ctx->inpanel32 && nt <= 16) {
+    if (ctx->tile_step && nt <= 16) {
         // stepped schedule: launch t inverts tile t (after eliminating tile t - 1 from the rows of the diagonal block), one
         // more launch runs all stages for the rows below the diagonal block
         double* Dv = ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB);
@@ -515,29 +515,16 @@ int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = f
         }
         return 0;
     }
-    const bool fused = ctx->fuse_su && ctx->inpanel32;      // a tile's scaling launch also updates the next column block
+    const bool fused = ctx->fuse_su != 0;                   // a tile's scaling launch also updates the next column block
     for (int t = 0; t < nt; ++t) {
         const int64_t j0 = c0 + (int64_t)t * TB, lcol = lc0 + (int64_t)t * TB;
         const int64_t below = g.Npad - (j0 + TB);
-        if (t > 0 && ctx->inpanel32 && !fused) {
+        if (t > 0 && !fused) {
             // left-looking in-panel update of this tile's column block with the t tiles before it (32-row blocks)
             const int64_t row_begin = (j0 / 32) * 32;
             hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - row_begin) / 32)), dim3(256), 0, stream,
                                ctx->A, g.Npad, lcol, ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, j0, t * TB, row_begin, g.Npad,
                                ha0, ha1, hb0, hb1, ctx->side_prio);
-            PYIPM_KCHECK();
-        } else if (t > 0 && !ctx->inpanel32) {
-            // left-looking in-panel update of this tile's column block with the t tiles before it
-            const int64_t row_begin = (j0 / BM) * BM;
-            const int64_t m = g.Npad - row_begin;
-            UpdGeo u;
-            u.row_begin = row_begin; u.Npad = g.Npad; u.first_lp = lp; u.sub0 = t;
-            u.nb = g.nb; u.world = g.world; u.rank = g.rank; u.nrt = (int)(m / BM); u.nct = 1;
-            u.dbg = nullptr; u.prio = ctx->side_prio; u.rt_min0 = 0; u.rt_step = 0;
-            u.a0 = ha0; u.a1 = ha1; u.b0 = hb0; u.b1 = hb1; u.tiles = nullptr; u.ks_cstride = 0;
-            dim3 grid((unsigned)(m / BM), 1);
-            hipLaunchKernelGGL((k_update<64, false>), grid, dim3(256), 0, stream, ctx->A, g.Npad,
-                               ctx->A + lc0 * g.Npad, g.Npad, W, g.Npad, t * TB, u);
             PYIPM_KCHECK();
         }
         const bool next = fused && t + 1 < nt && below > 0;   // the scaling launch below carries the update of tile t + 1
@@ -581,11 +568,16 @@ int ensure_rest_stream(Ctx* ctx) {
 // later sub-panels of the block (right-looking: the pending update, one source at a time -- the same products in the same
 // order).  on_done(id, stream): sub-panel `id` is complete once `stream` reaches this point.
 // Tile steps [ta, tb) of a diagonal block of nT tiles on `chain`: one k_tile_step launch per tile.
+// does the diagonal block at global column gc0 (nT tiles) take k_tile_chain (kernels_chain.hpp)?
+static bool chain_applies(const Ctx* ctx, int64_t gc0, int nT) {
+    const Geo& g = ctx->g;
+    const bool exposed = ctx->per_panel_mode || gc0 == 0 || g.Npad - gc0 <= ctx->tile8_rows;   // (where the chain is what the step waits for)
+    return ctx->tile_chain && nT >= 2 && nT <= 32 && (ctx->tile_chain >= 2 || exposed);
+}
 int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, int nT, int ta, int tb, double* Wg, double* Dv, double* Ts) {
     const Geo& g = ctx->g;
     if (tb <= ta) return 0;
-    const bool exposed = ctx->per_panel_mode || gc0 == 0 || g.Npad - gc0 <= ctx->tile8_rows;   // (where the chain is what the step waits for)
-    if (ctx->tile_chain && tb - ta >= 2 && nT <= 32 && (ctx->tile_chain >= 2 || exposed)) {
+    if (tb - ta >= 2 && chain_applies(ctx, gc0, nT)) {
         // the steps [ta, tb) as ONE launch of persistent workgroups (kernels_chain.hpp): no launch boundary between two tiles
         if (!ctx->chain_sync) {
             PYIPM_HIP(hipMalloc((void**)&ctx->chain_sync, (size_t)(Ctx::CHAIN_SLOTS * Ctx::CHAIN_WORDS + 1) * sizeof(unsigned)));
@@ -604,12 +596,22 @@ int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, in
         cg.sync = ctx->chain_sync + (size_t)(ctx->chain_epoch % Ctx::CHAIN_SLOTS) * Ctx::CHAIN_WORDS;
         cg.err = ctx->chain_sync + (size_t)Ctx::CHAIN_SLOTS * Ctx::CHAIN_WORDS;
         cg.timeout = (unsigned long long)2.0e8;          // 2 s (100 MHz clock)
+        cg.dbg = nullptr;
+        if (ctx->chain_dbg && ctx->chain_dbg_launch < 64) cg.dbg = ctx->chain_dbg + (size_t)(ctx->chain_dbg_launch++) * CHAIN_DBG_WORDS;
         const unsigned nblk = 1u + (unsigned)chain_units(ta, nT, cg.cpy);
-        hipLaunchKernelGGL(k_tile_chain, dim3(nblk), dim3(256), 0, chain, ctx->A, g.Npad, gc0, glc0, Wg, g.Npad, Dv, Ts,
+        // dynamic shared memory nobody touches: with it a workgroup of the chain has its compute unit to itself (single-rank
+        // schedule only: beside the bulk updates of the per-panel schedule it would wait for a whole CU to drain)
+        size_t pad = (ctx->chain_lds_kb > 0 && !ctx->per_panel_mode) ? (size_t)ctx->chain_lds_kb * 1024 : 0;
+        if (pad && !ctx->chain_lds_set) {
+            if (hipFuncSetAttribute((const void*)k_tile_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024) != hipSuccess) { (void)hipGetLastError(); ctx->chain_lds_kb = 0; pad = 0; }
+            ctx->chain_lds_set = true;
+        }
+        hipLaunchKernelGGL(k_tile_chain, dim3(nblk), dim3(256), pad, chain, ctx->A, g.Npad, gc0, glc0, Wg, g.Npad, Dv, Ts,
                            ctx->Tflag + gc0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats, g.N, ctx->pivtol_rel, ctx->anorm,
-                           g.n + g.mi, ctx->tile_blocked, cg);
+                           g.n + g.mi, ctx->tile_blocked, cg, ctx->dbg_buf);
         PYIPM_KCHECK();
         ctx->chain_used = true;
+        ctx->chain_last = cg;
         return 0;
     }
     for (int j = ta; j < tb; ++j) {
@@ -620,7 +622,6 @@ int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, in
         // beside every chain: owners' chain path 31.0 -> 32.1 ms in the replay -- it keeps the 256-thread kernel)
         const int64_t m_left = g.Npad - gc0;
         if (ctx->tile_waves == 8 && (ctx->per_panel_mode ? ctx->tile8_dist != 0 : (gc0 == 0 || m_left <= ctx->tile8_rows))) {
-            if (ctx->tile_ny3) { ny = (nT - j + 2) / 3; if (ny < 1) ny = 1; if (ny > 6) ny = 6; }
             const int units = (nT - j - 1) * ny;
             const int free_cus = (gc0 == 0 || ctx->reserve_cus <= 0 || ctx->per_panel_mode) ? ctx->num_cus : ctx->tile_free_cus;
             const int upb = ctx->tile_upb > 0 ? ctx->tile_upb : (units + 1 <= free_cus ? 1 : 2);
@@ -672,7 +673,15 @@ int factor_block(Ctx* ctx, const BlockDesc& bd, hipStream_t chain, const std::fu
     };
     // sub-panel q's columns are final inside the diagonal block once the first tile of sub-panel q + 1 has applied its last
     // stage: the tile steps run in pieces that END with that step, an event after each
-    for (int kp = 1, ta = 0; kp <= n0; ++kp) {
+    // (k_tile_chain: the whole diagonal block is ONE launch; the rows of sub-panel q wait on their own stream for the chain's
+    //  progress words instead -- k_chain_wait below)
+    const bool one_launch = ctx->chain_whole && chain_applies(ctx, gc0, nT);
+    ChainGeo cgw; memset(&cgw, 0, sizeof(cgw));
+    if (one_launch) {
+        int r0 = launch_tile_steps(ctx, chain, gc0, glc0, nT, 0, nT, Wg, Dv, Ts); if (r0) return r0;
+        cgw = ctx->chain_last;
+    }
+    for (int kp = 1, ta = 0; kp <= n0 && !one_launch; ++kp) {
         const int tb = kp < n0 ? toff[(size_t)kp] + 1 : nT;
         int r0 = launch_tile_steps(ctx, chain, gc0, glc0, nT, ta, tb, Wg, Dv, Ts); if (r0) return r0;
         if (kp < n0) PYIPM_HIP(hipEventRecord(ctx->ev_band[(size_t)(kp - 1)], chain));
@@ -689,6 +698,11 @@ int factor_block(Ctx* ctx, const BlockDesc& bd, hipStream_t chain, const std::fu
             PYIPM_HIP(hipEventRecord(ctx->ev_join, ctx->rest));
             PYIPM_HIP(hipStreamWaitEvent(chain, ctx->ev_join, 0));
             rs = chain;
+        } else if (one_launch) {
+            // sub-panel k's tiles are inverted (the chain has passed tile toff[k + 1] - 1) and every later row tile has the stages
+            // up to the sub-panel's last tile but one: W of the sub-panel's columns is final inside the diagonal block
+            hipLaunchKernelGGL(k_chain_wait, dim3(1), dim3(64), 0, ctx->rest, cgw, toff[(size_t)k + 1], toff[(size_t)k + 1], toff[(size_t)k + 1]);
+            PYIPM_KCHECK();
         } else {
             PYIPM_HIP(hipStreamWaitEvent(ctx->rest, ctx->ev_band[(size_t)k], 0));
         }
@@ -774,7 +788,7 @@ int factor_wide_panel(Ctx* ctx, int64_t p, hipStream_t stream) {
 // every entry in the same order as factor_panel does in one go: the same bits (tests/test_gpu_dist.py, tools/rank_replay.py).
 bool panel_piecewise_ok(const Ctx* ctx, int64_t p) {
     const Geo& g = ctx->g;
-    if (!ctx->tile_step || !ctx->inpanel32 || panel_in_s(ctx, p)) return false;
+    if (!ctx->tile_step || panel_in_s(ctx, p)) return false;
     const int nbw = (int)g.panel_w(p), nt = nbw / TB;
     const bool wide = ctx->wide_sub >= 128 && ctx->wide_sub % 128 == 0 && nbw > ctx->wide_sub;
     return wide ? (nt <= 32) : (nt <= 16);
@@ -985,7 +999,7 @@ int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_l
         e0 = ctx->ev_trailing[ctx->n_trailing].first; e1 = ctx->ev_trailing[ctx->n_trailing].second;
         PYIPM_HIP(hipEventRecord(e0, stream));
     }
-    if (ctx->inpanel32 && ctx->per_panel_mode && n_lp == 1 && g.Npad - row_begin <= ctx->head32_rows_dist) {
+    if (ctx->per_panel_mode && n_lp == 1 && g.Npad - row_begin <= ctx->head32_rows_dist) {
         // one panel of columns (the head of the per-panel schedule): 32 x 64 blocks instead of a handful of 128 x 128 tiles
         int64_t pa0, pa1, pb0, pb1;
         active_ranges(ctx, g.panel_c0(p0), g.panel_c0(p0) + K, &pa0, &pa1, &pb0, &pb1);
@@ -1038,24 +1052,15 @@ int trailing_update(Ctx* ctx, int64_t p) {
 // able to enqueue the first group's chain while the assembly is still running.
 int factor_begin(Ctx* ctx, hipStream_t st = nullptr) {
     if (!st) st = ctx->stream;
-    if (!ctx->head_counters) {                      // fused heads: one counter per group + the error flag of k_wait_counter
-        PYIPM_HIP(hipMalloc((void**)&ctx->head_counters, (256 + 1) * sizeof(unsigned)));
-        ctx->n_head_counters = 256;
-    }
     hipLaunchKernelGGL(k_init_stats, dim3(1), dim3(64), 0, st, ctx->dstats);
     PYIPM_KCHECK();
-    // (every stream of the handle is idle of factorisation work here: the factorisation before joined them and was waited for)
-    PYIPM_HIP(hipMemsetAsync(ctx->head_counters, 0, (ctx->n_head_counters + 1) * sizeof(unsigned), st));
     ctx->n_trailing = 0; ctx->trailing_flops = 0.0; ctx->trailing_area = 0.0;
     return 0;
 }
 
 int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
     DevStats z;
-    int wait_err = 0;
     PYIPM_HIP(hipMemcpyAsync(&z, ctx->dstats, sizeof(z), hipMemcpyDeviceToHost, ctx->stream));
-    if (ctx->head_counters)
-        PYIPM_HIP(hipMemcpyAsync(&wait_err, ctx->head_counters + ctx->n_head_counters, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     int sweep_err = 0;
     if (ctx->sweep_used && ctx->sweep_sync)
         PYIPM_HIP(hipMemcpyAsync(&sweep_err, ctx->sweep_sync + 3 * 4096, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1072,7 +1077,6 @@ int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
                    "(set_option(\"tile_chain\", 0) runs one launch per tile)";
         return PYIPM_E_HIP;
     }
-    if (wait_err) { ctx->err = "fused head: the next group's chain gave up waiting for the bulk update's head tiles"; return PYIPM_E_HIP; }
     if (sweep_err) {
         PYIPM_HIP(hipMemsetAsync(ctx->sweep_sync + 3 * 4096, 0, sizeof(unsigned), ctx->stream));
         ctx->err = "backward sweep (k_bwd_sweep): a poll timed out in an earlier solve; its result was NaN"; return PYIPM_E_HIP;
@@ -1531,43 +1535,14 @@ int assemble_dev(Ctx* ctx, double delta, double delta_c) {
     }
     ctx->cond_active = false;
     PYIPM_HIP(hipMemsetAsync(ctx->anorm, 0, sizeof(unsigned long long), ctx->stream));
-    ctx->asm_split_cols = 0;
     if (g.ncols_local > 0) {
         const int zip = (ctx->keep_zeros && !ctx->storage_exported && ctx->zeros_clean && g.world == 1 && g.mi > 0) ? 1 : 0;
-        // Round 4: the columns of the FIRST group first, the rest as a second launch.  The first group's chain has no bulk update
-        // to hide behind (3.2 ms exposed at N = 32768) and touches nothing but its own columns: factor_all starts it on the
-        // chain's stream as soon as the first launch is through, beside the second (1.3 ms of pure HBM traffic).  The scale of a
-        // static pivot is a maximum over the WHOLE matrix: the word behind it says "pending" until the second launch is through
-        // and the rare reader waits (static_pivot).  The same entries either way.
-        int64_t c1 = 0;
-        if (ctx->asm_split && g.world == 1 && ctx->lookahead && ctx->group_chain && ctx->inpanel32 && ctx->tile_step) {
-            const int64_t G0 = first_group_panels(ctx);
-            if (G0 < g.npanels) c1 = G0 * (int64_t)g.nb;
-        }
-        if (c1 > 0 && c1 < g.ncols_local) {
-            if (!ctx->ev_asm) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_asm, hipEventDisableTiming));
-            PYIPM_HIP(hipMemsetAsync(ctx->anorm + 1, 0x01, sizeof(unsigned long long), ctx->stream));      // pending
-            dim3 grid1a((unsigned)((g.Npad + 511) / 512), (unsigned)(c1 / 16));
-            hipLaunchKernelGGL(k_assemble, grid1a, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
-                               ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, ctx->sharded,
-                               zip, (int64_t)0, 0);
-            PYIPM_KCHECK();
-            PYIPM_HIP(hipEventRecord(ctx->ev_asm, ctx->stream));
-            dim3 grid1b((unsigned)((g.Npad + 511) / 512), (unsigned)((g.ncols_local - c1 + 15) / 16));
-            hipLaunchKernelGGL(k_assemble, grid1b, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
-                               ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, ctx->sharded,
-                               zip, c1, 0);
-            PYIPM_KCHECK();
-            PYIPM_HIP(hipMemsetAsync(ctx->anorm + 1, 0, sizeof(unsigned long long), ctx->stream));         // complete
-            ctx->asm_split_cols = c1;
-        } else {
         dim3 grid; int tri = 0;
         asm_grid(ctx, g, &grid, &tri);
         hipLaunchKernelGGL(k_assemble, grid, dim3(256), 0, ctx->stream, ctx->A, g.Npad, g, ctx->d2L, ctx->ld_d2L,
                            ctx->Je, ctx->ld_Je, ctx->Ji, ctx->ld_Ji, ctx->s, ctx->lda, ctx->eps, delta, delta_c, ctx->anorm, 0, ctx->sharded,
                            zip, (int64_t)0, tri);
         PYIPM_KCHECK();
-        }
     }
     // the zeros of this assembly survive a factorisation of finite numbers (every update that reaches them adds an exact zero);
     // whatever else may write into the storage clears the flag (zeros_dirty)
@@ -1667,21 +1642,12 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
     // does group grp run as a tile chain (factor_group)?
     auto chain_group = [&](int64_t grp) -> bool {
         const bool fast = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)grp];
-        return ctx->group_chain && ctx->inpanel32 && !fast && gsize(grp) * (g.nb / TB) <= 32 && g.nb % 128 == 0;
+        return ctx->group_chain && !fast && gsize(grp) * (g.nb / TB) <= 32 && g.nb % 128 == 0;
     };
-    // all panels of one group on stream S; with_early: every panel but the last records the event its early head waits for
-    auto run_group = [&](int64_t grp, hipStream_t S, bool with_early) -> int {
+    // all panels of one group on stream S
+    auto run_group = [&](int64_t grp, hipStream_t S) -> int {
         const int64_t pA = ctx->grp_first[(size_t)grp], nA = gsize(grp);
-        auto done = [&](int64_t q, hipStream_t used) -> int {
-            int r2 = after_panel(q, used); if (r2) return r2;
-            if (with_early && q + 1 < pA + nA) {
-                while (ctx->ev_early.size() <= (size_t)(q - pA)) {
-                    hipEvent_t e; PYIPM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_early.push_back(e);
-                }
-                PYIPM_HIP(hipEventRecord(ctx->ev_early[(size_t)(q - pA)], used));
-            }
-            return 0;
-        };
+        auto done = [&](int64_t q, hipStream_t used) -> int { return after_panel(q, used); };
         if (chain_group(grp)) return factor_group(ctx, pA, nA, S, done);
         for (int64_t q = pA; q < pA + nA; ++q) {
             if (!s_done_early[(size_t)q]) { int r2 = factor_panel(ctx, q, S, true); if (r2) return r2; }
@@ -1716,70 +1682,13 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         s_early = true;
         return 0;
     };
-    // (round 4) the assembly came as two launches and the second may still be running on the main stream: the first group, which
-    // touches only its own columns, runs on the chain's stream behind the first launch; the main stream joins it before the
-    // first head and the first bulk update.
-    bool g0_side = false, first_early = false;
-    if (ctx->asm_split_cols > 0 && ngroups > 1 && gsize(0) * (int64_t)g.nb == ctx->asm_split_cols && chain_group(0) && ctx->ev_asm &&
-        ctx->head_on_side) {
-        if (!ctx->ev_main) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
-        PYIPM_HIP(hipEventRecord(ctx->ev_main, ctx->stream));                      // everything the main stream has done: the whole assembly
-        PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_asm, 0));
-        { int r0 = ensure_rest_stream(ctx); if (r0) return r0; }
-        PYIPM_HIP(hipStreamWaitEvent(ctx->rest, ctx->ev_asm, 0));
-        rc = factor_begin(ctx, ctx->side); if (rc) return rc;                      // statistics reset ahead of the first tile kernel
-        rc = run_group(0, ctx->side, false); if (rc) return rc;
-        PYIPM_HIP(hipEventRecord(ctx->ev_panel, ctx->side));
-        PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
-        g0_side = true; (void)g0_side;
-    } else if (ctx->early_first && ctx->early_head && ctx->lookahead && ctx->head_on_side && ngroups > 2 && gsize(0) >= 2 &&
-               chain_group(0) && chain_group(1) && g.Npad - g.panel_c0(ctx->grp_first[1]) <= ctx->tail_cols) {
-        // Chain-bound from the first group on (small systems): the first group runs on the chain's stream and every panel of
-        // it but the last updates the second group's columns as soon as it is factored, on the main stream (the early heads of
-        // the tail regime, applied to the first group): the head that the second chain waits for is one panel's (K = nb), not
-        // the group's.  The same products in the same order.
-        rc = factor_begin(ctx); if (rc) return rc;
-        rc = enqueue_s_early(ctx->stream); if (rc) return rc;
-        PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));             // the assembly, the reset of the statistics
-        PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_head, 0));
-        mark("chain+rows begin", 0, ctx->side);
-        rc = run_group(0, ctx->side, true); if (rc) return rc;
-        mark("chain+rows end", 0, ctx->side);
-        first_early = true;
-    } else {
-        rc = factor_begin(ctx); if (rc) return rc;
-        rc = enqueue_s_early(ctx->stream); if (rc) return rc;
-        mark("chain+rows begin", 0, ctx->stream);
-        rc = run_group(0, ctx->stream, false); if (rc) return rc;
-        mark("chain+rows end", 0, ctx->stream);
-    }
-    ctx->asm_split_cols = 0;
-    std::vector<char> early((size_t)np, 0);       // panel's contribution to the NEXT group's columns already applied
+    rc = factor_begin(ctx); if (rc) return rc;
+    rc = enqueue_s_early(ctx->stream); if (rc) return rc;
+    mark("chain+rows begin", 0, ctx->stream);
+    rc = run_group(0, ctx->stream); if (rc) return rc;
+    mark("chain+rows end", 0, ctx->stream);
     bool across_prev = false;
-    if (group_trace) fprintf(stderr, "[pyipm group trace] first group: %s, %lld groups\n", first_early ? "early heads" : (g0_side ? "asm split" : "plain"), (long long)ngroups);
-    if (first_early) {
-        const int64_t n0 = gsize(0), p1 = ctx->grp_first[1], n1 = gsize(1);
-        for (int64_t q = 0; q + 1 < n0; ++q) {
-            PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_early[(size_t)q], 0));
-            // (the second group's columns, K = one panel; same launch form as the early heads of the group loop)
-            const int64_t tc0 = g.panel_c0(p1);
-            if (ctx->inpanel32 && g.Npad - tc0 <= ctx->head32_rows) {
-                int K = (int)g.panel_w(q); int64_t cols = 0;
-                for (int64_t t = p1; t < p1 + n1; ++t) cols += g.panel_w(t);
-                int64_t pa0, pa1, pb0, pb1;
-                active_ranges(ctx, g.panel_c0(q), g.panel_c0(q) + K, &pa0, &pa1, &pb0, &pb1);
-                hipLaunchKernelGGL(k_inpanel_update, dim3((unsigned)((g.Npad - tc0) / 32), (unsigned)(cols / TB)), dim3(256), 0,
-                                   ctx->stream, ctx->A, g.Npad, g.local_c0(p1), ctx->A + g.local_c0(q) * g.Npad, g.Npad,
-                                   wbuf(ctx, q), g.Npad, tc0, K, tc0, g.Npad, pa0, pa1, pb0, pb1, ctx->side_prio);
-                PYIPM_KCHECK();
-            } else {
-                rc = timed_update(ctx, q, 1, p1, n1, ctx->stream); if (rc) return rc;
-            }
-            early[(size_t)q] = 1;
-        }
-        PYIPM_HIP(hipEventRecord(ctx->ev_panel, ctx->side));
-        PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
-    }
+    if (group_trace) fprintf(stderr, "[pyipm group trace] %lld groups\n", (long long)ngroups);
     for (int64_t grp = 0; grp + 1 < ngroups; ++grp) {
         const int64_t p0 = ctx->grp_first[(size_t)grp], n0 = gsize(grp), p1 = p0 + n0, n1 = gsize(grp + 1);
         if (ctx->lookahead) {
@@ -1789,8 +1698,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             const bool fast_src = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)grp];
             auto head_from = [&](int64_t q0, int64_t nq, int64_t tp, int64_t tn, hipStream_t hs, bool split = false) -> int {
                 const int64_t tc0 = g.panel_c0(tp);
-                if (split && ctx->inpanel32 && !fast_src &&
-                    g.Npad - tc0 <= (ctx->head32_rows > ctx->head_split_rows ? ctx->head32_rows : ctx->head_split_rows)) {   // (where the chain is the bound)
+                if (split && !fast_src && g.Npad - tc0 <= ctx->head32_rows) {   // (where the chain is the bound)
                     // The chain of the target group needs the head only inside that group's diagonal block (rows [tc0, tend));
                     // the rows below it are first read by the group's rows stream.  Two launches: the block on the chain's
                     // stream, the rest on ctx->rest behind it -- the same entries, the same operations.
@@ -1824,7 +1732,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
                     }
                     return 0;
                 }
-                if (ctx->inpanel32 && !fast_src && g.Npad - tc0 <= ctx->head32_rows) {
+                if (!fast_src && g.Npad - tc0 <= ctx->head32_rows) {
                     int K = 0; int64_t cols = 0;
                     for (int64_t q = q0; q < q0 + nq; ++q) K += (int)g.panel_w(q);
                     for (int64_t q = tp; q < tp + tn; ++q) cols += g.panel_w(q);
@@ -1848,44 +1756,6 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             const bool nxt_fast = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)(grp + 1)];
             hipStream_t cs = (nxt_fast && ctx->fast_on_main) ? ctx->stream : ctx->side;      // where the next group runs
             hipStream_t hs = ctx->stream;
-            // Fused head (round 3, bulk-bound phase): no head launch at all.  The bulk update of this group also covers the
-            // next group's columns, with THEIR tiles first in its list; each of them bumps a device counter when its C tile
-            // is stored, and the next group's chain starts behind a one-wave kernel that waits for the count.  The head was
-            // 10 % of the update flops running as a second MFMA kernel beside the bulk launch (bulk 54 TF/s with it, 65
-            // without); as the first tiles of the bulk launch it runs at the bulk kernel's own rate.
-            bool fused = false;
-            {
-                bool any_early = false;
-                for (int64_t q = p0; q < p0 + n0; ++q) any_early = any_early || early[(size_t)q];
-                fused = ctx->fused_head && ctx->xcd_swizzle && ctx->bulk_waves == 8 && !fast_src && !nxt_fast &&
-                        cs == ctx->side && !any_early && g.world == 1 && g.Npad - g.panel_c0(p1) > ctx->persist_rows &&
-                        g.Npad - g.panel_c0(p1) > ctx->fused_head_rows &&
-                        (size_t)grp < ctx->n_head_counters;
-            }
-            if (fused) {
-                // (the wait kernel below reads a counter that factor_begin reset on the main stream -- without a host
-                //  synchronisation since round 4: the chain's stream is ordered behind it)
-                PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
-                PYIPM_HIP(hipStreamWaitEvent(cs, ctx->ev_head, 0));
-                unsigned nhead = 0;
-                unsigned* ctr = ctx->head_counters + grp;
-                const int hct = (int)(n1 * (g.nb / 128));
-                rc = timed_update(ctx, p0, n0, p1, np - p1, nullptr, hct, ctr, &nhead, /*list_only=*/true); if (rc) return rc;
-                if (nhead == 0) fused = false;
-                else {
-                    hipLaunchKernelGGL(k_wait_counter, dim3(1), dim3(64), 0, cs, ctr, nhead, (unsigned long long)3.0e8,     // 3 s
-                                       reinterpret_cast<int*>(ctx->head_counters + ctx->n_head_counters));
-                    PYIPM_KCHECK();
-                    const bool do_early_f = false;
-                    rc = run_group(grp + 1, cs, do_early_f); if (rc) return rc;
-                    PYIPM_HIP(hipEventRecord(ctx->ev_panel, cs));
-                    rc = timed_update(ctx, p0, n0, p1, np - p1, nullptr, hct, ctr, &nhead); if (rc) return rc;   // bulk incl. the head tiles
-                    if (!ctx->ev_main) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
-                    PYIPM_HIP(hipEventRecord(ctx->ev_main, ctx->stream));
-                    PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
-                    continue;
-                }
-            }
             // (the FIRST head stays on the main stream also when group 0 ran on the chain's stream: nothing runs beside it either
             //  way, and as a main-stream launch it takes the bulk instance and is part of the trailing figures, as in rounds 1-3)
             // (round 5) Lookahead ACROSS the slack block.  With its panels run up front the slack group between the last x group
@@ -1895,8 +1765,8 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             // is treated as the lookahead target: a head (split: its diagonal block on the chain's stream, the rows below on the
             // rows stream) applies this group's contribution to its columns, the bulk update starts beyond them.  The same
             // products in the same order per entry (x groups in order, then the slack block's diagonal update).
-            const bool across = s_early && ctx->s_across && nxt_fast && !fast_src && grp > 0 && grp + 2 < ngroups &&
-                                !ctx->grp_fast[(size_t)(grp + 2)] && chain_group(grp + 2) && ctx->head_on_side && ctx->head_split;
+            const bool across = s_early && nxt_fast && !fast_src && grp > 0 && grp + 2 < ngroups &&
+                                !ctx->grp_fast[(size_t)(grp + 2)] && chain_group(grp + 2) && ctx->head_on_side;
             const int64_t pT = across ? ctx->grp_first[(size_t)(grp + 2)] : 0, nT = across ? gsize(grp + 2) : 0;
             if (grp > 0 && ctx->head_on_side && (cs == ctx->side || across)) {
                 // (recorded at the end of the iteration before.  Behind an `across` iteration the source is the slack group: its
@@ -1907,9 +1777,8 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
                 if (s_early && fast_src) PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_sfast, 0));   // (k_s_schur reads the slack columns)
             }
             {
-                int64_t q = p0;
-                while (q < p0 + n0 && early[(size_t)q]) ++q;                       // applied early (always a prefix of the group)
-                const bool split = ctx->head_split && chain_group(grp + 1) && cs != ctx->stream;
+                const int64_t q = p0;
+                const bool split = chain_group(grp + 1) && cs != ctx->stream;
                 mark("head begin", grp, hs);
                 // (a head INTO the slack block is structurally empty: no x column reaches an s column, and a slack column's only
                 //  update is a diagonal entry of the multiplier block -- no launch, 10-15 us of the chain's path each)
@@ -1922,23 +1791,13 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             if (hs == ctx->stream && cs == ctx->side) {
                 PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->stream));
                 PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_head, 0));
-            } else if (hs == ctx->side && (ctx->head_serial == 1 || (ctx->head_serial == 2 && g.Npad - g.panel_c0(p1) <= ctx->persist_rows))) {
-                // the bulk update of this group starts behind the head instead of beside it (the head is what the next chain
-                // waits for; sharing the GPU with the bulk launch stretches it)
-                PYIPM_HIP(hipEventRecord(ctx->ev_head, ctx->side));
-                PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_head, 0));
             }
-            // early heads: in the tail regime the panels of the NEXT group except its last one update the group after it
-            // as soon as each is factored, on the main stream behind this group's bulk update
-            // (round 5: also behind a slack-block source group -- its "bulk update" is one k_s_schur launch, the main stream is free)
-            const bool do_early = ctx->early_head && grp + 2 < ngroups && n1 >= 2 && !nxt_fast && (!fast_src || ctx->early_first) &&
-                                  g.Npad - g.panel_c0(p1) <= ctx->tail_cols;
             mark("chain+rows begin", grp + 1, cs);
             if (s_early && nxt_fast) {                                   // its kernels ran up front: whoever follows on cs (and the
                 PYIPM_HIP(hipStreamWaitEvent(cs, ctx->ev_sfast, 0));      // update stream, for k_s_schur) is ordered behind them
                 if (cs != ctx->stream) PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_sfast, 0));
             }
-            rc = run_group(grp + 1, cs, do_early); if (rc) return rc;
+            rc = run_group(grp + 1, cs); if (rc) return rc;
             mark("chain+rows end", grp + 1, cs);
             PYIPM_HIP(hipEventRecord(ctx->ev_panel, cs));
             mark("bulk begin", grp, ctx->stream);
@@ -1947,15 +1806,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             else
             rc = timed_update(ctx, p0, n0, p1 + n1, np - (p1 + n1)); if (rc) return rc;   // bulk (overlaps the side stream)
             mark("bulk end", grp, ctx->stream);
-            if (do_early) {
-                const int64_t p2 = p1 + n1, n2 = gsize(grp + 2);
-                for (int64_t q = p1; q + 1 < p1 + n1; ++q) {
-                    PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_early[(size_t)(q - p1)], 0));
-                    rc = head_from(q, 1, p2, n2, ctx->stream); if (rc) return rc;
-                    early[(size_t)q] = 1;
-                }
-            }
-            // what the next head must not overtake on the main stream: this group's bulk update and the early heads -- recorded
+            // what the next head must not overtake on the main stream: this group's bulk update -- recorded
             // BEFORE the main stream starts waiting for the side stream (the head would otherwise wait for its own stream,
             // two stream crossings for nothing)
             if (!ctx->ev_main) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_main, hipEventDisableTiming));
@@ -1963,7 +1814,7 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_panel, 0));
         } else {
             rc = timed_update(ctx, p0, n0, p1, np - p1); if (rc) return rc;
-            rc = run_group(grp + 1, ctx->stream, false); if (rc) return rc;
+            rc = run_group(grp + 1, ctx->stream); if (rc) return rc;
         }
     }
     if (fuse_forward) {                     // join: the main stream continues after the forward pass
@@ -2261,10 +2112,8 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     if (ctx->ev_split) hipEventDestroy(ctx->ev_split);
     if (ctx->ev_sfast) hipEventDestroy(ctx->ev_sfast);
     if (ctx->ev_main) hipEventDestroy(ctx->ev_main);
-    if (ctx->ev_asm) hipEventDestroy(ctx->ev_asm);
     for (auto e : ctx->ev_band) hipEventDestroy(e);
     for (auto e : ctx->ev_done) hipEventDestroy(e);
-    for (auto e : ctx->ev_early) hipEventDestroy(e);
     if (ctx->stg_d2L) hipFree(ctx->stg_d2L);
     if (ctx->stg_Je) hipFree(ctx->stg_Je);
     if (ctx->stg_Ji) hipFree(ctx->stg_Ji);
@@ -2273,7 +2122,6 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     if (ctx->JT) hipFree(ctx->JT);
     if (ctx->Jx) hipFree(ctx->Jx);
     if (ctx->cond_pos && !ctx->batched) hipFree(ctx->cond_pos);      // (a batched handle's lives in its workspace)
-    if (ctx->head_counters) hipFree(ctx->head_counters);
     if (ctx->sweep_sync) hipFree(ctx->sweep_sync);
     if (ctx->chain_sync) hipFree(ctx->chain_sync);
     if (ctx->sweep_buf) hipFree(ctx->sweep_buf);
@@ -3054,11 +2902,8 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "expert")) { ctx->expert = (int)value != 0; return PYIPM_OK; }
     {   // expert switches (include/pyipm_newton.h): measurement knobs, test hooks, parked experiments
         static const char* const kExpert[] = {
-            "tail_group", "tail_cols", "xcd_swizzle", "side_prio", "bulk_waves", "group_chain", "pending_left_rows", "tile_step",
-            "head_on_side", "head_serial", "head_split", "head_split_rows", "fast_on_main", "rest_prio", "s_fast", "bwd_diag4",
-            "head_waves", "inpanel32", "fuse_scale_update", "pending32_rows", "head32_rows", "head32_rows_dist", "early_head",
-            "bulk_bn_rows", "bulk_bn_all", "bulk_bn_min_k", "sweep_max_blocks", "asm_tri", "asm_split", "fused_head",
-            "fused_head_rows", "dist_head_split", "tile_waves", "tile_upb", "tile8_rows", "tile_ny3", "tile_free_cus", "tile8_dist", "chain_cpy", "bc_per_problem", "s_early", "early_first", "s_across", "debug_fault", "debug_timeline_ptr"};
+            "tail_group", "group_chain", "tile_step", "tile_waves", "bc_per_problem", "chain_cpy", "chain_whole", "chain_lds_kb",
+            "sweep_max_blocks", "debug_fault", "debug_timeline_ptr", "debug_chain_ptr"};
         bool is_expert = false;
         for (const char* e : kExpert) if (!strcmp(name, e)) { is_expert = true; break; }
         if (is_expert && !ctx->expert) {
@@ -3070,28 +2915,19 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
         }
     }
     if (!strcmp(name, "pivtol_rel")) { ctx->pivtol_rel = value; return PYIPM_OK; }
-    if (!strcmp(name, "head_split_rows")) { ctx->head_split_rows = (int64_t)value; return PYIPM_OK; }
-    if (!strcmp(name, "fused_head")) { ctx->fused_head = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "asm_tri")) { ctx->asm_tri = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "asm_split")) { ctx->asm_split = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "fused_head_rows")) { ctx->fused_head_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "reserve_cus")) { ctx->reserve_cus = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "persist_rows")) { ctx->persist_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "bulk_bn")) { ctx->bulk_bn = (int)value == 256 ? 256 : 128; return PYIPM_OK; }
-    if (!strcmp(name, "bulk_bn_min_k")) { ctx->bulk_bn_min_k = (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "tile_blocked")) { ctx->tile_blocked = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "tile_waves")) { ctx->tile_waves = (int)value == 8 ? 8 : 4; return PYIPM_OK; }
-    if (!strcmp(name, "tile_chain")) { int v = (int)value; ctx->tile_chain = v < 0 ? 0 : (v > 2 ? 2 : v); return PYIPM_OK; }
-    if (!strcmp(name, "chain_cpy")) { int v = (int)value; ctx->chain_cpy = v < 1 ? 1 : (v > 32 ? 32 : v); return PYIPM_OK; }
-    if (!strcmp(name, "tile8_rows")) { ctx->tile8_rows = (int64_t)value; return PYIPM_OK; }
-    if (!strcmp(name, "tile_ny3")) { ctx->tile_ny3 = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "tile_free_cus")) { ctx->tile_free_cus = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "tile_blocked")) { ctx->tile_blocked = (int)value != 0; ctx->tile_blocked_user = true; return PYIPM_OK; }
+    if (!strcmp(name, "tile_waves")) {              // 4 | 8 (eight waves where a whole CU is to be had: first group, last 12288 rows) | 9 (eight waves everywhere: tests)
+        const int v = (int)value; ctx->tile_waves = v >= 8 ? 8 : 4; ctx->tile8_rows = v == 9 ? ((int64_t)1 << 40) : 12288; return PYIPM_OK; }
     if (!strcmp(name, "bc_per_problem")) { ctx->bc_per_problem = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "early_first")) { ctx->early_first = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "s_across")) { ctx->s_across = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "s_early")) { ctx->s_early = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "tile8_dist")) { ctx->tile8_dist = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "tile_upb")) { ctx->tile_upb = (int)value < 0 ? 0 : ((int)value > 2 ? 2 : (int)value); return PYIPM_OK; }
+    if (!strcmp(name, "tile_chain")) { int v = (int)value; ctx->tile_chain = v < 0 ? 0 : (v > 2 ? 2 : v); return PYIPM_OK; }
+    if (!strcmp(name, "debug_chain_ptr")) {         // diagnostics (tools/chain_clock.py): device buffer of 64 x CHAIN_DBG_WORDS u64, one region per chain launch from now on
+        ctx->chain_dbg = (unsigned long long*)(uintptr_t)(unsigned long long)value; ctx->chain_dbg_launch = 0; return PYIPM_OK; }
+    if (!strcmp(name, "chain_lds_kb")) { int v = (int)value; ctx->chain_lds_kb = v < 0 ? 0 : (v > 110 ? 110 : v); return PYIPM_OK; }
+    if (!strcmp(name, "chain_whole")) { ctx->chain_whole = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "chain_cpy")) { int v = (int)value; ctx->chain_cpy = v < 1 ? 1 : (v > 32 ? 32 : v); return PYIPM_OK; }
     if (!strcmp(name, "profile")) { ctx->profile = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "debug_fault")) { ctx->debug_fault = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "refine_target")) { ctx->refine_target = value; return PYIPM_OK; }
@@ -3103,7 +2939,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
         // a batched handle's tile inversion: blocked with the condensed form (4 tiles per problem: the chain is what is left --
         // 0.39 vs 0.49 ms for 512 x (256, 0, 256)), the single sweeps with the full one (12 tiles: throughput-bound, r03);
         // set "tile_blocked" after "condensed" to choose otherwise
-        if (ctx->batched) ctx->tile_blocked = ctx->condensed ? 1 : 0;
+        if (ctx->batched && !ctx->tile_blocked_user) ctx->tile_blocked = ctx->condensed ? 1 : 0;   // (an explicit choice stands: ADVICE r5)
         return PYIPM_OK; }
     if (!strcmp(name, "condensed_sigma_max")) { ctx->cond_sigma_max = value; return PYIPM_OK; }
     if (!strcmp(name, "condensed_refine")) { ctx->cond_min_refine = (int)value < 0 ? 0 : (int)value; return PYIPM_OK; }
@@ -3111,42 +2947,23 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "group")) {           // may only shrink below the create-time value (workspace is sized for it)
         int v = (int)value; if (v < 1 || v > default_group(ctx->g.world, ctx->g.nb)) { ctx->err = "group out of range"; return PYIPM_E_BADARG; }
         ctx->group = v; return PYIPM_OK; }
-    if (!strcmp(name, "bulk_waves")) { ctx->bulk_waves = (int)value == 8 ? 8 : 4; return PYIPM_OK; }
-    if (!strcmp(name, "s_fast")) { ctx->s_fast = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "skip_zeros")) { ctx->skip_zeros = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tail_group")) { ctx->tail_group = (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "tail_cols")) { ctx->tail_cols = (int64_t)value; return PYIPM_OK; }
-    if (!strcmp(name, "xcd_swizzle")) { ctx->xcd_swizzle = (int)value; return PYIPM_OK; }
     { bool handled = false; int rc = dist_set_option(ctx, name, value, &handled); if (handled) return rc; }
-    if (!strcmp(name, "inpanel32")) { ctx->inpanel32 = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "fuse_scale_update")) { ctx->fuse_su = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "tile_step")) { ctx->tile_step = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "group_chain")) { ctx->group_chain = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "bwd_diag4")) { ctx->bwd_diag4 = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "head_on_side")) { ctx->head_on_side = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "head_split")) { ctx->head_split = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "fast_on_main")) { ctx->fast_on_main = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "rest_prio")) { ctx->rest_prio = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "keep_zeros")) { ctx->keep_zeros = (int)value != 0; ctx->zeros_clean = false; ctx->storage_exported = false; return PYIPM_OK; }
-    if (!strcmp(name, "pending_left_rows")) { ctx->pending_left_rows = (int64_t)value; return PYIPM_OK; }
-    if (!strcmp(name, "head_waves")) { ctx->head_waves = ((int)value == 8) ? 8 : 4; return PYIPM_OK; }
-    if (!strcmp(name, "head_serial")) { ctx->head_serial = (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "pending32_rows")) { ctx->pending32_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "wide_sub")) { ctx->wide_sub = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "sweep_persist")) { ctx->sweep_persist = (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "bulk_bn_all")) { ctx->bulk_bn_all = (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "bulk_bn_rows")) { ctx->bulk_bn_rows = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "sweep_max_blocks")) { ctx->sweep_max_blocks = (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "head32_rows")) { ctx->head32_rows = (int64_t)value; return PYIPM_OK; }
-    if (!strcmp(name, "early_head")) { ctx->early_head = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "head32_rows_dist")) { ctx->head32_rows_dist = (int64_t)value; return PYIPM_OK; }
     if (!strcmp(name, "fuse_forward")) { ctx->fuse_forward = (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "side_prio")) { ctx->side_prio = (int)value; return PYIPM_OK; }
     if (!strcmp(name, "debug_timeline_ptr")) {      // diagnostics: device buffer of 8 x u64 per block (pointer passed as double-encoded integer halves is lossy; use set via low 52 bits)
         ctx->dbg_buf = (unsigned long long*)(uintptr_t)(unsigned long long)value; return PYIPM_OK; }
     ctx->err = std::string("unknown option ") + name;
     return PYIPM_E_BADARG;
 } PYIPM_CATCH_H(h)
+
+int pyipm_newton_abi_version(void) { return PYIPM_NEWTON_ABI_VERSION; }
 
 int pyipm_mfma_f64_peak(int device, int iters, double* tflops) try {
     if (!tflops || iters <= 0) return PYIPM_E_BADARG;

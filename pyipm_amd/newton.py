@@ -46,6 +46,9 @@ class NewtonError(RuntimeError):
 _lib = None
 
 
+ABI_VERSION = 6          # PYIPM_NEWTON_ABI_VERSION of include/pyipm_newton.h this file's signatures were written against
+
+
 def load_library(path: str | None = None):
     """dlopen the HIP core; fails loudly when it has not been built."""
     global _lib
@@ -135,12 +138,16 @@ def load_library(path: str | None = None):
         "pyipm_newton_kkt_matvec_dist": (c_int, [ctxp, c_void_p, c_void_p, c_int]),
         "pyipm_newton_step_dist": (c_int, [ctxp, c_double, c_double, c_int, c_void_p, POINTER(FactorStats), c_int]),
         "pyipm_newton_dist_timings": (c_int, [ctxp, POINTER(c_double)]),
+        "pyipm_newton_abi_version": (c_int, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
     lib._pyipm_symbols = tuple(sig)
+    if lib.pyipm_newton_abi_version() != ABI_VERSION:      # (an argument list changed under this binding: refuse before any call)
+        raise NewtonError("%s speaks interface version %d, this binding was written against %d (include/pyipm_newton.h: "
+                          "PYIPM_NEWTON_ABI_VERSION) -- rebuild the library" % (p, lib.pyipm_newton_abi_version(), ABI_VERSION))
     if path is None:
         _lib = lib
     return lib

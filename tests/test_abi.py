@@ -115,15 +115,28 @@ def test_bench_default_panel_width():
     assert bench.default_panel_width(8, 131072) == 1024 and bench.default_panel_width(2, 65536) == 1024
 
 
+def src_all():
+    out = ""
+    d = os.path.join(ROOT, "pyipm_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            out += open(os.path.join(d, f)).read()
+    return out
+
+
 def test_option_lists_of_header_and_sources_agree():
-    """include/pyipm_newton.h documents 25 public options and names the expert ones: both lists against
+    """include/pyipm_newton.h documents 28 public options and names the 12 expert ones -- at most 40 names in all, 15 expert
+    (round 6 removed 35 switches and the code behind the ones whose measurements lost): both lists against
     the option names the sources actually compare with, and against the table that gates the expert ones -- without a GPU."""
     hdr = open(os.path.join(ROOT, "include", "pyipm_newton.h")).read()
     pub = re.search(r"PUBLIC OPTIONS:(.*?)\n \*\n", hdr, re.S).group(1)
     exp = re.search(r"EXPERT OPTIONS:(.*?)\n \*   \(which stream", hdr, re.S).group(1)
     names = lambda blk: [w for w in re.sub(r"[*\n]", " ", blk).replace(",", " ").split() if w]     # noqa: E731
     pub, exp = names(pub), names(exp)
-    assert len(pub) <= 25 and len(set(pub)) == len(pub) and len(set(exp)) == len(exp) and not set(pub) & set(exp)
+    assert len(pub) + len(exp) <= 40 and len(exp) <= 15 and len(set(pub)) == len(pub) and len(set(exp)) == len(exp) and not set(pub) & set(exp)
+    for gone in ("early_head", "early_first", "fused_head", "fused_head_rows", "head_split", "head_split_rows", "head_serial", "tile_ny3",
+                 "bulk_bn_all", "asm_split", "inpanel32", "s_across"):
+        assert gone not in pub and gone not in exp and ("ctx->" + gone) not in src_all(), gone
     src = ""
     for f in ("pyipm_newton.hip", "dist_impl.hpp"):
         src += open(os.path.join(ROOT, "pyipm_amd", "csrc", f)).read()

@@ -140,3 +140,13 @@ def test_oracle_lu_at_the_metric_size():
     (inertia, backward error from the blocks).  About a minute of host LU at 16 BLAS threads.  Same assertions as the N = 26624
     test; 78 % of the bulk flops run on k_update<256,true,8> here."""
     _oracle_lu_check(16384, 4096, 6144, 0, 0.7)
+
+
+def test_oracle_lu_at_config3_size():
+    """BASELINE.json configs[2], the "MFMA roofline run": n=16384, me=8192, mi=8192 -> N=40960, bench.py's seed, default options,
+    against the oracle's LU (pyipm.py:1720-1721) -- the last single-GPU BASELINE size that was checked through properties only
+    (round 4's unwritten-memory read in the wide update tile was invisible to every property test).  About
+    two minutes of host LU at 16 BLAS threads, 27 GB for the oracle's matrix and its factors.  Same assertions as at N = 32768:
+    sampled rows of the assembly bit for bit, residual 1e-13, dz <= 1e-10, inertia; at least 70 % of the bulk flops on
+    k_update<256,true,8>."""
+    _oracle_lu_check(16384, 8192, 8192, 0, 0.7)

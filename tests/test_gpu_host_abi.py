@@ -189,6 +189,7 @@ def test_no_exception_crosses_the_abi():
         fresh = NewtonCore(n, me, mi, device=0, nb=128)          # tile lists are cached per handle: use a new one
         fresh.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
         fresh.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+        fresh.set_option("expert", 1)
         fresh.set_option("debug_fault", fault)
         with pytest.raises(NewtonError) as ei:
             fresh.step(0.0, 0.0)

@@ -433,7 +433,8 @@ def test_ragged_multi_group_shapes_vs_oracle(n, me, mi, nb, tail_cols):
     out = []
     for skip in (1, 0):
         core = _core(n, me, mi, nb=nb)
-        core.set_option("tail_cols", tail_cols)
+        core.set_option("expert", 1)
+        core.set_option("tail_group", 2 if tail_cols else 4)        # (group sizes 4 and 2; the column threshold itself is fixed since round 6)
         core.set_option("skip_zeros", skip)
         core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
         core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])

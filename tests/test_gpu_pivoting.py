@@ -350,31 +350,3 @@ def test_ipm_retraces_the_reference_lp_solve():
     assert p.backend.n_static == int(d["n_iter"]) and p.backend.n_unconverged == 0
 
 
-@pytest.mark.parametrize("name", ["lp", "lp_eq", "linear_vars"])
-def test_static_pivots_in_a_first_group_that_starts_before_the_assembly_ends(name):
-    """Round 4: K1 comes as two launches and the first group's chain starts behind the first.  The scale of a static pivot is
-    the largest entry of the WHOLE matrix, so a tile that has to place one waits for the second launch (the "pending" word
-    behind the maximum).  The LP fixtures place static pivots in every x pivot; with panels of 128 and groups of one panel
-    the first group is exactly the launch that runs ahead.  Same direction as the reference's, bit for bit the one of the
-    single-launch assembly."""
-    import torch
-    from pyipm_amd.newton import NewtonCore
-    d, n, me, mi, b = _load(name)
-    outs = {}
-    for split in (1, 0):
-        core = NewtonCore(n, me, mi, device=0, nb=128)
-        for k, v in (("group", 1), ("tail_group", 1), ("asm_split", split)):
-            core.set_option(k, v)
-        core.stage_blocks(b["d2L"], b["Je"], b["Ji"])
-        core.stage_vectors(b["df"], b["ce"], b["ci"], d["s"], d["lda"], mu=float(d["mu"]))
-        res = []
-        for _ in range(3):
-            core.residual(); core.assemble(0.0, 0.0)
-            st = core.factor()
-            res.append(core.solve(flip=True, refine=-1).clone())
-        assert st["n_zero"] >= 64 and core.solve_info()["converged"]
-        assert all(torch.equal(r, res[0]) for r in res)
-        outs[split] = res[0]
-        assert relerr(res[0].cpu().numpy(), d["dz"]) <= 1e-10
-        core.close()
-    assert torch.equal(outs[0], outs[1])

@@ -61,6 +61,7 @@ def test_tile_inversion_blocked_and_single_sweeps(name, H, blocks_expected):
     out = {}
     for blocked in (1, 0):
         core = NewtonCore(n, 0, 0, device=0)
+        core.set_option("expert", 1)
         core.set_option("tile_blocked", blocked)
         buf = torch.zeros(256, dtype=torch.int64, device="cuda")
         core.stage_blocks(np.triu(H) + np.triu(H, 1).T, None, None)
@@ -111,14 +112,14 @@ def test_eight_wave_tile_step_gives_the_bits_of_the_four_wave_one(shape):
     qp = _graded_qp(n, me, mi, seed, decades)
     out = {}
     for key, opts in (("w4", {"tile_waves": 4}),
-                      ("w8", {"tile_waves": 8, "tile8_rows": 1 << 20}),
-                      ("w8_upb1", {"tile_waves": 8, "tile8_rows": 1 << 20, "tile_upb": 1}),
-                      ("w8_upb2_ny3", {"tile_waves": 8, "tile8_rows": 1 << 20, "tile_upb": 2, "tile_ny3": 1}),
-                      ("w8_single_sweeps", {"tile_waves": 8, "tile8_rows": 1 << 20, "tile_blocked": 0}),
+                      ("w8", {"tile_waves": 9}),
+                      ("w8_exposed", {"tile_waves": 8}),
+                      ("w8_single_sweeps", {"tile_waves": 9, "tile_blocked": 0}),
                       ("w4_single_sweeps", {"tile_waves": 4, "tile_blocked": 0})):
         core = NewtonCore(n, me, mi, device=0)
         core.set_option("expert", 1)
         core.set_option("sweep_persist", 0)
+        core.set_option("tile_chain", 0)                  # (the launch-per-tile kernels are what is compared here)
         for k, v in opts.items():
             core.set_option(k, v)
         core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
@@ -130,7 +131,7 @@ def test_eight_wave_tile_step_gives_the_bits_of_the_four_wave_one(shape):
                 out[key] = (dz.clone(), fac, st)
             assert torch.equal(dz, out[key][0]) and torch.equal(fac, out[key][1]), (shape, key, rep)
         core.close()
-    for a, b in (("w4", "w8"), ("w4", "w8_upb1"), ("w4", "w8_upb2_ny3"), ("w4_single_sweeps", "w8_single_sweeps")):
+    for a, b in (("w4", "w8"), ("w4", "w8_exposed"), ("w4_single_sweeps", "w8_single_sweeps")):
         assert torch.equal(out[a][1], out[b][1]), (shape, a, b, "factor storage")
         assert torch.equal(out[a][0], out[b][0]), (shape, a, b, "direction")
         sa, sb = out[a][2], out[b][2]
@@ -156,9 +157,10 @@ def test_tile_chain_in_one_launch_gives_the_bits_of_the_launch_per_tile(shape):
     qp = _graded_qp(n, me, mi, seed, decades)
     out = {}
     for key, opts in (("steps4", {"tile_chain": 0, "tile_waves": 4}),
-                      ("steps8", {"tile_chain": 0, "tile_waves": 8}),
+                      ("steps8", {"tile_chain": 0, "tile_waves": 9}),
                       ("chain", {"tile_chain": 2}),
                       ("chain_exposed", {"tile_chain": 1}),
+                      ("chain_pieces", {"tile_chain": 2, "chain_whole": 0}),
                       ("chain_cpy2", {"tile_chain": 2, "chain_cpy": 2}),
                       ("chain_cpy9", {"tile_chain": 2, "chain_cpy": 9}),
                       ("chain_group2", {"tile_chain": 2, "group": 2, "tail_group": 2}),
@@ -178,7 +180,7 @@ def test_tile_chain_in_one_launch_gives_the_bits_of_the_launch_per_tile(shape):
                 out[key] = (dz.clone(), fac, st)
             assert torch.equal(dz, out[key][0]) and torch.equal(fac, out[key][1]), (shape, key, rep)
         core.close()
-    for a, b in (("steps4", "steps8"), ("steps4", "chain"), ("steps4", "chain_exposed"), ("steps4", "chain_cpy2"), ("steps4", "chain_cpy9"),
+    for a, b in (("steps4", "steps8"), ("steps4", "chain"), ("steps4", "chain_exposed"), ("steps4", "chain_pieces"), ("steps4", "chain_cpy2"), ("steps4", "chain_cpy9"),
                  ("steps4", "chain_group2"), ("steps_single", "chain_single")):
         assert torch.equal(out[a][1], out[b][1]), (shape, a, b, "factor storage")
         assert torch.equal(out[a][0], out[b][0]), (shape, a, b, "direction")

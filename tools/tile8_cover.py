@@ -13,7 +13,7 @@ for shape in [(700, 100, 200, 1, 5.0), (1100, 0, 300, 2, 9.0), (520, 130, 0, 3, 
     res = {}
     for key, opts in (("default", {}), ("no block refinement", {"block_refine": 0}), ("single sweeps", {"tile_blocked": 0})):
         core = NewtonCore(n, me, mi, device=0)
-        core.set_option("tile8_rows", float(1 << 20))
+        core.set_option("tile_waves", 9)                 # (eight waves everywhere)
         for k, v in opts.items():
             core.set_option(k, v)
         core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"]); core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
