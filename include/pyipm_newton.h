@@ -52,7 +52,7 @@ extern "C" {
 #define PYIPM_E_NOMEM        -3   /* workspace missing or too small, or host memory exhausted */
 #define PYIPM_E_NONFINITE    -4   /* NaN/Inf met during factorisation          */
 #define PYIPM_E_NODEVICE     -5   /* no usable HIP device                      */
-#define PYIPM_E_COMM         -6   /* a caller-supplied exchange callback failed */
+#define PYIPM_E_COMM         -6   /* the exchange failed (RCCL / a caller-supplied callback) or a distributed step timed out */
 
 #define PYIPM_MEM_DEVICE      0   /* pointer is device memory (e.g. torch.Tensor.data_ptr()) */
 #define PYIPM_MEM_HOST        1   /* pointer is host memory; the library stages it           */
@@ -351,6 +351,12 @@ int pyipm_newton_stage_blocks_batched(pyipm_newton_ctx* ctx, const double* d2L, 
  * assembly, [6] factorisation, [3] substitutions, [1] the whole step (ms). */
 int pyipm_newton_step_batched(pyipm_newton_ctx* ctx, double delta, double delta_c, double* dz,
                               pyipm_factor_stats* stats, int memkind);
+/* The per-problem statistics of the last pyipm_newton_step_batched (B records), for a step that was called with
+ * stats = NULL -- such a step returns once its launches are enqueued; this call synchronises the handle's stream.  Returns
+ * PYIPM_E_NONFINITE when a problem met NaN/Inf (the records are filled in all the same).  (The reference reads the inertia of
+ * every system eagerly, pyipm.py:1378-1381: one eigendecomposition per problem.) */
+int pyipm_newton_stats_batched(pyipm_newton_ctx* ctx, pyipm_factor_stats* stats);
+
 /* out[b] = |g - Hc raw_b| / |g| for every problem of the last step_batched: Hc applied from the staged blocks with that
  * step's shifts (never from the factor), raw = dz ([batch][N], DEVICE) with the multiplier flip undone.  The guard of the
  * condensed form (the host falls back to the full system when a problem misses its bar) and the batched counterpart of the

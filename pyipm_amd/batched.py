@@ -17,6 +17,34 @@ import numpy as np
 from .newton import ERRORS, MEM_DEVICE, FactorStats, NewtonError, load_library
 
 
+class LazyStats(object):
+    """The per-problem factor statistics of one ``step_all`` -- a list of dicts, read from the device at first use (``len``,
+    indexing, iteration).  Valid until the handle's next step."""
+
+    def __init__(self, owner, step_id):
+        self._owner, self._step_id, self._data = owner, step_id, None
+
+    def _fetch(self):
+        if self._data is None:
+            self._data = self._owner._fetch_stats(self._step_id)
+        return self._data
+
+    def __len__(self):
+        return len(self._fetch())
+
+    def __getitem__(self, i):
+        return self._fetch()[i]
+
+    def __iter__(self):
+        return iter(self._fetch())
+
+    def __eq__(self, other):
+        return list(self._fetch()) == list(other)
+
+    def __repr__(self):
+        return repr(self._fetch())
+
+
 class BatchedNewton(object):
     condensed_tol = 1e-9                   # backward-error bar (against the FULL blocks) a condensed direction must meet
 
@@ -63,6 +91,7 @@ class BatchedNewton(object):
         if rc:
             raise NewtonError("pyipm_newton_create_batched failed: %s" % ERRORS.get(rc, rc))
         self.h, self.batch = h, batch
+        self._step_id = getattr(self, "_step_id", 0) + 1    # (statistics of a step on the old handle are gone)
         for k, v in getattr(self, "_opts", {}).items():
             self._ck(self.lib.pyipm_newton_set_option(self.h, k.encode(), v))
 
@@ -114,9 +143,11 @@ class BatchedNewton(object):
         self._ck(self.lib.pyipm_newton_stage_vectors(self.h, ptr(vecs[0]), ptr(vecs[1]), ptr(vecs[2]), ptr(vecs[3]),
                                                      ptr(vecs[4]), float(mu), float(eps), MEM_DEVICE))
         out = torch.empty((B, self.N), dtype=torch.float64, device=self.device)
-        st = (FactorStats * B)()
-        self._ck(self.lib.pyipm_newton_step_batched(self.h, float(delta), float(delta_c), ptr(out), st, MEM_DEVICE))
-        stats = [x.as_dict() for x in st]
+        # the step is five launches and returns once they are enqueued; the B statistics records stay on the device until somebody
+        # looks at them (LazyStats: round 6 -- copying and unpacking 512 records per step was a third of the step's wall time)
+        self._ck(self.lib.pyipm_newton_step_batched(self.h, float(delta), float(delta_c), ptr(out), None, MEM_DEVICE))
+        self._step_id += 1
+        stats = LazyStats(self, self._step_id)
         if self._opts_get("condensed") and self.guard and mi:
             # the condensed form's guard (as HipNewtonBackend's for a single system): right inertia, no static pivot, and a
             # direction that satisfies the FULL blocks; otherwise the batch is redone with the full 4-block system
@@ -128,11 +159,23 @@ class BatchedNewton(object):
                 self.n_condensed_fallback += 1
                 self._ck(self.lib.pyipm_newton_set_option(self.h, b"condensed", 0.0))
                 try:
-                    self._ck(self.lib.pyipm_newton_step_batched(self.h, float(delta), float(delta_c), ptr(out), st, MEM_DEVICE))
+                    self._ck(self.lib.pyipm_newton_step_batched(self.h, float(delta), float(delta_c), ptr(out), None, MEM_DEVICE))
+                    self._step_id += 1
+                    stats = LazyStats(self, self._step_id)
+                    stats._fetch()                      # (read while the handle is in the full form)
                 finally:
                     self._ck(self.lib.pyipm_newton_set_option(self.h, b"condensed", 1.0))
-                stats = [x.as_dict() for x in st]
         return out, stats
+
+    def _fetch_stats(self, step_id):
+        if step_id != self._step_id:
+            raise NewtonError("the statistics of an earlier step_all are gone: the handle keeps the last step's only -- read them "
+                              "(len / index / iterate) before the next step")
+        st = (FactorStats * self.batch)()
+        rc = self.lib.pyipm_newton_stats_batched(self.h, st)
+        if rc and rc != -4:                                   # (-4 = PYIPM_E_NONFINITE: the records say which problems)
+            self._ck(rc)
+        return [x.as_dict() for x in st]
 
     def _opts_get(self, name):
         return getattr(self, "_opts", {}).get(name, 0.0)

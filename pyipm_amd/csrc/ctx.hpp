@@ -305,6 +305,30 @@ inline void set_err_noexcept(H* h, const char* what) noexcept {
 #define PYIPM_CATCH_SIZE  PYIPM_CATCH_CORE(PYIPM_SETERR_NONE, 0, 0)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+struct Carve { size_t off = 0; size_t take(size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; } };
+
+// Rows of the staged blocks a rank works on (the columns it owns: column j of the lower triangle is row j of
+// triu(d2L) | Je | Ji), in local column order; kernels_assemble.hpp.
+struct RowMap {
+    int64_t nloc;                 // rows this rank works on
+    int nb, world, rank, sharded;
+    __host__ __device__ int64_t glob(int64_t r) const {
+        return world == 1 ? r : ((r / nb) * world + rank) * (int64_t)nb + r % nb;
+    }
+    __host__ __device__ int64_t brow(int64_t r) const { return sharded ? r : glob(r); }
+};
+inline RowMap make_rowmap(const Geo& g, int sharded) {
+    RowMap m; m.nb = g.nb; m.world = g.world; m.rank = g.rank; m.sharded = sharded;
+    int64_t c = 0;
+    for (int64_t p = g.rank; p < g.npanels; p += g.world) {
+        const int64_t c0 = p * (int64_t)g.nb;
+        if (c0 >= g.n) break;
+        c += (c0 + g.nb <= g.n) ? g.nb : g.n - c0;
+    }
+    m.nloc = g.world == 1 ? g.n : c;
+    return m;
+}
+
 
 // Run a section of the single-rank machinery on another geometry (the condensed system).
 struct GeoSwap {

@@ -13,25 +13,8 @@ namespace pyipm {
 // belong to the x-columns the rank owns (block-cyclic by panels of nb, as the KKT columns: column j of the lower
 // triangle is row j of triu(d2L) | Je | Ji), in local column order; `sharded` says the caller staged only those rows
 // (pyipm_newton_stage_blocks_owned), so a block row is addressed by the LOCAL index.
-struct RowMap {
-    int64_t nloc;                 // rows this rank works on
-    int nb, world, rank, sharded;
-    __host__ __device__ int64_t glob(int64_t r) const {
-        return world == 1 ? r : ((r / nb) * world + rank) * (int64_t)nb + r % nb;
-    }
-    __host__ __device__ int64_t brow(int64_t r) const { return sharded ? r : glob(r); }
-};
-inline RowMap make_rowmap(const Geo& g, int sharded) {
-    RowMap m; m.nb = g.nb; m.world = g.world; m.rank = g.rank; m.sharded = sharded;
-    int64_t c = 0;
-    for (int64_t p = g.rank; p < g.npanels; p += g.world) {
-        const int64_t c0 = p * (int64_t)g.nb;
-        if (c0 >= g.n) break;
-        c += (c0 + g.nb <= g.n) ? g.nb : g.n - c0;
-    }
-    m.nloc = g.world == 1 ? g.n : c;
-    return m;
-}
+// (struct RowMap, make_rowmap: ctx.hpp -- the distributed driver is a translation unit of its own)
+
 
 // KKT entry (i, j), i >= j, in the reference's block order (pyipm.py:816-844 + reghess' shifts).
 __device__ __forceinline__ double kkt_entry(

@@ -1,10 +1,7 @@
 // pyipm_newton.hip — C-ABI of the MI355X Newton-step core (declared in include/pyipm_newton.h).
 // gfx950 only; no CUDA path, no CPU fallback.  Host-side orchestration of the HIP kernels in
 // kernels_*.hpp.  Replaces /root/reference/pyipm.py:1717-1725 (see the header for the mapping).
-#include "ctx.hpp"
-#include <algorithm>
-#include <functional>
-#include <chrono>
+#include "driver.hpp"
 #include "kernels_assemble.hpp"
 #include "kernels_factor.hpp"
 #include "kernels_panel.hpp"
@@ -14,26 +11,10 @@
 #include "kernels_merit.hpp"
 
 using namespace pyipm;
+using namespace pyipm::drv;
 
-// An exception unwinds out of the middle of a schedule: kernels may still be running on the helper streams against
-// storage the next call will overwrite.  Drain them and drop the half-done state before reporting.
-static void quiesce_noexcept(Ctx* c) noexcept {
-    if (!c) return;
-    try {
-        if (c->side) hipStreamSynchronize(c->side);
-        if (c->fwd) hipStreamSynchronize(c->fwd);
-        if (c->rest) hipStreamSynchronize(c->rest);
-        if (c->dist) hipDeviceSynchronize();            // the distributed driver's own streams
-        if (c->stream) hipStreamSynchronize(c->stream); else hipDeviceSynchronize();
-        c->factored = false; c->forward_pending = false; c->forward_fused = false; c->zeros_clean = false;
-    } catch (...) {}
-}
-#define PYIPM_SETERR_NEWTON(msg_) (quiesce_noexcept(reinterpret_cast<Ctx*>(h)), set_err_noexcept(reinterpret_cast<Ctx*>(h), (msg_)))
-#define PYIPM_CATCH_H(h_)  PYIPM_CATCH_CORE(PYIPM_SETERR_NEWTON, PYIPM_E_NOMEM, PYIPM_E_HIP)
+namespace pyipm { namespace drv {
 
-namespace {
-
-struct Carve { size_t off = 0; size_t take(size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; } };
 
 // Workspace layout; returns total bytes.  When base != nullptr also sets the pointers.
 size_t carve_workspace(Ctx* c, const Geo& g, char* base, bool provider_only = false) {
@@ -154,9 +135,7 @@ BatchCond batch_cond(Ctx* ctx) {
     return bc;
 }
 
-int check_ctx(pyipm_newton_ctx* h) { return h ? 0 : PYIPM_E_BADARG; }
 int single_only(Ctx* ctx) { ctx->err = "batched handle: only stage_*_batched / stage_vectors / step_batched apply"; return PYIPM_E_BADARG; }
-inline Ctx* C(pyipm_newton_ctx* h) { return reinterpret_cast<Ctx*>(h); }
 
 // copy `count` doubles from caller memory (host or device) into library device memory
 int put_vec(Ctx* ctx, double* dst, const double* src, size_t count, int memkind) {
@@ -188,15 +167,6 @@ int stage_block(Ctx* ctx, const double* src, int64_t rows, int64_t cols, int64_t
     return 0;
 }
 
-inline dim3 grid1(int64_t n, int b = 256) { return dim3((unsigned)((n + b - 1) / b)); }
-// -W columns of panel p: the buffer of its group (parity-alternating) + its offset inside the group
-inline double* wbuf(Ctx* ctx, int64_t p) {
-    // group id / offset: uniform groups unless factor_all built a variable schedule (short groups in the tail)
-    const int64_t G = ctx->group;
-    const int64_t grp = (size_t)p < ctx->grp_of.size() ? ctx->grp_of[p] : p / G;
-    const int64_t off = (size_t)p < ctx->grp_off.size() ? ctx->grp_off[p] : p % G;
-    return ctx->Wbuf + ((grp % 3) * G + off) * ctx->g.Npad * (int64_t)ctx->g.nb;
-}
 
 // ---- per-panel building blocks -----------------------------------------------------------------
 
@@ -342,13 +312,13 @@ int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, uns
 // Rank-K update of `n_lp` locally owned panels starting at local panel `first_lp`.
 // ldw / row_end / col_end default to the KKT storage's (the Gram launch of the condensed option narrows them).
 int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ldl, const double* Wop, int K,
-                     int64_t row_begin, int64_t first_lp, int64_t n_lp, bool bulk = true,
-                     int64_t ldw = 0, int64_t row_end = 0, int64_t col_end = 0, int64_t src_c0 = -1,
-                     int ksplit = 1, int64_t ks_cstride = 0, int waves = 0,        // waves: 0 = the handle's bulk_waves
-                     int head_ct = 0, unsigned* head_counter = nullptr, unsigned* head_count = nullptr, bool list_only = false,
-                     int sub0 = 0, int nct_sub = 0,    // nct_sub > 0: only column tiles [sub0, sub0 + nct_sub) of local panel first_lp
-                     int* used_bn = nullptr,           // out: the tile width of the instance that ran (128 / 256)
-                     int prio = -1) {                  // >= 0: wave priority flag of the launch whatever `bulk` says
+                     int64_t row_begin, int64_t first_lp, int64_t n_lp, bool bulk,
+                     int64_t ldw, int64_t row_end, int64_t col_end, int64_t src_c0,
+                     int ksplit, int64_t ks_cstride, int waves,        // waves: 0 = the handle's bulk_waves
+                     int head_ct, unsigned* head_counter, unsigned* head_count, bool list_only,
+                     int sub0, int nct_sub,    // nct_sub > 0: only column tiles [sub0, sub0 + nct_sub) of local panel first_lp
+                     int* used_bn,           // out: the tile width of the instance that ran (128 / 256)
+                     int prio) {                  // >= 0: wave priority flag of the launch whatever `bulk` says
     const Geo& g = ctx->g;                             // (128 wide; the sub-panels of a wide panel, factor_block)
     if (ldw <= 0) ldw = g.Npad;
     if (row_end <= 0) row_end = g.Npad;
@@ -451,7 +421,7 @@ int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, in
 
 // Factor panel p on `stream`.  apply_pending: first apply the earlier panels of p's group to p's columns
 // (grouped single-rank driver; their bulk update is deferred to the end of the group).
-int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending = false) {
+int factor_panel(Ctx* ctx, int64_t p, hipStream_t stream, bool apply_pending) {
     const Geo& g = ctx->g;
     if (p < 0 || p >= g.npanels || g.owner(p) != g.rank) { ctx->err = "factor_panel: not the owner"; return PYIPM_E_BADARG; }
     const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
@@ -739,6 +709,12 @@ int factor_block(Ctx* ctx, const BlockDesc& bd, hipStream_t chain, const std::fu
                 }
             }
         }
+        // One launch for the whole chain: the rows stream ran ahead of it on progress words, which say what the ROWS kernels read
+        // (W, inv(T): written through) is there -- not that L inside the diagonal block is (plain stores of a kernel still running).
+        // Whoever reads panel q as a whole (the forward substitution that trails the factorisation) is told at the end, below.
+        if (one_launch && k + 1 < n0) continue;
+        if (one_launch)                                     // (k + 1 == n0: rs is the chain's stream, behind the chain and every sub-panel's rows)
+            for (int64_t kk = 0; kk + 1 < n0; ++kk) { int rc = on_done(bd.sp[(size_t)kk].id, rs); if (rc) return rc; }
         int rc = on_done(q.id, rs); if (rc) return rc;
     }
     return 0;
@@ -949,9 +925,9 @@ int unpack_panel_from(Ctx* ctx, int64_t p, const double* buf, int64_t row_from, 
 
 // One bulk k_update<128> launch: panels [p0, p0+np) (contiguous, same rank) applied with K = their total
 // width to local panels [first_lp, first_lp+n_lp); timed with HIP events on the handle's stream.
-int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_lp, hipStream_t stream = nullptr,
-                 int head_ct = 0, unsigned* head_counter = nullptr, unsigned* head_count = nullptr, bool list_only = false,
-                 bool as_bulk = false) {             // as_bulk: a bulk launch although it runs on another stream
+int timed_update(Ctx* ctx, int64_t p0, int64_t np, int64_t first_lp, int64_t n_lp, hipStream_t stream,
+                 int head_ct, unsigned* head_counter, unsigned* head_count, bool list_only,
+                 bool as_bulk) {             // as_bulk: a bulk launch although it runs on another stream
     const Geo& g = ctx->g;
     if (!stream) stream = ctx->stream;
     if (n_lp <= 0) return 0;
@@ -1050,7 +1026,7 @@ int trailing_update(Ctx* ctx, int64_t p) {
 // Reset of the device-side statistics, on `st` (the stream the first tile kernels of this factorisation run on; default: the
 // handle's).  A kernel, not a copy from a stack temporary followed by a host synchronisation (rounds 1-3): the host must be
 // able to enqueue the first group's chain while the assembly is still running.
-int factor_begin(Ctx* ctx, hipStream_t st = nullptr) {
+int factor_begin(Ctx* ctx, hipStream_t st) {
     if (!st) st = ctx->stream;
     hipLaunchKernelGGL(k_init_stats, dim3(1), dim3(64), 0, st, ctx->dstats);
     PYIPM_KCHECK();
@@ -1132,7 +1108,7 @@ int factor_end(Ctx* ctx, pyipm_factor_stats* stats) {
 // callers use the defaults.
 // A panel wider than wide_sub columns is swept in sub-panels of that width (the in-panel kernels are one workgroup with nt - 1
 // dependent steps: at nb = 1024 the sweeps took 5.9 ms instead of 2.1): the launches of the same matrix at nb = wide_sub.
-int fwd_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr, int nrhs = 1, int64_t vstride = 0) {
+int fwd_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream, int nrhs, int64_t vstride) {
     if (!stream) stream = ctx->stream;
     const Geo& g = ctx->g;
     const int64_t pc0 = g.panel_c0(p), plc0 = g.local_c0(p);
@@ -1155,7 +1131,7 @@ int fwd_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr, int 
     return 0;
 }
 
-int diag_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr, int nrhs = 1, int64_t vstride = 0) {
+int diag_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream, int nrhs, int64_t vstride) {
     if (!stream) stream = ctx->stream;
     const Geo& g = ctx->g;
     const int64_t c0 = g.panel_c0(p);
@@ -1167,7 +1143,7 @@ int diag_panel(Ctx* ctx, int64_t p, double* v, hipStream_t stream = nullptr, int
 }
 
 // part / pstride: partial-sum buffer for several right-hand sides (>= nchunk*nb doubles each); default = the handle's own
-int bwd_panel(Ctx* ctx, int64_t p, double* v, int nrhs = 1, int64_t vstride = 0, double* part = nullptr, int64_t pstride = 0) {
+int bwd_panel(Ctx* ctx, int64_t p, double* v, int nrhs, int64_t vstride, double* part, int64_t pstride) {
     const Geo& g = ctx->g;
     if (!part) part = ctx->partial;
     const int64_t pc0 = g.panel_c0(p), plc0 = g.local_c0(p);
@@ -1198,8 +1174,8 @@ int bwd_panel(Ctx* ctx, int64_t p, double* v, int nrhs = 1, int64_t vstride = 0,
 }
 
 // x := M^{-1} x in place for the factored matrix of the current geometry (single-rank path)
-int solve_plain(Ctx* ctx, double* v, bool forward_done, int nrhs = 1, int64_t vstride = 0, double* part = nullptr,
-                int64_t pstride = 0) {
+int solve_plain(Ctx* ctx, double* v, bool forward_done, int nrhs, int64_t vstride, double* part,
+                int64_t pstride) {
     const Geo& g = ctx->g;
     const bool one_launch = ctx->sweep_persist && nrhs == 1 && g.world == 1 && g.nb <= 4 * TB && g.nb % TB == 0 && g.npanels >= 2 &&
                             g.npanels <= 4096 && g.Npad % 8 == 0 && g.Npad / TB <= 8192;
@@ -1312,7 +1288,7 @@ int cond_expand(Ctx* ctx, const double* vc, double* v) {
 // x := Hc^{-1} x  in place on a full-order Npad device vector (single-rank path).  With the condensed
 // factor: reduce, solve the (n+me) system, expand.  forward_done: the fused pass already ran (on v, or on
 // ctx->vc for the condensed factor, in which case v still holds the right-hand side).
-int solve_inplace(Ctx* ctx, double* v, bool forward_done = false) {
+int solve_inplace(Ctx* ctx, double* v, bool forward_done) {
     if (!ctx->cond_active) return solve_plain(ctx, v, forward_done);
     int rc;
     if (!forward_done) { rc = cond_reduce(ctx, v, ctx->vc); if (rc) return rc; }
@@ -1872,9 +1848,27 @@ int create_fail(Ctx* ctx, int code) {
     return code;
 }
 
-}  // namespace
+// kernels of this translation unit on behalf of the others (a kernel is launched from the unit that defines it)
+int launch_axpby(Ctx* ctx, hipStream_t st, double* out, const double* a, const double* b, double alpha, double beta, int64_t n) {
+    hipLaunchKernelGGL(k_axpby, grid1(n), dim3(256), 0, st, out, a, b, alpha, beta, n); PYIPM_KCHECK(); return 0; }
+int launch_fill(Ctx* ctx, hipStream_t st, double* out, double v, int64_t n) {
+    hipLaunchKernelGGL(k_fill, grid1(n), dim3(256), 0, st, out, v, n); PYIPM_KCHECK(); return 0; }
+int launch_copy_flip(Ctx* ctx, hipStream_t st, double* out, const double* in, int flip) {
+    hipLaunchKernelGGL(k_copy_flip, grid1(ctx->g.N), dim3(256), 0, st, out, in, ctx->g.N, ctx->g.n + ctx->g.mi, flip); PYIPM_KCHECK(); return 0; }
+int launch_mask_owned(Ctx* ctx, hipStream_t st, double* v, const double* b) {
+    hipLaunchKernelGGL(k_mask_owned, grid1(ctx->g.Npad), dim3(256), 0, st, v, b, ctx->g); PYIPM_KCHECK(); return 0; }
+int launch_sumsq2(Ctx* ctx, hipStream_t st, double* out, const double* a, const double* b, int64_t n) {
+    hipLaunchKernelGGL(k_sumsq2, dim3(1), dim3(1024), 0, st, out, a, b, n); PYIPM_KCHECK(); return 0; }
+int launch_inpanel_update(Ctx* ctx, hipStream_t st, dim3 grid, double* Cm, int64_t ldc, int64_t ccol, const double* Lop, int64_t ldl,
+                          const double* Wop, int64_t ldw, int64_t cglob, int K, int64_t row_begin, int64_t row_end,
+                          int64_t a0, int64_t a1, int64_t b0, int64_t b1, int prio) {
+    hipLaunchKernelGGL(k_inpanel_update, grid, dim3(256), 0, st, Cm, ldc, ccol, Lop, ldl, Wop, ldw, cglob, K, row_begin, row_end, a0, a1, b0, b1, prio);
+    PYIPM_KCHECK(); return 0; }
+
+} }  // namespace pyipm::drv
 
 // =================================================================================================
+#pragma GCC visibility push(default)
 extern "C" {
 
 size_t pyipm_newton_workspace_bytes(int64_t n, int64_t me, int64_t mi, int nb, int world, int rank) try {
@@ -2075,6 +2069,33 @@ int pyipm_newton_step_batched(pyipm_newton_ctx* h, double delta, double delta_c,
     return rc;
 } PYIPM_CATCH_H(h)
 
+// The per-problem statistics of the last step_batched, fetched when the caller wants them: a step called with stats = NULL
+// returns as soon as its five launches are enqueued (round 6: the copy of 512 statistics records and the synchronisation in
+// front of it were 0.3 of the 1.4 ms a batch step took on the host's clock).
+int pyipm_newton_stats_batched(pyipm_newton_ctx* h, pyipm_factor_stats* stats) try {
+    if (check_ctx(h) || !stats) return PYIPM_E_BADARG;
+    Ctx* ctx = C(h);
+    PYIPM_HIP(hipSetDevice(ctx->device));
+    if (!ctx->batched) { ctx->err = "stats_batched: not a batched handle"; return PYIPM_E_BADARG; }
+    if (!ctx->have_rhs) { ctx->err = "stats_batched: step_batched first"; return PYIPM_E_BADARG; }
+    const int B = ctx->batch;
+    std::vector<DevStats> z((size_t)B);
+    PYIPM_HIP(hipMemcpyAsync(z.data(), ctx->dstats, (size_t)B * sizeof(DevStats), hipMemcpyDeviceToHost, ctx->stream));
+    PYIPM_HIP(hipStreamSynchronize(ctx->stream));
+    int rc = PYIPM_OK;
+    for (int b = 0; b < B; ++b) {
+        stats[b].n_neg = z[b].n_neg; stats[b].n_zero = z[b].n_zero; stats[b].n_2x2 = z[b].n_2x2; stats[b].n_pos = z[b].n_pos;
+        stats[b].d_min = z[b].d_min; stats[b].d_max = z[b].d_max;
+        long long gb = (long long)z[b].growth_bits; double gr; memcpy(&gr, &gb, sizeof(gr));
+        stats[b].growth = gr; stats[b].nonfinite = z[b].nonfinite;
+        if (z[b].nonfinite) { ctx->err = "NaN/Inf met during factorisation"; rc = PYIPM_E_NONFINITE; }
+    }
+    float ms = 0.f;
+    PYIPM_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    ctx->t_factor = ms;
+    return rc;
+} PYIPM_CATCH_H(h)
+
 // out[b] = |g - Hc raw_b| / |g| of every problem of the last step_batched, Hc applied from the blocks (k_b_berr)
 int pyipm_newton_backward_error_batched(pyipm_newton_ctx* h, const double* dz, double* out, int memkind) try {
     if (check_ctx(h) || !dz || !out) return PYIPM_E_BADARG;
@@ -2188,13 +2209,17 @@ int pyipm_newton_stage_vectors(pyipm_newton_ctx* h, const double* df, const doub
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)
 
-static int copy_out(Ctx* ctx, double* dst, const double* src_dev, size_t count, int memkind) {
+}  // extern "C"
+namespace pyipm { namespace drv {
+int copy_out(Ctx* ctx, double* dst, const double* src_dev, size_t count, int memkind) {
     if (!dst || count == 0) return 0;
     PYIPM_HIP(hipMemcpyAsync(dst, src_dev, count * sizeof(double),
                              memkind == PYIPM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
     if (memkind == PYIPM_MEM_HOST) PYIPM_HIP(hipStreamSynchronize(ctx->stream));
     return 0;
 }
+} }
+extern "C" {
 
 int pyipm_newton_residual(pyipm_newton_ctx* h, double* g_out, int memkind) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
@@ -2217,7 +2242,6 @@ int pyipm_newton_assemble(pyipm_newton_ctx* h, double delta, double delta_c) try
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)
 
-static int solve_prepare(Ctx* ctx, const double* rhs, int memkind, bool for_fused_forward = false);
 
 int pyipm_newton_factor(pyipm_newton_ctx* h, pyipm_factor_stats* stats) try {
     if (check_ctx(h)) return PYIPM_E_BADARG;
@@ -2235,7 +2259,9 @@ int pyipm_newton_factor(pyipm_newton_ctx* h, pyipm_factor_stats* stats) try {
 } PYIPM_CATCH_H(h)
 
 // load the right-hand side into v1 (kept for refinement) and v0 (solved in place)
-static int solve_prepare(Ctx* ctx, const double* rhs, int memkind, bool for_fused_forward) {
+}  // extern "C"
+namespace pyipm { namespace drv {
+int solve_prepare(Ctx* ctx, const double* rhs, int memkind, bool for_fused_forward) {
     const Geo& g = ctx->g;
     if (rhs) {
         hipLaunchKernelGGL(k_fill, grid1(g.Npad), dim3(256), 0, ctx->stream, ctx->v1, 0.0, g.Npad); PYIPM_KCHECK();
@@ -2248,6 +2274,8 @@ static int solve_prepare(Ctx* ctx, const double* rhs, int memkind, bool for_fuse
     if (for_fused_forward && ctx->cond_active) return cond_reduce(ctx, ctx->v0, ctx->vc);   // the fused pass runs on vc
     return 0;
 }
+} }
+extern "C" {
 
 static int solve_finish(Ctx* ctx, double* dz, int flip, int refine, int memkind, bool forward_done) {
     const Geo& g = ctx->g;
@@ -2988,10 +3016,7 @@ int pyipm_mfma_f64_peak(int device, int iters, double* tflops) try {
 
 }  // extern "C"
 
-// =================================================================================================
-// The distributed driver (per-panel schedule, sweeps and exchanges in C): same shared object.
-#include "dist_impl.hpp"
+#pragma GCC visibility pop
 
-// =================================================================================================
-// L-BFGS search direction (include/pyipm_lbfgs.h): same shared object, built on the machinery above.
-#include "lbfgs_impl.hpp"
+// (The distributed driver -- pyipm_dist.hip / dist_impl.hpp -- and the L-BFGS direction -- pyipm_lbfgs.hip / lbfgs_impl.hpp -- are
+//  translation units of their own since round 6: what they share with this file is declared in driver.hpp.)

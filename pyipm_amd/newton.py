@@ -23,7 +23,7 @@ TILE, PAD = 64, 128
 
 ERRORS = {0: "ok", -1: "bad argument / call order", -2: "HIP runtime error", -3: "workspace too small",
           -4: "NaN/Inf met during factorisation", -5: "no usable HIP device",
-          -6: "a caller-supplied exchange callback failed"}
+          -6: "the exchange failed (RCCL or a caller-supplied callback) or a distributed step timed out"}
 
 
 class FactorStats(ctypes.Structure):
@@ -114,6 +114,7 @@ def load_library(path: str | None = None):
                                                       c_void_p, c_int64, c_int64]),
         "pyipm_newton_step_batched": (c_int, [ctxp, c_double, c_double, c_void_p, POINTER(FactorStats), c_int]),
         "pyipm_newton_backward_error_batched": (c_int, [ctxp, c_void_p, c_void_p, c_int]),
+        "pyipm_newton_stats_batched": (c_int, [ctxp, POINTER(FactorStats)]),
         "pyipm_mfma_f64_peak": (c_int, [c_int, c_int, POINTER(c_double)]),
         "pyipm_newton_block_products": (c_int, [ctxp, c_void_p, c_void_p, c_void_p, c_void_p]),
         "pyipm_newton_block_products_t": (c_int, [ctxp, c_void_p, c_void_p, c_void_p]),

@@ -641,8 +641,8 @@ def test_a_stalled_panel_message_is_an_error_code_not_a_hang():
         core.step_dist(0.0, 0.0)
     waited = time.perf_counter() - t0
     assert ei.value.code == -6, ei.value                    # PYIPM_E_COMM
-    npanels = core.npanels
-    assert "panel messages before panel %d " % (npanels // 2) in str(ei.value), str(ei.value)
+    npanels = core.npanels                                  # (9 panels; the middle one, panel 4, lies in the x block: it has a message)
+    assert "panel messages before panel %d," % (npanels // 2) in str(ei.value), str(ei.value)
     assert 0.4 <= waited <= 1.4, waited                     # the bound, not the stall (1.5 s)
     with pytest.raises(NewtonError):
         core.step_dist(0.0, 0.0)                            # the handle knows its streams are not to be trusted
