@@ -183,7 +183,7 @@ def pmc_traffic(N, nb, bn=256):
     tools/pmc_summary.py).  Counters cannot be collected inside this process, so the figure is attached
     only for the configuration it was measured on; otherwise null."""
     name = None
-    for rnd in ("r05", "r04", "r03"):                    # the latest committed counter passes of this command
+    for rnd in ("r06", "r05", "r04", "r03"):                    # the latest committed counter passes of this command
         cand = "%s_z_pmc_update.json" % rnd if bn == 256 else "%s_z_pmc_update_bn128.json" % rnd
         if os.path.exists(os.path.join(ROOT, "profiles", cand)):
             name = cand
@@ -209,7 +209,7 @@ def pmc_moved_fraction(N, nb):
     SURVEY 8d's algorithmic count: `achieved` on algorithmic bytes overstates the HBM rate by this factor."""
     if N != 32768 or nb != 256:
         return {}, None
-    for rnd in ("r05", "r04"):
+    for rnd in ("r06", "r05", "r04"):
         path = os.path.join(ROOT, "profiles", "%s_z_pmc_hbm_kernels.json" % rnd)
         if os.path.exists(path):
             try:

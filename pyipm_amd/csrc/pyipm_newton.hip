@@ -552,6 +552,10 @@ int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, in
         if (!ctx->chain_sync) {
             PYIPM_HIP(hipMalloc((void**)&ctx->chain_sync, (size_t)(Ctx::CHAIN_SLOTS * Ctx::CHAIN_WORDS + 1) * sizeof(unsigned)));
             PYIPM_HIP(hipMemset(ctx->chain_sync, 0, (size_t)(Ctx::CHAIN_SLOTS * Ctx::CHAIN_WORDS + 1) * sizeof(unsigned)));
+            // (the fill is ordered on the NULL stream; k_chain_wait polls these words from a non-blocking stream: it met the words of
+            //  an earlier handle's life in this memory -- larger epochs: "done" -- and let the rows kernels run ahead of the chain, on
+            //  the first step of a handle only: tools/chain_stress.py.  Once per handle: wait for the fill.)
+            PYIPM_HIP(hipDeviceSynchronize());
             ctx->chain_epoch = 0;
         }
         if (ctx->chain_epoch >= (1u << 24)) {            // the words' epochs must stay ordered: start over (every 16 M launches)
@@ -573,12 +577,23 @@ int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, in
         // schedule only: beside the bulk updates of the per-panel schedule it would wait for a whole CU to drain)
         size_t pad = (ctx->chain_lds_kb > 0 && !ctx->per_panel_mode) ? (size_t)ctx->chain_lds_kb * 1024 : 0;
         if (pad && !ctx->chain_lds_set) {
-            if (hipFuncSetAttribute((const void*)k_tile_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024) != hipSuccess) { (void)hipGetLastError(); ctx->chain_lds_kb = 0; pad = 0; }
+            if (hipFuncSetAttribute((const void*)k_tile_chain<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)k_tile_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024) != hipSuccess) {
+                (void)hipGetLastError(); ctx->chain_lds_kb = 0; pad = 0;
+            }
             ctx->chain_lds_set = true;
         }
-        hipLaunchKernelGGL(k_tile_chain, dim3(nblk), dim3(256), pad, chain, ctx->A, g.Npad, gc0, glc0, Wg, g.Npad, Dv, Ts,
-                           ctx->Tflag + gc0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats, g.N, ctx->pivtol_rel, ctx->anorm,
-                           g.n + g.mi, ctx->tile_blocked, cg, ctx->dbg_buf);
+        // with its compute unit to itself (pad >= the 33 KB copy of inv(T)) the chain workgroup prefetches the next step's operands
+        static const bool pre_env = !(getenv("PYIPM_CHAIN_PRE") && getenv("PYIPM_CHAIN_PRE")[0] == '0');     // (measurement: tools/ab_opts.py cannot reach it)
+        const bool pre = ctx->chain_pre && pre_env && pad >= sizeof(double) * TB * (TB + 2);
+        if (pre)
+            hipLaunchKernelGGL(k_tile_chain<true>, dim3(nblk), dim3(256), pad, chain, ctx->A, g.Npad, gc0, glc0, Wg, g.Npad, Dv, Ts,
+                               ctx->Tflag + gc0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats, g.N, ctx->pivtol_rel, ctx->anorm,
+                               g.n + g.mi, ctx->tile_blocked, cg, ctx->dbg_buf);
+        else
+            hipLaunchKernelGGL(k_tile_chain<false>, dim3(nblk), dim3(256), pad, chain, ctx->A, g.Npad, gc0, glc0, Wg, g.Npad, Dv, Ts,
+                               ctx->Tflag + gc0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats, g.N, ctx->pivtol_rel, ctx->anorm,
+                               g.n + g.mi, ctx->tile_blocked, cg, ctx->dbg_buf);
         PYIPM_KCHECK();
         ctx->chain_used = true;
         ctx->chain_last = cg;
@@ -671,7 +686,9 @@ int factor_block(Ctx* ctx, const BlockDesc& bd, hipStream_t chain, const std::fu
         } else if (one_launch) {
             // sub-panel k's tiles are inverted (the chain has passed tile toff[k + 1] - 1) and every later row tile has the stages
             // up to the sub-panel's last tile but one: W of the sub-panel's columns is final inside the diagonal block
-            hipLaunchKernelGGL(k_chain_wait, dim3(1), dim3(64), 0, ctx->rest, cgw, toff[(size_t)k + 1], toff[(size_t)k + 1], toff[(size_t)k + 1]);
+            static const int slack = getenv("PYIPM_CHAIN_WAIT_SLACK") ? atoi(getenv("PYIPM_CHAIN_WAIT_SLACK")) : 0;     // (diagnostics)
+            int tq = toff[(size_t)k + 1] + slack; if (tq > nT) tq = nT;
+            hipLaunchKernelGGL(k_chain_wait, dim3(1), dim3(64), 0, ctx->rest, cgw, tq, toff[(size_t)k + 1], tq);
             PYIPM_KCHECK();
         } else {
             PYIPM_HIP(hipStreamWaitEvent(ctx->rest, ctx->ev_band[(size_t)k], 0));
@@ -1235,6 +1252,9 @@ int solve_plain(Ctx* ctx, double* v, bool forward_done, int nrhs, int64_t vstrid
             ctx->occ_bwd_sweep = 1;                                  // (one workgroup per CU by design, whatever would fit)
         }
         if (blocks > ctx->num_cus) blocks = ctx->num_cus;
+        // a progress word per owner WAVE, (blocks - 1 - nearb) x 16 of them, inside the 4096 words zeroed above (on a part
+        // with more than 257 CUs the words beyond them would keep last sweep's counts and workgroup 0 would stop waiting)
+        if ((blocks - 1 - nearb) * 16 > 4096) blocks = 1 + nearb + 4096 / 16;
         if (ctx->sweep_max_blocks > 0 && blocks > ctx->sweep_max_blocks) blocks = ctx->sweep_max_blocks;
         if (blocks < 2 + nearb) blocks = 2 + nearb;
         hipLaunchKernelGGL(k_bwd_sweep, dim3((unsigned)blocks), dim3(1024), 0, ctx->stream, ctx->A, sg, v, ctx->sweep_sync,

@@ -32,6 +32,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from .newton import NewtonError
+
 
 class QPDeviceIPM(object):
     def __init__(self, Q, c, A=None, b=None, G=None, h=None, Je=None, Ji=None, x0=None, s0=None, lda0=None,
@@ -127,8 +129,8 @@ class QPDeviceIPM(object):
             if mi:
                 self.core.step_lengths(self.tau)
             self.core.merit_info()
-        except Exception:                                    # a singular warm-up system is nobody's problem
-            pass
+        except NewtonError as e:                             # a singular warm-up system is nobody's problem (anything else is a bug: raised)
+            self.timings["warmup_error"] = str(e)
         torch.cuda.synchronize(self.device)
         self._staged_key = None
         self.warm_seconds = time.perf_counter() - t0
@@ -283,14 +285,27 @@ class QPDeviceIPM(object):
                 res = torch.cat(parts) + c_new                                               # At z + c
                 if float(res.norm()) <= 1.0e-9 * max(float(c_new.norm()), 1.0e-300):
                     return z
-        except Exception:                                                                    # (no memory for the Gram matrix, ...)
-            pass
+        except (NewtonError, torch.cuda.OutOfMemoryError) as e:      # (no memory for the Gram matrix, a rank-deficient Jacobian: the SVD
+            self.timings.setdefault("fallbacks", []).append("restoration: %s" % e)   #  path below; programming errors are not swallowed)
         cols = [m for m in (self.Je, self.Ji) if m is not None]
         top = torch.cat(cols, dim=1)
         if mi:
             bottom = torch.cat([torch.zeros((mi, me), dtype=f64, device=dev), -torch.eye(mi, dtype=f64, device=dev)], dim=1)
             top = torch.cat([top, bottom], dim=0)
         return -self._pinv_svd(top.t().contiguous(), c_new)
+
+    def close(self):
+        """Release the library handles this solver owns (the restoration step's Gram workspace is (me + mi)^2 doubles)."""
+        rc = getattr(self, "_rcore", None)
+        if rc is not None:
+            rc.close()
+            self._rcore = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _restoration_core(self):
         """The L-BFGS direction handle the restoration step runs on: the limited-memory mode's own (Jacobians staged, J'J cached),
@@ -528,8 +543,9 @@ class QPDeviceIPM(object):
                     if info is not None:
                         info["path"] = "normal equations (library Gram + block LDL')"
                     return lam
-        except Exception:                               # (no memory for the Gram matrix: the SVD path needs less)
-            pass
+        except (NewtonError, torch.cuda.OutOfMemoryError) as e:     # (no memory for the Gram matrix: the SVD path needs less)
+            if info is not None:
+                info["fallback_reason"] = str(e)
         finally:
             if core is not None:
                 core.close()
