@@ -243,8 +243,6 @@ struct Ctx {
                                           // progress words on their own stream (k_chain_wait); 0: one launch per sub-panel piece, events between
     int chain_lds_kb = 100;               // ... KB of untouched dynamic shared memory per workgroup (keeps other workgroups off its CU)
     bool chain_lds_set = false;
-    int chain_pre = 1;                    // ... with that pad: the chain workgroup requests the next step's operands during the inversion (k_tile_chain<true>);
-                                          // PYIPM_CHAIN_PRE=0 in the environment at create time turns it off (measurement)
     int chain_cpy = 5;                    // ... column tiles per unit and stage a row tile is split for
     static constexpr int CHAIN_SLOTS = 8, CHAIN_WORDS = 160;
     unsigned* chain_sync = nullptr;       // ... progress words (CHAIN_SLOTS regions used round robin, epoch-stamped) + the sticky error word

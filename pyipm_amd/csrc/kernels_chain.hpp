@@ -70,6 +70,9 @@ __device__ __forceinline__ bool chain_wait(const unsigned* word, bool active, un
 // tiles and every unit of the row tiles from `row0` on has completed `unit_need` stages.  One wave on the rows' stream in
 // place of an event between two launches of the chain; the kernels behind it start with the acquire of a kernel boundary
 // and read what the chain has written through.  *err is the chain's sticky error word.
+// (Two uses per sub-panel q of a block: in front of its rows kernels -- tiles up to q's last inverted, the later row tiles one
+//  stage short of it: W of q's columns is final -- and behind them, in front of whoever reads panel q as a whole (the forward
+//  substitution): every stage of q's tiles applied to every row tile, i.e. L of q's columns complete inside the diagonal block.)
 __global__ __launch_bounds__(64) void k_chain_wait(ChainGeo cg, int crit_need, int row0, int unit_need)
 {
     const int lane = threadIdx.x;
@@ -81,14 +84,7 @@ __global__ __launch_bounds__(64) void k_chain_wait(ChainGeo cg, int crit_need, i
     }
 }
 
-// PRE (round 6, where a workgroup has its compute unit to itself -- option chain_lds_kb): the chain workgroup requests the
-// operands of step t + 1 -- S of row tile t + 1 in column tile t and that row tile's diagonal tile, both ready half a step
-// earlier -- between the micro-blocks 2 and 3 of tile t's inversion, into registers that an occupancy of one wave per SIMD
-// leaves free, and reads inv(T[t]) from a shared-memory copy the inversion leaves behind (carved from the dynamic shared
-// memory): step t + 1 starts its scaling product without a round trip to memory (-2.6 us of 22 per tile).  The same loads, the
-// same products: the same bits.
-template <bool PRE>
-__global__ __launch_bounds__(256, PRE ? 1 : 2) void k_tile_chain(
+__global__ __launch_bounds__(256, 2) void k_tile_chain(
     double* A, int64_t ld, int64_t c0, int64_t lc0,                          // the diagonal block: first global / local column
     double* W, int64_t ldw,                                                  // its -S buffer: W[row + k * ldw], k < 64 nT
     double* Dinv, double* Tsv, double* Tflag,                                // of the block's first tile
@@ -97,10 +93,9 @@ __global__ __launch_bounds__(256, PRE ? 1 : 2) void k_tile_chain(
     unsigned long long* tdbg)                                                // the tile inversion's diagnostics (NULL normally; debug_timeline_ptr)
 {
     __shared__ TileScratch sm;
-    extern __shared__ char chain_pad[];               // its SIZE keeps other workgroups off this one's compute unit (option chain_lds_kb); PRE: the first 33 KB hold inv(T)
+    extern __shared__ char chain_pad[];               // (never touched: its SIZE keeps other workgroups off this one's compute unit, option chain_lds_kb)
     static_assert(sizeof(TileScratch) >= sizeof(double) * TB * (TB + 2), "X must fit into the tile scratch");
     double (&X)[TB][TB + 2] = *reinterpret_cast<double (*)[TB][TB + 2]>(&sm);
-    double (&X2)[TB][TB + 2] = *reinterpret_cast<double (*)[TB][TB + 2]>(PRE ? (void*)chain_pad : (void*)&sm);
     __builtin_amdgcn_s_setprio(3);
     const int64_t TT = (int64_t)TB * TB;
     const int ta = cg.ta, tb = cg.tb, nT = cg.nT;
@@ -110,90 +105,36 @@ __global__ __launch_bounds__(256, PRE ? 1 : 2) void k_tile_chain(
 
     if (blockIdx.x == 0) {
         // ------------------------------------------------ the chain ------------------------------------------------
-        double sbn[16], c2n[16];                      // PRE: S and the diagonal tile of the NEXT step, requested during this step's inversion
-        bool have_pre = false;                        // (per wave: a wave that found the row's units not done yet loads them at the step itself)
         #pragma clang loop unroll(disable)
         for (int t = ta; t < tb; ++t) {
             const int tid = tile_tid<true>(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             const int l15 = lane & 15, l4 = lane >> 4;
 #define PYIPM_CH_STAMP(k_) if (cg.dbg && tid == 0) cg.dbg[8 * t + (k_)] = wall_clock64();
             PYIPM_CH_STAMP(0)
-            // what the inversion of tile t does between its micro-blocks 1 | 2 and 2 | 3 (PRE): poll the units of row tile t + 1,
-            // then -- if they are done with stage t - 1 -- request that row tile's S in column tile t and its diagonal tile
-            unsigned fl = 0u;
-            const int tn = t + 1;
-            const int64_t in = c0 + (int64_t)tn * TB + wave * 16 + l15;
-            const int need_n = t - sfirst;                                      // stages the units of row t + 1 must have completed
-            const bool pre_ok = PRE && tn < tb;
-            auto mid = [&](int k) {
-                if (!pre_ok) return;
-                const bool polled = tn >= rfirst && need_n > 0;
-                if (k == 1) {
-                    if (polled && lane < chain_ny(tn, ta, cg.cpy))
-                        fl = __hip_atomic_load(cg.sync + 1 + 4 * tn + (lane & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return;
-                }
-                bool ok = true;
-                if (polled) ok = __ballot(lane < chain_ny(tn, ta, cg.cpy) && (int)(fl - (cg.base + (unsigned)need_n)) < 0) == 0ull;
-                if (!ok) return;
-                asm volatile("" ::: "memory");
-                #pragma unroll
-                for (int ks = 0; ks < 16; ++ks) sbn[ks] = ldg_c<true>(W + in + (int64_t)(t * TB + ks * 4 + l4) * ldw);
-                #pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
-                    #pragma unroll
-                    for (int r = 0; r < 4; ++r) c2n[4 * tt + r] = ldg_c<true>(A + in + (lc0 + tn * TB + tt * 16 + l4 + 4 * r) * ld);
-                have_pre = true;
-            };
-            const bool had_pre = have_pre;            // (what the step before left for THIS step)
-            have_pre = false;
             if (t == 0) {
                 tile_invert_dev<false, true, true>(sm, A, ld, c0, lc0, Dinv, Tsv, Tflag, refine_cond, st, Nreal, pivtol_rel, anorm_bits,
-                                                   neg_from, tdbg, false, blocked != 0, nullptr, mid, PRE ? X2 : nullptr);
+                                                   neg_from, tdbg, false, blocked != 0);
             } else {
                 const int tp = t - 1;
                 const int64_t i = c0 + (int64_t)t * TB + wave * 16 + l15;        // this lane's (global) row
+                // row tile t has every stage before tp: its units' words (lane y polls unit y)
+                if (t >= rfirst) {
+                    const int need = tp - sfirst;                                  // stages the units of row t have completed by then
+                    const int ny = chain_ny(t, ta, cg.cpy);
+                    if (need > 0) chain_wait(cg.sync + 1 + 4 * t + (lane & 3), lane < ny, cg.base + (unsigned)need, cg.err, cg.timeout, false);
+                }
+                asm volatile("" ::: "memory");
+                PYIPM_CH_STAMP(1)
+                int nr = nref;
+                if (nr > 0 && ldg_c<true>(Tflag + tp) == 0.0) nr = 0;
+                PYIPM_STAGE_TILE_C(X, 1.0, Dinv + tp * TT, true)
                 double sb[16];
-                double4_t c2[4];
-                if (PRE && had_pre) {
-                    #pragma unroll
-                    for (int ks = 0; ks < 16; ++ks) sb[ks] = -sbn[ks];
-                    #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt)
-                        #pragma unroll
-                        for (int r = 0; r < 4; ++r) c2[tt][r] = c2n[4 * tt + r];
-                    PYIPM_CH_STAMP(1)
-                } else {
-                    // row tile t has every stage before tp: its units' words (lane y polls unit y)
-                    if (t >= rfirst) {
-                        const int need = tp - sfirst;                              // stages the units of row t have completed by then
-                        const int ny = chain_ny(t, ta, cg.cpy);
-                        if (need > 0) chain_wait(cg.sync + 1 + 4 * t + (lane & 3), lane < ny, cg.base + (unsigned)need, cg.err, cg.timeout, false);
-                    }
-                    asm volatile("" ::: "memory");
-                    PYIPM_CH_STAMP(1)
-                    #pragma unroll
-                    for (int ks = 0; ks < 16; ++ks) sb[ks] = -ldg_c<true>(W + i + (int64_t)(tp * TB + ks * 4 + l4) * ldw);
-                    if (PRE) {                  // (the diagonal tile with S: one round trip; without PRE it follows the scaling product -- registers)
-                        #pragma unroll
-                        for (int tt = 0; tt < 4; ++tt)
-                            #pragma unroll
-                            for (int r = 0; r < 4; ++r) c2[tt][r] = ldg_c<true>(A + i + (lc0 + t * TB + tt * 16 + l4 + 4 * r) * ld);
-                    }
-                }
-                // the refinement flag of tile tp: requested here, looked at behind the scaling product
-                const double tflag = nref > 0 ? ldg_c<true>(Tflag + tp) : 0.0;
-                if (!PRE || t == ta) {          // inv(T[tp]) from memory (PRE: only when an earlier launch inverted it)
-                    PYIPM_STAGE_TILE_C(X2, 1.0, Dinv + tp * TT, true)
-                    __syncthreads();
-                }
+                #pragma unroll
+                for (int ks = 0; ks < 16; ++ks) sb[ks] = -ldg_c<true>(W + i + (int64_t)(tp * TB + ks * 4 + l4) * ldw);
+                __syncthreads();
                 PYIPM_CH_STAMP(2)
                 double4_t acc[4];
-                strip_scale<false, true>(X2, Dinv + tp * TT, Tsv + tp * TT, 0, sb, tid, l15, l4, acc);
-                {
-                    const int nr = (nref > 0 && tflag != 0.0) ? nref : 0;
-                    for (int it = 0; it < nr; ++it) strip_refine_step<true>(X2, Dinv + tp * TT, Tsv + tp * TT, sb, tid, l15, l4, acc);
-                }
+                strip_scale<true, true>(X, Dinv + tp * TT, Tsv + tp * TT, nr, sb, tid, l15, l4, acc);
                 if (cg.dbg) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[3][3])); PYIPM_CH_STAMP(3) }
                 {
                     double gmax = 0.0;
@@ -201,22 +142,23 @@ __global__ __launch_bounds__(256, PRE ? 1 : 2) void k_tile_chain(
                     for (int tt = 0; tt < 4; ++tt)
                         #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            A[i + (lc0 + tp * TB + tt * 16 + l4 + 4 * r) * ld] = acc[tt][r];
+                            // (L is written through: the forward substitution that trails the factorisation reads panel q's L inside
+                            //  the diagonal block from a kernel that starts while this one still runs -- k_chain_wait in factor_block)
+                            stg_c<true>(A + i + (lc0 + tp * TB + tt * 16 + l4 + 4 * r) * ld, acc[tt][r]);
                             gmax = fmax(gmax, fabs(acc[tt][r]));
                         }
                     gmax = wave_max(gmax);
                     if (lane == 0) atomicMax(&st->growth_bits, (unsigned long long)__double_as_longlong(gmax));
                 }
                 // the diagonal tile: Wn = -S of the chain's own 64 rows, from the registers through shared memory (k_tile_step).
-                // (Without PRE the tile is requested here: ahead of the scaling product it spilled 30 more registers of the 256 and
-                //  slowed the product by 1.1 us.)
-                if (!PRE) {
+                // (Requesting the tile ahead of the scaling product -- it comes from memory, written through by row t's units --
+                //  spilled 30 more registers and slowed the product by 1.1 us: 8.6 against 7.3 us for the steps before an inversion.)
+                double4_t c2[4];
+                #pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
                     #pragma unroll
-                    for (int tt = 0; tt < 4; ++tt)
-                        #pragma unroll
-                        for (int r = 0; r < 4; ++r) c2[tt][r] = ldg_c<true>(A + i + (lc0 + t * TB + tt * 16 + l4 + 4 * r) * ld);
-                    __syncthreads();                                         // every wave is done with X (inv(T)): the same array
-                }
+                    for (int r = 0; r < 4; ++r) c2[tt][r] = ldg_c<true>(A + i + (lc0 + t * TB + tt * 16 + l4 + 4 * r) * ld);
+                __syncthreads();                                             // every wave is done with X (inv(T))
                 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks) X[ks * 4 + l4][wave * 16 + l15] = -sb[ks];      // Wn[c][k] = -S[c][k], stored [k][c]
                 __syncthreads();
@@ -239,7 +181,7 @@ __global__ __launch_bounds__(256, PRE ? 1 : 2) void k_tile_chain(
                 PYIPM_CH_STAMP(4)
                 tile_invert_dev<false, true, true>(sm, A, ld, c0 + (int64_t)t * TB, lc0 + (int64_t)t * TB, Dinv + t * TT, Tsv + t * TT,
                                                    Tflag + t, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from, tdbg,
-                                                   /*from_stage=*/true, blocked != 0, nullptr, mid, PRE ? X2 : nullptr);
+                                                   /*from_stage=*/true, blocked != 0);
             }
             // inv(T[t]), T[t] and its flag are out (every wave's stores drained) before the word says so
             PYIPM_CH_STAMP(5)
@@ -328,7 +270,7 @@ __global__ __launch_bounds__(256, PRE ? 1 : 2) void k_tile_chain(
             for (int tt = 0; tt < 4; ++tt)
                 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    A[i + (lc0 + tp * TB + tt * 16 + l4 + 4 * q) * ld] = acc[tt][q];
+                    stg_c<true>(A + i + (lc0 + tp * TB + tt * 16 + l4 + 4 * q) * ld, acc[tt][q]);      // (written through: see the chain's L)
                     gmax = fmax(gmax, fabs(acc[tt][q]));
                 }
             gmax = wave_max(gmax);

@@ -147,9 +147,7 @@ static_assert(sizeof(BlockedScratch) + 4 * TB * sizeof(double) <= 16 * TB * size
 // waves 0..3 as before.
 // COH: the tile's outputs (inverse, saved tile, refinement flag) are read by other workgroups of the SAME launch: written
 // through (stg_c).  LOOPED: called from inside a persistent loop (tile_tid).
-// Mid: see tile_blocked_sweep; Xout != NULL: inv(T) also goes to this shared-memory array in the layout the scaling product reads
-// ([k][c] = Tinv[k * 64 + c]: k_tile_chain's next step starts on it without a round trip to memory).
-template <bool W8 = false, bool COH = false, bool LOOPED = false, class Mid = NoMid>
+template <bool W8 = false, bool COH = false, bool LOOPED = false>
 __device__ __forceinline__ void tile_invert_dev(
     TileScratch& sm,
     const double* __restrict__ A, int64_t ld, int64_t grow0, int64_t lcol0,
@@ -161,8 +159,7 @@ __device__ __forceinline__ void tile_invert_dev(
     unsigned long long* __restrict__ dbg,      // diagnostics only (NULL normally)
     bool from_stage = false,                   // the caller has put the tile into sm.stage[i][j] (i >= j at least): no global read
     bool blocked = true,                       // try the blocked fast path first (tile_blocked.hpp); false: the sweeps of rounds 1-2 only
-    Blocked8Scratch* ex = nullptr,             // W8 only
-    Mid mid = Mid(), double (*Xout)[TB + 2] = nullptr)
+    Blocked8Scratch* ex = nullptr)             // W8 only
 {
     double (&stage)[TB][TB + 1] = sm.stage;
     double (&colbuf)[2][2][TB] = sm.colbuf;
@@ -267,7 +264,7 @@ __device__ __forceinline__ void tile_invert_dev(
         if (tid == 0) sm.f.bs.fail = 0;
         __syncthreads();
         if (dbg && tid == 0) dbg[4] = clock64() - dbg_c0;
-        kb_done = tile_blocked_sweep<TB + 1, LOOPED, Mid>(stage, sm.f.bs, sm.dsave, dbg, mid);
+        kb_done = tile_blocked_sweep<TB + 1, LOOPED>(stage, sm.f.bs, sm.dsave, dbg);
         if (dbg && tid == 0) { dbg[5] = clock64() - dbg_c0; dbg[6] = dbg_c0; dbg[7] += (unsigned long long)kb_done; }   // (micro-blocks committed, summed over tiles)
         #pragma unroll
         for (int c = 0; c < 16; ++c) {                 // the working matrix as it stands, back in the sweep layout
@@ -458,10 +455,6 @@ __device__ __forceinline__ void tile_invert_dev(
 #undef PYIPM_SWEEP1
     #pragma unroll
     for (int c = 0; c < 16; ++c) if (c < c_out) stg_c<COH>(Tinv + (cb + c) * TB + lane, -row[c]);
-    if (Xout) {
-        #pragma unroll
-        for (int c = 0; c < 16; ++c) Xout[cb + c][lane] = -row[c];
-    }
     if (dbg && tid == 0) { dbg[0] = clock64() - dbg_c0; dbg[1] = wall_clock64() - dbg_w0; dbg[2] += 1; }
     __syncthreads();                                     // dsave complete
     if (wave == 0) {                                     // statistics of the 1x1 pivots: lane p looks at pivot p

@@ -577,23 +577,12 @@ int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, in
         // schedule only: beside the bulk updates of the per-panel schedule it would wait for a whole CU to drain)
         size_t pad = (ctx->chain_lds_kb > 0 && !ctx->per_panel_mode) ? (size_t)ctx->chain_lds_kb * 1024 : 0;
         if (pad && !ctx->chain_lds_set) {
-            if (hipFuncSetAttribute((const void*)k_tile_chain<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void*)k_tile_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024) != hipSuccess) {
-                (void)hipGetLastError(); ctx->chain_lds_kb = 0; pad = 0;
-            }
+            if (hipFuncSetAttribute((const void*)k_tile_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 110 * 1024) != hipSuccess) { (void)hipGetLastError(); ctx->chain_lds_kb = 0; pad = 0; }
             ctx->chain_lds_set = true;
         }
-        // with its compute unit to itself (pad >= the 33 KB copy of inv(T)) the chain workgroup prefetches the next step's operands
-        static const bool pre_env = !(getenv("PYIPM_CHAIN_PRE") && getenv("PYIPM_CHAIN_PRE")[0] == '0');     // (measurement: tools/ab_opts.py cannot reach it)
-        const bool pre = ctx->chain_pre && pre_env && pad >= sizeof(double) * TB * (TB + 2);
-        if (pre)
-            hipLaunchKernelGGL(k_tile_chain<true>, dim3(nblk), dim3(256), pad, chain, ctx->A, g.Npad, gc0, glc0, Wg, g.Npad, Dv, Ts,
-                               ctx->Tflag + gc0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats, g.N, ctx->pivtol_rel, ctx->anorm,
-                               g.n + g.mi, ctx->tile_blocked, cg, ctx->dbg_buf);
-        else
-            hipLaunchKernelGGL(k_tile_chain<false>, dim3(nblk), dim3(256), pad, chain, ctx->A, g.Npad, gc0, glc0, Wg, g.Npad, Dv, Ts,
-                               ctx->Tflag + gc0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats, g.N, ctx->pivtol_rel, ctx->anorm,
-                               g.n + g.mi, ctx->tile_blocked, cg, ctx->dbg_buf);
+        hipLaunchKernelGGL(k_tile_chain, dim3(nblk), dim3(256), pad, chain, ctx->A, g.Npad, gc0, glc0, Wg, g.Npad, Dv, Ts,
+                           ctx->Tflag + gc0 / TB, ctx->refine_cond, ctx->block_refine, ctx->dstats, g.N, ctx->pivtol_rel, ctx->anorm,
+                           g.n + g.mi, ctx->tile_blocked, cg, ctx->dbg_buf);
         PYIPM_KCHECK();
         ctx->chain_used = true;
         ctx->chain_last = cg;
@@ -686,9 +675,7 @@ int factor_block(Ctx* ctx, const BlockDesc& bd, hipStream_t chain, const std::fu
         } else if (one_launch) {
             // sub-panel k's tiles are inverted (the chain has passed tile toff[k + 1] - 1) and every later row tile has the stages
             // up to the sub-panel's last tile but one: W of the sub-panel's columns is final inside the diagonal block
-            static const int slack = getenv("PYIPM_CHAIN_WAIT_SLACK") ? atoi(getenv("PYIPM_CHAIN_WAIT_SLACK")) : 0;     // (diagnostics)
-            int tq = toff[(size_t)k + 1] + slack; if (tq > nT) tq = nT;
-            hipLaunchKernelGGL(k_chain_wait, dim3(1), dim3(64), 0, ctx->rest, cgw, tq, toff[(size_t)k + 1], tq);
+            hipLaunchKernelGGL(k_chain_wait, dim3(1), dim3(64), 0, ctx->rest, cgw, toff[(size_t)k + 1], toff[(size_t)k + 1], toff[(size_t)k + 1]);
             PYIPM_KCHECK();
         } else {
             PYIPM_HIP(hipStreamWaitEvent(ctx->rest, ctx->ev_band[(size_t)k], 0));
@@ -726,12 +713,15 @@ int factor_block(Ctx* ctx, const BlockDesc& bd, hipStream_t chain, const std::fu
                 }
             }
         }
-        // One launch for the whole chain: the rows stream ran ahead of it on progress words, which say what the ROWS kernels read
-        // (W, inv(T): written through) is there -- not that L inside the diagonal block is (plain stores of a kernel still running).
-        // Whoever reads panel q as a whole (the forward substitution that trails the factorisation) is told at the end, below.
-        if (one_launch && k + 1 < n0) continue;
-        if (one_launch)                                     // (k + 1 == n0: rs is the chain's stream, behind the chain and every sub-panel's rows)
-            for (int64_t kk = 0; kk + 1 < n0; ++kk) { int rc = on_done(bd.sp[(size_t)kk].id, rs); if (rc) return rc; }
+        // One launch for the whole chain: the rows stream ran ahead of it on progress words that say what the ROWS kernels read (W,
+        // inv(T)) is there.  Whoever reads panel q as a whole (the forward substitution that trails the factorisation) needs L of its
+        // columns inside the diagonal block too, i.e. the state after the tile step of the next sub-panel's first tile (what an event
+        // behind that launch used to say): a second wait, behind the rows kernels.  L, like W and inv(T), is written through.
+        if (one_launch && k + 1 < n0) {
+            const int tq = toff[(size_t)k + 1] + 1;
+            hipLaunchKernelGGL(k_chain_wait, dim3(1), dim3(64), 0, ctx->rest, cgw, tq, tq, tq);
+            PYIPM_KCHECK();
+        }
         int rc = on_done(q.id, rs); if (rc) return rc;
     }
     return 0;

@@ -223,13 +223,9 @@ __device__ __forceinline__ bool tile_blocked_block(double (&stage)[TB][STRIDE], 
 // stage: the working matrix, lower triangle valid (entries [i][j], i >= j).  256 threads; everyone has passed a barrier
 // after the last write to stage / bs.ptol / bs.fail = 0.  Returns the number of micro-blocks swept (0..4); on return
 // everyone has passed a barrier after the last write.  dsave[p] = pivot p as used.
-// (Mid: called with 1 / 2 between the micro-blocks 1|2 and 2|3 -- k_tile_chain requests the operands of the NEXT tile step there,
-//  half an inversion before it needs them; the default does nothing)
-struct NoMid { __device__ __forceinline__ void operator()(int) const {} };
-template <int STRIDE, bool LOOPED = false, class Mid = NoMid>
+template <int STRIDE, bool LOOPED = false>
 __device__ __forceinline__ int tile_blocked_sweep(double (&stage)[TB][STRIDE], BlockedScratch& bs, double* __restrict__ dsave,
-                                                  unsigned long long* __restrict__ dbg = nullptr,    // diagnostics: dbg[8 + 32 kb + 8 wave + phase] = clock
-                                                  Mid mid = Mid())
+                                                  unsigned long long* __restrict__ dbg = nullptr)    // diagnostics: dbg[8 + 32 kb + 8 wave + phase] = clock
 {
     const int tid_ = tile_tid<LOOPED>();
     const int lane = tid_ & 63, i15 = lane & 15, q = lane >> 4;
@@ -247,9 +243,7 @@ __device__ __forceinline__ int tile_blocked_sweep(double (&stage)[TB][STRIDE], B
     }
     if (!tile_blocked_block<0, STRIDE, LOOPED>(stage, bs, dsave, L, dbg)) return 0;
     if (!tile_blocked_block<1, STRIDE, LOOPED>(stage, bs, dsave, L, dbg)) return 1;
-    mid(1);
     if (!tile_blocked_block<2, STRIDE, LOOPED>(stage, bs, dsave, L, dbg)) return 2;
-    mid(2);
     if (!tile_blocked_block<3, STRIDE, LOOPED>(stage, bs, dsave, L, dbg)) return 3;
     return 4;
 }
