@@ -415,7 +415,7 @@ int pyipm_newton_trailing_bytes(pyipm_newton_ctx* ctx, double out[4]);
  *   "refine_target" (1e-14) / "refine_max" (8): adaptive refinement of solve(refine < 0): stop at this backward error or
  *                       after this many steps.
  *   "pivtol_rel" (1e-14): a pivot below this fraction of its tile column's magnitude has cancelled: static pivot.
- *   "tile_blocked" 0|1  (1; batched handles: 0 with the full form, 1 with the condensed one, until set explicitly): the 64 x 64
+ *   "tile_blocked" 0|1  (1): the 64 x 64
  *                       tile inversion 16 pivots at a time (in-register LDL' of the micro-block + fp64 MFMA block sweeps,
  *                       Bunch-Kaufman verified afterwards, fallback to the single sweeps) -- same pivots and inertia, another
  *                       order of rounding than the single sweeps (not bit-identical).
@@ -463,7 +463,7 @@ int pyipm_newton_trailing_bytes(pyipm_newton_ctx* ctx, double out[4]);
  *
  * EXPERT OPTIONS: tail_group, group_chain, tile_step, tile_waves, bc_per_problem, chain_cpy, chain_whole, chain_lds_kb,
  *   sweep_max_blocks, debug_fault, debug_timeline_ptr, debug_chain_ptr
- *   (which stream runs what, in how many launches: tail_group = panels per group once at most 24576 columns remain (4);
+ *   (which stream runs what, in how many launches: tail_group = panels per group once at most 24576 columns remain (4; 8 for systems of at most 8192 rows);
  *   group_chain 0 = a group's panels one after the other instead of one tile chain; tile_step 0 = the two-launches-per-tile
  *   schedule of round 1; tile_waves 4|8|9 = the launch-per-tile kernel on four waves, on eight where a whole CU is to be had,
  *   on eight everywhere; bc_per_problem 0 = the batched condensed form's Gram part by one workgroup per tile; chain_cpy / chain_whole /

@@ -108,6 +108,7 @@ struct Ctx {
     std::map<std::vector<int64_t>, TileList> tile_lists;   // compact tile orders of the bulk launches (geometry repeats every step)
     int skip_zeros = 1;                   // trailing updates skip tiles that the KKT block structure makes exact zeros
     int group = 1;                        // panels per bulk trailing update
+    bool tail_group_user = false;         // set_option("tail_group") was called (else: 8 for systems of at most 8192 rows)
     int tail_group = 4;                   // group size once at most tail_cols columns remain: there the panel chain outlasts
     int64_t tail_cols = 24576;            // the bulk update, and shorter groups move in-group update work off the chain
     std::vector<int> grp_of, grp_off;     // per panel: group id and offset inside the group (built by factor_all)

@@ -1495,7 +1495,8 @@ void asm_grid(const Ctx* ctx, const Geo& g, dim3* grid, int* tri) {
 // panels of the first group of the single-rank schedule (the rule of factor_all)
 int64_t first_group_panels(const Ctx* ctx) {
     const Geo& g = ctx->g;
-    int64_t G = (ctx->tail_group > 0 && g.Npad <= ctx->tail_cols) ? ctx->tail_group : ctx->group;
+    const int tg = (!ctx->tail_group_user && g.Npad <= 8192) ? 8 : ctx->tail_group;
+    int64_t G = (tg > 0 && g.Npad <= ctx->tail_cols) ? tg : ctx->group;
     if (G > ctx->group) G = ctx->group;
     if (G > g.npanels) G = g.npanels;
     return G;
@@ -1567,7 +1568,11 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         int64_t p = 0; int gid = 0;
         while (p < np) {
             const int64_t remaining = g.Npad - g.panel_c0(p);
-            int64_t G = (ctx->tail_group > 0 && remaining <= ctx->tail_cols) ? ctx->tail_group : ctx->group;
+            // (round 6: systems of at most 8192 rows take groups of 8 in the tail too -- with the chain of a group as ONE launch a group
+            //  boundary costs more than the in-group updates of the longer group: config 2 2.25 against 2.29 ms; N = 32768: 104.9
+            //  against 102.4 ms, config 3 185.4 against 183.2: 4 stays there)
+            const int tg = (!ctx->tail_group_user && g.Npad <= 8192) ? 8 : ctx->tail_group;
+            int64_t G = (tg > 0 && remaining <= ctx->tail_cols) ? tg : ctx->group;
             if (G > ctx->group) G = ctx->group;
             if (p + G > np) G = np - p;
             // (round 5) the panels inside the slack block as ONE group: their kernels run up front (s_early) and what is left of
@@ -1982,8 +1987,9 @@ int pyipm_newton_create_batched(pyipm_newton_ctx** out, int64_t n, int64_t me, i
     ctx->ws_bytes = need;
     carve_batched(ctx, g, batch, ctx->ws);
     ctx->batched = true;
-    ctx->tile_blocked = 0;               // throughput-bound (two problems per CU, every CU busy): the blocked inversion's register and
-                                          // LDS appetite costs more there than its shorter chain gains (512 x N=768: 4.42 vs 4.04 ms, r03)
+    ctx->tile_blocked = 1;               // the blocked inversion in both forms since round 6 (512 x N = 768, full form: 3.24 against 3.44 ms;
+                                          // condensed: 0.99 against 1.10; round 3 measured the opposite for the full form, before the per-problem
+                                          // Gram kernel and the eight-wave-free register budget of today's k_b_factor)
     if (hipMemset(ctx->anorm, 0, (size_t)batch * 2 * sizeof(unsigned long long)) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) return create_fail(ctx, PYIPM_E_HIP);
     *out = reinterpret_cast<pyipm_newton_ctx*>(ctx);
@@ -2974,10 +2980,8 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
     if (!strcmp(name, "block_refine")) { int v = (int)value; ctx->block_refine = v < 0 ? 0 : (v > 3 ? 3 : v); return PYIPM_OK; }
     if (!strcmp(name, "condensed")) {
         ctx->condensed = (int)value;                          // (several ranks: full blocks on every rank, see assemble)
-        // a batched handle's tile inversion: blocked with the condensed form (4 tiles per problem: the chain is what is left --
-        // 0.39 vs 0.49 ms for 512 x (256, 0, 256)), the single sweeps with the full one (12 tiles: throughput-bound, r03);
-        // set "tile_blocked" after "condensed" to choose otherwise
-        if (ctx->batched && !ctx->tile_blocked_user) ctx->tile_blocked = ctx->condensed ? 1 : 0;   // (an explicit choice stands: ADVICE r5)
+        // (until round 6 this also rewrote a batched handle's tile_blocked -- 1 with the condensed form, 0 with the full one -- and so
+        //  discarded an explicit choice; the blocked inversion is the default of both forms now)
         return PYIPM_OK; }
     if (!strcmp(name, "condensed_sigma_max")) { ctx->cond_sigma_max = value; return PYIPM_OK; }
     if (!strcmp(name, "condensed_refine")) { ctx->cond_min_refine = (int)value < 0 ? 0 : (int)value; return PYIPM_OK; }
@@ -2986,7 +2990,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
         int v = (int)value; if (v < 1 || v > default_group(ctx->g.world, ctx->g.nb)) { ctx->err = "group out of range"; return PYIPM_E_BADARG; }
         ctx->group = v; return PYIPM_OK; }
     if (!strcmp(name, "skip_zeros")) { ctx->skip_zeros = (int)value != 0; return PYIPM_OK; }
-    if (!strcmp(name, "tail_group")) { ctx->tail_group = (int)value; return PYIPM_OK; }
+    if (!strcmp(name, "tail_group")) { ctx->tail_group = (int)value; ctx->tail_group_user = true; return PYIPM_OK; }
     { bool handled = false; int rc = dist_set_option(ctx, name, value, &handled); if (handled) return rc; }
     if (!strcmp(name, "tile_step")) { ctx->tile_step = (int)value != 0; return PYIPM_OK; }
     if (!strcmp(name, "group_chain")) { ctx->group_chain = (int)value != 0; return PYIPM_OK; }
