@@ -652,6 +652,10 @@ int factor_block(Ctx* ctx, const BlockDesc& bd, hipStream_t chain, const std::fu
     const bool one_launch = ctx->chain_whole && chain_applies(ctx, gc0, nT);
     ChainGeo cgw; memset(&cgw, 0, sizeof(cgw));
     if (one_launch) {
+        // (the rows stream polls the chain's progress with a bounded wait: it must not start polling before the chain can start --
+        //  behind a Gram launch of seconds, the condensed form at n = 65536, the bound ran out while the chain's stream was still busy)
+        PYIPM_HIP(hipEventRecord(ctx->ev_band[0], chain));
+        PYIPM_HIP(hipStreamWaitEvent(ctx->rest, ctx->ev_band[0], 0));
         int r0 = launch_tile_steps(ctx, chain, gc0, glc0, nT, 0, nT, Wg, Dv, Ts); if (r0) return r0;
         cgw = ctx->chain_last;
     }

@@ -184,12 +184,15 @@ def test_no_exception_crosses_the_abi():
     core = NewtonCore(n, me, mi, device=0, nb=128)
     core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
     core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+    core.set_option("expert", 1)
+    core.set_option("tail_group", 2)                             # (as the handles below: the same grouping, the same bits)
     ref, _ = core.step(0.0, 0.0)
     for fault, code in ((1, -3), (2, -2)):
         fresh = NewtonCore(n, me, mi, device=0, nb=128)          # tile lists are cached per handle: use a new one
         fresh.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
         fresh.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
         fresh.set_option("expert", 1)
+        fresh.set_option("tail_group", 2)                        # (groups of 2: a bulk launch -- a tile list -- after every group)
         fresh.set_option("debug_fault", fault)
         with pytest.raises(NewtonError) as ei:
             fresh.step(0.0, 0.0)
