@@ -430,8 +430,9 @@ int pyipm_newton_trailing_bytes(pyipm_newton_ctx* ctx, double out[4]);
  *                       factorisation) -- equal to rounding, not to the bit (another summation order), deterministic.
  *                       Their workgroups wait for each other, so all of them must become resident: under a CU mask, or
  *                       beside a kernel that holds CUs for seconds, use 0.
- *   "lookahead" 0|1     (1) one-group lookahead of the single-rank schedule; "group" 1..create-time value: panels per
- *                       bulk trailing update (K = group * nb).  Bitwise-neutral.
+ *   "lookahead" 0|1|2   (2) 1 = one-group lookahead of the single-rank schedule; 2 = that, and where the x block is one group
+ *                       its update is applied panel by panel under its own chain; "group" 1..create-time
+ *                       value: panels per bulk trailing update (K = group * nb).  Bitwise-neutral.
  *   "bulk_bn" 256|128   (256) column width of a bulk update tile; "reserve_cus" (16) / "persist_rows" (12288): in the
  *                       chain-bound phase (at most persist_rows rows left) the bulk update runs as a persistent launch
  *                       that leaves reserve_cus CUs to the panel chain; 0 = ordinary launches.  Bitwise-neutral.

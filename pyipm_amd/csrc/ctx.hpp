@@ -97,7 +97,9 @@ struct Ctx {
     int fuse_forward = 1;
     bool forward_fused = false;
     bool forward_pending = false;         // factor() already forward-substituted the pending residual into v0
-    int lookahead = 1;                    // 0 none, 1 one group (two groups on a dedicated stream measured no faster: removed)
+    int lookahead = 2;                    // 0 none, 1 one group (two groups on a dedicated stream measured no faster: removed), 2 = 1 + the
+                                          // first group's update panel by panel under its own chain where the slack block follows it (factor_all)
+    hipEvent_t ev_early = nullptr;
     int s_fast = 1;                       // panels inside the slack block: closed-form elimination (k_s_panel)
     std::vector<char> grp_fast;           // per group: every panel of it takes that path (built by factor_all)
     std::vector<char> grp_x;              // per group: lies inside the x block (its chain kernels may skip the slack rows)

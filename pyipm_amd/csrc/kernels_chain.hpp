@@ -84,6 +84,19 @@ __global__ __launch_bounds__(64) void k_chain_wait(ChainGeo cg, int crit_need, i
     }
 }
 
+// What the chain keeps close between two steps (the units' side is untouched, and so is every bit): inv(T[t-1]) and its
+// refinement flag stay in shared memory where the inversion leaves them -- the step starts at its S rows (staging the inverse
+// from memory: 1.4 us; with it in place 0.5; step 22.0 -> 21.0 us).
+// Measured and dropped after that (tools/r06_chain_mode.sh; the inversion pays for ANYTHING that lives across it or is
+// issued inside it -- its micro-blocks then reload constants from scratch, or lose their schedule):
+//   * the diagonal tile brought in beside S by global_load_lds: its latency was hidden already;
+//   * the next step's S rows requested from inside the inversion, when a wave's columns of the inverse are final: into registers
+//     they were spilled across the inversion's tail (14.2 -> 16.7 us); as global_load_lds into shared memory the compiler
+//     drained them at the inversion's last barrier (15.2); as asm statements they cost the tail what they saved the next
+//     step (eight M0 writes + issues: +0.7 against -0.6 us);
+//   * only the LOOK at the next row's unit words from inside the inversion (in front of its last micro-block) and the step's
+//     progress word sent from the start of the next step, behind the s_waitcnt its S rows need anyway: wait 0.32 -> 0.14,
+//     publish 0.24 -> 0.08, inversion 14.2 -> 14.8 us; config 2 2.22 -> 2.26 ms.
 __global__ __launch_bounds__(256, 2) void k_tile_chain(
     double* A, int64_t ld, int64_t c0, int64_t lc0,                          // the diagonal block: first global / local column
     double* W, int64_t ldw,                                                  // its -S buffer: W[row + k * ldw], k < 64 nT
@@ -93,6 +106,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
     unsigned long long* tdbg)                                                // the tile inversion's diagnostics (NULL normally; debug_timeline_ptr)
 {
     __shared__ TileScratch sm;
+    __shared__ double flag_s;                         // the refinement flag of the tile the chain inverted last
     extern __shared__ char chain_pad[];               // (never touched: its SIZE keeps other workgroups off this one's compute unit, option chain_lds_kb)
     static_assert(sizeof(TileScratch) >= sizeof(double) * TB * (TB + 2), "X must fit into the tile scratch");
     double (&X)[TB][TB + 2] = *reinterpret_cast<double (*)[TB][TB + 2]>(&sm);
@@ -113,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
             PYIPM_CH_STAMP(0)
             if (t == 0) {
                 tile_invert_dev<false, true, true>(sm, A, ld, c0, lc0, Dinv, Tsv, Tflag, refine_cond, st, Nreal, pivtol_rel, anorm_bits,
-                                                   neg_from, tdbg, false, blocked != 0);
+                                                   neg_from, tdbg, false, blocked != 0, nullptr, &X[0], &flag_s);
             } else {
                 const int tp = t - 1;
                 const int64_t i = c0 + (int64_t)t * TB + wave * 16 + l15;        // this lane's (global) row
@@ -125,13 +139,18 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
                 }
                 asm volatile("" ::: "memory");
                 PYIPM_CH_STAMP(1)
+                const bool inl = t > ta;                                         // inv(T[tp]) is this launch's: still in X (behind the barrier that ended its step)
                 int nr = nref;
-                if (nr > 0 && ldg_c<true>(Tflag + tp) == 0.0) nr = 0;
-                PYIPM_STAGE_TILE_C(X, 1.0, Dinv + tp * TT, true)
+                if (inl) {
+                    if (nr > 0 && flag_s == 0.0) nr = 0;
+                } else {
+                    if (nr > 0 && ldg_c<true>(Tflag + tp) == 0.0) nr = 0;
+                    PYIPM_STAGE_TILE_C(X, 1.0, Dinv + tp * TT, true)
+                }
                 double sb[16];
                 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks) sb[ks] = -ldg_c<true>(W + i + (int64_t)(tp * TB + ks * 4 + l4) * ldw);
-                __syncthreads();
+                if (!inl) __syncthreads();                                   // X staged by everybody
                 PYIPM_CH_STAMP(2)
                 double4_t acc[4];
                 strip_scale<true, true>(X, Dinv + tp * TT, Tsv + tp * TT, nr, sb, tid, l15, l4, acc);
@@ -181,9 +200,10 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
                 PYIPM_CH_STAMP(4)
                 tile_invert_dev<false, true, true>(sm, A, ld, c0 + (int64_t)t * TB, lc0 + (int64_t)t * TB, Dinv + t * TT, Tsv + t * TT,
                                                    Tflag + t, refine_cond, st, Nreal, pivtol_rel, anorm_bits, neg_from, tdbg,
-                                                   /*from_stage=*/true, blocked != 0);
+                                                   /*from_stage=*/true, blocked != 0, nullptr, &X[0], &flag_s);
             }
-            // inv(T[t]), T[t] and its flag are out (every wave's stores drained) before the word says so
+            // inv(T[t]), T[t] and its flag are out (every wave's stores drained) before the word says so; the barrier also
+            // stands between the inversion's last writes to X / flag_s and the next step's reads
             PYIPM_CH_STAMP(5)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();

@@ -159,8 +159,10 @@ __device__ __forceinline__ void tile_invert_dev(
     unsigned long long* __restrict__ dbg,      // diagnostics only (NULL normally)
     bool from_stage = false,                   // the caller has put the tile into sm.stage[i][j] (i >= j at least): no global read
     bool blocked = true,                       // try the blocked fast path first (tile_blocked.hpp); false: the sweeps of rounds 1-2 only
-    Blocked8Scratch* ex = nullptr)             // W8 only
-{
+    Blocked8Scratch* ex = nullptr,             // W8 only
+    double (*xkeep)[TB + 2] = nullptr,         // != NULL (k_tile_chain, four waves): inv(T) is also LEFT in shared memory, in the layout
+    double* fkeep = nullptr)                   //   PYIPM_STAGE_TILE gives it, and the refinement flag in *fkeep: the caller's next step
+{                                              //   reads them from there instead of from memory (xkeep may overlay sm.stage)
     double (&stage)[TB][TB + 1] = sm.stage;
     double (&colbuf)[2][2][TB] = sm.colbuf;
     double (&sh_red)[4] = sm.sh_red;
@@ -466,11 +468,17 @@ __device__ __forceinline__ void tile_invert_dev(
         dmin = fmin(dmin, -wave_max((is1 && real && !stat) ? -ad : -1.0e308));
         dmax = fmax(dmax, wave_max((is1 && real && !stat) ? ad : 0.0));
     }
+    if (xkeep) {                                         // (behind the barrier: nobody reads the stage any more)
+        #pragma unroll
+        for (int c = 0; c < 16; ++c) xkeep[cb + c][lane] = -row[c];
+    }
     if (tid == 0) {
         // pivot spread of THIS tile ~ cond(T): the explicit inverse is accurate to cond*eps, so only tiles
         // beyond refine_cond (or with 2x2 pivots) pay for refined block solves.  A tile with a rejected pivot
         // is singular to working precision: its "inverse" belongs to a perturbed tile, nothing to refine against.
-        stg_c<COH>(Tflag, (zero == 0 && (n2 > 0 || !(dmax <= refine_cond * dmin))) ? 1.0 : 0.0);
+        const double fl = (zero == 0 && (n2 > 0 || !(dmax <= refine_cond * dmin))) ? 1.0 : 0.0;
+        stg_c<COH>(Tflag, fl);
+        if (fkeep) *fkeep = fl;
         stats_add(st, neg, zero, n2, nreal - neg, bad, dmin, dmax);                          // static pivots count by their sign
     }
 }

@@ -254,7 +254,7 @@ int tile_list(Ctx* ctx, const UpdGeo& u, int64_t nsup, const unsigned** dev, uns
         const int64_t rt = (int64_t)sI * SUPER + (within & (SUPER - 1)), ct = (int64_t)sJ * SUPER + (within >> 3);
         if (rt >= u.nrt || ct >= u.nct) continue;
         int64_t jglob, jloc;
-        if (bn == 256) upd_col<256>(u, ct, jglob, jloc); else upd_col<128>(u, ct, jglob, jloc);
+        if (bn == 256) upd_col<256>(u, ct, jglob, jloc); else if (bn == 64) upd_col<64>(u, ct, jglob, jloc); else upd_col<128>(u, ct, jglob, jloc);
         if (jglob >= u.Npad) continue;
         const int64_t i0 = u.row_begin + rt * BM;
         if (i0 + BM <= jglob) continue;
@@ -362,6 +362,26 @@ int launch_update128(Ctx* ctx, hipStream_t stream, const double* Lop, int64_t ld
         unsigned ntiles = 0;
         int rc = tile_list(ctx, u, nsup, &u.tiles, &ntiles, 128, head_count, stream); if (rc) return rc;
         if (list_only || ntiles == 0) return 0;
+        if (ctx->bulk_bn == 256 && use_waves == 8 && waves == 0 && ksplit == 1 && head_ct == 0 && nct_sub == 0 &&
+            ntiles <= (unsigned)(ctx->num_cus * 5 / 8) && upd_swizzle_ok<64>(u)) {
+            // A launch that leaves most of the GPU idle (the last groups of a factorisation, the panel-by-panel updates of a small
+            // system's first group): 128 x 64 tiles, twice as many blocks of half the length, no scratch.  (Config 2's K = 2048
+            // launch of 136 tiles, 272 us: unchanged by itself -- 272 half tiles on 256 CUs end when 136 whole ones do -- but the K = 256
+            // pieces of lookahead = 2 gain 2 %.  As the instance of EVERY narrow launch at N = 32768 it lost 1 %: tools/r06_bn64.sh.)
+            // Every entry still receives its products k ascending in MFMA groups of 4: the same bits.
+            UpdGeo v = u;
+            v.nct = (int)(n_lp * (g.nb / 64)); v.tiles = nullptr;
+            upd_fill_affine<64>(v);
+            const int64_t nsup64 = upd_super_count<64>(v);
+            unsigned nt64 = 0;
+            if (nsup64 > 0) { rc = tile_list(ctx, v, nsup64, &v.tiles, &nt64, 64, nullptr, stream); if (rc) return rc; }
+            if (nt64 > 0) {
+                hipLaunchKernelGGL((k_update<64, true, 8>), dim3(nt64), dim3(512), 0, stream, ctx->A, g.Npad, Lop, ldl, Wop, ldw, K, v);
+                PYIPM_KCHECK();
+                if (used_bn) *used_bn = 64;
+                return 0;
+            }
+        }
         dim3 grid(ntiles, (unsigned)ksplit);             // K is the length of ONE split
         if (ksplit > 1) u.ks_cstride = ks_cstride;
         if (use_waves == 8 && waves == 0 && ksplit == 1 && ctx->reserve_cus > 0 &&
@@ -1639,10 +1659,33 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
         const bool fast = !ctx->grp_fast.empty() && ctx->grp_fast[(size_t)grp];
         return ctx->group_chain && !fast && gsize(grp) * (g.nb / TB) <= 32 && g.nb % 128 == 0;
     };
+    // Group 0 right-looking panel by panel (round 6, lookahead = 2): a system whose x block is ONE group followed by the slack
+    // block (config 2).  Nothing runs beside the first group's chain, the slack group is no work, and the x group's bulk
+    // update -- a launch of a hundred-odd tiles -- is what the multiplier block's chain waits for in full (272 us of 2.22 ms).
+    // Here every panel of group 0 goes to the columns beyond the group as soon as it is complete: a K = nb launch on the side
+    // stream (idle until the next chain) behind the panel's event, under the chain of the panels that follow; neither a head
+    // nor a bulk update is left for group 0.  Every entry receives the same products in the same order.  Measured
+    // (tools/r06_early.sh): config 2 2.225 -> 2.165 ms -- the chain itself slows from 880 to 970 us beside the pieces (its
+    // round trips to memory share the fabric with their operands), the next chain starts 140 us earlier.  Where the next group
+    // is an ordinary one the one-group lookahead already hides the bulk update under that group's chain and the pieces lose
+    // (n, me, mi = 3072, 512, 1024: 2.99 -> 3.08 ms): not applied there.  Fewer, persistent blocks per piece (64 ... 192
+    // of them) only made the last piece longer.
+    const bool early0 = ctx->lookahead >= 2 && ngroups > 2 && chain_group(0) && !ctx->grp_fast.empty() && !ctx->grp_fast[0] &&
+                        ctx->grp_fast[1] && ctx->s_early && ctx->head_on_side;
+    if (early0 && !ctx->ev_early) PYIPM_HIP(hipEventCreateWithFlags(&ctx->ev_early, hipEventDisableTiming));
+    auto early_piece = [&](int64_t q, hipStream_t used) -> int {
+        const int64_t p1 = ctx->grp_first[1];
+        PYIPM_HIP(hipEventRecord(ctx->ev_early, used));
+        PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_early, 0));
+        return timed_update(ctx, q, 1, p1, np - p1, ctx->side, 0, nullptr, nullptr, false, /*as_bulk=*/true);
+    };
     // all panels of one group on stream S
     auto run_group = [&](int64_t grp, hipStream_t S) -> int {
         const int64_t pA = ctx->grp_first[(size_t)grp], nA = gsize(grp);
-        auto done = [&](int64_t q, hipStream_t used) -> int { return after_panel(q, used); };
+        auto done = [&](int64_t q, hipStream_t used) -> int {
+            int r2 = after_panel(q, used); if (r2) return r2;
+            return (early0 && grp == 0) ? early_piece(q, used) : 0;
+        };
         if (chain_group(grp)) return factor_group(ctx, pA, nA, S, done);
         for (int64_t q = pA; q < pA + nA; ++q) {
             if (!s_done_early[(size_t)q]) { int r2 = factor_panel(ctx, q, S, true); if (r2) return r2; }
@@ -1771,7 +1814,13 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
                 hs = ctx->side;
                 if (s_early && fast_src) PYIPM_HIP(hipStreamWaitEvent(ctx->side, ctx->ev_sfast, 0));   // (k_s_schur reads the slack columns)
             }
-            {
+            const bool pieces = early0 && grp == 0;        // group 0's contribution is on the side stream already, panel by panel
+            if (pieces) {
+                PYIPM_HIP(hipEventRecord(ctx->ev_early, ctx->side));          // the last piece
+                PYIPM_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_early, 0)); // (later updates of those columns; cs, if it is the main stream)
+                if (ctx->rest) PYIPM_HIP(hipStreamWaitEvent(ctx->rest, ctx->ev_early, 0));
+            }
+            if (!pieces) {
                 const int64_t q = p0;
                 const bool split = chain_group(grp + 1) && cs != ctx->stream;
                 mark("head begin", grp, hs);
@@ -1797,9 +1846,10 @@ int factor_all(Ctx* ctx, pyipm_factor_stats* stats, bool fuse_forward = false) {
             PYIPM_HIP(hipEventRecord(ctx->ev_panel, cs));
             mark("bulk begin", grp, ctx->stream);
             across_prev = across;
-            if (across) { rc = timed_update(ctx, p0, n0, pT + nT, np - (pT + nT)); if (rc) return rc; }   // (the target's columns: the head above)
+            if (pieces) { /* applied panel by panel */ }
+            else if (across) { rc = timed_update(ctx, p0, n0, pT + nT, np - (pT + nT)); if (rc) return rc; }   // (the target's columns: the head above)
             else
-            rc = timed_update(ctx, p0, n0, p1 + n1, np - (p1 + n1)); if (rc) return rc;   // bulk (overlaps the side stream)
+            { rc = timed_update(ctx, p0, n0, p1 + n1, np - (p1 + n1)); if (rc) return rc; }   // bulk (overlaps the side stream)
             mark("bulk end", grp, ctx->stream);
             // what the next head must not overtake on the main stream: this group's bulk update -- recorded
             // BEFORE the main stream starts waiting for the side stream (the head would otherwise wait for its own stream,
@@ -2989,7 +3039,7 @@ int pyipm_newton_set_option(pyipm_newton_ctx* h, const char* name, double value)
         return PYIPM_OK; }
     if (!strcmp(name, "condensed_sigma_max")) { ctx->cond_sigma_max = value; return PYIPM_OK; }
     if (!strcmp(name, "condensed_refine")) { ctx->cond_min_refine = (int)value < 0 ? 0 : (int)value; return PYIPM_OK; }
-    if (!strcmp(name, "lookahead")) { ctx->lookahead = (int)value != 0; return PYIPM_OK; }
+    if (!strcmp(name, "lookahead")) { ctx->lookahead = (int)value < 0 ? 0 : ((int)value > 2 ? 2 : (int)value); return PYIPM_OK; }
     if (!strcmp(name, "group")) {           // may only shrink below the create-time value (workspace is sized for it)
         int v = (int)value; if (v < 1 || v > default_group(ctx->g.world, ctx->g.nb)) { ctx->err = "group out of range"; return PYIPM_E_BADARG; }
         ctx->group = v; return PYIPM_OK; }

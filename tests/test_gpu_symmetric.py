@@ -302,7 +302,7 @@ NOT_SCHEDULE = {"expert", "condensed", "condensed_sigma_max", "condensed_refine"
                 # test hooks and diagnostics
                 "bc_per_problem",                         # (batched handles: swept in tests/test_gpu_batched.py)
                 "sweep_max_blocks", "debug_fault", "debug_timeline_ptr", "debug_chain_ptr"}
-SCHEDULE_SPACE = {"lookahead": [0, 1], "group": [1, 2, 4, 8], "group_chain": [0, 1], "fuse_forward": [0, 1], "keep_zeros": [0, 1],
+SCHEDULE_SPACE = {"lookahead": [0, 1, 2], "group": [1, 2, 4, 8], "group_chain": [0, 1], "fuse_forward": [0, 1], "keep_zeros": [0, 1],
                   "skip_zeros": [0, 1], "tile_step": [0, 1],
                   # round 3: 128 x 256 bulk tiles, persistent bulk launches that leave CUs to the chain
                   "bulk_bn": [128, 256], "reserve_cus": [0, 16, 64], "persist_rows": [0, 4096, 1 << 20],

@@ -219,3 +219,45 @@ def test_tile_chain_in_the_per_panel_schedule():
         assert torch.equal(out["steps"][0], out["chain"][0]), nb
         sa, sb = out["steps"][1], out["chain"][1]
         assert {k: sa[k] for k in sa if not k.endswith("_ms")} == {k: sb[k] for k in sb if not k.endswith("_ms")}, nb
+
+
+@pytest.mark.parametrize("shape", [(2048, 0, 2048, 256, 8, 5, 3.0), (512, 64, 640, 128, 4, 6, 5.0), (1024, 100, 1100, 256, 4, 7, 2.0)])
+def test_first_group_panel_by_panel_gives_the_bits_of_the_bulk_update(shape):
+    """lookahead = 2 (factor_all, round 6): where the x block is ONE group and the slack block follows it (config 2), every panel of
+    that group is applied to the columns beyond it as soon as it is complete -- K = nb launches on the side stream under the
+    group's own chain, 128 x 64 tiles where a launch has few -- instead of one bulk update that the multiplier block's chain
+    waits for.  Against the one-group lookahead and no lookahead at all: factor storage, statistics and direction bit for bit
+    the same, three steps per handle; and the pieces did run (more update launches than with the bulk update).  Replaces the
+    LAPACK factorisation reached from pyipm.py:18-20, 1720-1721."""
+    import torch
+    from pyipm_amd.newton import NewtonCore
+    n, me, mi, nb, group, seed, decades = shape
+    qp = _graded_qp(n, me, mi, seed, decades)
+    out, launches = {}, {}
+    for key, opts in (("bulk", {"lookahead": 1}), ("pieces", {"lookahead": 2}), ("none", {"lookahead": 0}),
+                      ("pieces_steps", {"lookahead": 2, "tile_chain": 0}), ("pieces_bn128", {"lookahead": 2, "bulk_bn": 128})):
+        core = NewtonCore(n, me, mi, device=0, nb=nb)
+        core.set_option("expert", 1)
+        core.set_option("profile", 1)
+        core.set_option("group", group)
+        for k, v in opts.items():
+            core.set_option(k, v)
+        core.stage_blocks(qp["d2L"], qp["Je"], qp["Ji"])
+        core.stage_vectors(qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"], mu=qp["mu"])
+        for rep in range(3):
+            dz, st = core.step(0.0, 0.0)
+            fac = core.kkt_storage().clone().view(torch.int64)
+            if key not in out:
+                out[key] = (dz.clone(), fac, st)
+            assert torch.equal(dz, out[key][0]) and torch.equal(fac, out[key][1]), (shape, key, rep)
+        launches[key] = sum(v["launches"] for v in core.trailing_instances().values())
+        core.close()
+    for b in ("pieces", "none", "pieces_steps", "pieces_bn128"):
+        assert torch.equal(out["bulk"][1], out[b][1]), (shape, b, "factor storage")
+        assert torch.equal(out["bulk"][0], out[b][0]), (shape, b, "direction")
+        sa, sb = out["bulk"][2], out[b][2]
+        assert {k: sa[k] for k in sa if not k.endswith("_ms")} == {k: sb[k] for k in sb if not k.endswith("_ms")}, (shape, b)
+    if n >= 2048:          # (launches of less than 30 us are not counted: factor_end takes them for empty tile lists)
+        assert launches["pieces"] > launches["bulk"], (shape, launches)
+    st = out["bulk"][2]
+    assert st["n_neg"] == me + mi and st["nonfinite"] == 0, (shape, st)
