@@ -37,7 +37,7 @@ timeout 900 python tools/bench_lbfgs.py > $O/bench_lbfgs.txt 2>&1
 ( timeout 300 python tools/bench_tile.py 1 ) > $O/bench_tile.txt 2>&1
 ( timeout 300 python tools/chain_clock.py 2048 0 2048 0 1 ) > $O/chain_clock_cfg2.txt 2>&1
 ( timeout 300 python tools/group_trace.py 2048 0 2048 2>&1 | tail -45 ) > $O/group_trace_cfg2.txt 2>&1
-( timeout 600 python tools/ab_opts.py 2048 0 2048 30 "tile_chain=0" "" "chain_lds_kb=0" "chain_whole=0" "tail_group=8" ) > $O/ab_chain_cfg2.txt 2>&1
+( timeout 600 python tools/ab_opts.py 2048 0 2048 30 "tile_chain=0" "" "chain_lds_kb=0" "chain_whole=0" "lookahead=1" "lookahead=1,bulk_bn=128" ) > $O/ab_chain_cfg2.txt 2>&1
 ( timeout 900 python tools/ab_opts.py 16384 4096 6144 5 "tile_chain=0" "" "tile_chain=2" ) > $O/ab_chain_n32768.txt 2>&1
 ( timeout 300 python tools/update_cycles.py; echo; echo '--- one wide launch (K = 1024) repeated in isolation:'; timeout 300 python tools/timeline_update.py 1024 | head -8 ) > $O/update_cycles.txt 2>&1 < /dev/null
 rm -rf $O/pmc/*/*.db $O/pmc_hbm/*/*.db 2>/dev/null
