@@ -285,7 +285,9 @@ LADDER = (
     ("ncclBroadcast, one message per panel", {"dist_comm2": 0, "dist_slices": 0, "dist_sag": 0}),
     ("scatter + all-gather panels, one message per panel", {"dist_comm2": 0, "dist_slices": 0, "dist_sag": 1}),
     ("slices ahead of the panel message, one communicator", {"dist_comm2": 0, "dist_slices": 1, "dist_sag": 1}),
-    ("slices ahead of the panel message, slices on a second communicator", {"dist_slices": 1, "dist_sag": 1, "dist_comm2": 1}),
+    ("slices ahead of the panel message, one communicator, the second slice's rows inside the chain's launch",
+     {"dist_comm2": 0, "dist_slices": 2, "dist_sag": 1}),
+    ("slices ahead of the panel message, slices on a second communicator", {"dist_slices": 2, "dist_sag": 1, "dist_comm2": 1}),
 )
 
 

@@ -447,10 +447,11 @@ int pyipm_newton_trailing_bytes(pyipm_newton_ctx* ctx, double out[4]);
  *   "dist_sag" 0|1      COLLECTIVE: 0 keeps the plain broadcast for the panel messages, 1 goes back to what the exchange
  *                       self-test decided (see pyipm_newton_comm_bcast_mode); "dist_sag_min_bytes" (4 MiB): smaller messages
  *                       always take the plain broadcast.
- *   "dist_slices" 0|1   (1) COLLECTIVE: the two-message protocol of the distributed factorisation -- the rows of panel p
+ *   "dist_slices" 0|1|2 (2) COLLECTIVE: the two-message protocol of the distributed factorisation -- the rows of panel p
  *                       that meet the diagonal block of panel p + 1 (and the rows of panel p + 2) go from owner(p) to
  *                       owner(p + 1) point to point AHEAD of the panel message, so the next owner's tile chain starts on an
- *                       nb x nb message; 0: one message per panel (rounds 1-4).  Bit-identical either way.
+ *                       nb x nb message; 2: the rows of the second slice take their stages inside the chain's own launch
+ *                       (no launch of their own behind it); 0: one message per panel (rounds 1-4).  Bit-identical.
  *   "dist_comm2" 0|1    (0) COLLECTIVE, RCCL transport: the slice messages on a SECOND communicator over the same ranks, on
  *                       the owner's stream, so that they do not queue behind a panel broadcast in flight.  Setting it (before
  *                       or after comm_init) creates the communicator -- every rank must make the call; the ranks agree before

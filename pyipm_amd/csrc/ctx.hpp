@@ -74,6 +74,9 @@ struct DevStats {          // lives in device memory; tile kernels of one rank r
 struct ChainGeo {
     int ta, tb, nT;          // steps [ta, tb) of a diagonal block of nT tiles
     int cpy;                 // column tiles per unit and stage a row tile is split for (5: k_tile_step's rule)
+    int nR;                  // row tiles of the launch: nT, or more -- EXTRA rows right below the diagonal block whose every stage the
+                             // launch applies too (per-panel schedule: the rows the next panel's owner waits for)
+    const unsigned* xword; unsigned xwant;   // the extra rows may be touched once *xword has reached xwant (NULL: at once)
     unsigned base;           // epoch of the progress words: word - base = progress of THIS launch (wrap-safe compare)
     unsigned* sync;          // [0]: tiles inverted by the chain (base + t + 1 after tile t);  [1 + 4 r + y]: stages unit (r, y) completed
     unsigned* err;           // sticky: a poll timed out
@@ -159,7 +162,7 @@ struct Ctx {
     bool sweep_used = false;              // ... a sweep ran since the error word was last read (solve_info / factor_end look at it)
     int dist_head_split = 1;              // per-panel schedule: the owner's head in two launches -- the next panel's diagonal block (its chain waits for
                                           // that alone), then the rows below it on ctx->rest (round 4)
-    int dist_slices = 1;                  // distributed schedule: the two-message protocol (slices ahead of the panel message: the next owner's tile
+    int dist_slices = 2;                  // distributed schedule: the two-message protocol (slices ahead of the panel message: the next owner's tile
                                           // chain starts on an nb x nb message); 0 = one message per panel (rounds 1-4); collective
     double dist_timeout_s = 300.0;        // distributed step: bound on the host's wait for the device (dist_impl.hpp:bounded_wait); <= 0: none
     int dist_comm2 = 0;                   // RCCL transport: the slice messages on a second communicator of their own (set before comm_init; dist_impl.hpp:comm2_setup)

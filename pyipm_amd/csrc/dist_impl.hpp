@@ -119,6 +119,8 @@ struct DistState {
     // peer never joined does not return an error -- its stream just stops; the host waits for the step with a bound
     // (set_option("dist_timeout_s")) and reports WHICH panel's message / update / chain did not complete (PYIPM_E_COMM) instead
     // of blocking for ever.
+    unsigned* xflag = nullptr; unsigned xtoken = 0;                   // extra rows of a panel's chain launch: the word their units wait for, the count it last got
+    hipEvent_t ev_x = nullptr;
     unsigned* prog_host = nullptr; unsigned* prog_dev = nullptr;     // [0] panel messages, [1] bulk updates, [2] owned panels (count so far: index + 1)
     hipEvent_t ev_all = nullptr;
     bool broken = false;                               // a step timed out: the streams hold work that may never finish; only destroy is safe
@@ -172,6 +174,10 @@ int dist_state(Ctx* ctx, DistState** out) {
         DIST_HIP(hipHostMalloc((void**)&D->prog_host, 4 * sizeof(unsigned), hipHostMallocMapped));
         DIST_HIP(hipHostGetDevicePointer((void**)&D->prog_dev, D->prog_host, 0));
         for (int k = 0; k < 4; ++k) D->prog_host[k] = 0u;
+        DIST_HIP(hipMalloc((void**)&D->xflag, 64));
+        DIST_HIP(hipMemset(D->xflag, 0, 64));
+        DIST_HIP(hipDeviceSynchronize());              // (the fill is ordered on the NULL stream; the word is polled from non-blocking streams)
+        DIST_HIP(hipEventCreateWithFlags(&D->ev_x, hipEventDisableTiming));
         DIST_HIP(hipEventCreateWithFlags(&D->ev_all, hipEventDisableTiming));
     }
     *out = D;
@@ -188,6 +194,8 @@ void dist_free(Ctx* ctx) {
         if (D->comm) { g_rccl.CommAbort(D->comm); D->comm = nullptr; }
     }
     if (D->prog_host) hipHostFree(D->prog_host);
+    if (D->xflag) hipFree(D->xflag);
+    if (D->ev_x) hipEventDestroy(D->ev_x);
     if (D->ev_all) hipEventDestroy(D->ev_all);
     if (D->side) { hipStreamSynchronize(D->side); hipStreamDestroy(D->side); }
     if (D->cs) { hipStreamSynchronize(D->cs); hipStreamDestroy(D->cs); }
@@ -236,7 +244,7 @@ int dist_set_option(Ctx* ctx, const char* name, double value, bool* handled) {
         return PYIPM_OK;
     }
     if (!strcmp(name, "dist_timeout_s")) { *handled = true; ctx->dist_timeout_s = value; return PYIPM_OK; }
-    if (!strcmp(name, "dist_slices")) { *handled = true; ctx->dist_slices = (int)value != 0; return PYIPM_OK; }     // COLLECTIVE, like dist_sag
+    if (!strcmp(name, "dist_slices")) { *handled = true; ctx->dist_slices = (int)value <= 0 ? 0 : ((int)value >= 2 ? 2 : 1); return PYIPM_OK; }     // COLLECTIVE, like dist_sag
     if (!strcmp(name, "dist_comm2")) {                  // COLLECTIVE: the slice messages on a second communicator (comm2_setup below)
         *handled = true;
         ctx->dist_comm2 = (int)value != 0;
@@ -810,8 +818,33 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
                 const double* tiles_k = D->sbuf[b][0] + ldE1 * g.panel_w(k);      // slice 1 carries the panel's tile inverses, tiles, flags
                 rc = unpack_slice(ctx, k, 1, D->sbuf[b][0], tiles_k, D->EL[0], side); if (rc) return rc;
                 rc = head_rows(k, nxt, c1n, c2n, D->EL[0] - c1n, ldE1, side, true); if (rc) return rc;
+                // (round 6) The rows of panel k + 2 -- what the NEXT owner's chain waits for as its slice 1 -- ride in the chain's own
+                // launch: their units apply every stage as the chain publishes it, instead of a k_panel_rest launch behind the chain
+                // (34 us + two launch boundaries per panel on the owners' path).  Their head comes from slice 2 of panel k, which is
+                // still on its way when the chain starts: it is unpacked and applied on the rows stream, and a word set behind it
+                // releases those units (bounded poll, as every poll of that kernel).  Not with slices posted on the owner's own
+                // stream behind the chain (s2_late): the receive would sit behind the kernel that waits for it.
+                const bool ext = c3n > c2n && !s2_late && ctx->dist_slices >= 2 && chain_extra_ok(ctx, nxt, c3n - c2n);
+                if (ext) {
+                    // (on the collective stream, right behind the receive of slice 2: an idle stream woken through two events took
+                    //  longer to get there than the launch it saves)
+                    const hipStream_t xs = cs;
+                    DIST_HIP(hipEventRecord(D->ev_x, side));                      // (behind unpack 1 / head 1: the tiles are read from the same buffer,
+                    DIST_HIP(hipStreamWaitEvent(xs, D->ev_x, 0));                 //  EL[1]'s earlier readers are ordered)
+                    if (pre_rec) DIST_HIP(hipStreamWaitEvent(xs, D->ev_pre, 0));
+                    rc = unpack_slice(ctx, k, 2, D->sbuf[b][1], tiles_k, D->EL[1], xs); if (rc) return rc;
+                    DIST_HIP(hipEventRecord(D->ev_sfree[b][1], xs)); sfree_rec[b][1] = true;
+                    rc = head_rows(k, nxt, c2n, c3n, D->EL[1] - c2n, c3n - c2n, xs, true); if (rc) return rc;
+                    D->xtoken += 1;
+                    hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, xs, D->xflag, D->xtoken); DIST_KCHECK();
+                    rc = panel_chain(ctx, nxt, side, c3n - c2n, D->xflag, D->xtoken); if (rc) return rc;
+                    // (the slice-1 buffer's tiles are read by that unpack: it must have run before the buffer is freed below)
+                    DIST_HIP(hipEventRecord(D->ev_x, xs));
+                    DIST_HIP(hipStreamWaitEvent(side, D->ev_x, 0));
+                } else {
                 rc = panel_chain(ctx, nxt, side); if (rc) return rc;
-                if (c3n > c2n) {
+                }
+                if (c3n > c2n && !ext) {
                     rc = span_end(ctx, D, sp_chain, side); if (rc) return rc;
                     if (s2_late) { rc = xchg_s(k, 2, 2); if (rc) return rc; }
                     DIST_HIP(hipStreamWaitEvent(side, D->ev_srecv[b][1], 0));

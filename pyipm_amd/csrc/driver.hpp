@@ -67,7 +67,8 @@ int solve_plain(Ctx* ctx, double* v, bool forward_done, int nrhs = 1, int64_t vs
                 int64_t pstride = 0);
 int ensure_rest_stream(Ctx* ctx);
 bool panel_piecewise_ok(const Ctx* ctx, int64_t p);
-int panel_chain(Ctx* ctx, int64_t p, hipStream_t stream);
+int panel_chain(Ctx* ctx, int64_t p, hipStream_t stream, int64_t xrows = 0, const unsigned* xword = nullptr, unsigned xwant = 0);
+bool chain_extra_ok(const Ctx* ctx, int64_t p, int64_t xrows);
 int panel_rows(Ctx* ctx, int64_t p, int64_t r0, int64_t r1, hipStream_t stream);
 size_t slice_numel(const Geo& g, int64_t p, int j);
 int pack_slice(Ctx* ctx, int64_t p, int j, double* buf, hipStream_t st);

@@ -32,17 +32,20 @@ namespace pyipm {
 
 // (struct ChainGeo: ctx.hpp)
 
-// units of row tile r: ny = ceil(#column tiles of its first stage / cpy), 1 .. 4
-__host__ __device__ inline int chain_ny(int r, int ta, int cpy) {
-    const int cols = r - (ta > 0 ? ta - 1 : 0);
+// units of row tile r: ny = ceil(#column tiles of its first stage / cpy), 1 .. 4.  Row tiles r >= nT are EXTRA rows below the
+// diagonal block (per-panel schedule, ChainGeo::nR): their column tiles end at the block's last one.
+__host__ __device__ inline int chain_ny(int r, int ta, int cpy, int nT = 1 << 30) {
+    const int rc = r < nT ? r : nT - 1;
+    const int cols = rc - (ta > 0 ? ta - 1 : 0);
     int ny = (cols + cpy - 1) / cpy;
     return ny < 1 ? 1 : (ny > 4 ? 4 : ny);
 }
 // first row tile with a unit: ta = 0: row 1 (W of column tile 0 is saved by the units); else row ta + 1 (row ta's only stage left is the chain's)
 __host__ __device__ inline int chain_first_row(int ta) { return ta > 0 ? ta + 1 : 1; }
-__host__ inline int chain_units(int ta, int nT, int cpy) {
+__host__ inline int chain_units(int ta, int nT, int cpy, int nR = 0) {
     int u = 0;
-    for (int r = chain_first_row(ta); r < nT; ++r) u += chain_ny(r, ta, cpy);
+    if (nR < nT) nR = nT;
+    for (int r = chain_first_row(ta); r < nR; ++r) u += chain_ny(r, ta, cpy, nT);
     return u;
 }
 
@@ -215,18 +218,32 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
     }
 
     // ------------------------------------------------ the units ------------------------------------------------
+    // Row tiles nT .. nR - 1 (per-panel schedule, cg.nR > nT) are EXTRA rows right below the diagonal block: the rows of the
+    // panel that the next panel's owner is waiting for (its slice 1).  Their units apply EVERY stage 0 .. nT - 1 to the block's
+    // column tiles -- what k_panel_rest did in a launch of its own behind the chain (34 us + a launch boundary on every panel's
+    // path across GPUs) -- and start when *cg.xword has reached cg.xwant: the head of those rows comes from the second slice of
+    // the panel before, on another stream, while the chain is already running on the first.
+    const int nR = cg.nR > nT ? cg.nR : nT;
     int r = rfirst, y = 0, ny = 1;
     {
         int u = (int)blockIdx.x - 1;
-        for (; r < nT; ++r) {
-            ny = chain_ny(r, ta, cg.cpy);
+        for (; r < nR; ++r) {
+            ny = chain_ny(r, ta, cg.cpy, nT);
             if (u < ny) { y = u; break; }
             u -= ny;
         }
-        if (r >= nT) return;
+        if (r >= nR) return;
     }
+    const bool xr = r >= nT;                                        // an extra row tile
+    const int rc = xr ? nT - 1 : r;                                 // its last column tile
     unsigned* const my_w = cg.sync + 1 + 4 * r + y;
     int done = 0;                                                   // stages completed (the saving of W counts as one)
+    if (xr && cg.xword) {
+        // (every wave for itself: nothing of these rows is read before; they were written by kernels that ENDED before the word
+        //  was set -- read past this XCD's caches all the same, below)
+        chain_wait(cg.xword, (threadIdx.x & 63) == 0, cg.xwant, cg.err, cg.timeout, true);
+        asm volatile("" ::: "memory");
+    }
     if (ta == 0) {
         if (y == 0) {                                               // -S of column tile 0 (launch 0 of the stepped schedule)
             const int tid = threadIdx.x;
@@ -235,7 +252,8 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
             #pragma unroll
             for (int q = 0; q < TB * TB / 256; ++q) {
                 const int e = tid + 256 * q;
-                tmp[q] = A[(r0 + (e & 63)) + (lc0 + (e >> 6)) * ld];
+                const double* src = A + (r0 + (e & 63)) + (lc0 + (e >> 6)) * ld;
+                tmp[q] = xr ? ldg_c<true>(src) : *src;
             }
             #pragma unroll
             for (int q = 0; q < TB * TB / 256; ++q) {
@@ -249,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
         if (threadIdx.x == 0) __hip_atomic_store(my_w, cg.base + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const int s0 = ta > 0 ? ta - 1 : 0;
-    const int s1 = (r - 2 < tb - 2) ? r - 2 : tb - 2;               // last stage of this unit in this launch
+    const int s1 = xr ? tb - 1 : ((r - 2 < tb - 2) ? r - 2 : tb - 2);   // last stage of this unit in this launch (an extra row: every tile of the block)
     #pragma clang loop unroll(disable)
     for (int tp = s0; tp <= s1; ++tp) {
         const int tid = tile_tid<true>(), lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -257,16 +275,16 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
         const int64_t i = c0 + (int64_t)r * TB + wave * 16 + l15;
         // ---- what this stage reads from other workgroups ----
         //  inv(T[tp]) (the chain, unless an earlier launch inverted it);  S of column tile tp of this row tile = W(r, tp): the unit
-        //  of this row that owns column tile tp, stage tp - 1;  Wn operands W(v, tp), v = tp + 1 .. r - 1 with v mod ny = y: the
+        //  of this row that owns column tile tp, stage tp - 1;  Wn operands W(v, tp), v = tp + 1 .. rc (v < r) with v mod ny = y: the
         //  unit of row v that owns ITS column tile tp, stage tp - 1 (lane j polls for v = tp + 1 + j)
         if (tp >= ta) chain_wait(crit_w, lane == 0, cg.base + (unsigned)(tp + 1), cg.err, cg.timeout, true);
         {
             const int need = tp - sfirst;
-            const int v = tp + 1 + lane;
-            bool act = need > 0 && v <= r && (v == r || v % ny == y);
+            const int v = tp + 1 + lane;                            // (v = r is among them: r - tp - 1 < 64)
+            bool act = need > 0 && ((v <= rc && v % ny == y) || v == r);
             int nyv = 1;
             if (act) {
-                nyv = chain_ny(v, ta, cg.cpy);
+                nyv = chain_ny(v, ta, cg.cpy, nT);
                 // (stage tp - 1 of row v = tp + 1 is that row's last one: the owner of column tile tp wrote W(v, tp) then)
                 if (v == r && tp % ny == y) act = false;            // my own column tile
             }
@@ -274,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
             if (need > 0) chain_wait(cg.sync + 1 + 4 * v + yo, act && v >= rfirst, cg.base + (unsigned)need, cg.err, cg.timeout, true);
         }
         asm volatile("" ::: "memory");
-        if (cg.dbg && tid == 0) cg.dbg[256 + 64 * (4 * r + y) + 2 * tp] = wall_clock64();
+        if (cg.dbg && tid == 0 && r < 32) cg.dbg[256 + 64 * (4 * r + y) + 2 * tp] = wall_clock64();
         int nr = nref;
         if (nr > 0 && ldg_c<true>(Tflag + tp) == 0.0) nr = 0;
         PYIPM_STAGE_TILE_C(X, 1.0, Dinv + tp * TT, true)
@@ -296,13 +314,13 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
             gmax = wave_max(gmax);
             if (lane == 0) atomicMax(&st->growth_bits, (unsigned long long)__double_as_longlong(gmax));
         }
-        // my column tiles of this stage: v in (tp, r], v mod ny = y
+        // my column tiles of this stage: v in (tp, rc], v mod ny = y
         int vb = tp + 1;
         vb += ((y - vb) % ny + ny) % ny;
-        for (int v = vb; v <= r; v += ny) {
+        for (int v = vb; v <= rc; v += ny) {
             double4_t c2[4];
-            if (v == r) {                   // (written through by this unit, stage by stage: read the same way -- a written-through store
-                #pragma unroll              //  need not refresh the CU's own L1 copy of the line)
+            if (v == r || (xr && tp == s0)) {   // (written through by this unit, stage by stage: read the same way -- a written-through store
+                #pragma unroll                  //  need not refresh the CU's own L1 copy of the line; an extra row's first touch: see above)
                 for (int tt = 0; tt < 4; ++tt)
                     #pragma unroll
                     for (int q = 0; q < 4; ++q) c2[tt][q] = ldg_c<true>(A + i + (lc0 + v * TB + tt * 16 + l4 + 4 * q) * ld);
@@ -339,7 +357,7 @@ __global__ __launch_bounds__(256, 2) void k_tile_chain(
         __syncthreads();
         ++done;
         if (tid == 0) __hip_atomic_store(my_w, cg.base + (unsigned)done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cg.dbg && tid == 0) cg.dbg[256 + 64 * (4 * r + y) + 2 * tp + 1] = wall_clock64();
+        if (cg.dbg && tid == 0 && r < 32) cg.dbg[256 + 64 * (4 * r + y) + 2 * tp + 1] = wall_clock64();
     }
 }
 

@@ -437,7 +437,8 @@ void panel_hole(const Ctx* ctx, int64_t p, int64_t* h0, int64_t* h1) {
 }
 
 int factor_wide_panel(Ctx* ctx, int64_t p, hipStream_t stream);
-int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, int nT, int ta, int tb, double* Wg, double* Dv, double* Ts);
+int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, int nT, int ta, int tb, double* Wg, double* Dv, double* Ts,
+                      int nX = 0, const unsigned* xword = nullptr, unsigned xwant = 0);
 
 // Factor panel p on `stream`.  apply_pending: first apply the earlier panels of p's group to p's columns
 // (grouped single-rank driver; their bulk update is deferred to the end of the group).
@@ -564,7 +565,10 @@ static bool chain_applies(const Ctx* ctx, int64_t gc0, int nT) {
     const bool exposed = ctx->per_panel_mode || gc0 == 0 || g.Npad - gc0 <= ctx->tile8_rows;   // (where the chain is what the step waits for)
     return ctx->tile_chain && nT >= 2 && nT <= 32 && (ctx->tile_chain >= 2 || exposed);
 }
-int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, int nT, int ta, int tb, double* Wg, double* Dv, double* Ts) {
+// nX > 0 (k_tile_chain only, ta = 0, tb = nT): nX row tiles right below the diagonal block take every stage in the same launch,
+// once *xword has reached xwant (chain_extra_ok says whether a caller may ask for it).
+int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, int nT, int ta, int tb, double* Wg, double* Dv, double* Ts,
+                      int nX, const unsigned* xword, unsigned xwant) {
     const Geo& g = ctx->g;
     if (tb <= ta) return 0;
     if (tb - ta >= 2 && chain_applies(ctx, gc0, nT)) {
@@ -585,6 +589,7 @@ int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, in
         }
         ChainGeo cg;
         cg.ta = ta; cg.tb = tb; cg.nT = nT; cg.cpy = ctx->chain_cpy > 0 ? ctx->chain_cpy : 5;
+        cg.nR = nT + ((ta == 0 && tb == nT) ? nX : 0); cg.xword = xword; cg.xwant = xwant;
         ctx->chain_epoch += 1;
         cg.base = ctx->chain_epoch * 64u;
         cg.sync = ctx->chain_sync + (size_t)(ctx->chain_epoch % Ctx::CHAIN_SLOTS) * Ctx::CHAIN_WORDS;
@@ -592,7 +597,7 @@ int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, in
         cg.timeout = (unsigned long long)2.0e8;          // 2 s (100 MHz clock)
         cg.dbg = nullptr;
         if (ctx->chain_dbg && ctx->chain_dbg_launch < 64) cg.dbg = ctx->chain_dbg + (size_t)(ctx->chain_dbg_launch++) * CHAIN_DBG_WORDS;
-        const unsigned nblk = 1u + (unsigned)chain_units(ta, nT, cg.cpy);
+        const unsigned nblk = 1u + (unsigned)chain_units(ta, nT, cg.cpy, cg.nR);
         // dynamic shared memory nobody touches: with it a workgroup of the chain has its compute unit to itself (single-rank
         // schedule only: beside the bulk updates of the per-panel schedule it would wait for a whole CU to drain)
         size_t pad = (ctx->chain_lds_kb > 0 && !ctx->per_panel_mode) ? (size_t)ctx->chain_lds_kb * 1024 : 0;
@@ -608,6 +613,7 @@ int launch_tile_steps(Ctx* ctx, hipStream_t chain, int64_t gc0, int64_t glc0, in
         ctx->chain_last = cg;
         return 0;
     }
+    if (nX > 0) { ctx->err = "launch_tile_steps: extra rows need the one-launch chain (chain_extra_ok)"; return PYIPM_E_BADARG; }
     for (int j = ta; j < tb; ++j) {
         int ny = (nT - j + 4) / 5; if (ny < 1) ny = 1; if (ny > 4) ny = 4;     // <= ~5 column tiles per block
         // the critical block on eight waves (chain + helpers) where a whole CU is to be had: a 512-thread block owns the
@@ -801,12 +807,28 @@ bool panel_piecewise_ok(const Ctx* ctx, int64_t p) {
     return wide ? (nt <= 32) : (nt <= 16);
 }
 // the tile steps of panel p's diagonal block (all that needs is the diagonal block up to date)
-int panel_chain(Ctx* ctx, int64_t p, hipStream_t stream) {
+int panel_chain(Ctx* ctx, int64_t p, hipStream_t stream, int64_t xrows, const unsigned* xword, unsigned xwant) {
     const Geo& g = ctx->g;
     const int64_t c0 = g.panel_c0(p), lc0 = g.local_c0(p);
     const int nt = (int)(g.panel_w(p) / TB);
     return launch_tile_steps(ctx, stream, c0, lc0, nt, 0, nt, wbuf(ctx, p), ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB),
-                             ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB));
+                             ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB), (int)(xrows / TB), xword, xwant);
+}
+// may panel p's chain take the `xrows` rows right below its diagonal block along (every stage of theirs in the chain's launch
+// instead of panel_rows behind it)?  The one-launch chain, a panel that is not swept in sub-panels, whole tiles, none of them
+// inside the panel's hole of structural zeros (k_panel_rest leaves those alone), progress words enough.
+bool chain_extra_ok(const Ctx* ctx, int64_t p, int64_t xrows) {
+    const Geo& g = ctx->g;
+    const int64_t c0 = g.panel_c0(p);
+    const int nbw = (int)g.panel_w(p), nt = nbw / TB;
+    if (xrows <= 0 || xrows % TB != 0 || xrows / TB > 8 || c0 + nbw + xrows > g.Npad) return false;
+    if (!(nt >= 2 && chain_applies(ctx, c0, nt))) return false;
+    if (ctx->wide_sub >= 128 && ctx->wide_sub % 128 == 0 && nbw > ctx->wide_sub) return false;
+    if (1 + 4 * (nt + (int)(xrows / TB)) > Ctx::CHAIN_WORDS) return false;
+    int64_t h0 = 0, h1 = 0;
+    panel_hole(ctx, p, &h0, &h1);
+    const int64_t r0 = c0 + nbw, r1 = r0 + xrows;
+    return !(h1 > h0 && r1 > h0 && r0 < h1);
 }
 // every stage of panel p for the rows [r0, r1) below its diagonal block (128-aligned), the chain complete on `stream` before
 int panel_rows(Ctx* ctx, int64_t p, int64_t r0, int64_t r1, hipStream_t stream) {

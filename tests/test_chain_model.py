@@ -14,8 +14,9 @@ import random
 import pytest
 
 
-def chain_ny(r, ta, cpy):                      # kernels_chain.hpp:chain_ny
-    cols = r - (ta - 1 if ta > 0 else 0)
+def chain_ny(r, ta, cpy, nT=1 << 30):          # kernels_chain.hpp:chain_ny (row tiles r >= nT: extra rows below the diagonal block)
+    rc = r if r < nT else nT - 1
+    cols = rc - (ta - 1 if ta > 0 else 0)
     ny = (cols + cpy - 1) // cpy
     return 1 if ny < 1 else (4 if ny > 4 else ny)
 
@@ -27,17 +28,18 @@ def chain_first_row(ta):                       # kernels_chain.hpp:chain_first_r
 class Launch(object):
     """One k_tile_chain launch over the steps [ta, tb) of a block of nT tiles; `state` carries what earlier launches left."""
 
-    def __init__(self, nT, ta, tb, cpy, state):
+    def __init__(self, nT, ta, tb, cpy, state, nR=None):
         self.nT, self.ta, self.tb, self.cpy, self.st = nT, ta, tb, cpy, state
+        self.nR = nT if nR is None else nR      # nR > nT (ta = 0, tb = nT): extra row tiles that take EVERY stage in this launch
         self.sfirst = ta - 1 if ta > 0 else -1
         self.rfirst = chain_first_row(ta)
         self.crit = ta                          # progress word of the chain: tiles inverted so far (word - base)
         self.t = ta                             # next step of the chain
         self.units = {}
-        for r in range(self.rfirst, nT):
-            for y in range(chain_ny(r, ta, cpy)):
+        for r in range(self.rfirst, self.nR):
+            for y in range(chain_ny(r, ta, cpy, nT)):
                 s0 = ta - 1 if ta > 0 else 0
-                self.units[(r, y)] = {"done": 0, "next": (-1 if ta == 0 else s0), "last": min(r - 2, tb - 2)}
+                self.units[(r, y)] = {"done": 0, "next": (-1 if ta == 0 else s0), "last": (tb - 1 if r >= nT else min(r - 2, tb - 2))}
 
     # ---- what the kernel polls ----
     def _need(self, tp):
@@ -65,15 +67,16 @@ class Launch(object):
         need = self._need(tp)
         if need <= 0:
             return True
-        ny = chain_ny(r, self.ta, self.cpy)
-        for v in range(tp + 1, r + 1):
+        ny = chain_ny(r, self.ta, self.cpy, self.nT)
+        rc = min(r, self.nT - 1)
+        for v in list(range(tp + 1, rc + 1)) + ([r] if r > rc else []):
             if not (v == r or v % ny == y):
                 continue
             if v == r and tp % ny == y:
                 continue                                           # my own column tile
             if v < self.rfirst:
                 continue
-            yo = tp % chain_ny(v, self.ta, self.cpy)
+            yo = tp % chain_ny(v, self.ta, self.cpy, self.nT)
             if self.units[(v, yo)]["done"] < need:
                 return False
         return True
@@ -95,7 +98,7 @@ class Launch(object):
         r, y = key
         u, st = self.units[key], self.st
         tp = u["next"]
-        ny = chain_ny(r, self.ta, self.cpy)
+        ny = chain_ny(r, self.ta, self.cpy, self.nT)
         if tp == -1:
             if y == 0:
                 st["W"][(r, 0)] = True
@@ -105,7 +108,7 @@ class Launch(object):
             assert st["W"][(r, tp)], (key, tp, "S of the row tile in column tile tp")
             if y == 0:
                 st["L"][(r, tp)] = True
-            for v in range(tp + 1, r + 1):
+            for v in range(tp + 1, min(r, self.nT - 1) + 1):
                 if v % ny != y:
                     continue
                 if v < r:
@@ -121,9 +124,10 @@ class Launch(object):
         return self.t >= self.tb and all(u["next"] > u["last"] for u in self.units.values())
 
 
-def fresh_state(nT):
-    return {"inv": [False] * nT, "W": {(r, c): False for r in range(nT) for c in range(nT)},
-            "L": {(r, c): False for r in range(nT) for c in range(nT)}, "C": {(r, v): 0 for r in range(nT) for v in range(nT)}}
+def fresh_state(nT, nR=None):
+    nR = nT if nR is None else nR
+    return {"inv": [False] * nT, "W": {(r, c): False for r in range(nR) for c in range(nT)},
+            "L": {(r, c): False for r in range(nR) for c in range(nT)}, "C": {(r, v): 0 for r in range(nR) for v in range(nT)}}
 
 
 def rows_wait_ok(L, toff_next):
@@ -194,3 +198,31 @@ def test_a_chain_in_pieces_hands_the_state_from_launch_to_launch(nT, sub, cpy):
             assert all(st["C"][(r, v)] == min(tb - 1, v) for r in range(tb, nT) for v in range(tb - 1, r + 1)), (ta, tb)
             ta = tb
         assert all(st["inv"]) and all(st["L"][(r, t)] for r in range(nT) for t in range(r))
+
+
+@pytest.mark.parametrize("nT,nX,cpy", [(4, 4, 5), (4, 2, 5), (8, 4, 2), (16, 8, 5), (2, 4, 5), (4, 4, 1)])
+def test_extra_rows_below_the_block_take_every_stage_in_the_same_launch(nT, nX, cpy):
+    """ChainGeo::nR > nT (the per-panel schedule across GPUs, dist_slices = 2): row tiles below the diagonal block whose units
+    apply every stage 0 .. nT - 1 to the block's column tiles as the chain publishes the tiles -- in place of a k_panel_rest
+    launch behind the chain.  (They start on a word of their own, set when their rows' head is in place: any time, here.)"""
+    rnd = random.Random(31 * nT + nX + cpy)
+    nR = nT + nX
+    for trial in range(20):
+        st = fresh_state(nT, nR)
+        L = Launch(nT, 0, nT, cpy, st, nR)
+        held = set(k for k in L.units if k[0] >= nT) if trial % 2 else set()     # odd trials: the extra rows are released late
+        steps = 0
+        while not L.finished():
+            ready = [("chain", None)] if L.chain_ready() else []
+            ready += [("unit", k) for k in L.units if k not in held and L.unit_ready(k)]
+            if not ready or (held and steps > 3 * nT):
+                assert held, "deadlock"
+                held = set()                                                    # the word goes up
+                continue
+            kind, key = rnd.choice(ready)
+            L.run_chain() if kind == "chain" else L.run_unit(key)
+            steps += 1
+        assert all(st["inv"])
+        assert all(st["L"][(r, t)] for r in range(nR) for t in range(min(r, nT)))
+        assert all(st["C"][(r, v)] == v for r in range(nT, nR) for v in range(nT))    # column tile v got exactly its v stages
+        assert all(st["C"][(r, r)] == r for r in range(nT))

@@ -559,7 +559,9 @@ def test_exchange_forms_give_the_same_bits(world, shape, nb):
          the number of ranks, the stream hop, the self-test that switches the form on);
       B  slices as broadcasts (an exchange without point-to-point callbacks), plain panel broadcasts;
       C  one message per panel (dist_slices = 0), scatter + all-gather;
-      D  one message per panel, plain broadcast -- the protocol of rounds 1 - 4.
+      D  one message per panel, plain broadcast -- the protocol of rounds 1 - 4;
+      E  as B with dist_slices = 1: the rows of the second slice as a k_panel_rest launch behind the chain (round 5) instead of
+         units of the chain's own launch (round 6, the default in A and B).
     The same direction bit for bit from all four, on every rank; message and byte counts per form as predicted."""
     n, me, mi, seed = shape
     p2p = {"p2p": True, "serialize": True, "selftest": True}
@@ -567,7 +569,8 @@ def test_exchange_forms_give_the_same_bits(world, shape, nb):
     runs = {"A": _run_world(world, shape, nb, {"dist_sag_min_bytes": 8}, p2p),
             "B": _run_world(world, shape, nb, None, nop2p),
             "C": _run_world(world, shape, nb, {"dist_slices": 0, "dist_sag_min_bytes": 8}, {"p2p": True, "serialize": False, "selftest": True}),
-            "D": _run_world(world, shape, nb, {"dist_slices": 0}, nop2p)}
+            "D": _run_world(world, shape, nb, {"dist_slices": 0}, nop2p),
+            "E": _run_world(world, shape, nb, {"dist_slices": 1}, nop2p)}        # (B without the second slice's rows in the chain's launch)
     qp = make_qp(n, me, mi, seed)
     ref, _, _, _ = orc.newton_step(qp["d2L"], qp["Je"], qp["Ji"], qp["df"], qp["ce"], qp["ci"], qp["s"], qp["lam"],
                                    qp["mu"], n, me, mi, regularise=False)
@@ -594,7 +597,7 @@ def test_exchange_forms_give_the_same_bits(world, shape, nb):
                 assert w["slice_messages"] == 0 and w["slices_as_broadcast"] == 0
             if name == "A":
                 assert w["stream_hops"] > 0                                   # the sweeps' exchanges hop through the collective stream
-            if name in ("B", "C", "D") and not (name == "C"):
+            if name in ("B", "D", "E"):
                 assert w["stream_hops"] == 0
         if name == "A":
             assert sum(res[r][5]["wire"]["slice_messages"] for r in range(world)) == 2 * nsl     # counted by sender and receiver
@@ -660,11 +663,12 @@ def test_a_stalled_panel_message_is_an_error_code_not_a_hang():
 
 def test_bench_ladder_keeps_a_number_when_a_faster_wire_form_stalls():
     """VERDICT r5 item 2a.  Across GPUs bench.py times every wire form of the distributed factorisation, safest first (plain
-    broadcast -> scatter + all-gather -> slices on one communicator -> slices on a second communicator), and from the second
+    broadcast -> scatter + all-gather -> slices on one communicator -> the same with the second slice's rows inside the chain's
+    launch -> slices on a second communicator), and from the second
     rung on its watchdog holds the best completed result.  Two ranks on the one GPU over gloo; the third rung is made to stall
     (PYIPM_BENCH_LADDER_STALL=2: debug_fault = 3 with the step's own time bound off, i.e. a message that does not complete for
     30 s against a 8 s watch): the run ends with status 0 and ONE line whose value is the best of the two rungs that completed,
-    naming the rung that stalled.  Without a stall the line lists all four rungs and names the one the timed region ran on."""
+    naming the rung that stalled.  Without a stall the line lists all five rungs and names the one the timed region ran on."""
     import json
     import subprocess
     import sys
@@ -676,7 +680,7 @@ def test_bench_ladder_keeps_a_number_when_a_faster_wire_form_stalls():
     out = subprocess.run(base + ["--master-port", str(_free_port())] + tail, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
-    assert len(d["ladder"]) == 4 and d["wire_form"] in [r["wire_form"] for r in d["ladder"]] and d["value"] > 0
+    assert len(d["ladder"]) == 5 and d["wire_form"] in [r["wire_form"] for r in d["ladder"]] and d["value"] > 0
     assert all(r["value"] > 0 for r in d["ladder"])
     env = dict(env, PYIPM_BENCH_LADDER_STALL="2", PYIPM_BENCH_LADDER_WATCH="8")
     out = subprocess.run(base + ["--master-port", str(_free_port())] + tail, cwd=root, env=env, capture_output=True, text=True, timeout=600)

@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--ranks", default="", help="comma-separated ranks to replay (default: all)")
     ap.add_argument("--serialize", type=int, default=0, help="1: every exchange operation through the collective stream (one communicator)")
-    ap.add_argument("--slices", type=int, default=1, help="1: the two-message protocol (round 5, default); 0: one message per panel (rounds 1-4)")
+    ap.add_argument("--slices", type=int, default=2, help="2: the two-message protocol with the second slice's rows inside the chain's launch (round 6, default); 1: the two-message protocol of round 5; 0: one message per panel (rounds 1-4)")
     ap.add_argument("--opt", action="append", default=[])
     args = ap.parse_args()
     import numpy as np
@@ -258,7 +258,7 @@ def main():
                 core.set_exchange(*cb)
                 cb2 = (SEND_FN(send), RECV_FN(recv), ALLGATHER_FN(allgather))
                 core.set_exchange_p2p(*cb2, serialize=bool(args.serialize))     # (0: slices on their own stream -- the RCCL path's second communicator)
-                core.set_option("dist_slices", 1 if args.slices else 0)
+                core.set_option("dist_slices", int(args.slices))
                 walls, tms, dts, wrs = [], [], [], []
                 for it in range(args.steps + 1):
                     state["k"] = 0; state["link_ms"] = 0.0; state["rk"] = 0; state["slice_link_ms"] = 0.0
