@@ -815,15 +815,15 @@ int panel_chain(Ctx* ctx, int64_t p, hipStream_t stream, int64_t xrows, const un
                              ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB), (int)(xrows / TB), xword, xwant);
 }
 // may panel p's chain take the `xrows` rows right below its diagonal block along (every stage of theirs in the chain's launch
-// instead of panel_rows behind it)?  The one-launch chain, a panel that is not swept in sub-panels, whole tiles, none of them
-// inside the panel's hole of structural zeros (k_panel_rest leaves those alone), progress words enough.
+// instead of panel_rows behind it)?  The one-launch chain, whole tiles -- at most 16 of them: a wide panel's (nb = 1024) rows for
+// the next owner are 16 row tiles of 16 stages each, units that keep the chain's pace like the block's own far rows --, none of
+// them inside the panel's hole of structural zeros (k_panel_rest leaves those alone), progress words enough.
 bool chain_extra_ok(const Ctx* ctx, int64_t p, int64_t xrows) {
     const Geo& g = ctx->g;
     const int64_t c0 = g.panel_c0(p);
     const int nbw = (int)g.panel_w(p), nt = nbw / TB;
-    if (xrows <= 0 || xrows % TB != 0 || xrows / TB > 8 || c0 + nbw + xrows > g.Npad) return false;
+    if (xrows <= 0 || xrows % TB != 0 || xrows / TB > 16 || c0 + nbw + xrows > g.Npad) return false;
     if (!(nt >= 2 && chain_applies(ctx, c0, nt))) return false;
-    if (ctx->wide_sub >= 128 && ctx->wide_sub % 128 == 0 && nbw > ctx->wide_sub) return false;
     if (1 + 4 * (nt + (int)(xrows / TB)) > Ctx::CHAIN_WORDS) return false;
     int64_t h0 = 0, h1 = 0;
     panel_hole(ctx, p, &h0, &h1);
