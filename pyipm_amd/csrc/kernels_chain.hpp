@@ -12,7 +12,10 @@
 //   * every other workgroup is a unit (r, y): it OWNS row tile r of the diagonal block for the whole launch and applies the
 //     stages tp = max(ta - 1, 0) .. min(r - 2, tb - 2) to the column tiles v = tp + 1 .. r with v mod ny(r) = y (a far row tile
 //     has many: ny(r) units share it, each forming the scaling product itself, as the y-blocks of k_tile_step do).  Its
-//     column tiles never leave the unit, so they move through plain loads and stores.
+//     column tiles never leave the unit, so they move through plain loads and stores;
+//   * (per-panel schedule across GPUs, ChainGeo::nR > nT) EXTRA row tiles right below the block -- the rows the next panel's
+//     owner waits for -- have units of their own that apply every stage 0 .. nT - 1 as the chain publishes the tiles, in place of
+//     a k_panel_rest launch behind the chain; a word set behind their head (which arrives on another stream) releases them.
 // What crosses workgroups inside the launch -- inv(T), T and the refinement flag of a tile (chain -> units), the -S rows W of
 // a finished column tile (unit -> units, unit -> chain) and row tile t's diagonal tile (unit -> chain) -- is written and read
 // with relaxed agent-scope atomics (sc1: written through, read past the L1) and announced by ONE progress word per
