@@ -958,21 +958,23 @@ int unpack_panel_from(Ctx* ctx, int64_t p, const double* buf, int64_t row_from, 
     }
     const int64_t rf = row_from > c1 ? row_from : c1;
     if (m <= 0 || rf >= g.Npad) return 0;
-    // rows [c1, Npad) without the hole [h0, h1) sit in the message with leading dimension m; copy what lies at or beyond rf
+    // rows [c1, Npad) without the hole [h0, h1) sit in the message with leading dimension m.  One launch per segment at or beyond
+    // rf reads -S straight from the message, rebuilds L = S inv(T) into Lbuf and leaves -S where the update launches read it
+    // (round 6; until then: a strided copy of the segment into the W slot, then the product from there -- the panel's 8 nb bytes per
+    // row read twice and written twice on every receiver, 57-70 ms per rank of the N = 131072 replay).  The tile columns of a
+    // received panel are independent (L_t = W_t inv(T_t)): grid.y walks them.
     const int64_t segs[2][2] = {{c1, (h1 > h0) ? h0 : g.Npad}, {(h1 > h0) ? h1 : g.Npad, g.Npad}};
+    NextUpd nu_off; memset(&nu_off, 0, sizeof(nu_off));
     for (int k = 0; k < 2; ++k) {
         const int64_t a = segs[k][0] > rf ? segs[k][0] : rf, b = segs[k][1];
         if (b <= a) continue;
-        const int64_t mrow = a - c1 - ((h1 > h0 && a >= h1) ? (h1 - h0) : 0);
-        PYIPM_HIP(hipMemcpy2DAsync(wbuf(ctx, p) + a, (size_t)g.Npad * sizeof(double), buf + mrow, (size_t)m * sizeof(double),
-                                   (size_t)(b - a) * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, st));
+        const int64_t mrow = a - c1 - ((h1 > h0 && a >= h1) ? (h1 - h0) : 0);      // the message row of matrix row a
+        hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)((b - a) / TB), (unsigned)(nbw / TB)), dim3(256), 0, st,
+                           ctx->Lbuf, g.Npad, (int64_t)0, buf + mrow - a, m, (int64_t)0,
+                           wbuf(ctx, p), g.Npad, (int64_t)0, dinv, tsv, ctx->Tflag + c0 / TB, ctx->block_refine, a, (int64_t)0, (int64_t)0,
+                           (unsigned long long*)nullptr, -1.0, nu_off);
+        PYIPM_KCHECK();
     }
-    NextUpd nu_off; memset(&nu_off, 0, sizeof(nu_off));
-    hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)((g.Npad - rf) / TB), (unsigned)(nbw / TB)), dim3(256), 0, st,
-                       ctx->Lbuf, g.Npad, (int64_t)0, wbuf(ctx, p), g.Npad, (int64_t)0,
-                       (double*)nullptr, (int64_t)0, (int64_t)0, dinv, tsv, ctx->Tflag + c0 / TB, ctx->block_refine, rf, h0, h1,
-                       (unsigned long long*)nullptr, -1.0, nu_off);
-    PYIPM_KCHECK();
     return 0;
 }
 
@@ -2901,42 +2903,7 @@ int pyipm_newton_panel_unpack(pyipm_newton_ctx* h, int64_t p, const double* buf)
     if (ctx->batched) return single_only(ctx);
     PYIPM_HIP(hipSetDevice(ctx->device));
     if (p < 0 || p >= g.npanels || g.owner(p) == g.rank) { ctx->err = "panel_unpack: owner does not unpack"; return PYIPM_E_BADARG; }
-    int64_t h0, h1;
-    panel_hole(ctx, p, &h0, &h1);
-    const int64_t nbw = g.panel_w(p), c0 = g.panel_c0(p), c1 = c0 + nbw, m = g.Npad - c1 - (h1 - h0);
-    const int64_t seg0 = (h1 > h0) ? h0 - c1 : g.Npad - c1, seg1 = (h1 > h0) ? g.Npad - h1 : 0;
-    double* dinv = ctx->Dinv + (c0 / TB) * (int64_t)(TB * TB);
-    double* tsv = ctx->Tsv + (c0 / TB) * (int64_t)(TB * TB);
-    const size_t tbytes = (size_t)(nbw / TB) * TB * TB * sizeof(double);
-    PYIPM_HIP(hipMemcpyAsync(dinv, buf + m * nbw, tbytes, hipMemcpyDeviceToDevice, ctx->stream));
-    PYIPM_HIP(hipMemcpyAsync(tsv, buf + m * nbw + (nbw / TB) * TB * TB, tbytes, hipMemcpyDeviceToDevice, ctx->stream));
-    PYIPM_HIP(hipMemcpyAsync(ctx->Tflag + c0 / TB, buf + m * nbw + 2 * (nbw / TB) * TB * TB,
-                             (size_t)(nbw / TB) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-    if (m > 0) {
-        if (seg0 > 0)
-            PYIPM_HIP(hipMemcpy2DAsync(wbuf(ctx, p) + c1, (size_t)g.Npad * sizeof(double), buf, (size_t)m * sizeof(double),
-                                       (size_t)seg0 * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
-        if (seg1 > 0)
-            PYIPM_HIP(hipMemcpy2DAsync(wbuf(ctx, p) + h1, (size_t)g.Npad * sizeof(double), buf + seg0, (size_t)m * sizeof(double),
-                                       (size_t)seg1 * sizeof(double), (size_t)nbw, hipMemcpyDeviceToDevice, ctx->stream));
-        // rebuild the block column L = W * inv(T) tile by tile into Lbuf (rows of the hole: never read, skipped)
-        // (one launch for all tile columns -- they are independent on a receiver; sixteen launches in a row took 0.6 ms per
-        //  message at nb = 1024, on every receiver's path to its next head: tools/rank_replay.py)
-        NextUpd nu_off; memset(&nu_off, 0, sizeof(nu_off));
-        if (nbw / TB > 1) {
-            hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)((g.Npad - c1) / TB), (unsigned)(nbw / TB)), dim3(256), 0, ctx->stream,
-                               ctx->Lbuf, g.Npad, (int64_t)0, wbuf(ctx, p), g.Npad, (int64_t)0,
-                               (double*)nullptr, (int64_t)0, (int64_t)0, dinv, tsv, ctx->Tflag + c0 / TB, ctx->block_refine, c1, h0, h1,
-                               (unsigned long long*)nullptr, -1.0, nu_off);
-            PYIPM_KCHECK();
-        } else {
-            hipLaunchKernelGGL(k_panel_scale, dim3((unsigned)((g.Npad - c1) / TB)), dim3(256), 0, ctx->stream,
-                               ctx->Lbuf, g.Npad, (int64_t)0, wbuf(ctx, p), g.Npad, (int64_t)0,
-                               (double*)nullptr, (int64_t)0, (int64_t)0, dinv, tsv, ctx->Tflag + c0 / TB, ctx->block_refine, c1, h0, h1,
-                               (unsigned long long*)nullptr, -1.0, nu_off);
-            PYIPM_KCHECK();
-        }
-    }
+    { int rc = unpack_panel_from(ctx, p, buf, 0, /*with_tiles=*/true, ctx->stream); if (rc) return rc; }
     return PYIPM_OK;
 } PYIPM_CATCH_H(h)
 
