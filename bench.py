@@ -249,6 +249,27 @@ class Watchdog(object):
         with self.lock:
             self.fallback = dict(payload) if payload else None
 
+    def fail_now(self, phase, reason):
+        """A ladder rung that RAISES (an error code from the library: a poll of the tile chain timed out, PYIPM_E_COMM) is a rung
+        that did not complete, like one that stalls: the best completed result stands; status 0 with it, 3 without."""
+        with self.lock:
+            fb = dict(self.fallback) if self.fallback else None
+        if self.rank == 0:
+            out = dict(self.base)
+            if fb:
+                out.update(fb)
+                out.update({"ladder_failed_at": phase, "ladder_failure": str(reason)[:400],
+                            "note": "a faster wire form failed; `value` is the best form that completed its timed steps"})
+            else:
+                out.update({"value": None, "error": "phase '%s' failed: %s" % (phase, str(reason)[:400]), "failed_phase": phase})
+            try:
+                os.write(self.json_fd, (json.dumps(out) + "\n").encode())
+            except Exception:
+                pass
+        print("[bench] phase '%s' failed on rank %d (%s) -- %s" % (phase, self.rank, str(reason)[:200],
+              "reporting the best completed wire form" if fb else "giving up"), file=sys.stderr, flush=True)
+        os._exit(0 if fb else 3)
+
     def _run(self):
         while not self.done:
             time.sleep(1.0)
@@ -302,14 +323,17 @@ def run_ladder(core, one_step, fence, wd, world, rank, steps, warmup, reduce_max
         if stall_rung is not None and i == stall_rung:
             core.set_option("dist_timeout_s", 0.0)          # (test hook: this rung's first step stalls for 30 s and nothing bounds the wait)
             core.set_option("debug_fault", 3)
-        for _ in range(max(1, warmup)):
-            one_step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            one_step()
-        fence()
-        el = reduce_max(time.perf_counter() - t0)
+        try:
+            for _ in range(max(1, warmup)):
+                one_step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one_step()
+            fence()
+            el = reduce_max(time.perf_counter() - t0)
+        except Exception as e:          # (the other ranks stall in the rung's next collective: their watchdogs end them the same way)
+            wd.fail_now("ladder rung %d: %s" % (i, name), e)
         rec = {"wire_form": name, "ms_per_step": 1e3 * el / steps, "value": steps / el, "steps": steps,
                "rccl_ranks": core.comm_ranks(), "panel_bcast": "scatter+allgather" if core.comm_bcast_mode() else "broadcast"}
         records.append(rec)
@@ -411,7 +435,8 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
-    wd = Watchdog(json_fd, rank, {"metric": "newton_steps_per_sec", "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+    global _WD
+    wd = _WD = Watchdog(json_fd, rank, {"metric": "newton_steps_per_sec", "unit": "steps/s", "n_gpus": world, "steps": args.steps,
                                   "warmup": args.warmup, "higher_is_better": True, "scaling": "strong", "dtype": "f64",
                                   "data": "synthetic"})
     wd.watch("process-group initialisation", 600)
@@ -1012,5 +1037,15 @@ def lbfgs_block(device, n=131072, me=512, mi=1536, m=8, reps=3):
             "residual_H_dz_minus_g_rel": float((res - g).norm() / g.norm()), "regularised": st["regularised"]}
 
 
+_WD = None      # main()'s watchdog: an exception behind the ladder (the timed region on the rung it chose) still has a number to report
+
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception as e:
+        if _WD is not None and _WD.fallback:
+            import traceback
+            traceback.print_exc()
+            _WD.fail_now(_WD.phase or "after the ladder", e)
+        raise

@@ -104,6 +104,41 @@ def test_bench_watchdog_prints_an_error_line_instead_of_hanging(tmp_path):
     assert p2.returncode == 3 and not [l for l in p2.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_ladder_rung_that_raises_keeps_the_best_completed_number():
+    """bench.py's ladder: a rung whose step RAISES -- an error code from the library -- ends the run like a rung
+    that stalls: ONE line with the best completed rung's value and status 0; without a completed rung an `error` line and status 3."""
+    import json
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, time\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "wd = bench.Watchdog(1, 0, {'metric': 'newton_steps_per_sec', 'n_gpus': 8})\n"
+        "class Core:\n"
+        "    def set_option(self, k, v): pass\n"
+        "    def comm_ranks(self): return 8\n"
+        "    def comm_bcast_mode(self): return 0\n"
+        "n = [0]\n"
+        "def one_step():\n"
+        "    n[0] += 1\n"
+        "    if n[0] > FAIL_AFTER: raise RuntimeError('pyipm_newton_step_dist failed (-6): tile chain: a poll timed out')\n"
+        "    time.sleep(0.01)\n"
+        "bench.run_ladder(Core(), one_step, lambda: None, wd, 8, 0, 2, 1, lambda x: x, {'config': {'kkt_dim': 1}})\n"
+        "print('not reached')\n" % ROOT)
+    p = subprocess.run([sys.executable, "-c", code.replace("FAIL_AFTER", "7")], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 0, p.stderr[-500:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and "not reached" not in p.stdout
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and len(d["ladder"]) == 2 and "rung 2" in d["ladder_failed_at"] and "poll timed out" in d["ladder_failure"]
+    assert d["wire_form"] in [r["wire_form"] for r in d["ladder"]] and "error" not in d
+    p = subprocess.run([sys.executable, "-c", code.replace("FAIL_AFTER", "0")], capture_output=True, text=True, timeout=60)
+    assert p.returncode == 3
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["value"] is None and "rung 0" in d["failed_phase"] and "error" in d
+
+
 def test_bench_default_panel_width():
     """bench.py's panel width when --nb is not given: 256 on one GPU; across GPUs 256 while the owners' chain is the step
     and 1024 where the bulk update is (rank replays at three widths, profiles/r04_z_replay_nb.txt)."""
