@@ -2225,6 +2225,7 @@ int pyipm_newton_destroy(pyipm_newton_ctx* h) try {
     if (ctx->ev_fwd) hipEventDestroy(ctx->ev_fwd);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->ev_split) hipEventDestroy(ctx->ev_split);
+    if (ctx->ev_early) hipEventDestroy(ctx->ev_early);
     if (ctx->ev_sfast) hipEventDestroy(ctx->ev_sfast);
     if (ctx->ev_main) hipEventDestroy(ctx->ev_main);
     for (auto e : ctx->ev_band) hipEventDestroy(e);
