@@ -290,7 +290,8 @@ int pyipm_newton_exchange_selftest(pyipm_newton_ctx* ctx);
 /* Wire accounting of the last factor_dist / step_dist on this rank: out[0] panel messages that travelled as a plain broadcast,
  * [1] their bytes, [2] panel messages in the scatter + all-gather form, [3] their bytes, [4] point-to-point pieces sent or
  * received, [5] all-gathers, [6] hops through the collective stream, [7] slice messages sent or received (two-message
- * protocol), [8] their bytes, [9] slices that travelled as a broadcast, [10..11] 0. */
+ * protocol), [8] their bytes, [9] slices that travelled as a broadcast, [10] ms of the owner's rows work behind the chain path,
+ * [11] tile chains of this rank's panels that took the second slice's rows along in their own launch (dist_slices = 2). */
 int pyipm_newton_dist_wire(pyipm_newton_ctx* ctx, double out[12]);
 /* Exchange, variant 2 -- the handle owns an RCCL communicator over the `world` ranks it was created for.  Rank 0
  * obtains an id (128 bytes), it reaches the other ranks out of band (torch.distributed, MPI, a file), every rank calls

@@ -838,6 +838,7 @@ int factor_dist_geo(Ctx* ctx, pyipm_factor_stats* stats, const double* fwd_b) {
                     D->xtoken += 1;
                     hipLaunchKernelGGL(k_mark, dim3(1), dim3(64), 0, xs, D->xflag, D->xtoken); DIST_KCHECK();
                     rc = panel_chain(ctx, nxt, side, c3n - c2n, D->xflag, D->xtoken); if (rc) return rc;
+                    D->wire[11] += 1.0;
                     // (the slice-1 buffer's tiles are read by that unpack: it must have run before the buffer is freed below)
                     DIST_HIP(hipEventRecord(D->ev_x, xs));
                     DIST_HIP(hipStreamWaitEvent(side, D->ev_x, 0));

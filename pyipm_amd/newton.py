@@ -530,7 +530,9 @@ class NewtonCore(object):
     def dist_wire(self):
         t = (c_double * 12)()
         self._ck(self.lib.pyipm_newton_dist_wire(self.h, t))
-        return {k: int(t[i]) for i, k in enumerate(self.WIRE_KEYS)}
+        d = {k: int(t[i]) for i, k in enumerate(self.WIRE_KEYS)}
+        d["chains_with_extra_rows"] = int(t[11])
+        return d
 
     def comm_init(self, id128):
         buf = (ctypes.c_char * 128).from_buffer_copy(bytes(id128))

@@ -599,6 +599,9 @@ def test_exchange_forms_give_the_same_bits(world, shape, nb):
                 assert w["stream_hops"] > 0                                   # the sweeps' exchanges hop through the collective stream
             if name in ("B", "D", "E"):
                 assert w["stream_hops"] == 0
+        # the second slice's rows rode in the chain's launch where the slices arrive on the collective stream (A, B), nowhere else
+        xr = sum(res[r][5]["wire"]["chains_with_extra_rows"] for r in range(world))
+        assert (xr > 0) if name in ("A", "B") else (xr == 0), (name, xr)
         if name == "A":
             assert sum(res[r][5]["wire"]["slice_messages"] for r in range(world)) == 2 * nsl     # counted by sender and receiver
             assert all(res[r][5]["wire"]["slices_as_broadcast"] == 0 for r in range(world))
