@@ -15,21 +15,26 @@ for name in ['sq1', 'sq2', 'tcc1', 'tcc2']:
         for c, v in by[k].items():
             tot[c] += v
     out[name] = {'dispatches': len(by), **{k: float(v) for k, v in tot.items()}}
+# every counter group comes from a pass of its own, and a pass may see one of the command's steps or both (rocprofv3 sometimes
+# leaves the warm-up step's dispatches out): each group is normalised by ITS dispatch count
+def per(name, key):
+    return out[name][key] / max(out[name]['dispatches'], 1)
 n = out['tcc1']['dispatches']
-fetch = out['tcc1']['FETCH_SIZE'] * 1024
-write = out['tcc2']['WRITE_SIZE'] * 1024
-gui = out['tcc1']['GRBM_GUI_ACTIVE'] / 8
+fetch = per('tcc1', 'FETCH_SIZE') * 1024          # bytes per launch
+write = per('tcc2', 'WRITE_SIZE') * 1024
+gui = per('tcc1', 'GRBM_GUI_ACTIVE') / 8
+lps = max(out[g]['dispatches'] for g in out) / float(steps)      # launches per step (the fullest pass saw every step)
 summary = {
     'kernel': '%s (all main-stream launches, bench.py --steps 1 --warmup 1 => %d steps)' % (KERNEL, steps),
-    'launches': n,
+    'launches': n, 'launches_by_pass': {g: out[g]['dispatches'] for g in out},
     'units': 'FETCH_SIZE/WRITE_SIZE counters are KB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); '
-             'WRITE_SIZE matches the algorithmic C-tile store volume within 4% uncorrected',
-    'FETCH_SIZE_bytes_raw': fetch, 'FETCH_bytes_corrected_x2': 2 * fetch, 'WRITE_SIZE_bytes': write,
-    'hbm_bytes_per_launch_corrected': (2 * fetch + write) / n,
-    'hbm_bytes_per_step_corrected': (2 * fetch + write) / steps,
-    'MFMA_busy_frac_of_kernel_cycles': out['sq1']['SQ_VALU_MFMA_BUSY_CYCLES'] / (gui * 1024),
+             'WRITE_SIZE matches the algorithmic C-tile store volume within 4% uncorrected; every group per launch of its own pass',
+    'FETCH_SIZE_bytes_raw': fetch * n, 'FETCH_bytes_corrected_x2': 2 * fetch * n, 'WRITE_SIZE_bytes': write * n,
+    'hbm_bytes_per_launch_corrected': 2 * fetch + write,
+    'hbm_bytes_per_step_corrected': (2 * fetch + write) * lps,
+    'MFMA_busy_frac_of_kernel_cycles': per('sq1', 'SQ_VALU_MFMA_BUSY_CYCLES') / (gui * 1024),
     'L2_hit_rate': out['tcc2']['TCC_HIT_sum'] / (out['tcc2']['TCC_HIT_sum'] + out['tcc2']['TCC_MISS_sum']),
-    'LDS_busy_frac': out['sq2']['SQ_LDS_IDX_ACTIVE'] / (gui * 256),
+    'LDS_busy_frac': per('sq2', 'SQ_LDS_IDX_ACTIVE') / (gui * 256),
     'LDS_bank_conflict_cycles': out['sq2']['SQ_LDS_BANK_CONFLICT'],
     'raw': out}
 json.dump(summary, open(dst, 'w'), indent=1)
